@@ -1,0 +1,21 @@
+"""gramtools_amd — MI355X-native quasimap engine for gramtools (hot path only).
+
+The package holds the HIP kernels + C-ABI (``csrc/``, built in-tree into ``lib/libgmx.so``), the
+``gram`` drop-in executable (``bin/gram``) and this thin Python mirror of the reference's quasimap
+interface. See DESIGN.md for the path, the boundary and the data layout.
+"""
+from .quasimap import (  # noqa: F401
+    Index,
+    Quasimapper,
+    Coverage,
+    QuasimapReadsStats,
+    quasimap_reads,
+    master_seeds,
+    encode_dna_bases,
+    dump_allele_sum,
+    dump_allele_base,
+    dump_grouped_allele_counts,
+    RNG_LEMIRE,
+    RNG_DIVISION,
+)
+from ._lib import GmxError  # noqa: F401

@@ -1,0 +1,95 @@
+"""ctypes loader for libgmx.so (include/gmx.h). Fails loudly if the HIP library is missing."""
+import ctypes as C
+import os
+
+from .build import LIB, build_library
+
+
+class GmxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gmx error {code}: {msg}")
+        self.code = code
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_text", C.c_uint64), ("kmer_size", C.c_uint32), ("n_sites", C.c_uint32), ("is_nested", C.c_uint32),
+                ("n_allele_slots", C.c_uint32), ("n_per_base_slots", C.c_uint32), ("n_grouped_slots", C.c_uint32),
+                ("n_nodes", C.c_uint32), ("n_kmers_present", C.c_uint64), ("index_bytes", C.c_uint64)]
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("device", C.c_int), ("rng_mode", C.c_int), ("max_states", C.c_uint32),
+                ("max_path_nodes", C.c_uint32), ("max_batch_reads", C.c_uint64), ("forward_only", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("all_reads_count", C.c_uint64), ("skipped_reads_count", C.c_uint64),
+                ("missing_kmer_reads_count", C.c_uint64), ("no_extension_reads_count", C.c_uint64),
+                ("exact_mapped_reads_count", C.c_uint64)]
+
+
+class DeviceCoverage(C.Structure):
+    _fields_ = [("allele_sum", C.c_void_p), ("n_allele_sum", C.c_uint64), ("per_base", C.c_void_p),
+                ("n_per_base", C.c_uint64), ("grouped", C.c_void_p), ("n_grouped", C.c_uint64),
+                ("stats", C.c_void_p), ("n_stats", C.c_uint64)]
+
+
+# every symbol include/gmx.h declares: (restype, argtypes)
+_vp, _u64, _u32, _i64 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int64
+_u8p, _u32p, _i32p, _u64p, _i64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_uint64), C.POINTER(C.c_int64))
+SYMBOLS = {
+    "gmx_last_error": (C.c_char_p, []),
+    "gmx_index_build": (C.c_int, [_u32p, _u64, _u32, C.c_int, C.POINTER(_vp)]),
+    "gmx_index_build_from_file": (C.c_int, [C.c_char_p, _u32, C.c_int, C.POINTER(_vp)]),
+    "gmx_index_destroy": (None, [_vp]),
+    "gmx_index_get_info": (C.c_int, [_vp, C.POINTER(IndexInfo)]),
+    "gmx_index_site_layout": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p, _i32p]),
+    "gmx_index_per_base_layout": (_i64, [_vp, _u32p, _u64]),
+    "gmx_index_allele_base_layout": (C.c_int, [_vp, _u32p, _u32p]),
+    "gmx_index_copy_sa": (C.c_int, [_vp, _u32p]),
+    "gmx_index_copy_bwt": (C.c_int, [_vp, _u32p]),
+    "gmx_index_rank": (_u32, [_vp, _u32, _u32]),
+    "gmx_index_copy_pos_info": (C.c_int, [_vp, _i64p]),
+    "gmx_index_copy_target_map": (_i64, [_vp, _i64p, _u64]),
+    "gmx_index_seed_states": (_i64, [_vp, _u8p, _i64p, _u64]),
+    "gmx_index_jump_states": (_i64, [_vp, _u32, _u32, _i64p, _u64]),
+    "gmx_engine_default_opts": (None, [C.POINTER(EngineOpts)]),
+    "gmx_engine_create": (C.c_int, [_vp, C.POINTER(EngineOpts), C.POINTER(_vp)]),
+    "gmx_engine_destroy": (None, [_vp]),
+    "gmx_engine_reset": (C.c_int, [_vp]),
+    "gmx_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
+    "gmx_map_reads_device": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
+    "gmx_engine_sync": (C.c_int, [_vp]),
+    "gmx_master_seeds": (C.c_int, [_u32, _u64p, _u64, _u32p]),
+    "gmx_coverage_device": (C.c_int, [_vp, C.POINTER(DeviceCoverage)]),
+    "gmx_coverage_fetch": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
+    "gmx_coverage_fetch_grouped_log": (_i64, [_vp, _u32p, _u64]),
+    "gmx_finalize_u16": (None, [_u32p, _u64, C.c_int]),
+}
+
+_lib = None
+
+
+def load(build=True):
+    """Load libgmx.so (building it in-tree with hipcc when absent). Never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        if not build:
+            raise ImportError(f"{LIB} is missing: run `python -m gramtools_amd.build` (needs hipcc)")
+        build_library()
+    lib = C.CDLL(LIB)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc < 0:
+        raise GmxError(rc, load().gmx_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,62 @@
+"""In-tree build of libgmx.so and the `gram` executable with hipcc for gfx950.
+
+The shared object is kept next to the sources (gramtools_amd/lib/) so that it travels with the
+repository snapshot to the GPU box; it is git-ignored.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+BIN_DIR = os.path.join(HERE, "bin")
+LIB = os.path.join(LIB_DIR, "libgmx.so")
+GRAM = os.path.join(BIN_DIR, "gram")
+
+LIB_SOURCES = ["gmx_engine.hip", "gmx_capi.cpp", "gmx_index.cpp"]
+HEADERS = ["gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_index.h", "gmx_internal.h", "../../include/gmx.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
+
+
+def build_library(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB] + srcs + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_gram(force=False, verbose=False):
+    src = os.path.join(CSRC, "gram_main.cpp")
+    if not os.path.exists(src):
+        return None
+    build_library(force, verbose)
+    deps = [src, LIB] + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(GRAM, deps):
+        os.makedirs(BIN_DIR, exist_ok=True)
+        cmd = [HIPCC] + FLAGS + ["-o", GRAM, src, "-L" + LIB_DIR, "-lgmx", "-Wl,-rpath,$ORIGIN/../lib",
+                                 "-Wl,-rpath,/opt/rocm/lib", "-lz", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return GRAM
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))
+    g = build_gram(force="--force" in sys.argv, verbose=True)
+    if g:
+        print(g)

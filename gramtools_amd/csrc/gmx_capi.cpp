@@ -1,0 +1,281 @@
+// gmx_capi.cpp — host half of the C ABI: index construction, introspection, seeds, u16 finalisation.
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gmx_core.h"
+#include "gmx_internal.h"
+
+struct gmx_index {
+  gmx::HostIndex h;
+};
+
+static thread_local std::string g_error;
+void gmx_set_error(const std::string &msg) { g_error = msg; }
+const gmx::HostIndex &gmx_index_host(const gmx_index *ix) { return ix->h; }
+
+namespace {
+// host context used only by gmx_index_jump_states (introspection of the pre-resolved jump programs)
+struct ProbeCtx {
+  struct St {
+    uint32_t lo, hi, tvd, tvg;
+  };
+  std::vector<St> st;
+  uint32_t n = 0;
+  std::vector<GmxPathNode> arena;
+  uint32_t status = GMX_TASK_MAPPED;
+  uint32_t n_states() const { return n; }
+  void set_n_states(uint32_t v) { n = v; }
+  void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
+    lo = st[s].lo; hi = st[s].hi; tvd = st[s].tvd; tvg = st[s].tvg;
+  }
+  void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { st[s] = St{lo, hi, tvd, tvg}; }
+  bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n == st.size()) st.resize(st.size() ? st.size() * 2 : 16);
+    st[n++] = St{lo, hi, tvd, tvg};
+    return true;
+  }
+  uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    arena.push_back(GmxPathNode{site, allele, next});
+    return (uint32_t)arena.size() - 1;
+  }
+  uint32_t arena_site(uint32_t node) const { return arena[node].site; }
+  uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  void fail(uint32_t s) { status = s; }
+};
+}  // namespace
+
+extern "C" {
+
+const char *gmx_last_error(void) { return g_error.c_str(); }
+
+int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int threads, gmx_index **out) {
+  if (!prg || !out) {
+    gmx_set_error("gmx_index_build: null argument");
+    return GMX_EINVAL;
+  }
+  try {
+    gmx_index *ix = new gmx_index();
+    std::vector<uint32_t> v(prg, prg + n);
+    try {
+      gmx::build_index(v, kmer_size, ix->h, threads);
+    } catch (...) {
+      delete ix;
+      throw;
+    }
+    *out = ix;
+    return GMX_OK;
+  } catch (std::bad_alloc const &) {
+    gmx_set_error("out of memory while building the index");
+    return GMX_ENOMEM;
+  } catch (std::exception const &e) {
+    gmx_set_error(e.what());
+    return GMX_EINVAL;
+  }
+}
+
+int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads, gmx_index **out) {
+  try {
+    auto prg = gmx::read_prg_file(path);
+    return gmx_index_build(prg.data(), prg.size(), kmer_size, threads, out);
+  } catch (std::exception const &e) {
+    gmx_set_error(e.what());
+    return GMX_EINVAL;
+  }
+}
+
+void gmx_index_destroy(gmx_index *ix) { delete ix; }
+
+int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
+  const gmx::HostIndex &h = ix->h;
+  memset(o, 0, sizeof(*o));
+  o->n_text = h.prg.size() + 1;
+  o->kmer_size = h.kmer_size;
+  o->n_sites = (uint32_t)h.sites.size();
+  o->is_nested = h.is_nested ? 1 : 0;
+  o->n_allele_slots = h.n_allele_slots;
+  o->n_per_base_slots = h.n_pb_slots;
+  o->n_grouped_slots = h.n_grouped_slots;
+  o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
+  o->n_kmers_present = h.n_seed_kmers_present;
+  o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + (h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
+                   h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.nodes.size() * sizeof(GmxNode) +
+                   h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);
+  return GMX_OK;
+}
+
+int gmx_index_site_layout(const gmx_index *ix, uint32_t *n_alleles, uint32_t *allele_sum_off, uint32_t *grouped_off,
+                          uint32_t *parent_site, int32_t *parent_allele) {
+  const auto &s = ix->h.sites;
+  for (size_t i = 0; i < s.size(); ++i) {
+    if (n_alleles) n_alleles[i] = s[i].n_alleles;
+    if (allele_sum_off) allele_sum_off[i] = s[i].allele_sum_off;
+    if (grouped_off) grouped_off[i] = s[i].grouped_off;
+    if (parent_site) parent_site[i] = s[i].parent_site;
+    if (parent_allele) parent_allele[i] = s[i].parent_allele;
+  }
+  return GMX_OK;
+}
+
+int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t cap) {
+  const auto &h = ix->h;
+  uint64_t n = 0;
+  for (size_t i = 0; i + 1 < h.nodes.size(); ++i) {
+    const GmxNode &nd = h.nodes[i];
+    if (nd.cov_off == GMX_NO_COV) continue;
+    if (out && n < cap) {
+      out[5 * n + 0] = (nd.site - 5) / 2;
+      out[5 * n + 1] = (uint32_t)nd.allele;
+      out[5 * n + 2] = nd.first_pos;
+      out[5 * n + 3] = nd.cov_off;
+      out[5 * n + 4] = nd.seq_len;
+    }
+    ++n;
+  }
+  return (int64_t)n;
+}
+
+// allele_base_non_nested (allele_base.cpp:10-38): one slice per (site, allele); direct deletions have length 0.
+int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t *len) {
+  const auto &h = ix->h;
+  if (h.is_nested) {
+    gmx_set_error("allele_base_non_nested is empty by convention for nested PRGs");
+    return GMX_EINVAL;
+  }
+  for (size_t s = 0; s < h.sites.size(); ++s) {
+    const GmxSite &site = h.sites[s];
+    const GmxNode &entry = h.nodes[site.entry_node];
+    for (uint32_t a = 0; a < site.n_alleles; ++a) {
+      uint32_t tgt = h.edges[entry.edge_begin + a];
+      uint32_t slot = site.allele_sum_off + a;
+      if (tgt == site.exit_node) {
+        pb_off[slot] = 0;
+        len[slot] = 0;
+      } else {
+        pb_off[slot] = h.nodes[tgt].cov_off;
+        len[slot] = h.nodes[tgt].seq_len;
+      }
+    }
+  }
+  return GMX_OK;
+}
+
+int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out) {
+  memcpy(out, ix->h.sa.data(), ix->h.sa.size() * 4);
+  return GMX_OK;
+}
+int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out) {
+  memcpy(out, ix->h.bwt.data(), ix->h.bwt.size() * 4);
+  return GMX_OK;
+}
+uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base) {
+  if (base < 1 || base > 4) return 0;
+  GmxIndexView v = ix->h.view();
+  return gmx_rank(v, upper, base);
+}
+int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out) {
+  const auto &h = ix->h;
+  for (size_t p = 0; p < h.prg.size(); ++p) {
+    const GmxNode &nd = h.nodes[h.pos_node[p]];
+    out[5 * p + 0] = nd.site;
+    out[5 * p + 1] = nd.allele;
+    out[5 * p + 2] = h.prg[p] <= 4 ? (int64_t)p - nd.first_pos : 0;
+    out[5 * p + 3] = h.pos_target[p].first;
+    out[5 * p + 4] = h.pos_target[p].second;
+  }
+  return GMX_OK;
+}
+int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t cap) {
+  std::vector<int64_t> v{(int64_t)ix->h.target_map.size()};
+  for (auto &e : ix->h.target_map) {
+    v.push_back(e.first);
+    v.push_back((int64_t)e.second.size());
+    for (auto &t : e.second) {
+      v.push_back(t.id);
+      v.push_back(t.deletion_allele);
+    }
+  }
+  if (v.size() > cap) return -(int64_t)v.size();
+  std::copy(v.begin(), v.end(), out);
+  return (int64_t)v.size();
+}
+int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap) {
+  const auto &h = ix->h;
+  if (h.kmer_size == 0) return GMX_EINVAL;
+  uint32_t code = 0;
+  for (uint32_t j = 0; j < h.kmer_size; ++j) {
+    if (kmer[j] < 1 || kmer[j] > 4) return GMX_EINVAL;
+    code = (code << 2) | (uint32_t)(kmer[j] - 1);
+  }
+  auto v = gmx::seed_states_of(h, code);
+  if (v.size() > cap) return -(int64_t)v.size();
+  std::copy(v.begin(), v.end(), out);
+  return (int64_t)v.size();
+}
+int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int64_t *out, uint64_t cap) {
+  const auto &h = ix->h;
+  GmxIndexView v = h.view();
+  ProbeCtx ctx;
+  const GmxRankBlock b = v.blocks[lo >> GMX_BLK_SHIFT];
+  gmx_marker_pass(v, lo, hi, GMX_NIL, GMX_NIL, b, ctx);
+  std::vector<int64_t> r{(int64_t)ctx.n};
+  for (uint32_t s = 0; s < ctx.n; ++s) {
+    r.push_back(ctx.st[s].lo);
+    r.push_back(ctx.st[s].hi);
+    std::vector<std::pair<uint32_t, int32_t>> tmp;
+    for (uint32_t x = ctx.st[s].tvd; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, ctx.arena[x].allele});
+    r.push_back((int64_t)tmp.size());
+    for (size_t i = tmp.size(); i-- > 0;) {
+      r.push_back(tmp[i].first);
+      r.push_back(tmp[i].second);
+    }
+    tmp.clear();
+    for (uint32_t x = ctx.st[s].tvg; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, -1});
+    r.push_back((int64_t)tmp.size());
+    for (size_t i = tmp.size(); i-- > 0;) {
+      r.push_back(tmp[i].first);
+      r.push_back(-1);
+    }
+  }
+  if (r.size() > cap) return -(int64_t)r.size();
+  std::copy(r.begin(), r.end(), out);
+  return (int64_t)r.size();
+}
+
+// quasimap.cpp:120-141 + random.hpp:20: raw mt19937 outputs, 5000 per batch of <= 5000 reads
+int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out) {
+  uint32_t mt[624];
+  mt[0] = master_seed;
+  for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int idx = 624;
+  auto next = [&]() {
+    if (idx >= 624) {
+      for (int i = 0; i < 624; ++i) {
+        uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+        mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  };
+  uint64_t o = 0;
+  for (uint64_t f = 0; f < n_files; ++f)
+    for (uint64_t start = 0; start < reads_per_file[f]; start += 5000)
+      for (uint64_t i = 0; i < 5000; ++i) {
+        uint32_t s = next();
+        if (start + i < reads_per_file[f]) out[o++] = s;
+      }
+  return GMX_OK;
+}
+
+void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate) {
+  for (uint64_t i = 0; i < n; ++i) values[i] = saturate ? (values[i] > 65535u ? 65535u : values[i]) : (values[i] & 0xFFFFu);
+}
+
+}  // extern "C"

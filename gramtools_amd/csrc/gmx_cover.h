@@ -1,0 +1,563 @@
+// gmx_cover.h — per-(read, orientation) coverage recording on the flat index.
+//
+// What the reference does in coverage::record::search_states
+// (libgramtools/src/genotype/quasimap/coverage/coverage_common.cpp:166-197) after
+// handle_allele_encapsulated_states (search/encapsulated_search.cpp:90-107):
+//   encapsulation split -> LocusFinder per state -> equivalence classes over level-0
+//   sites -> one seeded uniform draw -> allele-sum, grouped allele counts and per-base
+//   (hull per node) increments for the chosen class.
+//
+// Written as GMX_HD functions over an `Env` so that the HIP coverage kernel runs them
+// one lane per task, and the test-only host build (tests/hostemu) can run the very
+// same logic against the oracle without a GPU. The product library only ever calls
+// them from kernels.
+//
+// Env interface:
+//   uint32_t sget(uint32_t word) / void sset(uint32_t word, uint32_t v)   per-task scratch words
+//   static constexpr I_MAX, B_MAX, LOC_MAX, H_MAX                            capacities
+//   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot)
+//   bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) / void log_grouped_id(int32_t) / void log_grouped_end()
+//   void fail(uint32_t status)
+//   const GmxPathNode *arena
+#pragma once
+#include "gmx_types.h"
+
+#define GMX_RNG_LEMIRE 0    // libstdc++ >= 11 uniform_int_distribution (default: the toolchain of this image)
+#define GMX_RNG_DIVISION 1  // libstdc++ <= 10
+
+// ---------------------------------------------------------------------------
+// std::mt19937 outputs #0.. without materialising the 624-word state: output j (< 227)
+// depends only on the seeded words s[j], s[j+1], s[j+397] (random.hpp:14-25; the per-read
+// generator is freshly seeded and almost always drawn once, coverage_common.cpp:169,102).
+// ---------------------------------------------------------------------------
+struct GmxMt {
+  uint32_t a;   // s[j]
+  uint32_t b;   // s[j + 397]
+  uint32_t j;
+};
+GMX_HD uint32_t gmx_mt_next_seed_word(uint32_t prev, uint32_t i) { return 1812433253u * (prev ^ (prev >> 30)) + i; }
+GMX_HD void gmx_mt_init(GmxMt &g, uint32_t seed) {
+  g.a = seed;
+  uint32_t x = seed;
+  for (uint32_t i = 1; i <= 397; ++i) x = gmx_mt_next_seed_word(x, i);
+  g.b = x;
+  g.j = 0;
+}
+// returns false once the cheap window (227 outputs) is exhausted
+GMX_HD bool gmx_mt_next(GmxMt &g, uint32_t &out) {
+  if (g.j >= 226) return false;
+  uint32_t a1 = gmx_mt_next_seed_word(g.a, g.j + 1);
+  uint32_t y = (g.a & 0x80000000u) | (a1 & 0x7fffffffu);
+  uint32_t v = g.b ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  v ^= (v >> 11);
+  v ^= (v << 7) & 0x9d2c5680u;
+  v ^= (v << 15) & 0xefc60000u;
+  v ^= (v >> 18);
+  out = v;
+  g.a = a1;
+  g.b = gmx_mt_next_seed_word(g.b, g.j + 398);
+  g.j++;
+  return true;
+}
+// std::uniform_int_distribution<uint32_t>(1, n)(mt19937(seed)), n >= 1 (random.cpp:15-18).
+GMX_HD bool gmx_uniform_1_to_n(uint32_t seed, uint32_t n, int mode, uint32_t &result) {
+  if (n == 1) {  // range of size one: the draw is consumed but cannot change the result
+    result = 1;
+    return true;
+  }
+  GmxMt g;
+  gmx_mt_init(g, seed);
+  uint32_t x;
+  if (mode == GMX_RNG_LEMIRE) {  // bits/uniform_int_dist.h (_S_nd): multiply-shift with rejection
+    if (!gmx_mt_next(g, x)) return false;
+    uint64_t product = (uint64_t)x * (uint64_t)n;
+    uint32_t low = (uint32_t)product;
+    if (low < n) {
+      uint32_t threshold = (0u - n) % n;
+      while (low < threshold) {
+        if (!gmx_mt_next(g, x)) return false;
+        product = (uint64_t)x * (uint64_t)n;
+        low = (uint32_t)product;
+      }
+    }
+    result = (uint32_t)(product >> 32) + 1u;
+    return true;
+  }
+  const uint32_t scaling = 0xffffffffu / n;
+  const uint64_t past = (uint64_t)n * scaling;
+  do {
+    if (!gmx_mt_next(g, x)) return false;
+  } while ((uint64_t)x >= past);
+  result = x / scaling + 1u;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// scratch layout (words)
+// ---------------------------------------------------------------------------
+template <class Env>
+struct GmxScratch {
+  // item i: lo, hi, tvd, tvg, enc_site, enc_allele
+  static constexpr uint32_t ITEM_W = 6;
+  static constexpr uint32_t items = 0;
+  static constexpr uint32_t keys = items + Env::I_MAX * ITEM_W;       // per item: len, B_MAX sites
+  static constexpr uint32_t loci = keys + Env::I_MAX * (1 + Env::B_MAX);  // (site, allele)
+  static constexpr uint32_t hull = loci + Env::LOC_MAX * 2;           // (node, start, end)
+  static constexpr uint32_t total = hull + Env::H_MAX * 3;
+};
+
+GMX_HD uint32_t gmx_n_edges(const GmxIndexView &ix, uint32_t node) {
+  return ix.nodes[node + 1].edge_begin - ix.nodes[node].edge_begin;
+}
+GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
+
+// The loci of item `it` appended to loci[n_loci..] (a LocusFinder run whose sets are merged into the
+// class's set, coverage_common.cpp:110-122). check_site_uniqueness (:17-32) is enforced.
+template <class Env>
+GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t n_loci_in) {
+  typedef GmxScratch<Env> S;
+  uint32_t base = S::items + it * S::ITEM_W;
+  uint32_t lo = env.sget(base), hi = env.sget(base + 1), tvd = env.sget(base + 2), tvg = env.sget(base + 3);
+  uint32_t enc_site = env.sget(base + 4);
+  int32_t enc_allele = (int32_t)env.sget(base + 5);
+  // A LocusFinder starts with empty used_sites: loci found by *this* item are searched from `first`.
+  // The merge into the class set is a set union, so de-duplicating against earlier items' loci is
+  // equivalent as long as the per-item `used_sites` short-circuit is evaluated on this item only.
+  // We therefore run the finder on a private window [first, n) and merge afterwards.
+  uint32_t first = n_loci_in;
+  uint32_t n = n_loci_in;
+  auto window_used = [&](uint32_t site) {
+    for (uint32_t i = first; i < n; ++i)
+      if (env.sget(S::loci + 2 * i) == site) return true;
+    return false;
+  };
+  auto window_add = [&](uint32_t site, int32_t allele) -> bool {
+    for (uint32_t i = first; i < n; ++i)
+      if (env.sget(S::loci + 2 * i) == site && (int32_t)env.sget(S::loci + 2 * i + 1) == allele) return true;
+    if (n >= Env::LOC_MAX) {
+      env.fail(GMX_TASK_OVERFLOW);
+      return false;
+    }
+    env.sset(S::loci + 2 * n, site);
+    env.sset(S::loci + 2 * n + 1, (uint32_t)allele);
+    ++n;
+    return true;
+  };
+  auto nested = [&](uint32_t site, int32_t allele) -> bool {
+    for (;;) {
+      if (window_used(site)) return true;
+      if (!window_add(site, allele)) return false;
+      const GmxSite &s = ix.sites[(site - 5) >> 1];
+      if (s.parent_site == 0) return true;
+      allele = s.parent_allele;
+      site = s.parent_site;
+    }
+  };
+  if (enc_site != 0) {
+    if (!nested(enc_site, enc_allele)) return 0xFFFFFFFFu;
+  } else {
+    // check_site_uniqueness over traversed + traversing
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.arena[x].next) {
+      uint32_t sx = env.arena[x].site;
+      for (uint32_t y = env.arena[x].next; y != GMX_NIL; y = env.arena[y].next)
+        if (env.arena[y].site == sx) {
+          env.fail(GMX_TASK_ERROR);
+          return 0xFFFFFFFFu;
+        }
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.arena[y].next)
+        if (env.arena[y].site == sx) {
+          env.fail(GMX_TASK_ERROR);
+          return 0xFFFFFFFFu;
+        }
+    }
+    for (uint32_t x = tvg; x != GMX_NIL; x = env.arena[x].next) {
+      uint32_t sx = env.arena[x].site;
+      for (uint32_t y = env.arena[x].next; y != GMX_NIL; y = env.arena[y].next)
+        if (env.arena[y].site == sx) {
+          env.fail(GMX_TASK_ERROR);
+          return 0xFFFFFFFFu;
+        }
+    }
+    if (tvg != GMX_NIL) {  // assign_traversing_loci, coverage_common.cpp:53-76
+      uint32_t parent_seed = env.arena[tvg].site;
+      int32_t last_allele = -1;
+      for (uint32_t i = lo;; ++i) {
+        uint32_t p = ix.sa[i];
+        last_allele = ix.nodes[ix.pos_node[p]].allele;
+        if (!window_add(parent_seed, last_allele)) return 0xFFFFFFFFu;
+        if (i == hi) break;
+      }
+      // assign_nested_locus(new_locus): the seed site itself is not yet in used_sites (unique_loci and
+      // used_sites are separate sets in the reference), so the walk continues with its parent chain.
+      const GmxSite &ps = ix.sites[(parent_seed - 5) >> 1];
+      if (ps.parent_site != 0 && !nested(ps.parent_site, ps.parent_allele)) return 0xFFFFFFFFu;
+    }
+    // assign_traversed_loci (:78-83): push order = oldest first; the list head is the newest.
+    // Process oldest-first by walking to each depth (paths are short).
+    uint32_t len = 0;
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.arena[x].next) ++len;
+    for (uint32_t d = len; d-- > 0;) {
+      uint32_t x = tvd;
+      for (uint32_t s = 0; s < d; ++s) x = env.arena[x].next;
+      if (!nested(env.arena[x].site, env.arena[x].allele)) return 0xFFFFFFFFu;
+    }
+  }
+  return n;
+}
+
+// key of item (sorted level-0 sites of its loci window [first, n)) -> keys[it]
+template <class Env>
+GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t first, uint32_t n) {
+  typedef GmxScratch<Env> S;
+  uint32_t kb = S::keys + it * (1 + Env::B_MAX);
+  uint32_t len = 0;
+  for (uint32_t i = first; i < n; ++i) {
+    uint32_t site = env.sget(S::loci + 2 * i);
+    if (ix.sites[(site - 5) >> 1].parent_site != 0) continue;
+    // insertion sort, distinct
+    uint32_t pos = 0;
+    bool dup = false;
+    while (pos < len) {
+      uint32_t v = env.sget(kb + 1 + pos);
+      if (v == site) {
+        dup = true;
+        break;
+      }
+      if (v > site) break;
+      ++pos;
+    }
+    if (dup) continue;
+    if (len >= Env::B_MAX) {
+      env.fail(GMX_TASK_OVERFLOW);
+      return false;
+    }
+    for (uint32_t q = len; q > pos; --q) env.sset(kb + 1 + q, env.sget(kb + q));
+    env.sset(kb + 1 + pos, site);
+    ++len;
+  }
+  env.sset(kb, len);
+  return true;
+}
+// lexicographic comparison of two keys (std::set<Marker> ordering inside std::map, coverage_common.hpp:133)
+template <class Env>
+GMX_HD int gmx_key_cmp(Env &env, uint32_t a, uint32_t b) {
+  typedef GmxScratch<Env> S;
+  uint32_t ka = S::keys + a * (1 + Env::B_MAX), kb = S::keys + b * (1 + Env::B_MAX);
+  uint32_t la = env.sget(ka), lb = env.sget(kb);
+  uint32_t m = la < lb ? la : lb;
+  for (uint32_t i = 0; i < m; ++i) {
+    uint32_t va = env.sget(ka + 1 + i), vb = env.sget(kb + 1 + i);
+    if (va != vb) return va < vb ? -1 : 1;
+  }
+  return la == lb ? 0 : (la < lb ? -1 : 1);
+}
+
+// ---------------------------------------------------------------------------
+// Traverser on the flat graph (allele_base.cpp:137-219)
+// ---------------------------------------------------------------------------
+struct GmxWalk {
+  uint32_t node;
+  uint32_t remaining;
+  uint32_t cursor;       // arena node of the next locus to consume (newest first); GMX_NIL = exhausted
+  uint32_t enc_site;     // encapsulated item: single locus, consumed when enc_left
+  int32_t enc_allele;
+  bool enc_left;
+  bool first;
+  uint32_t start, end;
+  bool bad;
+};
+#define GMX_NO_NODE 0xFFFFFFFFu
+
+GMX_HD void gmx_walk_update(const GmxIndexView &ix, GmxWalk &w) {  // update_coordinates :189-204
+  uint32_t len = ix.nodes[w.node].seq_len;
+  w.end = 0;
+  if (len > 0) {
+    if (w.remaining == 0) {  // never reached by the reference on valid mappings (would wrap a size_t)
+      w.bad = true;
+      return;
+    }
+    uint64_t e = (uint64_t)w.start + w.remaining - 1;
+    w.end = e < (uint64_t)(len - 1) ? (uint32_t)e : len - 1;
+    w.remaining -= (w.end - w.start + 1);
+  }
+}
+template <class Env>
+GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  // go_to_next_site :168-187
+  w.start = 0;
+  while (gmx_n_edges(ix, w.node) == 1) {
+    if (w.remaining == 0) {
+      w.node = GMX_NO_NODE;
+      return;
+    }
+    w.node = ix.edges[ix.nodes[w.node].edge_begin];
+    gmx_walk_update(ix, w);
+    if (w.bad) return;
+    if (gmx_in_bubble(ix.nodes[w.node])) return;
+  }
+  uint32_t ne = gmx_n_edges(ix, w.node);
+  int32_t allele;
+  if (w.enc_site != 0) {
+    if (!w.enc_left) {
+      w.bad = true;
+      return;
+    }
+    allele = w.enc_allele;
+    w.enc_left = false;
+  } else {
+    if (w.cursor == GMX_NIL) {
+      w.bad = true;
+      return;
+    }
+    allele = env.arena[w.cursor].allele;
+    w.cursor = env.arena[w.cursor].next;
+  }
+  if (allele < 0 || (uint32_t)allele >= ne) {
+    w.bad = true;
+    return;
+  }
+  w.node = ix.edges[ix.nodes[w.node].edge_begin + (uint32_t)allele];
+  gmx_walk_update(ix, w);
+}
+// next_Node :149-166. Returns GMX_NO_NODE at the end.
+template <class Env>
+GMX_HD uint32_t gmx_walk_next(const GmxIndexView &ix, Env &env, GmxWalk &w) {
+  if (w.first) {
+    w.first = false;
+    gmx_walk_update(ix, w);
+    if (w.bad) return GMX_NO_NODE;
+    if (!gmx_in_bubble(ix.nodes[w.node])) gmx_walk_next_site(ix, env, w);
+    if (w.node == GMX_NO_NODE) w.bad = true;  // the reference would dereference a null node here
+    return w.bad ? GMX_NO_NODE : w.node;
+  }
+  if (w.remaining == 0) return GMX_NO_NODE;
+  gmx_walk_next_site(ix, env, w);
+  if (w.bad) return GMX_NO_NODE;
+  return w.node;
+}
+
+// process_Node + DummyCovNode hull (allele_base.cpp:109-135,282-296)
+template <class Env>
+GMX_HD bool gmx_hull_add(const GmxIndexView &ix, Env &env, uint32_t &n_hull, uint32_t node, uint32_t s, uint32_t e) {
+  typedef GmxScratch<Env> S;
+  if (ix.nodes[node].seq_len == 0) return true;
+  for (uint32_t i = 0; i < n_hull; ++i) {
+    if (env.sget(S::hull + 3 * i) != node) continue;
+    uint32_t hs = env.sget(S::hull + 3 * i + 1), he = env.sget(S::hull + 3 * i + 2);
+    if (s < hs) env.sset(S::hull + 3 * i + 1, s);
+    if (e > he) env.sset(S::hull + 3 * i + 2, e);
+    return true;
+  }
+  if (n_hull >= Env::H_MAX) {
+    env.fail(GMX_TASK_OVERFLOW);
+    return false;
+  }
+  env.sset(S::hull + 3 * n_hull, node);
+  env.sset(S::hull + 3 * n_hull + 1, s);
+  env.sset(S::hull + 3 * n_hull + 2, e);
+  ++n_hull;
+  return true;
+}
+
+// PbCovRecorder::process_SearchState (allele_base.cpp:246-280) for item `it`
+template <class Env>
+GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t read_len, uint32_t &n_hull) {
+  typedef GmxScratch<Env> S;
+  uint32_t base = S::items + it * S::ITEM_W;
+  uint32_t lo = env.sget(base), hi = env.sget(base + 1), tvd = env.sget(base + 2);
+  uint32_t enc_site = env.sget(base + 4);
+  int32_t enc_allele = (int32_t)env.sget(base + 5);
+  bool first = true;
+  for (uint32_t occ = lo;; ++occ) {
+    uint32_t p = ix.sa[occ];
+    GmxWalk w;
+    w.node = ix.pos_node[p];
+    w.remaining = read_len;
+    w.cursor = tvd;
+    w.enc_site = enc_site;
+    w.enc_allele = enc_allele;
+    w.enc_left = enc_site != 0;
+    w.first = true;
+    w.start = p - ix.nodes[w.node].first_pos;
+    w.end = 0;
+    w.bad = false;
+    if (first) {
+      first = false;
+      for (;;) {
+        uint32_t node = gmx_walk_next(ix, env, w);
+        if (w.bad) {
+          env.fail(GMX_TASK_ERROR);
+          return false;
+        }
+        if (node == GMX_NO_NODE) break;
+        if (!gmx_hull_add(ix, env, n_hull, node, w.start, w.end)) return false;
+      }
+    } else {
+      uint32_t node = gmx_walk_next(ix, env, w);
+      if (w.bad || node == GMX_NO_NODE) {
+        env.fail(GMX_TASK_ERROR);
+        return false;
+      }
+      if (!gmx_hull_add(ix, env, n_hull, node, w.start, w.end)) return false;
+    }
+    if (occ == hi) break;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// The whole recording step for one mapped task.
+// ---------------------------------------------------------------------------
+template <class Env>
+GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState *finals, uint32_t n_final,
+                           uint32_t read_len, uint32_t seed, int rng_mode) {
+  typedef GmxScratch<Env> S;
+  // --- items: path-bearing states + allele-encapsulated positions (encapsulated_search.cpp:30-107) ---
+  uint32_t n_items = 0;
+  uint32_t nonvariant = 0;  // count_nonvar_search_states, coverage_common.cpp:130-141 (uint32 arithmetic)
+  auto add_item = [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg, uint32_t es, int32_t ea) -> bool {
+    if (n_items >= Env::I_MAX) {
+      env.fail(GMX_TASK_OVERFLOW);
+      return false;
+    }
+    uint32_t b = S::items + n_items * S::ITEM_W;
+    env.sset(b, lo);
+    env.sset(b + 1, hi);
+    env.sset(b + 2, tvd);
+    env.sset(b + 3, tvg);
+    env.sset(b + 4, es);
+    env.sset(b + 5, (uint32_t)ea);
+    ++n_items;
+    return true;
+  };
+  for (uint32_t f = 0; f < n_final; ++f) {
+    GmxFinalState st = finals[f];
+    if (st.traversed != GMX_NIL || st.traversing != GMX_NIL) {
+      if (!add_item(st.lo, st.hi, st.traversed, st.traversing, 0, -1)) return;
+      continue;
+    }
+    for (uint32_t i = st.lo;; ++i) {
+      const GmxNode &nd = ix.nodes[ix.pos_node[ix.sa[i]]];
+      if (nd.site == 0)
+        nonvariant += 1;
+      else if (!add_item(i, i, GMX_NIL, GMX_NIL, nd.site, nd.allele))
+        return;
+      if (i == st.hi) break;
+    }
+  }
+  if (n_items == 0) return;  // usps.size() == 0: nothing recorded, no draw (coverage_common.cpp:96-97)
+
+  // --- class keys ---
+  for (uint32_t it = 0; it < n_items; ++it) {
+    uint32_t n = gmx_item_loci(ix, env, it, 0);
+    if (n == 0xFFFFFFFFu) return;
+    if (!gmx_item_key(ix, env, it, 0, n)) return;
+  }
+  // number of distinct keys
+  uint32_t n_classes = 0;
+  for (uint32_t a = 0; a < n_items; ++a) {
+    bool seen = false;
+    for (uint32_t b = 0; b < a && !seen; ++b) seen = gmx_key_cmp(env, a, b) == 0;
+    if (!seen) ++n_classes;
+  }
+  // --- selection (random_select_entry, coverage_common.cpp:95-108) ---
+  uint32_t total = nonvariant + n_classes;
+  uint32_t r;
+  if (!gmx_uniform_1_to_n(seed, total, rng_mode, r)) {
+    env.fail(GMX_TASK_ERROR);
+    return;
+  }
+  if (r <= nonvariant) return;
+  uint32_t want = r - nonvariant - 1;  // 0-based index in the ordered map
+  // representative item of the class with `want` distinct keys strictly smaller
+  uint32_t chosen = 0xFFFFFFFFu;
+  for (uint32_t a = 0; a < n_items && chosen == 0xFFFFFFFFu; ++a) {
+    bool dup = false;
+    for (uint32_t b = 0; b < a && !dup; ++b) dup = gmx_key_cmp(env, a, b) == 0;
+    if (dup) continue;
+    uint32_t smaller = 0;
+    for (uint32_t b = 0; b < n_items; ++b) {
+      if (gmx_key_cmp(env, b, a) >= 0) continue;
+      bool dupb = false;
+      for (uint32_t c = 0; c < b && !dupb; ++c) dupb = gmx_key_cmp(env, c, b) == 0;
+      if (!dupb) ++smaller;
+    }
+    if (smaller == want) chosen = a;
+  }
+  if (chosen == 0xFFFFFFFFu) {
+    env.fail(GMX_TASK_ERROR);
+    return;
+  }
+  // --- loci of the class (union) + per-base hull ---
+  uint32_t n_loci = 0, n_hull = 0;
+  for (uint32_t it = 0; it < n_items; ++it) {
+    if (gmx_key_cmp(env, it, chosen) != 0) continue;
+    uint32_t first = n_loci;
+    uint32_t n = gmx_item_loci(ix, env, it, first);
+    if (n == 0xFFFFFFFFu) return;
+    // merge window [first, n) into [0, first): drop duplicates
+    uint32_t w = first;
+    for (uint32_t i = first; i < n; ++i) {
+      uint32_t site = env.sget(S::loci + 2 * i), al = env.sget(S::loci + 2 * i + 1);
+      bool dup = false;
+      for (uint32_t j = 0; j < first && !dup; ++j)
+        dup = env.sget(S::loci + 2 * j) == site && env.sget(S::loci + 2 * j + 1) == al;
+      if (dup) continue;
+      env.sset(S::loci + 2 * w, site);
+      env.sset(S::loci + 2 * w + 1, al);
+      ++w;
+    }
+    n_loci = w;
+    if (!gmx_item_per_base(ix, env, it, read_len, n_hull)) return;
+  }
+  // --- record (allele_base.cpp:230-244, allele_sum.cpp:31-43, grouped_allele_counts.cpp:17-49) ---
+  for (uint32_t h = 0; h < n_hull; ++h) {
+    uint32_t node = env.sget(S::hull + 3 * h), s = env.sget(S::hull + 3 * h + 1), e = env.sget(S::hull + 3 * h + 2);
+    uint32_t off = ix.nodes[node].cov_off;
+    if (off == GMX_NO_COV) {
+      env.fail(GMX_TASK_ERROR);
+      return;
+    }
+    for (uint32_t i = s; i <= e; ++i) env.add_per_base(off + i);
+  }
+  for (uint32_t i = 0; i < n_loci; ++i) {
+    uint32_t site = env.sget(S::loci + 2 * i);
+    int32_t allele = (int32_t)env.sget(S::loci + 2 * i + 1);
+    const GmxSite &s = ix.sites[(site - 5) >> 1];
+    if (allele < 0 || (uint32_t)allele >= s.n_alleles) {
+      env.fail(GMX_TASK_ERROR);
+      return;
+    }
+    env.add_allele_sum(s.allele_sum_off + (uint32_t)allele);
+  }
+  for (uint32_t i = 0; i < n_loci; ++i) {
+    uint32_t site = env.sget(S::loci + 2 * i);
+    bool first_of_site = true;
+    for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci + 2 * j) != site;
+    if (!first_of_site) continue;
+    const GmxSite &s = ix.sites[(site - 5) >> 1];
+    if (s.grouped_off != GMX_GROUPED_LOG) {
+      uint32_t mask = 0;
+      for (uint32_t j = i; j < n_loci; ++j)
+        if (env.sget(S::loci + 2 * j) == site) mask |= 1u << env.sget(S::loci + 2 * j + 1);
+      env.add_grouped_dense(s.grouped_off + mask - 1);
+    } else {
+      uint32_t cnt = 0;
+      for (uint32_t j = i; j < n_loci; ++j)
+        if (env.sget(S::loci + 2 * j) == site) ++cnt;
+      if (!env.log_grouped_begin((site - 5) >> 1, cnt)) return;
+      // ascending allele ids (std::set<AlleleId> order, grouped_allele_counts.cpp:25-37)
+      int32_t prev = -1;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        int32_t best = 0x7fffffff;
+        for (uint32_t j = i; j < n_loci; ++j)
+          if (env.sget(S::loci + 2 * j) == site) {
+            int32_t a = (int32_t)env.sget(S::loci + 2 * j + 1);
+            if (a > prev && a < best) best = a;
+          }
+        env.log_grouped_id(best);
+        prev = best;
+      }
+      env.log_grouped_end();
+    }
+  }
+}

@@ -1,0 +1,807 @@
+// gmx_engine.hip — HIP kernels (gfx950) and the device half of the C ABI.
+//
+// Execution model: one LANE per (read, orientation) task — 64
+// independent vBWT backward searches per wavefront. Every lane owns a small pool
+// of search states in LDS (lane-strided, bank-conflict free) and walks its read
+// right to left; each step fetches ONE 64-byte rank block per live state (two
+// when the interval straddles blocks), does the marker scan and the LF step from
+// the same line, and appends the rare marker fan-out states through a
+// pre-resolved jump program. Final states are handed to a second kernel that does
+// the seeded class selection and the coverage atomics.
+//
+// Kernels:
+//   gmx_validate_kernel  reads with a non-ACGT byte are flagged (encode_dna_bases, utils.cpp:73-92)
+//   gmx_search_kernel    search_read_backwards (quasimap.cpp:227-256), LDS state pools
+//   gmx_search_big_kernel  the same for reads that overflowed the LDS pools (global-memory pools)
+//   gmx_cover_kernel     coverage::record::search_states (coverage_common.cpp:179-197)
+//   gmx_stats_kernel     QuasimapReadsStats counters (quasimap.hpp:17-24)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gmx.h"
+#include "gmx_core.h"
+#include "gmx_cover.h"
+#include "gmx_index.h"
+#include "gmx_internal.h"
+
+#define GMX_BLOCK 256
+#define GMX_FAST_STATES 4     // LDS state slots per lane
+#define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
+#define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
+#define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
+
+// ---------------------------------------------------------------------------
+// read access: oriented base i of task (read r, orientation o)
+// ---------------------------------------------------------------------------
+struct ReadRef {
+  const uint8_t *p;
+  uint32_t len;
+  bool rc;
+  __device__ __forceinline__ uint32_t at(uint32_t i) const {
+    return rc ? 5u - (uint32_t)p[len - 1 - i] : (uint32_t)p[i];  // reverse_complement_read, quasimap.cpp:273-298
+  }
+};
+
+// ---------------------------------------------------------------------------
+// per-lane contexts
+// ---------------------------------------------------------------------------
+extern __shared__ uint32_t gmx_lds[];
+
+struct FastCtx {  // states in LDS, arena in global memory
+  uint32_t n;
+  GmxPathNode *arena;
+  uint32_t arena_n;
+  uint32_t status;
+  __device__ __forceinline__ uint32_t n_states() const { return n; }
+  __device__ __forceinline__ void set_n_states(uint32_t v) { n = v; }
+  __device__ __forceinline__ void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
+    const uint32_t *b = gmx_lds + (s * 4) * GMX_BLOCK + threadIdx.x;
+    lo = b[0];
+    hi = b[GMX_BLOCK];
+    tvd = b[2 * GMX_BLOCK];
+    tvg = b[3 * GMX_BLOCK];
+  }
+  __device__ __forceinline__ void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    uint32_t *b = gmx_lds + (s * 4) * GMX_BLOCK + threadIdx.x;
+    b[0] = lo;
+    b[GMX_BLOCK] = hi;
+    b[2 * GMX_BLOCK] = tvd;
+    b[3 * GMX_BLOCK] = tvg;
+  }
+  __device__ __forceinline__ bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n >= GMX_FAST_STATES) return false;
+    put(n, lo, hi, tvd, tvg);
+    ++n;
+    return true;
+  }
+  __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    if (arena_n >= GMX_FAST_ARENA) return GMX_NIL;
+    arena[arena_n] = GmxPathNode{site, allele, next};
+    return arena_n++;
+  }
+  __device__ __forceinline__ uint32_t arena_site(uint32_t node) const { return arena[node].site; }
+  __device__ __forceinline__ uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  __device__ __forceinline__ void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+struct BigCtx {  // states and arena in global memory, runtime capacities
+  uint32_t n;
+  GmxFinalState *st;
+  uint32_t cap;
+  GmxPathNode *arena;
+  uint32_t arena_n, arena_cap;
+  uint32_t status;
+  __device__ __forceinline__ uint32_t n_states() const { return n; }
+  __device__ __forceinline__ void set_n_states(uint32_t v) { n = v; }
+  __device__ __forceinline__ void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
+    GmxFinalState f = st[s];
+    lo = f.lo;
+    hi = f.hi;
+    tvd = f.traversed;
+    tvg = f.traversing;
+  }
+  __device__ __forceinline__ void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    st[s] = GmxFinalState{lo, hi, tvd, tvg};
+  }
+  __device__ __forceinline__ bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n >= cap) return false;
+    put(n, lo, hi, tvd, tvg);
+    ++n;
+    return true;
+  }
+  __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    if (arena_n >= arena_cap) return GMX_NIL;
+    arena[arena_n] = GmxPathNode{site, allele, next};
+    return arena_n++;
+  }
+  __device__ __forceinline__ uint32_t arena_site(uint32_t node) const { return arena[node].site; }
+  __device__ __forceinline__ uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  __device__ __forceinline__ void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+// k-mer code of oriented positions [start, start + k): leftmost base most significant
+__device__ __forceinline__ uint32_t kmer_code(const ReadRef &r, uint32_t start, uint32_t k) {
+  uint32_t code = 0;
+  for (uint32_t j = 0; j < k; ++j) code = (code << 2) | (r.at(start + j) - 1u);
+  return code;
+}
+
+// all_read_kmers_occur_in_index (quasimap.cpp:212-225)
+__device__ bool all_kmers_present(const GmxIndexView &ix, const ReadRef &r) {
+  const uint32_t k = ix.kmer_size;
+  const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
+  uint32_t code = kmer_code(r, 0, k);
+  for (uint32_t o = 0;; ++o) {
+    if (!((ix.kmer_bitmap[code >> 5] >> (code & 31)) & 1u)) return false;
+    if (o + k >= r.len) break;
+    code = ((code << 2) | (r.at(o + k) - 1u)) & mask;
+  }
+  return true;
+}
+
+// seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241)
+template <class Ctx>
+__device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx) {
+  GmxSeed s = ix.seeds[code];
+  if (s.a != GMX_SEED_COMPLEX) {
+    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL);
+    return;
+  }
+  const uint32_t *p = ix.seed_words + s.b;
+  uint32_t ns = *p++;
+  for (uint32_t i = 0; i < ns; ++i) {
+    uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+    p += 4;
+    uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
+    bool ok = true;
+    for (uint32_t j = 0; j < nt; ++j, p += 2) {
+      if (!ok) continue;
+      uint32_t nn = ctx.arena_new(p[0], (int32_t)p[1], tvd);
+      if (nn == GMX_NIL) ok = false; else tvd = nn;
+    }
+    for (uint32_t j = 0; j < ng; ++j, ++p) {
+      if (!ok) continue;
+      uint32_t nn = ctx.arena_new(p[0], -1, tvg);
+      if (nn == GMX_NIL) ok = false; else tvg = nn;
+    }
+    if (!ok || !ctx.push(lo, hi, tvd, tvg)) {
+      ctx.fail(GMX_TASK_OVERFLOW);
+      return;
+    }
+  }
+}
+
+// search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel)
+template <class Ctx>
+__device__ void search_task(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx) {
+  const uint32_t k = ix.kmer_size;
+  load_seed(ix, kmer_code(r, r.len - k, k), ctx);
+  if (ctx.status != GMX_TASK_MAPPED) return;
+  for (uint32_t i = r.len - k; i-- > 0;) {
+    if (ctx.n_states() == 0) break;
+    gmx_extend(ix, r.at(i), ctx);
+    if (ctx.status != GMX_TASK_MAPPED) return;
+  }
+}
+
+struct BatchView {
+  const uint8_t *reads;
+  const uint64_t *offsets;
+  const uint32_t *seeds;
+  const uint8_t *skip;   // per read
+  uint32_t n_reads;
+  uint32_t forward_only;
+};
+
+struct SearchOut {
+  uint32_t *status;          // per task
+  uint32_t *n_final;         // per task
+  GmxFinalState *finals;     // per task x GMX_FAST_STATES
+  GmxPathNode *arena;        // per task x GMX_FAST_ARENA
+  uint32_t *mapped_list;     // task ids with final states (bit 31 = big-pass slot index instead)
+  uint32_t *overflow_list;   // task ids to re-run with large capacities
+  uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
+  uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
+                             // [4] = n cover_overflow_list
+};
+
+__device__ __forceinline__ void wave_append(uint32_t *list, uint32_t *counter, bool want, uint32_t value) {
+  unsigned long long m = __ballot(want);
+  if (!m) return;
+  uint32_t lane = threadIdx.x & 63;
+  uint32_t leader = (uint32_t)__builtin_ctzll(m);
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, leader);
+  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_search_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+  uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  uint32_t n_tasks = b.n_reads * 2;
+  bool active = task < n_tasks;
+  uint32_t status = GMX_TASK_SKIPPED;
+  uint32_t nf = 0;
+  if (active) {
+    uint32_t read = task >> 1;
+    uint64_t off = b.offsets[read];
+    ReadRef r;
+    r.p = b.reads + off;
+    r.len = (uint32_t)(b.offsets[read + 1] - off);
+    r.rc = task & 1;
+    if (b.forward_only && r.rc) {
+      status = GMX_STATUS_IGNORED;
+    } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
+      FastCtx ctx;
+      ctx.n = 0;
+      ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+      ctx.arena_n = 0;
+      ctx.status = GMX_TASK_MAPPED;
+      search_task(ix, r, ctx);
+      status = ctx.status;
+      if (status == GMX_TASK_MAPPED) {
+        nf = ctx.n;
+        if (nf == 0) {
+          status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+        } else {
+          for (uint32_t s = 0; s < nf; ++s) {
+            GmxFinalState f;
+            ctx.get(s, f.lo, f.hi, f.traversed, f.traversing);
+            o.finals[(size_t)task * GMX_FAST_STATES + s] = f;
+          }
+        }
+      }
+    }
+    o.status[task] = status;
+    o.n_final[task] = nf;
+    if (status == GMX_TASK_ERROR) {
+      if (atomicCAS(&o.counters[2], 0u, status) == 0u) o.counters[3] = task;
+    }
+  }
+  wave_append(o.mapped_list, &o.counters[0], active && status == GMX_TASK_MAPPED && nf > 0, task);
+  wave_append(o.overflow_list, &o.counters[1], active && status == GMX_TASK_OVERFLOW, task);
+}
+
+struct BigOut {
+  GmxFinalState *states;   // slot x max_states
+  GmxPathNode *arena;      // slot x max_path_nodes
+  uint32_t *n_final;       // per slot
+  uint32_t *task_of_slot;  // per slot
+  uint32_t max_states, max_path_nodes, max_slots;
+};
+
+// One lane per overflowed task; persistent over the overflow list (its length is only known on the device).
+__global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
+  uint32_t n_over = o.counters[1];
+  for (uint32_t slot = blockIdx.x * 64 + threadIdx.x; slot < n_over; slot += gridDim.x * 64) {
+    uint32_t task = o.overflow_list[slot];
+    if (slot >= g.max_slots) {
+      if (atomicCAS(&o.counters[2], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3] = task;
+      continue;
+    }
+    uint32_t read = task >> 1;
+    uint64_t off = b.offsets[read];
+    ReadRef r;
+    r.p = b.reads + off;
+    r.len = (uint32_t)(b.offsets[read + 1] - off);
+    r.rc = task & 1;
+    BigCtx ctx;
+    ctx.n = 0;
+    ctx.st = g.states + (size_t)slot * g.max_states;
+    ctx.cap = g.max_states;
+    ctx.arena = g.arena + (size_t)slot * g.max_path_nodes;
+    ctx.arena_n = 0;
+    ctx.arena_cap = g.max_path_nodes;
+    ctx.status = GMX_TASK_MAPPED;
+    search_task(ix, r, ctx);
+    uint32_t status = ctx.status;
+    uint32_t nf = 0;
+    if (status == GMX_TASK_MAPPED) {
+      nf = ctx.n;
+      if (nf == 0) status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+    } else if (atomicCAS(&o.counters[2], 0u, status) == 0u) {
+      o.counters[3] = task;
+    }
+    o.status[task] = status;
+    o.n_final[task] = nf;
+    g.n_final[slot] = nf;
+    g.task_of_slot[slot] = task;
+    if (status == GMX_TASK_MAPPED && nf > 0) {
+      uint32_t at = atomicAdd(&o.counters[0], 1u);
+      o.mapped_list[at] = 0x80000000u | slot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// coverage kernel
+// ---------------------------------------------------------------------------
+struct CoverAcc {
+  uint32_t *allele_sum, *per_base, *grouped;
+  uint32_t *log;        // grouped log words
+  uint32_t *log_cursor; // [0] = words used
+  uint32_t log_cap;
+  uint32_t *scratch;    // GmxScratch words x n_lanes (lane-strided)
+  uint32_t n_lanes;
+  uint32_t *scratch_big;
+  uint32_t n_lanes_big;
+  int rng_mode;
+};
+
+template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
+struct CoverEnvT {
+  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
+  uint32_t *scratch;  // already offset by the lane
+  uint32_t stride;
+  const GmxPathNode *arena;
+  uint32_t *allele_sum, *per_base, *grouped, *log, *log_cursor;
+  uint32_t log_cap;
+  uint32_t status;
+  uint32_t log_at;
+  __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
+  __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&allele_sum[slot], 1u); }
+  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&per_base[slot], 1u); }
+  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&grouped[slot], 1u); }
+  __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
+    log_at = atomicAdd(log_cursor, n_ids + 2);
+    if (log_at + n_ids + 2 > log_cap) {
+      status = GMX_TASK_LOGFULL;  // not re-queued: part of this task's coverage is already recorded
+      return false;
+    }
+    log[log_at++] = site_index;
+    log[log_at++] = n_ids;
+    return true;
+  }
+  __device__ __forceinline__ void log_grouped_id(int32_t a) { log[log_at++] = (uint32_t)a; }
+  __device__ __forceinline__ void log_grouped_end() {}
+  __device__ __forceinline__ void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
+typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
+
+// BIG = false: every mapped task; a task whose selection exceeds the small scratch is queued (nothing has been
+// recorded for it yet) and redone by the BIG = true instance, which walks that queue.
+template <class Env, bool BIG>
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
+                                                              CoverAcc acc) {
+  uint32_t n_mapped = BIG ? o.counters[4] : o.counters[0];
+  const uint32_t *list = BIG ? o.cover_overflow_list : o.mapped_list;
+  uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+  for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * blockDim.x) {
+    uint32_t entry = list[m];
+    uint32_t task, nf;
+    const GmxFinalState *finals;
+    const GmxPathNode *arena;
+    if (entry & 0x80000000u) {
+      uint32_t slot = entry & 0x7fffffffu;
+      task = g.task_of_slot[slot];
+      nf = g.n_final[slot];
+      finals = g.states + (size_t)slot * g.max_states;
+      arena = g.arena + (size_t)slot * g.max_path_nodes;
+    } else {
+      task = entry;
+      nf = o.n_final[task];
+      finals = o.finals + (size_t)task * GMX_FAST_STATES;
+      arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+    }
+    uint32_t read = task >> 1;
+    uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+    Env env;
+    env.scratch = (BIG ? acc.scratch_big : acc.scratch) + lane_id;
+    env.stride = BIG ? acc.n_lanes_big : acc.n_lanes;
+    env.arena = arena;
+    env.allele_sum = acc.allele_sum;
+    env.per_base = acc.per_base;
+    env.grouped = acc.grouped;
+    env.log = acc.log;
+    env.log_cursor = acc.log_cursor;
+    env.log_cap = acc.log_cap;
+    env.status = GMX_TASK_MAPPED;
+    env.log_at = 0;
+    gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
+    if (env.status == GMX_TASK_OVERFLOW && !BIG) {
+      o.cover_overflow_list[atomicAdd(&o.counters[4], 1u)] = entry;
+    } else if (env.status != GMX_TASK_MAPPED) {
+      if (atomicCAS(&o.counters[2], 0u, env.status) == 0u) o.counters[3] = task;
+    }
+  }
+}
+
+// QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191)
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *status, uint32_t n_tasks,
+                                                              unsigned long long *stats) {
+  uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  uint32_t s = task < n_tasks ? status[task] : 0xFFFFFFFFu;
+  unsigned long long m_skip = __ballot(s == GMX_TASK_SKIPPED);
+  unsigned long long m_miss = __ballot(s == GMX_STATUS_MISSING_KMER);
+  unsigned long long m_noext = __ballot(s == GMX_TASK_UNMAPPED);
+  unsigned long long m_map = __ballot(s == GMX_TASK_MAPPED);
+  unsigned long long m_all = __ballot(task < n_tasks && s != GMX_STATUS_IGNORED);
+  if ((threadIdx.x & 63) == 0) {
+    if (m_all) atomicAdd(&stats[0], (unsigned long long)__popcll(m_all));
+    if (m_skip) atomicAdd(&stats[1], (unsigned long long)__popcll(m_skip));
+    if (m_miss) atomicAdd(&stats[2], (unsigned long long)__popcll(m_miss));
+    if (m_noext) atomicAdd(&stats[3], (unsigned long long)__popcll(m_noext));
+    if (m_map) atomicAdd(&stats[4], (unsigned long long)__popcll(m_map));
+  }
+}
+
+// reads holding a byte outside 1..4 are skipped as a whole (encode_dna_bases, utils.cpp:73-92)
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_validate_kernel(BatchView b, uint8_t *skip) {
+  uint32_t read = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (read >= b.n_reads) return;
+  uint64_t s = b.offsets[read], e = b.offsets[read + 1];
+  uint8_t bad = 0;
+  for (uint64_t i = s; i < e; ++i) {
+    uint8_t v = b.reads[i];
+    if (v < 1 || v > 4) bad = 1;
+  }
+  skip[read] = bad;
+}
+
+// ===========================================================================
+// engine (host side of the device half)
+// ===========================================================================
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gmx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+      return GMX_EHIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+struct gmx_engine {
+  gmx_engine_opts opts;
+  GmxIndexView dview;  // device pointers
+  std::vector<void *> allocs;
+  uint64_t index_bytes = 0;
+  // accumulators
+  uint32_t *d_allele_sum = nullptr, *d_per_base = nullptr, *d_grouped = nullptr;
+  unsigned long long *d_stats = nullptr;
+  uint32_t *d_log = nullptr, *d_log_cursor = nullptr;
+  uint32_t log_cap = 0;
+  uint32_t n_allele = 0, n_pb = 0, n_grouped = 0;
+  // batch workspace (sized for max_batch_reads)
+  uint64_t cap_reads = 0;
+  uint8_t *d_skip = nullptr;
+  uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
+  GmxFinalState *d_finals = nullptr;
+  GmxPathNode *d_arena = nullptr;
+  BigOut big{};
+  uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
+  uint32_t cover_blocks = 0, cover_big_lanes = 0;
+  // host staging for the _host entry point
+  uint8_t *d_reads = nullptr;
+  uint64_t *d_offsets = nullptr;
+  uint32_t *d_seeds = nullptr;
+  uint64_t cap_bases = 0, cap_stage_reads = 0;
+  hipStream_t last_stream = nullptr;
+
+  template <class T>
+  int alloc(T **p, size_t count, bool zero) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&q, bytes));
+    if (zero) HIP_TRY(hipMemset(q, 0, bytes));
+    allocs.push_back(q);
+    *p = (T *)q;
+    return GMX_OK;
+  }
+  template <class T>
+  int upload(const T **dst, const std::vector<T> &src) {
+    T *q = nullptr;
+    int rc = alloc(&q, src.size(), false);
+    if (rc) return rc;
+    if (!src.empty()) HIP_TRY(hipMemcpy(q, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    index_bytes += src.size() * sizeof(T);
+    *dst = q;
+    return GMX_OK;
+  }
+};
+
+extern "C" {
+
+void gmx_engine_default_opts(gmx_engine_opts *o) {
+  o->device = 0;
+  o->rng_mode = GMX_RNG_LEMIRE;
+  o->max_states = 1024;
+  o->max_path_nodes = 2048;
+  o->max_batch_reads = 4u << 20;
+  o->forward_only = 0;
+}
+
+static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
+  if (n_reads <= e->cap_reads) return GMX_OK;
+  // (re)allocate: old buffers stay in `allocs` until destroy; growth is rare (first call sizes it)
+  uint64_t cap = std::max<uint64_t>(n_reads, 1024);
+  uint64_t n_tasks = cap * 2;
+  int rc;
+  if ((rc = e->alloc(&e->d_skip, cap, true))) return rc;
+  if ((rc = e->alloc(&e->d_status, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_n_final, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_mapped, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
+  if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
+  e->cap_reads = cap;
+  return GMX_OK;
+}
+
+int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine **out) {
+  if (!ixh || !out) {
+    gmx_set_error("gmx_engine_create: null argument");
+    return GMX_EINVAL;
+  }
+  gmx_engine_opts opts;
+  if (opts_in)
+    opts = *opts_in;
+  else
+    gmx_engine_default_opts(&opts);
+  if (opts.max_states == 0) opts.max_states = 1024;
+  if (opts.max_path_nodes == 0) opts.max_path_nodes = 2048;
+  if (opts.max_batch_reads == 0) opts.max_batch_reads = 4u << 20;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    gmx_set_error("no HIP device available: the quasimap engine has no CPU fallback");
+    return GMX_ENODEV;
+  }
+  if (opts.device < 0 || opts.device >= ndev) {
+    gmx_set_error("device ordinal out of range");
+    return GMX_ENODEV;
+  }
+  HIP_TRY(hipSetDevice(opts.device));
+  const gmx::HostIndex &h = gmx_index_host(ixh);
+  if (h.kmer_size == 0) {
+    gmx_set_error("the index was built without a k-mer seed table (kmer_size = 0)");
+    return GMX_EINVAL;
+  }
+  gmx_engine *e = new gmx_engine();
+  e->opts = opts;
+  GmxIndexView v = h.view();
+  int rc = 0;
+  rc |= e->upload(&v.blocks, h.blocks);
+  rc |= e->upload(&v.hit_prog, h.hit_prog);
+  rc |= e->upload(&v.prog, h.prog);
+  rc |= e->upload(&v.sa, h.sa);
+  rc |= e->upload(&v.pos_node, h.pos_node);
+  rc |= e->upload(&v.nodes, h.nodes);
+  rc |= e->upload(&v.edges, h.edges);
+  rc |= e->upload(&v.sites, h.sites);
+  rc |= e->upload(&v.seeds, h.seeds);
+  rc |= e->upload(&v.seed_words, h.seed_words);
+  rc |= e->upload(&v.kmer_bitmap, h.kmer_bitmap);
+  e->dview = v;
+  e->n_allele = h.n_allele_slots;
+  e->n_pb = h.n_pb_slots;
+  e->n_grouped = h.n_grouped_slots;
+  rc |= e->alloc(&e->d_allele_sum, e->n_allele, true);
+  rc |= e->alloc(&e->d_per_base, e->n_pb, true);
+  rc |= e->alloc(&e->d_grouped, e->n_grouped, true);
+  rc |= e->alloc(&e->d_stats, 8, true);
+  e->log_cap = 1u << 24;
+  rc |= e->alloc(&e->d_log, e->log_cap, false);
+  rc |= e->alloc(&e->d_log_cursor, 4, true);
+  rc |= e->alloc(&e->d_counters, 8, true);
+  // large-capacity pass
+  e->big.max_states = opts.max_states;
+  e->big.max_path_nodes = opts.max_path_nodes;
+  e->big.max_slots = 16384;
+  rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
+  rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
+  rc |= e->alloc(&e->big.n_final, e->big.max_slots, false);
+  rc |= e->alloc(&e->big.task_of_slot, e->big.max_slots, false);
+  // coverage scratch
+  e->cover_blocks = 1024;
+  rc |= e->alloc(&e->d_scratch, (size_t)GmxScratch<CoverEnv>::total * e->cover_blocks * GMX_BLOCK, false);
+  e->cover_big_lanes = 64 * 32;
+  rc |= e->alloc(&e->d_scratch_big, (size_t)GmxScratch<CoverEnvBig>::total * e->cover_big_lanes, false);
+  if (rc) {
+    gmx_engine_destroy(e);
+    return GMX_EHIP;
+  }
+  *out = e;
+  return GMX_OK;
+}
+
+void gmx_engine_destroy(gmx_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->opts.device);
+  (void)hipDeviceSynchronize();
+  for (void *p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+int gmx_engine_reset(gmx_engine *e) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(e->d_allele_sum, 0, std::max<size_t>(e->n_allele, 1) * 4));
+  HIP_TRY(hipMemset(e->d_per_base, 0, std::max<size_t>(e->n_pb, 1) * 4));
+  HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
+  HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
+  HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
+  HIP_TRY(hipMemset(e->d_counters, 0, 32));
+  return GMX_OK;
+}
+
+static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
+                        uint64_t n_reads, hipStream_t stream) {
+  if (n_reads == 0) return GMX_OK;
+  if (n_reads > 0x3fffffffull) {
+    gmx_set_error("batch too large");
+    return GMX_EINVAL;
+  }
+  int rc = ensure_batch_capacity(e, n_reads);
+  if (rc) return rc;
+  BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
+  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow, e->d_counters};
+  uint32_t n_tasks = (uint32_t)n_reads * 2;
+  // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
+  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 4, stream));
+  hipLaunchKernelGGL(gmx_validate_kernel, dim3((n_reads + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream, b,
+                     e->d_skip);
+  size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
+  hipLaunchKernelGGL(gmx_search_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), lds, stream,
+                     e->dview, b, o);
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, stream, e->dview, b, o, e->big);
+  CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
+               e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, false>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
+                     o, e->big, acc);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, true>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
+                     b, o, e->big, acc);
+  hipLaunchKernelGGL(gmx_stats_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream,
+                     e->d_status, n_tasks, e->d_stats);
+  HIP_TRY(hipGetLastError());
+  e->last_stream = stream;
+  return GMX_OK;
+}
+
+int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
+                         uint64_t n_reads, uint64_t total_bases, void *hip_stream) {
+  (void)total_bases;
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(e->opts.device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  uint64_t done = 0;
+  while (done < n_reads) {
+    uint64_t n = std::min<uint64_t>(e->opts.max_batch_reads, n_reads - done);
+    int rc = launch_batch(e, d_reads, d_offsets + done, d_seeds + done, n, stream);
+    if (rc) return rc;
+    done += n;
+  }
+  return GMX_OK;
+}
+
+int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
+                       uint64_t n_reads) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  if (n_reads == 0) return GMX_OK;
+  HIP_TRY(hipSetDevice(e->opts.device));
+  uint64_t done = 0;
+  while (done < n_reads) {
+    uint64_t n = std::min<uint64_t>(e->opts.max_batch_reads, n_reads - done);
+    uint64_t b0 = offsets[done], b1 = offsets[done + n];
+    uint64_t bases = b1 - b0;
+    if (bases > e->cap_bases) {
+      uint64_t cb = std::max<uint64_t>(bases, 1 << 16);
+      int rc = e->alloc(&e->d_reads, cb + 16, false);
+      if (rc) return rc;
+      e->cap_bases = cb;
+    }
+    if (n > e->cap_stage_reads) {
+      uint64_t cr = std::max<uint64_t>(n, 1024);
+      int rc = e->alloc(&e->d_offsets, cr + 1, false);
+      if (rc) return rc;
+      rc = e->alloc(&e->d_seeds, cr, false);
+      if (rc) return rc;
+      e->cap_stage_reads = cr;
+    }
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) rel[i] = offsets[done + i] - b0;
+    HIP_TRY(hipMemcpy(e->d_reads, reads + b0, bases, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_offsets, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_seeds, seeds + done, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    int rc = launch_batch(e, e->d_reads, e->d_offsets, e->d_seeds, n, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));  // staging buffers are reused by the next batch
+    done += n;
+  }
+  return gmx_engine_sync(e);
+}
+
+int gmx_engine_sync(gmx_engine *e) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  HIP_TRY(hipStreamSynchronize(e->last_stream));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t c[4];
+  HIP_TRY(hipMemcpy(c, e->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  if (c[2] != 0) {
+    uint32_t zero[2] = {0, 0};
+    HIP_TRY(hipMemcpy(e->d_counters + 2, zero, sizeof(zero), hipMemcpyHostToDevice));
+    char msg[256];
+    if (c[2] == GMX_TASK_LOGFULL) {
+      gmx_set_error("the grouped-allele-count log (sites with more than 5 alleles) is full; coverage is incomplete");
+      return GMX_ECAP;
+    }
+    if (c[2] == GMX_TASK_OVERFLOW) {
+      snprintf(msg, sizeof(msg),
+               "read %u (orientation %u) exceeded the engine capacities (max_states=%u, max_path_nodes=%u, or a "
+               "coverage-selection limit); coverage of this batch is incomplete",
+               c[3] >> 1, c[3] & 1, e->opts.max_states, e->opts.max_path_nodes);
+      gmx_set_error(msg);
+      return GMX_ECAP;
+    }
+    snprintf(msg, sizeof(msg),
+             "read %u (orientation %u): inconsistent variant path (the reference throws/asserts here: a site "
+             "traversed twice or an exit that does not match the entered site)",
+             c[3] >> 1, c[3] & 1);
+    gmx_set_error(msg);
+    return GMX_EREF;
+  }
+  return GMX_OK;
+}
+
+int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
+  out->allele_sum = e->d_allele_sum;
+  out->n_allele_sum = e->n_allele;
+  out->per_base = e->d_per_base;
+  out->n_per_base = e->n_pb;
+  out->grouped = e->d_grouped;
+  out->n_grouped = e->n_grouped;
+  out->stats = e->d_stats;
+  out->n_stats = 5;
+  return GMX_OK;
+}
+
+int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (allele_sum && e->n_allele) HIP_TRY(hipMemcpy(allele_sum, e->d_allele_sum, (size_t)e->n_allele * 4, hipMemcpyDeviceToHost));
+  if (per_base && e->n_pb) HIP_TRY(hipMemcpy(per_base, e->d_per_base, (size_t)e->n_pb * 4, hipMemcpyDeviceToHost));
+  if (grouped && e->n_grouped) HIP_TRY(hipMemcpy(grouped, e->d_grouped, (size_t)e->n_grouped * 4, hipMemcpyDeviceToHost));
+  if (stats) {
+    unsigned long long s[5];
+    HIP_TRY(hipMemcpy(s, e->d_stats, sizeof(s), hipMemcpyDeviceToHost));
+    stats->all_reads_count = s[0];
+    stats->skipped_reads_count = s[1];
+    stats->missing_kmer_reads_count = s[2];
+    stats->no_extension_reads_count = s[3];
+    stats->exact_mapped_reads_count = s[4];
+  }
+  return GMX_OK;
+}
+
+int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words) {
+  if (hipSetDevice(e->opts.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return GMX_EHIP;
+  uint32_t used = 0;
+  if (hipMemcpy(&used, e->d_log_cursor, 4, hipMemcpyDeviceToHost) != hipSuccess) return GMX_EHIP;
+  if (used > e->log_cap) used = e->log_cap;
+  uint64_t n = std::min<uint64_t>(used, cap_words);
+  if (out && n)
+    if (hipMemcpy(out, e->d_log, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return GMX_EHIP;
+  return (int64_t)used;
+}
+
+}  // extern "C"

@@ -1,0 +1,780 @@
+// gmx_index.cpp — host-side index builder (see gmx_index.h).
+#include "gmx_index.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <stdexcept>
+#include <thread>
+#include <unordered_map>
+
+#include "gmx_core.h"
+
+namespace gmx {
+
+// ===========================================================================
+// Suffix array: SA-IS (Nong, Zhang, Chan 2009) on a compacted integer alphabet.
+// The SA of a text ending in a unique smallest sentinel is unique, hence equal
+// to the one SDSL builds for the reference (make_data_structures.cpp:9-33).
+// ===========================================================================
+namespace {
+
+typedef int32_t sidx;
+
+struct TypeBits {
+  std::vector<uint8_t> b;
+  explicit TypeBits(size_t n) : b((n + 7) / 8, 0) {}
+  bool get(sidx i) const { return (b[i >> 3] >> (i & 7)) & 1; }
+  void set(sidx i, bool v) {
+    if (v)
+      b[i >> 3] |= (uint8_t)(1u << (i & 7));
+    else
+      b[i >> 3] &= (uint8_t)~(1u << (i & 7));
+  }
+};
+
+inline bool is_lms(const TypeBits &t, sidx i) { return i > 0 && t.get(i) && !t.get(i - 1); }
+
+void get_buckets(const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K, bool end) {
+  std::fill(bkt.begin(), bkt.end(), 0);
+  for (sidx i = 0; i < n; ++i) bkt[s[i]]++;
+  sidx sum = 0;
+  for (sidx i = 0; i <= K; ++i) {
+    sum += bkt[i];
+    bkt[i] = end ? sum : sum - bkt[i];
+  }
+}
+
+void induce_l(const TypeBits &t, sidx *SA, const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K) {
+  get_buckets(s, bkt, n, K, false);
+  for (sidx i = 0; i < n; ++i) {
+    sidx j = SA[i] - 1;
+    if (SA[i] > 0 && !t.get(j)) SA[bkt[s[j]]++] = j;
+  }
+}
+
+void induce_s(const TypeBits &t, sidx *SA, const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K) {
+  get_buckets(s, bkt, n, K, true);
+  for (sidx i = n - 1; i >= 0; --i) {
+    sidx j = SA[i] - 1;
+    if (SA[i] > 0 && t.get(j)) SA[--bkt[s[j]]] = j;
+  }
+}
+
+// s[n-1] must be 0 and unique smallest. K = largest symbol.
+void sais(const sidx *s, sidx *SA, sidx n, sidx K) {
+  if (n == 1) {
+    SA[0] = 0;
+    return;
+  }
+  TypeBits t(n);
+  t.set(n - 1, true);
+  t.set(n - 2, false);
+  for (sidx i = n - 3; i >= 0; --i) t.set(i, s[i] < s[i + 1] || (s[i] == s[i + 1] && t.get(i + 1)));
+
+  std::vector<sidx> bkt((size_t)K + 1);
+  get_buckets(s, bkt, n, K, true);
+  for (sidx i = 0; i < n; ++i) SA[i] = -1;
+  for (sidx i = 1; i < n; ++i)
+    if (is_lms(t, i)) SA[--bkt[s[i]]] = i;
+  induce_l(t, SA, s, bkt, n, K);
+  induce_s(t, SA, s, bkt, n, K);
+
+  sidx n1 = 0;
+  for (sidx i = 0; i < n; ++i)
+    if (is_lms(t, SA[i])) SA[n1++] = SA[i];
+  for (sidx i = n1; i < n; ++i) SA[i] = -1;
+  sidx name = 0, prev = -1;
+  for (sidx i = 0; i < n1; ++i) {
+    sidx pos = SA[i];
+    bool diff = false;
+    for (sidx d = 0; d < n; ++d) {
+      if (prev == -1 || s[pos + d] != s[prev + d] || t.get(pos + d) != t.get(prev + d)) {
+        diff = true;
+        break;
+      } else if (d > 0 && (is_lms(t, pos + d) || is_lms(t, prev + d)))
+        break;
+    }
+    if (diff) {
+      name++;
+      prev = pos;
+    }
+    SA[n1 + pos / 2] = name - 1;
+  }
+  for (sidx i = n - 1, j = n - 1; i >= n1; --i)
+    if (SA[i] >= 0) SA[j--] = SA[i];
+
+  sidx *SA1 = SA, *s1 = SA + n - n1;
+  if (name < n1)
+    sais(s1, SA1, n1, name - 1);
+  else
+    for (sidx i = 0; i < n1; ++i) SA1[s1[i]] = i;
+
+  get_buckets(s, bkt, n, K, true);
+  for (sidx i = 1, j = 0; i < n; ++i)
+    if (is_lms(t, i)) s1[j++] = i;
+  for (sidx i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+  for (sidx i = n1; i < n; ++i) SA[i] = -1;
+  for (sidx i = n1 - 1; i >= 0; --i) {
+    sidx j = SA[i];
+    SA[i] = -1;
+    SA[--bkt[s[j]]] = j;
+  }
+  induce_l(t, SA, s, bkt, n, K);
+  induce_s(t, SA, s, bkt, n, K);
+}
+
+}  // namespace
+
+void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa) {
+  size_t n = text.size();
+  if (n == 0) {
+    sa.clear();
+    return;
+  }
+  if (n >= (size_t)0x7fffffff) throw std::runtime_error("text too long for the 32-bit suffix array builder");
+  if (text[n - 1] != 0) throw std::runtime_error("text must end with the sentinel 0");
+  // compact the alphabet
+  std::vector<uint32_t> sorted(text);
+  std::sort(sorted.begin(), sorted.end());
+  sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
+  std::vector<sidx> s(n);
+  {
+    // symbols 0..4 (sentinel + bases) through a small table, markers through binary search
+    sidx low[5];
+    for (uint32_t c = 0; c <= 4; ++c) low[c] = (sidx)(std::lower_bound(sorted.begin(), sorted.end(), c) - sorted.begin());
+    for (size_t i = 0; i < n; ++i)
+      s[i] = text[i] <= 4 ? low[text[i]] : (sidx)(std::lower_bound(sorted.begin(), sorted.end(), text[i]) - sorted.begin());
+  }
+  for (size_t i = 0; i + 1 < n; ++i)
+    if (text[i] == 0) throw std::runtime_error("sentinel 0 inside the text");
+  std::vector<sidx> SA(n);
+  sais(s.data(), SA.data(), (sidx)n, (sidx)sorted.size() - 1);
+  sa.resize(n);
+  for (size_t i = 0; i < n; ++i) sa[i] = (uint32_t)SA[i];
+}
+
+std::vector<uint32_t> read_prg_file(const std::string &path) {
+  std::ifstream in(path, std::ios::binary);
+  if (!in) throw std::runtime_error("PRG String file not found: " + path);
+  std::vector<unsigned char> bytes((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  size_t n = bytes.size() / 4;  // a trailing partial word is ignored, as the reference's read loop does
+  std::vector<uint32_t> prg(n);
+  for (size_t i = 0; i < n; ++i)
+    prg[i] = (uint32_t)bytes[4 * i] | ((uint32_t)bytes[4 * i + 1] << 8) | ((uint32_t)bytes[4 * i + 2] << 16) |
+             ((uint32_t)bytes[4 * i + 3] << 24);
+  return prg;
+}
+
+// ===========================================================================
+// Graph flattening + marker adjacency (coverage_graph.cpp:82-379)
+// ===========================================================================
+namespace {
+
+enum class MType { sequence, site_entry, allele_end, site_end };
+
+struct BuildNode {
+  uint32_t site = 0;
+  int32_t allele = -1;
+  uint32_t seq_len = 0;
+  uint32_t first_pos = 0;
+  std::vector<uint32_t> next;
+};
+
+struct OpenSite {
+  uint32_t site;
+  uint32_t entry, exit;
+  int32_t allele;
+};
+
+struct GraphBuild {
+  std::vector<BuildNode> nodes;
+  std::vector<uint32_t> pos_node;
+  std::vector<MType> mtype;
+  std::unordered_map<uint32_t, std::pair<uint32_t, int32_t>> parent;  // par_map
+  std::map<uint32_t, std::vector<TargetedMarker>> target_map;
+  std::vector<std::pair<uint32_t, int32_t>> pos_target;
+  std::map<uint32_t, std::pair<uint32_t, uint32_t>> bubbles;  // site -> (entry, exit)
+};
+
+void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
+  const size_t N = prg.size();
+  // linearised_prg.cpp:52-80: last position of each allele marker; duplicate site markers are an error
+  std::unordered_map<uint32_t, size_t> end_pos;
+  {
+    std::unordered_map<uint32_t, bool> seen;
+    for (size_t p = 0; p < N; ++p) {
+      uint32_t m = prg[p];
+      if (m == 0) throw std::runtime_error("PRG symbols must be >= 1");
+      if (m <= 4) continue;
+      if (m & 1) {
+        if (seen.count(m))
+          throw std::runtime_error("PRG consistency error: site marker " + std::to_string(m) + " used for two different sites");
+        seen[m] = true;
+      } else
+        end_pos[m] = p;
+    }
+  }
+  g.pos_node.assign(N, 0);
+  g.mtype.assign(N, MType::sequence);
+  g.pos_target.assign(N, {0u, -1});
+  std::vector<OpenSite> stack;
+  auto new_node = [&](uint32_t site, int32_t allele, uint32_t first_pos) {
+    BuildNode n;
+    n.site = site;
+    n.allele = allele;
+    n.first_pos = first_pos;
+    g.nodes.push_back(n);
+    return (uint32_t)g.nodes.size() - 1;
+  };
+  uint32_t back = new_node(0, -1, 0);  // root
+  int64_t cur = -1;                    // open sequence node
+  auto wire = [&](uint32_t target) {   // coverage_graph.cpp:260-266
+    if (cur >= 0) {
+      g.nodes[back].next.push_back((uint32_t)cur);
+      g.nodes[cur].next.push_back(target);
+      cur = -1;
+    } else
+      g.nodes[back].next.push_back(target);
+  };
+  MType prev_t = MType::sequence;
+  uint32_t prev_m = 0;
+  for (size_t p = 0; p < N; ++p) {
+    uint32_t m = prg[p];
+    MType t;
+    if (m <= 4) {
+      t = MType::sequence;
+      if (cur < 0) {
+        uint32_t site = stack.empty() ? 0 : stack.back().site;
+        int32_t allele = stack.empty() ? -1 : stack.back().allele;
+        cur = new_node(site, allele, (uint32_t)p);
+      }
+      g.nodes[cur].seq_len++;
+      g.pos_node[p] = (uint32_t)cur;
+      if (prev_t != MType::sequence) {  // map_targets, coverage_graph.cpp:280-284
+        int32_t cur_allele = stack.empty() ? -1 : stack.back().allele;
+        g.pos_target[p] = {prev_m, cur_allele};
+      }
+    } else if (m & 1) {
+      t = MType::site_entry;
+      uint32_t entry = new_node(m, -1, (uint32_t)p);
+      wire(entry);
+      uint32_t exit = new_node(m, -1, (uint32_t)p);
+      if (!stack.empty()) g.parent[m] = {stack.back().site, stack.back().allele};
+      if (prev_t != MType::sequence) {  // make_site_entry_target, coverage_graph.cpp:313-328
+        uint32_t target = prev_t == MType::allele_end ? prev_m - 1 : prev_m;
+        if (!g.target_map.count(m)) g.target_map[m] = {TargetedMarker{target, -1}};
+      }
+      stack.push_back(OpenSite{m, entry, exit, 0});
+      g.bubbles[m] = {entry, exit};
+      back = entry;
+      g.pos_node[p] = entry;
+    } else {
+      if (stack.empty() || stack.back().site + 1 != m)
+        throw std::runtime_error("PRG consistency error: allele marker " + std::to_string(m) + " does not close the open site");
+      OpenSite &top = stack.back();
+      bool last = end_pos.at(m) == p;
+      t = last ? MType::site_end : MType::allele_end;
+      int32_t ending_allele = top.allele;
+      if (prev_t != MType::sequence) {
+        if (last) {  // make_site_exit_target, coverage_graph.cpp:330-350
+          if (prev_t == MType::site_entry)
+            throw std::runtime_error("PRG consistency error: site number " + std::to_string(m) + " is empty");
+          if (prev_t == MType::site_end)
+            g.target_map[m].push_back(TargetedMarker{prev_m, -1});
+          else
+            g.target_map[m].push_back(TargetedMarker{prev_m - 1, ending_allele});
+        } else {  // make_allele_end_target, coverage_graph.cpp:352-369
+          if (prev_t == MType::site_entry)
+            g.target_map[m].push_back(TargetedMarker{prev_m, ending_allele});
+          else if (prev_t == MType::site_end)
+            g.target_map[m].push_back(TargetedMarker{prev_m, -1});
+          else
+            g.target_map[m].push_back(TargetedMarker{prev_m - 1, ending_allele});
+        }
+      }
+      wire(top.exit);
+      if (!last) {
+        top.allele++;
+        back = top.entry;
+        g.pos_node[p] = top.entry;
+      } else {
+        if (top.allele == 0)  // coverage_graph.cpp:220-222
+          throw std::runtime_error("Site numbered " + std::to_string(m) + " has only one allele");
+        uint32_t exit = top.exit;
+        g.nodes[exit].first_pos = (uint32_t)p;
+        stack.pop_back();
+        back = exit;
+        g.pos_node[p] = exit;
+      }
+    }
+    g.mtype[p] = t;
+    prev_t = t;
+    prev_m = m;
+  }
+  if (!stack.empty()) throw std::runtime_error("PRG consistency error: site " + std::to_string(stack.back().site) + " is never closed");
+  uint32_t sink = new_node(0, -1, (uint32_t)N);
+  wire(sink);
+}
+
+// ---------------------------------------------------------------------------
+// Host context for gmx_extend (seed-table enumeration)
+// ---------------------------------------------------------------------------
+struct HostCtx {
+  struct St {
+    uint32_t lo, hi, tvd, tvg;
+  };
+  std::vector<St> st;
+  uint32_t n = 0;
+  std::vector<GmxPathNode> arena;
+  uint32_t status = GMX_TASK_MAPPED;
+
+  uint32_t n_states() const { return n; }
+  void set_n_states(uint32_t v) { n = v; }
+  void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
+    lo = st[s].lo;
+    hi = st[s].hi;
+    tvd = st[s].tvd;
+    tvg = st[s].tvg;
+  }
+  void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { st[s] = St{lo, hi, tvd, tvg}; }
+  bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n == st.size()) st.resize(st.size() ? st.size() * 2 : 16);
+    st[n++] = St{lo, hi, tvd, tvg};
+    return true;
+  }
+  uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    arena.push_back(GmxPathNode{site, allele, next});
+    return (uint32_t)arena.size() - 1;
+  }
+  uint32_t arena_site(uint32_t node) const { return arena[node].site; }
+  uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  void fail(uint32_t s) { status = s; }
+};
+
+struct SeedOut {
+  uint32_t code;
+  std::vector<uint32_t> words;  // empty => simple (a, b) stored separately
+  uint32_t a, b;
+};
+
+void serialize_states(const HostCtx &ctx, SeedOut &o) {
+  bool simple = ctx.n == 1 && ctx.st[0].tvd == GMX_NIL && ctx.st[0].tvg == GMX_NIL;
+  if (simple) {
+    o.a = ctx.st[0].lo;
+    o.b = ctx.st[0].hi;
+    return;
+  }
+  o.a = GMX_SEED_COMPLEX;
+  o.b = 0;
+  o.words.push_back(ctx.n);
+  std::vector<std::pair<uint32_t, int32_t>> tmp;
+  for (uint32_t s = 0; s < ctx.n; ++s) {
+    auto const &st = ctx.st[s];
+    o.words.push_back(st.lo);
+    o.words.push_back(st.hi);
+    size_t at = o.words.size();
+    o.words.push_back(0);
+    o.words.push_back(0);
+    tmp.clear();
+    for (uint32_t x = st.tvd; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, ctx.arena[x].allele});
+    o.words[at] = (uint32_t)tmp.size();
+    for (size_t i = tmp.size(); i-- > 0;) {
+      o.words.push_back(tmp[i].first);
+      o.words.push_back((uint32_t)tmp[i].second);
+    }
+    tmp.clear();
+    for (uint32_t x = st.tvg; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, -1});
+    o.words[at + 1] = (uint32_t)tmp.size();
+    for (size_t i = tmp.size(); i-- > 0;) o.words.push_back(tmp[i].first);
+  }
+}
+
+// Depth-first enumeration of all k-mers sharing suffixes (the reference shares them through a cache of
+// prefix diffs, build.cpp:55-86). `depth` bases (the rightmost ones) have been processed in `ctx`.
+void seed_dfs(const GmxIndexView &ix, uint32_t k, uint32_t depth, uint32_t code, HostCtx &ctx, std::vector<SeedOut> &out) {
+  if (ctx.n == 0) return;  // every longer k-mer with this suffix is absent too
+  if (depth == k) {
+    SeedOut o;
+    o.code = code;
+    serialize_states(ctx, o);
+    out.push_back(std::move(o));
+    return;
+  }
+  // snapshot
+  std::vector<HostCtx::St> saved(ctx.st.begin(), ctx.st.begin() + ctx.n);
+  uint32_t saved_n = ctx.n;
+  size_t saved_arena = ctx.arena.size();
+  for (uint32_t b = 1; b <= 4; ++b) {
+    if (b > 1) {
+      if (ctx.st.size() < saved_n) ctx.st.resize(saved_n);
+      std::copy(saved.begin(), saved.end(), ctx.st.begin());
+      ctx.n = saved_n;
+      ctx.arena.resize(saved_arena);
+    }
+    gmx_extend(ix, b, ctx, depth == 0);
+    if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
+    seed_dfs(ix, k, depth + 1, code | ((b - 1) << (2 * depth)), ctx, out);
+  }
+}
+
+}  // namespace
+
+GmxIndexView HostIndex::view() const {
+  GmxIndexView v;
+  memset(&v, 0, sizeof(v));
+  v.n = (uint32_t)prg.size() + 1;
+  v.n_prg = (uint32_t)prg.size();
+  v.sentinel_pos = sentinel_pos;
+  v.kmer_size = kmer_size;
+  for (int i = 0; i < 8; ++i) v.C[i] = C[i];
+  v.n_blocks = (uint32_t)blocks.size();
+  v.n_hits = (uint32_t)hit_prog.size();
+  v.n_nodes = nodes.empty() ? 0 : (uint32_t)nodes.size() - 1;
+  v.n_sites = (uint32_t)sites.size();
+  v.n_allele_slots = n_allele_slots;
+  v.n_pb_slots = n_pb_slots;
+  v.n_grouped_slots = n_grouped_slots;
+  v.is_nested = is_nested ? 1 : 0;
+  v.blocks = blocks.data();
+  v.hit_prog = hit_prog.data();
+  v.prog = prog.data();
+  v.sa = sa.data();
+  v.pos_node = pos_node.data();
+  v.nodes = nodes.data();
+  v.edges = edges.data();
+  v.sites = sites.data();
+  v.seeds = seeds.data();
+  v.seed_words = seed_words.data();
+  v.kmer_bitmap = kmer_bitmap.data();
+  return v;
+}
+
+void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads) {
+  out = HostIndex();
+  out.prg = prg;
+  out.kmer_size = kmer_size;
+  const size_t N = prg.size();
+  if (N == 0) throw std::runtime_error("empty PRG");
+  if (N >= 0x7ffffff0ull) throw std::runtime_error("PRG too long for this build (2^31 limit)");
+
+  // --- graph ---------------------------------------------------------------
+  GraphBuild g;
+  build_graph(prg, g);
+  out.is_nested = !g.parent.empty();
+  out.pos_node = g.pos_node;
+  out.pos_target = g.pos_target;
+  for (auto &e : g.target_map) out.target_map.push_back({e.first, e.second});
+
+  // sites: markers must be 5,7,9,... contiguous (siteID_to_index indexing, data_types.hpp:78-81)
+  uint32_t n_sites = (uint32_t)g.bubbles.size();
+  out.sites.assign(n_sites, GmxSite{});
+  {
+    uint32_t expect = 5;
+    for (auto &b : g.bubbles) {
+      if (b.first != expect)
+        throw std::runtime_error("site markers must be numbered 5,7,9,... without gaps (found " + std::to_string(b.first) + ")");
+      expect += 2;
+    }
+  }
+  // nodes + edges
+  out.nodes.resize(g.nodes.size() + 1);
+  uint32_t pb = 0;
+  for (size_t i = 0; i < g.nodes.size(); ++i) {
+    auto const &bn = g.nodes[i];
+    GmxNode &n = out.nodes[i];
+    n.site = bn.site;
+    n.allele = bn.allele;
+    n.seq_len = bn.seq_len;
+    n.first_pos = bn.first_pos;
+    n.edge_begin = (uint32_t)out.edges.size();
+    bool in_bubble = bn.allele != -1 && bn.site != 0;  // is_in_bubble, coverage_graph.hpp:60-62
+    if (in_bubble && bn.seq_len > 0) {
+      n.cov_off = pb;
+      pb += bn.seq_len;
+    } else
+      n.cov_off = GMX_NO_COV;
+    for (auto e : bn.next) out.edges.push_back(e);
+  }
+  {
+    GmxNode &closing = out.nodes[g.nodes.size()];
+    memset(&closing, 0, sizeof(closing));
+    closing.allele = -1;
+    closing.cov_off = GMX_NO_COV;
+    closing.edge_begin = (uint32_t)out.edges.size();
+  }
+  out.n_pb_slots = pb;
+  uint32_t as = 0, gs = 0;
+  for (auto &b : g.bubbles) {
+    uint32_t idx = (b.first - 5) / 2;
+    GmxSite &s = out.sites[idx];
+    auto pit = g.parent.find(b.first);
+    s.parent_site = pit == g.parent.end() ? 0 : pit->second.first;
+    s.parent_allele = pit == g.parent.end() ? -1 : pit->second.second;
+    s.n_alleles = (uint32_t)g.nodes[b.second.first].next.size();
+    s.allele_sum_off = as;
+    as += s.n_alleles;
+    if (s.n_alleles <= GMX_GROUPED_DENSE_MAX_ALLELES) {
+      s.grouped_off = gs;
+      gs += (1u << s.n_alleles) - 1u;
+    } else
+      s.grouped_off = GMX_GROUPED_LOG;
+    s.entry_node = b.second.first;
+    s.exit_node = b.second.second;
+  }
+  out.n_allele_slots = as;
+  out.n_grouped_slots = gs;
+
+  // --- suffix array, BWT, rank blocks -----------------------------------------
+  std::vector<uint32_t> text(prg);
+  text.push_back(0);
+  const size_t n = text.size();
+  build_suffix_array(text, out.sa);
+  out.bwt.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    uint32_t p = out.sa[i];
+    out.bwt[i] = p == 0 ? 0u : text[p - 1];
+    if (p == 0) out.sentinel_pos = (uint32_t)i;
+  }
+  // symbol -> first SA index (FM-index C array over the compacted alphabet)
+  std::map<uint32_t, uint32_t> sym_count;
+  for (auto s : text) sym_count[s]++;
+  std::map<uint32_t, uint32_t> sym_first;
+  {
+    uint32_t acc = 0;
+    for (auto &e : sym_count) {
+      sym_first[e.first] = acc;
+      acc += e.second;
+    }
+  }
+  for (uint32_t c = 1; c <= 4; ++c) {
+    // char2comp of an absent symbol is 0 in SDSL, C[0] = 0; an absent base never yields a valid interval
+    out.C[c] = sym_first.count(c) ? sym_first[c] : 0;
+  }
+  size_t n_blocks = (n >> GMX_BLK_SHIFT) + 1;
+  out.blocks.assign(n_blocks, GmxRankBlock{});
+  {
+    uint32_t cA = 0, cC = 0, cG = 0, cM = 0;
+    for (size_t b = 0; b < n_blocks; ++b) {
+      GmxRankBlock &blk = out.blocks[b];
+      blk.cnt[0] = cA;
+      blk.cnt[1] = cC;
+      blk.cnt[2] = cG;
+      blk.cnt[3] = cM;
+      for (size_t j = 0; j < 128; ++j) {
+        size_t i = (b << GMX_BLK_SHIFT) + j;
+        if (i >= n) break;
+        uint32_t c = out.bwt[i];
+        size_t w = j >> 6, bit = j & 63;
+        if (c > 4) {
+          blk.mk[w] |= 1ull << bit;
+          cM++;
+        } else if (c == 0 || c == 1) {
+          cA++;  // sentinel counted with A (raw count), corrected at query time
+        } else if (c == 2) {
+          blk.lo[w] |= 1ull << bit;
+          cC++;
+        } else if (c == 3) {
+          blk.hi[w] |= 1ull << bit;
+          cG++;
+        } else {
+          blk.lo[w] |= 1ull << bit;
+          blk.hi[w] |= 1ull << bit;
+        }
+      }
+    }
+  }
+
+  // --- jump programs --------------------------------------------------------------
+  // marker SA intervals: site marker -> single index; allele marker -> [C[m], C[next symbol] - 1]
+  auto marker_first = [&](uint32_t m) -> uint32_t {
+    auto it = sym_first.find(m);
+    if (it == sym_first.end()) throw std::runtime_error("marker " + std::to_string(m) + " absent from the PRG");
+    return it->second;
+  };
+  auto marker_last = [&](uint32_t m) -> uint32_t { return marker_first(m) + sym_count[m] - 1; };
+  struct Work {
+    uint32_t marker;
+    int32_t allele;
+    std::vector<uint32_t> ops;  // flat (op, site, allele)
+  };
+  out.prog.clear();
+  out.prog.push_back(0);  // program 0: no outputs (marker positions that are never scanned)
+  std::map<std::pair<uint32_t, int32_t>, uint32_t> prog_of;
+  auto make_program = [&](uint32_t marker0, int32_t allele0) -> uint32_t {
+    auto key = std::make_pair(marker0, allele0);
+    auto f = prog_of.find(key);
+    if (f != prog_of.end()) return f->second;
+    std::vector<std::pair<std::vector<uint32_t>, std::pair<uint32_t, uint32_t>>> outputs;
+    std::vector<Work> stack;
+    stack.push_back(Work{marker0, allele0, {}});
+    size_t guard = 0;
+    while (!stack.empty()) {
+      if (++guard > 1000000) throw std::runtime_error("marker jump closure does not terminate");
+      Work w = std::move(stack.back());
+      stack.pop_back();
+      if (w.marker & 1) {  // extend_targets_site_exit, vBWT_jump.cpp:185-228
+        std::vector<uint32_t> ops = w.ops;
+        ops.insert(ops.end(), {GMX_OP_EXIT, w.marker, (uint32_t)w.allele});
+        uint32_t site = w.marker;
+        uint32_t idx = marker_first(site);
+        bool commit = true;
+        bool has_next = false;
+        uint32_t next_marker = 0;
+        while (g.target_map.count(site)) {
+          auto const &tm = g.target_map.at(site);
+          if (tm.size() != 1) throw std::runtime_error("site entry point with more than one target");
+          uint32_t nm = tm.back().id;
+          if ((nm & 1) == 0) {
+            has_next = true;
+            next_marker = nm;
+            commit = false;
+            break;
+          }
+          auto par = g.parent.find(site);
+          if (par == g.parent.end() || par->second.first != nm) throw std::runtime_error("double exit not recorded in the parental map");
+          ops.insert(ops.end(), {GMX_OP_EXIT, nm, (uint32_t)par->second.second});
+          idx = marker_first(nm);
+          site = nm;
+        }
+        if (commit) outputs.push_back({ops, {idx, idx}});
+        if (has_next) stack.push_back(Work{next_marker, 0, ops});
+      } else {  // extend_targets_site_entry, vBWT_jump.cpp:230-265
+        std::vector<uint32_t> ops = w.ops;
+        ops.insert(ops.end(), {GMX_OP_ENTER, w.marker - 1, (uint32_t)-1});
+        outputs.push_back({ops, {marker_first(w.marker), marker_last(w.marker)}});
+        auto tm = g.target_map.find(w.marker);
+        if (tm != g.target_map.end())
+          for (auto const &t : tm->second) {
+            if (t.id & 1)
+              stack.push_back(Work{t.id, t.deletion_allele, ops});
+            else
+              stack.push_back(Work{t.id, -1, ops});
+          }
+      }
+    }
+    uint32_t off = (uint32_t)out.prog.size();
+    out.prog.push_back((uint32_t)outputs.size());
+    for (auto &o : outputs) {
+      out.prog.push_back((uint32_t)(o.first.size() / 3));
+      out.prog.insert(out.prog.end(), o.first.begin(), o.first.end());
+      out.prog.push_back(o.second.first);
+      out.prog.push_back(o.second.second);
+    }
+    prog_of[key] = off;
+    return off;
+  };
+  out.hit_prog.clear();
+  for (size_t i = 0; i < n; ++i) {
+    if (out.bwt[i] <= 4) continue;
+    uint32_t p = out.sa[i];
+    uint32_t off = 0;
+    if (p < N && prg[p] <= 4) {
+      // left_markers_search, vBWT_jump.cpp:94-117
+      uint32_t m = g.pos_target[p].first;
+      int32_t a = g.pos_target[p].second;
+      if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
+      off = make_program(m, a);
+    }
+    out.hit_prog.push_back(off);
+  }
+
+  // --- seed table ---------------------------------------------------------------------
+  if (kmer_size > 0) {
+    if (kmer_size > 15) throw std::runtime_error("kmer_size > 15 is not supported");
+    const uint32_t k = kmer_size;
+    const uint64_t n_kmers = 1ull << (2 * k);
+    out.seeds.assign(n_kmers, GmxSeed{1, 0});
+    out.kmer_bitmap.assign((n_kmers + 31) / 32, 0);
+    GmxIndexView ix = out.view();
+    // split the enumeration by the rightmost `split` bases
+    uint32_t split = k >= 3 ? 3 : k;
+    uint32_t n_tasks = 1u << (2 * split);
+    unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    hw = std::min<unsigned>(hw, n_tasks);
+    std::vector<std::vector<SeedOut>> results(n_tasks);
+    std::vector<std::string> errors(n_tasks);
+    auto run_task = [&](uint32_t task) {
+      try {
+        HostCtx ctx;
+        ctx.push(0, (uint32_t)n - 1, GMX_NIL, GMX_NIL);  // get_initial_cache_element, build.cpp:35-46
+        uint32_t code = 0;
+        bool alive = true;
+        for (uint32_t d = 0; d < split && alive; ++d) {
+          uint32_t b = ((task >> (2 * d)) & 3) + 1;
+          gmx_extend(ix, b, ctx, d == 0);
+          code |= (b - 1) << (2 * d);
+          if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
+          if (ctx.n == 0) alive = false;
+        }
+        if (alive) seed_dfs(ix, k, split, code, ctx, results[task]);
+      } catch (std::exception const &e) {
+        errors[task] = e.what();
+      }
+    };
+    if (hw <= 1) {
+      for (uint32_t t = 0; t < n_tasks; ++t) run_task(t);
+    } else {
+      std::vector<std::thread> pool;
+      std::atomic<uint32_t> next{0};
+      for (unsigned w = 0; w < hw; ++w)
+        pool.emplace_back([&]() {
+          for (;;) {
+            uint32_t t = next.fetch_add(1);
+            if (t >= n_tasks) break;
+            run_task(t);
+          }
+        });
+      for (auto &th : pool) th.join();
+    }
+    for (auto &e : errors)
+      if (!e.empty()) throw std::runtime_error(e);
+    // NB on the code convention: bit pair d (from the least significant end) holds the base at distance d
+    // from the right end of the k-mer, i.e. the leftmost base is most significant.
+    for (auto &vec : results)
+      for (auto &o : vec) {
+        GmxSeed s{o.a, o.b};
+        if (o.a == GMX_SEED_COMPLEX) {
+          s.b = (uint32_t)out.seed_words.size();
+          out.seed_words.insert(out.seed_words.end(), o.words.begin(), o.words.end());
+        }
+        out.seeds[o.code] = s;
+        out.kmer_bitmap[o.code >> 5] |= 1u << (o.code & 31);
+        out.n_seed_kmers_present++;
+      }
+    if (out.seed_words.empty()) out.seed_words.push_back(0);
+  }
+}
+
+std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code) {
+  std::vector<int64_t> v;
+  GmxSeed s = ix.seeds.at(code);
+  if (s.a == 1 && s.b == 0) return {-1};
+  if (s.a != GMX_SEED_COMPLEX) return {1, s.a, s.b, 0, 0};
+  const uint32_t *p = ix.seed_words.data() + s.b;
+  uint32_t ns = *p++;
+  v.push_back(ns);
+  for (uint32_t i = 0; i < ns; ++i) {
+    v.push_back(p[0]);
+    v.push_back(p[1]);
+    uint32_t nt = p[2], ng = p[3];
+    p += 4;
+    v.push_back(nt);
+    for (uint32_t j = 0; j < nt; ++j) {
+      v.push_back(p[0]);
+      v.push_back((int32_t)p[1]);
+      p += 2;
+    }
+    v.push_back(ng);
+    for (uint32_t j = 0; j < ng; ++j) {
+      v.push_back(*p++);
+      v.push_back(-1);
+    }
+  }
+  return v;
+}
+
+}  // namespace gmx

@@ -1,0 +1,66 @@
+// gmx_index.h — host-side index builder: gram_dir/prg -> flat tables (see gmx_types.h).
+//
+// The reference derives the same information in `gram build`
+// (libgramtools/src/build/build.cpp:8-72: coverage graph, SDSL FM-index, BWT masks,
+// k-mer index) and reloads it in `gram genotype` (src/prg/prg_info.cpp:6-29,
+// src/build/kmer_index/load.cpp:161-173). All of it is a pure function of the
+// integer PRG and k, so this engine derives it from `prg` directly.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "gmx_types.h"
+
+namespace gmx {
+
+struct TargetedMarker {
+  uint32_t id;
+  int32_t deletion_allele;
+};
+
+struct HostIndex {
+  std::vector<uint32_t> prg;  // PRG symbols (no sentinel)
+  uint32_t kmer_size = 0;
+  uint32_t sentinel_pos = 0;
+  uint32_t C[8] = {0};
+  bool is_nested = false;
+
+  std::vector<GmxRankBlock> blocks;
+  std::vector<uint32_t> sa;
+  std::vector<uint32_t> hit_prog;
+  std::vector<uint32_t> prog;
+  std::vector<uint32_t> pos_node;
+  std::vector<GmxNode> nodes;  // + 1 closing record
+  std::vector<uint32_t> edges;
+  std::vector<GmxSite> sites;
+  std::vector<GmxSeed> seeds;
+  std::vector<uint32_t> seed_words;
+  std::vector<uint32_t> kmer_bitmap;
+  uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;
+
+  // introspection used by the tests (not needed on the device)
+  std::vector<uint32_t> bwt;
+  std::vector<std::pair<uint32_t, std::vector<TargetedMarker>>> target_map;  // ascending key
+  std::vector<std::pair<uint32_t, int32_t>> pos_target;                        // per PRG position (0,-1) if none
+  uint64_t n_seed_kmers_present = 0;
+
+  GmxIndexView view() const;  // host-pointer view
+};
+
+// Suffix array of `text` (last symbol must be the unique smallest symbol 0). SA-IS, O(n).
+void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa);
+
+// Builds everything. Throws std::runtime_error on an inconsistent PRG (same conditions as
+// PRG_String / cov_Graph_Builder: linearised_prg.cpp:52-80, coverage_graph.cpp:220-222,338-341).
+// kmer_size == 0 skips the seed table. threads <= 0 uses all hardware threads for the seed table.
+void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads = 0);
+
+// gram_dir/prg reader: little-endian uint32 per symbol (linearised_prg.cpp:8-45).
+std::vector<uint32_t> read_prg_file(const std::string &path);
+
+// Collects the k-mer index states of one k-mer from the seed table (test / debug helper).
+// Output format: [n_states, {lo, hi, n_traversed, (site, allele)*, n_traversing, (site, -1)*}*] or {-1} if absent.
+std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t kmer_code);
+
+}  // namespace gmx

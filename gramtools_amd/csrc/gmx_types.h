@@ -1,0 +1,126 @@
+// gmx_types.h — flat, GPU-resident index layout of the MI355X quasimap engine.
+//
+// Everything the mapping path reads is a plain array so that the same structs
+// describe host memory (index builder) and HBM (kernels). Replaces the reference's
+// PRG_Info bundle (libgramtools/include/prg/prg_info.hpp:22-59): SDSL csa_wt +
+// 4 bit_vectors + 4 rank_support_v + marker mask + pointer-based coverage_Graph.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GMX_HD __host__ __device__ inline __attribute__((always_inline))
+#else
+#define GMX_HD inline
+#endif
+
+// ---------------------------------------------------------------------------
+// Rank block: 128 BWT positions in one 64-byte line.
+//   cnt[0..2] = number of A, C, G in BWT[0, 128*b)   (A count includes the sentinel
+//               position, which is stored as code 00 with no marker bit; see gmx_rank())
+//   cnt[3]    = number of marker positions (BWT symbol > 4) in BWT[0, 128*b)
+//   lo/hi     = bit-sliced 2-bit base codes (A=00 C=01 G=10 T=11); markers/sentinel = 00
+//   mk        = marker bit plane (reference: bwt_markers_mask, make_data_structures.cpp:158-163)
+// T counts are derived: T = pos - A - C - G - M.
+// Replaces 4 x (sdsl::bit_vector + rank_support_v<1>) = 8 cache lines per LF step
+// (BWT_search.cpp:8-22, prg_info.cpp:20-26) by one 64-byte line.
+// ---------------------------------------------------------------------------
+struct alignas(64) GmxRankBlock {
+  uint32_t cnt[4];
+  uint64_t lo[2];
+  uint64_t hi[2];
+  uint64_t mk[2];
+};
+#define GMX_BLK_SHIFT 7
+#define GMX_BLK_MASK 127u
+
+// Graph node record (flattened coverage_Node, include/prg/coverage_graph.hpp:40-123).
+struct GmxNode {
+  uint32_t site;        // site marker (odd) or 0
+  int32_t allele;       // allele id or -1 (boundary / outside sites)
+  uint32_t seq_len;     // number of bases
+  uint32_t first_pos;   // PRG position of the first base (sequence nodes) / of the marker (boundary nodes)
+  uint32_t cov_off;     // offset into the per-base accumulator, 0xFFFFFFFF if the node owns none
+  uint32_t edge_begin;  // first out-edge in edges[]; n_edges = next node's edge_begin - edge_begin
+};
+#define GMX_NO_COV 0xFFFFFFFFu
+
+// Per-site record.
+struct GmxSite {
+  uint32_t parent_site;     // par_map[site].first, 0 when the site is level-0 (coverage_graph.cpp:193-196)
+  int32_t parent_allele;    // par_map[site].second
+  uint32_t n_alleles;       // edges of the bubble start
+  uint32_t allele_sum_off;  // offset of allele 0 in the allele-sum accumulator
+  uint32_t grouped_off;     // dense grouped-counts base (2^n_alleles - 1 slots) or GMX_GROUPED_LOG
+  uint32_t entry_node;      // bubble start node
+  uint32_t exit_node;       // bubble end node
+  uint32_t pad;
+};
+#define GMX_GROUPED_LOG 0xFFFFFFFFu
+#define GMX_GROUPED_DENSE_MAX_ALLELES 5
+
+// Seed directory entry (k-mer index, build/kmer_index/build.cpp:101-131), direct-addressed by k-mer code.
+//   a <= b               : exactly one path-less state [a, b]
+//   a == 1, b == 0       : k-mer absent
+//   a == 0xFFFFFFFF      : b = word offset into seed_words: [n_states, {lo, hi, n_traversed, n_traversing,
+//                          (site, allele) x n_traversed (push order), site x n_traversing (push order)}*]
+struct GmxSeed {
+  uint32_t a, b;
+};
+#define GMX_SEED_COMPLEX 0xFFFFFFFFu
+
+// Jump program words (pre-resolved closure of search_state_vBWT_jumps, vBWT_jump.cpp:134-265, for one marker hit):
+//   [n_outputs, { n_ops, (op, site, allele) x n_ops, lo, hi } x n_outputs]
+#define GMX_OP_EXIT 1u   // exiting_site_search_state / update_variant_site_path (vBWT_jump.cpp:51-92)
+#define GMX_OP_ENTER 2u  // entering_site_search_state (vBWT_jump.cpp:29-44)
+
+// The device/host view of the index. All pointers are device pointers on the GPU side.
+struct GmxIndexView {
+  uint32_t n;             // text length including the sentinel (= BWT length)
+  uint32_t n_prg;         // PRG length
+  uint32_t sentinel_pos;  // BWT index holding the sentinel
+  uint32_t kmer_size;
+  uint32_t C[8];          // C[1..4]: first SA index of each base
+  uint32_t n_blocks;
+  uint32_t n_hits;
+  uint32_t n_nodes;
+  uint32_t n_sites;
+  uint32_t n_allele_slots;   // allele-sum accumulator length
+  uint32_t n_pb_slots;       // per-base accumulator length
+  uint32_t n_grouped_slots;  // dense grouped accumulator length
+  uint32_t is_nested;
+  const GmxRankBlock *blocks;
+  const uint32_t *hit_prog;   // [n_hits] program offset for the h-th marker position of the BWT
+  const uint32_t *prog;       // jump programs
+  const uint32_t *sa;         // [n]
+  const uint32_t *pos_node;   // [n_prg]
+  const GmxNode *nodes;       // [n_nodes + 1] (sentinel record closes the last edge range)
+  const uint32_t *edges;
+  const GmxSite *sites;       // [n_sites]
+  const GmxSeed *seeds;       // [4^k]
+  const uint32_t *seed_words;
+  const uint32_t *kmer_bitmap;  // [4^k / 32] presence bits (all_read_kmers_occur_in_index, quasimap.cpp:212-225)
+};
+
+// Status of one (read, orientation) task after the search kernel.
+#define GMX_TASK_UNMAPPED 0u      // no final state (missing_kmer or no_extension, decided by the filter)
+#define GMX_TASK_MAPPED 1u
+#define GMX_TASK_OVERFLOW 2u      // capacity exceeded: must be re-run by the large-capacity kernel
+#define GMX_TASK_SKIPPED 3u       // read holds a non-ACGT symbol (encode_dna_bases, utils.cpp:73-92)
+#define GMX_TASK_ERROR 4u         // reference would have thrown / asserted (e.g. site traversed twice)
+#define GMX_TASK_LOGFULL 6u       // the grouped-allele-count log is full (sites with more than 5 alleles)
+
+#define GMX_NIL 0xFFFFFFFFu
+
+// Arena node of the persistent path lists (VariantSitePath, search/types.hpp:13-15).
+struct GmxPathNode {
+  uint32_t site;
+  int32_t allele;
+  uint32_t next;  // GMX_NIL terminates
+};
+
+// Final-state record handed from the search kernel to the coverage kernel.
+struct GmxFinalState {
+  uint32_t lo, hi;
+  uint32_t traversed;   // arena head (most recently pushed locus first) or GMX_NIL
+  uint32_t traversing;  // arena head (innermost site first) or GMX_NIL
+};

@@ -1,0 +1,355 @@
+"""Host-side mirror of the reference's quasimap interface over the C-ABI (include/gmx.h).
+
+Names follow libgramtools (paths relative to /root/reference/libgramtools/):
+  * ``PRG_Info`` + ``KmerIndex``  -> :class:`Index`              (include/prg/prg_info.hpp:22-59)
+  * ``quasimap_reads``            -> :func:`quasimap_reads`      (src/genotype/quasimap/quasimap.cpp:16-57)
+  * ``QuasimapReadsStats``        -> :class:`QuasimapReadsStats` (include/genotype/quasimap/quasimap.hpp:17-24)
+  * ``Coverage``                  -> :class:`Coverage`           (include/genotype/quasimap/coverage/types.hpp:40-46)
+  * ``coverage::dump::*``         -> :func:`dump_allele_sum`, :func:`dump_allele_base`, :func:`dump_grouped_allele_counts`
+
+Mapping always runs on the GPU through libgmx.so; nothing here computes coverage on the CPU.
+"""
+import ctypes as C
+import json
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+RNG_LEMIRE = 0
+RNG_DIVISION = 1
+GROUPED_LOG = 0xFFFFFFFF
+
+
+def _p(arr, ctype):
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def encode_dna_bases(seq: str) -> np.ndarray:
+    """A,C,G,T (any case) -> 1,2,3,4; any other character gives an empty read (common/utils.cpp:73-92)."""
+    b = np.frombuffer(seq.encode("ascii", "replace"), dtype=np.uint8)
+    lut = np.zeros(256, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [1, 2, 3, 4, 1, 2, 3, 4]):
+        lut[ch] = v
+    out = lut[b]
+    if out.size and out.min() == 0:
+        return np.zeros(0, dtype=np.uint8)
+    return out
+
+
+def master_seeds(master_seed: int, reads_per_file) -> np.ndarray:
+    """Per-read selection seeds: 5000 master draws per batch of <= 5000 reads, per file (quasimap.cpp:120-141)."""
+    rpf = np.ascontiguousarray(reads_per_file, dtype=np.uint64)
+    out = np.empty(int(rpf.sum()), dtype=np.uint32)
+    check(_lib.load().gmx_master_seeds(master_seed, _p(rpf, C.c_uint64), rpf.size, _p(out, C.c_uint32)))
+    return out
+
+
+class Index:
+    """Everything the mapping path needs, derived from the integer PRG and the k-mer size."""
+
+    def __init__(self, prg, kmer_size: int, threads: int = 0):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        if isinstance(prg, (str, bytes)):
+            path = prg if isinstance(prg, bytes) else prg.encode()
+            check(self.lib.gmx_index_build_from_file(path, kmer_size, threads, C.byref(self.h)))
+        else:
+            arr = np.ascontiguousarray(prg, dtype=np.uint32)
+            check(self.lib.gmx_index_build(_p(arr, C.c_uint32), arr.size, kmer_size, threads, C.byref(self.h)))
+        info = _lib.IndexInfo()
+        check(self.lib.gmx_index_get_info(self.h, C.byref(info)))
+        self.info = info
+        self.kmer_size = info.kmer_size
+        self.n_sites = info.n_sites
+        self.is_nested = bool(info.is_nested)
+        n = self.n_sites
+        self.n_alleles = np.zeros(n, dtype=np.uint32)
+        self.allele_sum_off = np.zeros(n, dtype=np.uint32)
+        self.grouped_off = np.zeros(n, dtype=np.uint32)
+        self.parent_site = np.zeros(n, dtype=np.uint32)
+        self.parent_allele = np.zeros(n, dtype=np.int32)
+        check(self.lib.gmx_index_site_layout(self.h, _p(self.n_alleles, C.c_uint32), _p(self.allele_sum_off, C.c_uint32),
+                                             _p(self.grouped_off, C.c_uint32), _p(self.parent_site, C.c_uint32),
+                                             _p(self.parent_allele, C.c_int32)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_index_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # -- layouts -------------------------------------------------------------
+    def per_base_layout(self):
+        """Rows (site_index, allele, first_prg_pos, per_base_offset, length) of every coverage-owning node."""
+        n = self.lib.gmx_index_per_base_layout(self.h, None, 0)
+        out = np.zeros((max(n, 1), 5), dtype=np.uint32)
+        self.lib.gmx_index_per_base_layout(self.h, _p(out, C.c_uint32), n)
+        return out[:n]
+
+    def allele_base_layout(self):
+        off = np.zeros(self.info.n_allele_slots, dtype=np.uint32)
+        ln = np.zeros(self.info.n_allele_slots, dtype=np.uint32)
+        check(self.lib.gmx_index_allele_base_layout(self.h, _p(off, C.c_uint32), _p(ln, C.c_uint32)))
+        return off, ln
+
+    # -- introspection (tests) -------------------------------------------------
+    def sa(self):
+        out = np.empty(self.info.n_text, dtype=np.uint32)
+        check(self.lib.gmx_index_copy_sa(self.h, _p(out, C.c_uint32)))
+        return out
+
+    def bwt(self):
+        out = np.empty(self.info.n_text, dtype=np.uint32)
+        check(self.lib.gmx_index_copy_bwt(self.h, _p(out, C.c_uint32)))
+        return out
+
+    def rank(self, upper, base):
+        return int(self.lib.gmx_index_rank(self.h, upper, base))
+
+    def pos_info(self):
+        """Per PRG position: node site, node allele, offset in node, target marker, target allele."""
+        n = self.info.n_text - 1
+        out = np.empty((n, 5), dtype=np.int64)
+        check(self.lib.gmx_index_copy_pos_info(self.h, _p(out, C.c_int64)))
+        return out
+
+    def _states_call(self, fn, *args):
+        cap = 1 << 12
+        while True:
+            out = np.empty(cap, dtype=np.int64)
+            n = fn(self.h, *args, _p(out, C.c_int64), cap)
+            if n < -1:
+                cap = -n
+                continue
+            check(n)
+            return [int(x) for x in out[:n]]
+
+    @staticmethod
+    def _unpack_states(v):
+        if v[0] == -1:
+            return None
+        n, i, out = v[0], 1, []
+        for _ in range(n):
+            lo, hi, nt = v[i], v[i + 1], v[i + 2]
+            i += 3
+            tvd = [(v[i + 2 * j], v[i + 2 * j + 1]) for j in range(nt)]
+            i += 2 * nt
+            ng = v[i]
+            i += 1
+            tvg = [(v[i + 2 * j], v[i + 2 * j + 1]) for j in range(ng)]
+            i += 2 * ng
+            out.append((lo, hi, tvd, tvg))
+        return out
+
+    def target_map(self):
+        v = self._states_call(self.lib.gmx_index_copy_target_map)
+        res, i = {}, 1
+        for _ in range(v[0]):
+            key, n = v[i], v[i + 1]
+            res[key] = [(v[i + 2 + 2 * j], v[i + 3 + 2 * j]) for j in range(n)]
+            i += 2 + 2 * n
+        return res
+
+    def seed_states(self, kmer):
+        """k-mer index entry (build/kmer_index/build.cpp:101-131) or None when the k-mer is absent."""
+        k = np.ascontiguousarray(kmer, dtype=np.uint8)
+        return self._unpack_states(self._states_call(self.lib.gmx_index_seed_states, _p(k, C.c_uint8)))
+
+    def jump_states(self, lo, hi):
+        """search_state_vBWT_jumps of the path-less state [lo, hi] (vBWT_jump.cpp:134-183)."""
+        return self._unpack_states(self._states_call(self.lib.gmx_index_jump_states, lo, hi))
+
+
+@dataclass
+class QuasimapReadsStats:
+    all_reads_count: int = 0
+    skipped_reads_count: int = 0
+    missing_kmer_reads_count: int = 0
+    no_extension_reads_count: int = 0
+    exact_mapped_reads_count: int = 0
+
+    def as_dict(self):
+        return dict(all=self.all_reads_count, skipped=self.skipped_reads_count, missing_kmer=self.missing_kmer_reads_count,
+                    no_extension=self.no_extension_reads_count, exact_mapped=self.exact_mapped_reads_count)
+
+
+class Coverage:
+    """Final coverage with the reference's uint16 semantics applied to the device totals."""
+
+    def __init__(self, index: Index, allele_sum_u32, per_base_u32, grouped_u32, grouped_log, stats: QuasimapReadsStats):
+        self.index = index
+        self.raw_allele_sum = allele_sum_u32
+        self.raw_per_base = per_base_u32
+        self.raw_grouped = grouped_u32
+        self.raw_grouped_log = grouped_log
+        self.stats = stats
+        self.allele_sum_flat = (allele_sum_u32 & 0xFFFF).astype(np.uint16)             # wraps, data_types.hpp:52
+        self.per_base_flat = np.minimum(per_base_u32, 65535).astype(np.uint16)           # saturates, allele_base.cpp:239
+
+    # AlleleSumCoverage: vector (per site) of vector (per allele)
+    @property
+    def allele_sum_coverage(self):
+        ix = self.index
+        return [[int(x) for x in self.allele_sum_flat[o:o + n]] for o, n in zip(ix.allele_sum_off, ix.n_alleles)]
+
+    # SitesGroupedAlleleCounts: per site {tuple(allele ids): count}
+    @property
+    def grouped_allele_counts(self):
+        ix = self.index
+        sites = [dict() for _ in range(ix.n_sites)]
+        for s in range(ix.n_sites):
+            off = int(ix.grouped_off[s])
+            if off == GROUPED_LOG:
+                continue
+            n = int(ix.n_alleles[s])
+            vals = self.raw_grouped[off:off + (1 << n) - 1]
+            for m in np.nonzero(vals)[0]:
+                c = int(vals[m]) & 0xFFFF  # a total that wrapped to 0 keeps its (zero-valued) key, as the reference's map does
+                mask = int(m) + 1
+                ids = tuple(a for a in range(n) if (mask >> a) & 1)
+                sites[s][ids] = c
+        log, i = self.raw_grouped_log, 0
+        while i < len(log):
+            s, n = int(log[i]), int(log[i + 1])
+            ids = tuple(int(np.int32(x)) for x in log[i + 2:i + 2 + n])
+            sites[s][ids] = (sites[s].get(ids, 0) + 1) & 0xFFFF
+            i += 2 + n
+        return sites
+
+    # SitesAlleleBaseCoverage (allele_base_non_nested, allele_base.cpp:10-38); [] for nested PRGs
+    @property
+    def allele_base_coverage(self):
+        ix = self.index
+        if ix.is_nested:
+            return []
+        off, ln = ix.allele_base_layout()
+        out = []
+        for s in range(ix.n_sites):
+            site = []
+            for a in range(int(ix.n_alleles[s])):
+                slot = int(ix.allele_sum_off[s]) + a
+                site.append([int(x) for x in self.per_base_flat[off[slot]:off[slot] + ln[slot]]])
+            out.append(site)
+        return out
+
+    def per_base_by_first_pos(self):
+        """{first PRG position of a coverage-owning node: [per-base counts]} (works for nested PRGs too)."""
+        return {int(r[2]): [int(x) for x in self.per_base_flat[r[3]:r[3] + r[4]]] for r in self.index.per_base_layout()}
+
+
+def dump_allele_sum(cov: Coverage) -> str:
+    """coverage/allele_sum_coverage text (allele_sum.cpp:45-57)."""
+    return "".join(" ".join(str(c) for c in site) + "\n" for site in cov.allele_sum_coverage)
+
+
+def dump_allele_base(cov: Coverage) -> str:
+    """coverage/allele_base_coverage.json (allele_base.cpp:49-107)."""
+    sites = ",".join("[" + ",".join("[" + ",".join(str(c) for c in al) + "]" for al in site) + "]"
+                     for site in cov.allele_base_coverage)
+    return '{"allele_base_counts":[' + sites + "]}\n"
+
+
+def dump_grouped_allele_counts(cov: Coverage) -> str:
+    """coverage/grouped_allele_counts_coverage.json (grouped_allele_counts.cpp:51-110). Group ids are labels
+    (the reference assigns them in unordered_map order); here: first appearance in site order."""
+    group_id, site_counts = {}, []
+    for site in cov.grouped_allele_counts:
+        d = {}
+        for ids in sorted(site):
+            gid = group_id.setdefault(ids, len(group_id))
+            d[gid] = site[ids]
+        site_counts.append(d)
+    groups = ",".join(f'"{g}":[' + ",".join(str(a) for a in ids) + "]" for ids, g in sorted(group_id.items(), key=lambda kv: kv[1]))
+    counts = ",".join("{" + ",".join(f'"{g}":{c}' for g, c in sorted(d.items())) + "}" for d in site_counts)
+    return '{"grouped_allele_counts":{"allele_groups":{' + groups + '},"site_counts":[' + counts + "]}}\n"
+
+
+class Quasimapper:
+    """An engine on one GPU: the index resident in HBM plus zeroed coverage accumulators."""
+
+    def __init__(self, index: Index, device: int = 0, rng_mode: int = RNG_LEMIRE, max_states: int = 0,
+                 max_path_nodes: int = 0, max_batch_reads: int = 0, forward_only: bool = False):
+        self.lib = _lib.load()
+        self.index = index
+        opts = _lib.EngineOpts()
+        self.lib.gmx_engine_default_opts(C.byref(opts))
+        opts.device = device
+        opts.rng_mode = rng_mode
+        if max_states:
+            opts.max_states = max_states
+        if max_path_nodes:
+            opts.max_path_nodes = max_path_nodes
+        if max_batch_reads:
+            opts.max_batch_reads = max_batch_reads
+        opts.forward_only = 1 if forward_only else 0
+        self.h = C.c_void_p()
+        check(self.lib.gmx_engine_create(index.h, C.byref(opts), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        check(self.lib.gmx_engine_reset(self.h))
+
+    def map_reads(self, reads_flat, offsets, seeds):
+        """Host buffers: forward + reverse-complement mapping of every read (quasimap.cpp:82-157)."""
+        r = np.ascontiguousarray(reads_flat, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if r.size == 0:
+            r = np.zeros(1, dtype=np.uint8)
+        check(self.lib.gmx_map_reads_host(self.h, _p(r, C.c_uint8), _p(o, C.c_uint64), _p(s, C.c_uint32), o.size - 1))
+
+    def map_reads_device(self, d_reads, d_offsets, d_seeds, n_reads, stream=None):
+        """Device-resident buffers (torch CUDA tensors: uint8 / int64-or-uint64 / int32-or-uint32). Asynchronous."""
+        sp = C.c_void_p(stream) if stream else None
+        check(self.lib.gmx_map_reads_device(self.h, C.c_void_p(d_reads.data_ptr()), C.c_void_p(d_offsets.data_ptr()),
+                                            C.c_void_p(d_seeds.data_ptr()), n_reads, d_reads.numel(), sp))
+
+    def sync(self):
+        check(self.lib.gmx_engine_sync(self.h))
+
+    def device_coverage(self):
+        dc = _lib.DeviceCoverage()
+        check(self.lib.gmx_coverage_device(self.h, C.byref(dc)))
+        return dc
+
+    def coverage(self) -> Coverage:
+        info = self.index.info
+        a = np.zeros(max(info.n_allele_slots, 1), dtype=np.uint32)
+        p = np.zeros(max(info.n_per_base_slots, 1), dtype=np.uint32)
+        g = np.zeros(max(info.n_grouped_slots, 1), dtype=np.uint32)
+        st = _lib.Stats()
+        check(self.lib.gmx_coverage_fetch(self.h, _p(a, C.c_uint32), _p(p, C.c_uint32), _p(g, C.c_uint32), C.byref(st)))
+        n = check(self.lib.gmx_coverage_fetch_grouped_log(self.h, None, 0))
+        log = np.zeros(max(n, 1), dtype=np.uint32)
+        if n:
+            check(self.lib.gmx_coverage_fetch_grouped_log(self.h, _p(log, C.c_uint32), n))
+        stats = QuasimapReadsStats(st.all_reads_count, st.skipped_reads_count, st.missing_kmer_reads_count,
+                                   st.no_extension_reads_count, st.exact_mapped_reads_count)
+        return Coverage(self.index, a[:info.n_allele_slots], p[:info.n_per_base_slots], g[:info.n_grouped_slots], log[:n], stats)
+
+
+def quasimap_reads(index: Index, read_files, seed: int, device: int = 0, rng_mode: int = RNG_LEMIRE) -> Coverage:
+    """quasimap_reads (quasimap.cpp:16-57) over already-parsed reads.
+
+    ``read_files``: list (one entry per reads file) of lists of read strings. Returns the Coverage, whose
+    ``stats`` member is the reference's QuasimapReadsStats."""
+    qm = Quasimapper(index, device=device, rng_mode=rng_mode)
+    seeds = master_seeds(seed, [len(f) for f in read_files])
+    enc = [encode_dna_bases(r) for f in read_files for r in f]
+    # an unencodable read stays in the batch as an empty read: it consumes its seed and is counted as skipped
+    offs = np.concatenate([[0], np.cumsum([len(e) for e in enc])]).astype(np.uint64)
+    flat = np.concatenate(enc) if enc else np.zeros(0, dtype=np.uint8)
+    qm.map_reads(flat, offs, seeds)
+    cov = qm.coverage()
+    qm.close()
+    return cov

@@ -1,0 +1,153 @@
+/* gmx.h — C ABI of the MI355X-native quasimap engine (libgmx.so).
+ *
+ * Drop-in boundary for gramtools' quasimap path. The reference has no in-process
+ * seam here: `gram genotype` calls quasimap_reads() directly
+ * (libgramtools/src/genotype/genotype.cpp:45-46). Each entry point below names the
+ * reference interface it replaces (paths relative to libgramtools/).
+ *
+ * Conventions: plain pointers and sizes; the caller owns every host buffer; the
+ * library owns device memory. Every function returns 0 on success or a negative
+ * GMX_E* code; gmx_last_error() returns the message of the calling thread's last
+ * failure. One engine = one GPU = one host thread at a time.
+ * Mapping entry points ALWAYS run on the GPU; there is no CPU fallback.
+ */
+#ifndef GMX_H
+#define GMX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMX_OK 0
+#define GMX_EINVAL (-1)   /* bad argument / inconsistent PRG (reference: std::runtime_error in PRG_String / cov_Graph_Builder) */
+#define GMX_ENODEV (-2)   /* no usable HIP device */
+#define GMX_EHIP (-3)     /* HIP runtime error */
+#define GMX_ECAP (-4)     /* a read exceeded the engine's state/path capacities (raise gmx_engine_opts) */
+#define GMX_EREF (-5)     /* a read hit a condition on which the reference throws/asserts */
+#define GMX_ENOMEM (-6)
+
+typedef struct gmx_index gmx_index;   /* host-side index: stands for PRG_Info + KmerIndex (include/prg/prg_info.hpp:22-59) */
+typedef struct gmx_engine gmx_engine; /* index resident in HBM + coverage accumulators (Coverage, coverage/types.hpp:40-46) */
+
+const char *gmx_last_error(void);
+
+/* ---- index construction (host) ------------------------------------------------
+ * Replaces load_prg_info() (src/prg/prg_info.cpp:6-29) + kmer_index::load()
+ * (src/build/kmer_index/load.cpp:161-173): everything is re-derived from the integer
+ * PRG (gram_dir/prg, little-endian uint32 per symbol) and the k-mer size. */
+int gmx_index_build(const uint32_t *prg, uint64_t n_symbols, uint32_t kmer_size, int threads, gmx_index **out);
+int gmx_index_build_from_file(const char *prg_path, uint32_t kmer_size, int threads, gmx_index **out);
+void gmx_index_destroy(gmx_index *ix);
+
+typedef struct gmx_index_info {
+  uint64_t n_text;           /* PRG length + sentinel */
+  uint32_t kmer_size;
+  uint32_t n_sites;          /* prg_info.num_variant_sites */
+  uint32_t is_nested;        /* coverage_graph.is_nested */
+  uint32_t n_allele_slots;   /* length of the flat allele-sum array */
+  uint32_t n_per_base_slots; /* length of the flat per-base array */
+  uint32_t n_grouped_slots;  /* length of the dense grouped-counts array */
+  uint32_t n_nodes;
+  uint64_t n_kmers_present;
+  uint64_t index_bytes;      /* bytes uploaded to HBM by gmx_engine_create */
+} gmx_index_info;
+int gmx_index_get_info(const gmx_index *ix, gmx_index_info *out);
+
+/* Per-site layout: for site index s (site marker 5 + 2s):
+ *   n_alleles[s], allele_sum_off[s], grouped_off[s] (0xFFFFFFFF = site uses the grouped log),
+ *   parent_site[s] (0 = level-0), parent_allele[s]. Any pointer may be NULL. */
+int gmx_index_site_layout(const gmx_index *ix, uint32_t *n_alleles, uint32_t *allele_sum_off, uint32_t *grouped_off,
+                          uint32_t *parent_site, int32_t *parent_allele);
+/* Per-base layout of non-boundary allele nodes: for each (site index, allele id, k-th sequence node of that
+ * allele) the slice [pb_off, pb_off+len). Records are (site_index, allele, first_prg_pos, pb_off, len) x n;
+ * returns the number of records; pass out == NULL to query the count. */
+int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t cap_records);
+/* allele_base_non_nested view (allele_base.cpp:10-38): for every site and allele the per-base slice of the
+ * allele's single sequence node, or len 0 for a direct deletion. Records (pb_off, len) in site-major order. */
+int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t *len);
+
+/* Introspection (tests, debugging): copies of the derived structures. */
+int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out);             /* n_text entries (fm_index[i]) */
+int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out);            /* n_text entries */
+uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base); /* dna_bwt_rank, BWT_search.cpp:8-22 */
+int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out);        /* per PRG position: node site, node allele,
+                                                                          offset in node, target marker, target allele */
+int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t cap); /* [n, {key, n_t, (id, del)*}*] */
+int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap);
+        /* k-mer index entry: [n_states, {lo, hi, n_tvd, (site, allele)*, n_tvg, (site, -1)*}*] or [-1] if absent */
+int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int64_t *out, uint64_t cap);
+        /* search_state_vBWT_jumps of a path-less state [lo, hi] (vBWT_jump.cpp:134-183), same format */
+
+/* ---- engine (device) ---------------------------------------------------------------*/
+typedef struct gmx_engine_opts {
+  int device;              /* HIP device ordinal */
+  int rng_mode;            /* 0 = libstdc++ >= 11 uniform_int_distribution (default), 1 = libstdc++ <= 10 */
+  uint32_t max_states;     /* per-read search-state capacity of the large-capacity pass (default 4096) */
+  uint32_t max_path_nodes; /* per-read path arena of the large-capacity pass (default 8192) */
+  uint64_t max_batch_reads;/* reads per internal launch (default 4M) */
+  int forward_only;        /* 1 = map only the given orientation of each read (quasimap_read, quasimap.cpp:159-194,
+                              as the reference's unit tests call it); 0 = forward + reverse complement (default) */
+} gmx_engine_opts;
+void gmx_engine_default_opts(gmx_engine_opts *opts);
+
+/* Uploads the index to HBM and allocates zeroed coverage accumulators.
+ * Replaces coverage::generate::empty_structure (coverage_common.cpp:206-213). */
+int gmx_engine_create(const gmx_index *ix, const gmx_engine_opts *opts, gmx_engine **out);
+void gmx_engine_destroy(gmx_engine *e);
+int gmx_engine_reset(gmx_engine *e); /* zero coverage + statistics */
+
+/* Quasimap a batch of reads, forward and reverse complement (replaces handle_reads_buffer +
+ * quasimap_forward_reverse + quasimap_read, quasimap.cpp:82-194).
+ *   reads   : concatenated encoded reads, one byte per base, A,C,G,T = 1,2,3,4 (encode_dna_bases,
+ *             common/utils.cpp:73-92). A read holding any other value is skipped (both orientations counted
+ *             as skipped), as is a read shorter than the k-mer size.
+ *   offsets : n_reads + 1 byte offsets into `reads`
+ *   seeds   : per-read selection seed (the i-th draw of the master generator, quasimap.cpp:136-137)
+ * The _host variant copies the buffers to the device; the _device variant takes device pointers
+ * (already resident in HBM) and enqueues on `hip_stream` (a hipStream_t, NULL = default stream)
+ * without synchronising. Coverage accumulates on the device across calls. */
+int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
+                       uint64_t n_reads);
+int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
+                         uint64_t n_reads, uint64_t total_bases, void *hip_stream);
+/* Waits for enqueued work and reports a read that overflowed / errored (GMX_ECAP, GMX_EREF). */
+int gmx_engine_sync(gmx_engine *e);
+
+/* The i-th master-generator draws for reads_per_file (quasimap.cpp:120-141: 5000 draws per batch of
+ * <= 5000 reads, one mt19937(master_seed) shared by all files). `out` receives sum(reads_per_file) seeds. */
+int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out);
+
+typedef struct gmx_stats { /* QuasimapReadsStats, quasimap.hpp:17-24 */
+  uint64_t all_reads_count;
+  uint64_t skipped_reads_count;
+  uint64_t missing_kmer_reads_count;
+  uint64_t no_extension_reads_count;
+  uint64_t exact_mapped_reads_count;
+} gmx_stats;
+
+/* Device pointers of the uint32 accumulators, for an RCCL all-reduce(sum) by the caller
+ * (one collective per array; then gmx_coverage_fetch on every rank or on rank 0). */
+typedef struct gmx_device_coverage {
+  void *allele_sum;  uint64_t n_allele_sum;
+  void *per_base;    uint64_t n_per_base;
+  void *grouped;     uint64_t n_grouped;
+  void *stats;       uint64_t n_stats;      /* 5 x uint64 */
+} gmx_device_coverage;
+int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out);
+
+/* Copies the raw uint32 totals to the host (any pointer may be NULL). The reference's uint16 semantics are
+ * functions of these totals: allele-sum and grouped counts wrap (mod 65536, data_types.hpp:52), per-base
+ * saturates at 65535 (allele_base.cpp:239). gmx_finalize_u16 applies them. */
+int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped_dense,
+                       gmx_stats *stats);
+/* Grouped counts of sites with more than 5 alleles are appended to a log of records
+ * [site_index, n_ids, ids...]; returns the number of uint32 words (copies at most cap words). */
+int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words);
+void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

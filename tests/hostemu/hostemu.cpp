@@ -1,0 +1,253 @@
+// hostemu.cpp — TEST-ONLY host build of the per-lane device logic (gmx_core.h + gmx_cover.h).
+//
+// The HIP kernels in gramtools_amd/csrc/gmx_engine.hip run these headers one lane per task. There is no
+// GPU in the build container, so this file drives the SAME headers sequentially on the host with the same
+// capacities, letting `-m "not gpu"` tests check the search/selection/recording logic against the oracle
+// before GPU time is spent. It is never linked into libgmx.so and the product never loads it.
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../gramtools_amd/csrc/gmx_core.h"
+#include "../../gramtools_amd/csrc/gmx_cover.h"
+#include "../../gramtools_amd/csrc/gmx_index.h"
+
+namespace {
+
+struct EmuCtx {
+  std::vector<GmxFinalState> st;
+  uint32_t n = 0, cap;
+  std::vector<GmxPathNode> arena;
+  uint32_t arena_cap;
+  uint32_t status = GMX_TASK_MAPPED;
+  EmuCtx(uint32_t c, uint32_t ac) : st(c), cap(c), arena_cap(ac) {}
+  uint32_t n_states() const { return n; }
+  void set_n_states(uint32_t v) { n = v; }
+  void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
+    lo = st[s].lo; hi = st[s].hi; tvd = st[s].traversed; tvg = st[s].traversing;
+  }
+  void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { st[s] = GmxFinalState{lo, hi, tvd, tvg}; }
+  bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n >= cap) return false;
+    put(n++, lo, hi, tvd, tvg);
+    return true;
+  }
+  uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    if (arena.size() >= arena_cap) return GMX_NIL;
+    arena.push_back(GmxPathNode{site, allele, next});
+    return (uint32_t)arena.size() - 1;
+  }
+  uint32_t arena_site(uint32_t node) const { return arena[node].site; }
+  uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+struct Emu {
+  gmx::HostIndex h;
+  std::vector<uint32_t> allele_sum, per_base, grouped, log;
+  uint64_t stats[5] = {0, 0, 0, 0, 0};
+  int rng_mode = 0;
+  uint32_t first_error = 0, error_task = 0;
+  uint64_t n_overflow_tasks = 0, n_cover_overflow = 0;
+  std::string err;
+};
+
+template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
+struct EmuEnvT {
+  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
+  std::vector<uint32_t> scratch;
+  const GmxPathNode *arena;
+  Emu *e;
+  uint32_t status = GMX_TASK_MAPPED;
+  EmuEnvT() : scratch(GmxScratch<EmuEnvT>::total, 0xDEADBEEFu) {}
+  uint32_t sget(uint32_t w) const { return scratch.at(w); }
+  void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
+  void add_allele_sum(uint32_t s) { e->allele_sum.at(s)++; }
+  void add_per_base(uint32_t s) { e->per_base.at(s)++; }
+  void add_grouped_dense(uint32_t s) { e->grouped.at(s)++; }
+  bool log_grouped_begin(uint32_t site, uint32_t n) {
+    e->log.push_back(site);
+    e->log.push_back(n);
+    return true;
+  }
+  void log_grouped_id(int32_t a) { e->log.push_back((uint32_t)a); }
+  void log_grouped_end() {}
+  void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+typedef EmuEnvT<32, 8, 64, 64> EmuEnv;            // same capacities as CoverEnv / CoverEnvBig in gmx_engine.hip
+typedef EmuEnvT<1024, 32, 1024, 1024> EmuEnvBig;
+
+struct Read {
+  const uint8_t *p;
+  uint32_t len;
+  bool rc;
+  uint32_t at(uint32_t i) const { return rc ? 5u - p[len - 1 - i] : p[i]; }
+};
+
+uint32_t kmer_code(const Read &r, uint32_t start, uint32_t k) {
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < k; ++j) c = (c << 2) | (r.at(start + j) - 1u);
+  return c;
+}
+
+bool all_kmers_present(const GmxIndexView &ix, const Read &r) {
+  uint32_t k = ix.kmer_size;
+  for (uint32_t o = 0; o + k <= r.len; ++o) {
+    uint32_t code = kmer_code(r, o, k);
+    if (!((ix.kmer_bitmap[code >> 5] >> (code & 31)) & 1u)) return false;
+  }
+  return true;
+}
+
+void load_seed(const GmxIndexView &ix, uint32_t code, EmuCtx &ctx) {
+  GmxSeed s = ix.seeds[code];
+  if (s.a != GMX_SEED_COMPLEX) {
+    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL);
+    return;
+  }
+  const uint32_t *p = ix.seed_words + s.b;
+  uint32_t ns = *p++;
+  for (uint32_t i = 0; i < ns; ++i) {
+    uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+    p += 4;
+    uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
+    bool ok = true;
+    for (uint32_t j = 0; j < nt; ++j, p += 2) {
+      if (!ok) continue;
+      uint32_t nn = ctx.arena_new(p[0], (int32_t)p[1], tvd);
+      if (nn == GMX_NIL) ok = false; else tvd = nn;
+    }
+    for (uint32_t j = 0; j < ng; ++j, ++p) {
+      if (!ok) continue;
+      uint32_t nn = ctx.arena_new(p[0], -1, tvg);
+      if (nn == GMX_NIL) ok = false; else tvg = nn;
+    }
+    if (!ok || !ctx.push(lo, hi, tvd, tvg)) {
+      ctx.fail(GMX_TASK_OVERFLOW);
+      return;
+    }
+  }
+}
+
+void search_task(const GmxIndexView &ix, const Read &r, EmuCtx &ctx) {
+  uint32_t k = ix.kmer_size;
+  load_seed(ix, kmer_code(r, r.len - k, k), ctx);
+  if (ctx.status != GMX_TASK_MAPPED) return;
+  for (uint32_t i = r.len - k; i-- > 0;) {
+    if (ctx.n_states() == 0) break;
+    gmx_extend(ix, r.at(i), ctx);
+    if (ctx.status != GMX_TASK_MAPPED) return;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void *hostemu_create(const uint32_t *prg, uint64_t n, uint32_t k, int rng_mode, char *err, uint64_t errcap) {
+  try {
+    Emu *e = new Emu();
+    gmx::build_index(std::vector<uint32_t>(prg, prg + n), k, e->h, 1);
+    e->allele_sum.assign(e->h.n_allele_slots, 0);
+    e->per_base.assign(e->h.n_pb_slots, 0);
+    e->grouped.assign(e->h.n_grouped_slots, 0);
+    e->rng_mode = rng_mode;
+    return e;
+  } catch (std::exception const &ex) {
+    if (err && errcap) {
+      strncpy(err, ex.what(), errcap - 1);
+      err[errcap - 1] = 0;
+    }
+    return nullptr;
+  }
+}
+void hostemu_destroy(void *p) { delete (Emu *)p; }
+
+// Same two-tier flow as launch_batch(): fast pass (4 states / 24 arena nodes), large-capacity pass, cover, stats.
+int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads,
+                uint32_t fast_states, uint32_t fast_arena, uint32_t big_states, uint32_t big_arena) {
+  Emu *e = (Emu *)p;
+  GmxIndexView ix = e->h.view();
+  for (uint64_t read = 0; read < n_reads; ++read) {
+    uint32_t len = (uint32_t)(offsets[read + 1] - offsets[read]);
+    bool bad = false;
+    for (uint32_t i = 0; i < len; ++i) {
+      uint8_t v = reads[offsets[read] + i];
+      if (v < 1 || v > 4) bad = true;
+    }
+    for (int o = 0; o < 2; ++o) {
+      e->stats[0]++;
+      if (bad || len < ix.kmer_size || len == 0) {
+        e->stats[1]++;
+        continue;
+      }
+      Read r{reads + offsets[read], len, o == 1};
+      EmuCtx ctx(fast_states, fast_arena);
+      search_task(ix, r, ctx);
+      EmuCtx big(big_states, big_arena);
+      EmuCtx *use = &ctx;
+      if (ctx.status == GMX_TASK_OVERFLOW) {
+        e->n_overflow_tasks++;
+        search_task(ix, r, big);
+        use = &big;
+      }
+      if (use->status != GMX_TASK_MAPPED) {
+        if (!e->first_error) {
+          e->first_error = use->status;
+          e->error_task = (uint32_t)(read * 2 + o);
+        }
+        continue;
+      }
+      if (use->n == 0) {
+        if (all_kmers_present(ix, r)) e->stats[3]++; else e->stats[2]++;
+        continue;
+      }
+      e->stats[4]++;
+      EmuEnv env;
+      env.arena = use->arena.data();
+      env.e = e;
+      gmx_cover_task(ix, env, use->st.data(), use->n, len, seeds[read], e->rng_mode);
+      uint32_t cstatus = env.status;
+      if (cstatus == GMX_TASK_OVERFLOW) {  // nothing recorded yet: redo with the large scratch
+        e->n_cover_overflow++;
+        EmuEnvBig big_env;
+        big_env.arena = use->arena.data();
+        big_env.e = e;
+        gmx_cover_task(ix, big_env, use->st.data(), use->n, len, seeds[read], e->rng_mode);
+        cstatus = big_env.status;
+      }
+      if (cstatus != GMX_TASK_MAPPED && !e->first_error) {
+        e->first_error = cstatus;
+        e->error_task = (uint32_t)(read * 2 + o);
+      }
+    }
+  }
+  return e->first_error ? -(int)e->first_error : 0;
+}
+
+void hostemu_sizes(void *p, uint64_t *out) {
+  Emu *e = (Emu *)p;
+  out[0] = e->allele_sum.size();
+  out[1] = e->per_base.size();
+  out[2] = e->grouped.size();
+  out[3] = e->log.size();
+  out[4] = e->n_overflow_tasks;
+  out[5] = e->n_cover_overflow;
+}
+void hostemu_fetch(void *p, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, uint32_t *log, uint64_t *stats) {
+  Emu *e = (Emu *)p;
+  memcpy(allele_sum, e->allele_sum.data(), e->allele_sum.size() * 4);
+  memcpy(per_base, e->per_base.data(), e->per_base.size() * 4);
+  memcpy(grouped, e->grouped.data(), e->grouped.size() * 4);
+  memcpy(log, e->log.data(), e->log.size() * 4);
+  memcpy(stats, e->stats, sizeof(e->stats));
+}
+
+}  // extern "C"
