@@ -28,6 +28,11 @@ class Stats(C.Structure):
                 ("exact_mapped_reads_count", C.c_uint64)]
 
 
+class Timing(C.Structure):
+    _fields_ = [("search_ms", C.c_double), ("search_launches", C.c_uint64), ("cover_ms", C.c_double),
+                ("cover_launches", C.c_uint64), ("reads", C.c_uint64)]
+
+
 class DeviceCoverage(C.Structure):
     _fields_ = [("allele_sum", C.c_void_p), ("n_allele_sum", C.c_uint64), ("per_base", C.c_void_p),
                 ("n_per_base", C.c_uint64), ("grouped", C.c_void_p), ("n_grouped", C.c_uint64),
@@ -61,6 +66,8 @@ SYMBOLS = {
     "gmx_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
     "gmx_map_reads_device": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
     "gmx_engine_sync": (C.c_int, [_vp]),
+    "gmx_engine_enable_timing": (C.c_int, [_vp, C.c_int]),
+    "gmx_engine_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "gmx_master_seeds": (C.c_int, [_u32, _u64p, _u64, _u32p]),
     "gmx_coverage_device": (C.c_int, [_vp, C.POINTER(DeviceCoverage)]),
     "gmx_coverage_fetch": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(Stats)]),

@@ -490,6 +490,12 @@ struct gmx_engine {
   uint32_t *d_seeds = nullptr;
   uint64_t cap_bases = 0, cap_stage_reads = 0;
   hipStream_t last_stream = nullptr;
+  // optional HIP-event timing of the kernels (bench.py roofline leg)
+  bool timing = false;
+  struct EvTriple { hipEvent_t a, b, c; uint64_t reads; };
+  std::vector<EvTriple> pending;
+  double search_ms = 0, cover_ms = 0;
+  uint64_t search_launches = 0, cover_launches = 0, timed_reads = 0;
 
   template <class T>
   int alloc(T **p, size_t count, bool zero) {
@@ -656,8 +662,17 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL(gmx_validate_kernel, dim3((n_reads + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream, b,
                      e->d_skip);
   size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
+  gmx_engine::EvTriple ev{};
+  if (e->timing) {
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventCreate(&ev.c));
+    ev.reads = n_reads;
+    HIP_TRY(hipEventRecord(ev.a, stream));
+  }
   hipLaunchKernelGGL(gmx_search_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), lds, stream,
                      e->dview, b, o);
+  if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, stream, e->dview, b, o, e->big);
   CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
                e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
@@ -667,6 +682,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
                      b, o, e->big, acc);
   hipLaunchKernelGGL(gmx_stats_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream,
                      e->d_status, n_tasks, e->d_stats);
+  if (e->timing) {
+    HIP_TRY(hipEventRecord(ev.c, stream));
+    e->pending.push_back(ev);
+  }
   HIP_TRY(hipGetLastError());
   e->last_stream = stream;
   return GMX_OK;
@@ -760,6 +779,38 @@ int gmx_engine_sync(gmx_engine *e) {
     gmx_set_error(msg);
     return GMX_EREF;
   }
+  return GMX_OK;
+}
+
+int gmx_engine_enable_timing(gmx_engine *e, int on) {
+  e->timing = on != 0;
+  return GMX_OK;
+}
+
+int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  for (auto &ev : e->pending) {
+    HIP_TRY(hipEventSynchronize(ev.c));
+    float ms1 = 0, ms2 = 0;
+    HIP_TRY(hipEventElapsedTime(&ms1, ev.a, ev.b));
+    HIP_TRY(hipEventElapsedTime(&ms2, ev.b, ev.c));
+    e->search_ms += ms1;
+    e->cover_ms += ms2;
+    e->search_launches++;
+    e->cover_launches++;
+    e->timed_reads += ev.reads;
+    (void)hipEventDestroy(ev.a);
+    (void)hipEventDestroy(ev.b);
+    (void)hipEventDestroy(ev.c);
+  }
+  e->pending.clear();
+  out->search_ms = e->search_ms;
+  out->search_launches = e->search_launches;
+  out->cover_ms = e->cover_ms;
+  out->cover_launches = e->cover_launches;
+  out->reads = e->timed_reads;
+  e->search_ms = e->cover_ms = 0;
+  e->search_launches = e->cover_launches = e->timed_reads = 0;
   return GMX_OK;
 }
 

@@ -317,6 +317,16 @@ class Quasimapper:
     def sync(self):
         check(self.lib.gmx_engine_sync(self.h))
 
+    def enable_timing(self, on=True):
+        check(self.lib.gmx_engine_enable_timing(self.h, 1 if on else 0))
+
+    def timing(self):
+        """HIP-event time of the kernels since the last call: dict(search_ms, search_launches, cover_ms, ..., reads)."""
+        t = _lib.Timing()
+        check(self.lib.gmx_engine_timing(self.h, C.byref(t)))
+        return dict(search_ms=t.search_ms, search_launches=t.search_launches, cover_ms=t.cover_ms,
+                    cover_launches=t.cover_launches, reads=t.reads)
+
     def device_coverage(self):
         dc = _lib.DeviceCoverage()
         check(self.lib.gmx_coverage_device(self.h, C.byref(dc)))

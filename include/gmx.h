@@ -115,6 +115,18 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
 /* Waits for enqueued work and reports a read that overflowed / errored (GMX_ECAP, GMX_EREF). */
 int gmx_engine_sync(gmx_engine *e);
 
+/* Kernel timing with HIP events recorded on the launch stream (bench.py's roofline leg). After
+ * gmx_engine_enable_timing(e, 1) every internal launch of the search and coverage kernels is bracketed by events;
+ * gmx_engine_timing() (call after gmx_engine_sync) returns the accumulated milliseconds and launch counts since
+ * the last call and resets them. */
+int gmx_engine_enable_timing(gmx_engine *e, int on);
+typedef struct gmx_timing {
+  double search_ms;  uint64_t search_launches;   /* gmx_search_kernel (the dominant kernel) */
+  double cover_ms;   uint64_t cover_launches;    /* big-pass search + both coverage kernels + stats */
+  uint64_t reads;                                /* reads covered by those launches */
+} gmx_timing;
+int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
+
 /* The i-th master-generator draws for reads_per_file (quasimap.cpp:120-141: 5000 draws per batch of
  * <= 5000 reads, one mt19937(master_seed) shared by all files). `out` receives sum(reads_per_file) seeds. */
 int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out);

@@ -1,0 +1,186 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+from common import oracle_map, canonical_cov, flatten_reads
+from golden_runner import all_cases, prg_ints, seq, grouped_key
+from gramtools_amd import Index, Quasimapper, master_seeds
+from gramtools_amd.synth import (nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, snp_prg,
+                                 simulate_snp_reads, flat_offsets)
+
+pytestmark = pytest.mark.gpu
+
+GPU_OPS = {"quasimap_read", "map_reads", "expect_allele_sum", "expect_allele_base", "expect_grouped", "expect_node_cov",
+           "expect_stats"}
+
+
+def _gpu_cases():
+    out = []
+    for f, c in all_cases():
+        kinds = {op["op"] for op in c["ops"]}
+        if c.get("expect_build_error") or not kinds or not kinds <= GPU_OPS:
+            continue
+        out.append((f, c))
+    return out
+
+
+CASES = _gpu_cases()
+
+
+@pytest.mark.parametrize("fname,case", CASES, ids=[f"{f}:{c['name']}" for f, c in CASES])
+def test_golden_vectors_on_gpu(fname, case):
+    """Every coverage-level known answer of the reference's tests, mapped by the HIP kernels."""
+    ints = prg_ints(case["prg"])
+    ix = Index(ints, case["k"])
+    fwd = Quasimapper(ix, forward_only=True)   # quasimap_read (one orientation), as the reference's unit tests call it
+    both = Quasimapper(ix)                      # quasimap_forward_reverse, as `gram genotype` runs it
+    used = None
+    for op in case["ops"]:
+        kind = op["op"]
+        if kind == "quasimap_read":
+            r = seq(op["read"])
+            fwd.map_reads(r, np.array([0, len(r)], dtype=np.uint64), np.array([op.get("seed", 42)], dtype=np.uint32))
+            used = fwd
+        elif kind == "map_reads":
+            reads = [seq(r) for r in op["reads"]]
+            flat, offs = flatten_reads(reads)
+            both.map_reads(flat, offs, master_seeds(op["master_seed"], [len(reads)]))
+            used = both
+        else:
+            cov = used.coverage()
+            if kind == "expect_allele_sum":
+                assert cov.allele_sum_coverage == op["value"]
+            elif kind == "expect_allele_base":
+                assert cov.allele_base_coverage == op["value"]
+            elif kind == "expect_grouped":
+                assert [grouped_key(d) for d in cov.grouped_allele_counts] == op["value"]
+            elif kind == "expect_node_cov":
+                pb = cov.per_base_by_first_pos()
+                pi = ix.pos_info()
+                got = []
+                for p in op["positions"]:
+                    first = p - int(pi[p][2])
+                    got.append(pb.get(first, []))
+                assert got == op["value"]
+            elif kind == "expect_stats":
+                s = cov.stats.as_dict()
+                for key, v in op["value"].items():
+                    assert s[key] == v
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    s = nested_prg(seed, n_top=int(rng.integers(1, 6)), max_depth=int(rng.integers(1, 4)), seq_max=int(rng.integers(1, 7)))
+    if seed % 3 == 0:
+        s = s.replace("t", "a").replace("g", "c")
+    prg = bracket_to_ints(s)
+    L, k = int(rng.integers(4, 25)), int(rng.integers(1, 5))
+    reads = simulate_graph_reads(prg, 60, L, seed + 100)
+    reads += [rng.integers(1, 5, size=L).astype(np.uint8) for _ in range(6)]
+    reads.append(np.array([1, 2, 0, 3] * 3, dtype=np.uint8))
+    reads.append(np.zeros(0, dtype=np.uint8))
+    reads = [r for r in reads if len(r) >= k or len(r) == 0]
+    seeds = rng.integers(0, 2 ** 32, size=len(reads), dtype=np.uint64).astype(np.uint32)
+    return prg, k, reads, seeds
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_nested_prgs_match_oracle(seed):
+    prg, k, reads, seeds = _random_case(seed)
+    mode = seed % 2
+    want = oracle_map(prg, k, reads, seeds, rng_mode=mode)
+    qm = Quasimapper(Index(prg, k), rng_mode=mode)
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+
+
+def _snp_workload(G, n_sites, n_reads, seed, multi=0.0):
+    ref = random_ref(G, seed)
+    prg, pos, alts, n_alts = snp_prg(ref, n_sites, seed + 1, multi_allelic_frac=multi)
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, n_reads, 150, seed + 2)
+    return prg, reads
+
+
+def test_config1_1kb_10snps_10k_reads():
+    """BASELINE.json configs[0]: 1 kb ref + 10 SNPs, 10k x 150 bp, k = 5, --seed 42."""
+    prg, reads = _snp_workload(1000, 10, 10000, 1)
+    seeds = master_seeds(42, [10000])
+    offs = flat_offsets(10000, 150)
+    want = oracle_map(prg, 5, list(reads), seeds, threads=8)
+    qm = Quasimapper(Index(prg, 5))
+    qm.map_reads(reads.reshape(-1), offs, seeds)
+    got = canonical_cov(qm.coverage())
+    assert got == want
+    assert got["stats"]["exact_mapped"] >= 10000
+
+
+def test_mtb_like_sample_matches_oracle():
+    """A 200 kb slice of the configs[1] recipe (SNP every ~73 bp, k = 10), 20k reads, oracle-checked."""
+    prg, reads = _snp_workload(200000, 2700, 20000, 5, multi=0.05)
+    seeds = master_seeds(7, [20000])
+    offs = flat_offsets(20000, 150)
+    want = oracle_map(prg, 10, list(reads), seeds, threads=8)
+    qm = Quasimapper(Index(prg, 10))
+    qm.map_reads(reads.reshape(-1), offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+
+
+def test_batching_and_accumulation_are_equivalent():
+    """Coverage is additive over calls and independent of the internal batch size (size-independent property)."""
+    prg, reads = _snp_workload(50000, 600, 6000, 9)
+    seeds = master_seeds(3, [6000])
+    offs = flat_offsets(6000, 150)
+    ix = Index(prg, 8)
+    a = Quasimapper(ix)
+    a.map_reads(reads.reshape(-1), offs, seeds)
+    b = Quasimapper(ix, max_batch_reads=1000)
+    b.map_reads(reads[:2500].reshape(-1), flat_offsets(2500, 150), seeds[:2500])
+    b.map_reads(reads[2500:].reshape(-1), flat_offsets(3500, 150), seeds[2500:])
+    assert canonical_cov(a.coverage()) == canonical_cov(b.coverage())
+
+
+def test_device_resident_entry_point_matches_host_entry_point():
+    import torch
+    prg, reads = _snp_workload(50000, 600, 4000, 21)
+    seeds = master_seeds(5, [4000])
+    offs = flat_offsets(4000, 150)
+    ix = Index(prg, 8)
+    a = Quasimapper(ix)
+    a.map_reads(reads.reshape(-1), offs, seeds)
+    b = Quasimapper(ix)
+    d_reads = torch.from_numpy(reads.reshape(-1).copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(torch.int32).cuda()
+    b.map_reads_device(d_reads, d_offs, d_seeds, 4000)
+    b.sync()
+    assert canonical_cov(a.coverage()) == canonical_cov(b.coverage())
+
+
+def test_full_size_properties_mtb_scale():
+    """configs[1] scale (4.4 Mb, 60k SNPs, k = 10): too large for the oracle in seconds, so check
+    size-independent properties: every error-free read maps exactly once per read (one orientation),
+    reversing every read's strand leaves coverage unchanged, and a checksum-of-checksums over batches."""
+    prg, reads = _snp_workload(4411532, 60000, 200000, 101)
+    n = reads.shape[0]
+    seeds = master_seeds(42, [n])
+    offs = flat_offsets(n, 150)
+    ix = Index(prg, 10)
+    a = Quasimapper(ix)
+    a.map_reads(reads.reshape(-1), offs, seeds)
+    ca = a.coverage()
+    st = ca.stats.as_dict()
+    assert st["all"] == 2 * n and st["skipped"] == 0
+    assert st["exact_mapped"] >= n            # each read maps in its own orientation (plus rare palindromic hits)
+    assert st["exact_mapped"] + st["missing_kmer"] + st["no_extension"] == 2 * n
+    # strand symmetry: mapping the reverse complements gives identical coverage
+    rc = np.ascontiguousarray((5 - reads)[:, ::-1])
+    b = Quasimapper(ix)
+    b.map_reads(rc.reshape(-1), offs, seeds)
+    cb = b.coverage()
+    assert (ca.raw_allele_sum == cb.raw_allele_sum).all()
+    assert (ca.raw_per_base == cb.raw_per_base).all()
+    assert (ca.raw_grouped == cb.raw_grouped).all()
+    # every mapped read crossing a site adds exactly one grouped count per level-0 site it covers, and
+    # allele-sum totals dominate grouped totals (a group holds >= 1 allele)
+    assert int(ca.raw_allele_sum.sum()) >= int(ca.raw_grouped.sum()) > 0

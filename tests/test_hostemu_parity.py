@@ -1,0 +1,45 @@
+"""The per-lane device logic (gmx_core.h + gmx_cover.h), run sequentially on the host by the TEST-ONLY
+build tests/hostemu, must reproduce the oracle's coverage bit for bit — including the overflow tiers."""
+import numpy as np
+import pytest
+
+from common import oracle_map, hostemu_map
+from gramtools_amd.synth import nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, snp_prg, simulate_snp_reads
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    s = nested_prg(seed, n_top=int(rng.integers(1, 6)), max_depth=int(rng.integers(1, 4)), seq_max=int(rng.integers(1, 7)))
+    if seed % 3 == 0:  # low-complexity PRGs: repeats, multi-mapping, seeded selection
+        s = s.replace("t", "a").replace("g", "c")
+    prg = bracket_to_ints(s)
+    L, k = int(rng.integers(4, 25)), int(rng.integers(1, 5))
+    reads = simulate_graph_reads(prg, 40, L, seed + 100)
+    reads += [rng.integers(1, 5, size=L).astype(np.uint8) for _ in range(5)]
+    reads.append(np.array([1, 2, 0, 3] * 3, dtype=np.uint8))  # non-ACGT symbol -> skipped
+    reads.append(np.zeros(0, dtype=np.uint8))                   # empty read -> skipped
+    reads = [r for r in reads if len(r) >= k or len(r) == 0]
+    seeds = rng.integers(0, 2 ** 32, size=len(reads), dtype=np.uint64).astype(np.uint32)
+    return prg, k, reads, seeds
+
+
+@pytest.mark.parametrize("seed", range(90))
+def test_device_logic_matches_oracle(seed):
+    prg, k, reads, seeds = _case(seed)
+    mode = seed % 2
+    want = oracle_map(prg, k, reads, seeds, rng_mode=mode)
+    caps = dict(fast_states=1, fast_arena=2) if seed % 5 == 0 else {}
+    got, _, rc = hostemu_map(prg, k, reads, seeds, rng_mode=mode, **caps)
+    assert rc == 0
+    assert got == want
+
+
+def test_device_logic_on_snp_prg_150bp():
+    ref = random_ref(6000, 11)
+    prg, pos, alts, n_alts = snp_prg(ref, 80, 12, multi_allelic_frac=0.2)
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, 300, 150, 13)
+    seeds = np.arange(300, dtype=np.uint32) * 7919
+    want = oracle_map(prg, 7, list(reads), seeds)
+    got, _, rc = hostemu_map(prg, 7, list(reads), seeds)
+    assert rc == 0 and got == want
+    assert want["stats"]["exact_mapped"] == 300
