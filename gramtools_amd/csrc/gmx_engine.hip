@@ -30,7 +30,7 @@
 #include "gmx_internal.h"
 
 #define GMX_BLOCK 256
-#define GMX_FAST_STATES 4     // LDS state slots per lane
+#define GMX_FAST_STATES 8     // LDS state slots per lane (k-mer seeds of short k carry several states)
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
@@ -606,7 +606,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
-  e->big.max_slots = 16384;
+  e->big.max_slots = 65536;
   rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
   rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
   rc |= e->alloc(&e->big.n_final, e->big.max_slots, false);

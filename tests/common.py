@@ -68,7 +68,7 @@ def _load_emu():
     return lib
 
 
-def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=4, fast_arena=24, big_states=1024, big_arena=2048):
+def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048):
     """Runs the device headers on the host. Returns (canonical coverage, n_overflow_tasks, rc)."""
     lib = _load_emu()
     arr = np.ascontiguousarray(prg, dtype=np.uint32)

@@ -31,7 +31,7 @@ CASES = _gpu_cases()
 def test_golden_vectors_on_gpu(fname, case):
     """Every coverage-level known answer of the reference's tests, mapped by the HIP kernels."""
     ints = prg_ints(case["prg"])
-    ix = Index(ints, case["k"])
+    ix = Index(ints, case["k"] or 1)  # structure-only vectors carry k = 0; the engine needs a seed table
     fwd = Quasimapper(ix, forward_only=True)   # quasimap_read (one orientation), as the reference's unit tests call it
     both = Quasimapper(ix)                      # quasimap_forward_reverse, as `gram genotype` runs it
     used = None
