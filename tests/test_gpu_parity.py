@@ -34,7 +34,7 @@ def test_golden_vectors_on_gpu(fname, case):
     ix = Index(ints, case["k"] or 1)  # structure-only vectors carry k = 0; the engine needs a seed table
     fwd = Quasimapper(ix, forward_only=True)   # quasimap_read (one orientation), as the reference's unit tests call it
     both = Quasimapper(ix)                      # quasimap_forward_reverse, as `gram genotype` runs it
-    used = None
+    used = fwd
     for op in case["ops"]:
         kind = op["op"]
         if kind == "quasimap_read":
