@@ -40,8 +40,10 @@ GMX_HD void gmx_match_words(const GmxRankBlock &b, uint32_t c, uint64_t &w0, uin
 
 // count of base c in BWT[0, 128*b): cnt[] holds A(raw), C, G, M; T is derived
 GMX_HD uint32_t gmx_block_base_count(const GmxRankBlock &b, uint32_t blk, uint32_t c) {
-  if (c <= 3) return b.cnt[c - 1];
-  return (blk << GMX_BLK_SHIFT) - b.cnt[0] - b.cnt[1] - b.cnt[2] - b.cnt[3];
+  // selects, not b.cnt[c - 1]: a runtime index would force the register copy of the block into scratch memory
+  uint32_t a = b.cnt[0], cc = b.cnt[1], g = b.cnt[2];
+  uint32_t t = (blk << GMX_BLK_SHIFT) - a - cc - g - b.cnt[3];
+  return c == 1 ? a : (c == 2 ? cc : (c == 3 ? g : t));
 }
 
 // rank_c(i) = number of base c in BWT[0, i)  (dna_bwt_rank, BWT_search.cpp:8-22). Host/index-build use.

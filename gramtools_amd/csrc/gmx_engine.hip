@@ -420,36 +420,75 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   }
 }
 
-// QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191)
+// QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
+// Grid-stride over the task statuses, per-thread tallies, one LDS reduction and five atomics per block.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *status, uint32_t n_tasks,
                                                               unsigned long long *stats) {
-  uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
-  uint32_t s = task < n_tasks ? status[task] : 0xFFFFFFFFu;
-  unsigned long long m_skip = __ballot(s == GMX_TASK_SKIPPED);
-  unsigned long long m_miss = __ballot(s == GMX_STATUS_MISSING_KMER);
-  unsigned long long m_noext = __ballot(s == GMX_TASK_UNMAPPED);
-  unsigned long long m_map = __ballot(s == GMX_TASK_MAPPED);
-  unsigned long long m_all = __ballot(task < n_tasks && s != GMX_STATUS_IGNORED);
-  if ((threadIdx.x & 63) == 0) {
-    if (m_all) atomicAdd(&stats[0], (unsigned long long)__popcll(m_all));
-    if (m_skip) atomicAdd(&stats[1], (unsigned long long)__popcll(m_skip));
-    if (m_miss) atomicAdd(&stats[2], (unsigned long long)__popcll(m_miss));
-    if (m_noext) atomicAdd(&stats[3], (unsigned long long)__popcll(m_noext));
-    if (m_map) atomicAdd(&stats[4], (unsigned long long)__popcll(m_map));
+  __shared__ uint32_t acc[5];
+  if (threadIdx.x < 5) acc[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t c_all = 0, c_skip = 0, c_miss = 0, c_noext = 0, c_map = 0;
+  for (uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x; task < n_tasks; task += gridDim.x * GMX_BLOCK) {
+    uint32_t s = status[task];
+    c_all += s != GMX_STATUS_IGNORED;
+    c_skip += s == GMX_TASK_SKIPPED;
+    c_miss += s == GMX_STATUS_MISSING_KMER;
+    c_noext += s == GMX_TASK_UNMAPPED;
+    c_map += s == GMX_TASK_MAPPED;
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    c_all += __shfl_down(c_all, off);
+    c_skip += __shfl_down(c_skip, off);
+    c_miss += __shfl_down(c_miss, off);
+    c_noext += __shfl_down(c_noext, off);
+    c_map += __shfl_down(c_map, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&acc[0], c_all);
+    atomicAdd(&acc[1], c_skip);
+    atomicAdd(&acc[2], c_miss);
+    atomicAdd(&acc[3], c_noext);
+    atomicAdd(&acc[4], c_map);
+  }
+  __syncthreads();
+  if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
-// reads holding a byte outside 1..4 are skipped as a whole (encode_dna_bases, utils.cpp:73-92)
+// Reads holding a byte outside 1..4 are skipped as a whole (encode_dna_bases, utils.cpp:73-92).
+// Coalesced: each lane checks 16 consecutive bytes of the concatenated buffer; the (rare) offender looks up
+// its read by binary search over the offsets.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_validate_kernel(BatchView b, uint8_t *skip) {
-  uint32_t read = blockIdx.x * GMX_BLOCK + threadIdx.x;
-  if (read >= b.n_reads) return;
-  uint64_t s = b.offsets[read], e = b.offsets[read + 1];
-  uint8_t bad = 0;
-  for (uint64_t i = s; i < e; ++i) {
-    uint8_t v = b.reads[i];
-    if (v < 1 || v > 4) bad = 1;
+  uint64_t begin = b.offsets[0], end = b.offsets[b.n_reads];
+  uint64_t base = (begin & ~15ull) + ((uint64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * 16ull;
+  if (base >= end) return;
+  uint32_t bad_mask = 0;
+  if (base >= begin && base + 16 <= end && (((uintptr_t)(b.reads + base)) & 15) == 0) {
+    uint4 v = *reinterpret_cast<const uint4 *>(b.reads + base);
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // a byte is valid iff 1 <= x <= 4  <=>  (x - 1) < 4 : test bits 2..7 of (x - 1) per byte, and no borrow
+      uint32_t x = w[j];
+      uint32_t zero = (x - 0x01010101u) & ~x & 0x80808080u;  // bytes equal to 0
+      uint32_t big = ((x - 0x01010101u) & 0xFCFCFCFCu);      // (x-1) >= 4 for some byte (valid when no byte is 0)
+      if (zero | big) bad_mask |= 1u << j;
+    }
+  } else {
+    bad_mask = 0xF;  // ragged edge: fall through to the byte loop
   }
-  skip[read] = bad;
+  if (!bad_mask) return;
+  for (uint32_t j = 0; j < 16; ++j) {
+    uint64_t p = base + j;
+    if (p < begin || p >= end) continue;
+    uint8_t x = b.reads[p];
+    if (x >= 1 && x <= 4) continue;
+    uint32_t lo = 0, hi = b.n_reads;  // last read with offsets[r] <= p
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (b.offsets[mid] <= p) lo = mid; else hi = mid;
+    }
+    skip[lo] = 1;
+  }
 }
 
 // ===========================================================================
@@ -645,7 +684,7 @@ int gmx_engine_reset(gmx_engine *e) {
 }
 
 static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
-                        uint64_t n_reads, hipStream_t stream) {
+                        uint64_t n_reads, uint64_t total_bases, hipStream_t stream) {
   if (n_reads == 0) return GMX_OK;
   if (n_reads > 0x3fffffffull) {
     gmx_set_error("batch too large");
@@ -659,8 +698,12 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8, stream));
   HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 4, stream));
-  hipLaunchKernelGGL(gmx_validate_kernel, dim3((n_reads + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream, b,
-                     e->d_skip);
+  HIP_TRY(hipMemsetAsync(e->d_skip, 0, n_reads, stream));
+  {
+    uint64_t chunks = (total_bases + 15) / 16 + 2;
+    hipLaunchKernelGGL(gmx_validate_kernel, dim3((unsigned)((chunks + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0,
+                       stream, b, e->d_skip);
+  }
   size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
@@ -680,8 +723,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
                      o, e->big, acc);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, true>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
                      b, o, e->big, acc);
-  hipLaunchKernelGGL(gmx_stats_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), 0, stream,
-                     e->d_status, n_tasks, e->d_stats);
+  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK, 1024u)),
+                     dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
     e->pending.push_back(ev);
@@ -693,7 +736,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
 
 int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                          uint64_t n_reads, uint64_t total_bases, void *hip_stream) {
-  (void)total_bases;
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -703,7 +745,7 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
   uint64_t done = 0;
   while (done < n_reads) {
     uint64_t n = std::min<uint64_t>(e->opts.max_batch_reads, n_reads - done);
-    int rc = launch_batch(e, d_reads, d_offsets + done, d_seeds + done, n, stream);
+    int rc = launch_batch(e, d_reads, d_offsets + done, d_seeds + done, n, total_bases, stream);
     if (rc) return rc;
     done += n;
   }
@@ -742,7 +784,7 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
     HIP_TRY(hipMemcpy(e->d_reads, reads + b0, bases, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_offsets, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_seeds, seeds + done, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    int rc = launch_batch(e, e->d_reads, e->d_offsets, e->d_seeds, n, nullptr);
+    int rc = launch_batch(e, e->d_reads, e->d_offsets, e->d_seeds, n, bases, nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));  // staging buffers are reused by the next batch
     done += n;

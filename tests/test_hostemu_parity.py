@@ -17,6 +17,7 @@ def _case(seed):
     reads = simulate_graph_reads(prg, 40, L, seed + 100)
     reads += [rng.integers(1, 5, size=L).astype(np.uint8) for _ in range(5)]
     reads.append(np.array([1, 2, 0, 3] * 3, dtype=np.uint8))  # non-ACGT symbol -> skipped
+    reads.append(np.array([4, 4, 1, 2, 5, 1, 1, 2, 3, 4, 1, 78], dtype=np.uint8))
     reads.append(np.zeros(0, dtype=np.uint8))                   # empty read -> skipped
     reads = [r for r in reads if len(r) >= k or len(r) == 0]
     seeds = rng.integers(0, 2 ** 32, size=len(reads), dtype=np.uint64).astype(np.uint32)
