@@ -33,6 +33,11 @@ class Timing(C.Structure):
                 ("cover_launches", C.c_uint64), ("reads", C.c_uint64)]
 
 
+class DepthStats(C.Structure):
+    _fields_ = [("mean_cov_depth", C.c_double), ("variance_cov_depth", C.c_double), ("num_sites_noCov", C.c_uint64),
+                ("num_sites_total", C.c_uint64)]
+
+
 class DeviceCoverage(C.Structure):
     _fields_ = [("allele_sum", C.c_void_p), ("n_allele_sum", C.c_uint64), ("per_base", C.c_void_p),
                 ("n_per_base", C.c_uint64), ("grouped", C.c_void_p), ("n_grouped", C.c_uint64),
@@ -52,6 +57,8 @@ SYMBOLS = {
     "gmx_index_site_layout": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p, _i32p]),
     "gmx_index_per_base_layout": (_i64, [_vp, _u32p, _u64]),
     "gmx_index_allele_base_layout": (C.c_int, [_vp, _u32p, _u32p]),
+    "gmx_compute_coverage_depth": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u64, C.POINTER(DepthStats)]),
+    "gmx_index_bubble_order": (C.c_int, [_vp, _u32p]),
     "gmx_index_copy_sa": (C.c_int, [_vp, _u32p]),
     "gmx_index_copy_bwt": (C.c_int, [_vp, _u32p]),
     "gmx_index_rank": (_u32, [_vp, _u32, _u32]),

@@ -1,5 +1,8 @@
 // gmx_capi.cpp — host half of the C ABI: index construction, introspection, seeds, u16 finalisation.
+#include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -158,6 +161,114 @@ int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t
       }
     }
   }
+  return GMX_OK;
+}
+
+static std::vector<uint32_t> bubble_order(const gmx::HostIndex &h) {
+  std::vector<uint32_t> order(h.sites.size());
+  for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    if (h.sites[a].ref_pos != h.sites[b].ref_pos) return h.sites[a].ref_pos > h.sites[b].ref_pos;
+    return a > b;
+  });
+  return order;
+}
+
+int gmx_index_bubble_order(const gmx_index *ix, uint32_t *out) {
+  auto o = bubble_order(ix->h);
+  for (size_t i = 0; i < o.size(); ++i) out[i] = 5 + 2 * o[i];
+  return GMX_OK;
+}
+
+int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw, const uint32_t *grouped_raw,
+                               const uint32_t *glog, uint64_t n_log, gmx_depth_stats *out) {
+  const gmx::HostIndex &h = ix->h;
+  // per-site haplogroup totals in uint16 arithmetic (get_max_cov_haplogroup, read_stats.cpp:72-92)
+  std::vector<std::map<int32_t, uint16_t>> hap(h.sites.size());
+  std::vector<std::map<std::vector<int32_t>, uint16_t>> logged(h.sites.size());
+  for (uint64_t i = 0; i + 1 < n_log;) {
+    uint32_t s = glog[i], n = glog[i + 1];
+    if (s >= h.sites.size() || i + 2 + n > n_log) {
+      gmx_set_error("corrupt grouped log");
+      return GMX_EINVAL;
+    }
+    std::vector<int32_t> ids(glog + i + 2, glog + i + 2 + n);
+    logged[s][ids] = (uint16_t)(logged[s][ids] + 1);
+    i += 2 + n;
+  }
+  for (size_t s = 0; s < h.sites.size(); ++s) {
+    const GmxSite &site = h.sites[s];
+    if (site.grouped_off != GMX_GROUPED_LOG) {
+      uint32_t nm = (1u << site.n_alleles) - 1u;
+      for (uint32_t m = 0; m < nm; ++m) {
+        uint32_t tot = grouped_raw[site.grouped_off + m];
+        if (!tot) continue;
+        uint16_t c = (uint16_t)(tot & 0xFFFFu);
+        for (uint32_t a = 0; a < site.n_alleles; ++a)
+          if (((m + 1) >> a) & 1u) hap[s][(int32_t)a] = (uint16_t)(hap[s][(int32_t)a] + c);
+      }
+    }
+    for (auto &e : logged[s])
+      for (auto a : e.first) hap[s][a] = (uint16_t)(hap[s][a] + e.second);
+  }
+  auto max_hap = [&](size_t s) -> std::pair<int32_t, uint16_t> {
+    std::pair<int32_t, uint16_t> best{0, 0};
+    bool any = false;
+    for (auto &e : hap[s])
+      if (!any || e.second > best.second) {
+        best = {e.first, e.second};
+        any = true;
+      }
+    return best;
+  };
+  std::vector<double> coverages;
+  double total = 0;
+  uint64_t no_cov = 0;
+  for (uint32_t s : bubble_order(h)) {
+    const GmxSite &site = h.sites[s];
+    if (site.parent_site != 0) continue;  // nested sites are skipped (read_stats.cpp:128-132)
+    auto mx = max_hap(s);
+    uint16_t allele_cov = mx.second;
+    double sum = 0;
+    uint64_t n_bases = 0;
+    uint32_t cur = site.entry_node;
+    size_t guard = 0;
+    while (cur != site.exit_node) {  // extract_max_coverage_allele, read_stats.cpp:94-117
+      if (++guard > h.nodes.size() + 8) {
+        gmx_set_error("coverage graph walk does not terminate");
+        return GMX_EINVAL;
+      }
+      const GmxNode &nd = h.nodes[cur];
+      uint32_t ne = h.nodes[cur + 1].edge_begin - nd.edge_begin;
+      if (ne > 1 && nd.seq_len == 0) {
+        auto m2 = max_hap((nd.site - 5) / 2);
+        if (m2.first < 0 || (uint32_t)m2.first >= ne) {
+          gmx_set_error("haplogroup out of range");
+          return GMX_EINVAL;
+        }
+        cur = h.edges[nd.edge_begin + (uint32_t)m2.first];
+        continue;
+      }
+      if (nd.seq_len > 0 && nd.cov_off != GMX_NO_COV)
+        for (uint32_t i = 0; i < nd.seq_len; ++i) {
+          uint32_t v = per_base_raw[nd.cov_off + i];
+          sum += (double)(v > 65535u ? 65535u : v);
+          ++n_bases;
+        }
+      cur = h.edges[nd.edge_begin];
+    }
+    double site_cov = n_bases ? sum / (double)n_bases : (double)allele_cov;
+    total += site_cov;
+    coverages.push_back(site_cov);
+    if (allele_cov == 0) no_cov++;
+  }
+  double mean = total / (double)coverages.size();
+  double tv = 0;
+  for (double c : coverages) tv += std::pow(c - mean, 2);
+  out->mean_cov_depth = mean;
+  out->variance_cov_depth = tv / (double)coverages.size();
+  out->num_sites_noCov = no_cov;
+  out->num_sites_total = coverages.size();
   return GMX_OK;
 }
 

@@ -188,6 +188,7 @@ struct OpenSite {
   uint32_t site;
   uint32_t entry, exit;
   int32_t allele;
+  uint64_t entry_pos, exit_pos;  // coverage_Node::pos bookkeeping (coverage_graph.cpp:97-110,174-258)
 };
 
 struct GraphBuild {
@@ -198,6 +199,7 @@ struct GraphBuild {
   std::map<uint32_t, std::vector<TargetedMarker>> target_map;
   std::vector<std::pair<uint32_t, int32_t>> pos_target;
   std::map<uint32_t, std::pair<uint32_t, uint32_t>> bubbles;  // site -> (entry, exit)
+  std::map<uint32_t, uint64_t> site_ref_pos;                   // site -> pos of its bubble start
 };
 
 void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
@@ -242,6 +244,7 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
   };
   MType prev_t = MType::sequence;
   uint32_t prev_m = 0;
+  uint64_t cur_pos = 0;  // position along the all-first-alleles path
   for (size_t p = 0; p < N; ++p) {
     uint32_t m = prg[p];
     MType t;
@@ -253,6 +256,7 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
         cur = new_node(site, allele, (uint32_t)p);
       }
       g.nodes[cur].seq_len++;
+      cur_pos++;
       g.pos_node[p] = (uint32_t)cur;
       if (prev_t != MType::sequence) {  // map_targets, coverage_graph.cpp:280-284
         int32_t cur_allele = stack.empty() ? -1 : stack.back().allele;
@@ -268,8 +272,9 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
         uint32_t target = prev_t == MType::allele_end ? prev_m - 1 : prev_m;
         if (!g.target_map.count(m)) g.target_map[m] = {TargetedMarker{target, -1}};
       }
-      stack.push_back(OpenSite{m, entry, exit, 0});
+      stack.push_back(OpenSite{m, entry, exit, 0, cur_pos, cur_pos});
       g.bubbles[m] = {entry, exit};
+      g.site_ref_pos[m] = cur_pos;
       back = entry;
       g.pos_node[p] = entry;
     } else {
@@ -297,7 +302,9 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
         }
       }
       wire(top.exit);
+      if (top.allele == 0) top.exit_pos = cur_pos;  // the exit takes the end coordinate of the FIRST allele
       if (!last) {
+        cur_pos = top.entry_pos;
         top.allele++;
         back = top.entry;
         g.pos_node[p] = top.entry;
@@ -306,6 +313,7 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
           throw std::runtime_error("Site numbered " + std::to_string(m) + " has only one allele");
         uint32_t exit = top.exit;
         g.nodes[exit].first_pos = (uint32_t)p;
+        cur_pos = top.exit_pos;
         stack.pop_back();
         back = exit;
         g.pos_node[p] = exit;
@@ -524,6 +532,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       s.grouped_off = GMX_GROUPED_LOG;
     s.entry_node = b.second.first;
     s.exit_node = b.second.second;
+    s.ref_pos = (uint32_t)g.site_ref_pos[b.first];
   }
   out.n_allele_slots = as;
   out.n_grouped_slots = gs;

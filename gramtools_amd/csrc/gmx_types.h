@@ -53,7 +53,7 @@ struct GmxSite {
   uint32_t grouped_off;     // dense grouped-counts base (2^n_alleles - 1 slots) or GMX_GROUPED_LOG
   uint32_t entry_node;      // bubble start node
   uint32_t exit_node;       // bubble end node
-  uint32_t pad;
+  uint32_t ref_pos;         // coverage_Node::pos of the bubble start (first-allele coordinate; orders bubble_map)
 };
 #define GMX_GROUPED_LOG 0xFFFFFFFFu
 #define GMX_GROUPED_DENSE_MAX_ALLELES 5

@@ -1,0 +1,507 @@
+// gram_main.cpp — the `gram` executable: drop-in for the quasimap phase of the reference's backend CLI.
+//
+// Process boundary reproduced: the Python front-end runs
+//   gram genotype --gram_dir D --reads F1 [F2 ...] --sample_id S --ploidy {haploid,diploid} --kmer_size K
+//                 --genotype_dir G --max_threads T [--seed U32] [--debug]
+// (gramtools/commands/genotype/genotype.py:71-93; flags of libgramtools/src/genotype/parameters.cpp:54-72;
+// two-stage parse and exit codes of libgramtools/src/main.cpp:28-100), reads D/prg and must find
+//   G/coverage/allele_sum_coverage, G/coverage/allele_base_coverage.json,
+//   G/coverage/grouped_allele_counts_coverage.json and G/read_stats.json (parameters.cpp:94-105).
+// Host code here only parses, feeds and writes; mapping is done by the HIP engine through the C ABI (gmx.h).
+// The infer stage (genotyped.json / .vcf.gz / personalised reference) is outside this engine's scope.
+#include <sys/stat.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/gmx.h"
+
+namespace {
+
+const char *kGlobalHelp =
+    "Gramtools! Global options:\n"
+    "  --command arg         command to execute: {build, genotype, simulate}\n"
+    "  --subargs arg         arguments to command\n"
+    "  --help                Produce this help message\n"
+    "  --debug               Turn on debug output\n";
+
+const char *kGenotypeHelp =
+    "genotype options:\n"
+    "  --gram_dir arg              gramtools directory\n"
+    "  --reads arg                 file containing reads (FASTA or FASTQ)\n"
+    "  --sample_id arg\n"
+    "  --ploidy arg                expected ploidy of the sample. Choices: {haploid, diploid}\n"
+    "  --kmer_size arg             kmer size that got used in build step\n"
+    "  --genotype_dir arg          output directory\n"
+    "  --max_threads arg (=1)      maximum number of threads used\n"
+    "  --seed arg                  seed for pseudo-random selection of multi-mapping reads. a random seed is\n"
+    "                              generated if this option is not used.\n"
+    "  --device arg (=0)           HIP device ordinal (engine extension)\n"
+    "  --rng_compat arg (=gcc11)   uniform_int_distribution flavour of the reference build to reproduce:\n"
+    "                              gcc11 (libstdc++ >= 11) or gcc10 (libstdc++ <= 10) (engine extension)\n";
+
+[[noreturn]] void die(const std::string &msg, int code = 1) {
+  std::cout << msg << std::endl;
+  exit(code);
+}
+
+void mkdirs(const std::string &path) {
+  std::string cur;
+  for (size_t i = 0; i <= path.size(); ++i) {
+    if (i == path.size() || path[i] == '/') {
+      if (!cur.empty()) mkdir(cur.c_str(), 0777);
+    }
+    if (i < path.size()) cur += path[i];
+  }
+}
+
+std::string join(const std::string &dir, const std::string &name) {
+  if (dir.empty()) return name;
+  return dir.back() == '/' ? dir + name : dir + "/" + name;
+}
+
+// ---- sequence file reader: FASTQ / FASTA / one-sequence-per-line, optionally gzipped -------------------
+// (the reference uses the third-party seq_file reader, include/sequence_read/seq_file.h; SAM/BAM/CRAM need
+// htslib and are not supported here)
+struct SeqRecord {
+  std::string seq, qual;
+};
+class SeqReader {
+ public:
+  explicit SeqReader(const std::string &path) : gz_(gzopen(path.c_str(), "rb")) {
+    if (!gz_) die("Cannot open reads file: " + path);
+    gzbuffer(gz_, 1 << 20);
+    have_line_ = next_line(line_);
+  }
+  ~SeqReader() {
+    if (gz_) gzclose(gz_);
+  }
+  bool next(SeqRecord &r) {
+    r.seq.clear();
+    r.qual.clear();
+    while (have_line_ && line_.empty()) have_line_ = next_line(line_);
+    if (!have_line_) return false;
+    if (line_[0] == '@') {  // FASTQ (multi-line tolerant)
+      std::string l;
+      while ((have_line_ = next_line(l)) && (l.empty() || l[0] != '+')) r.seq += l;
+      if (!have_line_) return !r.seq.empty();
+      while ((have_line_ = next_line(l))) {
+        r.qual += l;
+        if (r.qual.size() >= r.seq.size()) break;
+      }
+      have_line_ = next_line(line_);
+      return true;
+    }
+    if (line_[0] == '>') {  // FASTA
+      std::string l;
+      while ((have_line_ = next_line(l)) && (l.empty() || l[0] != '>')) r.seq += l;
+      line_ = l;
+      return true;
+    }
+    r.seq = line_;  // plain
+    have_line_ = next_line(line_);
+    return true;
+  }
+
+ private:
+  bool next_line(std::string &out) {
+    out.clear();
+    char buf[1 << 16];
+    bool any = false;
+    while (gzgets(gz_, buf, sizeof(buf))) {
+      any = true;
+      size_t n = strlen(buf);
+      bool eol = n && buf[n - 1] == '\n';
+      if (eol) --n;
+      if (n && buf[n - 1] == '\r') --n;
+      out.append(buf, n);
+      if (eol) return true;
+    }
+    return any;
+  }
+  gzFile gz_;
+  std::string line_;
+  bool have_line_ = false;
+};
+
+// encode_dna_bases (common/utils.cpp:73-92): A,C,G,T -> 1..4; anything else => the whole read is dropped
+bool encode_read(const std::string &s, std::vector<uint8_t> &out) {
+  size_t at = out.size();
+  for (char c : s) {
+    uint8_t v;
+    switch (c) {
+      case 'A': case 'a': v = 1; break;
+      case 'C': case 'c': v = 2; break;
+      case 'G': case 'g': v = 3; break;
+      case 'T': case 't': v = 4; break;
+      default: out.resize(at); return false;
+    }
+    out.push_back(v);
+  }
+  return true;
+}
+
+struct ReadStats {  // include/genotype/read_stats.hpp
+  double mean_cov_depth = -1, variance_cov_depth = -1;
+  uint64_t num_sites_noCov = 0;
+  int64_t num_sites_total = -1;
+  double mean_pb_error = -1;
+  int64_t no_qual_reads = -1, num_bases_processed = -1;
+  uint64_t max_read_length = 0;
+};
+
+// ReadStats::process_read_perbase_error_rates (src/genotype/read_stats.cpp:21-70): first <= 10000 reads with qualities
+void compute_base_error_rate(const std::string &path, ReadStats &rs) {
+  SeqReader reader(path);
+  SeqRecord rec;
+  uint64_t informative = 0;
+  int64_t no_qual = 0, n_bases = 0;
+  float running = 0.0f;
+  while (informative < 10000 && reader.next(rec)) {
+    if (rec.seq.size() > rs.max_read_length) rs.max_read_length = rec.seq.size();
+    if (rec.qual.empty()) {
+      no_qual++;
+      continue;
+    }
+    for (char q : rec.qual) {
+      running += (float)(q - 33);
+      n_bases++;
+    }
+    informative++;
+  }
+  double mean_error = 0;
+  if (n_bases > 0) {
+    double mean_qual = running / n_bases;
+    mean_error = std::pow(10, -mean_qual / 10);
+  }
+  rs.num_bases_processed = n_bases;
+  rs.no_qual_reads = no_qual;
+  rs.mean_pb_error = mean_error;
+}
+
+void write_read_stats(const std::string &path, const ReadStats &rs) {  // ReadStats::serialise, read_stats.cpp:162-209
+  std::ofstream o(path);
+  o << "\n{\n\"Read_depth\":\n    {\"Mean\": " << rs.mean_cov_depth << ",";
+  o << "\n    \"Variance\": " << rs.variance_cov_depth << ",";
+  o << "\n    \"num_sites_noCov\": " << rs.num_sites_noCov << ",";
+  o << "\n    \"num_sites_total\": " << rs.num_sites_total;
+  o << "\n    },";
+  o << "\n\"Max_read_length\": " << rs.max_read_length << ",";
+  o << "\n\"Quality\":\n    {\"Error_rate_mean\": " << rs.mean_pb_error << ",";
+  o << "\n    \"Num_bases\": " << rs.num_bases_processed << ",";
+  o << "\n    \"No_qual_reads\": " << rs.no_qual_reads;
+  o << "\n    }}\n";
+}
+
+#define GMX_CHECK(expr)                                                        \
+  do {                                                                         \
+    int _rc = (expr);                                                          \
+    if (_rc < 0) die(std::string("gram: ") + #expr + " failed: " + gmx_last_error()); \
+  } while (0)
+
+struct Args {
+  std::map<std::string, std::vector<std::string>> opt;
+  bool has(const std::string &k) const { return opt.count(k) != 0; }
+  std::string one(const std::string &k) const {
+    auto it = opt.find(k);
+    if (it == opt.end() || it->second.size() != 1) die("the option '--" + k + "' is required and takes one value\n" + kGenotypeHelp);
+    return it->second[0];
+  }
+};
+
+Args parse_sub(int argc, const char *const *argv, int from) {
+  Args a;
+  std::string cur;
+  for (int i = from; i < argc; ++i) {
+    std::string t = argv[i];
+    if (t.rfind("--", 0) == 0) {
+      cur = t.substr(2);
+      size_t eq = cur.find('=');
+      if (eq != std::string::npos) {
+        a.opt[cur.substr(0, eq)].push_back(cur.substr(eq + 1));
+        cur = cur.substr(0, eq);
+      } else
+        a.opt[cur];
+    } else if (!cur.empty())
+      a.opt[cur].push_back(t);
+  }
+  return a;
+}
+
+int run_build(const Args &a) {
+  // The reference's `gram build` writes SDSL/Boost artefacts derived from gram_dir/prg (src/build/build.cpp:8-72).
+  // This engine re-derives everything from `prg` at genotype time, so build only validates the PRG.
+  std::string gram_dir = a.one("gram_dir");
+  uint32_t k = a.has("kmer_size") ? (uint32_t)std::stoul(a.one("kmer_size")) : 0;
+  gmx_index *ix = nullptr;
+  GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), k, 0, &ix));
+  gmx_index_info info;
+  gmx_index_get_info(ix, &info);
+  std::cout << "PRG ok: " << info.n_text - 1 << " symbols, " << info.n_sites << " variant sites, " << info.n_kmers_present
+            << " indexed kmers" << std::endl;
+  gmx_index_destroy(ix);
+  return 0;
+}
+
+int run_genotype(const Args &a) {
+  using clk = std::chrono::steady_clock;
+  std::string gram_dir = a.one("gram_dir");
+  if (!a.has("reads") || a.opt.at("reads").empty()) die(std::string("the option '--reads' is required but missing\n") + kGenotypeHelp);
+  std::vector<std::string> reads_paths = a.opt.at("reads");
+  std::string sample_id = a.one("sample_id");
+  std::string ploidy = a.one("ploidy");
+  if (ploidy != "haploid" && ploidy != "diploid") die(std::string("Invalid/unsupported ploidy\n") + kGenotypeHelp);
+  uint32_t kmer_size = (uint32_t)std::stoul(a.one("kmer_size"));
+  std::string run_dir = a.one("genotype_dir");
+  int max_threads = a.has("max_threads") ? std::stoi(a.one("max_threads")) : 1;
+  int device = a.has("device") ? std::stoi(a.one("device")) : 0;
+  int rng_mode = 0;
+  if (a.has("rng_compat")) {
+    std::string m = a.one("rng_compat");
+    if (m == "gcc10")
+      rng_mode = 1;
+    else if (m != "gcc11")
+      die("--rng_compat must be gcc11 or gcc10");
+  }
+  uint32_t seed;
+  if (a.has("seed"))
+    seed = (uint32_t)std::stoul(a.one("seed"));
+  else {
+    std::random_device rd;  // random.cpp:8-13
+    seed = rd();
+  }
+  std::string cov_dir = join(run_dir, "coverage"), geno_dir = join(run_dir, "genotype");
+  mkdirs(cov_dir);
+  mkdirs(geno_dir);
+
+  std::cout << "Executing genotype command" << std::endl;
+  ReadStats rs;
+  compute_base_error_rate(reads_paths[0], rs);  // genotype.cpp:32-34
+
+  auto t0 = clk::now();
+  std::cout << "Loading PRG data" << std::endl;
+  gmx_index *ix = nullptr;
+  GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), kmer_size, max_threads, &ix));
+  gmx_index_info info;
+  GMX_CHECK(gmx_index_get_info(ix, &info));
+  std::cout << "Loading kmer index data" << std::endl;
+  gmx_engine_opts opts;
+  gmx_engine_default_opts(&opts);
+  opts.device = device;
+  opts.rng_mode = rng_mode;
+  gmx_engine *eng = nullptr;
+  GMX_CHECK(gmx_engine_create(ix, &opts, &eng));
+  double t_load = std::chrono::duration<double>(clk::now() - t0).count();
+
+  std::cout << "Running quasimap" << std::endl;
+  std::cout << "Generating allele quasimap data structure" << std::endl;
+  std::cout << "Done generating allele quasimap data structure" << std::endl;
+  std::cout << "Master random seed for read selection: " << seed << std::endl;
+  std::cout << "Maximum thread count: " << max_threads << std::endl;
+  std::cout << "Processing reads:" << std::endl;
+  t0 = clk::now();
+  // One master mt19937(seed) for all files; 5000 draws per batch of <= 5000 reads (quasimap.cpp:120-141).
+  std::mt19937 master(seed);
+  const uint64_t kBatch = 5000;
+  const uint64_t kChunkReads = 1u << 20;  // reads staged per engine call (multiple of 5000 not required: seeds are per read)
+  uint64_t total_reads = 0;
+  for (auto const &path : reads_paths) {
+    SeqReader reader(path);
+    SeqRecord rec;
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets{0};
+    std::vector<uint32_t> seeds;
+    uint64_t in_batch = 0;
+    auto flush = [&]() {
+      if (offsets.size() > 1) {
+        if (bases.empty()) bases.push_back(0);
+        GMX_CHECK(gmx_map_reads_host(eng, bases.data(), offsets.data(), seeds.data(), offsets.size() - 1));
+      }
+      bases.clear();
+      offsets.assign(1, 0);
+      seeds.clear();
+    };
+    std::vector<uint32_t> batch_seeds(kBatch);
+    while (reader.next(rec)) {
+      if (in_batch == 0)
+        for (auto &s : batch_seeds) s = (uint32_t)master();  // always 5000 draws per batch
+      encode_read(rec.seq, bases);  // an unencodable read stays as an empty read: counted as skipped, keeps its seed
+      offsets.push_back(bases.size());
+      seeds.push_back(batch_seeds[in_batch]);
+      if (++in_batch == kBatch) in_batch = 0;
+      total_reads++;
+      if (offsets.size() - 1 >= kChunkReads && in_batch == 0) flush();
+    }
+    flush();
+  }
+  GMX_CHECK(gmx_engine_sync(eng));
+  double t_map = std::chrono::duration<double>(clk::now() - t0).count();
+
+  // ---- coverage read-back + uint16 semantics --------------------------------------------------------------
+  std::vector<uint32_t> allele_sum(std::max<uint32_t>(info.n_allele_slots, 1)), per_base(std::max<uint32_t>(info.n_per_base_slots, 1)),
+      grouped(std::max<uint32_t>(info.n_grouped_slots, 1));
+  gmx_stats st;
+  GMX_CHECK(gmx_coverage_fetch(eng, allele_sum.data(), per_base.data(), grouped.data(), &st));
+  int64_t n_log = gmx_coverage_fetch_grouped_log(eng, nullptr, 0);
+  if (n_log < 0) die(std::string("gram: grouped log: ") + gmx_last_error());
+  std::vector<uint32_t> glog(std::max<int64_t>(n_log, 1));
+  if (n_log) gmx_coverage_fetch_grouped_log(eng, glog.data(), (uint64_t)n_log);
+
+  gmx_depth_stats ds;  // readstats.compute_coverage_depth, quasimap.cpp:48
+  GMX_CHECK(gmx_compute_coverage_depth(ix, per_base.data(), grouped.data(), glog.data(), (uint64_t)n_log, &ds));
+  rs.mean_cov_depth = ds.mean_cov_depth;
+  rs.variance_cov_depth = ds.variance_cov_depth;
+  rs.num_sites_noCov = ds.num_sites_noCov;
+  rs.num_sites_total = (int64_t)ds.num_sites_total;
+
+  std::vector<uint32_t> n_alleles(info.n_sites), as_off(info.n_sites), g_off(info.n_sites);
+  GMX_CHECK(gmx_index_site_layout(ix, n_alleles.data(), as_off.data(), g_off.data(), nullptr, nullptr));
+
+  {  // coverage::dump::allele_sum (allele_sum.cpp:45-57): uint16 wrap
+    std::ofstream o(join(cov_dir, "allele_sum_coverage"));
+    for (uint32_t s = 0; s < info.n_sites; ++s) {
+      for (uint32_t al = 0; al < n_alleles[s]; ++al) {
+        o << (allele_sum[as_off[s] + al] & 0xFFFFu);
+        if (al + 1 < n_alleles[s]) o << " ";
+      }
+      o << "\n";
+    }
+  }
+  {  // coverage::dump::allele_base (allele_base.cpp:49-107): saturating uint16; [] for nested PRGs
+    std::ofstream o(join(cov_dir, "allele_base_coverage.json"));
+    o << "{\"allele_base_counts\":[";
+    if (!info.is_nested) {
+      std::vector<uint32_t> pb_off(std::max<uint32_t>(info.n_allele_slots, 1)), pb_len(std::max<uint32_t>(info.n_allele_slots, 1));
+      GMX_CHECK(gmx_index_allele_base_layout(ix, pb_off.data(), pb_len.data()));
+      for (uint32_t s = 0; s < info.n_sites; ++s) {
+        o << "[";
+        for (uint32_t al = 0; al < n_alleles[s]; ++al) {
+          o << "[";
+          uint32_t slot = as_off[s] + al;
+          for (uint32_t i = 0; i < pb_len[slot]; ++i) {
+            o << std::min<uint32_t>(per_base[pb_off[slot] + i], 65535u);
+            if (i + 1 < pb_len[slot]) o << ",";
+          }
+          o << "]";
+          if (al + 1 < n_alleles[s]) o << ",";
+        }
+        o << "]";
+        if (s + 1 < info.n_sites) o << ",";
+      }
+    }
+    o << "]}\n";
+  }
+  {  // coverage::dump::grouped_allele_counts (grouped_allele_counts.cpp:51-110): uint16 wrap, arbitrary group ids
+    std::vector<std::map<std::vector<int32_t>, uint32_t>> sites(info.n_sites);
+    for (uint32_t s = 0; s < info.n_sites; ++s) {
+      if (g_off[s] == 0xFFFFFFFFu) continue;
+      uint32_t nm = (1u << n_alleles[s]) - 1u;
+      for (uint32_t m = 0; m < nm; ++m) {
+        uint32_t tot = grouped[g_off[s] + m];
+        if (!tot) continue;
+        std::vector<int32_t> ids;
+        for (uint32_t al = 0; al < n_alleles[s]; ++al)
+          if (((m + 1) >> al) & 1u) ids.push_back((int32_t)al);
+        sites[s][ids] = tot & 0xFFFFu;
+      }
+    }
+    for (int64_t i = 0; i + 1 < n_log;) {
+      uint32_t s = glog[i], n = glog[i + 1];
+      std::vector<int32_t> ids(glog.begin() + i + 2, glog.begin() + i + 2 + n);
+      sites[s][ids] = (sites[s][ids] + 1) & 0xFFFFu;
+      i += 2 + n;
+    }
+    std::map<std::vector<int32_t>, uint64_t> group_id;
+    std::vector<std::vector<int32_t>> by_id;
+    for (auto &site : sites)
+      for (auto &e : site)
+        if (!group_id.count(e.first)) {
+          group_id[e.first] = by_id.size();
+          by_id.push_back(e.first);
+        }
+    std::ofstream o(join(cov_dir, "grouped_allele_counts_coverage.json"));
+    o << "{\"grouped_allele_counts\":{\"allele_groups\":{";
+    for (size_t g = 0; g < by_id.size(); ++g) {
+      o << "\"" << g << "\":[";
+      for (size_t j = 0; j < by_id[g].size(); ++j) o << by_id[g][j] << (j + 1 < by_id[g].size() ? "," : "");
+      o << "]" << (g + 1 < by_id.size() ? "," : "");
+    }
+    o << "},\"site_counts\":[";
+    for (uint32_t s = 0; s < info.n_sites; ++s) {
+      std::map<uint64_t, uint32_t> by_gid;
+      for (auto &e : sites[s]) by_gid[group_id[e.first]] = e.second;
+      o << "{";
+      size_t j = 0;
+      for (auto &e : by_gid) o << "\"" << e.first << "\":" << e.second << (++j < by_gid.size() ? "," : "");
+      o << "}" << (s + 1 < info.n_sites ? "," : "");
+    }
+    o << "]}}\n";
+  }
+  std::string rs_path = join(run_dir, "read_stats.json");
+  std::cout << "Writing read stats to " << rs_path << std::endl;
+  write_read_stats(rs_path, rs);
+
+  std::cout << std::endl;
+  std::cout << "The following counts include generated reverse complement reads." << std::endl;
+  std::cout << "Count all reads: " << st.all_reads_count << std::endl;
+  std::cout << "Count skipped reads with no sequence: " << st.skipped_reads_count << std::endl;
+  std::cout << "Count reads with >0 kmers not in kmer index: " << st.missing_kmer_reads_count << std::endl;
+  std::cout << "Count reads with no exact mapping: " << st.no_extension_reads_count << std::endl;
+  std::cout << "Count exact mapped reads: " << st.exact_mapped_reads_count << std::endl;
+  std::cout << std::endl
+            << "Timer report (wall seconds)" << std::endl
+            << "  Load data (index build + upload): " << t_load << std::endl
+            << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl;
+  std::cout << "====================" << std::endl
+            << "Genotyping (infer stage) is not part of the MI355X quasimap engine: " << geno_dir
+            << " is left empty; see INTEGRATION.md." << std::endl;
+  (void)sample_id;
+  gmx_engine_destroy(eng);
+  gmx_index_destroy(ix);
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, const char *const *argv) {
+  // main.cpp:51-100: first positional token is the command; --help or no command prints help and exits 0
+  std::string command;
+  int cmd_at = -1;
+  bool help = false;
+  for (int i = 1; i < argc; ++i) {
+    std::string t = argv[i];
+    if (t == "--help") help = true;
+    if (cmd_at < 0 && t.rfind("--", 0) != 0) {
+      command = t;
+      cmd_at = i;
+      break;
+    }
+  }
+  if (help || command.empty()) {
+    std::cout << kGlobalHelp << std::endl;
+    return 0;
+  }
+  if (command != "build" && command != "genotype" && command != "simulate") {
+    std::cout << "Unrecognised command: " << command << std::endl;
+    std::cout << kGlobalHelp << std::endl;
+    return 1;
+  }
+  Args a = parse_sub(argc, argv, cmd_at + 1);
+  if (command == "genotype") return run_genotype(a);
+  if (command == "build") return run_build(a);
+  std::cout << "The simulate command is not part of the MI355X quasimap engine." << std::endl;
+  return 1;
+}

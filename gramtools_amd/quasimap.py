@@ -159,6 +159,11 @@ class Index:
         k = np.ascontiguousarray(kmer, dtype=np.uint8)
         return self._unpack_states(self._states_call(self.lib.gmx_index_seed_states, _p(k, C.c_uint8)))
 
+    def bubble_order(self):
+        out = np.zeros(max(self.n_sites, 1), dtype=np.uint32)
+        check(self.lib.gmx_index_bubble_order(self.h, _p(out, C.c_uint32)))
+        return out[:self.n_sites].tolist()
+
     def jump_states(self, lo, hi):
         """search_state_vBWT_jumps of the path-less state [lo, hi] (vBWT_jump.cpp:134-183)."""
         return self._unpack_states(self._states_call(self.lib.gmx_index_jump_states, lo, hi))
@@ -235,6 +240,18 @@ class Coverage:
                 site.append([int(x) for x in self.per_base_flat[off[slot]:off[slot] + ln[slot]]])
             out.append(site)
         return out
+
+    def depth_stats(self):
+        """read_stats.json depth block: mean / population variance of per-site max-haplogroup coverage over
+        level-0 sites (AbstractReadStats::compute_coverage_depth, read_stats.cpp:119-160)."""
+        d = _lib.DepthStats()
+        pb = np.ascontiguousarray(self.raw_per_base if self.raw_per_base.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        g = np.ascontiguousarray(self.raw_grouped if self.raw_grouped.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        lg = np.ascontiguousarray(self.raw_grouped_log if self.raw_grouped_log.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        check(_lib.load().gmx_compute_coverage_depth(self.index.h, _p(pb, C.c_uint32), _p(g, C.c_uint32), _p(lg, C.c_uint32),
+                                                     self.raw_grouped_log.size, C.byref(d)))
+        return dict(mean=d.mean_cov_depth, variance=d.variance_cov_depth, num_sites_noCov=d.num_sites_noCov,
+                    num_sites_total=d.num_sites_total)
 
     def per_base_by_first_pos(self):
         """{first PRG position of a coverage-owning node: [per-base counts]} (works for nested PRGs too)."""

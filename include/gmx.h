@@ -68,6 +68,18 @@ int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t c
  * allele's single sequence node, or len 0 for a direct deletion. Records (pb_off, len) in site-major order. */
 int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t *len);
 
+/* Read-depth statistics of read_stats.json (AbstractReadStats::compute_coverage_depth, src/genotype/read_stats.cpp:72-160),
+ * from the raw uint32 totals returned by gmx_coverage_fetch (+ the grouped log). */
+typedef struct gmx_depth_stats {
+  double mean_cov_depth, variance_cov_depth;
+  uint64_t num_sites_noCov, num_sites_total;
+} gmx_depth_stats;
+int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw, const uint32_t *grouped_dense_raw,
+                               const uint32_t *grouped_log, uint64_t n_log_words, gmx_depth_stats *out);
+/* Site markers in the iteration order of the reference's bubble_map (descending first-allele position, then
+ * descending site id; prg/types.hpp:26, coverage_graph.cpp:381-389). */
+int gmx_index_bubble_order(const gmx_index *ix, uint32_t *site_markers_out);
+
 /* Introspection (tests, debugging): copies of the derived structures. */
 int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out);             /* n_text entries (fm_index[i]) */
 int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out);            /* n_text entries */

@@ -68,7 +68,8 @@ def _load_emu():
     return lib
 
 
-def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048):
+def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048,
+                return_raw=False):
     """Runs the device headers on the host. Returns (canonical coverage, n_overflow_tasks, rc)."""
     lib = _load_emu()
     arr = np.ascontiguousarray(prg, dtype=np.uint32)
@@ -93,8 +94,12 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         st = np.zeros(5, dtype=np.uint64)
         lib.hostemu_fetch(h, *(x.ctypes.data_as(C.POINTER(C.c_uint32)) for x in (a, p, g, lg)),
                           st.ctypes.data_as(C.POINTER(C.c_uint64)))
+        raw = dict(allele_sum=a[:int(sizes[0])], per_base=p[:int(sizes[1])], grouped=g[:int(sizes[2])],
+                   grouped_log=lg[:int(sizes[3])], stats=st)
+        if return_raw:
+            return raw, (int(sizes[4]), int(sizes[5])), rc
         ix = Index(prg, k, threads=1)
-        cov = Coverage(ix, a[:int(sizes[0])], p[:int(sizes[1])], g[:int(sizes[2])], lg[:int(sizes[3])],
+        cov = Coverage(ix, raw["allele_sum"], raw["per_base"], raw["grouped"], raw["grouped_log"],
                        QuasimapReadsStats(*(int(x) for x in st)))
         return canonical_cov(cov), (int(sizes[4]), int(sizes[5])), rc
     finally:

@@ -1,0 +1,110 @@
+"""The `gram` drop-in executable: argv/exit-code contract on CPU, end-to-end IT1-IT3 runs on the GPU."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from golden_runner import load_cases
+from gramtools_amd.build import build_gram
+from oracle import ints_to_prg_bytes
+
+GRAM = build_gram()
+
+
+def run(*args):
+    # the Python front-end passes only LD_LIBRARY_PATH in the child environment (gramtools/commands/common.py:33-49)
+    return subprocess.run([GRAM, *args], capture_output=True, text=True, env={"LD_LIBRARY_PATH": ""})
+
+
+def test_no_arguments_prints_help_and_exits_zero():
+    r = run()
+    assert r.returncode == 0 and "command to execute" in r.stdout  # probed by gramtools_main.py:73-90
+
+
+def test_unknown_command_exits_one():
+    r = run("frobnicate")
+    assert r.returncode == 1 and "Unrecognised command" in r.stdout
+
+
+def test_build_validates_prg(tmp_path):
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes([1, 5, 2, 6, 3, 6, 4]))
+    assert run("build", "--gram_dir", str(tmp_path), "--kmer_size", "2").returncode == 0
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes([5, 1, 6, 2, 6, 2, 5, 1, 6, 3, 6]))  # duplicate site marker
+    assert run("build", "--gram_dir", str(tmp_path), "--kmer_size", "2").returncode == 1
+
+
+def _it_cases():
+    return [c for c in load_cases("graph_and_kmers.json") if c["name"].startswith("IT")]
+
+
+def _write_fastq(path, reads, gz=False):
+    txt = "".join(f"@r{i}\n{r}\n+\n{'5' * len(r)}\n" for i, r in enumerate(reads))
+    if gz:
+        with gzip.open(path, "wt") as fh:
+            fh.write(txt)
+    else:
+        path.write_text(txt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _it_cases(), ids=[c["name"] for c in _it_cases()])
+@pytest.mark.parametrize("gz", [False, True])
+def test_integration_cases_through_the_cli(tmp_path, case, gz):
+    """gramtools/tests/genotype/test_genotype_integration_tests.py:68-157 through `gram genotype`."""
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes(case["prg"]["ints"]))
+    reads = [op for op in case["ops"] if op["op"] == "map_reads"][0]["reads"]
+    fq = tmp_path / ("reads.fastq.gz" if gz else "reads.fastq")
+    _write_fastq(fq, reads, gz)
+    out = tmp_path / "run"
+    r = run("genotype", "--gram_dir", str(tmp_path), "--reads", str(fq), "--sample_id", "test", "--ploidy", "haploid",
+            "--kmer_size", "5", "--genotype_dir", str(out), "--max_threads", "1", "--seed", "42")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Count all reads: 4" in r.stdout and "Count exact mapped reads: 2" in r.stdout
+    pb = json.loads((out / "coverage" / "allele_base_coverage.json").read_text())["allele_base_counts"]
+    gp = json.loads((out / "coverage" / "grouped_allele_counts_coverage.json").read_text())["grouped_allele_counts"]
+    for op in case["ops"]:
+        if op["op"] == "expect_allele_base":
+            assert pb == op["value"]
+        if op["op"] == "expect_grouped":
+            groups = {gid: ",".join(str(a) for a in ids) for gid, ids in gp["allele_groups"].items()}
+            got = [{groups[g]: c for g, c in site.items()} for site in gp["site_counts"]]
+            assert got == op["value"]
+    asum = [[int(x) for x in line.split()] for line in (out / "coverage" / "allele_sum_coverage").read_text().splitlines()]
+    assert len(asum) == len(gp["site_counts"])
+    rs = json.loads((out / "read_stats.json").read_text())
+    assert rs["Max_read_length"] == max(len(x) for x in reads)
+    assert abs(rs["Quality"]["Error_rate_mean"] - 0.01) < 1e-9 and rs["Quality"]["Num_bases"] == sum(len(x) for x in reads)
+    assert (out / "genotype").is_dir()
+
+
+@pytest.mark.gpu
+def test_cli_files_equal_python_mirror_dumps(tmp_path):
+    """Two reads files, 5000-per-batch seeding across files, non-ACGT reads: the files `gram` writes are
+    byte-identical to the dumps of the Python mirror fed with the same reads."""
+    from gramtools_amd import Index, quasimap_reads, dump_allele_sum, dump_allele_base, dump_grouped_allele_counts
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads
+    ref = random_ref(3000, 4)
+    prg, pos, alts, n_alts = snp_prg(ref, 40, 5, multi_allelic_frac=0.3)
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes(prg))
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, 5200, 60, 6)
+    as_txt = ["".join("ACGT"[b - 1] for b in r) for r in reads]
+    as_txt[17] = as_txt[17][:10] + "N" + as_txt[17][11:]
+    f1, f2 = as_txt[:5100], as_txt[5100:]
+    _write_fastq(tmp_path / "a.fq", f1)
+    _write_fastq(tmp_path / "b.fq", f2)
+    out = tmp_path / "run"
+    r = run("genotype", "--gram_dir", str(tmp_path), "--reads", str(tmp_path / "a.fq"), str(tmp_path / "b.fq"),
+            "--sample_id", "s", "--ploidy", "diploid", "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234")
+    assert r.returncode == 0, r.stdout + r.stderr
+    cov = quasimap_reads(Index(prg, 6), [f1, f2], seed=1234)
+    assert (out / "coverage" / "allele_sum_coverage").read_text() == dump_allele_sum(cov)
+    assert (out / "coverage" / "allele_base_coverage.json").read_text() == dump_allele_base(cov)
+    assert (out / "coverage" / "grouped_allele_counts_coverage.json").read_text() == dump_grouped_allele_counts(cov)
+    assert f"Count skipped reads with no sequence: 2" in r.stdout
+    d = cov.depth_stats()
+    rs = json.loads((out / "read_stats.json").read_text())
+    assert abs(rs["Read_depth"]["Mean"] - d["mean"]) < 1e-4 * max(1, d["mean"])
+    assert rs["Read_depth"]["num_sites_total"] == d["num_sites_total"]
