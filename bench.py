@@ -12,7 +12,6 @@ Extra objects on the JSON line:
   cpu_baseline the oracle (CPU restatement of the reference algorithm, "port") on a bounded read sample
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -30,24 +29,6 @@ READ_LEN = 150
 READS_PER_GPU = 1_000_000
 B_ALG_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070 B/read at k = 10
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-
-class _DevArray:
-    """Zero-copy view of a device allocation for torch (``__cuda_array_interface__``)."""
-
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
-
-
-def coverage_tensors(qm):
-    import torch
-    dc = qm.device_coverage()
-    out = []
-    for ptr, n, ts in ((dc.allele_sum, dc.n_allele_sum, "<i4"), (dc.per_base, dc.n_per_base, "<i4"),
-                       (dc.grouped, dc.n_grouped, "<i4"), (dc.stats, dc.n_stats, "<i8")):
-        if n:
-            out.append(torch.as_tensor(_DevArray(ptr, n, ts), device="cuda"))
-    return out
 
 
 def cpu_baseline(prg, reads, seeds, max_seconds=20.0):
@@ -109,9 +90,12 @@ def main():
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(torch.int32).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    cov_t = coverage_tensors(qm) if world > 1 else []
+    from gramtools_amd.distributed import device_coverage_tensors
+    cov_t = device_coverage_tensors(qm) if world > 1 else []
 
     def step():
+        # a step is a whole job: zeroed accumulators -> map the rank's reads -> one sum-exchange of the coverage
+        qm.reset(stream=stream)
         qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
         for t in cov_t:                                   # single exchange: sum of the coverage arrays
             dist.all_reduce(t)
@@ -123,10 +107,8 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        qm.reset()
         step()
     fence()
-    qm.reset()
     qm.enable_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -162,7 +144,7 @@ def main():
                          "alg_bytes_per_read": B_ALG_PER_READ, "reads_per_launch": reads_per_launch,
                          "avg_launch_ms": search_s * 1e3,
                          "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1)},
-            "stats_last_run": st,
+            "stats_last_step": st,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prg, reads, seeds)

@@ -683,6 +683,17 @@ int gmx_engine_reset(gmx_engine *e) {
   return GMX_OK;
 }
 
+int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIP_TRY(hipMemsetAsync(e->d_allele_sum, 0, std::max<size_t>(e->n_allele, 1) * 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_per_base, 0, std::max<size_t>(e->n_pb, 1) * 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_stats, 0, 8 * 8, st));
+  HIP_TRY(hipMemsetAsync(e->d_log_cursor, 0, 16, st));
+  return GMX_OK;
+}
+
 static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                         uint64_t n_reads, uint64_t total_bases, hipStream_t stream) {
   if (n_reads == 0) return GMX_OK;

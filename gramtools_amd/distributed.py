@@ -81,3 +81,30 @@ def gpu_map_shard(index, device=0, rng_mode=0):
                     stats=np.array([s.all_reads_count, s.skipped_reads_count, s.missing_kmer_reads_count,
                                     s.no_extension_reads_count, s.exact_mapped_reads_count], dtype=np.uint64))
     return run
+
+
+class _DevArray:
+    """Zero-copy view of a device allocation for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_coverage_tensors(qm):
+    """torch tensors ALIASING the engine's device accumulators (allele_sum, per_base, grouped as int32 views of
+    the uint32 totals; stats as int64). An in-place ``dist.all_reduce`` on them is the single exchange of the
+    multi-GPU path: afterwards every rank's engine holds the job-wide totals and ``qm.coverage()`` finalises them."""
+    import torch
+    dc = qm.device_coverage()
+    out = []
+    for ptr, n, ts in ((dc.allele_sum, dc.n_allele_sum, "<i4"), (dc.per_base, dc.n_per_base, "<i4"),
+                       (dc.grouped, dc.n_grouped, "<i4"), (dc.stats, dc.n_stats, "<i8")):
+        if n:
+            out.append(torch.as_tensor(_DevArray(ptr, n, ts), device="cuda"))
+    return out
+
+
+def allreduce_device_coverage(qm, dist):
+    """One RCCL all-reduce(sum) per flat coverage array, in place on the engine's accumulators."""
+    for t in device_coverage_tensors(qm):
+        dist.all_reduce(t)

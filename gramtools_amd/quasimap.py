@@ -313,8 +313,12 @@ class Quasimapper:
 
     __del__ = close
 
-    def reset(self):
-        check(self.lib.gmx_engine_reset(self.h))
+    def reset(self, stream=None):
+        """Zero coverage and statistics; with `stream` (a hipStream_t value) the memsets are enqueued, not awaited."""
+        if stream is None:
+            check(self.lib.gmx_engine_reset(self.h))
+        else:
+            check(self.lib.gmx_engine_reset_async(self.h, C.c_void_p(stream) if stream else None))
 
     def map_reads(self, reads_flat, offsets, seeds):
         """Host buffers: forward + reverse-complement mapping of every read (quasimap.cpp:82-157)."""

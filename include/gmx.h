@@ -108,7 +108,8 @@ void gmx_engine_default_opts(gmx_engine_opts *opts);
  * Replaces coverage::generate::empty_structure (coverage_common.cpp:206-213). */
 int gmx_engine_create(const gmx_index *ix, const gmx_engine_opts *opts, gmx_engine **out);
 void gmx_engine_destroy(gmx_engine *e);
-int gmx_engine_reset(gmx_engine *e); /* zero coverage + statistics */
+int gmx_engine_reset(gmx_engine *e); /* zero coverage + statistics (synchronises the device) */
+int gmx_engine_reset_async(gmx_engine *e, void *hip_stream); /* the same, enqueued on hip_stream */
 
 /* Quasimap a batch of reads, forward and reverse complement (replaces handle_reads_buffer +
  * quasimap_forward_reverse + quasimap_read, quasimap.cpp:82-194).

@@ -185,3 +185,33 @@ def test_full_size_properties_mtb_scale():
     # every mapped read crossing a site adds exactly one grouped count per level-0 site it covers, and
     # allele-sum totals dominate grouped totals (a group holds >= 1 allele)
     assert int(ca.raw_allele_sum.sum()) >= int(ca.raw_grouped.sum()) > 0
+
+
+def test_device_accumulators_alias_as_torch_tensors_and_allreduce_in_place():
+    """The multi-GPU exchange: torch tensors aliasing the engine's accumulators, RCCL all-reduce in place
+    (world_size 1 here: the mechanics, not the scaling)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from gramtools_amd.distributed import device_coverage_tensors, allreduce_device_coverage
+    prg, reads = _snp_workload(20000, 250, 2000, 33)
+    seeds = master_seeds(5, [2000])
+    qm = Quasimapper(Index(prg, 7))
+    qm.map_reads(reads.reshape(-1), flat_offsets(2000, 150), seeds)
+    before = qm.coverage()
+    ts = device_coverage_tensors(qm)
+    assert ts[0].cpu().numpy().astype(np.uint32).tolist() == before.raw_allele_sum.tolist()
+    assert ts[1].cpu().numpy().astype(np.uint32).tolist() == before.raw_per_base.tolist()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        allreduce_device_coverage(qm, dist)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    after = qm.coverage()
+    assert canonical_cov(after) == canonical_cov(before)
+    ts[0].add_(1)  # aliasing, not a copy: a write through the tensor is seen by the engine
+    torch.cuda.synchronize()
+    assert (qm.coverage().raw_allele_sum == before.raw_allele_sum + 1).all()
