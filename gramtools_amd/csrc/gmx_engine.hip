@@ -11,7 +11,9 @@
 //
 // Kernels:
 //   gmx_validate_kernel  reads with a non-ACGT byte are flagged (encode_dna_bases, utils.cpp:73-92)
-//   gmx_search_kernel    search_read_backwards (quasimap.cpp:227-256), LDS state pools
+//   gmx_probe_kernel     seed lookup + first GMX_PROBE_STEPS bases of search_read_backwards (quasimap.cpp:227-256)
+//   gmx_extend_kernel    the rest of the read for the compacted survivors (the dominant kernel)
+//   gmx_filter_kernel    all_read_kmers_occur_in_index for tasks without final state (quasimap.cpp:212-225)
 //   gmx_search_big_kernel  the same for reads that overflowed the LDS pools (global-memory pools)
 //   gmx_cover_kernel     coverage::record::search_states (coverage_common.cpp:179-197)
 //   gmx_stats_kernel     QuasimapReadsStats counters (quasimap.hpp:17-24)
@@ -180,17 +182,24 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx) {
   }
 }
 
-// search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel)
+// search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel):
+// extend the pool by oriented bases i = from-1 ... to (right to left). Returns the next index to process.
+template <class Ctx>
+__device__ uint32_t extend_range(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx, uint32_t from, uint32_t to) {
+  uint32_t i = from;
+  while (i > to) {
+    if (ctx.n_states() == 0 || ctx.status != GMX_TASK_MAPPED) break;
+    --i;
+    gmx_extend(ix, r.at(i), ctx);
+  }
+  return i;
+}
 template <class Ctx>
 __device__ void search_task(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx) {
   const uint32_t k = ix.kmer_size;
   load_seed(ix, kmer_code(r, r.len - k, k), ctx);
   if (ctx.status != GMX_TASK_MAPPED) return;
-  for (uint32_t i = r.len - k; i-- > 0;) {
-    if (ctx.n_states() == 0) break;
-    gmx_extend(ix, r.at(i), ctx);
-    if (ctx.status != GMX_TASK_MAPPED) return;
-  }
+  extend_range(ix, r, ctx, r.len - k, 0);
 }
 
 struct BatchView {
@@ -210,8 +219,10 @@ struct SearchOut {
   uint32_t *mapped_list;     // task ids with final states (bit 31 = big-pass slot index instead)
   uint32_t *overflow_list;   // task ids to re-run with large capacities
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
+  uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
+  uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
-                             // [4] = n cover_overflow_list
+                             // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
 };
 
 __device__ __forceinline__ void wave_append(uint32_t *list, uint32_t *counter, bool want, uint32_t value) {
@@ -225,50 +236,121 @@ __device__ __forceinline__ void wave_append(uint32_t *list, uint32_t *counter, b
   if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_search_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
-  uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
-  uint32_t n_tasks = b.n_reads * 2;
-  bool active = task < n_tasks;
-  uint32_t status = GMX_TASK_SKIPPED;
-  uint32_t nf = 0;
-  if (active) {
-    uint32_t read = task >> 1;
-    uint64_t off = b.offsets[read];
-    ReadRef r;
-    r.p = b.reads + off;
-    r.len = (uint32_t)(b.offsets[read + 1] - off);
-    r.rc = task & 1;
-    if (b.forward_only && r.rc) {
-      status = GMX_STATUS_IGNORED;
-    } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
-      FastCtx ctx;
-      ctx.n = 0;
-      ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
-      ctx.arena_n = 0;
-      ctx.status = GMX_TASK_MAPPED;
-      search_task(ix, r, ctx);
-      status = ctx.status;
-      if (status == GMX_TASK_MAPPED) {
-        nf = ctx.n;
-        if (nf == 0) {
-          status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
-        } else {
-          for (uint32_t s = 0; s < nf; ++s) {
-            GmxFinalState f;
-            ctx.get(s, f.lo, f.hi, f.traversed, f.traversing);
-            o.finals[(size_t)task * GMX_FAST_STATES + s] = f;
-          }
+__device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
+  uint32_t read = task >> 1;
+  uint64_t off = b.offsets[read];
+  ReadRef r;
+  r.p = b.reads + off;
+  r.len = (uint32_t)(b.offsets[read + 1] - off);
+  r.rc = task & 1;
+  return r;
+}
+
+// Common epilogue of the probe and extend kernels: park / publish the lane's states and queue the task.
+//   done  : the whole read has been consumed (states are final)
+__device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uint32_t task, FastCtx &ctx, uint32_t status,
+                                            bool done) {
+  bool mapped = false, alive = false, dead = false, over = false;
+  if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
+    if (status == GMX_TASK_MAPPED) {
+      if (ctx.n == 0)
+        dead = true;
+      else {
+        for (uint32_t s = 0; s < ctx.n; ++s) {
+          GmxFinalState f;
+          ctx.get(s, f.lo, f.hi, f.traversed, f.traversing);
+          o.finals[(size_t)task * GMX_FAST_STATES + s] = f;
         }
+        o.n_final[task] = ctx.n | (ctx.arena_n << 8);
+        mapped = done;
+        alive = !done;
       }
-    }
-    o.status[task] = status;
-    o.n_final[task] = nf;
-    if (status == GMX_TASK_ERROR) {
-      if (atomicCAS(&o.counters[2], 0u, status) == 0u) o.counters[3] = task;
+    } else if (status == GMX_TASK_OVERFLOW) {
+      over = true;
+    } else if (atomicCAS(&o.counters[2], 0u, status) == 0u) {
+      o.counters[3] = task;
     }
   }
-  wave_append(o.mapped_list, &o.counters[0], active && status == GMX_TASK_MAPPED && nf > 0, task);
-  wave_append(o.overflow_list, &o.counters[1], active && status == GMX_TASK_OVERFLOW, task);
+  if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
+    o.status[task] = status;
+  wave_append(o.mapped_list, &o.counters[0], mapped, task);
+  wave_append(o.overflow_list, &o.counters[1], over, task);
+  wave_append(o.alive_list, &o.counters[5], alive, task);
+  wave_append(o.dead_list, &o.counters[6], dead, task);
+}
+
+#define GMX_PROBE_STEPS 6  // bases extended by the probe phase; a wrong-orientation task survives them with p ~ 1e-3
+
+// Phase 1 — every (read, orientation): seed lookup + the first GMX_PROBE_STEPS extensions. Half of the tasks
+// (the orientation that does not map) die here; the survivors are compacted for the main phase.
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+  uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  bool active = task < b.n_reads * 2;
+  uint32_t status = GMX_TASK_SKIPPED;
+  bool done = false;
+  FastCtx ctx;
+  ctx.n = 0;
+  ctx.arena_n = 0;
+  ctx.status = GMX_TASK_MAPPED;
+  ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  if (active) {
+    ReadRef r = task_read(b, task);
+    if (b.forward_only && r.rc) {
+      status = GMX_STATUS_IGNORED;
+    } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
+      const uint32_t k = ix.kmer_size;
+      load_seed(ix, kmer_code(r, r.len - k, k), ctx);
+      uint32_t from = r.len - k;
+      uint32_t to = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
+      uint32_t at = from;
+      if (ctx.status == GMX_TASK_MAPPED) at = extend_range(ix, r, ctx, from, to);
+      status = ctx.status;
+      done = to == 0 && at == 0;
+    }
+  }
+  finish_lane(o, active, task, ctx, status, done);
+}
+
+// Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+  uint32_t n_alive = o.counters[5];
+  if (blockIdx.x * GMX_BLOCK >= n_alive) return;
+  uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  bool active = slot < n_alive;
+  uint32_t task = active ? o.alive_list[slot] : 0;
+  uint32_t status = GMX_TASK_MAPPED;
+  FastCtx ctx;
+  ctx.n = 0;
+  ctx.arena_n = 0;
+  ctx.status = GMX_TASK_MAPPED;
+  ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  if (active) {
+    ReadRef r = task_read(b, task);
+    uint32_t packed = o.n_final[task];
+    uint32_t n = packed & 0xFF;
+    ctx.arena_n = packed >> 8;
+    for (uint32_t s = 0; s < n; ++s) {
+      GmxFinalState f = o.finals[(size_t)task * GMX_FAST_STATES + s];
+      ctx.put(s, f.lo, f.hi, f.traversed, f.traversing);
+    }
+    ctx.n = n;
+    uint32_t from = r.len - ix.kmer_size - GMX_PROBE_STEPS;  // alive tasks have more than GMX_PROBE_STEPS bases left
+    extend_range(ix, r, ctx, from, 0);
+    status = ctx.status;
+  }
+  finish_lane(o, active, task, ctx, status, true);
+}
+
+// Phase 3 — tasks without a final state: all_read_kmers_occur_in_index decides between the
+// missing_kmer and no_extension counters (quasimap.cpp:168-186); it never affects coverage.
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+  uint32_t n_dead = o.counters[6];
+  if (blockIdx.x * GMX_BLOCK >= n_dead) return;
+  uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (slot >= n_dead) return;
+  uint32_t task = o.dead_list[slot];
+  ReadRef r = task_read(b, task);
+  o.status[task] = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
 }
 
 struct BigOut {
@@ -393,7 +475,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       arena = g.arena + (size_t)slot * g.max_path_nodes;
     } else {
       task = entry;
-      nf = o.n_final[task];
+      nf = o.n_final[task] & 0xFF;
       finals = o.finals + (size_t)task * GMX_FAST_STATES;
       arena = o.arena + (size_t)task * GMX_FAST_ARENA;
     }
@@ -518,6 +600,7 @@ struct gmx_engine {
   uint64_t cap_reads = 0;
   uint8_t *d_skip = nullptr;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
+  uint32_t *d_alive = nullptr, *d_dead = nullptr;
   GmxFinalState *d_finals = nullptr;
   GmxPathNode *d_arena = nullptr;
   BigOut big{};
@@ -531,7 +614,7 @@ struct gmx_engine {
   hipStream_t last_stream = nullptr;
   // optional HIP-event timing of the kernels (bench.py roofline leg)
   bool timing = false;
-  struct EvTriple { hipEvent_t a, b, c; uint64_t reads; };
+  struct EvTriple { hipEvent_t s, a, b, c; uint64_t reads; };
   std::vector<EvTriple> pending;
   double search_ms = 0, cover_ms = 0;
   uint64_t search_launches = 0, cover_launches = 0, timed_reads = 0;
@@ -581,6 +664,8 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_mapped, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
   e->cap_reads = cap;
@@ -641,7 +726,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
   rc |= e->alloc(&e->d_log_cursor, 4, true);
-  rc |= e->alloc(&e->d_counters, 8, true);
+  rc |= e->alloc(&e->d_counters, 16, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
@@ -679,7 +764,7 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
   HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
   HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
-  HIP_TRY(hipMemset(e->d_counters, 0, 32));
+  HIP_TRY(hipMemset(e->d_counters, 0, 64));
   return GMX_OK;
 }
 
@@ -704,11 +789,12 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
-  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow, e->d_counters};
+  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow,
+              e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 12, stream));
   HIP_TRY(hipMemsetAsync(e->d_skip, 0, n_reads, stream));
   {
     uint64_t chunks = (total_bases + 15) / 16 + 2;
@@ -718,16 +804,20 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
+    HIP_TRY(hipEventCreate(&ev.s));
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventCreate(&ev.c));
     ev.reads = n_reads;
-    HIP_TRY(hipEventRecord(ev.a, stream));
+    HIP_TRY(hipEventRecord(ev.s, stream));
   }
-  hipLaunchKernelGGL(gmx_search_kernel, dim3((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK), dim3(GMX_BLOCK), lds, stream,
-                     e->dview, b, o);
+  dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
+  hipLaunchKernelGGL(gmx_probe_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
+  hipLaunchKernelGGL(gmx_extend_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, stream, e->dview, b, o, e->big);
+  hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
   CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
                e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, false>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
@@ -844,14 +934,16 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
   HIP_TRY(hipSetDevice(e->opts.device));
   for (auto &ev : e->pending) {
     HIP_TRY(hipEventSynchronize(ev.c));
-    float ms1 = 0, ms2 = 0;
+    float ms0 = 0, ms1 = 0, ms2 = 0;
+    HIP_TRY(hipEventElapsedTime(&ms0, ev.s, ev.a));
     HIP_TRY(hipEventElapsedTime(&ms1, ev.a, ev.b));
     HIP_TRY(hipEventElapsedTime(&ms2, ev.b, ev.c));
     e->search_ms += ms1;
-    e->cover_ms += ms2;
+    e->cover_ms += ms0 + ms2;
     e->search_launches++;
     e->cover_launches++;
     e->timed_reads += ev.reads;
+    (void)hipEventDestroy(ev.s);
     (void)hipEventDestroy(ev.a);
     (void)hipEventDestroy(ev.b);
     (void)hipEventDestroy(ev.c);

@@ -134,8 +134,8 @@ int gmx_engine_sync(gmx_engine *e);
  * the last call and resets them. */
 int gmx_engine_enable_timing(gmx_engine *e, int on);
 typedef struct gmx_timing {
-  double search_ms;  uint64_t search_launches;   /* gmx_search_kernel (the dominant kernel) */
-  double cover_ms;   uint64_t cover_launches;    /* big-pass search + both coverage kernels + stats */
+  double search_ms;  uint64_t search_launches;   /* gmx_extend_kernel (the dominant kernel) */
+  double cover_ms;   uint64_t cover_launches;    /* everything else: validate, probe, big pass, filter, coverage, stats */
   uint64_t reads;                                /* reads covered by those launches */
 } gmx_timing;
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
