@@ -10,7 +10,7 @@
 // the seeded class selection and the coverage atomics.
 //
 // Kernels:
-//   gmx_validate_kernel  reads with a non-ACGT byte are flagged (encode_dna_bases, utils.cpp:73-92)
+//   gmx_pack_kernel      flags reads with a non-ACGT byte (encode_dna_bases, utils.cpp:73-92) and packs bases to 2 bits
 //   gmx_probe_kernel     seed lookup + first GMX_PROBE_STEPS bases of search_read_backwards (quasimap.cpp:227-256)
 //   gmx_extend_kernel    the rest of the read for the compacted survivors (the dominant kernel)
 //   gmx_filter_kernel    all_read_kmers_occur_in_index for tasks without final state (quasimap.cpp:212-225)
@@ -41,11 +41,20 @@
 // read access: oriented base i of task (read r, orientation o)
 // ---------------------------------------------------------------------------
 struct ReadRef {
-  const uint8_t *p;
+  const uint32_t *w;   // 2-bit packed bases (A,C,G,T = 0..3), 16 per dword, this read's first dword
   uint32_t len;
   bool rc;
-  __device__ __forceinline__ uint32_t at(uint32_t i) const {
-    return rc ? 5u - (uint32_t)p[len - 1 - i] : (uint32_t)p[i];  // reverse_complement_read, quasimap.cpp:273-298
+  uint32_t cur_idx;    // index of the cached dword (0xFFFFFFFF = none)
+  uint32_t cur;        // cached dword: the walk is sequential, so one load serves 16 steps
+  __device__ __forceinline__ uint32_t at(uint32_t i) {
+    uint32_t idx = rc ? len - 1 - i : i;  // reverse_complement_read, quasimap.cpp:273-298
+    uint32_t wi = idx >> 4;
+    if (wi != cur_idx) {
+      cur = w[wi];
+      cur_idx = wi;
+    }
+    uint32_t code = (cur >> ((idx & 15u) * 2u)) & 3u;
+    return rc ? 4u - code : code + 1u;
   }
 };
 
@@ -131,14 +140,14 @@ struct BigCtx {  // states and arena in global memory, runtime capacities
 };
 
 // k-mer code of oriented positions [start, start + k): leftmost base most significant
-__device__ __forceinline__ uint32_t kmer_code(const ReadRef &r, uint32_t start, uint32_t k) {
+__device__ __forceinline__ uint32_t kmer_code(ReadRef &r, uint32_t start, uint32_t k) {
   uint32_t code = 0;
   for (uint32_t j = 0; j < k; ++j) code = (code << 2) | (r.at(start + j) - 1u);
   return code;
 }
 
 // all_read_kmers_occur_in_index (quasimap.cpp:212-225)
-__device__ bool all_kmers_present(const GmxIndexView &ix, const ReadRef &r) {
+__device__ bool all_kmers_present(const GmxIndexView &ix, ReadRef &r) {
   const uint32_t k = ix.kmer_size;
   const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
   uint32_t code = kmer_code(r, 0, k);
@@ -185,7 +194,7 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx) {
 // search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel):
 // extend the pool by oriented bases i = from-1 ... to (right to left). Returns the next index to process.
 template <class Ctx>
-__device__ uint32_t extend_range(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx, uint32_t from, uint32_t to) {
+__device__ uint32_t extend_range(const GmxIndexView &ix, ReadRef &r, Ctx &ctx, uint32_t from, uint32_t to) {
   uint32_t i = from;
   while (i > to) {
     if (ctx.n_states() == 0 || ctx.status != GMX_TASK_MAPPED) break;
@@ -195,7 +204,7 @@ __device__ uint32_t extend_range(const GmxIndexView &ix, const ReadRef &r, Ctx &
   return i;
 }
 template <class Ctx>
-__device__ void search_task(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx) {
+__device__ void search_task(const GmxIndexView &ix, ReadRef &r, Ctx &ctx) {
   const uint32_t k = ix.kmer_size;
   load_seed(ix, kmer_code(r, r.len - k, k), ctx);
   if (ctx.status != GMX_TASK_MAPPED) return;
@@ -203,13 +212,17 @@ __device__ void search_task(const GmxIndexView &ix, const ReadRef &r, Ctx &ctx) 
 }
 
 struct BatchView {
-  const uint8_t *reads;
+  const uint8_t *reads;      // caller's buffer: one byte per base
   const uint64_t *offsets;
   const uint32_t *seeds;
-  const uint8_t *skip;   // per read
+  const uint8_t *skip;       // per read: holds a non-ACGT byte
+  const uint32_t *packed;    // 2-bit packed copy written by gmx_pack_kernel; read r starts at dword pack_off(r)
   uint32_t n_reads;
   uint32_t forward_only;
 };
+__device__ __forceinline__ uint64_t pack_off(const BatchView &b, uint32_t read) {
+  return ((b.offsets[read] - b.offsets[0]) >> 4) + read;  // ceil(len/16) dwords fit between consecutive starts
+}
 
 struct SearchOut {
   uint32_t *status;          // per task
@@ -238,11 +251,12 @@ __device__ __forceinline__ void wave_append(uint32_t *list, uint32_t *counter, b
 
 __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
   uint32_t read = task >> 1;
-  uint64_t off = b.offsets[read];
   ReadRef r;
-  r.p = b.reads + off;
-  r.len = (uint32_t)(b.offsets[read + 1] - off);
+  r.w = b.packed + pack_off(b, read);
+  r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
   r.rc = task & 1;
+  r.cur_idx = 0xFFFFFFFFu;
+  r.cur = 0;
   return r;
 }
 
@@ -370,12 +384,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       if (atomicCAS(&o.counters[2], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3] = task;
       continue;
     }
-    uint32_t read = task >> 1;
-    uint64_t off = b.offsets[read];
-    ReadRef r;
-    r.p = b.reads + off;
-    r.len = (uint32_t)(b.offsets[read + 1] - off);
-    r.rc = task & 1;
+    ReadRef r = task_read(b, task);
     BigCtx ctx;
     ctx.n = 0;
     ctx.st = g.states + (size_t)slot * g.max_states;
@@ -536,41 +545,42 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
-// Reads holding a byte outside 1..4 are skipped as a whole (encode_dna_bases, utils.cpp:73-92).
-// Coalesced: each lane checks 16 consecutive bytes of the concatenated buffer; the (rare) offender looks up
-// its read by binary search over the offsets.
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_validate_kernel(BatchView b, uint8_t *skip) {
-  uint64_t begin = b.offsets[0], end = b.offsets[b.n_reads];
-  uint64_t base = (begin & ~15ull) + ((uint64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * 16ull;
-  if (base >= end) return;
-  uint32_t bad_mask = 0;
-  if (base >= begin && base + 16 <= end && (((uintptr_t)(b.reads + base)) & 15) == 0) {
-    uint4 v = *reinterpret_cast<const uint4 *>(b.reads + base);
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+// Validation + 2-bit packing, one lane per read. Reads holding a byte outside 1..4 are skipped as a whole
+// (encode_dna_bases, utils.cpp:73-92). The search kernels then fetch 16 bases per dword load instead of one
+// byte per step (the per-step byte loads of 64 different reads thrashed L1 and L2: one L2 miss per lane-step).
+typedef uint32_t __attribute__((aligned(1))) gmx_u32_unaligned;
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_pack_kernel(BatchView b, uint8_t *skip, uint32_t *packed) {
+  uint32_t read = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (read >= b.n_reads) return;
+  uint64_t s = b.offsets[read], e = b.offsets[read + 1];
+  uint32_t len = (uint32_t)(e - s);
+  const uint8_t *p = b.reads + s;
+  uint32_t *out = packed + pack_off(b, read);
+  uint32_t bad = 0;
+  uint32_t full = len >> 4;
+  for (uint32_t c = 0; c < full; ++c) {
+    uint32_t word = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      // a byte is valid iff 1 <= x <= 4  <=>  (x - 1) < 4 : test bits 2..7 of (x - 1) per byte, and no borrow
-      uint32_t x = w[j];
-      uint32_t zero = (x - 0x01010101u) & ~x & 0x80808080u;  // bytes equal to 0
-      uint32_t big = ((x - 0x01010101u) & 0xFCFCFCFCu);      // (x-1) >= 4 for some byte (valid when no byte is 0)
-      if (zero | big) bad_mask |= 1u << j;
+      uint32_t x = *reinterpret_cast<const gmx_u32_unaligned *>(p + c * 16 + j * 4);
+      uint32_t y = x - 0x01010101u;                       // per-byte code 0..3 when every byte is in 1..4
+      bad |= ((y & ~x & 0x80808080u) | (y & 0xFCFCFCFCu));  // a zero byte, or a byte > 4
+      uint32_t q = (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;  // 4 x 2 bits
+      word |= q << (8 * j);
     }
-  } else {
-    bad_mask = 0xF;  // ragged edge: fall through to the byte loop
+    out[c] = word;
   }
-  if (!bad_mask) return;
-  for (uint32_t j = 0; j < 16; ++j) {
-    uint64_t p = base + j;
-    if (p < begin || p >= end) continue;
-    uint8_t x = b.reads[p];
-    if (x >= 1 && x <= 4) continue;
-    uint32_t lo = 0, hi = b.n_reads;  // last read with offsets[r] <= p
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (b.offsets[mid] <= p) lo = mid; else hi = mid;
+  uint32_t rem = len & 15u;
+  if (rem) {
+    uint32_t word = 0;
+    for (uint32_t j = 0; j < rem; ++j) {
+      uint32_t x = p[full * 16 + j];
+      if (x < 1 || x > 4) bad = 1;
+      word |= ((x - 1u) & 3u) << (2 * j);
     }
-    skip[lo] = 1;
+    out[full] = word;
   }
+  skip[read] = bad ? 1 : 0;
 }
 
 // ===========================================================================
@@ -599,6 +609,8 @@ struct gmx_engine {
   // batch workspace (sized for max_batch_reads)
   uint64_t cap_reads = 0;
   uint8_t *d_skip = nullptr;
+  uint32_t *d_packed = nullptr;
+  uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr;
   GmxFinalState *d_finals = nullptr;
@@ -788,19 +800,23 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
-  BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
+  {
+    uint64_t need = total_bases / 16 + n_reads + 16;
+    if (need > e->cap_packed) {
+      rc = e->alloc(&e->d_packed, need, false);
+      if (rc) return rc;
+      e->cap_packed = need;
+    }
+  }
+  BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow,
               e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8, stream));
   HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 12, stream));
-  HIP_TRY(hipMemsetAsync(e->d_skip, 0, n_reads, stream));
-  {
-    uint64_t chunks = (total_bases + 15) / 16 + 2;
-    hipLaunchKernelGGL(gmx_validate_kernel, dim3((unsigned)((chunks + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0,
-                       stream, b, e->d_skip);
-  }
+  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0, stream, b,
+                     e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
