@@ -157,29 +157,29 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     if (!nested(enc_site, enc_allele)) return 0xFFFFFFFFu;
   } else {
     // check_site_uniqueness over traversed + traversing
-    for (uint32_t x = tvd; x != GMX_NIL; x = env.arena[x].next) {
-      uint32_t sx = env.arena[x].site;
-      for (uint32_t y = env.arena[x].next; y != GMX_NIL; y = env.arena[y].next)
-        if (env.arena[y].site == sx) {
+    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
+      uint32_t sx = gmx_h_site(env.arena, x);
+      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
-      for (uint32_t y = tvg; y != GMX_NIL; y = env.arena[y].next)
-        if (env.arena[y].site == sx) {
+      for (uint32_t y = tvg; y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
     }
-    for (uint32_t x = tvg; x != GMX_NIL; x = env.arena[x].next) {
-      uint32_t sx = env.arena[x].site;
-      for (uint32_t y = env.arena[x].next; y != GMX_NIL; y = env.arena[y].next)
-        if (env.arena[y].site == sx) {
+    for (uint32_t x = tvg; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
+      uint32_t sx = gmx_h_site(env.arena, x);
+      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
     }
     if (tvg != GMX_NIL) {  // assign_traversing_loci, coverage_common.cpp:53-76
-      uint32_t parent_seed = env.arena[tvg].site;
+      uint32_t parent_seed = gmx_h_site(env.arena, tvg);
       int32_t last_allele = -1;
       for (uint32_t i = lo;; ++i) {
         uint32_t p = ix.sa[i];
@@ -195,11 +195,11 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     // assign_traversed_loci (:78-83): push order = oldest first; the list head is the newest.
     // Process oldest-first by walking to each depth (paths are short).
     uint32_t len = 0;
-    for (uint32_t x = tvd; x != GMX_NIL; x = env.arena[x].next) ++len;
+    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) ++len;
     for (uint32_t d = len; d-- > 0;) {
       uint32_t x = tvd;
-      for (uint32_t s = 0; s < d; ++s) x = env.arena[x].next;
-      if (!nested(env.arena[x].site, env.arena[x].allele)) return 0xFFFFFFFFu;
+      for (uint32_t s = 0; s < d; ++s) x = gmx_h_next(env.arena, x);
+      if (!nested(gmx_h_site(env.arena, x), gmx_h_allele(env.arena, x))) return 0xFFFFFFFFu;
     }
   }
   return n;
@@ -308,8 +308,8 @@ GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  
       w.bad = true;
       return;
     }
-    allele = env.arena[w.cursor].allele;
-    w.cursor = env.arena[w.cursor].next;
+    allele = gmx_h_allele(env.arena, w.cursor);
+    w.cursor = gmx_h_next(env.arena, w.cursor);
   }
   if (allele < 0 || (uint32_t)allele >= ne) {
     w.bad = true;

@@ -28,11 +28,14 @@
 #include "../../include/gmx.h"
 #include "gmx_core.h"
 #include "gmx_cover.h"
+#include "gmx_dfs.h"
 #include "gmx_index.h"
 #include "gmx_internal.h"
 
 #define GMX_BLOCK 256
-#define GMX_FAST_STATES 8     // LDS state slots per lane (k-mer seeds of short k carry several states)
+#define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
+#define GMX_STACK_DEPTH 6     // pending entries (sibling states, unresolved marker hits) per lane, in LDS
+#define GMX_STACK_WORDS 5
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
@@ -63,40 +66,59 @@ struct ReadRef {
 // ---------------------------------------------------------------------------
 extern __shared__ uint32_t gmx_lds[];
 
-struct FastCtx {  // states in LDS, arena in global memory
-  uint32_t n;
+struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path arena and emitted states in global memory
+  uint32_t sp;
   GmxPathNode *arena;
   uint32_t arena_n;
   uint32_t status;
-  __device__ __forceinline__ uint32_t n_states() const { return n; }
-  __device__ __forceinline__ void set_n_states(uint32_t v) { n = v; }
-  __device__ __forceinline__ void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
-    const uint32_t *b = gmx_lds + (s * 4) * GMX_BLOCK + threadIdx.x;
-    lo = b[0];
-    hi = b[GMX_BLOCK];
-    tvd = b[2 * GMX_BLOCK];
-    tvg = b[3 * GMX_BLOCK];
-  }
-  __device__ __forceinline__ void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-    uint32_t *b = gmx_lds + (s * 4) * GMX_BLOCK + threadIdx.x;
-    b[0] = lo;
-    b[GMX_BLOCK] = hi;
-    b[2 * GMX_BLOCK] = tvd;
-    b[3 * GMX_BLOCK] = tvg;
-  }
-  __device__ __forceinline__ bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-    if (n >= GMX_FAST_STATES) return false;
-    put(n, lo, hi, tvd, tvg);
-    ++n;
+  GmxFinalState *out;
+  uint32_t n_out, out_cap;
+  __device__ __forceinline__ bool pop(uint32_t &a, uint32_t &b, uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    if (sp == 0) return false;
+    --sp;
+    const uint32_t *e = gmx_lds + (sp * GMX_STACK_WORDS) * GMX_BLOCK + threadIdx.x;
+    a = e[0];
+    b = e[GMX_BLOCK];
+    tvd = e[2 * GMX_BLOCK];
+    tvg = e[3 * GMX_BLOCK];
+    uint32_t pm = e[4 * GMX_BLOCK];
+    pos = pm & 0x3FFFFFFFu;
+    mode = pm >> 30;
     return true;
   }
-  __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+  __device__ __forceinline__ bool push(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
+    if (sp >= GMX_STACK_DEPTH) return false;
+    uint32_t *e = gmx_lds + (sp * GMX_STACK_WORDS) * GMX_BLOCK + threadIdx.x;
+    e[0] = a;
+    e[GMX_BLOCK] = b;
+    e[2 * GMX_BLOCK] = tvd;
+    e[3 * GMX_BLOCK] = tvg;
+    e[4 * GMX_BLOCK] = pos | (mode << 30);
+    ++sp;
+    return true;
+  }
+  __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n_out >= out_cap) return false;
+    out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
+    return true;
+  }
+  __device__ __forceinline__ uint32_t alloc_node(uint32_t site, int32_t allele, uint32_t next) {
     if (arena_n >= GMX_FAST_ARENA) return GMX_NIL;
     arena[arena_n] = GmxPathNode{site, allele, next};
     return arena_n++;
   }
-  __device__ __forceinline__ uint32_t arena_site(uint32_t node) const { return arena[node].site; }
-  __device__ __forceinline__ uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    if (allele == -1) {  // traversing path: a single entered site stays inline in the handle (no node, no load to pop)
+      if (next == GMX_NIL) return GMX_INLINE_FLAG | ((site - 5u) >> 1);
+      if (gmx_h_inline(next)) {
+        next = alloc_node(gmx_h_site(arena, next), -1, GMX_NIL);
+        if (next == GMX_NIL) return GMX_NIL;
+      }
+    }
+    return alloc_node(site, allele, next);
+  }
+  __device__ __forceinline__ uint32_t arena_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ uint32_t arena_next(uint32_t h) const { return gmx_h_next(arena, h); }
   __device__ __forceinline__ void fail(uint32_t s) {
     if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
   }
@@ -159,12 +181,13 @@ __device__ bool all_kmers_present(const GmxIndexView &ix, ReadRef &r) {
   return true;
 }
 
-// seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241)
-template <class Ctx>
-__device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx) {
+// seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241);
+// push(lo, hi, tvd, tvg) receives every seed state
+template <class Ctx, class Push>
+__device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push push) {
   GmxSeed s = ix.seeds[code];
   if (s.a != GMX_SEED_COMPLEX) {
-    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL);
+    if (s.a <= s.b) push(s.a, s.b, GMX_NIL, GMX_NIL);
     return;
   }
   const uint32_t *p = ix.seed_words + s.b;
@@ -184,7 +207,7 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx) {
       uint32_t nn = ctx.arena_new(p[0], -1, tvg);
       if (nn == GMX_NIL) ok = false; else tvg = nn;
     }
-    if (!ok || !ctx.push(lo, hi, tvd, tvg)) {
+    if (!ok || !push(lo, hi, tvd, tvg)) {
       ctx.fail(GMX_TASK_OVERFLOW);
       return;
     }
@@ -206,7 +229,8 @@ __device__ uint32_t extend_range(const GmxIndexView &ix, ReadRef &r, Ctx &ctx, u
 template <class Ctx>
 __device__ void search_task(const GmxIndexView &ix, ReadRef &r, Ctx &ctx) {
   const uint32_t k = ix.kmer_size;
-  load_seed(ix, kmer_code(r, r.len - k, k), ctx);
+  load_seed(ix, kmer_code(r, r.len - k, k), ctx,
+            [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { return ctx.push(lo, hi, tvd, tvg); });
   if (ctx.status != GMX_TASK_MAPPED) return;
   extend_range(ix, r, ctx, r.len - k, 0);
 }
@@ -260,22 +284,17 @@ __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) 
   return r;
 }
 
-// Common epilogue of the probe and extend kernels: park / publish the lane's states and queue the task.
-//   done  : the whole read has been consumed (states are final)
+// Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
+//   done  : the whole read has been consumed (the emitted states are final, not parked)
 __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uint32_t task, FastCtx &ctx, uint32_t status,
                                             bool done) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
-      if (ctx.n == 0)
+      if (ctx.n_out == 0)
         dead = true;
       else {
-        for (uint32_t s = 0; s < ctx.n; ++s) {
-          GmxFinalState f;
-          ctx.get(s, f.lo, f.hi, f.traversed, f.traversing);
-          o.finals[(size_t)task * GMX_FAST_STATES + s] = f;
-        }
-        o.n_final[task] = ctx.n | (ctx.arena_n << 8);
+        o.n_final[task] = ctx.n_out | (ctx.arena_n << 8);
         mapped = done;
         alive = !done;
       }
@@ -296,30 +315,35 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
 #define GMX_PROBE_STEPS 6  // bases extended by the probe phase; a wrong-orientation task survives them with p ~ 1e-3
 
 // Phase 1 — every (read, orientation): seed lookup + the first GMX_PROBE_STEPS extensions. Half of the tasks
-// (the orientation that does not map) die here; the survivors are compacted for the main phase.
+// (the orientation that does not map) die here; the survivors are parked and compacted for the main phase.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = task < b.n_reads * 2;
   uint32_t status = GMX_TASK_SKIPPED;
   bool done = false;
   FastCtx ctx;
-  ctx.n = 0;
+  ctx.sp = 0;
   ctx.arena_n = 0;
   ctx.status = GMX_TASK_MAPPED;
   ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
+  ctx.n_out = 0;
+  ctx.out_cap = GMX_STACK_DEPTH;  // parked states must fit the extend kernel's stack
   if (active) {
     ReadRef r = task_read(b, task);
     if (b.forward_only && r.rc) {
       status = GMX_STATUS_IGNORED;
     } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
       const uint32_t k = ix.kmer_size;
-      load_seed(ix, kmer_code(r, r.len - k, k), ctx);
-      uint32_t from = r.len - k;
-      uint32_t to = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
-      uint32_t at = from;
-      if (ctx.status == GMX_TASK_MAPPED) at = extend_range(ix, r, ctx, from, to);
+      const uint32_t from = r.len - k;
+      const uint32_t stop = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
+      load_seed(ix, kmer_code(r, from, k), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+        return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
+      });
+      if (ctx.status == GMX_TASK_MAPPED) gmx_dfs_run(ix, ctx, r, stop);
       status = ctx.status;
-      done = to == 0 && at == 0;
+      done = stop == 0;
+      if (done) ctx.out_cap = GMX_FAST_STATES;
     }
   }
   finish_lane(o, active, task, ctx, status, done);
@@ -334,22 +358,24 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   uint32_t task = active ? o.alive_list[slot] : 0;
   uint32_t status = GMX_TASK_MAPPED;
   FastCtx ctx;
-  ctx.n = 0;
+  ctx.sp = 0;
   ctx.arena_n = 0;
   ctx.status = GMX_TASK_MAPPED;
   ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
+  ctx.n_out = 0;
+  ctx.out_cap = GMX_FAST_STATES;
   if (active) {
     ReadRef r = task_read(b, task);
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
     ctx.arena_n = packed >> 8;
+    const uint32_t at = r.len - ix.kmer_size - GMX_PROBE_STEPS;  // parked tasks have more than GMX_PROBE_STEPS bases left
     for (uint32_t s = 0; s < n; ++s) {
-      GmxFinalState f = o.finals[(size_t)task * GMX_FAST_STATES + s];
-      ctx.put(s, f.lo, f.hi, f.traversed, f.traversing);
+      GmxFinalState f = ctx.out[s];
+      ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
     }
-    ctx.n = n;
-    uint32_t from = r.len - ix.kmer_size - GMX_PROBE_STEPS;  // alive tasks have more than GMX_PROBE_STEPS bases left
-    extend_range(ix, r, ctx, from, 0);
+    gmx_dfs_run(ix, ctx, r, 0);
     status = ctx.status;
   }
   finish_lane(o, active, task, ctx, status, true);
@@ -717,7 +743,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   GmxIndexView v = h.view();
   int rc = 0;
   rc |= e->upload(&v.blocks, h.blocks);
-  rc |= e->upload(&v.hit_prog, h.hit_prog);
+  rc |= e->upload(&v.hits, h.hits);
   rc |= e->upload(&v.prog, h.prog);
   rc |= e->upload(&v.sa, h.sa);
   rc |= e->upload(&v.pos_node, h.pos_node);
@@ -817,7 +843,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 12, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0, stream, b,
                      e->d_skip, e->d_packed);
-  size_t lds = (size_t)GMX_FAST_STATES * 4 * GMX_BLOCK * sizeof(uint32_t);
+  size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));

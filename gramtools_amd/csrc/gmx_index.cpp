@@ -440,7 +440,7 @@ GmxIndexView HostIndex::view() const {
   v.kmer_size = kmer_size;
   for (int i = 0; i < 8; ++i) v.C[i] = C[i];
   v.n_blocks = (uint32_t)blocks.size();
-  v.n_hits = (uint32_t)hit_prog.size();
+  v.n_hits = (uint32_t)hits.size();
   v.n_nodes = nodes.empty() ? 0 : (uint32_t)nodes.size() - 1;
   v.n_sites = (uint32_t)sites.size();
   v.n_allele_slots = n_allele_slots;
@@ -448,7 +448,7 @@ GmxIndexView HostIndex::view() const {
   v.n_grouped_slots = n_grouped_slots;
   v.is_nested = is_nested ? 1 : 0;
   v.blocks = blocks.data();
-  v.hit_prog = hit_prog.data();
+  v.hits = hits.data();
   v.prog = prog.data();
   v.sa = sa.data();
   v.pos_node = pos_node.data();
@@ -676,19 +676,55 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     prog_of[key] = off;
     return off;
   };
-  out.hit_prog.clear();
-  for (size_t i = 0; i < n; ++i) {
-    if (out.bwt[i] <= 4) continue;
-    uint32_t p = out.sa[i];
-    uint32_t off = 0;
-    if (p < N && prg[p] <= 4) {
-      // left_markers_search, vBWT_jump.cpp:94-117
-      uint32_t m = g.pos_target[p].first;
-      int32_t a = g.pos_target[p].second;
-      if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
-      off = make_program(m, a);
+  out.hits.clear();
+  {
+    GmxIndexView hv = out.view();  // blocks are in place: the LF steps below only need them and C[]
+    for (size_t i = 0; i < n; ++i) {
+      if (out.bwt[i] <= 4) continue;
+      uint32_t p = out.sa[i];
+      GmxHit hit;
+      memset(&hit, 0, sizeof(hit));
+      hit.kind = GMX_HIT_PROG;
+      hit.prog_off = 0;
+      if (p < N && prg[p] <= 4) {
+        // left_markers_search, vBWT_jump.cpp:94-117
+        uint32_t m = g.pos_target[p].first;
+        int32_t a = g.pos_target[p].second;
+        if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
+        hit.prog_off = make_program(m, a);
+        const uint32_t *pw = out.prog.data() + hit.prog_off;
+        if (pw[0] == 1 && pw[1] == 1) {  // one output, one op: pre-resolve it together with its LF step
+          uint32_t op = pw[2], site = pw[3], lo = pw[5], hi = pw[6];
+          hit.site = site;
+          hit.allele = (int32_t)pw[4];
+          if (op == GMX_OP_EXIT && lo == hi) {
+            hit.kind = GMX_HIT_EXIT;
+            uint32_t b0 = out.bwt[lo];
+            if (b0 >= 1 && b0 <= 4) {
+              uint32_t l2 = lo, h2 = hi;
+              const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
+              if (!gmx_lf(hv, b0, l2, h2, blk)) throw std::runtime_error("internal: exit LF precomputation failed");
+              hit.lf[0] = b0;
+              hit.lf[1] = l2;
+            }
+          } else if (op == GMX_OP_ENTER) {
+            hit.kind = GMX_HIT_ENTER;
+            for (uint32_t c = 1; c <= 4; ++c) {
+              uint32_t l2 = lo, h2 = hi;
+              const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
+              if (gmx_lf(hv, c, l2, h2, blk)) {
+                hit.lf[2 * (c - 1)] = l2;
+                hit.lf[2 * (c - 1) + 1] = h2;
+              } else {
+                hit.lf[2 * (c - 1)] = 1;
+                hit.lf[2 * (c - 1) + 1] = 0;
+              }
+            }
+          }
+        }
+      }
+      out.hits.push_back(hit);
     }
-    out.hit_prog.push_back(off);
   }
 
   // --- seed table ---------------------------------------------------------------------

@@ -73,6 +73,25 @@ struct GmxSeed {
 #define GMX_OP_EXIT 1u   // exiting_site_search_state / update_variant_site_path (vBWT_jump.cpp:51-92)
 #define GMX_OP_ENTER 2u  // entering_site_search_state (vBWT_jump.cpp:29-44)
 
+// Marker hit record, one 64-byte line per marker position of the BWT (indexed by marker rank).
+// `prog_off` always points at the general jump program; kind 1/2 additionally pre-resolve the two cases that make
+// up flat SNP/indel PRGs so that a hit costs one line fetch and no further dependent load:
+//   kind 1  single output, single op EXIT(site, allele) -> interval [x, x]; lf[0] = the base b preceding the site
+//           marker (0 if it is not a base), lf[1] = C[b] + rank_b(x): the state after the LF step with b
+//   kind 2  single output, single op ENTER(site) -> interval I; lf[2(c-1)], lf[2(c-1)+1] = LF(I, c) for c = 1..4
+//           (lo > hi when empty)
+struct alignas(64) GmxHit {
+  uint32_t kind;
+  uint32_t prog_off;
+  uint32_t site;
+  int32_t allele;
+  uint32_t lf[8];
+  uint32_t pad[4];
+};
+#define GMX_HIT_PROG 0u
+#define GMX_HIT_EXIT 1u
+#define GMX_HIT_ENTER 2u
+
 // The device/host view of the index. All pointers are device pointers on the GPU side.
 struct GmxIndexView {
   uint32_t n;             // text length including the sentinel (= BWT length)
@@ -89,7 +108,7 @@ struct GmxIndexView {
   uint32_t n_grouped_slots;  // dense grouped accumulator length
   uint32_t is_nested;
   const GmxRankBlock *blocks;
-  const uint32_t *hit_prog;   // [n_hits] program offset for the h-th marker position of the BWT
+  const GmxHit *hits;         // [n_hits] record of the h-th marker position of the BWT
   const uint32_t *prog;       // jump programs
   const uint32_t *sa;         // [n]
   const uint32_t *pos_node;   // [n_prg]
@@ -117,6 +136,16 @@ struct GmxPathNode {
   int32_t allele;
   uint32_t next;  // GMX_NIL terminates
 };
+
+// A list handle is either GMX_NIL, an arena node index (< 2^31), or — for the common one-element traversing
+// path of a flat PRG — the element itself, inline: GMX_INLINE_FLAG | site_index (no arena node, no load to pop it).
+#define GMX_INLINE_FLAG 0x80000000u
+GMX_HD bool gmx_h_inline(uint32_t h) { return h != GMX_NIL && (h & GMX_INLINE_FLAG) != 0; }
+GMX_HD uint32_t gmx_h_site(const GmxPathNode *arena, uint32_t h) {
+  return gmx_h_inline(h) ? 5u + 2u * (h & ~GMX_INLINE_FLAG) : arena[h].site;
+}
+GMX_HD int32_t gmx_h_allele(const GmxPathNode *arena, uint32_t h) { return gmx_h_inline(h) ? -1 : arena[h].allele; }
+GMX_HD uint32_t gmx_h_next(const GmxPathNode *arena, uint32_t h) { return gmx_h_inline(h) ? GMX_NIL : arena[h].next; }
 
 // Final-state record handed from the search kernel to the coverage kernel.
 struct GmxFinalState {

@@ -12,6 +12,7 @@
 
 #include "../../gramtools_amd/csrc/gmx_core.h"
 #include "../../gramtools_amd/csrc/gmx_cover.h"
+#include "../../gramtools_amd/csrc/gmx_dfs.h"
 #include "../../gramtools_amd/csrc/gmx_index.h"
 
 namespace {
@@ -41,6 +42,58 @@ struct EmuCtx {
   }
   uint32_t arena_site(uint32_t node) const { return arena[node].site; }
   uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+// Mirror of FastCtx in gmx_engine.hip: bounded LIFO of pending entries, bounded emit buffer, inline traversing handle.
+struct EmuDfsCtx {
+  struct Entry {
+    uint32_t a, b, tvd, tvg, pos, mode;
+  };
+  std::vector<Entry> stack;
+  uint32_t stack_cap;
+  std::vector<GmxFinalState> out;
+  uint32_t out_cap;
+  std::vector<GmxPathNode> arena;
+  uint32_t arena_cap;
+  uint32_t status = GMX_TASK_MAPPED;
+  EmuDfsCtx(uint32_t sc, uint32_t oc, uint32_t ac) : stack_cap(sc), out_cap(oc), arena_cap(ac) {}
+  bool pop(uint32_t &a, uint32_t &b, uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    if (stack.empty()) return false;
+    Entry e = stack.back();
+    stack.pop_back();
+    a = e.a; b = e.b; tvd = e.tvd; tvg = e.tvg; pos = e.pos; mode = e.mode;
+    return true;
+  }
+  bool push(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
+    if (stack.size() >= stack_cap) return false;
+    stack.push_back(Entry{a, b, tvd, tvg, pos, mode});
+    return true;
+  }
+  bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (out.size() >= out_cap) return false;
+    out.push_back(GmxFinalState{lo, hi, tvd, tvg});
+    return true;
+  }
+  uint32_t alloc_node(uint32_t site, int32_t allele, uint32_t next) {
+    if (arena.size() >= arena_cap) return GMX_NIL;
+    arena.push_back(GmxPathNode{site, allele, next});
+    return (uint32_t)arena.size() - 1;
+  }
+  uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
+    if (allele == -1) {
+      if (next == GMX_NIL) return GMX_INLINE_FLAG | ((site - 5u) >> 1);
+      if (gmx_h_inline(next)) {
+        next = alloc_node(gmx_h_site(arena.data(), next), -1, GMX_NIL);
+        if (next == GMX_NIL) return GMX_NIL;
+      }
+    }
+    return alloc_node(site, allele, next);
+  }
+  uint32_t arena_site(uint32_t h) const { return gmx_h_site(arena.data(), h); }
+  uint32_t arena_next(uint32_t h) const { return gmx_h_next(arena.data(), h); }
   void fail(uint32_t s) {
     if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
   }
@@ -136,6 +189,50 @@ void load_seed(const GmxIndexView &ix, uint32_t code, EmuCtx &ctx) {
   }
 }
 
+// probe (GMX_PROBE_STEPS bases, survivors parked) + extend, as gmx_probe_kernel / gmx_extend_kernel do
+void dfs_task(const GmxIndexView &ix, const Read &r, EmuDfsCtx &ctx, uint32_t probe_steps, uint32_t final_cap) {
+  const uint32_t k = ix.kmer_size;
+  const uint32_t from = r.len - k;
+  const uint32_t stop = from > probe_steps ? from - probe_steps : 0;
+  GmxSeed s = ix.seeds[kmer_code(r, from, k)];
+  if (s.a != GMX_SEED_COMPLEX) {
+    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+  } else {
+    const uint32_t *p = ix.seed_words + s.b;
+    uint32_t ns = *p++;
+    for (uint32_t i = 0; i < ns; ++i) {
+      uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+      p += 4;
+      uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
+      bool ok = true;
+      for (uint32_t j = 0; j < nt; ++j, p += 2) {
+        if (!ok) continue;
+        uint32_t nn = ctx.arena_new(p[0], (int32_t)p[1], tvd);
+        if (nn == GMX_NIL) ok = false; else tvd = nn;
+      }
+      for (uint32_t j = 0; j < ng; ++j, ++p) {
+        if (!ok) continue;
+        uint32_t nn = ctx.arena_new(p[0], -1, tvg);
+        if (nn == GMX_NIL) ok = false; else tvg = nn;
+      }
+      if (!ok || !ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE)) {
+        ctx.fail(GMX_TASK_OVERFLOW);
+        return;
+      }
+    }
+  }
+  if (ctx.status != GMX_TASK_MAPPED) return;
+  Read rr = r;
+  gmx_dfs_run(ix, ctx, rr, stop);
+  if (ctx.status != GMX_TASK_MAPPED || stop == 0 || ctx.out.empty()) return;
+  // extend phase: parked states go back on the stack, finals replace them
+  std::vector<GmxFinalState> parked;
+  parked.swap(ctx.out);
+  ctx.out_cap = final_cap;
+  for (auto &f : parked) ctx.push(f.lo, f.hi, f.traversed, f.traversing, stop, GMX_MODE_STATE);
+  gmx_dfs_run(ix, ctx, rr, 0);
+}
+
 void search_task(const GmxIndexView &ix, const Read &r, EmuCtx &ctx) {
   uint32_t k = ix.kmer_size;
   load_seed(ix, kmer_code(r, r.len - k, k), ctx);
@@ -189,38 +286,44 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
         continue;
       }
       Read r{reads + offsets[read], len, o == 1};
-      EmuCtx ctx(fast_states, fast_arena);
-      search_task(ix, r, ctx);
+      // fast tier: the DFS loop with the kernel's capacities (stack = fast_states - 2, parked <= stack, finals <= fast_states)
+      EmuDfsCtx dfs(fast_states > 2 ? fast_states - 2 : 1, fast_states > 2 ? fast_states - 2 : 1, fast_arena);
+      dfs_task(ix, r, dfs, 6, fast_states);
       EmuCtx big(big_states, big_arena);
-      EmuCtx *use = &ctx;
-      if (ctx.status == GMX_TASK_OVERFLOW) {
+      struct View {
+        const GmxFinalState *st;
+        uint32_t n;
+        const GmxPathNode *arena;
+        uint32_t status;
+      } use{dfs.out.data(), (uint32_t)dfs.out.size(), dfs.arena.data(), dfs.status};
+      if (dfs.status == GMX_TASK_OVERFLOW) {
         e->n_overflow_tasks++;
         search_task(ix, r, big);
-        use = &big;
+        use = View{big.st.data(), big.n, big.arena.data(), big.status};
       }
-      if (use->status != GMX_TASK_MAPPED) {
+      if (use.status != GMX_TASK_MAPPED) {
         if (!e->first_error) {
-          e->first_error = use->status;
+          e->first_error = use.status;
           e->error_task = (uint32_t)(read * 2 + o);
         }
         continue;
       }
-      if (use->n == 0) {
+      if (use.n == 0) {
         if (all_kmers_present(ix, r)) e->stats[3]++; else e->stats[2]++;
         continue;
       }
       e->stats[4]++;
       EmuEnv env;
-      env.arena = use->arena.data();
+      env.arena = use.arena;
       env.e = e;
-      gmx_cover_task(ix, env, use->st.data(), use->n, len, seeds[read], e->rng_mode);
+      gmx_cover_task(ix, env, use.st, use.n, len, seeds[read], e->rng_mode);
       uint32_t cstatus = env.status;
       if (cstatus == GMX_TASK_OVERFLOW) {  // nothing recorded yet: redo with the large scratch
         e->n_cover_overflow++;
         EmuEnvBig big_env;
-        big_env.arena = use->arena.data();
+        big_env.arena = use.arena;
         big_env.e = e;
-        gmx_cover_task(ix, big_env, use->st.data(), use->n, len, seeds[read], e->rng_mode);
+        gmx_cover_task(ix, big_env, use.st, use.n, len, seeds[read], e->rng_mode);
         cstatus = big_env.status;
       }
       if (cstatus != GMX_TASK_MAPPED && !e->first_error) {
