@@ -95,76 +95,143 @@ GMX_HD GmxRankBlock gmx_line_as_block(const GmxLine &l) {
   return b;
 }
 
-// Runs the lane's queue dry. `rd.at(i)` is the oriented base i of the read; states stop at position `stop`
-// (0 = the whole read; > 0 = the probe phase parks survivors there).
-template <class Ctx, class Reader>
-GMX_HD void gmx_dfs_run(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop) {
+// The lane's current entry.
+struct GmxLane {
   uint32_t a, b, tvd, tvg, pos, mode;
-  bool have = ctx.pop(a, b, tvd, tvg, pos, mode);
-  while (have) {
-    if (pos <= stop) {  // parked / seed already at the stop position
-      if (mode == GMX_MODE_HIT) {
-        ctx.fail(GMX_TASK_ERROR);  // hits are only created for positions > stop
-        break;
-      }
-      if (!ctx.emit(a, b, tvd, tvg)) ctx.fail(GMX_TASK_OVERFLOW);
-      if (ctx.status != GMX_TASK_MAPPED) break;
-      have = ctx.pop(a, b, tvd, tvg, pos, mode);
-      continue;
+  bool have;
+};
+#define GMX_MODE_DEAD 3u  // the fast path found the state dead: the general path only has to pop the next entry
+
+// One GENERAL iteration: handles every case (emit at the stop position, marker hits, wide intervals, programs).
+template <class Ctx, class Reader>
+GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, GmxLane &ln) {
+  if (ln.mode == GMX_MODE_DEAD) {
+    ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+    return;
+  }
+  if (ln.pos <= stop) {  // parked / seed already at the stop position
+    if (ln.mode == GMX_MODE_HIT) {
+      ctx.fail(GMX_TASK_ERROR);  // hits are only created for positions > stop
+      ln.have = false;
+      return;
     }
-    // --- the iteration's one line fetch ---
-    const GmxLine *src = mode == GMX_MODE_HIT ? reinterpret_cast<const GmxLine *>(ix.hits + a)
-                                              : reinterpret_cast<const GmxLine *>(ix.blocks + (a >> GMX_BLK_SHIFT));
-    const GmxLine line = *src;
-    const uint32_t c = rd.at(pos - 1);
-    bool alive = false;
-    if (mode == GMX_MODE_HIT) {
-      const uint32_t kind = line.w[0];
-      if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
-        const uint32_t site = line.w[2];
-        bool ok = true;
-        if (tvg != GMX_NIL) {
-          if (ctx.arena_site(tvg) != site) {
-            ctx.fail(GMX_TASK_ERROR);
-            ok = false;
-          } else
-            tvg = ctx.arena_next(tvg);
-        }
-        if (ok) {
-          uint32_t nn = ctx.arena_new(site, (int32_t)line.w[3], tvd);
-          if (nn == GMX_NIL) {
-            ctx.fail(GMX_TASK_OVERFLOW);
-          } else {
-            tvd = nn;
-            alive = line.w[4] == c;  // the only base that can precede the site marker
-            a = b = line.w[5];
-          }
-        }
-      } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
-        uint32_t nn = ctx.arena_new(line.w[2], -1, tvg);
+    if (!ctx.emit(ln.a, ln.b, ln.tvd, ln.tvg)) ctx.fail(GMX_TASK_OVERFLOW);
+    ln.have = ctx.status == GMX_TASK_MAPPED && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+    return;
+  }
+  // --- the iteration's one line fetch ---
+  const GmxLine *src = ln.mode == GMX_MODE_HIT ? reinterpret_cast<const GmxLine *>(ix.hits + ln.a)
+                                               : reinterpret_cast<const GmxLine *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+  const GmxLine line = *src;
+  const uint32_t c = rd.at(ln.pos - 1);
+  bool alive = false;
+  if (ln.mode == GMX_MODE_HIT) {
+    const uint32_t kind = line.w[0];
+    if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
+      const uint32_t site = line.w[2];
+      bool ok = true;
+      if (ln.tvg != GMX_NIL) {
+        if (ctx.arena_site(ln.tvg) != site) {
+          ctx.fail(GMX_TASK_ERROR);
+          ok = false;
+        } else
+          ln.tvg = ctx.arena_next(ln.tvg);
+      }
+      if (ok) {
+        uint32_t nn = ctx.arena_new(site, (int32_t)line.w[3], ln.tvd);
         if (nn == GMX_NIL) {
           ctx.fail(GMX_TASK_OVERFLOW);
         } else {
-          tvg = nn;
-          a = c == 1 ? line.w[4] : (c == 2 ? line.w[6] : (c == 3 ? line.w[8] : line.w[10]));
-          b = c == 1 ? line.w[5] : (c == 2 ? line.w[7] : (c == 3 ? line.w[9] : line.w[11]));
-          alive = a <= b;
+          ln.tvd = nn;
+          alive = line.w[4] == c;  // the only base that can precede the site marker
+          ln.a = ln.b = line.w[5];
         }
-      } else {  // general jump program: its outputs still need their LF step -> pushed as LF-only entries
-        GmxDfsProgSink<Ctx> sink{ctx, pos};
-        gmx_run_program(ix, line.w[1], tvd, tvg, sink);
       }
-    } else {
-      const GmxRankBlock blk = gmx_line_as_block(line);
-      if (mode == GMX_MODE_STATE) gmx_dfs_push_hits(ix, a, b, tvd, tvg, pos, blk, ctx);
-      alive = gmx_lf(ix, c, a, b, blk);
+    } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
+      uint32_t nn = ctx.arena_new(line.w[2], -1, ln.tvg);
+      if (nn == GMX_NIL) {
+        ctx.fail(GMX_TASK_OVERFLOW);
+      } else {
+        ln.tvg = nn;
+        ln.a = c == 1 ? line.w[4] : (c == 2 ? line.w[6] : (c == 3 ? line.w[8] : line.w[10]));
+        ln.b = c == 1 ? line.w[5] : (c == 2 ? line.w[7] : (c == 3 ? line.w[9] : line.w[11]));
+        alive = ln.a <= ln.b;
+      }
+    } else {  // general jump program: its outputs still need their LF step -> pushed as LF-only entries
+      GmxDfsProgSink<Ctx> sink{ctx, ln.pos};
+      gmx_run_program(ix, line.w[1], ln.tvd, ln.tvg, sink);
     }
-    if (ctx.status != GMX_TASK_MAPPED) break;
-    if (alive) {
-      --pos;
-      mode = GMX_MODE_STATE;
-    } else {
-      have = ctx.pop(a, b, tvd, tvg, pos, mode);
-    }
+  } else {
+    const GmxRankBlock blk = gmx_line_as_block(line);
+    if (ln.mode == GMX_MODE_STATE) gmx_dfs_push_hits(ix, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, blk, ctx);
+    alive = gmx_lf(ix, c, ln.a, ln.b, blk);
+  }
+  if (ctx.status != GMX_TASK_MAPPED) {
+    ln.have = false;
+    return;
+  }
+  if (alive) {
+    --ln.pos;
+    ln.mode = GMX_MODE_STATE;
+  } else {
+    ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+  }
+}
+
+// The FAST iteration covers the dominant case — a width-1 interval whose BWT symbol is a base:
+// 32-bit word arithmetic on one block, no stack traffic, no calls. Preconditions: gmx_dfs_fast_ok().
+// Returns false, leaving the lane untouched, when the general path is needed (marker to the left).
+GMX_HD bool gmx_dfs_fast_ok(const GmxLane &ln, uint32_t stop) {
+  return ln.have && ln.mode == GMX_MODE_STATE && ln.pos > stop && ln.a == ln.b;
+}
+template <class Reader>
+GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Reader &rd, GmxLane &ln) {
+  const uint32_t i = ln.a;
+  const uint32_t bi = i >> GMX_BLK_SHIFT;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(ix.blocks + bi);
+  const uint32_t j = (i >> 5) & 3u, t = i & 31u;
+  // one 64-byte line: counts | lo plane | hi plane | marker plane (32 positions per word)
+  const uint32_t cA = w[0], cC = w[1], cG = w[2], cM = w[3];
+  const uint32_t l0 = w[4], l1 = w[5], l2 = w[6], l3 = w[7];
+  const uint32_t h0 = w[8], h1 = w[9], h2 = w[10], h3 = w[11];
+  const uint32_t k0 = w[12], k1 = w[13], k2 = w[14], k3 = w[15];
+  const uint32_t kj = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3));
+  if ((kj >> t) & 1u) return false;  // a variant marker precedes this position: general path
+  const uint32_t c = rd.at(ln.pos - 1);
+  const uint32_t code = c - 1u;
+  const uint32_t xl = (code & 1u) ? 0u : ~0u, xh = (code & 2u) ? 0u : ~0u, ka = c == 1 ? ~0u : 0u;
+  const uint32_t m0 = (l0 ^ xl) & (h0 ^ xh) & ~(k0 & ka);
+  const uint32_t m1 = (l1 ^ xl) & (h1 ^ xh) & ~(k1 & ka);
+  const uint32_t m2 = (l2 ^ xl) & (h2 ^ xh) & ~(k2 & ka);
+  const uint32_t m3 = (l3 ^ xl) & (h3 ^ xh) & ~(k3 & ka);
+  const uint32_t mj = j == 0 ? m0 : (j == 1 ? m1 : (j == 2 ? m2 : m3));
+  uint32_t rank = (j > 0 ? (uint32_t)__builtin_popcount(m0) : 0u) + (j > 1 ? (uint32_t)__builtin_popcount(m1) : 0u) +
+                  (j > 2 ? (uint32_t)__builtin_popcount(m2) : 0u) + (uint32_t)__builtin_popcount(mj & ((1u << t) - 1u));
+  const uint32_t cT = (bi << GMX_BLK_SHIFT) - cA - cC - cG - cM;
+  rank += c == 1 ? cA : (c == 2 ? cC : (c == 3 ? cG : cT));
+  bool hit = ((mj >> t) & 1u) != 0;
+  if (c == 1) {  // the sentinel is stored as code 00
+    if (ix.sentinel_pos < i) rank -= 1;
+    if (ix.sentinel_pos == i) hit = false;
+  }
+  if (hit) {
+    const uint32_t first = c == 1 ? ix.C[1] : (c == 2 ? ix.C[2] : (c == 3 ? ix.C[3] : ix.C[4]));
+    ln.a = ln.b = first + rank;
+    --ln.pos;
+  } else {
+    ln.mode = GMX_MODE_DEAD;
+  }
+  return true;
+}
+
+// Host-style driver (one lane at a time): the kernels interleave the same two functions with wave-level
+// batching of the general path (gmx_engine.hip: dfs_run_wave).
+template <class Ctx, class Reader>
+GMX_HD void gmx_dfs_run(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop) {
+  GmxLane ln;
+  ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+  while (ln.have) {
+    if (gmx_dfs_fast_ok(ln, stop) && gmx_dfs_fast_iter(ix, rd, ln)) continue;
+    gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
   }
 }

@@ -214,6 +214,33 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
   }
 }
 
+// Wave-level driver of the DFS queue (gmx_dfs.h). All lanes spin in the cheap fast iteration; a lane that needs
+// the general iteration (marker hit, state death/finish, wide interval) waits, and the general code runs for the
+// whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
+// count is amortised instead of being executed (mostly masked off) on every step.
+#define GMX_SLOW_BATCH 12
+template <class Ctx>
+__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active) {
+  GmxLane ln;
+  ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
+  ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+  bool wait_slow = false;
+  for (;;) {
+    bool can_fast = !wait_slow && gmx_dfs_fast_ok(ln, stop);
+    bool need_slow = ln.have && !can_fast;
+    unsigned long long mf = __ballot(can_fast), ms = __ballot(need_slow);
+    if ((mf | ms) == 0) break;
+    if (mf != 0 && __popcll(ms) < GMX_SLOW_BATCH) {
+      if (can_fast && !gmx_dfs_fast_iter(ix, rd, ln)) wait_slow = true;
+      continue;
+    }
+    if (need_slow) {
+      gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
+      wait_slow = false;
+    }
+  }
+}
+
 // search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel):
 // extend the pool by oriented bases i = from-1 ... to (right to left). Returns the next index to process.
 template <class Ctx>
@@ -329,8 +356,16 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_STACK_DEPTH;  // parked states must fit the extend kernel's stack
+  ReadRef r;
+  r.w = b.packed;
+  r.len = 0;
+  r.rc = false;
+  r.cur_idx = 0xFFFFFFFFu;
+  r.cur = 0;
+  bool run = false;
+  uint32_t lane_stop = 0;
   if (active) {
-    ReadRef r = task_read(b, task);
+    r = task_read(b, task);
     if (b.forward_only && r.rc) {
       status = GMX_STATUS_IGNORED;
     } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
@@ -340,12 +375,14 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       load_seed(ix, kmer_code(r, from, k), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
         return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
       });
-      if (ctx.status == GMX_TASK_MAPPED) gmx_dfs_run(ix, ctx, r, stop);
+      run = ctx.status == GMX_TASK_MAPPED;
       status = ctx.status;
       done = stop == 0;
-      if (done) ctx.out_cap = GMX_FAST_STATES;
+      lane_stop = stop;
     }
   }
+  dfs_run_wave(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
+  if (run) status = ctx.status;
   finish_lane(o, active, task, ctx, status, done);
 }
 
@@ -365,8 +402,14 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_FAST_STATES;
+  ReadRef r;
+  r.w = b.packed;
+  r.len = 0;
+  r.rc = false;
+  r.cur_idx = 0xFFFFFFFFu;
+  r.cur = 0;
   if (active) {
-    ReadRef r = task_read(b, task);
+    r = task_read(b, task);
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
     ctx.arena_n = packed >> 8;
@@ -375,9 +418,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
       GmxFinalState f = ctx.out[s];
       ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
     }
-    gmx_dfs_run(ix, ctx, r, 0);
-    status = ctx.status;
   }
+  dfs_run_wave(ix, ctx, r, 0, active);
+  status = ctx.status;
   finish_lane(o, active, task, ctx, status, true);
 }
 
