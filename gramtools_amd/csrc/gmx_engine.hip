@@ -124,29 +124,40 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   }
 };
 
-struct BigCtx {  // states and arena in global memory, runtime capacities
-  uint32_t n;
-  GmxFinalState *st;
-  uint32_t cap;
+struct BigCtx {  // the same DFS queue with everything in global memory and runtime capacities (large-capacity pass)
+  uint32_t sp, cap;
+  uint32_t *stack;  // cap x GMX_STACK_WORDS
   GmxPathNode *arena;
   uint32_t arena_n, arena_cap;
   uint32_t status;
-  __device__ __forceinline__ uint32_t n_states() const { return n; }
-  __device__ __forceinline__ void set_n_states(uint32_t v) { n = v; }
-  __device__ __forceinline__ void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
-    GmxFinalState f = st[s];
-    lo = f.lo;
-    hi = f.hi;
-    tvd = f.traversed;
-    tvg = f.traversing;
+  GmxFinalState *out;
+  uint32_t n_out, out_cap;
+  __device__ __forceinline__ bool pop(uint32_t &a, uint32_t &b, uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    if (sp == 0) return false;
+    --sp;
+    const uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
+    a = e[0];
+    b = e[1];
+    tvd = e[2];
+    tvg = e[3];
+    pos = e[4] & 0x3FFFFFFFu;
+    mode = e[4] >> 30;
+    return true;
   }
-  __device__ __forceinline__ void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-    st[s] = GmxFinalState{lo, hi, tvd, tvg};
+  __device__ __forceinline__ bool push(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
+    if (sp >= cap) return false;
+    uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
+    e[0] = a;
+    e[1] = b;
+    e[2] = tvd;
+    e[3] = tvg;
+    e[4] = pos | (mode << 30);
+    ++sp;
+    return true;
   }
-  __device__ __forceinline__ bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-    if (n >= cap) return false;
-    put(n, lo, hi, tvd, tvg);
-    ++n;
+  __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (n_out >= out_cap) return false;
+    out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
     return true;
   }
   __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
@@ -154,8 +165,8 @@ struct BigCtx {  // states and arena in global memory, runtime capacities
     arena[arena_n] = GmxPathNode{site, allele, next};
     return arena_n++;
   }
-  __device__ __forceinline__ uint32_t arena_site(uint32_t node) const { return arena[node].site; }
-  __device__ __forceinline__ uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  __device__ __forceinline__ uint32_t arena_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ uint32_t arena_next(uint32_t h) const { return gmx_h_next(arena, h); }
   __device__ __forceinline__ void fail(uint32_t s) {
     if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
   }
@@ -239,27 +250,6 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       wait_slow = false;
     }
   }
-}
-
-// search_read_backwards (quasimap.cpp:227-256) minus the encapsulation pass (done by the cover kernel):
-// extend the pool by oriented bases i = from-1 ... to (right to left). Returns the next index to process.
-template <class Ctx>
-__device__ uint32_t extend_range(const GmxIndexView &ix, ReadRef &r, Ctx &ctx, uint32_t from, uint32_t to) {
-  uint32_t i = from;
-  while (i > to) {
-    if (ctx.n_states() == 0 || ctx.status != GMX_TASK_MAPPED) break;
-    --i;
-    gmx_extend(ix, r.at(i), ctx);
-  }
-  return i;
-}
-template <class Ctx>
-__device__ void search_task(const GmxIndexView &ix, ReadRef &r, Ctx &ctx) {
-  const uint32_t k = ix.kmer_size;
-  load_seed(ix, kmer_code(r, r.len - k, k), ctx,
-            [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { return ctx.push(lo, hi, tvd, tvg); });
-  if (ctx.status != GMX_TASK_MAPPED) return;
-  extend_range(ix, r, ctx, r.len - k, 0);
 }
 
 struct BatchView {
@@ -437,36 +427,59 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
 }
 
 struct BigOut {
-  GmxFinalState *states;   // slot x max_states
+  GmxFinalState *states;   // slot x max_states (final states)
+  uint32_t *stack;         // slot x max_states x GMX_STACK_WORDS (pending entries)
   GmxPathNode *arena;      // slot x max_path_nodes
   uint32_t *n_final;       // per slot
   uint32_t *task_of_slot;  // per slot
   uint32_t max_states, max_path_nodes, max_slots;
 };
 
-// One lane per overflowed task; persistent over the overflow list (its length is only known on the device).
+// Large-capacity pass: one lane per task that overflowed the LDS stack / parked-state / arena limits, whole read
+// from the seed, same DFS loop with global-memory pools. Persistent over the device-side overflow list.
 __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
   uint32_t n_over = o.counters[1];
-  for (uint32_t slot = blockIdx.x * 64 + threadIdx.x; slot < n_over; slot += gridDim.x * 64) {
-    uint32_t task = o.overflow_list[slot];
-    if (slot >= g.max_slots) {
+  uint32_t rounds = (n_over + gridDim.x * 64 - 1) / (gridDim.x * 64);
+  for (uint32_t rd = 0; rd < rounds; ++rd) {
+    uint32_t slot = rd * gridDim.x * 64 + blockIdx.x * 64 + threadIdx.x;
+    bool active = slot < n_over;
+    uint32_t task = active ? o.overflow_list[slot] : 0;
+    if (active && slot >= g.max_slots) {
       if (atomicCAS(&o.counters[2], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3] = task;
-      continue;
+      active = false;
     }
-    ReadRef r = task_read(b, task);
     BigCtx ctx;
-    ctx.n = 0;
-    ctx.st = g.states + (size_t)slot * g.max_states;
+    ctx.sp = 0;
     ctx.cap = g.max_states;
-    ctx.arena = g.arena + (size_t)slot * g.max_path_nodes;
+    ctx.stack = g.stack + (size_t)(active ? slot : 0) * g.max_states * GMX_STACK_WORDS;
+    ctx.arena = g.arena + (size_t)(active ? slot : 0) * g.max_path_nodes;
     ctx.arena_n = 0;
     ctx.arena_cap = g.max_path_nodes;
     ctx.status = GMX_TASK_MAPPED;
-    search_task(ix, r, ctx);
+    ctx.out = g.states + (size_t)(active ? slot : 0) * g.max_states;
+    ctx.n_out = 0;
+    ctx.out_cap = g.max_states;
+    ReadRef r;
+    r.w = b.packed;
+    r.len = 0;
+    r.rc = false;
+    r.cur_idx = 0xFFFFFFFFu;
+    r.cur = 0;
+    bool run = false;
+    if (active) {
+      r = task_read(b, task);
+      const uint32_t from = r.len - ix.kmer_size;
+      load_seed(ix, kmer_code(r, from, ix.kmer_size), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+        return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
+      });
+      run = ctx.status == GMX_TASK_MAPPED;
+    }
+    dfs_run_wave(ix, ctx, r, 0, run);
+    if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
     if (status == GMX_TASK_MAPPED) {
-      nf = ctx.n;
+      nf = ctx.n_out;
       if (nf == 0) status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
     } else if (atomicCAS(&o.counters[2], 0u, status) == 0u) {
       o.counters[3] = task;
@@ -811,8 +824,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
-  e->big.max_slots = 65536;
+  e->big.max_slots = 16384;
   rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
+  rc |= e->alloc(&e->big.stack, (size_t)e->big.max_slots * e->big.max_states * GMX_STACK_WORDS, false);
   rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
   rc |= e->alloc(&e->big.n_final, e->big.max_slots, false);
   rc |= e->alloc(&e->big.task_of_slot, e->big.max_slots, false);
