@@ -36,6 +36,7 @@
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
 #define GMX_STACK_DEPTH 6     // pending entries (sibling states, unresolved marker hits) per lane, in LDS
 #define GMX_STACK_WORDS 5
+#define GMX_CNT_STRIDE 32      // device counters sit 128 B apart: same-line atomics would serialise in one L2 channel
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
@@ -279,15 +280,27 @@ struct SearchOut {
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
 };
 
-__device__ __forceinline__ void wave_append(uint32_t *list, uint32_t *counter, bool want, uint32_t value) {
+// Appends `value` of every lane with `want` to a device list: the block's lanes are ranked with ballots, the
+// block reserves its range with ONE atomic (31 k blocks x 4 lists of per-wave atomics on one cache line made the
+// probe kernel atomic-bound). Must be called by all threads of the block.
+__device__ __forceinline__ void block_append(uint32_t *list, uint32_t *counter, bool want, uint32_t value) {
+  __shared__ uint32_t wave_cnt[GMX_BLOCK / 64];
+  __shared__ uint32_t block_base;
   unsigned long long m = __ballot(want);
-  if (!m) return;
-  uint32_t lane = threadIdx.x & 63;
-  uint32_t leader = (uint32_t)__builtin_ctzll(m);
-  uint32_t base = 0;
-  if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+  uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) {
+    uint32_t c = wave_cnt[w];
+    before += w < wave ? c : 0;
+    total += c;
+  }
+  if (threadIdx.x == 0 && total) block_base = atomicAdd(counter, total);
+  __syncthreads();
+  if (want) list[block_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+  __syncthreads();  // block_base / wave_cnt are reused by the next call
 }
 
 __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
@@ -317,16 +330,16 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
       }
     } else if (status == GMX_TASK_OVERFLOW) {
       over = true;
-    } else if (atomicCAS(&o.counters[2], 0u, status) == 0u) {
-      o.counters[3] = task;
+    } else if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, status) == 0u) {
+      o.counters[3 * GMX_CNT_STRIDE] = task;
     }
   }
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
     o.status[task] = status;
-  wave_append(o.mapped_list, &o.counters[0], mapped, task);
-  wave_append(o.overflow_list, &o.counters[1], over, task);
-  wave_append(o.alive_list, &o.counters[5], alive, task);
-  wave_append(o.dead_list, &o.counters[6], dead, task);
+  block_append(o.mapped_list, &o.counters[0 * GMX_CNT_STRIDE], mapped, task);
+  block_append(o.overflow_list, &o.counters[1 * GMX_CNT_STRIDE], over, task);
+  block_append(o.alive_list, &o.counters[5 * GMX_CNT_STRIDE], alive, task);
+  block_append(o.dead_list, &o.counters[6 * GMX_CNT_STRIDE], dead, task);
 }
 
 #define GMX_PROBE_STEPS 6  // bases extended by the probe phase; a wrong-orientation task survives them with p ~ 1e-3
@@ -378,7 +391,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
-  uint32_t n_alive = o.counters[5];
+  uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = slot < n_alive;
@@ -417,7 +430,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
 // Phase 3 — tasks without a final state: all_read_kmers_occur_in_index decides between the
 // missing_kmer and no_extension counters (quasimap.cpp:168-186); it never affects coverage.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
-  uint32_t n_dead = o.counters[6];
+  uint32_t n_dead = o.counters[6 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_dead) return;
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   if (slot >= n_dead) return;
@@ -438,14 +451,14 @@ struct BigOut {
 // Large-capacity pass: one lane per task that overflowed the LDS stack / parked-state / arena limits, whole read
 // from the seed, same DFS loop with global-memory pools. Persistent over the device-side overflow list.
 __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
-  uint32_t n_over = o.counters[1];
+  uint32_t n_over = o.counters[1 * GMX_CNT_STRIDE];
   uint32_t rounds = (n_over + gridDim.x * 64 - 1) / (gridDim.x * 64);
   for (uint32_t rd = 0; rd < rounds; ++rd) {
     uint32_t slot = rd * gridDim.x * 64 + blockIdx.x * 64 + threadIdx.x;
     bool active = slot < n_over;
     uint32_t task = active ? o.overflow_list[slot] : 0;
     if (active && slot >= g.max_slots) {
-      if (atomicCAS(&o.counters[2], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3] = task;
+      if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
       active = false;
     }
     BigCtx ctx;
@@ -481,15 +494,15 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     if (status == GMX_TASK_MAPPED) {
       nf = ctx.n_out;
       if (nf == 0) status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
-    } else if (atomicCAS(&o.counters[2], 0u, status) == 0u) {
-      o.counters[3] = task;
+    } else if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, status) == 0u) {
+      o.counters[3 * GMX_CNT_STRIDE] = task;
     }
     o.status[task] = status;
     o.n_final[task] = nf;
     g.n_final[slot] = nf;
     g.task_of_slot[slot] = task;
     if (status == GMX_TASK_MAPPED && nf > 0) {
-      uint32_t at = atomicAdd(&o.counters[0], 1u);
+      uint32_t at = atomicAdd(&o.counters[0 * GMX_CNT_STRIDE], 1u);
       o.mapped_list[at] = 0x80000000u | slot;
     }
   }
@@ -550,7 +563,7 @@ typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping
 template <class Env, bool BIG>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
-  uint32_t n_mapped = BIG ? o.counters[4] : o.counters[0];
+  uint32_t n_mapped = BIG ? o.counters[4 * GMX_CNT_STRIDE] : o.counters[0 * GMX_CNT_STRIDE];
   const uint32_t *list = BIG ? o.cover_overflow_list : o.mapped_list;
   uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * blockDim.x) {
@@ -586,9 +599,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     env.log_at = 0;
     gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
     if (env.status == GMX_TASK_OVERFLOW && !BIG) {
-      o.cover_overflow_list[atomicAdd(&o.counters[4], 1u)] = entry;
+      o.cover_overflow_list[atomicAdd(&o.counters[4 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status != GMX_TASK_MAPPED) {
-      if (atomicCAS(&o.counters[2], 0u, env.status) == 0u) o.counters[3] = task;
+      if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
     }
   }
 }
@@ -820,7 +833,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
   rc |= e->alloc(&e->d_log_cursor, 4, true);
-  rc |= e->alloc(&e->d_counters, 16, true);
+  rc |= e->alloc(&e->d_counters, 8 * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
@@ -859,7 +872,7 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
   HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
   HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
-  HIP_TRY(hipMemset(e->d_counters, 0, 64));
+  HIP_TRY(hipMemset(e->d_counters, 0, 8 * GMX_CNT_STRIDE * 4));
   return GMX_OK;
 }
 
@@ -896,8 +909,9 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
               e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
-  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 8, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4, 0, 12, stream));
+  // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
+  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 3 * GMX_CNT_STRIDE * 4, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -996,11 +1010,13 @@ int gmx_engine_sync(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
-  uint32_t c[4];
-  HIP_TRY(hipMemcpy(c, e->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+  uint32_t raw[4 * GMX_CNT_STRIDE];
+  HIP_TRY(hipMemcpy(raw, e->d_counters, sizeof(raw), hipMemcpyDeviceToHost));
+  uint32_t c[4] = {raw[0], raw[GMX_CNT_STRIDE], raw[2 * GMX_CNT_STRIDE], raw[3 * GMX_CNT_STRIDE]};
   if (c[2] != 0) {
     uint32_t zero[2] = {0, 0};
-    HIP_TRY(hipMemcpy(e->d_counters + 2, zero, sizeof(zero), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_counters + 2 * GMX_CNT_STRIDE, zero, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_counters + 3 * GMX_CNT_STRIDE, zero, 4, hipMemcpyHostToDevice));
     char msg[256];
     if (c[2] == GMX_TASK_LOGFULL) {
       gmx_set_error("the grouped-allele-count log (sites with more than 5 alleles) is full; coverage is incomplete");
