@@ -178,26 +178,69 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
   }
 }
 
-// The FAST iteration covers the dominant case — a width-1 interval whose BWT symbol is a base:
-// 32-bit word arithmetic on one block, no stack traffic, no calls. Preconditions: gmx_dfs_fast_ok().
-// Returns false, leaving the lane untouched, when the general path is needed (marker to the left).
+// The FAST iteration covers the cases that make up almost every step of a read on a flat PRG:
+//   * a width-1 interval: LF step with 32-bit word arithmetic on one block; if a variant marker precedes the
+//     position, the state turns into the pending hit itself (its own LF step would die: the BWT symbol is not a base);
+//   * a pending hit whose record is pre-resolved (GMX_HIT_EXIT / GMX_HIT_ENTER) and whose traversing path is empty
+//     or inline: path update + the precomputed LF result, no further fetch.
+// No stack traffic, no calls, one 64-byte line per iteration. Preconditions: gmx_dfs_fast_ok().
+// Returns false, leaving the lane untouched, when the general iteration is needed.
 GMX_HD bool gmx_dfs_fast_ok(const GmxLane &ln, uint32_t stop) {
-  return ln.have && ln.mode == GMX_MODE_STATE && ln.pos > stop && ln.a == ln.b;
+  return ln.have && ln.pos > stop && ((ln.mode == GMX_MODE_STATE && ln.a == ln.b) || ln.mode == GMX_MODE_HIT);
 }
-template <class Reader>
-GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Reader &rd, GmxLane &ln) {
+template <class Ctx, class Reader>
+GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln) {
+  const bool is_hit = ln.mode == GMX_MODE_HIT;
   const uint32_t i = ln.a;
   const uint32_t bi = i >> GMX_BLK_SHIFT;
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(ix.blocks + bi);
-  const uint32_t j = (i >> 5) & 3u, t = i & 31u;
-  // one 64-byte line: counts | lo plane | hi plane | marker plane (32 positions per word)
-  const uint32_t cA = w[0], cC = w[1], cG = w[2], cM = w[3];
+  const uint32_t *w = is_hit ? reinterpret_cast<const uint32_t *>(ix.hits + i) : reinterpret_cast<const uint32_t *>(ix.blocks + bi);
+  // one 64-byte line: a rank block (counts | lo plane | hi plane | marker plane) or a hit record
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
   const uint32_t l0 = w[4], l1 = w[5], l2 = w[6], l3 = w[7];
   const uint32_t h0 = w[8], h1 = w[9], h2 = w[10], h3 = w[11];
   const uint32_t k0 = w[12], k1 = w[13], k2 = w[14], k3 = w[15];
-  const uint32_t kj = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3));
-  if ((kj >> t) & 1u) return false;  // a variant marker precedes this position: general path
   const uint32_t c = rd.at(ln.pos - 1);
+  if (is_hit) {
+    (void)w1;
+    bool alive;
+    if (w0 == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
+      if (ln.tvg != GMX_NIL) {
+        if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != w2) return false;  // general path (or error there)
+      }
+      uint32_t nn = ctx.arena_new(w2, (int32_t)w3, ln.tvd);
+      if (nn == GMX_NIL) return false;
+      ln.tvg = GMX_NIL;
+      ln.tvd = nn;
+      alive = l0 == c;  // lf[0]: the only base that can precede the site marker
+      ln.a = ln.b = l1;
+    } else if (w0 == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
+      if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
+      ln.tvg = GMX_INLINE_FLAG | ((w2 - 5u) >> 1);
+      ln.a = c == 1 ? l0 : (c == 2 ? l2 : (c == 3 ? h0 : h2));
+      ln.b = c == 1 ? l1 : (c == 2 ? l3 : (c == 3 ? h1 : h3));
+      alive = ln.a <= ln.b;
+    } else
+      return false;
+    if (alive) {
+      --ln.pos;
+      ln.mode = GMX_MODE_STATE;
+    } else
+      ln.mode = GMX_MODE_DEAD;
+    return true;
+  }
+  const uint32_t j = (i >> 5) & 3u, t = i & 31u;
+  const uint32_t below = (1u << t) - 1u;
+  const uint32_t kj = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3));
+  if ((kj >> t) & 1u) {
+    // a variant marker precedes this position: the state becomes its own (single) pending hit; marker rank =
+    // block count + markers below the position (left_markers_search, vBWT_jump.cpp:94-117)
+    uint32_t r = w3 + (j > 0 ? (uint32_t)__builtin_popcount(k0) : 0u) + (j > 1 ? (uint32_t)__builtin_popcount(k1) : 0u) +
+                 (j > 2 ? (uint32_t)__builtin_popcount(k2) : 0u) + (uint32_t)__builtin_popcount(kj & below);
+    ln.a = r;
+    ln.b = 0;
+    ln.mode = GMX_MODE_HIT;
+    return true;
+  }
   const uint32_t code = c - 1u;
   const uint32_t xl = (code & 1u) ? 0u : ~0u, xh = (code & 2u) ? 0u : ~0u, ka = c == 1 ? ~0u : 0u;
   const uint32_t m0 = (l0 ^ xl) & (h0 ^ xh) & ~(k0 & ka);
@@ -206,9 +249,9 @@ GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Reader &rd, GmxLane &ln) {
   const uint32_t m3 = (l3 ^ xl) & (h3 ^ xh) & ~(k3 & ka);
   const uint32_t mj = j == 0 ? m0 : (j == 1 ? m1 : (j == 2 ? m2 : m3));
   uint32_t rank = (j > 0 ? (uint32_t)__builtin_popcount(m0) : 0u) + (j > 1 ? (uint32_t)__builtin_popcount(m1) : 0u) +
-                  (j > 2 ? (uint32_t)__builtin_popcount(m2) : 0u) + (uint32_t)__builtin_popcount(mj & ((1u << t) - 1u));
-  const uint32_t cT = (bi << GMX_BLK_SHIFT) - cA - cC - cG - cM;
-  rank += c == 1 ? cA : (c == 2 ? cC : (c == 3 ? cG : cT));
+                  (j > 2 ? (uint32_t)__builtin_popcount(m2) : 0u) + (uint32_t)__builtin_popcount(mj & below);
+  const uint32_t cT = (bi << GMX_BLK_SHIFT) - w0 - w1 - w2 - w3;
+  rank += c == 1 ? w0 : (c == 2 ? w1 : (c == 3 ? w2 : cT));
   bool hit = ((mj >> t) & 1u) != 0;
   if (c == 1) {  // the sentinel is stored as code 00
     if (ix.sentinel_pos < i) rank -= 1;
@@ -231,7 +274,7 @@ GMX_HD void gmx_dfs_run(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t s
   GmxLane ln;
   ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   while (ln.have) {
-    if (gmx_dfs_fast_ok(ln, stop) && gmx_dfs_fast_iter(ix, rd, ln)) continue;
+    if (gmx_dfs_fast_ok(ln, stop) && gmx_dfs_fast_iter(ix, ctx, rd, ln)) continue;
     gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
   }
 }

@@ -243,7 +243,7 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
     unsigned long long mf = __ballot(can_fast), ms = __ballot(need_slow);
     if ((mf | ms) == 0) break;
     if (mf != 0 && __popcll(ms) < GMX_SLOW_BATCH) {
-      if (can_fast && !gmx_dfs_fast_iter(ix, rd, ln)) wait_slow = true;
+      if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
       continue;
     }
     if (need_slow) {
