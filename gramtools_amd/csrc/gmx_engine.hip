@@ -231,39 +231,8 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
 // count is amortised instead of being executed (mostly masked off) on every step.
 #define GMX_SLOW_BATCH 12
-#define GMX_XPOSE_STRIDE 20  // dwords per lane in the transpose area: 80 B keeps ds_read_b128 conflict-free
-
-// Quad-cooperative fetch of every lane's 64-byte line. A lane-private dwordx4 load makes the L1 look up 64
-// different lines per instruction (the extend kernel spent ~75 % of its cycles on TCP lookups: 256 per
-// wave-iteration). Here the 4 lanes of a quad read the 4 consecutive 16-byte chunks of ONE lane's line, so each
-// of the 4 load instructions touches 16 lines, fully used; the chunks are handed to their owner through LDS.
-// Must be executed by all 64 lanes (a lane without work passes any valid address).
-__device__ __forceinline__ void coop_fetch(const uint32_t *src, uint32_t *xpose /* this wave's area */, uint32_t w[16]) {
-  const uint32_t lane = threadIdx.x & 63u, q = lane & 3u, qbase = lane & ~3u;
-  const unsigned long long p = (unsigned long long)src;
-  uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
-#pragma unroll
-  for (uint32_t r = 0; r < 4; ++r) {
-    uint32_t olo = (uint32_t)__shfl((int)plo, (int)(qbase + r));
-    uint32_t ohi = (uint32_t)__shfl((int)phi, (int)(qbase + r));
-    const uint4 *osrc = reinterpret_cast<const uint4 *>(((unsigned long long)ohi << 32) | olo);
-    uint4 v = osrc[q];
-    *reinterpret_cast<uint4 *>(xpose + (qbase + r) * GMX_XPOSE_STRIDE + q * 4) = v;
-  }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (uint32_t k = 0; k < 4; ++k) {
-    uint4 v = *reinterpret_cast<const uint4 *>(xpose + lane * GMX_XPOSE_STRIDE + k * 4);
-    w[4 * k] = v.x;
-    w[4 * k + 1] = v.y;
-    w[4 * k + 2] = v.z;
-    w[4 * k + 3] = v.w;
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <bool COOP, class Ctx>
-__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active, uint32_t *xpose) {
+template <class Ctx>
+__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active) {
   GmxLane ln;
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
@@ -274,14 +243,7 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
     unsigned long long mf = __ballot(can_fast), ms = __ballot(need_slow);
     if ((mf | ms) == 0) break;
     if (mf != 0 && __popcll(ms) < GMX_SLOW_BATCH) {
-      if (COOP) {
-        const uint32_t *src = can_fast ? gmx_dfs_fast_src(ix, ln) : reinterpret_cast<const uint32_t *>(ix.blocks);
-        uint32_t w[16];
-        coop_fetch(src, xpose, w);
-        if (can_fast && !gmx_dfs_fast_iter_line(ix, ctx, rd, ln, w)) wait_slow = true;
-      } else {
-        if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
-      }
+      if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
       continue;
     }
     if (need_slow) {
@@ -422,8 +384,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       lane_stop = stop;
     }
   }
-  uint32_t *xpose = gmx_lds + GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK + (threadIdx.x >> 6) * 64 * GMX_XPOSE_STRIDE;
-  dfs_run_wave<true>(ix, ctx, r, lane_stop, run, xpose);  // every lane of the wave takes part in the ballots
+  dfs_run_wave(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
   if (run) status = ctx.status;
   finish_lane(o, active, task, ctx, status, done);
 }
@@ -461,8 +422,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
       ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
     }
   }
-  uint32_t *xpose = gmx_lds + GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK + (threadIdx.x >> 6) * 64 * GMX_XPOSE_STRIDE;
-  dfs_run_wave<true>(ix, ctx, r, 0, active, xpose);
+  dfs_run_wave(ix, ctx, r, 0, active);
   status = ctx.status;
   finish_lane(o, active, task, ctx, status, true);
 }
@@ -527,7 +487,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       });
       run = ctx.status == GMX_TASK_MAPPED;
     }
-    dfs_run_wave<false>(ix, ctx, r, 0, run, nullptr);
+    dfs_run_wave(ix, ctx, r, 0, run);
     if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
@@ -954,7 +914,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 3 * GMX_CNT_STRIDE * 4, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0, stream, b,
                      e->d_skip, e->d_packed);
-  size_t lds = ((size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS + GMX_XPOSE_STRIDE) * GMX_BLOCK * sizeof(uint32_t);
+  size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));
