@@ -238,15 +238,18 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   bool wait_slow = false;
   for (;;) {
-    bool can_fast = !wait_slow && gmx_dfs_fast_ok(ln, stop);
-    bool need_slow = ln.have && !can_fast;
-    unsigned long long mf = __ballot(can_fast), ms = __ballot(need_slow);
-    if ((mf | ms) == 0) break;
-    if (mf != 0 && __popcll(ms) < GMX_SLOW_BATCH) {
+    // ---- fast phase: a tight loop; lanes that need the general iteration drop out and wait ----
+    unsigned long long mf, ms;
+    for (;;) {
+      bool can_fast = !wait_slow && gmx_dfs_fast_ok(ln, stop);
+      mf = __ballot(can_fast);
+      ms = __ballot(ln.have && !can_fast);
+      if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
       if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
-      continue;
     }
-    if (need_slow) {
+    if ((mf | ms) == 0) break;
+    // ---- one general iteration for every waiting lane ----
+    if (ln.have && (wait_slow || !gmx_dfs_fast_ok(ln, stop))) {
       gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
       wait_slow = false;
     }
