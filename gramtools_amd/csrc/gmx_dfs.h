@@ -188,12 +188,17 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
 GMX_HD bool gmx_dfs_fast_ok(const GmxLane &ln, uint32_t stop) {
   return ln.have && ln.pos > stop && ((ln.mode == GMX_MODE_STATE && ln.a == ln.b) || ln.mode == GMX_MODE_HIT);
 }
+// address of the 64-byte line the lane's fast iteration consumes: a rank block or a hit record
+GMX_HD const uint32_t *gmx_dfs_fast_src(const GmxIndexView &ix, const GmxLane &ln) {
+  return ln.mode == GMX_MODE_HIT ? reinterpret_cast<const uint32_t *>(ix.hits + ln.a)
+                                 : reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+}
+// `w` = the 16 words of that line (the extend kernel fetches it quad-cooperatively, everything else directly)
 template <class Ctx, class Reader>
-GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln) {
+GMX_HD bool gmx_dfs_fast_iter_line(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln, const uint32_t *w) {
   const bool is_hit = ln.mode == GMX_MODE_HIT;
   const uint32_t i = ln.a;
   const uint32_t bi = i >> GMX_BLK_SHIFT;
-  const uint32_t *w = is_hit ? reinterpret_cast<const uint32_t *>(ix.hits + i) : reinterpret_cast<const uint32_t *>(ix.blocks + bi);
   // one 64-byte line: a rank block (counts | lo plane | hi plane | marker plane) or a hit record
   const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
   const uint32_t l0 = w[4], l1 = w[5], l2 = w[6], l3 = w[7];
@@ -265,6 +270,14 @@ GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxL
     ln.mode = GMX_MODE_DEAD;
   }
   return true;
+}
+
+template <class Ctx, class Reader>
+GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln) {
+  const uint32_t *src = gmx_dfs_fast_src(ix, ln);
+  uint32_t w[16];
+  for (int k = 0; k < 16; ++k) w[k] = src[k];
+  return gmx_dfs_fast_iter_line(ix, ctx, rd, ln, w);
 }
 
 // Host-style driver (one lane at a time): the kernels interleave the same two functions with wave-level

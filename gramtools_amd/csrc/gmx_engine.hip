@@ -231,7 +231,68 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
 // count is amortised instead of being executed (mostly masked off) on every step.
 #define GMX_SLOW_BATCH 12
-template <class Ctx>
+// Quad-cooperative fetch of every lane's 64-byte line, register-only. A lane-private dwordx4 load makes the L1
+// look up 64 different lines per instruction (PMC: ~250 TCP accesses per wave-iteration, ~0.7 per CU-cycle over
+// the whole extend kernel). Here the 4 lanes of a quad read the 4 consecutive 16-byte chunks of ONE lane's line
+// (one coalesced 64-byte request), for each of the quad's 4 owners in turn; a two-stage DPP butterfly then
+// transposes the 4x4 chunk matrix inside the quad so that every lane ends up with its own line.
+// Must be executed by all 64 lanes (a lane without work passes any valid address).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void coop_fetch(const uint32_t *src, uint32_t w[16]) {
+  const uint32_t q = threadIdx.x & 3u;
+  const unsigned long long p = (unsigned long long)src;
+  const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
+  uint4 R[4];
+  {
+    const uint4 *o0 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0x00>(phi) << 32) | dpp_quad<0x00>(plo));
+    const uint4 *o1 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0x55>(phi) << 32) | dpp_quad<0x55>(plo));
+    const uint4 *o2 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0xAA>(phi) << 32) | dpp_quad<0xAA>(plo));
+    const uint4 *o3 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0xFF>(phi) << 32) | dpp_quad<0xFF>(plo));
+    R[0] = o0[q];
+    R[1] = o1[q];
+    R[2] = o2[q];
+    R[3] = o3[q];
+  }
+  // stage 1: exchange with lane^1 (quad_perm [1,0,3,2] = 0xB1); stage 2: with lane^2 (quad_perm [2,3,0,1] = 0x4E)
+  const bool q0 = (q & 1u) != 0, q1 = (q & 2u) != 0;
+  uint4 S[4], T[4];
+  // The DPP moves are evaluated for ALL lanes first (a move placed under the `take` predicate would read
+  // disabled partner lanes), the per-lane choice is a plain select afterwards.
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool take = ((e & 1) != 0) != q0;
+    const uint4 other = R[e ^ 1];
+    const uint32_t ox = dpp_quad<0xB1>(other.x), oy = dpp_quad<0xB1>(other.y), oz = dpp_quad<0xB1>(other.z),
+                   ow = dpp_quad<0xB1>(other.w);
+    S[e].x = take ? ox : R[e].x;
+    S[e].y = take ? oy : R[e].y;
+    S[e].z = take ? oz : R[e].z;
+    S[e].w = take ? ow : R[e].w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool take = ((e & 2) != 0) != q1;
+    const uint4 other = S[e ^ 2];
+    const uint32_t ox = dpp_quad<0x4E>(other.x), oy = dpp_quad<0x4E>(other.y), oz = dpp_quad<0x4E>(other.z),
+                   ow = dpp_quad<0x4E>(other.w);
+    T[e].x = take ? ox : S[e].x;
+    T[e].y = take ? oy : S[e].y;
+    T[e].z = take ? oz : S[e].z;
+    T[e].w = take ? ow : S[e].w;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    w[4 * e] = T[e].x;
+    w[4 * e + 1] = T[e].y;
+    w[4 * e + 2] = T[e].z;
+    w[4 * e + 3] = T[e].w;
+  }
+}
+
+template <bool COOP, class Ctx>
 __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active) {
   GmxLane ln;
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
@@ -245,7 +306,14 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       mf = __ballot(can_fast);
       ms = __ballot(ln.have && !can_fast);
       if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
-      if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
+      if (COOP) {
+        const uint32_t *src = can_fast ? gmx_dfs_fast_src(ix, ln) : reinterpret_cast<const uint32_t *>(ix.blocks);
+        uint32_t w[16];
+        coop_fetch(src, w);
+        if (can_fast && !gmx_dfs_fast_iter_line(ix, ctx, rd, ln, w)) wait_slow = true;
+      } else {
+        if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
+      }
     }
     if ((mf | ms) == 0) break;
     // ---- one general iteration for every waiting lane ----
@@ -387,7 +455,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       lane_stop = stop;
     }
   }
-  dfs_run_wave(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
+  dfs_run_wave<false>(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
   if (run) status = ctx.status;
   finish_lane(o, active, task, ctx, status, done);
 }
@@ -425,7 +493,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
       ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
     }
   }
-  dfs_run_wave(ix, ctx, r, 0, active);
+  dfs_run_wave<true>(ix, ctx, r, 0, active);
   status = ctx.status;
   finish_lane(o, active, task, ctx, status, true);
 }
@@ -490,7 +558,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       });
       run = ctx.status == GMX_TASK_MAPPED;
     }
-    dfs_run_wave(ix, ctx, r, 0, run);
+    dfs_run_wave<false>(ix, ctx, r, 0, run);
     if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
