@@ -106,9 +106,6 @@ struct GmxScratch {
   static constexpr uint32_t total = hull + Env::H_MAX * 3;
 };
 
-GMX_HD uint32_t gmx_n_edges(const GmxIndexView &ix, uint32_t node) {
-  return ix.nodes[node + 1].edge_begin - ix.nodes[node].edge_begin;
-}
 GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
 
 // The loci of item `it` appended to loci[n_loci..] (a LocusFinder run whose sets are merged into the
@@ -253,10 +250,12 @@ GMX_HD int gmx_key_cmp(Env &env, uint32_t a, uint32_t b) {
 }
 
 // ---------------------------------------------------------------------------
-// Traverser on the flat graph (allele_base.cpp:137-219)
+// Traverser on the flat graph (allele_base.cpp:137-219). The current node's record travels in
+// registers: a single-edge hop costs one dependent load (GmxNode::edge0), a bubble entry two.
 // ---------------------------------------------------------------------------
 struct GmxWalk {
   uint32_t node;
+  GmxNode rec;           // nodes[node]
   uint32_t remaining;
   uint32_t cursor;       // arena node of the next locus to consume (newest first); GMX_NIL = exhausted
   uint32_t enc_site;     // encapsulated item: single locus, consumed when enc_left
@@ -268,8 +267,22 @@ struct GmxWalk {
 };
 #define GMX_NO_NODE 0xFFFFFFFFu
 
-GMX_HD void gmx_walk_update(const GmxIndexView &ix, GmxWalk &w) {  // update_coordinates :189-204
-  uint32_t len = ix.nodes[w.node].seq_len;
+GMX_HD void gmx_walk_init(const GmxIndexView &ix, GmxWalk &w, uint32_t p, uint32_t node, const GmxNode &rec,
+                          uint32_t read_len, uint32_t tvd, uint32_t enc_site, int32_t enc_allele) {
+  w.node = node;
+  w.rec = rec;
+  w.remaining = read_len;
+  w.cursor = tvd;
+  w.enc_site = enc_site;
+  w.enc_allele = enc_allele;
+  w.enc_left = enc_site != 0;
+  w.first = true;
+  w.start = p - rec.first_pos;
+  w.end = 0;
+  w.bad = false;
+}
+GMX_HD void gmx_walk_update(GmxWalk &w) {  // update_coordinates :189-204
+  uint32_t len = w.rec.seq_len;
   w.end = 0;
   if (len > 0) {
     if (w.remaining == 0) {  // never reached by the reference on valid mappings (would wrap a size_t)
@@ -284,17 +297,18 @@ GMX_HD void gmx_walk_update(const GmxIndexView &ix, GmxWalk &w) {  // update_coo
 template <class Env>
 GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  // go_to_next_site :168-187
   w.start = 0;
-  while (gmx_n_edges(ix, w.node) == 1) {
+  while (w.rec.n_edges == 1) {
     if (w.remaining == 0) {
       w.node = GMX_NO_NODE;
       return;
     }
-    w.node = ix.edges[ix.nodes[w.node].edge_begin];
-    gmx_walk_update(ix, w);
+    w.node = w.rec.edge0;
+    w.rec = ix.nodes[w.node];
+    gmx_walk_update(w);
     if (w.bad) return;
-    if (gmx_in_bubble(ix.nodes[w.node])) return;
+    if (gmx_in_bubble(w.rec)) return;
   }
-  uint32_t ne = gmx_n_edges(ix, w.node);
+  uint32_t ne = w.rec.n_edges;
   int32_t allele;
   if (w.enc_site != 0) {
     if (!w.enc_left) {
@@ -315,17 +329,18 @@ GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  
     w.bad = true;
     return;
   }
-  w.node = ix.edges[ix.nodes[w.node].edge_begin + (uint32_t)allele];
-  gmx_walk_update(ix, w);
+  w.node = allele == 0 ? w.rec.edge0 : ix.edges[w.rec.edge_begin + (uint32_t)allele];
+  w.rec = ix.nodes[w.node];
+  gmx_walk_update(w);
 }
 // next_Node :149-166. Returns GMX_NO_NODE at the end.
 template <class Env>
 GMX_HD uint32_t gmx_walk_next(const GmxIndexView &ix, Env &env, GmxWalk &w) {
   if (w.first) {
     w.first = false;
-    gmx_walk_update(ix, w);
+    gmx_walk_update(w);
     if (w.bad) return GMX_NO_NODE;
-    if (!gmx_in_bubble(ix.nodes[w.node])) gmx_walk_next_site(ix, env, w);
+    if (!gmx_in_bubble(w.rec)) gmx_walk_next_site(ix, env, w);
     if (w.node == GMX_NO_NODE) w.bad = true;  // the reference would dereference a null node here
     return w.bad ? GMX_NO_NODE : w.node;
   }
@@ -337,9 +352,9 @@ GMX_HD uint32_t gmx_walk_next(const GmxIndexView &ix, Env &env, GmxWalk &w) {
 
 // process_Node + DummyCovNode hull (allele_base.cpp:109-135,282-296)
 template <class Env>
-GMX_HD bool gmx_hull_add(const GmxIndexView &ix, Env &env, uint32_t &n_hull, uint32_t node, uint32_t s, uint32_t e) {
+GMX_HD bool gmx_hull_add(Env &env, uint32_t &n_hull, uint32_t node, uint32_t seq_len, uint32_t s, uint32_t e) {
   typedef GmxScratch<Env> S;
-  if (ix.nodes[node].seq_len == 0) return true;
+  if (seq_len == 0) return true;
   for (uint32_t i = 0; i < n_hull; ++i) {
     if (env.sget(S::hull + 3 * i) != node) continue;
     uint32_t hs = env.sget(S::hull + 3 * i + 1), he = env.sget(S::hull + 3 * i + 2);
@@ -370,16 +385,10 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
   for (uint32_t occ = lo;; ++occ) {
     uint32_t p = ix.sa[occ];
     GmxWalk w;
-    w.node = ix.pos_node[p];
-    w.remaining = read_len;
-    w.cursor = tvd;
-    w.enc_site = enc_site;
-    w.enc_allele = enc_allele;
-    w.enc_left = enc_site != 0;
-    w.first = true;
-    w.start = p - ix.nodes[w.node].first_pos;
-    w.end = 0;
-    w.bad = false;
+    {
+      uint32_t node0 = ix.pos_node[p];
+      gmx_walk_init(ix, w, p, node0, ix.nodes[node0], read_len, tvd, enc_site, enc_allele);
+    }
     if (first) {
       first = false;
       for (;;) {
@@ -389,7 +398,7 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
           return false;
         }
         if (node == GMX_NO_NODE) break;
-        if (!gmx_hull_add(ix, env, n_hull, node, w.start, w.end)) return false;
+        if (!gmx_hull_add(env, n_hull, node, w.rec.seq_len, w.start, w.end)) return false;
       }
     } else {
       uint32_t node = gmx_walk_next(ix, env, w);
@@ -397,11 +406,80 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
         env.fail(GMX_TASK_ERROR);
         return false;
       }
-      if (!gmx_hull_add(ix, env, n_hull, node, w.start, w.end)) return false;
+      if (!gmx_hull_add(env, n_hull, node, w.rec.seq_len, w.start, w.end)) return false;
     }
     if (occ == hi) break;
   }
   return true;
+}
+
+// ---------------------------------------------------------------------------
+// The common case, without scratch: ONE final state of interval width one on a non-nested PRG.
+// There is one item, hence one equivalence class and total == 1 (or only a non-variant
+// instance): the draw cannot change the outcome, the loci are the state's own path plus the
+// allele under SA[lo], and one DAG walk visits each node once, so the hull is the walk itself.
+// Results are identical to the general routine below (tests/hostemu runs both).
+// ---------------------------------------------------------------------------
+template <class Env>
+GMX_HD bool gmx_record_locus(const GmxIndexView &ix, Env &env, uint32_t site, int32_t allele) {
+  const GmxSite &s = ix.sites[(site - 5) >> 1];
+  if (allele < 0 || (uint32_t)allele >= s.n_alleles) {
+    env.fail(GMX_TASK_ERROR);
+    return false;
+  }
+  env.add_allele_sum(s.allele_sum_off + (uint32_t)allele);
+  if (s.grouped_off != GMX_GROUPED_LOG) {
+    env.add_grouped_dense(s.grouped_off + (1u << allele) - 1);
+  } else {
+    if (!env.log_grouped_begin((site - 5) >> 1, 1)) return false;
+    env.log_grouped_id(allele);
+    env.log_grouped_end();
+  }
+  return true;
+}
+template <class Env>
+GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
+  const uint32_t tvd = st.traversed, tvg = st.traversing;
+  const uint32_t p = ix.sa[st.lo];
+  const uint32_t node0 = ix.pos_node[p];
+  const GmxNode rec0 = ix.nodes[node0];
+  uint32_t enc_site = 0;
+  int32_t enc_allele = -1;
+  if (tvd == GMX_NIL && tvg == GMX_NIL) {
+    if (rec0.site == 0) return;  // a non-variant instance only: nothing to record
+    enc_site = rec0.site;
+    enc_allele = rec0.allele;
+  } else {  // check_site_uniqueness (coverage_common.cpp:17-32)
+    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
+      uint32_t sx = gmx_h_site(env.arena, x);
+      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
+      for (uint32_t y = tvg; y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
+    }
+    for (uint32_t x = tvg; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
+      uint32_t sx = gmx_h_site(env.arena, x);
+      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
+        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
+    }
+  }
+  GmxWalk w;
+  gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
+  for (;;) {
+    uint32_t node = gmx_walk_next(ix, env, w);
+    if (w.bad) return env.fail(GMX_TASK_ERROR);
+    if (node == GMX_NO_NODE) break;
+    if (w.rec.seq_len == 0) continue;
+    if (w.rec.cov_off == GMX_NO_COV) return env.fail(GMX_TASK_ERROR);
+    for (uint32_t i = w.start; i <= w.end; ++i) env.add_per_base(w.rec.cov_off + i);
+  }
+  if (enc_site != 0) {
+    gmx_record_locus(ix, env, enc_site, enc_allele);
+    return;
+  }
+  if (tvg != GMX_NIL && !gmx_record_locus(ix, env, gmx_h_site(env.arena, tvg), rec0.allele)) return;
+  for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x))
+    if (!gmx_record_locus(ix, env, gmx_h_site(env.arena, x), gmx_h_allele(env.arena, x))) return;
 }
 
 // ---------------------------------------------------------------------------
@@ -411,6 +489,10 @@ template <class Env>
 GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState *finals, uint32_t n_final,
                            uint32_t read_len, uint32_t seed, int rng_mode) {
   typedef GmxScratch<Env> S;
+  if (n_final == 1 && !ix.is_nested && finals[0].lo == finals[0].hi) {
+    gmx_cover_single(ix, env, finals[0], read_len);
+    return;
+  }
   // --- items: path-bearing states + allele-encapsulated positions (encapsulated_search.cpp:30-107) ---
   uint32_t n_items = 0;
   uint32_t nonvariant = 0;  // count_nonvar_search_states, coverage_common.cpp:130-141 (uint32 arithmetic)

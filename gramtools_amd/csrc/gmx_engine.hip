@@ -185,12 +185,17 @@ __device__ bool all_kmers_present(const GmxIndexView &ix, ReadRef &r) {
   const uint32_t k = ix.kmer_size;
   const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
   uint32_t code = kmer_code(r, 0, k);
-  for (uint32_t o = 0;; ++o) {
-    if (!((ix.kmer_bitmap[code >> 5] >> (code & 31)) & 1u)) return false;
-    if (o + k >= r.len) break;
-    code = ((code << 2) | (r.at(o + k) - 1u)) & mask;
+  for (uint32_t o = 0;;) {  // four independent bitmap probes in flight per round
+    uint32_t present = 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      present &= ix.kmer_bitmap[code >> 5] >> (code & 31);
+      if (o + k >= r.len) return present & 1u;
+      code = ((code << 2) | (r.at(o + k) - 1u)) & mask;
+      ++o;
+    }
+    if (!(present & 1u)) return false;
   }
-  return true;
 }
 
 // seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241);
@@ -345,6 +350,7 @@ struct SearchOut {
   uint32_t *mapped_list;     // task ids with final states (bit 31 = big-pass slot index instead)
   uint32_t *overflow_list;   // task ids to re-run with large capacities
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
+  uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
@@ -573,8 +579,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     g.n_final[slot] = nf;
     g.task_of_slot[slot] = task;
     if (status == GMX_TASK_MAPPED && nf > 0) {
-      uint32_t at = atomicAdd(&o.counters[0 * GMX_CNT_STRIDE], 1u);
-      o.mapped_list[at] = 0x80000000u | slot;
+      uint32_t at = atomicAdd(&o.counters[7 * GMX_CNT_STRIDE], 1u);
+      o.big_mapped_list[at] = 0x80000000u | slot;
     }
   }
 }
@@ -591,6 +597,8 @@ struct CoverAcc {
   uint32_t n_lanes;
   uint32_t *scratch_big;
   uint32_t n_lanes_big;
+  uint32_t *scratch_side;  // regular-size scratch of the instance that follows the large-capacity search
+  uint32_t n_lanes_side;
   int rng_mode;
 };
 
@@ -629,13 +637,17 @@ struct CoverEnvT {
 typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
-// BIG = false: every mapped task; a task whose selection exceeds the small scratch is queued (nothing has been
-// recorded for it yet) and redone by the BIG = true instance, which walks that queue.
-template <class Env, bool BIG>
+// Three instances over three device-side queues (LIST):
+//   0  tasks finished by the extend kernel, small per-lane scratch
+//   2  tasks finished by the large-capacity search (runs on the engine's side stream), small scratch
+//   1  entries of either whose selection exceeded the small scratch (nothing has been recorded for them yet),
+//      redone with the large scratch after both
+template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
-  uint32_t n_mapped = BIG ? o.counters[4 * GMX_CNT_STRIDE] : o.counters[0 * GMX_CNT_STRIDE];
-  const uint32_t *list = BIG ? o.cover_overflow_list : o.mapped_list;
+  constexpr bool BIG = LIST == 1;
+  uint32_t n_mapped = o.counters[(LIST == 0 ? 0 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  const uint32_t *list = LIST == 0 ? o.mapped_list : LIST == 1 ? o.cover_overflow_list : o.big_mapped_list;
   uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * blockDim.x) {
     uint32_t entry = list[m];
@@ -657,8 +669,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     uint32_t read = task >> 1;
     uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
     Env env;
-    env.scratch = (BIG ? acc.scratch_big : acc.scratch) + lane_id;
-    env.stride = BIG ? acc.n_lanes_big : acc.n_lanes;
+    env.scratch = (LIST == 0 ? acc.scratch : LIST == 1 ? acc.scratch_big : acc.scratch_side) + lane_id;
+    env.stride = LIST == 0 ? acc.n_lanes : LIST == 1 ? acc.n_lanes_big : acc.n_lanes_side;
     env.arena = arena;
     env.allele_sum = acc.allele_sum;
     env.per_base = acc.per_base;
@@ -714,10 +726,77 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
 // Validation + 2-bit packing, one lane per read. Reads holding a byte outside 1..4 are skipped as a whole
 // (encode_dna_bases, utils.cpp:73-92). The search kernels then fetch 16 bases per dword load instead of one
 // byte per step (the per-step byte loads of 64 different reads thrashed L1 and L2: one L2 miss per lane-step).
+//
+// A block owns GMX_PACK_READS consecutive reads, whose bytes and whose packed words are both contiguous:
+// the bytes are staged through LDS with coalesced 16-byte loads, packed from LDS (aligned dwords joined with
+// v_alignbyte), and written back from LDS with coalesced stores. Blocks whose reads do not fit the LDS
+// window (very long reads) take the direct per-lane path.
+#define GMX_PACK_READS 128
+#define GMX_PACK_IN_BYTES (24 * 1024)
+#define GMX_PACK_OUT_WORDS (GMX_PACK_IN_BYTES / 16 + GMX_PACK_READS + 8)
 typedef uint32_t __attribute__((aligned(1))) gmx_u32_unaligned;
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_pack_kernel(BatchView b, uint8_t *skip, uint32_t *packed) {
-  uint32_t read = blockIdx.x * GMX_BLOCK + threadIdx.x;
-  if (read >= b.n_reads) return;
+__device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t &bad) {
+  uint32_t y = x - 0x01010101u;                         // per-byte code 0..3 when every byte is in 1..4
+  bad |= ((y & ~x & 0x80808080u) | (y & 0xFCFCFCFCu));  // a zero byte, or a byte > 4
+  return (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;  // 4 x 2 bits
+}
+__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint32_t *packed) {
+  __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
+  __shared__ uint32_t outw[GMX_PACK_OUT_WORDS];
+  const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
+  const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
+  const uint32_t read = r0 + threadIdx.x;
+  const uint64_t s0 = b.offsets[r0], s1 = b.offsets[r1];
+  const uintptr_t g0 = reinterpret_cast<uintptr_t>(b.reads + s0);
+  const uint32_t shift = (uint32_t)(g0 & 15u);
+  const uint64_t span = (s1 - s0) + shift;
+  if (span <= GMX_PACK_IN_BYTES) {  // block-uniform
+    const uint4 *src = reinterpret_cast<const uint4 *>(g0 - shift);
+    const uint32_t n16 = (uint32_t)((span + 15) >> 4);
+    for (uint32_t i = threadIdx.x; i < n16; i += GMX_PACK_READS) in4[i] = src[i];
+    const uint64_t po0 = pack_off(b, r0);
+    const uint32_t n_out = (uint32_t)(pack_off(b, r1) - po0);
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) outw[i] = 0;
+    __syncthreads();
+    if (read < r1) {
+      const uint64_t s = b.offsets[read];
+      const uint32_t len = (uint32_t)(b.offsets[read + 1] - s);
+      const uint32_t q = shift + (uint32_t)(s - s0);
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(in4);
+      const uint8_t *bytes = reinterpret_cast<const uint8_t *>(in4);
+      uint32_t *out = outw + (uint32_t)(pack_off(b, read) - po0);
+      uint32_t idx = q >> 2;
+      const uint32_t sh = q & 3u;
+      uint32_t bad = 0;
+      const uint32_t full = len >> 4;
+      uint32_t carry = w[idx];
+      for (uint32_t c = 0; c < full; ++c) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t nxt = w[++idx];
+          word |= pack4(__builtin_amdgcn_alignbyte(nxt, carry, sh), bad) << (8 * j);
+          carry = nxt;
+        }
+        out[c] = word;
+      }
+      const uint32_t rem = len & 15u;
+      if (rem) {
+        uint32_t word = 0;
+        for (uint32_t j = 0; j < rem; ++j) {
+          uint32_t x = bytes[q + full * 16 + j];
+          if (x < 1 || x > 4) bad = 1;
+          word |= ((x - 1u) & 3u) << (2 * j);
+        }
+        out[full] = word;
+      }
+      skip[read] = bad ? 1 : 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) packed[po0 + i] = outw[i];
+    return;
+  }
+  if (read >= r1) return;
   uint64_t s = b.offsets[read], e = b.offsets[read + 1];
   uint32_t len = (uint32_t)(e - s);
   const uint8_t *p = b.reads + s;
@@ -727,13 +806,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_pack_kernel(BatchView b, uint8_
   for (uint32_t c = 0; c < full; ++c) {
     uint32_t word = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t x = *reinterpret_cast<const gmx_u32_unaligned *>(p + c * 16 + j * 4);
-      uint32_t y = x - 0x01010101u;                       // per-byte code 0..3 when every byte is in 1..4
-      bad |= ((y & ~x & 0x80808080u) | (y & 0xFCFCFCFCu));  // a zero byte, or a byte > 4
-      uint32_t q = (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;  // 4 x 2 bits
-      word |= q << (8 * j);
-    }
+    for (int j = 0; j < 4; ++j)
+      word |= pack4(*reinterpret_cast<const gmx_u32_unaligned *>(p + c * 16 + j * 4), bad) << (8 * j);
     out[c] = word;
   }
   uint32_t rem = len & 15u;
@@ -783,7 +857,10 @@ struct gmx_engine {
   GmxPathNode *d_arena = nullptr;
   BigOut big{};
   uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
-  uint32_t cover_blocks = 0, cover_big_lanes = 0;
+  uint32_t cover_blocks = 0, cover_big_lanes = 0, cover_side_blocks = 0;
+  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr;
+  hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
   uint64_t *d_offsets = nullptr;
@@ -917,6 +994,12 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // coverage scratch
   e->cover_blocks = 1024;
   rc |= e->alloc(&e->d_scratch, (size_t)GmxScratch<CoverEnv>::total * e->cover_blocks * GMX_BLOCK, false);
+  e->cover_side_blocks = 32;
+  rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
+  rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
+  rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
+  rc |= hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess;
+  rc |= hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess;
   e->cover_big_lanes = 64 * 32;
   rc |= e->alloc(&e->d_scratch_big, (size_t)GmxScratch<CoverEnvBig>::total * e->cover_big_lanes, false);
   if (rc) {
@@ -931,6 +1014,9 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->opts.device);
   (void)hipDeviceSynchronize();
+  if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (void *p : e->allocs) (void)hipFree(p);
   delete e;
 }
@@ -977,13 +1063,13 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow,
-              e->d_alive,  e->d_dead,    e->d_counters};
+              e->d_big_mapped, e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 3 * GMX_CNT_STRIDE * 4, stream));
-  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0, stream, b,
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 4 * GMX_CNT_STRIDE * 4, stream));
+  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
@@ -1000,13 +1086,21 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
   hipLaunchKernelGGL(gmx_extend_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, stream, e->dview, b, o, e->big);
-  hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
   CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
-               e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, false>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
+               e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes,
+               e->d_scratch_side, e->cover_side_blocks * GMX_BLOCK, e->opts.rng_mode};
+  // fork: the few tasks of the large-capacity pass (one wave per CU, latency-bound) run beside filter + coverage
+  HIP_TRY(hipEventRecord(e->ev_fork, stream));
+  HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side_stream, e->dview, b, o, e->big);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side_stream,
+                     e->dview, b, o, e->big, acc);
+  HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
+  hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
                      o, e->big, acc);
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, true>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
+  HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
                      b, o, e->big, acc);
   hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK, 1024u)),
                      dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);

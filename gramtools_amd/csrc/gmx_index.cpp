@@ -506,12 +506,15 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     } else
       n.cov_off = GMX_NO_COV;
     for (auto e : bn.next) out.edges.push_back(e);
+    n.n_edges = (uint32_t)bn.next.size();
+    n.edge0 = bn.next.empty() ? 0xFFFFFFFFu : bn.next[0];
   }
   {
     GmxNode &closing = out.nodes[g.nodes.size()];
     memset(&closing, 0, sizeof(closing));
     closing.allele = -1;
     closing.cov_off = GMX_NO_COV;
+    closing.edge0 = 0xFFFFFFFFu;
     closing.edge_begin = (uint32_t)out.edges.size();
   }
   out.n_pb_slots = pb;

@@ -41,6 +41,8 @@ struct GmxNode {
   uint32_t first_pos;   // PRG position of the first base (sequence nodes) / of the marker (boundary nodes)
   uint32_t cov_off;     // offset into the per-base accumulator, 0xFFFFFFFF if the node owns none
   uint32_t edge_begin;  // first out-edge in edges[]; n_edges = next node's edge_begin - edge_begin
+  uint32_t n_edges;     // copy of that difference, and
+  uint32_t edge0;       // edges[edge_begin] (0xFFFFFFFF if none): a single-edge hop needs no second load
 };
 #define GMX_NO_COV 0xFFFFFFFFu
 
