@@ -107,6 +107,9 @@ struct GmxScratch {
 };
 
 GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
+// A final state is an SA interval [lo, hi], or — text form (gmx_types.h, GmxTextRec) — the single PRG position lo.
+GMX_HD bool gmx_text_form(uint32_t hi) { return hi == GMX_TEXT_MARK; }
+GMX_HD uint32_t gmx_occ_pos(const GmxIndexView &ix, uint32_t hi, uint32_t i) { return gmx_text_form(hi) ? i : ix.sa[i]; }
 
 // The loci of item `it` appended to loci[n_loci..] (a LocusFinder run whose sets are merged into the
 // class's set, coverage_common.cpp:110-122). check_site_uniqueness (:17-32) is enforced.
@@ -179,10 +182,10 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
       uint32_t parent_seed = gmx_h_site(env.arena, tvg);
       int32_t last_allele = -1;
       for (uint32_t i = lo;; ++i) {
-        uint32_t p = ix.sa[i];
+        uint32_t p = gmx_occ_pos(ix, hi, i);
         last_allele = ix.nodes[ix.pos_node[p]].allele;
         if (!window_add(parent_seed, last_allele)) return 0xFFFFFFFFu;
-        if (i == hi) break;
+        if (gmx_text_form(hi) || i == hi) break;
       }
       // assign_nested_locus(new_locus): the seed site itself is not yet in used_sites (unique_loci and
       // used_sites are separate sets in the reference), so the walk continues with its parent chain.
@@ -383,7 +386,7 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
   int32_t enc_allele = (int32_t)env.sget(base + 5);
   bool first = true;
   for (uint32_t occ = lo;; ++occ) {
-    uint32_t p = ix.sa[occ];
+    uint32_t p = gmx_occ_pos(ix, hi, occ);
     GmxWalk w;
     {
       uint32_t node0 = ix.pos_node[p];
@@ -408,7 +411,7 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
       }
       if (!gmx_hull_add(env, n_hull, node, w.rec.seq_len, w.start, w.end)) return false;
     }
-    if (occ == hi) break;
+    if (gmx_text_form(hi) || occ == hi) break;
   }
   return true;
 }
@@ -440,7 +443,7 @@ GMX_HD bool gmx_record_locus(const GmxIndexView &ix, Env &env, uint32_t site, in
 template <class Env>
 GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
   const uint32_t tvd = st.traversed, tvg = st.traversing;
-  const uint32_t p = ix.sa[st.lo];
+  const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
   const uint32_t node0 = ix.pos_node[p];
   const GmxNode rec0 = ix.nodes[node0];
   uint32_t enc_site = 0;
@@ -489,7 +492,7 @@ template <class Env>
 GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState *finals, uint32_t n_final,
                            uint32_t read_len, uint32_t seed, int rng_mode) {
   typedef GmxScratch<Env> S;
-  if (n_final == 1 && !ix.is_nested && finals[0].lo == finals[0].hi) {
+  if (n_final == 1 && !ix.is_nested && (finals[0].lo == finals[0].hi || gmx_text_form(finals[0].hi))) {
     gmx_cover_single(ix, env, finals[0], read_len);
     return;
   }
@@ -518,12 +521,12 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
       continue;
     }
     for (uint32_t i = st.lo;; ++i) {
-      const GmxNode &nd = ix.nodes[ix.pos_node[ix.sa[i]]];
+      const GmxNode &nd = ix.nodes[ix.pos_node[gmx_occ_pos(ix, st.hi, i)]];
       if (nd.site == 0)
         nonvariant += 1;
-      else if (!add_item(i, i, GMX_NIL, GMX_NIL, nd.site, nd.allele))
+      else if (!add_item(i, gmx_text_form(st.hi) ? st.hi : i, GMX_NIL, GMX_NIL, nd.site, nd.allele))
         return;
-      if (i == st.hi) break;
+      if (gmx_text_form(st.hi) || i == st.hi) break;
     }
   }
   if (n_items == 0) return;  // usps.size() == 0: nothing recorded, no draw (coverage_common.cpp:96-97)

@@ -4,7 +4,8 @@
 // read one base at a time. States never interact, so a lane may instead carry ONE state in registers down the
 // read and keep the others (siblings created at variant markers, extra seed states) on a small LIFO stack:
 //
-//   every iteration = one 64-byte line fetch (a rank block, or a marker-hit record) + register arithmetic.
+//   every iteration = one small fetch (a rank block, a marker-hit record, or 32 symbols of the PRG itself once
+//   the state has narrowed to a single suffix-array position) + register arithmetic.
 //
 // No second dependent load inside an iteration, no per-wave serialisation of the rare marker path: a marker
 // hit only pushes {hit rank, path handles, position}; it is resolved when popped — by then as the lane's
@@ -21,7 +22,7 @@
 
 #define GMX_MODE_STATE 0u  // marker pass, then LF with the base left of `pos`
 #define GMX_MODE_LF 1u     // LF only (state fresh from a general jump program; reference: appended states, vBWT_jump.cpp:119-132)
-#define GMX_MODE_HIT 2u    // unresolved marker hit: a = marker rank
+#define GMX_MODE_HIT 2u    // unresolved marker hit: a = index of its record in hits[]
 
 // adapter: states produced by the general jump-program interpreter go on the stack as LF-only entries
 template <class Ctx>
@@ -63,14 +64,14 @@ GMX_HD void gmx_dfs_push_hits(const GmxIndexView &ix, uint32_t lo, uint32_t hi, 
     while (s0) {
       uint32_t bit = (uint32_t)__builtin_ctzll(s0);
       s0 &= s0 - 1;
-      uint32_t h = mbase + gmx_popc64(k0 & ((1ull << bit) - 1ull));
+      uint32_t h = ix.hit_perm[mbase + gmx_popc64(k0 & ((1ull << bit) - 1ull))];
       if (!ctx.push(h, 0, tvd, tvg, pos, GMX_MODE_HIT)) ctx.fail(GMX_TASK_OVERFLOW);
     }
     uint32_t c0 = gmx_popc64(k0);
     while (s1) {
       uint32_t bit = (uint32_t)__builtin_ctzll(s1);
       s1 &= s1 - 1;
-      uint32_t h = mbase + c0 + gmx_popc64(k1 & ((1ull << bit) - 1ull));
+      uint32_t h = ix.hit_perm[mbase + c0 + gmx_popc64(k1 & ((1ull << bit) - 1ull))];
       if (!ctx.push(h, 0, tvd, tvg, pos, GMX_MODE_HIT)) ctx.fail(GMX_TASK_OVERFLOW);
     }
   }
@@ -119,6 +120,11 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
     ln.have = ctx.status == GMX_TASK_MAPPED && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
     return;
   }
+  if (ln.mode == GMX_MODE_STATE && ln.b == GMX_TEXT_MARK) {  // text-form states only ever take the fast iteration
+    ctx.fail(GMX_TASK_ERROR);
+    ln.have = false;
+    return;
+  }
   // --- the iteration's one line fetch ---
   const GmxLine *src = ln.mode == GMX_MODE_HIT ? reinterpret_cast<const GmxLine *>(ix.hits + ln.a)
                                                : reinterpret_cast<const GmxLine *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
@@ -145,6 +151,10 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
           ln.tvd = nn;
           alive = line.w[4] == c;  // the only base that can precede the site marker
           ln.a = ln.b = line.w[5];
+          if (line.w[12] != GMX_NIL) {
+            ln.a = line.w[12];
+            ln.b = GMX_TEXT_MARK;
+          }
         }
       }
     } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
@@ -156,6 +166,11 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
         ln.a = c == 1 ? line.w[4] : (c == 2 ? line.w[6] : (c == 3 ? line.w[8] : line.w[10]));
         ln.b = c == 1 ? line.w[5] : (c == 2 ? line.w[7] : (c == 3 ? line.w[9] : line.w[11]));
         alive = ln.a <= ln.b;
+        const uint32_t tp = c == 1 ? line.w[12] : (c == 2 ? line.w[13] : (c == 3 ? line.w[14] : line.w[15]));
+        if (ln.a == ln.b && tp != GMX_NIL) {
+          ln.a = tp;
+          ln.b = GMX_TEXT_MARK;
+        }
       }
     } else {  // general jump program: its outputs still need their LF step -> pushed as LF-only entries
       GmxDfsProgSink<Ctx> sink{ctx, ln.pos};
@@ -178,106 +193,155 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
   }
 }
 
-// The FAST iteration covers the cases that make up almost every step of a read on a flat PRG:
-//   * a width-1 interval: LF step with 32-bit word arithmetic on one block; if a variant marker precedes the
-//     position, the state turns into the pending hit itself (its own LF step would die: the BWT symbol is not a base);
-//   * a pending hit whose record is pre-resolved (GMX_HIT_EXIT / GMX_HIT_ENTER) and whose traversing path is empty
-//     or inline: path update + the precomputed LF result, no further fetch.
-// No stack traffic, no calls, one 64-byte line per iteration. Preconditions: gmx_dfs_fast_ok().
-// Returns false, leaving the lane untouched, when the general iteration is needed.
-GMX_HD bool gmx_dfs_fast_ok(const GmxLane &ln, uint32_t stop) {
-  return ln.have && ln.pos > stop && ((ln.mode == GMX_MODE_STATE && ln.a == ln.b) || ln.mode == GMX_MODE_HIT);
+// The FAST iterations cover what makes up almost every step of a read on a flat PRG. A lane is in exactly one
+// of three situations (gmx_dfs_fast_kind), each costing one small fetch and register arithmetic:
+//   CONVERT  a width-one interval [i, i]: the state switches to TEXT FORM (a = SA[i], b = GMX_TEXT_MARK);
+//   TEXT     a text-form state compares up to 32 read bases against one GmxTextRec. Equivalent to that many
+//            backward steps of the reference: for a single SA position i the LF step with base c succeeds iff
+//            BWT[i] == c, BWT[i] = PRG[SA[i] - 1], and the next position is SA[i] - 1 (BWT_search.cpp:28-76);
+//            a variant marker left of the position is the marker hit left_markers_search would report
+//            (vBWT_jump.cpp:94-117), and the state's own LF step dies on it (a marker is not a base);
+//   HIT      a pending hit whose record is pre-resolved (GMX_HIT_EXIT / GMX_HIT_ENTER) and whose traversing
+//            path is empty or inline: path update + the precomputed LF result.
+// No stack traffic, no calls. A fast HIT iteration returns false, leaving the lane untouched, when the general
+// iteration is needed.
+#define GMX_FAST_NONE 0u
+#define GMX_FAST_HIT 1u
+#define GMX_FAST_TEXT 2u
+#define GMX_FAST_CONVERT 3u
+GMX_HD uint32_t gmx_dfs_fast_kind(const GmxLane &ln, uint32_t stop) {
+  if (!ln.have || ln.pos <= stop) return GMX_FAST_NONE;
+  if (ln.mode == GMX_MODE_HIT) return GMX_FAST_HIT;
+  if (ln.mode != GMX_MODE_STATE) return GMX_FAST_NONE;
+  return ln.b == GMX_TEXT_MARK ? GMX_FAST_TEXT : (ln.a == ln.b ? GMX_FAST_CONVERT : GMX_FAST_NONE);
 }
-// address of the 64-byte line the lane's fast iteration consumes: a rank block or a hit record
-GMX_HD const uint32_t *gmx_dfs_fast_src(const GmxIndexView &ix, const GmxLane &ln) {
-  return ln.mode == GMX_MODE_HIT ? reinterpret_cast<const uint32_t *>(ix.hits + ln.a)
-                                 : reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+
+GMX_HD uint32_t gmx_bitrev32(uint32_t v) {
+#if defined(__clang__)
+  return __builtin_bitreverse32(v);  // v_bfrev_b32
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(v);
+#endif
 }
-// `w` = the 16 words of that line (the extend kernel fetches it quad-cooperatively, everything else directly)
-template <class Ctx, class Reader>
-GMX_HD bool gmx_dfs_fast_iter_line(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln, const uint32_t *w) {
-  const bool is_hit = ln.mode == GMX_MODE_HIT;
-  const uint32_t i = ln.a;
-  const uint32_t bi = i >> GMX_BLK_SHIFT;
-  // one 64-byte line: a rank block (counts | lo plane | hi plane | marker plane) or a hit record
-  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-  const uint32_t l0 = w[4], l1 = w[5], l2 = w[6], l3 = w[7];
-  const uint32_t h0 = w[8], h1 = w[9], h2 = w[10], h3 = w[11];
-  const uint32_t k0 = w[12], k1 = w[13], k2 = w[14], k3 = w[15];
-  const uint32_t c = rd.at(ln.pos - 1);
-  if (is_hit) {
-    (void)w1;
-    bool alive;
-    if (w0 == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
-      if (ln.tvg != GMX_NIL) {
-        if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != w2) return false;  // general path (or error there)
-      }
-      uint32_t nn = ctx.arena_new(w2, (int32_t)w3, ln.tvd);
-      if (nn == GMX_NIL) return false;
-      ln.tvg = GMX_NIL;
-      ln.tvd = nn;
-      alive = l0 == c;  // lf[0]: the only base that can precede the site marker
-      ln.a = ln.b = l1;
-    } else if (w0 == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
-      if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
-      ln.tvg = GMX_INLINE_FLAG | ((w2 - 5u) >> 1);
-      ln.a = c == 1 ? l0 : (c == 2 ? l2 : (c == 3 ? h0 : h2));
-      ln.b = c == 1 ? l1 : (c == 2 ? l3 : (c == 3 ? h1 : h3));
-      alive = ln.a <= ln.b;
-    } else
-      return false;
-    if (alive) {
-      --ln.pos;
-      ln.mode = GMX_MODE_STATE;
-    } else
-      ln.mode = GMX_MODE_DEAD;
-    return true;
+// TEXT: which record and which 32 raw read bases the iteration needs.
+//   q = a - 1 is the PRG position left of the state, t its slot in the record. Slot s (<= t) is compared with
+//   oriented read base pos - 1 - (t - s).
+//   forward read: that is raw base (pos - 1 - t) + s   -> window from max(pos - 1 - t, 0), shifted up by `shift`
+//   reverse-complement read: raw base (len - pos) + (t - s), complemented -> window from len - pos, bit-reversed
+GMX_HD uint32_t gmx_dfs_text_rec(const GmxLane &ln) { return (ln.a ? ln.a - 1u : 0u) >> 5; }
+GMX_HD void gmx_dfs_text_window(const GmxLane &ln, uint32_t len, bool rc, uint32_t &start, uint32_t &shift) {
+  const uint32_t t = (ln.a ? ln.a - 1u : 0u) & 31u;
+  if (rc) {
+    start = len - ln.pos;
+    shift = 0;
+  } else if (ln.pos > t) {
+    start = ln.pos - 1u - t;
+    shift = 0;
+  } else {
+    start = 0;
+    shift = t + 1u - ln.pos;
   }
-  const uint32_t j = (i >> 5) & 3u, t = i & 31u;
-  const uint32_t below = (1u << t) - 1u;
-  const uint32_t kj = j == 0 ? k0 : (j == 1 ? k1 : (j == 2 ? k2 : k3));
-  if ((kj >> t) & 1u) {
-    // a variant marker precedes this position: the state becomes its own (single) pending hit; marker rank =
-    // block count + markers below the position (left_markers_search, vBWT_jump.cpp:94-117)
-    uint32_t r = w3 + (j > 0 ? (uint32_t)__builtin_popcount(k0) : 0u) + (j > 1 ? (uint32_t)__builtin_popcount(k1) : 0u) +
-                 (j > 2 ? (uint32_t)__builtin_popcount(k2) : 0u) + (uint32_t)__builtin_popcount(kj & below);
-    ln.a = r;
+}
+// xlo/xhi: bit planes of raw read bases start .. start + 31 (bits past the read's end are ignored)
+GMX_HD void gmx_dfs_text_apply(GmxLane &ln, uint32_t stop, bool rc, const GmxTextRec &rec, uint32_t xlo, uint32_t xhi,
+                               uint32_t shift) {
+  if (ln.a == 0) {  // PRG start: BWT holds the sentinel, no base extends the match
+    ln.mode = GMX_MODE_DEAD;
+    return;
+  }
+  const uint32_t t = (ln.a - 1u) & 31u;
+  const uint32_t avail = ln.pos - stop;
+  const uint32_t n = avail < t + 1u ? avail : t + 1u;
+  uint32_t rlo, rhi;
+  if (rc) {
+    rlo = ~(gmx_bitrev32(xlo) >> (31u - t));
+    rhi = ~(gmx_bitrev32(xhi) >> (31u - t));
+  } else {
+    rlo = xlo << shift;
+    rhi = xhi << shift;
+  }
+  const uint32_t range = (n == 32u ? ~0u : ((1u << n) - 1u)) << (t + 1u - n);
+  const uint32_t events = (((rec.lo ^ rlo) | (rec.hi ^ rhi)) | rec.mk) & range;
+  if (events == 0) {
+    ln.a -= n;
+    ln.pos -= n;
+    return;
+  }
+  const uint32_t e = 31u - (uint32_t)__builtin_clz(events);  // nearest slot with a marker or a mismatch
+  ln.a -= t - e;
+  ln.pos -= t - e;
+  if ((rec.mk >> e) & 1u) {
+    ln.a = rec.mrank + (uint32_t)__builtin_popcount(rec.mk & ((1u << e) - 1u));
     ln.b = 0;
     ln.mode = GMX_MODE_HIT;
-    return true;
-  }
-  const uint32_t code = c - 1u;
-  const uint32_t xl = (code & 1u) ? 0u : ~0u, xh = (code & 2u) ? 0u : ~0u, ka = c == 1 ? ~0u : 0u;
-  const uint32_t m0 = (l0 ^ xl) & (h0 ^ xh) & ~(k0 & ka);
-  const uint32_t m1 = (l1 ^ xl) & (h1 ^ xh) & ~(k1 & ka);
-  const uint32_t m2 = (l2 ^ xl) & (h2 ^ xh) & ~(k2 & ka);
-  const uint32_t m3 = (l3 ^ xl) & (h3 ^ xh) & ~(k3 & ka);
-  const uint32_t mj = j == 0 ? m0 : (j == 1 ? m1 : (j == 2 ? m2 : m3));
-  uint32_t rank = (j > 0 ? (uint32_t)__builtin_popcount(m0) : 0u) + (j > 1 ? (uint32_t)__builtin_popcount(m1) : 0u) +
-                  (j > 2 ? (uint32_t)__builtin_popcount(m2) : 0u) + (uint32_t)__builtin_popcount(mj & below);
-  const uint32_t cT = (bi << GMX_BLK_SHIFT) - w0 - w1 - w2 - w3;
-  rank += c == 1 ? w0 : (c == 2 ? w1 : (c == 3 ? w2 : cT));
-  bool hit = ((mj >> t) & 1u) != 0;
-  if (c == 1) {  // the sentinel is stored as code 00
-    if (ix.sentinel_pos < i) rank -= 1;
-    if (ix.sentinel_pos == i) hit = false;
-  }
-  if (hit) {
-    const uint32_t first = c == 1 ? ix.C[1] : (c == 2 ? ix.C[2] : (c == 3 ? ix.C[3] : ix.C[4]));
-    ln.a = ln.b = first + rank;
-    --ln.pos;
   } else {
     ln.mode = GMX_MODE_DEAD;
   }
+}
+
+// HIT: `w` = the 16 words of the hit record
+template <class Ctx, class Reader>
+GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, Reader &rd, GmxLane &ln, const uint32_t *w) {
+  const uint32_t kind = w[0], site = w[2];
+  const uint32_t c = rd.at(ln.pos - 1);
+  bool alive;
+  if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
+    if (ln.tvg != GMX_NIL) {
+      if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != site) return false;  // general path (or error there)
+    }
+    uint32_t nn = ctx.arena_new(site, (int32_t)w[3], ln.tvd);
+    if (nn == GMX_NIL) return false;
+    ln.tvg = GMX_NIL;
+    ln.tvd = nn;
+    alive = w[4] == c;  // lf[0]: the only base that can precede the site marker
+    ln.a = ln.b = w[5];
+    if (w[12] != GMX_NIL) {
+      ln.a = w[12];
+      ln.b = GMX_TEXT_MARK;
+    }
+  } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
+    if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
+    ln.tvg = GMX_INLINE_FLAG | ((site - 5u) >> 1);
+    ln.a = c == 1 ? w[4] : (c == 2 ? w[6] : (c == 3 ? w[8] : w[10]));
+    ln.b = c == 1 ? w[5] : (c == 2 ? w[7] : (c == 3 ? w[9] : w[11]));
+    const uint32_t tp = c == 1 ? w[12] : (c == 2 ? w[13] : (c == 3 ? w[14] : w[15]));
+    alive = ln.a <= ln.b;
+    if (ln.a == ln.b && tp != GMX_NIL) {
+      ln.a = tp;
+      ln.b = GMX_TEXT_MARK;
+    }
+  } else
+    return false;
+  if (alive) {
+    --ln.pos;
+    ln.mode = GMX_MODE_STATE;
+  } else
+    ln.mode = GMX_MODE_DEAD;
   return true;
 }
 
+// One fast iteration with direct loads (host emulation, and the reference for the kernels' split version).
 template <class Ctx, class Reader>
-GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, GmxLane &ln) {
-  const uint32_t *src = gmx_dfs_fast_src(ix, ln);
-  uint32_t w[16];
-  for (int k = 0; k < 16; ++k) w[k] = src[k];
-  return gmx_dfs_fast_iter_line(ix, ctx, rd, ln, w);
+GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, GmxLane &ln, uint32_t kind) {
+  if (kind == GMX_FAST_HIT) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(ix.hits + ln.a);
+    uint32_t w[16];
+    for (int k = 0; k < 16; ++k) w[k] = src[k];
+    return gmx_dfs_fast_hit(ctx, rd, ln, w);
+  }
+  if (kind == GMX_FAST_CONVERT) {
+    ln.a = ix.sa[ln.a];
+    ln.b = GMX_TEXT_MARK;
+    return true;
+  }
+  uint32_t start, shift, xlo, xhi;
+  gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+  rd.planes(start, xlo, xhi);
+  gmx_dfs_text_apply(ln, stop, rd.rc, ix.text[gmx_dfs_text_rec(ln)], xlo, xhi, shift);
+  return true;
 }
 
 // Host-style driver (one lane at a time): the kernels interleave the same two functions with wave-level
@@ -287,7 +351,8 @@ GMX_HD void gmx_dfs_run(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t s
   GmxLane ln;
   ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   while (ln.have) {
-    if (gmx_dfs_fast_ok(ln, stop) && gmx_dfs_fast_iter(ix, ctx, rd, ln)) continue;
+    const uint32_t kind = gmx_dfs_fast_kind(ln, stop);
+    if (kind != GMX_FAST_NONE && gmx_dfs_fast_iter(ix, ctx, rd, stop, ln, kind)) continue;
     gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
   }
 }

@@ -45,20 +45,27 @@
 // read access: oriented base i of task (read r, orientation o)
 // ---------------------------------------------------------------------------
 struct ReadRef {
-  const uint32_t *w;   // 2-bit packed bases (A,C,G,T = 0..3), 16 per dword, this read's first dword
+  const uint2 *w;      // bit planes of the base codes (A,C,G,T = 0..3): .x = low bits, .y = high bits of 32 bases
   uint32_t len;
   bool rc;
-  uint32_t cur_idx;    // index of the cached dword (0xFFFFFFFF = none)
-  uint32_t cur;        // cached dword: the walk is sequential, so one load serves 16 steps
+  uint32_t cur_idx;    // index of the cached pair (0xFFFFFFFF = none)
+  uint2 cur;           // cached pair: the walk is sequential, so one load serves 32 steps
   __device__ __forceinline__ uint32_t at(uint32_t i) {
     uint32_t idx = rc ? len - 1 - i : i;  // reverse_complement_read, quasimap.cpp:273-298
-    uint32_t wi = idx >> 4;
+    uint32_t wi = idx >> 5;
     if (wi != cur_idx) {
       cur = w[wi];
       cur_idx = wi;
     }
-    uint32_t code = (cur >> ((idx & 15u) * 2u)) & 3u;
+    uint32_t code = ((cur.x >> (idx & 31u)) & 1u) | (((cur.y >> (idx & 31u)) & 1u) << 1);
     return rc ? 4u - code : code + 1u;
+  }
+  // planes of raw bases start .. start + 31 (gmx_dfs.h, text-form iteration); the packed buffer has slack
+  // behind the last read, bits past this read's end are never used
+  __device__ __forceinline__ void planes(uint32_t start, uint32_t &lo, uint32_t &hi) const {
+    const uint2 p0 = w[start >> 5], p1 = w[(start >> 5) + 1];
+    lo = __builtin_amdgcn_alignbit(p1.x, p0.x, start & 31u);
+    hi = __builtin_amdgcn_alignbit(p1.y, p0.y, start & 31u);
   }
 };
 
@@ -236,68 +243,7 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
 // count is amortised instead of being executed (mostly masked off) on every step.
 #define GMX_SLOW_BATCH 12
-// Quad-cooperative fetch of every lane's 64-byte line, register-only. A lane-private dwordx4 load makes the L1
-// look up 64 different lines per instruction (PMC: ~250 TCP accesses per wave-iteration, ~0.7 per CU-cycle over
-// the whole extend kernel). Here the 4 lanes of a quad read the 4 consecutive 16-byte chunks of ONE lane's line
-// (one coalesced 64-byte request), for each of the quad's 4 owners in turn; a two-stage DPP butterfly then
-// transposes the 4x4 chunk matrix inside the quad so that every lane ends up with its own line.
-// Must be executed by all 64 lanes (a lane without work passes any valid address).
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_quad(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
-}
-__device__ __forceinline__ void coop_fetch(const uint32_t *src, uint32_t w[16]) {
-  const uint32_t q = threadIdx.x & 3u;
-  const unsigned long long p = (unsigned long long)src;
-  const uint32_t plo = (uint32_t)p, phi = (uint32_t)(p >> 32);
-  uint4 R[4];
-  {
-    const uint4 *o0 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0x00>(phi) << 32) | dpp_quad<0x00>(plo));
-    const uint4 *o1 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0x55>(phi) << 32) | dpp_quad<0x55>(plo));
-    const uint4 *o2 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0xAA>(phi) << 32) | dpp_quad<0xAA>(plo));
-    const uint4 *o3 = reinterpret_cast<const uint4 *>(((unsigned long long)dpp_quad<0xFF>(phi) << 32) | dpp_quad<0xFF>(plo));
-    R[0] = o0[q];
-    R[1] = o1[q];
-    R[2] = o2[q];
-    R[3] = o3[q];
-  }
-  // stage 1: exchange with lane^1 (quad_perm [1,0,3,2] = 0xB1); stage 2: with lane^2 (quad_perm [2,3,0,1] = 0x4E)
-  const bool q0 = (q & 1u) != 0, q1 = (q & 2u) != 0;
-  uint4 S[4], T[4];
-  // The DPP moves are evaluated for ALL lanes first (a move placed under the `take` predicate would read
-  // disabled partner lanes), the per-lane choice is a plain select afterwards.
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool take = ((e & 1) != 0) != q0;
-    const uint4 other = R[e ^ 1];
-    const uint32_t ox = dpp_quad<0xB1>(other.x), oy = dpp_quad<0xB1>(other.y), oz = dpp_quad<0xB1>(other.z),
-                   ow = dpp_quad<0xB1>(other.w);
-    S[e].x = take ? ox : R[e].x;
-    S[e].y = take ? oy : R[e].y;
-    S[e].z = take ? oz : R[e].z;
-    S[e].w = take ? ow : R[e].w;
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const bool take = ((e & 2) != 0) != q1;
-    const uint4 other = S[e ^ 2];
-    const uint32_t ox = dpp_quad<0x4E>(other.x), oy = dpp_quad<0x4E>(other.y), oz = dpp_quad<0x4E>(other.z),
-                   ow = dpp_quad<0x4E>(other.w);
-    T[e].x = take ? ox : S[e].x;
-    T[e].y = take ? oy : S[e].y;
-    T[e].z = take ? oz : S[e].z;
-    T[e].w = take ? ow : S[e].w;
-  }
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    w[4 * e] = T[e].x;
-    w[4 * e + 1] = T[e].y;
-    w[4 * e + 2] = T[e].z;
-    w[4 * e + 3] = T[e].w;
-  }
-}
-
-template <bool COOP, class Ctx>
+template <class Ctx>
 __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active) {
   GmxLane ln;
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
@@ -307,22 +253,41 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
     // ---- fast phase: a tight loop; lanes that need the general iteration drop out and wait ----
     unsigned long long mf, ms;
     for (;;) {
-      bool can_fast = !wait_slow && gmx_dfs_fast_ok(ln, stop);
-      mf = __ballot(can_fast);
-      ms = __ballot(ln.have && !can_fast);
+      const uint32_t kind = wait_slow ? GMX_FAST_NONE : gmx_dfs_fast_kind(ln, stop);
+      mf = __ballot(kind != GMX_FAST_NONE);
+      ms = __ballot(ln.have && kind == GMX_FAST_NONE);
       if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
-      if (COOP) {
-        const uint32_t *src = can_fast ? gmx_dfs_fast_src(ix, ln) : reinterpret_cast<const uint32_t *>(ix.blocks);
-        uint32_t w[16];
-        coop_fetch(src, w);
-        if (can_fast && !gmx_dfs_fast_iter_line(ix, ctx, rd, ln, w)) wait_slow = true;
-      } else {
-        if (can_fast && !gmx_dfs_fast_iter(ix, ctx, rd, ln)) wait_slow = true;
+      // all fetches of the iteration are issued before any of them is consumed
+      uint4 h0, h1, h2, h3;
+      h0 = h1 = h2 = h3 = make_uint4(0, 0, 0, 0);
+      uint32_t xlo = 0, xhi = 0, shift = 0;
+      if (kind == GMX_FAST_HIT) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(ix.hits + ln.a);
+        h0 = src[0];
+        h1 = src[1];
+        h2 = src[2];
+        h3 = src[3];
+      } else if (kind == GMX_FAST_TEXT) {
+        h0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+        uint32_t start;
+        gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+        rd.planes(start, xlo, xhi);
+      } else if (kind == GMX_FAST_CONVERT) {
+        h0.x = ix.sa[ln.a];
+      }
+      if (kind == GMX_FAST_HIT) {
+        const uint32_t w[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
+        if (!gmx_dfs_fast_hit(ctx, rd, ln, w)) wait_slow = true;
+      } else if (kind == GMX_FAST_TEXT) {
+        gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{h0.x, h0.y, h0.z, h0.w}, xlo, xhi, shift);
+      } else if (kind == GMX_FAST_CONVERT) {
+        ln.a = h0.x;
+        ln.b = GMX_TEXT_MARK;
       }
     }
     if ((mf | ms) == 0) break;
     // ---- one general iteration for every waiting lane ----
-    if (ln.have && (wait_slow || !gmx_dfs_fast_ok(ln, stop))) {
+    if (ln.have && (wait_slow || gmx_dfs_fast_kind(ln, stop) == GMX_FAST_NONE)) {
       gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
       wait_slow = false;
     }
@@ -334,12 +299,12 @@ struct BatchView {
   const uint64_t *offsets;
   const uint32_t *seeds;
   const uint8_t *skip;       // per read: holds a non-ACGT byte
-  const uint32_t *packed;    // 2-bit packed copy written by gmx_pack_kernel; read r starts at dword pack_off(r)
+  const uint2 *packed;       // bit-plane copy written by gmx_pack_kernel; read r starts at pair pack_off(r)
   uint32_t n_reads;
   uint32_t forward_only;
 };
 __device__ __forceinline__ uint64_t pack_off(const BatchView &b, uint32_t read) {
-  return ((b.offsets[read] - b.offsets[0]) >> 4) + read;  // ceil(len/16) dwords fit between consecutive starts
+  return ((b.offsets[read] - b.offsets[0]) >> 5) + read;  // ceil(len/32) pairs fit between consecutive starts
 }
 
 struct SearchOut {
@@ -387,7 +352,7 @@ __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) 
   r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
   r.rc = task & 1;
   r.cur_idx = 0xFFFFFFFFu;
-  r.cur = 0;
+  r.cur = make_uint2(0, 0);
   return r;
 }
 
@@ -441,7 +406,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   r.len = 0;
   r.rc = false;
   r.cur_idx = 0xFFFFFFFFu;
-  r.cur = 0;
+  r.cur = make_uint2(0, 0);
   bool run = false;
   uint32_t lane_stop = 0;
   if (active) {
@@ -461,7 +426,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       lane_stop = stop;
     }
   }
-  dfs_run_wave<false>(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
+  dfs_run_wave(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
   if (run) status = ctx.status;
   finish_lane(o, active, task, ctx, status, done);
 }
@@ -487,7 +452,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   r.len = 0;
   r.rc = false;
   r.cur_idx = 0xFFFFFFFFu;
-  r.cur = 0;
+  r.cur = make_uint2(0, 0);
   if (active) {
     r = task_read(b, task);
     uint32_t packed = o.n_final[task];
@@ -499,7 +464,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
       ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
     }
   }
-  dfs_run_wave<true>(ix, ctx, r, 0, active);
+  dfs_run_wave(ix, ctx, r, 0, active);
   status = ctx.status;
   finish_lane(o, active, task, ctx, status, true);
 }
@@ -531,7 +496,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
   uint32_t n_over = o.counters[1 * GMX_CNT_STRIDE];
   uint32_t rounds = (n_over + gridDim.x * 64 - 1) / (gridDim.x * 64);
   for (uint32_t rd = 0; rd < rounds; ++rd) {
-    uint32_t slot = rd * gridDim.x * 64 + blockIdx.x * 64 + threadIdx.x;
+    // interleaved: a short queue spreads over all waves (few active lanes each) instead of filling the first ones
+    uint32_t slot = rd * gridDim.x * 64 + threadIdx.x * gridDim.x + blockIdx.x;
     bool active = slot < n_over;
     uint32_t task = active ? o.overflow_list[slot] : 0;
     if (active && slot >= g.max_slots) {
@@ -554,7 +520,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     r.len = 0;
     r.rc = false;
     r.cur_idx = 0xFFFFFFFFu;
-    r.cur = 0;
+    r.cur = make_uint2(0, 0);
     bool run = false;
     if (active) {
       r = task_read(b, task);
@@ -564,7 +530,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       });
       run = ctx.status == GMX_TASK_MAPPED;
     }
-    dfs_run_wave<false>(ix, ctx, r, 0, run);
+    dfs_run_wave(ix, ctx, r, 0, run);
     if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
@@ -723,26 +689,39 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
-// Validation + 2-bit packing, one lane per read. Reads holding a byte outside 1..4 are skipped as a whole
-// (encode_dna_bases, utils.cpp:73-92). The search kernels then fetch 16 bases per dword load instead of one
-// byte per step (the per-step byte loads of 64 different reads thrashed L1 and L2: one L2 miss per lane-step).
+// Validation + packing, one lane per read. Reads holding a byte outside 1..4 are skipped as a whole
+// (encode_dna_bases, utils.cpp:73-92). The packed form is two bit planes per 32 bases (uint2: low bits, high
+// bits of the codes 0..3): the search kernels compare 32 bases per step against the PRG's planes (GmxTextRec),
+// and a single base is two bit extracts.
 //
-// A block owns GMX_PACK_READS consecutive reads, whose bytes and whose packed words are both contiguous:
+// A block owns GMX_PACK_READS consecutive reads, whose bytes and whose packed pairs are both contiguous:
 // the bytes are staged through LDS with coalesced 16-byte loads, packed from LDS (aligned dwords joined with
 // v_alignbyte), and written back from LDS with coalesced stores. Blocks whose reads do not fit the LDS
 // window (very long reads) take the direct per-lane path.
 #define GMX_PACK_READS 128
 #define GMX_PACK_IN_BYTES (24 * 1024)
-#define GMX_PACK_OUT_WORDS (GMX_PACK_IN_BYTES / 16 + GMX_PACK_READS + 8)
+#define GMX_PACK_OUT_PAIRS (GMX_PACK_IN_BYTES / 32 + GMX_PACK_READS + 8)
 typedef uint32_t __attribute__((aligned(1))) gmx_u32_unaligned;
-__device__ __forceinline__ uint32_t pack4(uint32_t x, uint32_t &bad) {
+// four bytes -> four bits of each plane (bit i = byte i), flagging bytes outside 1..4
+__device__ __forceinline__ void pack4(uint32_t x, uint32_t &lo, uint32_t &hi, uint32_t &bad) {
   uint32_t y = x - 0x01010101u;                         // per-byte code 0..3 when every byte is in 1..4
   bad |= ((y & ~x & 0x80808080u) | (y & 0xFCFCFCFCu));  // a zero byte, or a byte > 4
-  return (y | (y >> 6) | (y >> 12) | (y >> 18)) & 0xFFu;  // 4 x 2 bits
+  lo = (((y & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+  hi = ((((y >> 1) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
 }
-__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint32_t *packed) {
+__device__ __forceinline__ uint2 pack_tail(const uint8_t *p, uint32_t rem, uint32_t &bad) {
+  uint2 out = make_uint2(0, 0);
+  for (uint32_t j = 0; j < rem; ++j) {
+    uint32_t x = p[j];
+    if (x < 1 || x > 4) bad = 1;
+    out.x |= ((x - 1u) & 1u) << j;
+    out.y |= (((x - 1u) >> 1) & 1u) << j;
+  }
+  return out;
+}
+__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed) {
   __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
-  __shared__ uint32_t outw[GMX_PACK_OUT_WORDS];
+  __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
   const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
   const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
   const uint32_t read = r0 + threadIdx.x;
@@ -756,7 +735,7 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
     for (uint32_t i = threadIdx.x; i < n16; i += GMX_PACK_READS) in4[i] = src[i];
     const uint64_t po0 = pack_off(b, r0);
     const uint32_t n_out = (uint32_t)(pack_off(b, r1) - po0);
-    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) outw[i] = 0;
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) outp[i] = make_uint2(0, 0);
     __syncthreads();
     if (read < r1) {
       const uint64_t s = b.offsets[read];
@@ -764,62 +743,52 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
       const uint32_t q = shift + (uint32_t)(s - s0);
       const uint32_t *w = reinterpret_cast<const uint32_t *>(in4);
       const uint8_t *bytes = reinterpret_cast<const uint8_t *>(in4);
-      uint32_t *out = outw + (uint32_t)(pack_off(b, read) - po0);
+      uint2 *out = outp + (uint32_t)(pack_off(b, read) - po0);
       uint32_t idx = q >> 2;
       const uint32_t sh = q & 3u;
       uint32_t bad = 0;
-      const uint32_t full = len >> 4;
+      const uint32_t full = len >> 5;
       uint32_t carry = w[idx];
       for (uint32_t c = 0; c < full; ++c) {
-        uint32_t word = 0;
+        uint2 pair = make_uint2(0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t nxt = w[++idx];
-          word |= pack4(__builtin_amdgcn_alignbyte(nxt, carry, sh), bad) << (8 * j);
+        for (int j = 0; j < 8; ++j) {
+          uint32_t nxt = w[++idx], lo, hi;
+          pack4(__builtin_amdgcn_alignbyte(nxt, carry, sh), lo, hi, bad);
+          pair.x |= lo << (4 * j);
+          pair.y |= hi << (4 * j);
           carry = nxt;
         }
-        out[c] = word;
+        out[c] = pair;
       }
-      const uint32_t rem = len & 15u;
-      if (rem) {
-        uint32_t word = 0;
-        for (uint32_t j = 0; j < rem; ++j) {
-          uint32_t x = bytes[q + full * 16 + j];
-          if (x < 1 || x > 4) bad = 1;
-          word |= ((x - 1u) & 3u) << (2 * j);
-        }
-        out[full] = word;
-      }
+      const uint32_t rem = len & 31u;
+      if (rem) out[full] = pack_tail(bytes + q + full * 32, rem, bad);
       skip[read] = bad ? 1 : 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) packed[po0 + i] = outw[i];
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) packed[po0 + i] = outp[i];
     return;
   }
   if (read >= r1) return;
   uint64_t s = b.offsets[read], e = b.offsets[read + 1];
   uint32_t len = (uint32_t)(e - s);
   const uint8_t *p = b.reads + s;
-  uint32_t *out = packed + pack_off(b, read);
+  uint2 *out = packed + pack_off(b, read);
   uint32_t bad = 0;
-  uint32_t full = len >> 4;
+  uint32_t full = len >> 5;
   for (uint32_t c = 0; c < full; ++c) {
-    uint32_t word = 0;
+    uint2 pair = make_uint2(0, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      word |= pack4(*reinterpret_cast<const gmx_u32_unaligned *>(p + c * 16 + j * 4), bad) << (8 * j);
-    out[c] = word;
-  }
-  uint32_t rem = len & 15u;
-  if (rem) {
-    uint32_t word = 0;
-    for (uint32_t j = 0; j < rem; ++j) {
-      uint32_t x = p[full * 16 + j];
-      if (x < 1 || x > 4) bad = 1;
-      word |= ((x - 1u) & 3u) << (2 * j);
+    for (int j = 0; j < 8; ++j) {
+      uint32_t lo, hi;
+      pack4(*reinterpret_cast<const gmx_u32_unaligned *>(p + c * 32 + j * 4), lo, hi, bad);
+      pair.x |= lo << (4 * j);
+      pair.y |= hi << (4 * j);
     }
-    out[full] = word;
+    out[c] = pair;
   }
+  uint32_t rem = len & 31u;
+  if (rem) out[full] = pack_tail(p + full * 32, rem, bad);
   skip[read] = bad ? 1 : 0;
 }
 
@@ -849,7 +818,7 @@ struct gmx_engine {
   // batch workspace (sized for max_batch_reads)
   uint64_t cap_reads = 0;
   uint8_t *d_skip = nullptr;
-  uint32_t *d_packed = nullptr;
+  uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr;
@@ -961,6 +930,8 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   int rc = 0;
   rc |= e->upload(&v.blocks, h.blocks);
   rc |= e->upload(&v.hits, h.hits);
+  rc |= e->upload(&v.hit_perm, h.hit_perm);
+  rc |= e->upload(&v.text, h.text);
   rc |= e->upload(&v.prog, h.prog);
   rc |= e->upload(&v.sa, h.sa);
   rc |= e->upload(&v.pos_node, h.pos_node);
@@ -1054,7 +1025,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
   {
-    uint64_t need = total_bases / 16 + n_reads + 16;
+    uint64_t need = total_bases / 32 + n_reads + 16;  // pairs; the slack covers the one-pair look-ahead of planes()
     if (need > e->cap_packed) {
       rc = e->alloc(&e->d_packed, need, false);
       if (rc) return rc;

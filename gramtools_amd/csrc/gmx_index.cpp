@@ -449,6 +449,8 @@ GmxIndexView HostIndex::view() const {
   v.is_nested = is_nested ? 1 : 0;
   v.blocks = blocks.data();
   v.hits = hits.data();
+  v.hit_perm = hit_perm.data();
+  v.text = text.data();
   v.prog = prog.data();
   v.sa = sa.data();
   v.pos_node = pos_node.data();
@@ -689,6 +691,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       memset(&hit, 0, sizeof(hit));
       hit.kind = GMX_HIT_PROG;
       hit.prog_off = 0;
+      for (auto &t : hit.tp) t = GMX_NIL;
       if (p < N && prg[p] <= 4) {
         // left_markers_search, vBWT_jump.cpp:94-117
         uint32_t m = g.pos_target[p].first;
@@ -709,6 +712,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
               if (!gmx_lf(hv, b0, l2, h2, blk)) throw std::runtime_error("internal: exit LF precomputation failed");
               hit.lf[0] = b0;
               hit.lf[1] = l2;
+              hit.tp[0] = out.sa[l2];
             }
           } else if (op == GMX_OP_ENTER) {
             hit.kind = GMX_HIT_ENTER;
@@ -718,6 +722,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
               if (gmx_lf(hv, c, l2, h2, blk)) {
                 hit.lf[2 * (c - 1)] = l2;
                 hit.lf[2 * (c - 1) + 1] = h2;
+                if (l2 == h2) hit.tp[c - 1] = out.sa[l2];
               } else {
                 hit.lf[2 * (c - 1)] = 1;
                 hit.lf[2 * (c - 1) + 1] = 0;
@@ -728,6 +733,38 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       }
       out.hits.push_back(hit);
     }
+  }
+  // --- PRG text records; hit records re-ordered from BWT order to text order ---------------
+  {
+    out.text.assign(N / 32 + 1, GmxTextRec{0, 0, 0, 0});
+    uint32_t markers = 0;
+    for (uint32_t q = 0; q < N; ++q) {
+      GmxTextRec &r = out.text[q >> 5];
+      if ((q & 31u) == 0) r.mrank = markers;
+      uint32_t sym = prg[q];
+      if (sym > 4) {
+        r.mk |= 1u << (q & 31u);
+        ++markers;
+      } else {
+        r.lo |= ((sym - 1u) & 1u) << (q & 31u);
+        r.hi |= (((sym - 1u) >> 1) & 1u) << (q & 31u);
+      }
+    }
+    out.text[N >> 5].mrank = (N & 31u) == 0 ? markers : out.text[N >> 5].mrank;
+    if (markers != out.hits.size()) throw std::runtime_error("internal: marker count mismatch");
+    std::vector<GmxHit> by_text(out.hits.size());
+    out.hit_perm.assign(out.hits.size(), 0);
+    uint32_t rank = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (out.bwt[i] <= 4) continue;
+      uint32_t q = out.sa[i] - 1;  // the marker's PRG position
+      const GmxTextRec &r = out.text[q >> 5];
+      uint32_t t = r.mrank + (uint32_t)__builtin_popcount(r.mk & ((1u << (q & 31u)) - 1u));
+      by_text[t] = out.hits[rank];
+      out.hit_perm[rank] = t;
+      ++rank;
+    }
+    out.hits.swap(by_text);
   }
 
   // --- seed table ---------------------------------------------------------------------

@@ -29,6 +29,8 @@ struct HostIndex {
   std::vector<GmxRankBlock> blocks;
   std::vector<uint32_t> sa;
   std::vector<GmxHit> hits;
+  std::vector<uint32_t> hit_perm;
+  std::vector<GmxTextRec> text;
   std::vector<uint32_t> prog;
   std::vector<uint32_t> pos_node;
   std::vector<GmxNode> nodes;  // + 1 closing record

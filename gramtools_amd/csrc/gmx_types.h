@@ -82,17 +82,33 @@ struct GmxSeed {
 //           marker (0 if it is not a base), lf[1] = C[b] + rank_b(x): the state after the LF step with b
 //   kind 2  single output, single op ENTER(site) -> interval I; lf[2(c-1)], lf[2(c-1)+1] = LF(I, c) for c = 1..4
 //           (lo > hi when empty)
+//   tp[]    PRG position (SA value) of a width-one LF result, GMX_NIL otherwise: kind 1 -> tp[0] = SA[lf[1]];
+//           kind 2 -> tp[c-1] = SA[lf[2(c-1)]] when the interval has width one. The state continues in text
+//           form (GmxTextRec) without an SA look-up.
+// Records are stored in PRG (text) order of the marker; `hit_perm` maps a BWT marker rank to the record.
 struct alignas(64) GmxHit {
   uint32_t kind;
   uint32_t prog_off;
   uint32_t site;
   int32_t allele;
   uint32_t lf[8];
-  uint32_t pad[4];
+  uint32_t tp[4];
 };
 #define GMX_HIT_PROG 0u
 #define GMX_HIT_EXIT 1u
 #define GMX_HIT_ENTER 2u
+
+// The PRG itself, 32 symbols per 16-byte record, as the search consumes it once a state has narrowed to ONE
+// suffix-array position i: its next backward step is decided by the symbol left of PRG position SA[i] alone
+// (the LF step succeeds iff BWT[i] equals the read base, and BWT[i] = PRG[SA[i] - 1]; a marker there is the
+// marker hit). Such a state is kept in TEXT FORM (a = PRG position, b = GMX_TEXT_MARK) and compares up to 32
+// read bases per record against the PRG instead of fetching one rank block per base.
+struct alignas(16) GmxTextRec {
+  uint32_t lo, hi;  // bit planes of the base codes (A,C,G,T = 0..3); 0 at marker positions
+  uint32_t mk;      // 1 = variant marker
+  uint32_t mrank;   // markers of the PRG before this record (= index of its first marker in hits[])
+};
+#define GMX_TEXT_MARK 0xFFFFFFFEu
 
 // The device/host view of the index. All pointers are device pointers on the GPU side.
 struct GmxIndexView {
@@ -110,7 +126,9 @@ struct GmxIndexView {
   uint32_t n_grouped_slots;  // dense grouped accumulator length
   uint32_t is_nested;
   const GmxRankBlock *blocks;
-  const GmxHit *hits;         // [n_hits] record of the h-th marker position of the BWT
+  const GmxHit *hits;         // [n_hits] record of the h-th marker of the PRG (text order)
+  const uint32_t *hit_perm;   // [n_hits] BWT marker rank -> index into hits[]
+  const GmxTextRec *text;     // [n_prg / 32 + 1]
   const uint32_t *prog;       // jump programs
   const uint32_t *sa;         // [n]
   const uint32_t *pos_node;   // [n_prg]

@@ -142,6 +142,15 @@ struct Read {
   uint32_t len;
   bool rc;
   uint32_t at(uint32_t i) const { return rc ? 5u - p[len - 1 - i] : p[i]; }
+  // bit planes of raw bases start .. start + 31 (what the pack kernel's output gives the device reader)
+  void planes(uint32_t start, uint32_t &lo, uint32_t &hi) const {
+    lo = hi = 0;
+    for (uint32_t j = 0; j < 32 && start + j < len; ++j) {
+      uint32_t code = p[start + j] - 1u;
+      lo |= (code & 1u) << j;
+      hi |= ((code >> 1) & 1u) << j;
+    }
+  }
 };
 
 uint32_t kmer_code(const Read &r, uint32_t start, uint32_t k) {
