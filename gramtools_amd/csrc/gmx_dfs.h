@@ -209,11 +209,19 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
 #define GMX_FAST_HIT 1u
 #define GMX_FAST_TEXT 2u
 #define GMX_FAST_CONVERT 3u
+#define GMX_FAST_WIDE 4u  // an interval inside one rank block: marker check + LF step from that one line
 GMX_HD uint32_t gmx_dfs_fast_kind(const GmxLane &ln, uint32_t stop) {
   if (!ln.have || ln.pos <= stop) return GMX_FAST_NONE;
   if (ln.mode == GMX_MODE_HIT) return GMX_FAST_HIT;
   if (ln.mode != GMX_MODE_STATE) return GMX_FAST_NONE;
-  return ln.b == GMX_TEXT_MARK ? GMX_FAST_TEXT : (ln.a == ln.b ? GMX_FAST_CONVERT : GMX_FAST_NONE);
+  if (ln.b == GMX_TEXT_MARK) return GMX_FAST_TEXT;
+  if (ln.a == ln.b) return GMX_FAST_CONVERT;
+  return (ln.a >> GMX_BLK_SHIFT) == (ln.b >> GMX_BLK_SHIFT) ? GMX_FAST_WIDE : GMX_FAST_NONE;
+}
+// address of the 64-byte line a HIT / WIDE iteration consumes
+GMX_HD const uint32_t *gmx_dfs_fast_line(const GmxIndexView &ix, const GmxLane &ln, uint32_t kind) {
+  return kind == GMX_FAST_HIT ? reinterpret_cast<const uint32_t *>(ix.hits + ln.a)
+                              : reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
 }
 
 GMX_HD uint32_t gmx_bitrev32(uint32_t v) {
@@ -323,14 +331,31 @@ GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, Reader &rd, GmxLane &ln, const uint32_t *
   return true;
 }
 
+// WIDE: `w` = the 16 words of the rank block holding [a, b]. A marker inside the interval needs the general path.
+template <class Reader>
+GMX_HD bool gmx_dfs_fast_wide(const GmxIndexView &ix, Reader &rd, GmxLane &ln, const uint32_t *w) {
+  GmxLine line;
+  for (int k = 0; k < 16; ++k) line.w[k] = w[k];
+  const GmxRankBlock blk = gmx_line_as_block(line);
+  uint64_t a0, a1, z0, z1;
+  gmx_prefix_mask(ln.a & GMX_BLK_MASK, a0, a1);
+  gmx_prefix_mask((ln.b & GMX_BLK_MASK) + 1, z0, z1);
+  if ((blk.mk[0] & z0 & ~a0) | (blk.mk[1] & z1 & ~a1)) return false;
+  if (gmx_lf(ix, rd.at(ln.pos - 1), ln.a, ln.b, blk))
+    --ln.pos;
+  else
+    ln.mode = GMX_MODE_DEAD;
+  return true;
+}
+
 // One fast iteration with direct loads (host emulation, and the reference for the kernels' split version).
 template <class Ctx, class Reader>
 GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, GmxLane &ln, uint32_t kind) {
-  if (kind == GMX_FAST_HIT) {
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(ix.hits + ln.a);
+  if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
+    const uint32_t *src = gmx_dfs_fast_line(ix, ln, kind);
     uint32_t w[16];
     for (int k = 0; k < 16; ++k) w[k] = src[k];
-    return gmx_dfs_fast_hit(ctx, rd, ln, w);
+    return kind == GMX_FAST_HIT ? gmx_dfs_fast_hit(ctx, rd, ln, w) : gmx_dfs_fast_wide(ix, rd, ln, w);
   }
   if (kind == GMX_FAST_CONVERT) {
     ln.a = ix.sa[ln.a];

@@ -187,16 +187,15 @@ __device__ __forceinline__ uint32_t kmer_code(ReadRef &r, uint32_t start, uint32
   return code;
 }
 
-// all_read_kmers_occur_in_index (quasimap.cpp:212-225)
-__device__ bool all_kmers_present(const GmxIndexView &ix, ReadRef &r) {
-  const uint32_t k = ix.kmer_size;
+// all_read_kmers_occur_in_index (quasimap.cpp:212-225); `bitmap` is the presence bitmap in global memory or LDS
+__device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r) {
   const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
   uint32_t code = kmer_code(r, 0, k);
   for (uint32_t o = 0;;) {  // four independent bitmap probes in flight per round
     uint32_t present = 1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      present &= ix.kmer_bitmap[code >> 5] >> (code & 31);
+      present &= bitmap[code >> 5] >> (code & 31);
       if (o + k >= r.len) return present & 1u;
       code = ((code << 2) | (r.at(o + k) - 1u)) & mask;
       ++o;
@@ -261,8 +260,8 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       uint4 h0, h1, h2, h3;
       h0 = h1 = h2 = h3 = make_uint4(0, 0, 0, 0);
       uint32_t xlo = 0, xhi = 0, shift = 0;
-      if (kind == GMX_FAST_HIT) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(ix.hits + ln.a);
+      if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(gmx_dfs_fast_line(ix, ln, kind));
         h0 = src[0];
         h1 = src[1];
         h2 = src[2];
@@ -275,9 +274,9 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       } else if (kind == GMX_FAST_CONVERT) {
         h0.x = ix.sa[ln.a];
       }
-      if (kind == GMX_FAST_HIT) {
+      if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
         const uint32_t w[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
-        if (!gmx_dfs_fast_hit(ctx, rd, ln, w)) wait_slow = true;
+        if (!(kind == GMX_FAST_HIT ? gmx_dfs_fast_hit(ctx, rd, ln, w) : gmx_dfs_fast_wide(ix, rd, ln, w))) wait_slow = true;
       } else if (kind == GMX_FAST_TEXT) {
         gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{h0.x, h0.y, h0.z, h0.w}, xlo, xhi, shift);
       } else if (kind == GMX_FAST_CONVERT) {
@@ -478,7 +477,27 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
   if (slot >= n_dead) return;
   uint32_t task = o.dead_list[slot];
   ReadRef r = task_read(b, task);
-  o.status[task] = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+  o.status[task] = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+}
+
+// The same with the presence bitmap staged in LDS (k <= 10: 4^k bits <= 128 KB of the CU's 160 KB). The probes
+// of a wave go to 64 unrelated words: from LDS that costs a few bank-conflict cycles, from L1/L2 one tag
+// look-up per lane. One 1024-thread block per CU, persistent over the dead-task queue.
+#define GMX_FILTER_LDS_THREADS 1024
+__global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(GmxIndexView ix, BatchView b, SearchOut o,
+                                                                                 uint32_t n_words) {
+  const uint32_t n_dead = o.counters[6 * GMX_CNT_STRIDE];
+  if (blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
+  const uint4 *src = reinterpret_cast<const uint4 *>(ix.kmer_bitmap);
+  uint4 *dst = reinterpret_cast<uint4 *>(gmx_lds);
+  for (uint32_t i = threadIdx.x; i < n_words / 4; i += GMX_FILTER_LDS_THREADS) dst[i] = src[i];
+  __syncthreads();
+  for (uint32_t slot = blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
+       slot += gridDim.x * GMX_FILTER_LDS_THREADS) {
+    uint32_t task = o.dead_list[slot];
+    ReadRef r = task_read(b, task);
+    o.status[task] = all_kmers_present(gmx_lds, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+  }
 }
 
 struct BigOut {
@@ -536,7 +555,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     uint32_t nf = 0;
     if (status == GMX_TASK_MAPPED) {
       nf = ctx.n_out;
-      if (nf == 0) status = all_kmers_present(ix, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+      if (nf == 0) status = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
     } else if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, status) == 0u) {
       o.counters[3 * GMX_CNT_STRIDE] = task;
     }
@@ -830,6 +849,8 @@ struct gmx_engine {
   uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
+  uint32_t n_cus = 256;
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
   uint64_t *d_offsets = nullptr;
@@ -965,6 +986,17 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // coverage scratch
   e->cover_blocks = 1024;
   rc |= e->alloc(&e->d_scratch, (size_t)GmxScratch<CoverEnv>::total * e->cover_blocks * GMX_BLOCK, false);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, opts.device) == hipSuccess && prop.multiProcessorCount > 0)
+      e->n_cus = (uint32_t)prop.multiProcessorCount;
+    const size_t words = h.kmer_bitmap.size();
+    if (words >= 4 && words % 4 == 0 && words * 4 <= 128 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(gmx_filter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(words * 4)) == hipSuccess)
+      e->filter_lds_words = (uint32_t)words;
+    (void)hipGetLastError();
+  }
   e->cover_side_blocks = 32;
   rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
   rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
@@ -1067,7 +1099,11 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side_stream,
                      e->dview, b, o, e->big, acc);
   HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
-  hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
+  if (e->filter_lds_words)
+    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4, stream,
+                       e->dview, b, o, e->filter_lds_words);
+  else
+    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
                      o, e->big, acc);
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
