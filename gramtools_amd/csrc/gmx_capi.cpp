@@ -102,7 +102,7 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_grouped_slots = h.n_grouped_slots;
   o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
   o->n_kmers_present = h.n_seed_kmers_present;
-  o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
+  o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
                    h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.nodes.size() * sizeof(GmxNode) +
                    h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);
   return GMX_OK;

@@ -142,14 +142,14 @@ GMX_HD void gmx_marker_pass(const GmxIndexView &ix, uint32_t lo, uint32_t hi, ui
       uint32_t bit = (uint32_t)__builtin_ctzll(s0);
       s0 &= s0 - 1;
       uint32_t h = mbase + gmx_popc64(k0 & ((1ull << bit) - 1ull));
-      gmx_run_program(ix, ix.hits[ix.hit_perm[h]].prog_off, tvd, tvg, ctx);
+      gmx_run_program(ix, ix.hit_prog[ix.hit_perm[h]], tvd, tvg, ctx);
     }
     uint32_t c0 = gmx_popc64(k0);
     while (s1) {
       uint32_t bit = (uint32_t)__builtin_ctzll(s1);
       s1 &= s1 - 1;
       uint32_t h = mbase + c0 + gmx_popc64(k1 & ((1ull << bit) - 1ull));
-      gmx_run_program(ix, ix.hits[ix.hit_perm[h]].prog_off, tvd, tvg, ctx);
+      gmx_run_program(ix, ix.hit_prog[ix.hit_perm[h]], tvd, tvg, ctx);
     }
   }
 }

@@ -125,59 +125,47 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
     ln.have = false;
     return;
   }
-  // --- the iteration's one line fetch ---
-  const GmxLine *src = ln.mode == GMX_MODE_HIT ? reinterpret_cast<const GmxLine *>(ix.hits + ln.a)
-                                               : reinterpret_cast<const GmxLine *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
-  const GmxLine line = *src;
   const uint32_t c = rd.at(ln.pos - 1);
   bool alive = false;
   if (ln.mode == GMX_MODE_HIT) {
-    const uint32_t kind = line.w[0];
+    const GmxHitSub hs = ix.hits[ln.a].sub[c - 1];
+    const uint32_t kind = hs.head & 3u;
     if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
-      const uint32_t site = line.w[2];
       bool ok = true;
       if (ln.tvg != GMX_NIL) {
-        if (ctx.arena_site(ln.tvg) != site) {
+        if (ctx.arena_site(ln.tvg) != hs.site) {
           ctx.fail(GMX_TASK_ERROR);
           ok = false;
         } else
           ln.tvg = ctx.arena_next(ln.tvg);
       }
       if (ok) {
-        uint32_t nn = ctx.arena_new(site, (int32_t)line.w[3], ln.tvd);
+        uint32_t nn = ctx.arena_new(hs.site, (int32_t)hs.y, ln.tvd);
         if (nn == GMX_NIL) {
           ctx.fail(GMX_TASK_OVERFLOW);
         } else {
           ln.tvd = nn;
-          alive = line.w[4] == c;  // the only base that can precede the site marker
-          ln.a = ln.b = line.w[5];
-          if (line.w[12] != GMX_NIL) {
-            ln.a = line.w[12];
-            ln.b = GMX_TEXT_MARK;
-          }
+          alive = (hs.head & GMX_HITF_ALIVE) != 0;  // c is the only base that can precede the site marker
+          ln.a = hs.x;
+          ln.b = GMX_TEXT_MARK;
         }
       }
     } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
-      uint32_t nn = ctx.arena_new(line.w[2], -1, ln.tvg);
+      uint32_t nn = ctx.arena_new(hs.site, -1, ln.tvg);
       if (nn == GMX_NIL) {
         ctx.fail(GMX_TASK_OVERFLOW);
       } else {
         ln.tvg = nn;
-        ln.a = c == 1 ? line.w[4] : (c == 2 ? line.w[6] : (c == 3 ? line.w[8] : line.w[10]));
-        ln.b = c == 1 ? line.w[5] : (c == 2 ? line.w[7] : (c == 3 ? line.w[9] : line.w[11]));
-        alive = ln.a <= ln.b;
-        const uint32_t tp = c == 1 ? line.w[12] : (c == 2 ? line.w[13] : (c == 3 ? line.w[14] : line.w[15]));
-        if (ln.a == ln.b && tp != GMX_NIL) {
-          ln.a = tp;
-          ln.b = GMX_TEXT_MARK;
-        }
+        alive = (hs.head & GMX_HITF_ALIVE) != 0;
+        ln.a = hs.x;
+        ln.b = (hs.head & GMX_HITF_TEXT) ? GMX_TEXT_MARK : hs.y;
       }
     } else {  // general jump program: its outputs still need their LF step -> pushed as LF-only entries
       GmxDfsProgSink<Ctx> sink{ctx, ln.pos};
-      gmx_run_program(ix, line.w[1], ln.tvd, ln.tvg, sink);
+      gmx_run_program(ix, hs.site, ln.tvd, ln.tvg, sink);
     }
   } else {
-    const GmxRankBlock blk = gmx_line_as_block(line);
+    const GmxRankBlock blk = ix.blocks[ln.a >> GMX_BLK_SHIFT];
     if (ln.mode == GMX_MODE_STATE) gmx_dfs_push_hits(ix, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, blk, ctx);
     alive = gmx_lf(ix, c, ln.a, ln.b, blk);
   }
@@ -210,20 +198,27 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
 #define GMX_FAST_TEXT 2u
 #define GMX_FAST_CONVERT 3u
 #define GMX_FAST_WIDE 4u  // an interval inside one rank block: marker check + LF step from that one line
+#define GMX_FAST_EMIT 5u  // the state reached the stop position: publish it, take the next pending entry
+#define GMX_FAST_POP 6u   // the state died: take the next pending entry
 GMX_HD uint32_t gmx_dfs_fast_kind(const GmxLane &ln, uint32_t stop) {
-  if (!ln.have || ln.pos <= stop) return GMX_FAST_NONE;
+  if (!ln.have) return GMX_FAST_NONE;
+  if (ln.mode == GMX_MODE_DEAD) return GMX_FAST_POP;
+  if (ln.pos <= stop) return ln.mode == GMX_MODE_HIT ? GMX_FAST_NONE : GMX_FAST_EMIT;
   if (ln.mode == GMX_MODE_HIT) return GMX_FAST_HIT;
   if (ln.mode != GMX_MODE_STATE) return GMX_FAST_NONE;
   if (ln.b == GMX_TEXT_MARK) return GMX_FAST_TEXT;
   if (ln.a == ln.b) return GMX_FAST_CONVERT;
   return (ln.a >> GMX_BLK_SHIFT) == (ln.b >> GMX_BLK_SHIFT) ? GMX_FAST_WIDE : GMX_FAST_NONE;
 }
-// address of the 64-byte line a HIT / WIDE iteration consumes
-GMX_HD const uint32_t *gmx_dfs_fast_line(const GmxIndexView &ix, const GmxLane &ln, uint32_t kind) {
-  return kind == GMX_FAST_HIT ? reinterpret_cast<const uint32_t *>(ix.hits + ln.a)
-                              : reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+template <class Ctx>
+GMX_HD void gmx_dfs_emit(Ctx &ctx, GmxLane &ln) {
+  if (!ctx.emit(ln.a, ln.b, ln.tvd, ln.tvg)) ctx.fail(GMX_TASK_OVERFLOW);
+  ln.have = ctx.status == GMX_TASK_MAPPED && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
 }
-
+template <class Ctx>
+GMX_HD void gmx_dfs_pop(Ctx &ctx, GmxLane &ln) {
+  ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+}
 GMX_HD uint32_t gmx_bitrev32(uint32_t v) {
 #if defined(__clang__)
   return __builtin_bitreverse32(v);  // v_bfrev_b32
@@ -290,40 +285,32 @@ GMX_HD void gmx_dfs_text_apply(GmxLane &ln, uint32_t stop, bool rc, const GmxTex
   }
 }
 
-// HIT: `w` = the 16 words of the hit record
-template <class Ctx, class Reader>
-GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, Reader &rd, GmxLane &ln, const uint32_t *w) {
-  const uint32_t kind = w[0], site = w[2];
-  const uint32_t c = rd.at(ln.pos - 1);
-  bool alive;
+// HIT: `hs` = the record's sub-record for the next read base (gmx_dfs_hit_sub)
+template <class Reader>
+GMX_HD const GmxHitSub *gmx_dfs_hit_sub(const GmxIndexView &ix, Reader &rd, const GmxLane &ln) {
+  return &ix.hits[ln.a].sub[rd.at(ln.pos - 1) - 1u];
+}
+template <class Ctx>
+GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, const GmxHitSub &hs) {
+  const uint32_t kind = hs.head & 3u;
   if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
     if (ln.tvg != GMX_NIL) {
-      if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != site) return false;  // general path (or error there)
+      if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != hs.site) return false;  // general path (or error there)
     }
-    uint32_t nn = ctx.arena_new(site, (int32_t)w[3], ln.tvd);
+    uint32_t nn = ctx.arena_new(hs.site, (int32_t)hs.y, ln.tvd);
     if (nn == GMX_NIL) return false;
     ln.tvg = GMX_NIL;
     ln.tvd = nn;
-    alive = w[4] == c;  // lf[0]: the only base that can precede the site marker
-    ln.a = ln.b = w[5];
-    if (w[12] != GMX_NIL) {
-      ln.a = w[12];
-      ln.b = GMX_TEXT_MARK;
-    }
+    ln.a = hs.x;
+    ln.b = GMX_TEXT_MARK;
   } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
     if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
-    ln.tvg = GMX_INLINE_FLAG | ((site - 5u) >> 1);
-    ln.a = c == 1 ? w[4] : (c == 2 ? w[6] : (c == 3 ? w[8] : w[10]));
-    ln.b = c == 1 ? w[5] : (c == 2 ? w[7] : (c == 3 ? w[9] : w[11]));
-    const uint32_t tp = c == 1 ? w[12] : (c == 2 ? w[13] : (c == 3 ? w[14] : w[15]));
-    alive = ln.a <= ln.b;
-    if (ln.a == ln.b && tp != GMX_NIL) {
-      ln.a = tp;
-      ln.b = GMX_TEXT_MARK;
-    }
+    ln.tvg = GMX_INLINE_FLAG | ((hs.site - 5u) >> 1);
+    ln.a = hs.x;
+    ln.b = (hs.head & GMX_HITF_TEXT) ? GMX_TEXT_MARK : hs.y;
   } else
     return false;
-  if (alive) {
+  if (hs.head & GMX_HITF_ALIVE) {
     --ln.pos;
     ln.mode = GMX_MODE_STATE;
   } else
@@ -348,25 +335,32 @@ GMX_HD bool gmx_dfs_fast_wide(const GmxIndexView &ix, Reader &rd, GmxLane &ln, c
   return true;
 }
 
-// One fast iteration with direct loads (host emulation, and the reference for the kernels' split version).
+// One fast iteration with direct loads (host emulation, and the reference for the kernels' scheduled version).
 template <class Ctx, class Reader>
 GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, GmxLane &ln, uint32_t kind) {
-  if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
-    const uint32_t *src = gmx_dfs_fast_line(ix, ln, kind);
-    uint32_t w[16];
-    for (int k = 0; k < 16; ++k) w[k] = src[k];
-    return kind == GMX_FAST_HIT ? gmx_dfs_fast_hit(ctx, rd, ln, w) : gmx_dfs_fast_wide(ix, rd, ln, w);
+  switch (kind) {
+    case GMX_FAST_HIT:
+      return gmx_dfs_fast_hit(ctx, ln, *gmx_dfs_hit_sub(ix, rd, ln));
+    case GMX_FAST_WIDE:
+      return gmx_dfs_fast_wide(ix, rd, ln, reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT)));
+    case GMX_FAST_CONVERT:
+      ln.a = ix.sa[ln.a];
+      ln.b = GMX_TEXT_MARK;
+      return true;
+    case GMX_FAST_EMIT:
+      gmx_dfs_emit(ctx, ln);
+      return true;
+    case GMX_FAST_POP:
+      gmx_dfs_pop(ctx, ln);
+      return true;
+    default: {
+      uint32_t start, shift, xlo, xhi;
+      gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+      rd.planes(start, xlo, xhi);
+      gmx_dfs_text_apply(ln, stop, rd.rc, ix.text[gmx_dfs_text_rec(ln)], xlo, xhi, shift);
+      return true;
+    }
   }
-  if (kind == GMX_FAST_CONVERT) {
-    ln.a = ix.sa[ln.a];
-    ln.b = GMX_TEXT_MARK;
-    return true;
-  }
-  uint32_t start, shift, xlo, xhi;
-  gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-  rd.planes(start, xlo, xhi);
-  gmx_dfs_text_apply(ln, stop, rd.rc, ix.text[gmx_dfs_text_rec(ln)], xlo, xhi, shift);
-  return true;
 }
 
 // Host-style driver (one lane at a time): the kernels interleave the same two functions with wave-level

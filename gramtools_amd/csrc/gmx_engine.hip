@@ -44,6 +44,10 @@
 // ---------------------------------------------------------------------------
 // read access: oriented base i of task (read r, orientation o)
 // ---------------------------------------------------------------------------
+
+struct __attribute__((aligned(8))) gmx_pair2 {
+  uint32_t x, y, z, w;
+};
 struct ReadRef {
   const uint2 *w;      // bit planes of the base codes (A,C,G,T = 0..3): .x = low bits, .y = high bits of 32 bases
   uint32_t len;
@@ -63,9 +67,9 @@ struct ReadRef {
   // planes of raw bases start .. start + 31 (gmx_dfs.h, text-form iteration); the packed buffer has slack
   // behind the last read, bits past this read's end are never used
   __device__ __forceinline__ void planes(uint32_t start, uint32_t &lo, uint32_t &hi) const {
-    const uint2 p0 = w[start >> 5], p1 = w[(start >> 5) + 1];
-    lo = __builtin_amdgcn_alignbit(p1.x, p0.x, start & 31u);
-    hi = __builtin_amdgcn_alignbit(p1.y, p0.y, start & 31u);
+    const gmx_pair2 p = *reinterpret_cast<const gmx_pair2 *>(w + (start >> 5));  // one 16-byte load, 8-byte aligned
+    lo = __builtin_amdgcn_alignbit(p.z, p.x, start & 31u);
+    hi = __builtin_amdgcn_alignbit(p.w, p.y, start & 31u);
   }
 };
 
@@ -249,39 +253,64 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   bool wait_slow = false;
   for (;;) {
-    // ---- fast phase: a tight loop; lanes that need the general iteration drop out and wait ----
+    // ---- fast phase. Every iteration runs ONE of the three heavier kinds — the one most lanes are waiting
+    // for (a wave-uniform choice, so the other kinds' code is branched over, not masked off) — plus the cheap
+    // kinds (convert / emit / pop). Lanes of the other kinds wait a round; lanes that need the general
+    // iteration wait for the slow phase.
     unsigned long long mf, ms;
     for (;;) {
       const uint32_t kind = wait_slow ? GMX_FAST_NONE : gmx_dfs_fast_kind(ln, stop);
-      mf = __ballot(kind != GMX_FAST_NONE);
+      const unsigned long long m_text = __ballot(kind == GMX_FAST_TEXT), m_hit = __ballot(kind == GMX_FAST_HIT),
+                               m_wide = __ballot(kind == GMX_FAST_WIDE),
+                               m_light = __ballot(kind == GMX_FAST_CONVERT || kind == GMX_FAST_EMIT || kind == GMX_FAST_POP);
       ms = __ballot(ln.have && kind == GMX_FAST_NONE);
+      mf = m_text | m_hit | m_wide | m_light;
       if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
+      const uint32_t n_text = (uint32_t)__popcll(m_text), n_hit = (uint32_t)__popcll(m_hit), n_wide = (uint32_t)__popcll(m_wide);
+      const uint32_t heavy = (n_text | n_hit | n_wide) == 0 ? GMX_FAST_NONE
+                             : n_text >= n_hit ? (n_text >= n_wide ? GMX_FAST_TEXT : GMX_FAST_WIDE)
+                                               : (n_hit >= n_wide ? GMX_FAST_HIT : GMX_FAST_WIDE);
       // all fetches of the iteration are issued before any of them is consumed
-      uint4 h0, h1, h2, h3;
-      h0 = h1 = h2 = h3 = make_uint4(0, 0, 0, 0);
-      uint32_t xlo = 0, xhi = 0, shift = 0;
-      if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(gmx_dfs_fast_line(ix, ln, kind));
-        h0 = src[0];
-        h1 = src[1];
-        h2 = src[2];
-        h3 = src[3];
-      } else if (kind == GMX_FAST_TEXT) {
-        h0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
-        uint32_t start;
-        gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-        rd.planes(start, xlo, xhi);
-      } else if (kind == GMX_FAST_CONVERT) {
-        h0.x = ix.sa[ln.a];
+      uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+      uint32_t xlo = 0, xhi = 0, shift = 0, sa_val = 0;
+      if (m_light && kind == GMX_FAST_CONVERT) sa_val = ix.sa[ln.a];
+      if (heavy == GMX_FAST_TEXT) {
+        if (kind == GMX_FAST_TEXT) {
+          q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+          uint32_t start;
+          gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+          rd.planes(start, xlo, xhi);
+        }
+      } else if (heavy == GMX_FAST_HIT) {
+        if (kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
+      } else if (heavy == GMX_FAST_WIDE) {
+        if (kind == GMX_FAST_WIDE) {
+          const uint4 *src = reinterpret_cast<const uint4 *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+          q0 = src[0];
+          q1 = src[1];
+          q2 = src[2];
+          q3 = src[3];
+        }
       }
-      if (kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE) {
-        const uint32_t w[16] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w, h2.x, h2.y, h2.z, h2.w, h3.x, h3.y, h3.z, h3.w};
-        if (!(kind == GMX_FAST_HIT ? gmx_dfs_fast_hit(ctx, rd, ln, w) : gmx_dfs_fast_wide(ix, rd, ln, w))) wait_slow = true;
-      } else if (kind == GMX_FAST_TEXT) {
-        gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{h0.x, h0.y, h0.z, h0.w}, xlo, xhi, shift);
-      } else if (kind == GMX_FAST_CONVERT) {
-        ln.a = h0.x;
-        ln.b = GMX_TEXT_MARK;
+      if (m_light) {
+        if (kind == GMX_FAST_CONVERT) {
+          ln.a = sa_val;
+          ln.b = GMX_TEXT_MARK;
+        } else if (kind == GMX_FAST_EMIT) {
+          gmx_dfs_emit(ctx, ln);
+        } else if (kind == GMX_FAST_POP) {
+          gmx_dfs_pop(ctx, ln);
+        }
+      }
+      if (heavy == GMX_FAST_TEXT) {
+        if (kind == GMX_FAST_TEXT) gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+      } else if (heavy == GMX_FAST_HIT) {
+        if (kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+      } else if (heavy == GMX_FAST_WIDE) {
+        if (kind == GMX_FAST_WIDE) {
+          const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+          if (!gmx_dfs_fast_wide(ix, rd, ln, w)) wait_slow = true;
+        }
       }
     }
     if ((mf | ms) == 0) break;
@@ -952,6 +981,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= e->upload(&v.blocks, h.blocks);
   rc |= e->upload(&v.hits, h.hits);
   rc |= e->upload(&v.hit_perm, h.hit_perm);
+  rc |= e->upload(&v.hit_prog, h.hit_prog);
   rc |= e->upload(&v.text, h.text);
   rc |= e->upload(&v.prog, h.prog);
   rc |= e->upload(&v.sa, h.sa);

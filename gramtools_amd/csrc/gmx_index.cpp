@@ -450,6 +450,7 @@ GmxIndexView HostIndex::view() const {
   v.blocks = blocks.data();
   v.hits = hits.data();
   v.hit_perm = hit_perm.data();
+  v.hit_prog = hit_prog.data();
   v.text = text.data();
   v.prog = prog.data();
   v.sa = sa.data();
@@ -682,6 +683,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     return off;
   };
   out.hits.clear();
+  std::vector<uint32_t> progs_bwt;
   {
     GmxIndexView hv = out.view();  // blocks are in place: the LF steps below only need them and C[]
     for (size_t i = 0; i < n; ++i) {
@@ -689,48 +691,57 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       uint32_t p = out.sa[i];
       GmxHit hit;
       memset(&hit, 0, sizeof(hit));
-      hit.kind = GMX_HIT_PROG;
-      hit.prog_off = 0;
-      for (auto &t : hit.tp) t = GMX_NIL;
+      uint32_t prog_off = 0;
       if (p < N && prg[p] <= 4) {
         // left_markers_search, vBWT_jump.cpp:94-117
         uint32_t m = g.pos_target[p].first;
         int32_t a = g.pos_target[p].second;
         if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
-        hit.prog_off = make_program(m, a);
-        const uint32_t *pw = out.prog.data() + hit.prog_off;
-        if (pw[0] == 1 && pw[1] == 1) {  // one output, one op: pre-resolve it together with its LF step
-          uint32_t op = pw[2], site = pw[3], lo = pw[5], hi = pw[6];
-          hit.site = site;
-          hit.allele = (int32_t)pw[4];
-          if (op == GMX_OP_EXIT && lo == hi) {
-            hit.kind = GMX_HIT_EXIT;
-            uint32_t b0 = out.bwt[lo];
-            if (b0 >= 1 && b0 <= 4) {
+        prog_off = make_program(m, a);
+      }
+      for (auto &sub : hit.sub) {
+        sub.head = GMX_HIT_PROG;
+        sub.site = prog_off;
+      }
+      const uint32_t *pw = out.prog.data() + prog_off;
+      if (prog_off != 0 && pw[0] == 1 && pw[1] == 1) {  // one output, one op: pre-resolve it together with its LF step
+        uint32_t op = pw[2], site = pw[3], lo = pw[5], hi = pw[6];
+        if (op == GMX_OP_EXIT && lo == hi) {
+          uint32_t b0 = out.bwt[lo];
+          for (uint32_t c = 1; c <= 4; ++c) {
+            GmxHitSub &sub = hit.sub[c - 1];
+            sub.head = GMX_HIT_EXIT;
+            sub.site = site;
+            sub.y = pw[4];
+            if (b0 == c) {
               uint32_t l2 = lo, h2 = hi;
               const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
-              if (!gmx_lf(hv, b0, l2, h2, blk)) throw std::runtime_error("internal: exit LF precomputation failed");
-              hit.lf[0] = b0;
-              hit.lf[1] = l2;
-              hit.tp[0] = out.sa[l2];
+              if (!gmx_lf(hv, c, l2, h2, blk) || l2 != h2) throw std::runtime_error("internal: exit LF precomputation failed");
+              sub.head |= GMX_HITF_ALIVE | GMX_HITF_TEXT;
+              sub.x = out.sa[l2];
             }
-          } else if (op == GMX_OP_ENTER) {
-            hit.kind = GMX_HIT_ENTER;
-            for (uint32_t c = 1; c <= 4; ++c) {
-              uint32_t l2 = lo, h2 = hi;
-              const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
-              if (gmx_lf(hv, c, l2, h2, blk)) {
-                hit.lf[2 * (c - 1)] = l2;
-                hit.lf[2 * (c - 1) + 1] = h2;
-                if (l2 == h2) hit.tp[c - 1] = out.sa[l2];
+          }
+        } else if (op == GMX_OP_ENTER) {
+          for (uint32_t c = 1; c <= 4; ++c) {
+            GmxHitSub &sub = hit.sub[c - 1];
+            sub.head = GMX_HIT_ENTER;
+            sub.site = site;
+            uint32_t l2 = lo, h2 = hi;
+            const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
+            if (gmx_lf(hv, c, l2, h2, blk)) {
+              sub.head |= GMX_HITF_ALIVE;
+              if (l2 == h2) {
+                sub.head |= GMX_HITF_TEXT;
+                sub.x = out.sa[l2];
               } else {
-                hit.lf[2 * (c - 1)] = 1;
-                hit.lf[2 * (c - 1) + 1] = 0;
+                sub.x = l2;
+                sub.y = h2;
               }
             }
           }
         }
       }
+      progs_bwt.push_back(prog_off);
       out.hits.push_back(hit);
     }
   }
@@ -754,6 +765,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     if (markers != out.hits.size()) throw std::runtime_error("internal: marker count mismatch");
     std::vector<GmxHit> by_text(out.hits.size());
     out.hit_perm.assign(out.hits.size(), 0);
+    out.hit_prog.assign(out.hits.size(), 0);
     uint32_t rank = 0;
     for (size_t i = 0; i < n; ++i) {
       if (out.bwt[i] <= 4) continue;
@@ -761,6 +773,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       const GmxTextRec &r = out.text[q >> 5];
       uint32_t t = r.mrank + (uint32_t)__builtin_popcount(r.mk & ((1u << (q & 31u)) - 1u));
       by_text[t] = out.hits[rank];
+      out.hit_prog[t] = progs_bwt[rank];
       out.hit_perm[rank] = t;
       ++rank;
     }

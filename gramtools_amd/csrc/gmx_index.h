@@ -29,7 +29,7 @@ struct HostIndex {
   std::vector<GmxRankBlock> blocks;
   std::vector<uint32_t> sa;
   std::vector<GmxHit> hits;
-  std::vector<uint32_t> hit_perm;
+  std::vector<uint32_t> hit_perm, hit_prog;
   std::vector<GmxTextRec> text;
   std::vector<uint32_t> prog;
   std::vector<uint32_t> pos_node;

@@ -75,25 +75,25 @@ struct GmxSeed {
 #define GMX_OP_EXIT 1u   // exiting_site_search_state / update_variant_site_path (vBWT_jump.cpp:51-92)
 #define GMX_OP_ENTER 2u  // entering_site_search_state (vBWT_jump.cpp:29-44)
 
-// Marker hit record, one 64-byte line per marker position of the BWT (indexed by marker rank).
-// `prog_off` always points at the general jump program; kind 1/2 additionally pre-resolve the two cases that make
-// up flat SNP/indel PRGs so that a hit costs one line fetch and no further dependent load:
-//   kind 1  single output, single op EXIT(site, allele) -> interval [x, x]; lf[0] = the base b preceding the site
-//           marker (0 if it is not a base), lf[1] = C[b] + rank_b(x): the state after the LF step with b
-//   kind 2  single output, single op ENTER(site) -> interval I; lf[2(c-1)], lf[2(c-1)+1] = LF(I, c) for c = 1..4
-//           (lo > hi when empty)
-//   tp[]    PRG position (SA value) of a width-one LF result, GMX_NIL otherwise: kind 1 -> tp[0] = SA[lf[1]];
-//           kind 2 -> tp[c-1] = SA[lf[2(c-1)]] when the interval has width one. The state continues in text
-//           form (GmxTextRec) without an SA look-up.
-// Records are stored in PRG (text) order of the marker; `hit_perm` maps a BWT marker rank to the record.
-struct alignas(64) GmxHit {
-  uint32_t kind;
-  uint32_t prog_off;
+// Marker hit record: one 64-byte line per variant marker of the PRG, in PRG (text) order; `hit_perm` maps a BWT
+// marker rank to the record. The line holds four 16-byte sub-records, one per possible NEXT READ BASE c: what the
+// hit does when the read continues with c. A hit therefore costs one 16-byte fetch at a known address.
+//   kind PROG   site = word offset of the general jump program (pre-resolved closure of the marker's jumps)
+//   kind EXIT   single output, single op EXIT(site, allele = y) -> interval [i, i]. ALIVE iff c is the base that
+//               precedes the site marker; then x = SA[LF(i, c)]: the state continues in text form
+//   kind ENTER  single output, single op ENTER(site) -> interval I. ALIVE iff LF(I, c) is non-empty; a width-one
+//               result continues in text form (TEXT, x = its PRG position), a wider one as [x, y]
+// `hit_prog[h]` keeps the general program of every record (host-side lock-step search, seed table).
+struct GmxHitSub {
+  uint32_t head;  // kind | flags
   uint32_t site;
-  int32_t allele;
-  uint32_t lf[8];
-  uint32_t tp[4];
+  uint32_t x, y;
 };
+struct alignas(64) GmxHit {
+  GmxHitSub sub[4];
+};
+#define GMX_HITF_ALIVE 4u
+#define GMX_HITF_TEXT 8u
 #define GMX_HIT_PROG 0u
 #define GMX_HIT_EXIT 1u
 #define GMX_HIT_ENTER 2u
@@ -128,6 +128,7 @@ struct GmxIndexView {
   const GmxRankBlock *blocks;
   const GmxHit *hits;         // [n_hits] record of the h-th marker of the PRG (text order)
   const uint32_t *hit_perm;   // [n_hits] BWT marker rank -> index into hits[]
+  const uint32_t *hit_prog;   // [n_hits] jump program of each record
   const GmxTextRec *text;     // [n_prg / 32 + 1]
   const uint32_t *prog;       // jump programs
   const uint32_t *sa;         // [n]
