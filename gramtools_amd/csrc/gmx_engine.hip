@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -34,7 +35,10 @@
 
 #define GMX_BLOCK 256
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
-#define GMX_STACK_DEPTH 6     // pending entries (sibling states, unresolved marker hits) per lane, in LDS
+#ifndef GMX_STACK_DEPTH
+#define GMX_STACK_DEPTH 6
+#endif
+// GMX_STACK_DEPTH: pending entries (sibling states, unresolved marker hits) per lane, in LDS
 #define GMX_STACK_WORDS 5
 #define GMX_CNT_STRIDE 32      // device counters sit 128 B apart: same-line atomics would serialise in one L2 channel
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
@@ -78,6 +82,12 @@ struct ReadRef {
 // ---------------------------------------------------------------------------
 extern __shared__ uint32_t gmx_lds[];
 
+// A pending entry of a task handed from the probe kernel to the extend kernel (overlays the task's finals[]).
+struct GmxParked {
+  uint32_t a, b, tvd, tvg, pm;  // pm = read position | mode << 30, as on the stack
+};
+static_assert(GMX_STACK_DEPTH * sizeof(GmxParked) <= GMX_FAST_STATES * sizeof(GmxFinalState), "parked entries overlay finals[]");
+
 struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path arena and emitted states in global memory
   uint32_t sp;
   GmxPathNode *arena;
@@ -85,6 +95,13 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint32_t status;
   GmxFinalState *out;
   uint32_t n_out, out_cap;
+  bool parking;       // probe kernel: "emitted" states are parked for the extend kernel (GmxParked, same memory)
+  uint32_t park_pos;  // read position of states parked by emit()
+  __device__ __forceinline__ bool park(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
+    if (n_out >= out_cap) return false;
+    reinterpret_cast<GmxParked *>(out)[n_out++] = GmxParked{a, b, tvd, tvg, pos | (mode << 30)};
+    return true;
+  }
   __device__ __forceinline__ bool pop(uint32_t &a, uint32_t &b, uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
     if (sp == 0) return false;
     --sp;
@@ -110,6 +127,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     return true;
   }
   __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+    if (parking) return park(lo, hi, tvd, tvg, park_pos, GMX_MODE_STATE);
     if (n_out >= out_cap) return false;
     out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
     return true;
@@ -246,17 +264,42 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
 // count is amortised instead of being executed (mostly masked off) on every step.
 #define GMX_SLOW_BATCH 12
-template <class Ctx>
-__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active) {
-  GmxLane ln;
+#ifdef GMX_LOOP_STATS
+// Debug build only (-DGMX_LOOP_STATS): iteration mix of the wave loop, summed over all kernels using it.
+//   [0] fast iterations  [1] heavy TEXT  [2] heavy HIT  [3] heavy WIDE  [4] light only  [5] slow iterations
+//   [6] lanes served by fast heavy kinds  [7] lanes served by slow iterations  [8] waves  [9] light lanes
+__device__ unsigned long long gmx_loop_stats[48];  // x3: probe, extend, large-capacity kernel
+extern "C" int gmx_debug_loop_stats(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_loop_stats), sizeof(gmx_loop_stats)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gmx_loop_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define GMX_STAT(i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gmx_loop_stats[KID * 16 + (i)], (unsigned long long)(v)); } while (0)
+#else
+#define GMX_STAT(i, v) do { } while (0)
+#endif
+#ifndef GMX_KIND_SHARE
+#define GMX_KIND_SHARE 64
+#endif
+// GMX_KIND_SHARE: a heavier kind runs in an iteration when it holds at least 1/GMX_KIND_SHARE of the heavy lanes.
+// Measured on MI355X: the loop is latency-bound, so running every kind present (64) beats gathering lanes (4).
+template <int KID, class Ctx>
+__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active, uint32_t budget,
+                             GmxLane &ln) {
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   bool wait_slow = false;
+  uint32_t iters = 0;
+  GMX_STAT(8, 1);
   for (;;) {
-    // ---- fast phase. Every iteration runs ONE of the three heavier kinds — the one most lanes are waiting
-    // for (a wave-uniform choice, so the other kinds' code is branched over, not masked off) — plus the cheap
-    // kinds (convert / emit / pop). Lanes of the other kinds wait a round; lanes that need the general
-    // iteration wait for the slow phase.
+    // ---- fast phase. Of the three heavier kinds an iteration runs those that hold a fair share of the lanes
+    // (a wave-uniform choice: the code of the others is branched over, not masked off), plus the cheap kinds
+    // (convert / emit / pop). Lanes of a kind with few takers wait until it has gathered more; lanes that need
+    // the general iteration wait for the slow phase. `budget` (probe kernel) bounds the number of iterations:
+    // whatever is still pending then is parked and continues in the compacted extend kernel.
     unsigned long long mf, ms;
     for (;;) {
       const uint32_t kind = wait_slow ? GMX_FAST_NONE : gmx_dfs_fast_kind(ln, stop);
@@ -266,31 +309,36 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       ms = __ballot(ln.have && kind == GMX_FAST_NONE);
       mf = m_text | m_hit | m_wide | m_light;
       if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
+      if (budget && iters >= budget) return;
+      ++iters;
       const uint32_t n_text = (uint32_t)__popcll(m_text), n_hit = (uint32_t)__popcll(m_hit), n_wide = (uint32_t)__popcll(m_wide);
-      const uint32_t heavy = (n_text | n_hit | n_wide) == 0 ? GMX_FAST_NONE
-                             : n_text >= n_hit ? (n_text >= n_wide ? GMX_FAST_TEXT : GMX_FAST_WIDE)
-                                               : (n_hit >= n_wide ? GMX_FAST_HIT : GMX_FAST_WIDE);
+      const uint32_t n_heavy = n_text + n_hit + n_wide;
+      const bool run_text = n_text && n_text * GMX_KIND_SHARE >= n_heavy, run_hit = n_hit && n_hit * GMX_KIND_SHARE >= n_heavy,
+                 run_wide = n_wide && n_wide * GMX_KIND_SHARE >= n_heavy;
+      GMX_STAT(0, 1);
+      GMX_STAT(1, run_text);
+      GMX_STAT(2, run_hit);
+      GMX_STAT(3, run_wide);
+      GMX_STAT(4, n_heavy == 0);
+      GMX_STAT(6, (run_text ? n_text : 0) + (run_hit ? n_hit : 0) + (run_wide ? n_wide : 0));
+      GMX_STAT(9, __popcll(m_light));
       // all fetches of the iteration are issued before any of them is consumed
       uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
       uint32_t xlo = 0, xhi = 0, shift = 0, sa_val = 0;
       if (m_light && kind == GMX_FAST_CONVERT) sa_val = ix.sa[ln.a];
-      if (heavy == GMX_FAST_TEXT) {
-        if (kind == GMX_FAST_TEXT) {
-          q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
-          uint32_t start;
-          gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-          rd.planes(start, xlo, xhi);
-        }
-      } else if (heavy == GMX_FAST_HIT) {
-        if (kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
-      } else if (heavy == GMX_FAST_WIDE) {
-        if (kind == GMX_FAST_WIDE) {
-          const uint4 *src = reinterpret_cast<const uint4 *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
-          q0 = src[0];
-          q1 = src[1];
-          q2 = src[2];
-          q3 = src[3];
-        }
+      if (run_text && kind == GMX_FAST_TEXT) {
+        q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+        uint32_t start;
+        gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+        rd.planes(start, xlo, xhi);
+      }
+      if (run_hit && kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
+      if (run_wide && kind == GMX_FAST_WIDE) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT));
+        q0 = src[0];
+        q1 = src[1];
+        q2 = src[2];
+        q3 = src[3];
       }
       if (m_light) {
         if (kind == GMX_FAST_CONVERT) {
@@ -302,19 +350,20 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
           gmx_dfs_pop(ctx, ln);
         }
       }
-      if (heavy == GMX_FAST_TEXT) {
-        if (kind == GMX_FAST_TEXT) gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
-      } else if (heavy == GMX_FAST_HIT) {
-        if (kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
-      } else if (heavy == GMX_FAST_WIDE) {
-        if (kind == GMX_FAST_WIDE) {
-          const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-          if (!gmx_dfs_fast_wide(ix, rd, ln, w)) wait_slow = true;
-        }
+      if (run_text && kind == GMX_FAST_TEXT)
+        gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+      if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+      if (run_wide && kind == GMX_FAST_WIDE) {
+        const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+        if (!gmx_dfs_fast_wide(ix, rd, ln, w)) wait_slow = true;
       }
     }
     if ((mf | ms) == 0) break;
+    if (budget && iters >= budget) return;
+    ++iters;
     // ---- one general iteration for every waiting lane ----
+    GMX_STAT(5, 1);
+    GMX_STAT(7, __popcll(ms));
     if (ln.have && (wait_slow || gmx_dfs_fast_kind(ln, stop) == GMX_FAST_NONE)) {
       gmx_dfs_slow_iter(ix, ctx, rd, stop, ln);
       wait_slow = false;
@@ -344,6 +393,7 @@ struct SearchOut {
   uint32_t *overflow_list;   // task ids to re-run with large capacities
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
   uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
+  uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
@@ -412,11 +462,12 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   block_append(o.dead_list, &o.counters[6 * GMX_CNT_STRIDE], dead, task);
 }
 
+#define GMX_PROBE_ITERS 10  // default iteration budget of the probe kernel (GMX_PROBE_ITERS in the environment overrides)
 #define GMX_PROBE_STEPS 6  // bases extended by the probe phase; a wrong-orientation task survives them with p ~ 1e-3
 
 // Phase 1 — every (read, orientation): seed lookup + the first GMX_PROBE_STEPS extensions. Half of the tasks
 // (the orientation that does not map) die here; the survivors are parked and compacted for the main phase.
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t probe_iters) {
   uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = task < b.n_reads * 2;
   uint32_t status = GMX_TASK_SKIPPED;
@@ -428,7 +479,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
-  ctx.out_cap = GMX_STACK_DEPTH;  // parked states must fit the extend kernel's stack
+  ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
+  ctx.parking = true;
+  ctx.park_pos = 0;
   ReadRef r;
   r.w = b.packed;
   r.len = 0;
@@ -452,10 +505,30 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       status = ctx.status;
       done = stop == 0;
       lane_stop = stop;
+      ctx.parking = !done;
+      ctx.park_pos = stop;
+      if (done) ctx.out_cap = GMX_FAST_STATES;
     }
   }
-  dfs_run_wave(ix, ctx, r, lane_stop, run);  // every lane of the wave takes part in the ballots
-  if (run) status = ctx.status;
+  GmxLane ln;
+  dfs_run_wave<0>(ix, ctx, r, lane_stop, run, probe_iters, ln);  // every lane of the wave takes part in the ballots
+  if (run) {
+    // iteration budget spent with work left: park the lane's entry and its stack as they are
+    if ((ln.have || ctx.sp) && ctx.status == GMX_TASK_MAPPED) {
+      if (done) {
+        ctx.fail(GMX_TASK_OVERFLOW);  // a short read whose states are final ones: redone by the large-capacity pass
+      } else {
+        do {
+          if (ln.have && ln.mode != GMX_MODE_DEAD && !ctx.park(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode)) {
+            ctx.fail(GMX_TASK_OVERFLOW);
+            break;
+          }
+          ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+        } while (ln.have);
+      }
+    }
+    status = ctx.status;
+  }
   finish_lane(o, active, task, ctx, status, done);
 }
 
@@ -475,6 +548,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_FAST_STATES;
+  ctx.parking = false;
+  ctx.park_pos = 0;
   ReadRef r;
   r.w = b.packed;
   r.len = 0;
@@ -486,13 +561,14 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
     ctx.arena_n = packed >> 8;
-    const uint32_t at = r.len - ix.kmer_size - GMX_PROBE_STEPS;  // parked tasks have more than GMX_PROBE_STEPS bases left
+    const GmxParked *parked = reinterpret_cast<const GmxParked *>(ctx.out);  // all read before the first emit overwrites them
     for (uint32_t s = 0; s < n; ++s) {
-      GmxFinalState f = ctx.out[s];
-      ctx.push(f.lo, f.hi, f.traversed, f.traversing, at, GMX_MODE_STATE);
+      GmxParked f = parked[s];
+      ctx.push(f.a, f.b, f.tvd, f.tvg, f.pm & 0x3FFFFFFFu, f.pm >> 30);
     }
   }
-  dfs_run_wave(ix, ctx, r, 0, active);
+  GmxLane ln;
+  dfs_run_wave<1>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
   finish_lane(o, active, task, ctx, status, true);
 }
@@ -578,7 +654,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       });
       run = ctx.status == GMX_TASK_MAPPED;
     }
-    dfs_run_wave(ix, ctx, r, 0, run);
+    GmxLane ln;
+    dfs_run_wave<2>(ix, ctx, r, 0, run, 0, ln);
     if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
@@ -652,7 +729,7 @@ typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
 // Three instances over three device-side queues (LIST):
-//   0  tasks finished by the extend kernel, small per-lane scratch
+//   0  tasks finished by the probe / extend kernels that gmx_cover_single_kernel passed on, small per-lane scratch
 //   2  tasks finished by the large-capacity search (runs on the engine's side stream), small scratch
 //   1  entries of either whose selection exceeded the small scratch (nothing has been recorded for them yet),
 //      redone with the large scratch after both
@@ -660,8 +737,8 @@ template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
   constexpr bool BIG = LIST == 1;
-  uint32_t n_mapped = o.counters[(LIST == 0 ? 0 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
-  const uint32_t *list = LIST == 0 ? o.mapped_list : LIST == 1 ? o.cover_overflow_list : o.big_mapped_list;
+  uint32_t n_mapped = o.counters[(LIST == 0 ? 8 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  const uint32_t *list = LIST == 0 ? o.cover_general_list : LIST == 1 ? o.cover_overflow_list : o.big_mapped_list;
   uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
   for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * blockDim.x) {
     uint32_t entry = list[m];
@@ -701,6 +778,38 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
     }
   }
+}
+
+// The common case first, one lane per mapped task and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
+// final state of width one on a non-nested PRG. Few registers, so many more waves are in flight to hide the
+// dependent look-ups (state -> node -> walk -> atomics). Everything else is queued for the general instance.
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
+  const uint32_t n_mapped = o.counters[0 * GMX_CNT_STRIDE];
+  const uint32_t m = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (m >= n_mapped) return;
+  const uint32_t task = o.mapped_list[m];
+  const uint32_t nf = o.n_final[task] & 0xFF;
+  const GmxFinalState st = o.finals[(size_t)task * GMX_FAST_STATES];
+  if (nf != 1 || ix.is_nested || !(st.lo == st.hi || gmx_text_form(st.hi))) {
+    o.cover_general_list[atomicAdd(&o.counters[8 * GMX_CNT_STRIDE], 1u)] = task;
+    return;
+  }
+  const uint32_t read = task >> 1;
+  CoverEnv env;
+  env.scratch = nullptr;
+  env.stride = 0;
+  env.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  env.allele_sum = acc.allele_sum;
+  env.per_base = acc.per_base;
+  env.grouped = acc.grouped;
+  env.log = acc.log;
+  env.log_cursor = acc.log_cursor;
+  env.log_cap = acc.log_cap;
+  env.status = GMX_TASK_MAPPED;
+  env.log_at = 0;
+  gmx_cover_single(ix, env, st, (uint32_t)(b.offsets[read + 1] - b.offsets[read]));
+  if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u)
+    o.counters[3 * GMX_CNT_STRIDE] = task;
 }
 
 // QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
@@ -875,11 +984,12 @@ struct gmx_engine {
   BigOut big{};
   uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
   uint32_t cover_blocks = 0, cover_big_lanes = 0, cover_side_blocks = 0;
-  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr;
+  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr, *d_cover_general = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
   uint32_t n_cus = 256;
+  uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
   uint64_t *d_offsets = nullptr;
@@ -938,6 +1048,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_mapped, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
@@ -1003,7 +1114,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
   rc |= e->alloc(&e->d_log_cursor, 4, true);
-  rc |= e->alloc(&e->d_counters, 8 * GMX_CNT_STRIDE, true);
+  rc |= e->alloc(&e->d_counters, 16 * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
@@ -1027,6 +1138,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       e->filter_lds_words = (uint32_t)words;
     (void)hipGetLastError();
   }
+  if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   e->cover_side_blocks = 32;
   rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
   rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
@@ -1062,7 +1174,7 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
   HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
   HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
-  HIP_TRY(hipMemset(e->d_counters, 0, 8 * GMX_CNT_STRIDE * 4));
+  HIP_TRY(hipMemset(e->d_counters, 0, 16 * GMX_CNT_STRIDE * 4));
   return GMX_OK;
 }
 
@@ -1096,12 +1208,12 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow,
-              e->d_big_mapped, e->d_alive,  e->d_dead,    e->d_counters};
+              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 4 * GMX_CNT_STRIDE * 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 5 * GMX_CNT_STRIDE * 4, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -1115,7 +1227,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     HIP_TRY(hipEventRecord(ev.s, stream));
   }
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
-  hipLaunchKernelGGL(gmx_probe_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  hipLaunchKernelGGL(gmx_probe_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
   hipLaunchKernelGGL(gmx_extend_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
@@ -1134,6 +1246,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
                        e->dview, b, o, e->filter_lds_words);
   else
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
+  hipLaunchKernelGGL(gmx_cover_single_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
                      o, e->big, acc);
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
