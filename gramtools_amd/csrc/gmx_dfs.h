@@ -318,20 +318,43 @@ GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, const GmxHitSub &hs) {
   return true;
 }
 
-// WIDE: `w` = the 16 words of the rank block holding [a, b]. A marker inside the interval needs the general path.
+// WIDE: `w` = the 16 words of the rank block holding [a, b] (counts | low plane | high plane | marker plane).
+// A marker inside the interval needs the general path. Same arithmetic as gmx_lf, on 32-bit words.
+GMX_HD uint32_t gmx_prefix32(uint32_t r, uint32_t word) {  // bits of 32-bit word `word` that lie below block position r
+  const int32_t t = (int32_t)r - (int32_t)(32u * word);
+  return t <= 0 ? 0u : (t >= 32 ? ~0u : ((1u << t) - 1u));
+}
 template <class Reader>
 GMX_HD bool gmx_dfs_fast_wide(const GmxIndexView &ix, Reader &rd, GmxLane &ln, const uint32_t *w) {
-  GmxLine line;
-  for (int k = 0; k < 16; ++k) line.w[k] = w[k];
-  const GmxRankBlock blk = gmx_line_as_block(line);
-  uint64_t a0, a1, z0, z1;
-  gmx_prefix_mask(ln.a & GMX_BLK_MASK, a0, a1);
-  gmx_prefix_mask((ln.b & GMX_BLK_MASK) + 1, z0, z1);
-  if ((blk.mk[0] & z0 & ~a0) | (blk.mk[1] & z1 & ~a1)) return false;
-  if (gmx_lf(ix, rd.at(ln.pos - 1), ln.a, ln.b, blk))
-    --ln.pos;
-  else
+  const uint32_t r_lo = ln.a & GMX_BLK_MASK, r_hi = (ln.b & GMX_BLK_MASK) + 1u;
+  const uint32_t a0 = gmx_prefix32(r_lo, 0), a1 = gmx_prefix32(r_lo, 1), a2 = gmx_prefix32(r_lo, 2), a3 = gmx_prefix32(r_lo, 3);
+  const uint32_t z0 = gmx_prefix32(r_hi, 0), z1 = gmx_prefix32(r_hi, 1), z2 = gmx_prefix32(r_hi, 2), z3 = gmx_prefix32(r_hi, 3);
+  if ((w[12] & z0 & ~a0) | (w[13] & z1 & ~a1) | (w[14] & z2 & ~a2) | (w[15] & z3 & ~a3)) return false;
+  const uint32_t c = rd.at(ln.pos - 1);
+  const uint32_t code = c - 1u;
+  const uint32_t xl = (code & 1u) ? 0u : ~0u, xh = (code & 2u) ? 0u : ~0u, ka = c == 1 ? ~0u : 0u;
+  const uint32_t m0 = (w[4] ^ xl) & (w[8] ^ xh) & ~(w[12] & ka);
+  const uint32_t m1 = (w[5] ^ xl) & (w[9] ^ xh) & ~(w[13] & ka);
+  const uint32_t m2 = (w[6] ^ xl) & (w[10] ^ xh) & ~(w[14] & ka);
+  const uint32_t m3 = (w[7] ^ xl) & (w[11] ^ xh) & ~(w[15] & ka);
+  const uint32_t blk = ln.a >> GMX_BLK_SHIFT;
+  const uint32_t base = c == 1 ? w[0] : (c == 2 ? w[1] : (c == 3 ? w[2] : (blk << GMX_BLK_SHIFT) - w[0] - w[1] - w[2] - w[3]));
+  uint32_t rank_lo = base + (uint32_t)__builtin_popcount(m0 & a0) + (uint32_t)__builtin_popcount(m1 & a1) +
+                     (uint32_t)__builtin_popcount(m2 & a2) + (uint32_t)__builtin_popcount(m3 & a3);
+  uint32_t rank_hi1 = base + (uint32_t)__builtin_popcount(m0 & z0) + (uint32_t)__builtin_popcount(m1 & z1) +
+                      (uint32_t)__builtin_popcount(m2 & z2) + (uint32_t)__builtin_popcount(m3 & z3);
+  if (c == 1) {  // the sentinel is stored as code 00, it is not a base
+    if (ix.sentinel_pos < ln.a) rank_lo -= 1;
+    if (ix.sentinel_pos <= ln.b) rank_hi1 -= 1;
+  }
+  if (rank_lo == rank_hi1) {
     ln.mode = GMX_MODE_DEAD;
+    return true;
+  }
+  const uint32_t first = c == 1 ? ix.C[1] : (c == 2 ? ix.C[2] : (c == 3 ? ix.C[3] : ix.C[4]));
+  ln.a = first + rank_lo;
+  ln.b = first + rank_hi1 - 1u;
+  --ln.pos;
   return true;
 }
 

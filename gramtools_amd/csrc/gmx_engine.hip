@@ -1237,7 +1237,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // fork: the few tasks of the large-capacity pass (one wave per CU, latency-bound) run beside filter + coverage
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side_stream, e->dview, b, o, e->big);
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side_stream,
                      e->dview, b, o, e->big, acc);
   HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));

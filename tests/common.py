@@ -51,7 +51,7 @@ def _load_emu():
     so = os.path.join(HERE, "hostemu", "libhostemu.so")
     srcs = [os.path.join(HERE, "hostemu", "hostemu.cpp"), os.path.join(ROOT, "gramtools_amd", "csrc", "gmx_index.cpp")]
     deps = srcs + [os.path.join(ROOT, "gramtools_amd", "csrc", h) for h in
-                   ("gmx_core.h", "gmx_cover.h", "gmx_types.h", "gmx_index.h")]
+                   ("gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_types.h", "gmx_index.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs + ["-lpthread"])
     lib = C.CDLL(so)
