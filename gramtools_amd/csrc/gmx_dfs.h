@@ -150,7 +150,17 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
           ln.b = GMX_TEXT_MARK;
         }
       }
-    } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
+    } else if (kind == GMX_HIT_FUSED && ln.pos - 1u > stop) {
+      uint32_t nn = ctx.arena_new(hs.site, (int32_t)hs.y, ln.tvd);
+      if (nn == GMX_NIL) {
+        ctx.fail(GMX_TASK_OVERFLOW);
+      } else {
+        ln.tvd = nn;
+        alive = true;
+        ln.a = hs.x - (hs.head >> 4);
+        ln.b = GMX_TEXT_MARK;
+      }
+    } else if (kind == GMX_HIT_ENTER || kind == GMX_HIT_FUSED) {  // entering_site_search_state, vBWT_jump.cpp:29-44
       uint32_t nn = ctx.arena_new(hs.site, -1, ln.tvg);
       if (nn == GMX_NIL) {
         ctx.fail(GMX_TASK_OVERFLOW);
@@ -291,7 +301,7 @@ GMX_HD const GmxHitSub *gmx_dfs_hit_sub(const GmxIndexView &ix, Reader &rd, cons
   return &ix.hits[ln.a].sub[rd.at(ln.pos - 1) - 1u];
 }
 template <class Ctx>
-GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, const GmxHitSub &hs) {
+GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, uint32_t stop, const GmxHitSub &hs) {
   const uint32_t kind = hs.head & 3u;
   if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
     if (ln.tvg != GMX_NIL) {
@@ -303,7 +313,13 @@ GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, const GmxHitSub &hs) {
     ln.tvd = nn;
     ln.a = hs.x;
     ln.b = GMX_TEXT_MARK;
-  } else if (kind == GMX_HIT_ENTER) {  // entering_site_search_state, vBWT_jump.cpp:29-44
+  } else if (kind == GMX_HIT_FUSED && ln.pos - 1u > stop) {  // ENTER, then EXIT of the one-base allele entered
+    uint32_t nn = ctx.arena_new(hs.site, (int32_t)hs.y, ln.tvd);
+    if (nn == GMX_NIL) return false;
+    ln.tvd = nn;
+    ln.a = hs.x - (hs.head >> 4);
+    ln.b = GMX_TEXT_MARK;
+  } else if (kind == GMX_HIT_ENTER || kind == GMX_HIT_FUSED) {  // entering_site_search_state, vBWT_jump.cpp:29-44
     if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
     ln.tvg = GMX_INLINE_FLAG | ((hs.site - 5u) >> 1);
     ln.a = hs.x;
@@ -363,7 +379,7 @@ template <class Ctx, class Reader>
 GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, GmxLane &ln, uint32_t kind) {
   switch (kind) {
     case GMX_FAST_HIT:
-      return gmx_dfs_fast_hit(ctx, ln, *gmx_dfs_hit_sub(ix, rd, ln));
+      return gmx_dfs_fast_hit(ctx, ln, stop, *gmx_dfs_hit_sub(ix, rd, ln));
     case GMX_FAST_WIDE:
       return gmx_dfs_fast_wide(ix, rd, ln, reinterpret_cast<const uint32_t *>(ix.blocks + (ln.a >> GMX_BLK_SHIFT)));
     case GMX_FAST_CONVERT:

@@ -326,11 +326,24 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
       uint32_t xlo = 0, xhi = 0, shift = 0, sa_val = 0;
       if (m_light && kind == GMX_FAST_CONVERT) sa_val = ix.sa[ln.a];
+      bool second = false;  // TEXT: the record below is fetched along, 64 symbols per round trip
+      uint32_t ylo = 0, yhi = 0, shift2 = 0, rec1 = 0;
       if (run_text && kind == GMX_FAST_TEXT) {
-        q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+        rec1 = gmx_dfs_text_rec(ln);
+        q0 = *reinterpret_cast<const uint4 *>(ix.text + rec1);
         uint32_t start;
         gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
         rd.planes(start, xlo, xhi);
+        const uint32_t first_n = ((ln.a ? ln.a - 1u : 0u) & 31u) + 1u;  // symbols of the first record left of the state
+        second = rec1 > 0 && ln.a != 0 && ln.pos > stop + first_n;
+        if (second) {
+          GmxLane l2 = ln;
+          l2.a = rec1 << 5;
+          l2.pos = ln.pos - first_n;
+          q1 = *reinterpret_cast<const uint4 *>(ix.text + rec1 - 1);
+          gmx_dfs_text_window(l2, rd.len, rd.rc, start, shift2);
+          rd.planes(start, ylo, yhi);
+        }
       }
       if (run_hit && kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
       if (run_wide && kind == GMX_FAST_WIDE) {
@@ -350,9 +363,12 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
           gmx_dfs_pop(ctx, ln);
         }
       }
-      if (run_text && kind == GMX_FAST_TEXT)
+      if (run_text && kind == GMX_FAST_TEXT) {
         gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
-      if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+        if (second && ln.mode == GMX_MODE_STATE && ln.b == GMX_TEXT_MARK && ln.a == (rec1 << 5) && ln.pos > stop)
+          gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q1.x, q1.y, q1.z, q1.w}, ylo, yhi, shift2);
+      }
+      if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
       if (run_wide && kind == GMX_FAST_WIDE) {
         const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
         if (!gmx_dfs_fast_wide(ix, rd, ln, w)) wait_slow = true;

@@ -778,6 +778,23 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       ++rank;
     }
     out.hits.swap(by_text);
+    // ENTER + EXIT of a one-base allele -> FUSED (gmx_types.h)
+    auto text_rank = [&](uint32_t q) {
+      const GmxTextRec &r = out.text[q >> 5];
+      return r.mrank + (uint32_t)__builtin_popcount(r.mk & ((1u << (q & 31u)) - 1u));
+    };
+    for (auto &hit : out.hits)
+      for (auto &sub : hit.sub) {
+        if ((sub.head & 3u) != GMX_HIT_ENTER || !(sub.head & GMX_HITF_ALIVE) || !(sub.head & GMX_HITF_TEXT)) continue;
+        const uint32_t p1 = sub.x;  // the allele's last base
+        if (p1 == 0 || prg[p1 - 1] <= 4) continue;
+        const GmxHitSub &ex = out.hits[text_rank(p1 - 1)].sub[0];
+        if ((ex.head & 3u) != GMX_HIT_EXIT || ex.site != sub.site) continue;
+        const uint32_t open_pos = out.nodes[out.sites[(sub.site - 5) >> 1].entry_node].first_pos;
+        if (open_pos >= p1 || prg[open_pos] != sub.site || (p1 - open_pos) >= (1u << 28)) continue;
+        sub.head = GMX_HIT_FUSED | GMX_HITF_ALIVE | GMX_HITF_TEXT | ((p1 - open_pos) << 4);
+        sub.y = ex.y;
+      }
   }
 
   // --- seed table ---------------------------------------------------------------------

@@ -83,6 +83,12 @@ struct GmxSeed {
 //               precedes the site marker; then x = SA[LF(i, c)]: the state continues in text form
 //   kind ENTER  single output, single op ENTER(site) -> interval I. ALIVE iff LF(I, c) is non-empty; a width-one
 //               result continues in text form (TEXT, x = its PRG position), a wider one as [x, y]
+//   kind FUSED  an ENTER whose width-one result sits in a ONE-BASE allele of the same site (a SNP allele): the
+//               symbol left of it is again a marker, whose hit is the EXIT of that allele. Sub-record = the ENTER
+//               (x = PRG position of the allele base) plus y = allele id and head >> 4 = distance from the site's
+//               opening marker to x, so that both hits resolve in one step: traversed += (site, allele), the
+//               traversing path is unchanged (pushed by the ENTER, popped by the EXIT), the state continues in
+//               text form at the opening marker. Used only when the read has bases left after the allele base.
 // `hit_prog[h]` keeps the general program of every record (host-side lock-step search, seed table).
 struct GmxHitSub {
   uint32_t head;  // kind | flags
@@ -92,6 +98,7 @@ struct GmxHitSub {
 struct alignas(64) GmxHit {
   GmxHitSub sub[4];
 };
+#define GMX_HIT_FUSED 3u
 #define GMX_HITF_ALIVE 4u
 #define GMX_HITF_TEXT 8u
 #define GMX_HIT_PROG 0u
