@@ -77,6 +77,70 @@ struct ReadRef {
   }
 };
 
+// The same with the read held in registers (reads of up to 192 bases; longer ones fall back to memory). The search
+// loop then issues no memory request for read bases at all: its kernels sit near the L2's request rate for
+// scattered lines, and the read windows were about 40 % of the requests.
+#define GMX_READ_REG_PAIRS 6
+struct ReadRegs {
+  uint2 p0, p1, p2, p3, p4, p5;
+  const uint2 *w;
+  uint32_t len;
+  bool rc;
+  bool in_regs;
+  __device__ __forceinline__ uint2 sel(uint32_t d) const {
+    uint2 r = make_uint2(0, 0);
+    r = d == 0 ? p0 : r;
+    r = d == 1 ? p1 : r;
+    r = d == 2 ? p2 : r;
+    r = d == 3 ? p3 : r;
+    r = d == 4 ? p4 : r;
+    r = d == 5 ? p5 : r;
+    return r;
+  }
+  __device__ __forceinline__ void load(const uint2 *pairs, uint32_t length, bool reverse) {
+    w = pairs;
+    len = length;
+    rc = reverse;
+    in_regs = length <= 32u * GMX_READ_REG_PAIRS;
+    p0 = p1 = p2 = p3 = p4 = p5 = make_uint2(0, 0);
+    if (in_regs) {  // the packed buffer has slack behind the last read
+      const gmx_pair2 a = *reinterpret_cast<const gmx_pair2 *>(pairs), b = *reinterpret_cast<const gmx_pair2 *>(pairs + 2),
+                      c = *reinterpret_cast<const gmx_pair2 *>(pairs + 4);
+      p0 = make_uint2(a.x, a.y);
+      p1 = make_uint2(a.z, a.w);
+      p2 = make_uint2(b.x, b.y);
+      p3 = make_uint2(b.z, b.w);
+      p4 = make_uint2(c.x, c.y);
+      p5 = make_uint2(c.z, c.w);
+    }
+  }
+  __device__ __forceinline__ void clear(const uint2 *pairs) {
+    w = pairs;
+    len = 0;
+    rc = false;
+    in_regs = true;
+    p0 = p1 = p2 = p3 = p4 = p5 = make_uint2(0, 0);
+  }
+  __device__ __forceinline__ uint32_t at(uint32_t i) const {
+    const uint32_t idx = rc ? len - 1 - i : i;
+    const uint2 pr = in_regs ? sel(idx >> 5) : w[idx >> 5];
+    const uint32_t code = ((pr.x >> (idx & 31u)) & 1u) | (((pr.y >> (idx & 31u)) & 1u) << 1);
+    return rc ? 4u - code : code + 1u;
+  }
+  __device__ __forceinline__ void planes(uint32_t start, uint32_t &lo, uint32_t &hi) const {
+    uint2 a, b;
+    if (in_regs) {
+      a = sel(start >> 5);
+      b = sel((start >> 5) + 1);
+    } else {
+      a = w[start >> 5];
+      b = w[(start >> 5) + 1];
+    }
+    lo = __builtin_amdgcn_alignbit(b.x, a.x, start & 31u);
+    hi = __builtin_amdgcn_alignbit(b.y, a.y, start & 31u);
+  }
+};
+
 // ---------------------------------------------------------------------------
 // per-lane contexts
 // ---------------------------------------------------------------------------
@@ -203,7 +267,8 @@ struct BigCtx {  // the same DFS queue with everything in global memory and runt
 };
 
 // k-mer code of oriented positions [start, start + k): leftmost base most significant
-__device__ __forceinline__ uint32_t kmer_code(ReadRef &r, uint32_t start, uint32_t k) {
+template <class Reader>
+__device__ __forceinline__ uint32_t kmer_code(Reader &r, uint32_t start, uint32_t k) {
   uint32_t code = 0;
   for (uint32_t j = 0; j < k; ++j) code = (code << 2) | (r.at(start + j) - 1u);
   return code;
@@ -281,13 +346,20 @@ extern "C" int gmx_debug_loop_stats(unsigned long long *out, int reset) {
 #else
 #define GMX_STAT(i, v) do { } while (0)
 #endif
+#ifdef GMX_LOOP_STATS
+#define GMX_CLK() clock64()
+#define GMX_TSTAT(kid, i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&gmx_loop_stats[(kid) * 16 + (i)], (unsigned long long)(v)); } while (0)
+#else
+#define GMX_CLK() 0ll
+#define GMX_TSTAT(kid, i, v) do { } while (0)
+#endif
 #ifndef GMX_KIND_SHARE
 #define GMX_KIND_SHARE 64
 #endif
 // GMX_KIND_SHARE: a heavier kind runs in an iteration when it holds at least 1/GMX_KIND_SHARE of the heavy lanes.
 // Measured on MI355X: the loop is latency-bound, so running every kind present (64) beats gathering lanes (4).
-template <int KID, class Ctx>
-__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint32_t stop, bool active, uint32_t budget,
+template <int KID, class Ctx, class Reader>
+__device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, bool active, uint32_t budget,
                              GmxLane &ln) {
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
@@ -326,24 +398,11 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
       uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
       uint32_t xlo = 0, xhi = 0, shift = 0, sa_val = 0;
       if (m_light && kind == GMX_FAST_CONVERT) sa_val = ix.sa[ln.a];
-      bool second = false;  // TEXT: the record below is fetched along, 64 symbols per round trip
-      uint32_t ylo = 0, yhi = 0, shift2 = 0, rec1 = 0;
       if (run_text && kind == GMX_FAST_TEXT) {
-        rec1 = gmx_dfs_text_rec(ln);
-        q0 = *reinterpret_cast<const uint4 *>(ix.text + rec1);
+        q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
         uint32_t start;
         gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
         rd.planes(start, xlo, xhi);
-        const uint32_t first_n = ((ln.a ? ln.a - 1u : 0u) & 31u) + 1u;  // symbols of the first record left of the state
-        second = rec1 > 0 && ln.a != 0 && ln.pos > stop + first_n;
-        if (second) {
-          GmxLane l2 = ln;
-          l2.a = rec1 << 5;
-          l2.pos = ln.pos - first_n;
-          q1 = *reinterpret_cast<const uint4 *>(ix.text + rec1 - 1);
-          gmx_dfs_text_window(l2, rd.len, rd.rc, start, shift2);
-          rd.planes(start, ylo, yhi);
-        }
       }
       if (run_hit && kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
       if (run_wide && kind == GMX_FAST_WIDE) {
@@ -363,11 +422,8 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, ReadRef &rd, uint
           gmx_dfs_pop(ctx, ln);
         }
       }
-      if (run_text && kind == GMX_FAST_TEXT) {
+      if (run_text && kind == GMX_FAST_TEXT)
         gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
-        if (second && ln.mode == GMX_MODE_STATE && ln.b == GMX_TEXT_MARK && ln.a == (rec1 << 5) && ln.pos > stop)
-          gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q1.x, q1.y, q1.z, q1.w}, ylo, yhi, shift2);
-      }
       if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
       if (run_wide && kind == GMX_FAST_WIDE) {
         const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -450,6 +506,11 @@ __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) 
   return r;
 }
 
+__device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task, ReadRegs &r) {
+  const uint32_t read = task >> 1;
+  r.load(b.packed + pack_off(b, read), (uint32_t)(b.offsets[read + 1] - b.offsets[read]), (task & 1) != 0);
+}
+
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
 //   done  : the whole read has been consumed (the emitted states are final, not parked)
 __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uint32_t task, FastCtx &ctx, uint32_t status,
@@ -498,16 +559,12 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
   ctx.parking = true;
   ctx.park_pos = 0;
-  ReadRef r;
-  r.w = b.packed;
-  r.len = 0;
-  r.rc = false;
-  r.cur_idx = 0xFFFFFFFFu;
-  r.cur = make_uint2(0, 0);
+  ReadRegs r;
+  r.clear(b.packed);
   bool run = false;
   uint32_t lane_stop = 0;
   if (active) {
-    r = task_read(b, task);
+    task_read_regs(b, task, r);
     if (b.forward_only && r.rc) {
       status = GMX_STATUS_IGNORED;
     } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
@@ -552,6 +609,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
+  const long long t0 = GMX_CLK();
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = slot < n_alive;
   uint32_t task = active ? o.alive_list[slot] : 0;
@@ -566,14 +624,10 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.out_cap = GMX_FAST_STATES;
   ctx.parking = false;
   ctx.park_pos = 0;
-  ReadRef r;
-  r.w = b.packed;
-  r.len = 0;
-  r.rc = false;
-  r.cur_idx = 0xFFFFFFFFu;
-  r.cur = make_uint2(0, 0);
+  ReadRegs r;
+  r.clear(b.packed);
   if (active) {
-    r = task_read(b, task);
+    task_read_regs(b, task, r);
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
     ctx.arena_n = packed >> 8;
@@ -583,10 +637,16 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
       ctx.push(f.a, f.b, f.tvd, f.tvg, f.pm & 0x3FFFFFFFu, f.pm >> 30);
     }
   }
+  const long long t1 = GMX_CLK();
   GmxLane ln;
   dfs_run_wave<1>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
+  const long long t2 = GMX_CLK();
   finish_lane(o, active, task, ctx, status, true);
+  const long long t3 = GMX_CLK();
+  GMX_TSTAT(1, 10, t1 - t0);
+  GMX_TSTAT(1, 11, t2 - t1);
+  GMX_TSTAT(1, 12, t3 - t2);
 }
 
 // Phase 3 — tasks without a final state: all_read_kmers_occur_in_index decides between the
@@ -1233,6 +1293,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
+  if (const char *x = getenv("GMX_EXTRA_LDS")) lds += (size_t)atoi(x);  // occupancy experiments
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));

@@ -27,9 +27,10 @@ qm.map_reads(reads.reshape(-1), offsets, seeds)
 qm.sync()
 lib.gmx_debug_loop_stats(buf, 1)
 names = ["fast iterations", "heavy TEXT", "heavy HIT", "heavy WIDE", "light only", "slow iterations",
-         "lanes in heavy kinds", "lanes in slow iterations", "waves", "lanes in light kinds"]
+         "lanes in heavy kinds", "lanes in slow iterations", "waves", "lanes in light kinds",
+         "clk prologue", "clk loop", "clk epilogue"]
 for k, kern in enumerate(["probe", "extend", "large-capacity"]):
-    v = np.array(buf[k * 16:k * 16 + 10], dtype=np.float64)
+    v = np.array(buf[k * 16:k * 16 + 13], dtype=np.float64)
     waves = max(v[8], 1)
     print(kern, f"waves={int(v[8])}")
     for n, x in zip(names, v):
