@@ -462,7 +462,8 @@ struct SearchOut {
   GmxFinalState *finals;     // per task x GMX_FAST_STATES
   GmxPathNode *arena;        // per task x GMX_FAST_ARENA
   uint32_t *mapped_list;     // task ids with final states (bit 31 = big-pass slot index instead)
-  uint32_t *overflow_list;   // task ids to re-run with large capacities
+  uint32_t *overflow_list;   // task ids to re-run with large capacities (from the probe kernel); counter [1]
+  uint32_t *overflow2_list;  // the same from the extend kernel; counter [9]
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
   uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
   uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
@@ -514,7 +515,7 @@ __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
 //   done  : the whole read has been consumed (the emitted states are final, not parked)
 __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uint32_t task, FastCtx &ctx, uint32_t status,
-                                            bool done) {
+                                            bool done, bool second_phase) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
@@ -534,7 +535,8 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
     o.status[task] = status;
   block_append(o.mapped_list, &o.counters[0 * GMX_CNT_STRIDE], mapped, task);
-  block_append(o.overflow_list, &o.counters[1 * GMX_CNT_STRIDE], over, task);
+  // two overflow queues: the probe kernel's is served while the extend kernel still runs
+  block_append(second_phase ? o.overflow2_list : o.overflow_list, &o.counters[(second_phase ? 9 : 1) * GMX_CNT_STRIDE], over, task);
   block_append(o.alive_list, &o.counters[5 * GMX_CNT_STRIDE], alive, task);
   block_append(o.dead_list, &o.counters[6 * GMX_CNT_STRIDE], dead, task);
 }
@@ -602,7 +604,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     }
     status = ctx.status;
   }
-  finish_lane(o, active, task, ctx, status, done);
+  finish_lane(o, active, task, ctx, status, done, false);
 }
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   dfs_run_wave<1>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(o, active, task, ctx, status, true);
+  finish_lane(o, active, task, ctx, status, true, true);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -692,14 +694,18 @@ struct BigOut {
 
 // Large-capacity pass: one lane per task that overflowed the LDS stack / parked-state / arena limits, whole read
 // from the seed, same DFS loop with global-memory pools. Persistent over the device-side overflow list.
-__global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
-  uint32_t n_over = o.counters[1 * GMX_CNT_STRIDE];
+__global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, int second) {
+  // instance 0 serves the probe kernel's overflow queue, instance 1 the extend kernel's (slots after instance 0's)
+  const uint32_t n_over = o.counters[(second ? 9 : 1) * GMX_CNT_STRIDE];
+  const uint32_t slot_base = second ? o.counters[1 * GMX_CNT_STRIDE] : 0;
+  const uint32_t *queue = second ? o.overflow2_list : o.overflow_list;
   uint32_t rounds = (n_over + gridDim.x * 64 - 1) / (gridDim.x * 64);
   for (uint32_t rd = 0; rd < rounds; ++rd) {
     // interleaved: a short queue spreads over all waves (few active lanes each) instead of filling the first ones
-    uint32_t slot = rd * gridDim.x * 64 + threadIdx.x * gridDim.x + blockIdx.x;
-    bool active = slot < n_over;
-    uint32_t task = active ? o.overflow_list[slot] : 0;
+    const uint32_t qi = rd * gridDim.x * 64 + threadIdx.x * gridDim.x + blockIdx.x;
+    bool active = qi < n_over;
+    uint32_t task = active ? queue[qi] : 0;
+    const uint32_t slot = slot_base + qi;
     if (active && slot >= g.max_slots) {
       if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
       active = false;
@@ -1060,7 +1066,9 @@ struct gmx_engine {
   BigOut big{};
   uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
   uint32_t cover_blocks = 0, cover_big_lanes = 0, cover_side_blocks = 0;
-  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr, *d_cover_general = nullptr;
+  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr, *d_cover_general = nullptr, *d_overflow2 = nullptr;
+  hipStream_t side2_stream = nullptr;
+  hipEvent_t ev_fork2 = nullptr, ev_side1 = nullptr, ev_filter = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
@@ -1123,6 +1131,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_n_final, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_mapped, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_overflow2, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
@@ -1219,6 +1228,10 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
   rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
+  rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
+  rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;
+  rc |= hipEventCreateWithFlags(&e->ev_side1, hipEventDisableTiming) != hipSuccess;
+  rc |= hipEventCreateWithFlags(&e->ev_filter, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess;
   e->cover_big_lanes = 64 * 32;
@@ -1236,6 +1249,10 @@ void gmx_engine_destroy(gmx_engine *e) {
   (void)hipSetDevice(e->opts.device);
   (void)hipDeviceSynchronize();
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
+  if (e->side2_stream) (void)hipStreamDestroy(e->side2_stream);
+  if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
+  if (e->ev_side1) (void)hipEventDestroy(e->ev_side1);
+  if (e->ev_filter) (void)hipEventDestroy(e->ev_filter);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   for (void *p : e->allocs) (void)hipFree(p);
@@ -1283,13 +1300,13 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     }
   }
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
-  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_cover_overflow,
+  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 5 * GMX_CNT_STRIDE * 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 6 * GMX_CNT_STRIDE * 4, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -1306,27 +1323,39 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
   hipLaunchKernelGGL(gmx_probe_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
+  // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel
+  // on a side stream while the extend kernel runs
+  HIP_TRY(hipEventRecord(e->ev_fork, stream));
+  HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
+  HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   hipLaunchKernelGGL(gmx_extend_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
                e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes,
                e->d_scratch_side, e->cover_side_blocks * GMX_BLOCK, e->opts.rng_mode};
-  // fork: the few tasks of the large-capacity pass (one wave per CU, latency-bound) run beside filter + coverage
-  HIP_TRY(hipEventRecord(e->ev_fork, stream));
-  HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big);
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side_stream,
+  // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
+  // beside filter + coverage of the regular tasks
+  HIP_TRY(hipEventRecord(e->ev_fork2, stream));
+  HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
+  HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side2_stream,
                      e->dview, b, o, e->big, acc);
-  HIP_TRY(hipEventRecord(e->ev_join, e->side_stream));
+  HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
+  // the k-mer filter (LDS + ALU) runs beside the coverage kernels (memory + atomics) on the first side stream
+  HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
   if (e->filter_lds_words)
-    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4, stream,
-                       e->dview, b, o, e->filter_lds_words);
+    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
+                       e->side_stream, e->dview, b, o, e->filter_lds_words);
   else
-    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o);
+    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o);
+  HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
                      o, e->big, acc);
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+  HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
                      b, o, e->big, acc);
   hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK, 1024u)),
