@@ -159,6 +159,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint32_t status;
   GmxFinalState *out;
   uint32_t n_out, out_cap;
+  uint32_t first_pos; // PRG position of the first emitted text-form state (GMX_NIL if none): the task's coverage region
   bool parking;       // probe kernel: "emitted" states are parked for the extend kernel (GmxParked, same memory)
   uint32_t park_pos;  // read position of states parked by emit()
   __device__ __forceinline__ bool park(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
@@ -193,6 +194,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
     if (parking) return park(lo, hi, tvd, tvg, park_pos, GMX_MODE_STATE);
     if (n_out >= out_cap) return false;
+    if (n_out == 0 && hi == GMX_TEXT_MARK) first_pos = lo;
     out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
     return true;
   }
@@ -461,7 +463,9 @@ struct SearchOut {
   uint32_t *n_final;         // per task
   GmxFinalState *finals;     // per task x GMX_FAST_STATES
   GmxPathNode *arena;        // per task x GMX_FAST_ARENA
-  uint32_t *mapped_list;     // task ids with final states (bit 31 = big-pass slot index instead)
+  uint32_t *mapped_list;     // GMX_REGIONS lists x region_cap task ids with final states, by PRG region; counters [16 + r]
+  uint32_t region_cap;       // capacity of one region list
+  uint32_t region_inv;       // ceil(2^32 * GMX_REGIONS / n_prg): region = umulhi(position, region_inv)
   uint32_t *overflow_list;   // task ids to re-run with large capacities (from the probe kernel); counter [1]
   uint32_t *overflow2_list;  // the same from the extend kernel; counter [9]
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
@@ -494,6 +498,38 @@ __device__ __forceinline__ void block_append(uint32_t *list, uint32_t *counter, 
   __syncthreads();
   if (want) list[block_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
   __syncthreads();  // block_base / wave_cnt are reused by the next call
+}
+
+// The same into one of GMX_REGIONS lists (list r at `lists + r * cap`, its counter GMX_CNT_STRIDE words after
+// the previous one): one barrier pair and one atomic per region and block.
+#define GMX_REGIONS 8
+__device__ __forceinline__ void block_append_regions(uint32_t *lists, uint32_t cap, uint32_t *counters, bool want,
+                                                     uint32_t region, uint32_t value) {
+  __shared__ uint32_t cnt[GMX_BLOCK / 64][GMX_REGIONS];
+  __shared__ uint32_t base[GMX_REGIONS];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long mine = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < GMX_REGIONS; ++r) {
+    const unsigned long long m = __ballot(want && region == r);
+    if (lane == 0) cnt[wave][r] = (uint32_t)__popcll(m);
+    if (region == r) mine = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < GMX_REGIONS) {
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += cnt[w][threadIdx.x];
+    base[threadIdx.x] = total ? atomicAdd(&counters[threadIdx.x * GMX_CNT_STRIDE], total) : 0;
+  }
+  __syncthreads();
+  if (want) {
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) before += w < wave ? cnt[w][region] : 0;
+    lists[(size_t)region * cap + base[region] + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = value;
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
@@ -534,7 +570,12 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   }
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
     o.status[task] = status;
-  block_append(o.mapped_list, &o.counters[0 * GMX_CNT_STRIDE], mapped, task);
+  // mapped tasks are queued by the PRG region they map to: workgroup b of the coverage kernel serves region
+  // b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the graph tables and
+  // of the accumulators (they do not fit one 4 MiB L2 as a whole)
+  uint32_t region = task & (GMX_REGIONS - 1);
+  if (ctx.first_pos != GMX_NIL) region = min(__umulhi(ctx.first_pos, o.region_inv), (uint32_t)(GMX_REGIONS - 1));
+  block_append_regions(o.mapped_list, o.region_cap, &o.counters[16 * GMX_CNT_STRIDE], mapped, region, task);
   // two overflow queues: the probe kernel's is served while the extend kernel still runs
   block_append(second_phase ? o.overflow2_list : o.overflow_list, &o.counters[(second_phase ? 9 : 1) * GMX_CNT_STRIDE], over, task);
   block_append(o.alive_list, &o.counters[5 * GMX_CNT_STRIDE], alive, task);
@@ -561,6 +602,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
   ctx.parking = true;
   ctx.park_pos = 0;
+  ctx.first_pos = GMX_NIL;
   ReadRegs r;
   r.clear(b.packed);
   bool run = false;
@@ -626,6 +668,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.out_cap = GMX_FAST_STATES;
   ctx.parking = false;
   ctx.park_pos = 0;
+  ctx.first_pos = GMX_NIL;
   ReadRegs r;
   r.clear(b.packed);
   if (active) {
@@ -866,10 +909,11 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
 // final state of width one on a non-nested PRG. Few registers, so many more waves are in flight to hide the
 // dependent look-ups (state -> node -> walk -> atomics). Everything else is queued for the general instance.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
-  const uint32_t n_mapped = o.counters[0 * GMX_CNT_STRIDE];
-  const uint32_t m = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
+  const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
+  const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
   if (m >= n_mapped) return;
-  const uint32_t task = o.mapped_list[m];
+  const uint32_t task = o.mapped_list[(size_t)region * o.region_cap + m];
   const uint32_t nf = o.n_final[task] & 0xFF;
   const GmxFinalState st = o.finals[(size_t)task * GMX_FAST_STATES];
   if (nf != 1 || ix.is_nested || !(st.lo == st.hi || gmx_text_form(st.hi))) {
@@ -1129,7 +1173,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_skip, cap, true))) return rc;
   if ((rc = e->alloc(&e->d_status, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_n_final, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_mapped, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_mapped, n_tasks * GMX_REGIONS, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow2, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
@@ -1199,7 +1243,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
   rc |= e->alloc(&e->d_log_cursor, 4, true);
-  rc |= e->alloc(&e->d_counters, 16 * GMX_CNT_STRIDE, true);
+  rc |= e->alloc(&e->d_counters, 32 * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
@@ -1267,7 +1311,7 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
   HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
   HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
-  HIP_TRY(hipMemset(e->d_counters, 0, 16 * GMX_CNT_STRIDE * 4));
+  HIP_TRY(hipMemset(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4));
   return GMX_OK;
 }
 
@@ -1300,13 +1344,14 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     }
   }
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
-  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
+  const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
+  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead,    e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 6 * GMX_CNT_STRIDE * 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 28 * GMX_CNT_STRIDE * 4, stream));
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -1351,7 +1396,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   else
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
-  hipLaunchKernelGGL(gmx_cover_single_kernel, task_grid, dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
                      o, e->big, acc);
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
