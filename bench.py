@@ -8,7 +8,13 @@ coverage atomics, forward and reverse complement) over the rank's 1 M reads, whi
 before the timed region starts; for N > 1 every step ends with the RCCL all-reduce of the coverage arrays.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel (gmx_extend_kernel): algorithmic bytes per launch / HIP-event duration
+  roofline     gmx_extend_kernel (the per-base extension of the mapping orientation, the kernel SURVEY.md §8(d)'s
+               algorithmic-byte figure describes): nominal algorithmic bytes per launch / HIP-event duration measured
+               inside the library on the launch stream. `frac` exceeds 1 by design: the figure prices one 128-byte
+               rank block per base, the kernel compares 32 bases per 16-byte PRG record once a state has narrowed to
+               one suffix-array position. `traffic` = HBM-side bytes per launch of that kernel from
+               the committed rocprofv3 --pmc passes (profiles/round1/hbm_traffic.json), `design_*` = what the kernel
+               itself has to move per read.
   cpu_baseline the oracle (CPU restatement of the reference algorithm, "port") on a bounded read sample
 """
 import argparse
@@ -31,6 +37,20 @@ B_ALG_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070
 PROBE_STEPS = 6                                        # bases done by gmx_probe_kernel, not by the dominant kernel
 B_ALG_DOMINANT = 128 * (READ_LEN - KMER - PROBE_STEPS) + READ_LEN  # what gmx_extend_kernel itself is credited with
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# bytes gmx_extend_kernel itself moves per mapped read: parked entry 20 + packed read 48 + PRG records
+# ~6 x 16 + marker sub-records ~3 x 16 + final state 16 + path nodes 2 x 12 + queue/status words 16
+B_DESIGN_PER_READ = 20 + 48 + 6 * 16 + 3 * 16 + 16 + 2 * 12 + 16
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round1", "hbm_traffic.json")
+
+
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; tools/pmc_hbm.sh)."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            k = json.load(fh)[kernel]
+        return int(k["fetch_bytes"] + k["write_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(prg, reads, seeds, max_seconds=20.0):
@@ -142,10 +162,14 @@ def main():
                        "index replicated, one RCCL all-reduce of coverage per step",
                        "index_build_s": round(t_index, 2), "index_bytes": int(ix.info.index_bytes)},
             "roofline": {"bound": "hbm", "kernel": "gmx_extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("gmx_extend_kernel"),
+                         "traffic_source": "profiles/round1/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
                          "alg_bytes_per_read": B_ALG_DOMINANT, "alg_bytes_per_read_whole_path": B_ALG_PER_READ, "reads_per_launch": reads_per_launch,
                          "avg_launch_ms": search_s * 1e3,
-                         "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1)},
+                         "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
+                         "design_bytes_per_read": B_DESIGN_PER_READ,
+                         "design_achieved": B_DESIGN_PER_READ * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0,
+                         "note": "frac > 1: the nominal figure prices a 128 B rank block per base; text-form states read 16 B per 32 bases"},
             "stats_last_step": st,
         }
         if not args.no_cpu_baseline:

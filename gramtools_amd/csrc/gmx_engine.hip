@@ -1,22 +1,21 @@
 // gmx_engine.hip — HIP kernels (gfx950) and the device half of the C ABI.
 //
-// Execution model: one LANE per (read, orientation) task — 64
-// independent vBWT backward searches per wavefront. Every lane owns a small pool
-// of search states in LDS (lane-strided, bank-conflict free) and walks its read
-// right to left; each step fetches ONE 64-byte rank block per live state (two
-// when the interval straddles blocks), does the marker scan and the LF step from
-// the same line, and appends the rare marker fan-out states through a
-// pre-resolved jump program. Final states are handed to a second kernel that does
-// the seeded class selection and the coverage atomics.
+// Execution model: one LANE per (read, orientation) task — 64 independent vBWT backward
+// searches per wavefront. A lane carries one search state in registers and keeps the others on a small LIFO
+// stack in LDS (gmx_dfs.h). A state that has narrowed to ONE suffix-array position is kept in text form and
+// compares 32 read bases per step against a 16-byte record of the PRG itself; wide intervals use 64-byte rank
+// blocks; a variant marker costs one 16-byte sub-record of its pre-resolved hit record. Final states go to
+// the coverage kernels (gmx_cover.h): class selection with the seeded draw, then the coverage atomics.
 //
-// Kernels:
-//   gmx_pack_kernel      flags reads with a non-ACGT byte (encode_dna_bases, utils.cpp:73-92) and packs bases to 2 bits
-//   gmx_probe_kernel     seed lookup + first GMX_PROBE_STEPS bases of search_read_backwards (quasimap.cpp:227-256)
-//   gmx_extend_kernel    the rest of the read for the compacted survivors (the dominant kernel)
-//   gmx_filter_kernel    all_read_kmers_occur_in_index for tasks without final state (quasimap.cpp:212-225)
-//   gmx_search_big_kernel  the same for reads that overflowed the LDS pools (global-memory pools)
-//   gmx_cover_kernel     coverage::record::search_states (coverage_common.cpp:179-197)
-//   gmx_stats_kernel     QuasimapReadsStats counters (quasimap.hpp:17-24)
+// Kernels (launch order):
+//   gmx_pack_kernel          flags reads with a non-ACGT byte (encode_dna_bases, utils.cpp:73-92), packs bases to bit planes
+//   gmx_probe_kernel         seed look-up + the first steps of search_read_backwards (quasimap.cpp:227-256); survivors are parked
+//   gmx_extend_kernel        the rest of the read for the compacted survivors
+//   gmx_search_big_kernel    the same search for tasks that overflowed the per-lane pools (global-memory pools; side streams)
+//   gmx_filter[_lds]_kernel  all_read_kmers_occur_in_index for tasks without final state (quasimap.cpp:212-225)
+//   gmx_cover_single_kernel  coverage::record::search_states (coverage_common.cpp:179-197) for single-instance tasks
+//   gmx_cover_kernel         the same in general (classes, seeded selection, hull), two scratch sizes
+//   gmx_stats_kernel         QuasimapReadsStats counters (quasimap.hpp:17-24)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
