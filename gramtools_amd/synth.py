@@ -202,3 +202,71 @@ def simulate_graph_reads(prg_ints, n_reads: int, read_len: int, seed: int, rc_pr
             r = (5 - r)[::-1]
         reads.append(np.ascontiguousarray(r))
     return reads
+
+
+def mixed_variant_prg(ref: np.ndarray, n_sites: int, seed: int, max_alleles: int = 7, max_len: int = 6,
+                      adjacent_prob: float = 0.05):
+    """A flat (non-nested) PRG with SNPs, indels (alleles of 0..max_len bases, pure deletions included), multi-allelic
+    sites (up to `max_alleles`, so both the dense grouped slots and the append log are used) and some adjacent sites.
+
+    Returns (prg_ints uint32, sites) with sites = [(ref_start, ref_len, [allele arrays, allele 0 = reference])]."""
+    rng = np.random.default_rng(seed)
+    G = int(ref.size)
+    sites = []
+    p = int(rng.integers(1, 20))
+    while len(sites) < n_sites and p + max_len + 2 < G:
+        ref_len = int(rng.integers(1, max_len + 1)) if rng.random() < 0.3 else 1
+        n_all = 2 if rng.random() < 0.8 else int(rng.integers(3, max_alleles + 1))
+        alleles = [ref[p:p + ref_len].copy()]
+        seen = {alleles[0].tobytes()}
+        tries = 0
+        while len(alleles) < n_all and tries < 50:
+            tries += 1
+            if ref_len == 1 and rng.random() < 0.7:
+                a = rng.integers(1, 5, size=1, dtype=np.uint8)
+            else:
+                a = rng.integers(1, 5, size=int(rng.integers(0, max_len + 1)), dtype=np.uint8)
+            if a.tobytes() in seen:
+                continue
+            seen.add(a.tobytes())
+            alleles.append(a)
+        sites.append((p, ref_len, alleles))
+        gap = 0 if rng.random() < adjacent_prob else int(rng.integers(1, max(2, 2 * (G // max(n_sites, 1)))))
+        p += ref_len + gap
+    out = []
+    cur = 0
+    for i, (start, ref_len, alleles) in enumerate(sites):
+        out.extend(int(x) for x in ref[cur:start])
+        m = 5 + 2 * i
+        out.append(m)
+        for a in alleles:
+            out.extend(int(x) for x in a)
+            out.append(m + 1)
+        cur = start + ref_len
+    out.extend(int(x) for x in ref[cur:])
+    return np.asarray(out, dtype=np.uint32), sites
+
+
+def simulate_haplotype_reads(ref: np.ndarray, sites, n_reads: int, len_lo: int, len_hi: int, seed: int, n_haps: int = 16,
+                             rc_prob: float = 0.5):
+    """Error-free reads of ragged lengths in [len_lo, len_hi] from `n_haps` random haplotypes of a mixed_variant_prg."""
+    rng = np.random.default_rng(seed)
+    haps = []
+    for _ in range(n_haps):
+        parts, cur = [], 0
+        for start, ref_len, alleles in sites:
+            parts.append(ref[cur:start])
+            parts.append(alleles[int(rng.integers(0, len(alleles)))])
+            cur = start + ref_len
+        parts.append(ref[cur:])
+        haps.append(np.concatenate(parts).astype(np.uint8))
+    reads = []
+    for _ in range(n_reads):
+        h = haps[int(rng.integers(0, n_haps))]
+        L = int(min(rng.integers(len_lo, len_hi + 1), h.size))
+        st = int(rng.integers(0, h.size - L + 1))
+        r = h[st:st + L].copy()
+        if rng.random() < rc_prob:
+            r = (5 - r[::-1]).astype(np.uint8)
+        reads.append(r)
+    return reads
