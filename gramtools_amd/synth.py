@@ -4,7 +4,10 @@ No real genomes are available offline, so every workload is generated here with 
   * :func:`snp_prg`        random reference + SNP sites written as ``... 5 ref 6 alt 6 ...`` (the `normal`
                            mode of gramtools/commands/build/vcf_to_prg_string.py:81-101)
   * :func:`nested_prg`     small random bracket PRGs with nesting, empty alleles and adjacent sites
-  * :func:`simulate_snp_reads` / :func:`simulate_graph_reads`   error-free reads from random haplotypes
+  * :func:`mixed_variant_prg` flat PRG with SNPs, indels, multi-allelic and adjacent sites
+  * :func:`nested_regions_prg`  random sequence interleaved with nested bracket regions (the configs[2] recipe in small)
+  * :func:`simulate_snp_reads` / :func:`simulate_graph_reads` / :func:`simulate_haplotype_reads`
+                           error-free reads from random haplotypes
 """
 import numpy as np
 
@@ -152,11 +155,11 @@ def bracket_to_ints(s: str):
     return np.asarray(out, dtype=np.uint32)
 
 
-def simulate_graph_reads(prg_ints, n_reads: int, read_len: int, seed: int, rc_prob: float = 0.5):
+def simulate_graph_reads(prg_ints, n_reads: int, read_len: int, seed: int, rc_prob: float = 0.5, n_haps: int = 0):
     """Reads from random walks through an arbitrary (nested) PRG. Pure-Python: small cases only.
 
     A walk expands the PRG into one haplotype by picking a random allele at every site, then reads are
-    substrings of haplotypes (a fresh haplotype per read)."""
+    substrings of haplotypes (a fresh haplotype per read, or one of `n_haps` pre-drawn haplotypes)."""
     rng = np.random.default_rng(seed)
     prg = [int(x) for x in prg_ints]
     n = len(prg)
@@ -192,9 +195,17 @@ def simulate_graph_reads(prg_ints, n_reads: int, read_len: int, seed: int, rc_pr
                 i = close + 1
 
     reads = []
-    for _ in range(n_reads):
+    pool = []
+    for _ in range(n_haps):
         hap = []
         expand(0, n, hap)
+        pool.append(hap)
+    for _ in range(n_reads):
+        if pool:
+            hap = pool[int(rng.integers(0, len(pool)))]
+        else:
+            hap = []
+            expand(0, n, hap)
         L = min(read_len, len(hap))
         st = int(rng.integers(0, len(hap) - L + 1))
         r = np.asarray(hap[st:st + L], dtype=np.uint8)
@@ -270,3 +281,17 @@ def simulate_haplotype_reads(ref: np.ndarray, sites, n_reads: int, len_lo: int, 
             r = (5 - r[::-1]).astype(np.uint8)
         reads.append(r)
     return reads
+
+
+def nested_regions_prg(n_regions: int, seed: int, spacer_lo: int = 30, spacer_hi: int = 200):
+    """Random sequence interleaved with `n_regions` nested bracket regions (depth <= 3, empty alleles, adjacent sites):
+    BASELINE.json configs[2]'s "MSA regions" in small. Returns prg_ints (site markers renumbered 5, 7, 9, ...)."""
+    rng = np.random.default_rng(seed)
+    letters = "acgt"
+    parts = []
+    for r in range(n_regions):
+        parts.append("".join(letters[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(spacer_lo, spacer_hi)))))
+        parts.append(nested_prg(seed * 1000 + r, n_top=int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 4)),
+                                seq_max=int(rng.integers(2, 8))))
+    parts.append("".join(letters[int(x)] for x in rng.integers(0, 4, size=spacer_hi)))
+    return bracket_to_ints("".join(parts))

@@ -1,0 +1,44 @@
+"""Nested PRGs at a size where the text-form steps, the general jump programs, parking and the tiers all take part:
+random sequence interleaved with 60-150 nested bracket regions (depth <= 3, empty alleles, adjacent sites), 100-200 bp
+reads from pre-drawn haplotypes, both orientations. Host emulation (not gpu) and the HIP path (gpu) against the
+oracle, bit-exact. Nested PRGs never take the single-instance coverage kernel."""
+import numpy as np
+import pytest
+
+from gramtools_amd import Index, Quasimapper
+from gramtools_amd.synth import nested_regions_prg, simulate_graph_reads
+
+from common import canonical_cov, flatten_reads, hostemu_map, oracle_map
+
+
+def _case(seed, n_regions, n_reads):
+    prg = nested_regions_prg(n_regions, seed)
+    rng = np.random.default_rng(seed)
+    L = int(rng.integers(100, 201))
+    reads = simulate_graph_reads(prg, n_reads, L, seed + 1, n_haps=12)
+    k = int(rng.integers(5, 11))
+    reads = [r for r in reads if len(r) >= k]
+    seeds = (np.arange(len(reads), dtype=np.uint64) * 104729 + seed).astype(np.uint32)
+    return prg, k, reads, seeds
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_host_emulation_matches_oracle(seed):
+    prg, k, reads, seeds = _case(seed, 60, 300)
+    want = oracle_map(prg, k, reads, seeds, rng_mode=seed % 2, threads=4)
+    got, _, rc = hostemu_map(prg, k, reads, seeds, rng_mode=seed % 2)
+    assert rc == 0
+    assert got == want
+    assert want["stats"]["exact_mapped"] >= 250
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_gpu_matches_oracle(seed):
+    prg, k, reads, seeds = _case(10 + seed, 150, 3000)
+    want = oracle_map(prg, k, reads, seeds, rng_mode=seed % 2, threads=8)
+    qm = Quasimapper(Index(prg, k), rng_mode=seed % 2)
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    assert want["stats"]["exact_mapped"] >= 2500
