@@ -275,6 +275,32 @@ __device__ __forceinline__ uint32_t kmer_code(Reader &r, uint32_t start, uint32_
   return code;
 }
 
+// k-mer code of the read's LAST k oriented bases (the seed, quasimap.cpp:235-241) from one 32-base window of the
+// bit planes instead of k single-base extractions: forward reads reverse the bit order (leftmost base most
+// significant), reverse-complement reads take the first k raw bases complemented (their order is already reversed).
+__device__ __forceinline__ uint32_t spread_even(uint32_t x) {  // bit i -> bit 2i (i < 16)
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+template <class Reader>
+__device__ __forceinline__ uint32_t last_kmer_code(Reader &r, uint32_t k) {
+  uint32_t lo, hi;
+  const uint32_t mask = (1u << k) - 1u;  // k <= 15
+  if (r.rc) {
+    r.planes(0, lo, hi);
+    lo = ~lo & mask;
+    hi = ~hi & mask;
+  } else {
+    r.planes(r.len - k, lo, hi);
+    lo = __builtin_bitreverse32(lo) >> (32u - k);
+    hi = __builtin_bitreverse32(hi) >> (32u - k);
+  }
+  return spread_even(lo) | (spread_even(hi) << 1);
+}
+
 // all_read_kmers_occur_in_index (quasimap.cpp:212-225); `bitmap` is the presence bitmap in global memory or LDS
 __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r) {
   const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
@@ -569,16 +595,44 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   }
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
     o.status[task] = status;
-  // mapped tasks are queued by the PRG region they map to: workgroup b of the coverage kernel serves region
-  // b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the graph tables and
-  // of the accumulators (they do not fit one 4 MiB L2 as a whole)
+  // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
+  // queue and block). Mapped tasks are queued by the PRG region they map to: workgroup b of the coverage kernel
+  // serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the graph
+  // tables and of the accumulators (they do not fit one 4 MiB L2 as a whole). The probe kernel's
+  // overflow queue is separate from the extend kernel's: it is served while the extend kernel still runs.
   uint32_t region = task & (GMX_REGIONS - 1);
   if (ctx.first_pos != GMX_NIL) region = min(__umulhi(ctx.first_pos, o.region_inv), (uint32_t)(GMX_REGIONS - 1));
-  block_append_regions(o.mapped_list, o.region_cap, &o.counters[16 * GMX_CNT_STRIDE], mapped, region, task);
-  // two overflow queues: the probe kernel's is served while the extend kernel still runs
-  block_append(second_phase ? o.overflow2_list : o.overflow_list, &o.counters[(second_phase ? 9 : 1) * GMX_CNT_STRIDE], over, task);
-  block_append(o.alive_list, &o.counters[5 * GMX_CNT_STRIDE], alive, task);
-  block_append(o.dead_list, &o.counters[6 * GMX_CNT_STRIDE], dead, task);
+  const uint32_t cat = mapped ? region : over ? GMX_REGIONS : alive ? GMX_REGIONS + 1 : dead ? GMX_REGIONS + 2 : 0xFFu;
+  __shared__ uint32_t q_cnt[GMX_BLOCK / 64][GMX_REGIONS + 3];
+  __shared__ uint32_t q_base[GMX_REGIONS + 3];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long mine = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < GMX_REGIONS + 3; ++c) {
+    const unsigned long long m = __ballot(cat == c);
+    if (lane == 0) q_cnt[wave][c] = (uint32_t)__popcll(m);
+    if (cat == c) mine = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < GMX_REGIONS + 3) {
+    const uint32_t c = threadIdx.x;
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
+    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == GMX_REGIONS ? (second_phase ? 9u : 1u) : c == GMX_REGIONS + 1 ? 5u : 6u;
+    q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
+  }
+  __syncthreads();
+  if (cat != 0xFFu) {
+    uint32_t before = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) before += w < wave ? q_cnt[w][cat] : 0;
+    uint32_t *list = cat < GMX_REGIONS          ? o.mapped_list + (size_t)cat * o.region_cap
+                     : cat == GMX_REGIONS       ? (second_phase ? o.overflow2_list : o.overflow_list)
+                     : cat == GMX_REGIONS + 1   ? o.alive_list
+                                                : o.dead_list;
+    list[q_base[cat] + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = task;
+  }
 }
 
 #define GMX_PROBE_ITERS 10  // default iteration budget of the probe kernel (GMX_PROBE_ITERS in the environment overrides)
@@ -614,7 +668,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       const uint32_t k = ix.kmer_size;
       const uint32_t from = r.len - k;
       const uint32_t stop = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
-      load_seed(ix, kmer_code(r, from, k), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+      load_seed(ix, last_kmer_code(r, k), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
         return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
       });
       run = ctx.status == GMX_TASK_MAPPED;
