@@ -112,15 +112,15 @@ def main():
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
     d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(torch.int32).cuda()
     stream = torch.cuda.current_stream().cuda_stream
-    from gramtools_amd.distributed import device_coverage_tensors
-    cov_t = device_coverage_tensors(qm) if world > 1 else []
+    from gramtools_amd.distributed import allreduce_device_coverage, fused_coverage_tensor
+    cov_t = fused_coverage_tensor(qm) if world > 1 else None
 
     def step():
         # a step is a whole job: zeroed accumulators -> map the rank's reads -> one sum-exchange of the coverage
         qm.reset(stream=stream)
         qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
-        for t in cov_t:                                   # single exchange: sum of the coverage arrays
-            dist.all_reduce(t)
+        if cov_t is not None:                             # THE exchange: one all-reduce of the fused coverage block
+            allreduce_device_coverage(qm, dist, cov_t, stream)
 
     def fence():
         qm.sync()

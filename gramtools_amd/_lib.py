@@ -41,7 +41,7 @@ class DepthStats(C.Structure):
 class DeviceCoverage(C.Structure):
     _fields_ = [("allele_sum", C.c_void_p), ("n_allele_sum", C.c_uint64), ("per_base", C.c_void_p),
                 ("n_per_base", C.c_uint64), ("grouped", C.c_void_p), ("n_grouped", C.c_uint64),
-                ("stats", C.c_void_p), ("n_stats", C.c_uint64)]
+                ("stats", C.c_void_p), ("n_stats", C.c_uint64), ("fused", C.c_void_p), ("n_fused", C.c_uint64)]
 
 
 # every symbol include/gmx.h declares: (restype, argtypes)
@@ -78,6 +78,8 @@ SYMBOLS = {
     "gmx_engine_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "gmx_master_seeds": (C.c_int, [_u32, _u64p, _u64, _u32p]),
     "gmx_coverage_device": (C.c_int, [_vp, C.POINTER(DeviceCoverage)]),
+    "gmx_coverage_reduce_begin": (C.c_int, [_vp, _vp]),
+    "gmx_coverage_reduce_end": (C.c_int, [_vp, _vp]),
     "gmx_coverage_fetch": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
     "gmx_coverage_fetch_grouped_log": (_i64, [_vp, _u32p, _u64]),
     "gmx_finalize_u16": (None, [_u32p, _u64, C.c_int]),

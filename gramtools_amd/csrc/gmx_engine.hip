@@ -1025,6 +1025,20 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
 }
 
+// The five uint64 read counters <-> 16-bit limbs in uint32 words, so that they travel inside the one uint32
+// all-reduce(sum) of the coverage block: limb sums of up to 65536 ranks cannot overflow (gmx_coverage_reduce_*).
+__global__ void gmx_stats_limbs_kernel(unsigned long long *stats, uint32_t *limbs, int recombine) {
+  const uint32_t t = threadIdx.x;
+  if (!recombine) {
+    if (t < 20) limbs[t] = (uint32_t)((stats[t >> 2] >> (16 * (t & 3))) & 0xFFFFull);
+    else if (t < 32) limbs[t] = 0;
+  } else if (t < 5) {
+    unsigned long long v = 0;
+    for (int l = 3; l >= 0; --l) v = (v << 16) + limbs[4 * t + l];  // limb sums carry into the limbs above
+    stats[t] = v;
+  }
+}
+
 // Validation + packing, one lane per read. Reads holding a byte outside 1..4 are skipped as a whole
 // (encode_dna_bases, utils.cpp:73-92). The packed form is two bit planes per 32 bases (uint2: low bits, high
 // bits of the codes 0..3): the search kernels compare 32 bases per step against the PRG's planes (GmxTextRec),
@@ -1146,7 +1160,9 @@ struct gmx_engine {
   std::vector<void *> allocs;
   uint64_t index_bytes = 0;
   // accumulators
-  uint32_t *d_allele_sum = nullptr, *d_per_base = nullptr, *d_grouped = nullptr;
+  uint32_t *d_allele_sum = nullptr, *d_per_base = nullptr, *d_grouped = nullptr;  // views into d_fused
+  uint32_t *d_fused = nullptr, *d_limbs = nullptr;
+  size_t n_fused = 0;
   unsigned long long *d_stats = nullptr;
   uint32_t *d_log = nullptr, *d_log_cursor = nullptr;
   uint32_t log_cap = 0;
@@ -1289,9 +1305,16 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->n_allele = h.n_allele_slots;
   e->n_pb = h.n_pb_slots;
   e->n_grouped = h.n_grouped_slots;
-  rc |= e->alloc(&e->d_allele_sum, e->n_allele, true);
-  rc |= e->alloc(&e->d_per_base, e->n_pb, true);
-  rc |= e->alloc(&e->d_grouped, e->n_grouped, true);
+  {  // one contiguous block: a single all-reduce covers the whole coverage (gmx_coverage_device)
+    auto pad = [](size_t n) { return (n + 63) / 64 * 64; };
+    const size_t o_pb = pad(e->n_allele), o_grp = o_pb + pad(e->n_pb), o_limbs = o_grp + pad(e->n_grouped);
+    e->n_fused = o_limbs + 32;
+    rc |= e->alloc(&e->d_fused, e->n_fused, true);
+    e->d_allele_sum = e->d_fused;
+    e->d_per_base = e->d_fused ? e->d_fused + o_pb : nullptr;
+    e->d_grouped = e->d_fused ? e->d_fused + o_grp : nullptr;
+    e->d_limbs = e->d_fused ? e->d_fused + o_limbs : nullptr;
+  }
   rc |= e->alloc(&e->d_stats, 8, true);
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
@@ -1359,9 +1382,7 @@ void gmx_engine_destroy(gmx_engine *e) {
 int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(e->d_allele_sum, 0, std::max<size_t>(e->n_allele, 1) * 4));
-  HIP_TRY(hipMemset(e->d_per_base, 0, std::max<size_t>(e->n_pb, 1) * 4));
-  HIP_TRY(hipMemset(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4));
+  HIP_TRY(hipMemset(e->d_fused, 0, e->n_fused * 4));
   HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
   HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
   HIP_TRY(hipMemset(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4));
@@ -1371,9 +1392,7 @@ int gmx_engine_reset(gmx_engine *e) {
 int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   HIP_TRY(hipSetDevice(e->opts.device));
   hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(hipMemsetAsync(e->d_allele_sum, 0, std::max<size_t>(e->n_allele, 1) * 4, st));
-  HIP_TRY(hipMemsetAsync(e->d_per_base, 0, std::max<size_t>(e->n_pb, 1) * 4, st));
-  HIP_TRY(hipMemsetAsync(e->d_grouped, 0, std::max<size_t>(e->n_grouped, 1) * 4, st));
+  HIP_TRY(hipMemsetAsync(e->d_fused, 0, e->n_fused * 4, st));
   HIP_TRY(hipMemsetAsync(e->d_stats, 0, 8 * 8, st));
   HIP_TRY(hipMemsetAsync(e->d_log_cursor, 0, 16, st));
   return GMX_OK;
@@ -1602,6 +1621,22 @@ int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
   out->n_grouped = e->n_grouped;
   out->stats = e->d_stats;
   out->n_stats = 5;
+  out->fused = e->d_fused;
+  out->n_fused = e->n_fused;
+  return GMX_OK;
+}
+
+int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 0);
+  HIP_TRY(hipGetLastError());
+  return GMX_OK;
+}
+
+int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 1);
+  HIP_TRY(hipGetLastError());
   return GMX_OK;
 }
 

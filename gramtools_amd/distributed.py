@@ -92,8 +92,7 @@ class _DevArray:
 
 def device_coverage_tensors(qm):
     """torch tensors ALIASING the engine's device accumulators (allele_sum, per_base, grouped as int32 views of
-    the uint32 totals; stats as int64). An in-place ``dist.all_reduce`` on them is the single exchange of the
-    multi-GPU path: afterwards every rank's engine holds the job-wide totals and ``qm.coverage()`` finalises them."""
+    the uint32 totals; stats as int64). Kept for inspection; the exchange itself uses :func:`fused_coverage_tensor`."""
     import torch
     dc = qm.device_coverage()
     out = []
@@ -104,7 +103,17 @@ def device_coverage_tensors(qm):
     return out
 
 
-def allreduce_device_coverage(qm, dist):
-    """One RCCL all-reduce(sum) per flat coverage array, in place on the engine's accumulators."""
-    for t in device_coverage_tensors(qm):
-        dist.all_reduce(t)
+def fused_coverage_tensor(qm):
+    """One int32 tensor aliasing the engine's whole coverage block (allele_sum | per_base | grouped | counter limbs)."""
+    import torch
+    dc = qm.device_coverage()
+    return torch.as_tensor(_DevArray(dc.fused, dc.n_fused, "<i4"), device="cuda")
+
+
+def allreduce_device_coverage(qm, dist, tensor=None, stream=None):
+    """THE exchange of the multi-GPU path: one RCCL all-reduce(sum), in place on the engine's coverage block
+    (uint32 totals wrap exactly like int32 sums; the uint64 read counters travel as 16-bit limbs)."""
+    t = fused_coverage_tensor(qm) if tensor is None else tensor
+    qm.reduce_begin(stream)
+    dist.all_reduce(t)
+    qm.reduce_end(stream)

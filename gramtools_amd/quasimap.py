@@ -353,6 +353,14 @@ class Quasimapper:
         check(self.lib.gmx_coverage_device(self.h, C.byref(dc)))
         return dc
 
+    def reduce_begin(self, stream=None):
+        """Before the all-reduce of the fused block: read counters -> 16-bit limbs inside it."""
+        check(self.lib.gmx_coverage_reduce_begin(self.h, C.c_void_p(stream) if stream else None))
+
+    def reduce_end(self, stream=None):
+        """After the all-reduce: limb sums -> read counters."""
+        check(self.lib.gmx_coverage_reduce_end(self.h, C.c_void_p(stream) if stream else None))
+
     def coverage(self) -> Coverage:
         info = self.index.info
         a = np.zeros(max(info.n_allele_slots, 1), dtype=np.uint32)

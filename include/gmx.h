@@ -152,15 +152,22 @@ typedef struct gmx_stats { /* QuasimapReadsStats, quasimap.hpp:17-24 */
   uint64_t exact_mapped_reads_count;
 } gmx_stats;
 
-/* Device pointers of the uint32 accumulators, for an RCCL all-reduce(sum) by the caller
- * (one collective per array; then gmx_coverage_fetch on every rank or on rank 0). */
+/* Device pointers of the accumulators, for the RCCL all-reduce(sum) by the caller (reads shard,
+ * the index is replicated, ONE exchange at the end; then gmx_coverage_fetch on every rank or on rank 0).
+ * `fused` is one contiguous uint32 block holding allele_sum | per_base | grouped (each padded to 256 B) followed
+ * by 32 words for the five uint64 read counters as 16-bit limbs: a single all-reduce(sum) of `n_fused` uint32
+ * between gmx_coverage_reduce_begin (counters -> limbs) and gmx_coverage_reduce_end (limb sums -> counters)
+ * is the whole exchange, exact for up to 65536 ranks. The per-array pointers alias the same memory. */
 typedef struct gmx_device_coverage {
   void *allele_sum;  uint64_t n_allele_sum;
   void *per_base;    uint64_t n_per_base;
   void *grouped;     uint64_t n_grouped;
   void *stats;       uint64_t n_stats;      /* 5 x uint64 */
+  void *fused;       uint64_t n_fused;      /* uint32 words */
 } gmx_device_coverage;
 int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out);
+int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream);
+int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream);
 
 /* Copies the raw uint32 totals to the host (any pointer may be NULL). The reference's uint16 semantics are
  * functions of these totals: allele-sum and grouped counts wrap (mod 65536, data_types.hpp:52), per-base

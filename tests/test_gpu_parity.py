@@ -215,3 +215,16 @@ def test_device_accumulators_alias_as_torch_tensors_and_allreduce_in_place():
     ts[0].add_(1)  # aliasing, not a copy: a write through the tensor is seen by the engine
     torch.cuda.synchronize()
     assert (qm.coverage().raw_allele_sum == before.raw_allele_sum + 1).all()
+    ts[0].sub_(1)
+    # what three ranks with identical totals would leave after the exchange: every word of the fused block tripled
+    from gramtools_amd.distributed import fused_coverage_tensor
+    fused = fused_coverage_tensor(qm)
+    qm.reduce_begin()
+    fused.mul_(3)
+    qm.reduce_end()
+    torch.cuda.synchronize()
+    tripled = qm.coverage()
+    assert (tripled.raw_allele_sum == 3 * before.raw_allele_sum).all()
+    assert (tripled.raw_per_base == 3 * before.raw_per_base).all()
+    assert (tripled.raw_grouped == 3 * before.raw_grouped).all()
+    assert tripled.stats.as_dict() == {k: 3 * v for k, v in before.stats.as_dict().items()}
