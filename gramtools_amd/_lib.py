@@ -28,6 +28,11 @@ class Stats(C.Structure):
                 ("exact_mapped_reads_count", C.c_uint64)]
 
 
+class QueueCounts(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("mapped", "alive", "dead", "overflow_probe", "overflow_extend", "big_mapped",
+                                          "cover_general", "cover_overflow", "seed_cursor")]
+
+
 class Timing(C.Structure):
     _fields_ = [("search_ms", C.c_double), ("search_launches", C.c_uint64), ("cover_ms", C.c_double),
                 ("cover_launches", C.c_uint64), ("reads", C.c_uint64)]
@@ -76,6 +81,7 @@ SYMBOLS = {
     "gmx_engine_sync": (C.c_int, [_vp]),
     "gmx_engine_enable_timing": (C.c_int, [_vp, C.c_int]),
     "gmx_engine_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
+    "gmx_engine_queue_counts": (C.c_int, [_vp, C.POINTER(QueueCounts)]),
     "gmx_master_seeds": (C.c_int, [_u32, _u64p, _u64, _u32p]),
     "gmx_coverage_device": (C.c_int, [_vp, C.POINTER(DeviceCoverage)]),
     "gmx_coverage_reduce_begin": (C.c_int, [_vp, _vp]),

@@ -161,6 +161,45 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint32_t first_pos; // PRG position of the first emitted text-form state (GMX_NIL if none): the task's coverage region
   bool parking;       // probe kernel: "emitted" states are parked for the extend kernel (GmxParked, same memory)
   uint32_t park_pos;  // read position of states parked by emit()
+  // Seed cursor: the states of a multi-state k-mer index entry are taken ONE AT A TIME from the index (seed_words)
+  // whenever the stack runs empty, instead of being pushed all at once — a k-mer of a large or dense PRG has tens of
+  // states, far more than the stack holds. Path nodes of a seed state whose descendants all died are released.
+  uint32_t seed_left;               // states of the k-mer index entry not started yet
+  uint32_t seed_off, seed_pos;      // word offset of the next one in seed_words; read position of the seed states
+  uint32_t mark_arena, mark_out;    // arena / emitted-state counts when the current seed state started
+  __device__ __forceinline__ bool more_seeds() const { return seed_left != 0 && status == GMX_TASK_MAPPED; }
+  __device__ __forceinline__ bool next_seed(const GmxIndexView &ix, bool release, uint32_t &a, uint32_t &b, uint32_t &tvd,
+                                            uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    // nothing emitted since the previous seed state started: all its descendants died, its path nodes are garbage
+    if (release && n_out == mark_out) arena_n = mark_arena;
+    mark_arena = arena_n;
+    mark_out = n_out;
+    const uint32_t *p = ix.seed_words + seed_off;
+    const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+    p += 4;
+    tvd = tvg = GMX_NIL;
+    for (uint32_t j = 0; j < nt; ++j, p += 2) {
+      tvd = arena_new(p[0], (int32_t)p[1], tvd);
+      if (tvd == GMX_NIL) break;
+    }
+    bool ok = nt == 0 || tvd != GMX_NIL;
+    for (uint32_t j = 0; ok && j < ng; ++j, ++p) {
+      tvg = arena_new(p[0], -1, tvg);
+      ok = tvg != GMX_NIL;
+    }
+    if (!ok) {
+      fail(GMX_TASK_OVERFLOW);
+      seed_left = 0;
+      return false;
+    }
+    seed_off = (uint32_t)(p - ix.seed_words);
+    --seed_left;
+    a = lo;
+    b = hi;
+    pos = seed_pos;
+    mode = GMX_MODE_STATE;
+    return true;
+  }
   __device__ __forceinline__ bool park(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
     if (n_out >= out_cap) return false;
     reinterpret_cast<GmxParked *>(out)[n_out++] = GmxParked{a, b, tvd, tvg, pos | (mode << 30)};
@@ -220,6 +259,11 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
 };
 
 struct BigCtx {  // the same DFS queue with everything in global memory and runtime capacities (large-capacity pass)
+  __device__ __forceinline__ bool more_seeds() const { return false; }
+  __device__ __forceinline__ bool next_seed(const GmxIndexView &, bool, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &,
+                                            uint32_t &) {
+    return false;
+  }
   uint32_t sp, cap;
   uint32_t *stack;  // cap x GMX_STACK_WORDS
   GmxPathNode *arena;
@@ -351,11 +395,43 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
   }
 }
 
+#define GMX_SEED_PUSH_MAX 4u  // multi-state k-mer entries up to this size are pushed at once, larger ones use the seed cursor
+// FastCtx: a single path-less state is pushed, a small multi-state entry too, a large one arms the seed cursor.
+// CURSOR = false (engines whose index has hardly any large entry): every entry is pushed; one that does not fit
+// the stack overflows to the large-capacity pass.
+template <bool CURSOR>
+__device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, uint32_t code, FastCtx &ctx, uint32_t from) {
+  GmxSeed s = ix.seeds[code];
+  if (s.a != GMX_SEED_COMPLEX) {
+    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+    return;
+  }
+  const uint32_t ns = ix.seed_words[s.b];
+  if (ns > 0xFFFFu) {
+    ctx.fail(GMX_TASK_OVERFLOW);
+    return;
+  }
+  ctx.seed_off = s.b + 1;
+  ctx.seed_pos = from;
+  ctx.seed_left = ns;
+  ctx.mark_arena = ctx.arena_n;
+  ctx.mark_out = ctx.n_out;
+  if (!CURSOR || ns <= GMX_SEED_PUSH_MAX) {  // all on the stack at once (no dependent index fetch between them)
+    uint32_t a, b, tvd, tvg, pos, mode;
+    while (ctx.seed_left && ctx.next_seed(ix, false, a, b, tvd, tvg, pos, mode))
+      if (!ctx.push(a, b, tvd, tvg, pos, mode)) {
+        ctx.fail(GMX_TASK_OVERFLOW);
+        ctx.seed_left = 0;
+      }
+  }
+}
+
 // Wave-level driver of the DFS queue (gmx_dfs.h). All lanes spin in the cheap fast iteration; a lane that needs
 // the general iteration (marker hit, state death/finish, wide interval) waits, and the general code runs for the
 // whole wave only when GMX_SLOW_BATCH lanes are waiting or nobody can go fast — so its ~10x higher instruction
 // count is amortised instead of being executed (mostly masked off) on every step.
 #define GMX_SLOW_BATCH 12
+#define GMX_WAVE_SEED 7u  // a light kind of the wave loop only (gmx_dfs.h kinds are 0..6)
 #ifdef GMX_LOOP_STATS
 // Debug build only (-DGMX_LOOP_STATS): iteration mix of the wave loop, summed over all kernels using it.
 //   [0] fast iterations  [1] heavy TEXT  [2] heavy HIT  [3] heavy WIDE  [4] light only  [5] slow iterations
@@ -385,7 +461,7 @@ extern "C" int gmx_debug_loop_stats(unsigned long long *out, int reset) {
 #endif
 // GMX_KIND_SHARE: a heavier kind runs in an iteration when it holds at least 1/GMX_KIND_SHARE of the heavy lanes.
 // Measured on MI355X: the loop is latency-bound, so running every kind present (64) beats gathering lanes (4).
-template <int KID, class Ctx, class Reader>
+template <int KID, bool CURSOR, class Ctx, class Reader>
 __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, bool active, uint32_t budget,
                              GmxLane &ln) {
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
@@ -401,10 +477,12 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
     // whatever is still pending then is parked and continues in the compacted extend kernel.
     unsigned long long mf, ms;
     for (;;) {
-      const uint32_t kind = wait_slow ? GMX_FAST_NONE : gmx_dfs_fast_kind(ln, stop);
+      uint32_t kind = wait_slow ? GMX_FAST_NONE : gmx_dfs_fast_kind(ln, stop);
+      if (CURSOR && !ln.have && ctx.more_seeds()) kind = GMX_WAVE_SEED;  // stack empty: the next state of the k-mer index entry
       const unsigned long long m_text = __ballot(kind == GMX_FAST_TEXT), m_hit = __ballot(kind == GMX_FAST_HIT),
                                m_wide = __ballot(kind == GMX_FAST_WIDE),
-                               m_light = __ballot(kind == GMX_FAST_CONVERT || kind == GMX_FAST_EMIT || kind == GMX_FAST_POP);
+                               m_light = __ballot(kind == GMX_FAST_CONVERT || kind == GMX_FAST_EMIT || kind == GMX_FAST_POP ||
+                                                  kind == GMX_WAVE_SEED);
       ms = __ballot(ln.have && kind == GMX_FAST_NONE);
       mf = m_text | m_hit | m_wide | m_light;
       if (mf == 0 || __popcll(ms) >= GMX_SLOW_BATCH) break;
@@ -447,6 +525,8 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
           gmx_dfs_emit(ctx, ln);
         } else if (kind == GMX_FAST_POP) {
           gmx_dfs_pop(ctx, ln);
+        } else if (CURSOR && kind == GMX_WAVE_SEED) {
+          ln.have = ctx.next_seed(ix, true, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
         }
       }
       if (run_text && kind == GMX_FAST_TEXT)
@@ -498,6 +578,7 @@ struct SearchOut {
   uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter
+  uint32_t *seed_cursor;     // per task: word offset into seed_words of the next seed state (when n_final's bits 16.. > 0)
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
 };
@@ -580,10 +661,10 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
-      if (ctx.n_out == 0)
+      if (ctx.n_out == 0 && ctx.seed_left == 0)
         dead = true;
       else {
-        o.n_final[task] = ctx.n_out | (ctx.arena_n << 8);
+        o.n_final[task] = ctx.n_out | (ctx.arena_n << 8) | (ctx.seed_left << 16);
         mapped = done;
         alive = !done;
       }
@@ -640,6 +721,7 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
 
 // Phase 1 — every (read, orientation): seed lookup + the first GMX_PROBE_STEPS extensions. Half of the tasks
 // (the orientation that does not map) die here; the survivors are parked and compacted for the main phase.
+template <bool CURSOR>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t probe_iters) {
   uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = task < b.n_reads * 2;
@@ -656,6 +738,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.parking = true;
   ctx.park_pos = 0;
   ctx.first_pos = GMX_NIL;
+  ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
   r.clear(b.packed);
   bool run = false;
@@ -668,9 +751,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       const uint32_t k = ix.kmer_size;
       const uint32_t from = r.len - k;
       const uint32_t stop = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
-      load_seed(ix, last_kmer_code(r, k), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-        return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
-      });
+      load_seed_cursor<CURSOR>(ix, last_kmer_code(r, k), ctx, from);
       run = ctx.status == GMX_TASK_MAPPED;
       status = ctx.status;
       done = stop == 0;
@@ -681,20 +762,22 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     }
   }
   GmxLane ln;
-  dfs_run_wave<0>(ix, ctx, r, lane_stop, run, probe_iters, ln);  // every lane of the wave takes part in the ballots
+  dfs_run_wave<0, CURSOR>(ix, ctx, r, lane_stop, run, probe_iters, ln);  // every lane of the wave takes part in the ballots
   if (run) {
-    // iteration budget spent with work left: park the lane's entry and its stack as they are
-    if ((ln.have || ctx.sp) && ctx.status == GMX_TASK_MAPPED) {
+    // iteration budget spent with work left: park the lane's entry and its stack as they are; seed states not yet
+    // started stay in the index, the extend kernel continues the cursor
+    if ((ln.have || ctx.sp || ctx.seed_left) && ctx.status == GMX_TASK_MAPPED) {
       if (done) {
         ctx.fail(GMX_TASK_OVERFLOW);  // a short read whose states are final ones: redone by the large-capacity pass
       } else {
-        do {
+        while (ln.have || ctx.sp) {
           if (ln.have && ln.mode != GMX_MODE_DEAD && !ctx.park(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode)) {
             ctx.fail(GMX_TASK_OVERFLOW);
             break;
           }
           ln.have = ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
-        } while (ln.have);
+        }
+        if (ctx.seed_left) o.seed_cursor[task] = ctx.seed_off;
       }
     }
     status = ctx.status;
@@ -703,6 +786,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 }
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
+template <bool CURSOR>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
@@ -722,13 +806,20 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.parking = false;
   ctx.park_pos = 0;
   ctx.first_pos = GMX_NIL;
+  ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
   r.clear(b.packed);
   if (active) {
     task_read_regs(b, task, r);
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
-    ctx.arena_n = packed >> 8;
+    ctx.arena_n = (packed >> 8) & 0xFF;
+    ctx.mark_arena = ctx.arena_n;  // the parked entries are this kernel's pending work: nothing of theirs is released
+    ctx.seed_left = CURSOR ? packed >> 16 : 0;
+    if (ctx.seed_left) {
+      ctx.seed_off = o.seed_cursor[task];
+      ctx.seed_pos = r.len - ix.kmer_size;
+    }
     const GmxParked *parked = reinterpret_cast<const GmxParked *>(ctx.out);  // all read before the first emit overwrites them
     for (uint32_t s = 0; s < n; ++s) {
       GmxParked f = parked[s];
@@ -737,7 +828,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   }
   const long long t1 = GMX_CLK();
   GmxLane ln;
-  dfs_run_wave<1>(ix, ctx, r, 0, active, 0, ln);
+  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
   const long long t2 = GMX_CLK();
   finish_lane(o, active, task, ctx, status, true, true);
@@ -833,7 +924,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
       run = ctx.status == GMX_TASK_MAPPED;
     }
     GmxLane ln;
-    dfs_run_wave<2>(ix, ctx, r, 0, run, 0, ln);
+    dfs_run_wave<2, false>(ix, ctx, r, 0, run, 0, ln);
     if (!active) continue;
     uint32_t status = ctx.status;
     uint32_t nf = 0;
@@ -1173,7 +1264,8 @@ struct gmx_engine {
   uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
-  uint32_t *d_alive = nullptr, *d_dead = nullptr;
+  uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_seed_cursor = nullptr;
+  bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
   GmxPathNode *d_arena = nullptr;
   BigOut big{};
@@ -1249,6 +1341,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_seed_cursor, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
   e->cap_reads = cap;
@@ -1344,6 +1437,11 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     (void)hipGetLastError();
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
+  // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
+  // more than 10 % of the seed states the kernels take them one state at a time (seed cursor, a few % slower), else
+  // the rare large entry goes to the large-capacity pass
+  e->seed_cursor = h.n_seed_states_large * 10 > h.n_seed_states;
+  if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
   e->cover_side_blocks = 32;
   rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
   rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
@@ -1418,7 +1516,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead,    e->d_counters};
+              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead, e->d_seed_cursor, e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
   // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
@@ -1438,7 +1536,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     HIP_TRY(hipEventRecord(ev.s, stream));
   }
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
-  hipLaunchKernelGGL(gmx_probe_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
+  if (e->seed_cursor)
+    hipLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
+  else
+    hipLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
   // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel
   // on a side stream while the extend kernel runs
@@ -1446,7 +1547,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
-  hipLaunchKernelGGL(gmx_extend_kernel, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  if (e->seed_cursor)
+    hipLaunchKernelGGL(gmx_extend_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  else
+    hipLaunchKernelGGL(gmx_extend_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
                e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes,
@@ -1609,6 +1713,25 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
   out->reads = e->timed_reads;
   e->search_ms = e->cover_ms = 0;
   e->search_launches = e->cover_launches = e->timed_reads = 0;
+  return GMX_OK;
+}
+
+int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
+  HIP_TRY(hipSetDevice(e->opts.device));
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t raw[32 * GMX_CNT_STRIDE];
+  HIP_TRY(hipMemcpy(raw, e->d_counters, sizeof(raw), hipMemcpyDeviceToHost));
+  auto c = [&](int i) { return (uint64_t)raw[i * GMX_CNT_STRIDE]; };
+  out->mapped = 0;
+  for (int r = 0; r < GMX_REGIONS; ++r) out->mapped += c(16 + r);
+  out->alive = c(5);
+  out->dead = c(6);
+  out->overflow_probe = c(1);
+  out->overflow_extend = c(9);
+  out->big_mapped = c(7);
+  out->cover_general = c(8);
+  out->cover_overflow = c(4);
+  out->seed_cursor = e->seed_cursor ? 1 : 0;
   return GMX_OK;
 }
 

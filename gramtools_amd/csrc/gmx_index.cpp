@@ -852,10 +852,14 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     for (auto &vec : results)
       for (auto &o : vec) {
         GmxSeed s{o.a, o.b};
+        uint64_t n_states = 1;
         if (o.a == GMX_SEED_COMPLEX) {
           s.b = (uint32_t)out.seed_words.size();
           out.seed_words.insert(out.seed_words.end(), o.words.begin(), o.words.end());
+          n_states = o.words.empty() ? 0 : o.words[0];
         }
+        out.n_seed_states += n_states;
+        if (n_states > 4) out.n_seed_states_large += n_states;
         out.seeds[o.code] = s;
         out.kmer_bitmap[o.code >> 5] |= 1u << (o.code & 31);
         out.n_seed_kmers_present++;

@@ -46,6 +46,7 @@ struct HostIndex {
   std::vector<std::pair<uint32_t, std::vector<TargetedMarker>>> target_map;  // ascending key
   std::vector<std::pair<uint32_t, int32_t>> pos_target;                        // per PRG position (0,-1) if none
   uint64_t n_seed_kmers_present = 0;
+  uint64_t n_seed_states = 0, n_seed_states_large = 0;  // states of all entries / of entries with more than 4 states
 
   GmxIndexView view() const;  // host-pointer view
 };

@@ -353,6 +353,12 @@ class Quasimapper:
         check(self.lib.gmx_coverage_device(self.h, C.byref(dc)))
         return dc
 
+    def queue_counts(self):
+        """Queue lengths of the last batch (which route the tasks took); see gmx_queue_counts."""
+        q = _lib.QueueCounts()
+        check(self.lib.gmx_engine_queue_counts(self.h, C.byref(q)))
+        return {n: int(getattr(q, n)) for n, _ in q._fields_}
+
     def reduce_begin(self, stream=None):
         """Before the all-reduce of the fused block: read counters -> 16-bit limbs inside it."""
         check(self.lib.gmx_coverage_reduce_begin(self.h, C.c_void_p(stream) if stream else None))

@@ -140,6 +140,21 @@ typedef struct gmx_timing {
 } gmx_timing;
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
 
+/* Queue lengths of the LAST batch (after gmx_engine_sync): how many (read, orientation) tasks took which route.
+ * Diagnostics for capacity planning; tasks_overflow_* are redone by the large-capacity kernel. */
+typedef struct gmx_queue_counts {
+  uint64_t mapped;            /* tasks with final states from the probe / extend kernels */
+  uint64_t alive;             /* tasks parked by the probe kernel for the extend kernel */
+  uint64_t dead;              /* tasks without final state (k-mer filter decides their counter) */
+  uint64_t overflow_probe;    /* tasks that overflowed the per-lane pools in the probe kernel */
+  uint64_t overflow_extend;   /* ... in the extend kernel */
+  uint64_t big_mapped;        /* large-capacity tasks with final states */
+  uint64_t cover_general;     /* mapped tasks that needed the general coverage kernel */
+  uint64_t cover_overflow;    /* ... and its large scratch */
+  uint64_t seed_cursor;       /* 1: the engine runs the seed-cursor kernels (index with many multi-state k-mer entries) */
+} gmx_queue_counts;
+int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out);
+
 /* The i-th master-generator draws for reads_per_file (quasimap.cpp:120-141: 5000 draws per batch of
  * <= 5000 reads, one mt19937(master_seed) shared by all files). `out` receives sum(reads_per_file) seeds. */
 int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out);
