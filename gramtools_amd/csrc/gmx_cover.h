@@ -18,7 +18,8 @@
 //   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot)
 //   bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) / void log_grouped_id(int32_t) / void log_grouped_end()
 //   void fail(uint32_t status)
-//   const GmxPathNode *arena
+//   uint32_t h_site(h) / int32_t h_allele(h) / uint32_t h_next(h)            path-list handles (arena nodes, inline handles, or a
+//                                                                            compact record's entries: gmx_engine.hip CompactEnv)
 #pragma once
 #include "gmx_types.h"
 
@@ -157,29 +158,29 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     if (!nested(enc_site, enc_allele)) return 0xFFFFFFFFu;
   } else {
     // check_site_uniqueness over traversed + traversing
-    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
-      uint32_t sx = gmx_h_site(env.arena, x);
-      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) {
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
-      for (uint32_t y = tvg; y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) {
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
     }
-    for (uint32_t x = tvg; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
-      uint32_t sx = gmx_h_site(env.arena, x);
-      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) {
+    for (uint32_t x = tvg; x != GMX_NIL; x = env.h_next(x)) {
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) {
           env.fail(GMX_TASK_ERROR);
           return 0xFFFFFFFFu;
         }
     }
     if (tvg != GMX_NIL) {  // assign_traversing_loci, coverage_common.cpp:53-76
-      uint32_t parent_seed = gmx_h_site(env.arena, tvg);
+      uint32_t parent_seed = env.h_site(tvg);
       int32_t last_allele = -1;
       for (uint32_t i = lo;; ++i) {
         uint32_t p = gmx_occ_pos(ix, hi, i);
@@ -195,11 +196,11 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     // assign_traversed_loci (:78-83): push order = oldest first; the list head is the newest.
     // Process oldest-first by walking to each depth (paths are short).
     uint32_t len = 0;
-    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) ++len;
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) ++len;
     for (uint32_t d = len; d-- > 0;) {
       uint32_t x = tvd;
-      for (uint32_t s = 0; s < d; ++s) x = gmx_h_next(env.arena, x);
-      if (!nested(gmx_h_site(env.arena, x), gmx_h_allele(env.arena, x))) return 0xFFFFFFFFu;
+      for (uint32_t s = 0; s < d; ++s) x = env.h_next(x);
+      if (!nested(env.h_site(x), env.h_allele(x))) return 0xFFFFFFFFu;
     }
   }
   return n;
@@ -325,8 +326,8 @@ GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  
       w.bad = true;
       return;
     }
-    allele = gmx_h_allele(env.arena, w.cursor);
-    w.cursor = gmx_h_next(env.arena, w.cursor);
+    allele = env.h_allele(w.cursor);
+    w.cursor = env.h_next(w.cursor);
   }
   if (allele < 0 || (uint32_t)allele >= ne) {
     w.bad = true;
@@ -453,17 +454,17 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     enc_site = rec0.site;
     enc_allele = rec0.allele;
   } else {  // check_site_uniqueness (coverage_common.cpp:17-32)
-    for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
-      uint32_t sx = gmx_h_site(env.arena, x);
-      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
-      for (uint32_t y = tvg; y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
     }
-    for (uint32_t x = tvg; x != GMX_NIL; x = gmx_h_next(env.arena, x)) {
-      uint32_t sx = gmx_h_site(env.arena, x);
-      for (uint32_t y = gmx_h_next(env.arena, x); y != GMX_NIL; y = gmx_h_next(env.arena, y))
-        if (gmx_h_site(env.arena, y) == sx) return env.fail(GMX_TASK_ERROR);
+    for (uint32_t x = tvg; x != GMX_NIL; x = env.h_next(x)) {
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
     }
   }
   GmxWalk w;
@@ -480,9 +481,9 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     gmx_record_locus(ix, env, enc_site, enc_allele);
     return;
   }
-  if (tvg != GMX_NIL && !gmx_record_locus(ix, env, gmx_h_site(env.arena, tvg), rec0.allele)) return;
-  for (uint32_t x = tvd; x != GMX_NIL; x = gmx_h_next(env.arena, x))
-    if (!gmx_record_locus(ix, env, gmx_h_site(env.arena, x), gmx_h_allele(env.arena, x))) return;
+  if (tvg != GMX_NIL && !gmx_record_locus(ix, env, env.h_site(tvg), rec0.allele)) return;
+  for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x))
+    if (!gmx_record_locus(ix, env, env.h_site(x), env.h_allele(x))) return;
 }
 
 // ---------------------------------------------------------------------------

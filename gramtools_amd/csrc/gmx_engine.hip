@@ -145,6 +145,20 @@ struct ReadRegs {
 // ---------------------------------------------------------------------------
 extern __shared__ uint32_t gmx_lds[];
 
+// What the single-instance coverage kernel needs of a mapped task, in one 32-byte record written by the search
+// kernel that finished it: the final state's PRG position, the read length, the traversing path (inline handle or
+// nil) and up to three traversed loci, newest first. The kernel reads its queue coalesced and touches neither the
+// task's final states nor its path arena. Tasks that do not fit (several final states, an SA-form or nested final
+// state, longer paths, allele ids >= 65536, reads >= 65536 bases) go to the general coverage queue as task ids.
+struct alignas(32) GmxCoverRec {
+  uint32_t p;
+  uint32_t len_n;  // read length | number of traversed loci << 16
+  uint32_t tvg;
+  uint32_t site[3];
+  uint32_t a01;    // allele 0 | allele 1 << 16
+  uint32_t a2;
+};
+
 // A pending entry of a task handed from the probe kernel to the extend kernel (overlays the task's finals[]).
 struct GmxParked {
   uint32_t a, b, tvd, tvg, pm;  // pm = read position | mode << 30, as on the stack
@@ -159,6 +173,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   GmxFinalState *out;
   uint32_t n_out, out_cap;
   uint32_t first_pos; // PRG position of the first emitted text-form state (GMX_NIL if none): the task's coverage region
+  uint32_t first_tvd, first_tvg;  // its path handles
   bool parking;       // probe kernel: "emitted" states are parked for the extend kernel (GmxParked, same memory)
   uint32_t park_pos;  // read position of states parked by emit()
   // Seed cursor: the states of a multi-state k-mer index entry are taken ONE AT A TIME from the index (seed_words)
@@ -232,7 +247,11 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
     if (parking) return park(lo, hi, tvd, tvg, park_pos, GMX_MODE_STATE);
     if (n_out >= out_cap) return false;
-    if (n_out == 0 && hi == GMX_TEXT_MARK) first_pos = lo;
+    if (n_out == 0 && hi == GMX_TEXT_MARK) {
+      first_pos = lo;
+      first_tvd = tvd;
+      first_tvg = tvg;
+    }
     out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
     return true;
   }
@@ -568,7 +587,8 @@ struct SearchOut {
   uint32_t *n_final;         // per task
   GmxFinalState *finals;     // per task x GMX_FAST_STATES
   GmxPathNode *arena;        // per task x GMX_FAST_ARENA
-  uint32_t *mapped_list;     // GMX_REGIONS lists x region_cap task ids with final states, by PRG region; counters [16 + r]
+  GmxCoverRec *cover_recs;   // GMX_REGIONS queues x region_cap records of single-instance mapped tasks, by PRG region;
+  uint32_t *cover_rec_task;  // their task ids (error reporting); counters [16 + r]
   uint32_t region_cap;       // capacity of one region list
   uint32_t region_inv;       // ceil(2^32 * GMX_REGIONS / n_prg): region = umulhi(position, region_inv)
   uint32_t *overflow_list;   // task ids to re-run with large capacities (from the probe kernel); counter [1]
@@ -656,8 +676,8 @@ __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task
 
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
 //   done  : the whole read has been consumed (the emitted states are final, not parked)
-__device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uint32_t task, FastCtx &ctx, uint32_t status,
-                                            bool done, bool second_phase) {
+__device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const SearchOut &o, bool active, uint32_t task, FastCtx &ctx,
+                                            uint32_t status, bool done, bool second_phase, uint32_t read_len) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
@@ -676,31 +696,55 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
   }
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
     o.status[task] = status;
+  // a mapped task with ONE text-form final state and a short path leaves as a compact record (GmxCoverRec)
+  GmxCoverRec rec{0, 0, GMX_NIL, {0, 0, 0}, 0, 0};
+  bool compact = mapped && !ix.is_nested && ctx.n_out == 1 && ctx.first_pos != GMX_NIL && read_len < 0x10000u &&
+                 (ctx.first_tvg == GMX_NIL || gmx_h_inline(ctx.first_tvg));
+  if (compact) {
+    uint32_t n = 0, alleles[3] = {0, 0, 0};
+    uint32_t x = ctx.first_tvd;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (x != GMX_NIL) {
+        const GmxPathNode nd = ctx.arena[x];
+        rec.site[i] = nd.site;
+        alleles[i] = (uint32_t)nd.allele;
+        compact = compact && alleles[i] < 0x10000u;
+        x = nd.next;
+        ++n;
+      }
+    compact = compact && x == GMX_NIL;
+    rec.p = ctx.first_pos;
+    rec.len_n = read_len | (n << 16);
+    rec.tvg = ctx.first_tvg;
+    rec.a01 = alleles[0] | (alleles[1] << 16);
+    rec.a2 = alleles[2];
+  }
   // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
-  // queue and block). Mapped tasks are queued by the PRG region they map to: workgroup b of the coverage kernel
-  // serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the graph
-  // tables and of the accumulators (they do not fit one 4 MiB L2 as a whole). The probe kernel's
-  // overflow queue is separate from the extend kernel's: it is served while the extend kernel still runs.
-  uint32_t region = task & (GMX_REGIONS - 1);
-  if (ctx.first_pos != GMX_NIL) region = min(__umulhi(ctx.first_pos, o.region_inv), (uint32_t)(GMX_REGIONS - 1));
-  const uint32_t cat = mapped ? region : over ? GMX_REGIONS : alive ? GMX_REGIONS + 1 : dead ? GMX_REGIONS + 2 : 0xFFu;
-  __shared__ uint32_t q_cnt[GMX_BLOCK / 64][GMX_REGIONS + 3];
-  __shared__ uint32_t q_base[GMX_REGIONS + 3];
+  // queue and block). Compact mapped tasks are queued by the PRG region they map to: workgroup b of the coverage
+  // kernel serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the
+  // graph tables and of the accumulators (they do not fit one 4 MiB L2 as a whole). The probe
+  // kernel's overflow queue is separate from the extend kernel's: it is served while the extend kernel still runs.
+  const uint32_t region = min(__umulhi(ctx.first_pos, o.region_inv), (uint32_t)(GMX_REGIONS - 1));
+  enum : uint32_t { Q_OVER = GMX_REGIONS, Q_ALIVE, Q_DEAD, Q_GENERAL, Q_N };
+  const uint32_t cat = mapped ? (compact ? region : Q_GENERAL) : over ? Q_OVER : alive ? Q_ALIVE : dead ? Q_DEAD : 0xFFu;
+  __shared__ uint32_t q_cnt[GMX_BLOCK / 64][Q_N];
+  __shared__ uint32_t q_base[Q_N];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long mine = 0;
 #pragma unroll
-  for (uint32_t c = 0; c < GMX_REGIONS + 3; ++c) {
+  for (uint32_t c = 0; c < Q_N; ++c) {
     const unsigned long long m = __ballot(cat == c);
     if (lane == 0) q_cnt[wave][c] = (uint32_t)__popcll(m);
     if (cat == c) mine = m;
   }
   __syncthreads();
-  if (threadIdx.x < GMX_REGIONS + 3) {
+  if (threadIdx.x < Q_N) {
     const uint32_t c = threadIdx.x;
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
-    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == GMX_REGIONS ? (second_phase ? 9u : 1u) : c == GMX_REGIONS + 1 ? 5u : 6u;
+    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? 5u : c == Q_DEAD ? 6u : 8u;
     q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
@@ -708,11 +752,17 @@ __device__ __forceinline__ void finish_lane(const SearchOut &o, bool active, uin
     uint32_t before = 0;
 #pragma unroll
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) before += w < wave ? q_cnt[w][cat] : 0;
-    uint32_t *list = cat < GMX_REGIONS          ? o.mapped_list + (size_t)cat * o.region_cap
-                     : cat == GMX_REGIONS       ? (second_phase ? o.overflow2_list : o.overflow_list)
-                     : cat == GMX_REGIONS + 1   ? o.alive_list
-                                                : o.dead_list;
-    list[q_base[cat] + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = task;
+    const uint32_t at = q_base[cat] + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+    if (cat < GMX_REGIONS) {
+      o.cover_recs[(size_t)cat * o.region_cap + at] = rec;
+      o.cover_rec_task[(size_t)cat * o.region_cap + at] = task;
+    } else {
+      uint32_t *list = cat == Q_OVER ? (second_phase ? o.overflow2_list : o.overflow_list)
+                       : cat == Q_ALIVE ? o.alive_list
+                       : cat == Q_DEAD  ? o.dead_list
+                                        : o.cover_general_list;
+      list[at] = task;
+    }
   }
 }
 
@@ -737,7 +787,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
   ctx.parking = true;
   ctx.park_pos = 0;
-  ctx.first_pos = GMX_NIL;
+  ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
   r.clear(b.packed);
@@ -782,7 +832,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     }
     status = ctx.status;
   }
-  finish_lane(o, active, task, ctx, status, done, false);
+  finish_lane(ix, o, active, task, ctx, status, done, false, r.len);
 }
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
@@ -805,7 +855,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.out_cap = GMX_FAST_STATES;
   ctx.parking = false;
   ctx.park_pos = 0;
-  ctx.first_pos = GMX_NIL;
+  ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
   r.clear(b.packed);
@@ -831,7 +881,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(o, active, task, ctx, status, true, true);
+  finish_lane(ix, o, active, task, ctx, status, true, true, r.len);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -972,6 +1022,9 @@ struct CoverEnvT {
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
+  __device__ __forceinline__ uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
   __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
   __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&allele_sum[slot], 1u); }
@@ -1049,26 +1102,56 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   }
 }
 
-// The common case first, one lane per mapped task and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
-// final state of width one on a non-nested PRG. Few registers, so many more waves are in flight to hide the
-// dependent look-ups (state -> node -> walk -> atomics). Everything else is queued for the general instance.
+// Path handles of a GmxCoverRec: traversed loci are addressed by their index in the record (newest first), the
+// traversing path is an inline handle (gmx_types.h) or nil.
+struct CompactEnv {
+  GmxCoverRec rec;
+  uint32_t *allele_sum, *per_base, *grouped, *log, *log_cursor;
+  uint32_t log_cap;
+  uint32_t status;
+  uint32_t log_at;
+  __device__ __forceinline__ uint32_t n_trav() const { return (rec.len_n >> 16) & 3u; }
+  __device__ __forceinline__ uint32_t h_site(uint32_t h) const {
+    if (h & GMX_INLINE_FLAG) return 5u + 2u * (h & ~GMX_INLINE_FLAG);
+    return h == 0 ? rec.site[0] : (h == 1 ? rec.site[1] : rec.site[2]);
+  }
+  __device__ __forceinline__ int32_t h_allele(uint32_t h) const {
+    if (h & GMX_INLINE_FLAG) return -1;
+    return (int32_t)(h == 0 ? (rec.a01 & 0xFFFFu) : (h == 1 ? (rec.a01 >> 16) : rec.a2));
+  }
+  __device__ __forceinline__ uint32_t h_next(uint32_t h) const {
+    if (h & GMX_INLINE_FLAG) return GMX_NIL;
+    return h + 1 < n_trav() ? h + 1 : GMX_NIL;
+  }
+  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&allele_sum[slot], 1u); }
+  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&per_base[slot], 1u); }
+  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&grouped[slot], 1u); }
+  __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
+    log_at = atomicAdd(log_cursor, n_ids + 2);
+    if (log_at + n_ids + 2 > log_cap) {
+      status = GMX_TASK_LOGFULL;
+      return false;
+    }
+    log[log_at++] = site_index;
+    log[log_at++] = n_ids;
+    return true;
+  }
+  __device__ __forceinline__ void log_grouped_id(int32_t a) { log[log_at++] = (uint32_t)a; }
+  __device__ __forceinline__ void log_grouped_end() {}
+  __device__ __forceinline__ void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+// The common case, one lane per compact record and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
+// final state of width one on a non-nested PRG. Few registers, a coalesced queue, region-local tables.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
   const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
   const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
   const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
   if (m >= n_mapped) return;
-  const uint32_t task = o.mapped_list[(size_t)region * o.region_cap + m];
-  const uint32_t nf = o.n_final[task] & 0xFF;
-  const GmxFinalState st = o.finals[(size_t)task * GMX_FAST_STATES];
-  if (nf != 1 || ix.is_nested || !(st.lo == st.hi || gmx_text_form(st.hi))) {
-    o.cover_general_list[atomicAdd(&o.counters[8 * GMX_CNT_STRIDE], 1u)] = task;
-    return;
-  }
-  const uint32_t read = task >> 1;
-  CoverEnv env;
-  env.scratch = nullptr;
-  env.stride = 0;
-  env.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  CompactEnv env;
+  env.rec = o.cover_recs[(size_t)region * o.region_cap + m];
   env.allele_sum = acc.allele_sum;
   env.per_base = acc.per_base;
   env.grouped = acc.grouped;
@@ -1077,9 +1160,10 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   env.log_cap = acc.log_cap;
   env.status = GMX_TASK_MAPPED;
   env.log_at = 0;
-  gmx_cover_single(ix, env, st, (uint32_t)(b.offsets[read + 1] - b.offsets[read]));
+  const GmxFinalState st{env.rec.p, GMX_TEXT_MARK, env.n_trav() ? 0u : GMX_NIL, env.rec.tvg};
+  gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
   if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u)
-    o.counters[3 * GMX_CNT_STRIDE] = task;
+    o.counters[3 * GMX_CNT_STRIDE] = o.cover_rec_task[(size_t)region * o.region_cap + m];
 }
 
 // QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
@@ -1268,6 +1352,7 @@ struct gmx_engine {
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
   GmxPathNode *d_arena = nullptr;
+  GmxCoverRec *d_cover_recs = nullptr;
   BigOut big{};
   uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
   uint32_t cover_blocks = 0, cover_big_lanes = 0, cover_side_blocks = 0;
@@ -1334,6 +1419,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_skip, cap, true))) return rc;
   if ((rc = e->alloc(&e->d_status, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_n_final, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_cover_recs, n_tasks * GMX_REGIONS, false))) return rc;
   if ((rc = e->alloc(&e->d_mapped, n_tasks * GMX_REGIONS, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_overflow2, n_tasks, false))) return rc;
@@ -1515,7 +1601,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
-  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
+  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead, e->d_seed_cursor, e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
@@ -1724,6 +1810,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   auto c = [&](int i) { return (uint64_t)raw[i * GMX_CNT_STRIDE]; };
   out->mapped = 0;
   for (int r = 0; r < GMX_REGIONS; ++r) out->mapped += c(16 + r);
+  out->mapped += c(8);
   out->alive = c(5);
   out->dead = c(6);
   out->overflow_probe = c(1);

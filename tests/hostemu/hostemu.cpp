@@ -114,6 +114,9 @@ struct EmuEnvT {
   static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
   std::vector<uint32_t> scratch;
   const GmxPathNode *arena;
+  uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
   Emu *e;
   uint32_t status = GMX_TASK_MAPPED;
   EmuEnvT() : scratch(GmxScratch<EmuEnvT>::total, 0xDEADBEEFu) {}
