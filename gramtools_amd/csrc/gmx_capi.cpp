@@ -113,8 +113,8 @@ int gmx_index_site_layout(const gmx_index *ix, uint32_t *n_alleles, uint32_t *al
   const auto &s = ix->h.sites;
   for (size_t i = 0; i < s.size(); ++i) {
     if (n_alleles) n_alleles[i] = s[i].n_alleles;
-    if (allele_sum_off) allele_sum_off[i] = s[i].allele_sum_off;
-    if (grouped_off) grouped_off[i] = s[i].grouped_off;
+    if (allele_sum_off) allele_sum_off[i] = ix->h.l_allele_off[i];
+    if (grouped_off) grouped_off[i] = ix->h.l_grouped_off[i];
     if (parent_site) parent_site[i] = s[i].parent_site;
     if (parent_allele) parent_allele[i] = s[i].parent_allele;
   }
@@ -128,10 +128,11 @@ int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t c
     const GmxNode &nd = h.nodes[i];
     if (nd.cov_off == GMX_NO_COV) continue;
     if (out && n < cap) {
+      const uint32_t l_cov = h.l_cov_off[i];
       out[5 * n + 0] = (nd.site - 5) / 2;
       out[5 * n + 1] = (uint32_t)nd.allele;
       out[5 * n + 2] = nd.first_pos;
-      out[5 * n + 3] = nd.cov_off;
+      out[5 * n + 3] = l_cov;
       out[5 * n + 4] = nd.seq_len;
     }
     ++n;
@@ -151,12 +152,12 @@ int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t
     const GmxNode &entry = h.nodes[site.entry_node];
     for (uint32_t a = 0; a < site.n_alleles; ++a) {
       uint32_t tgt = h.edges[entry.edge_begin + a];
-      uint32_t slot = site.allele_sum_off + a;
+      uint32_t slot = h.l_allele_off[s] + a;
       if (tgt == site.exit_node) {
         pb_off[slot] = 0;
         len[slot] = 0;
       } else {
-        pb_off[slot] = h.nodes[tgt].cov_off;
+        pb_off[slot] = h.l_cov_off[tgt];
         len[slot] = h.nodes[tgt].seq_len;
       }
     }
@@ -198,10 +199,10 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
   }
   for (size_t s = 0; s < h.sites.size(); ++s) {
     const GmxSite &site = h.sites[s];
-    if (site.grouped_off != GMX_GROUPED_LOG) {
+    if (h.l_grouped_off[s] != GMX_GROUPED_LOG) {
       uint32_t nm = (1u << site.n_alleles) - 1u;
       for (uint32_t m = 0; m < nm; ++m) {
-        uint32_t tot = grouped_raw[site.grouped_off + m];
+        uint32_t tot = grouped_raw[h.l_grouped_off[s] + m];
         if (!tot) continue;
         uint16_t c = (uint16_t)(tot & 0xFFFFu);
         for (uint32_t a = 0; a < site.n_alleles; ++a)
@@ -251,7 +252,7 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
       }
       if (nd.seq_len > 0 && nd.cov_off != GMX_NO_COV)
         for (uint32_t i = 0; i < nd.seq_len; ++i) {
-          uint32_t v = per_base_raw[nd.cov_off + i];
+          uint32_t v = per_base_raw[h.l_cov_off[cur] + i];
           sum += (double)(v > 65535u ? 65535u : v);
           ++n_bases;
         }

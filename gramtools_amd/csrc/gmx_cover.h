@@ -15,7 +15,8 @@
 // Env interface:
 //   uint32_t sget(uint32_t word) / void sset(uint32_t word, uint32_t v)   per-task scratch words
 //   static constexpr I_MAX, B_MAX, LOC_MAX, H_MAX                            capacities
-//   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot)
+//   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot): +1 on a slot of the
+//        accumulator block (gmx_types.h: gmx_slot_*); add_allele_and_group(slot): +1 on slot and slot + 1 (one 64-bit add)
 //   bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) / void log_grouped_id(int32_t) / void log_grouped_end()
 //   void fail(uint32_t status)
 //   uint32_t h_site(h) / int32_t h_allele(h) / uint32_t h_next(h)            path-list handles (arena nodes, inline handles, or a
@@ -431,10 +432,10 @@ GMX_HD bool gmx_record_locus(const GmxIndexView &ix, Env &env, uint32_t site, in
     env.fail(GMX_TASK_ERROR);
     return false;
   }
-  env.add_allele_sum(s.allele_sum_off + (uint32_t)allele);
   if (s.grouped_off != GMX_GROUPED_LOG) {
-    env.add_grouped_dense(s.grouped_off + (1u << allele) - 1);
+    env.add_allele_and_group(gmx_slot_allele(s, (uint32_t)allele));  // allele-sum and group {allele}: one 64-bit word
   } else {
+    env.add_allele_sum(gmx_slot_allele(s, (uint32_t)allele));
     if (!env.log_grouped_begin((site - 5) >> 1, 1)) return false;
     env.log_grouped_id(allele);
     env.log_grouped_end();
@@ -613,7 +614,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
       env.fail(GMX_TASK_ERROR);
       return;
     }
-    env.add_allele_sum(s.allele_sum_off + (uint32_t)allele);
+    env.add_allele_sum(gmx_slot_allele(s, (uint32_t)allele));
   }
   for (uint32_t i = 0; i < n_loci; ++i) {
     uint32_t site = env.sget(S::loci + 2 * i);
@@ -625,7 +626,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
       uint32_t mask = 0;
       for (uint32_t j = i; j < n_loci; ++j)
         if (env.sget(S::loci + 2 * j) == site) mask |= 1u << env.sget(S::loci + 2 * j + 1);
-      env.add_grouped_dense(s.grouped_off + mask - 1);
+      env.add_grouped_dense(gmx_slot_grouped(s, mask));
     } else {
       uint32_t cnt = 0;
       for (uint32_t j = i; j < n_loci; ++j)

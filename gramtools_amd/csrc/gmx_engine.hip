@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
 // coverage kernel
 // ---------------------------------------------------------------------------
 struct CoverAcc {
-  uint32_t *allele_sum, *per_base, *grouped;
+  uint32_t *acc;        // the accumulator block (gmx_types.h: gmx_slot_*)
   uint32_t *log;        // grouped log words
   uint32_t *log_cursor; // [0] = words used
   uint32_t log_cap;
@@ -1018,7 +1018,7 @@ struct CoverEnvT {
   uint32_t *scratch;  // already offset by the lane
   uint32_t stride;
   const GmxPathNode *arena;
-  uint32_t *allele_sum, *per_base, *grouped, *log, *log_cursor;
+  uint32_t *acc, *log, *log_cursor;
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
@@ -1027,9 +1027,12 @@ struct CoverEnvT {
   __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
   __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
   __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
-  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&allele_sum[slot], 1u); }
-  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&per_base[slot], 1u); }
-  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&grouped[slot], 1u); }
+  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
+  }
   __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
     log_at = atomicAdd(log_cursor, n_ids + 2);
     if (log_at + n_ids + 2 > log_cap) {
@@ -1085,9 +1088,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     env.scratch = (LIST == 0 ? acc.scratch : LIST == 1 ? acc.scratch_big : acc.scratch_side) + lane_id;
     env.stride = LIST == 0 ? acc.n_lanes : LIST == 1 ? acc.n_lanes_big : acc.n_lanes_side;
     env.arena = arena;
-    env.allele_sum = acc.allele_sum;
-    env.per_base = acc.per_base;
-    env.grouped = acc.grouped;
+    env.acc = acc.acc;
     env.log = acc.log;
     env.log_cursor = acc.log_cursor;
     env.log_cap = acc.log_cap;
@@ -1106,7 +1107,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
 // traversing path is an inline handle (gmx_types.h) or nil.
 struct CompactEnv {
   GmxCoverRec rec;
-  uint32_t *allele_sum, *per_base, *grouped, *log, *log_cursor;
+  uint32_t *acc, *log, *log_cursor;
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
@@ -1123,9 +1124,12 @@ struct CompactEnv {
     if (h & GMX_INLINE_FLAG) return GMX_NIL;
     return h + 1 < n_trav() ? h + 1 : GMX_NIL;
   }
-  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&allele_sum[slot], 1u); }
-  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&per_base[slot], 1u); }
-  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&grouped[slot], 1u); }
+  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
+  }
   __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
     log_at = atomicAdd(log_cursor, n_ids + 2);
     if (log_at + n_ids + 2 > log_cap) {
@@ -1152,9 +1156,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   if (m >= n_mapped) return;
   CompactEnv env;
   env.rec = o.cover_recs[(size_t)region * o.region_cap + m];
-  env.allele_sum = acc.allele_sum;
-  env.per_base = acc.per_base;
-  env.grouped = acc.grouped;
+  env.acc = acc.acc;
   env.log = acc.log;
   env.log_cursor = acc.log_cursor;
   env.log_cap = acc.log_cap;
@@ -1335,9 +1337,9 @@ struct gmx_engine {
   std::vector<void *> allocs;
   uint64_t index_bytes = 0;
   // accumulators
-  uint32_t *d_allele_sum = nullptr, *d_per_base = nullptr, *d_grouped = nullptr;  // views into d_fused
-  uint32_t *d_fused = nullptr, *d_limbs = nullptr;
-  size_t n_fused = 0;
+  uint32_t *d_fused = nullptr, *d_limbs = nullptr;  // accumulator block (n_acc words, gmx_types.h) | 32 counter-limb words
+  size_t n_fused = 0, n_acc = 0;
+  std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;  // logical slot -> slot of the block (gmx_coverage_fetch)
   unsigned long long *d_stats = nullptr;
   uint32_t *d_log = nullptr, *d_log_cursor = nullptr;
   uint32_t log_cap = 0;
@@ -1485,14 +1487,13 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->n_pb = h.n_pb_slots;
   e->n_grouped = h.n_grouped_slots;
   {  // one contiguous block: a single all-reduce covers the whole coverage (gmx_coverage_device)
-    auto pad = [](size_t n) { return (n + 63) / 64 * 64; };
-    const size_t o_pb = pad(e->n_allele), o_grp = o_pb + pad(e->n_pb), o_limbs = o_grp + pad(e->n_grouped);
-    e->n_fused = o_limbs + 32;
+    e->n_acc = ((size_t)h.n_acc_slots + 63) / 64 * 64;
+    e->n_fused = e->n_acc + 32;
     rc |= e->alloc(&e->d_fused, e->n_fused, true);
-    e->d_allele_sum = e->d_fused;
-    e->d_per_base = e->d_fused ? e->d_fused + o_pb : nullptr;
-    e->d_grouped = e->d_fused ? e->d_fused + o_grp : nullptr;
-    e->d_limbs = e->d_fused ? e->d_fused + o_limbs : nullptr;
+    e->d_limbs = e->d_fused ? e->d_fused + e->n_acc : nullptr;
+    e->phys_allele = h.phys_allele;
+    e->phys_pb = h.phys_pb;
+    e->phys_grouped = h.phys_grouped;
   }
   rc |= e->alloc(&e->d_stats, 8, true);
   e->log_cap = 1u << 24;
@@ -1638,7 +1639,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   else
     hipLaunchKernelGGL(gmx_extend_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
-  CoverAcc acc{e->d_allele_sum, e->d_per_base,   e->d_grouped,           e->d_log,          e->d_log_cursor,  e->log_cap,
+  CoverAcc acc{e->d_fused,           e->d_log,          e->d_log_cursor,  e->log_cap,
                e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes,
                e->d_scratch_side, e->cover_side_blocks * GMX_BLOCK, e->opts.rng_mode};
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
@@ -1823,11 +1824,9 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
 }
 
 int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
-  out->allele_sum = e->d_allele_sum;
+  out->allele_sum = out->per_base = out->grouped = nullptr;  // interleaved in the block: use `fused`, or gmx_coverage_fetch
   out->n_allele_sum = e->n_allele;
-  out->per_base = e->d_per_base;
   out->n_per_base = e->n_pb;
-  out->grouped = e->d_grouped;
   out->n_grouped = e->n_grouped;
   out->stats = e->d_stats;
   out->n_stats = 5;
@@ -1853,9 +1852,11 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
 int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
-  if (allele_sum && e->n_allele) HIP_TRY(hipMemcpy(allele_sum, e->d_allele_sum, (size_t)e->n_allele * 4, hipMemcpyDeviceToHost));
-  if (per_base && e->n_pb) HIP_TRY(hipMemcpy(per_base, e->d_per_base, (size_t)e->n_pb * 4, hipMemcpyDeviceToHost));
-  if (grouped && e->n_grouped) HIP_TRY(hipMemcpy(grouped, e->d_grouped, (size_t)e->n_grouped * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> block(std::max<size_t>(e->n_acc, 1));
+  if (e->n_acc) HIP_TRY(hipMemcpy(block.data(), e->d_fused, e->n_acc * 4, hipMemcpyDeviceToHost));
+  if (allele_sum) for (size_t i = 0; i < e->phys_allele.size(); ++i) allele_sum[i] = block[e->phys_allele[i]];
+  if (per_base) for (size_t i = 0; i < e->phys_pb.size(); ++i) per_base[i] = block[e->phys_pb[i]];
+  if (grouped) for (size_t i = 0; i < e->phys_grouped.size(); ++i) grouped[i] = block[e->phys_grouped[i]];
   if (stats) {
     unsigned long long s[5];
     HIP_TRY(hipMemcpy(s, e->d_stats, sizeof(s), hipMemcpyDeviceToHost));

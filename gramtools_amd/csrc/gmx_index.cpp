@@ -446,6 +446,7 @@ GmxIndexView HostIndex::view() const {
   v.n_allele_slots = n_allele_slots;
   v.n_pb_slots = n_pb_slots;
   v.n_grouped_slots = n_grouped_slots;
+  v.n_acc_slots = n_acc_slots;
   v.is_nested = is_nested ? 1 : 0;
   v.blocks = blocks.data();
   v.hits = hits.data();
@@ -542,6 +543,50 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
   out.n_allele_slots = as;
   out.n_grouped_slots = gs;
+  // --- logical layout -> accumulator block (gmx_types.h) ---------------------------------
+  {
+    const size_t n_sites = out.sites.size(), n_nodes = g.nodes.size();
+    out.l_allele_off.resize(n_sites);
+    out.l_grouped_off.resize(n_sites);
+    out.l_cov_off.assign(n_nodes + 1, GMX_NO_COV);
+    out.phys_allele.assign(as, 0);
+    out.phys_grouped.assign(gs, 0);
+    out.phys_pb.assign(pb, 0);
+    std::vector<std::vector<uint32_t>> nodes_of_site(n_sites);
+    for (size_t i = 0; i < n_nodes; ++i) {
+      out.l_cov_off[i] = out.nodes[i].cov_off;
+      if (out.nodes[i].cov_off != GMX_NO_COV) nodes_of_site[(out.nodes[i].site - 5) / 2].push_back((uint32_t)i);
+    }
+    uint32_t at = 0;
+    for (size_t i = 0; i < n_sites; ++i) {
+      GmxSite &s = out.sites[i];
+      out.l_allele_off[i] = s.allele_sum_off;
+      out.l_grouped_off[i] = s.grouped_off;
+      const uint32_t A = s.n_alleles;
+      at += at & 1u;  // even: (allele-sum, single-allele group) pairs are 64-bit words
+      const uint32_t base = at;
+      for (uint32_t a = 0; a < A; ++a) out.phys_allele[s.allele_sum_off + a] = base + 2 * a;
+      at += 2 * A;
+      uint32_t multi = GMX_GROUPED_LOG;
+      if (s.grouped_off != GMX_GROUPED_LOG) {
+        multi = at;
+        GmxSite probe = s;
+        probe.allele_sum_off = base;
+        probe.grouped_off = multi;
+        for (uint32_t mask = 1; mask < (1u << A); ++mask) out.phys_grouped[s.grouped_off + mask - 1] = gmx_slot_grouped(probe, mask);
+        at += (1u << A) - 1u - A;
+      }
+      for (uint32_t nd : nodes_of_site[i]) {
+        GmxNode &n = out.nodes[nd];
+        for (uint32_t j = 0; j < n.seq_len; ++j) out.phys_pb[n.cov_off + j] = at + j;
+        n.cov_off = at;
+        at += n.seq_len;
+      }
+      s.allele_sum_off = base;
+      s.grouped_off = multi;
+    }
+    out.n_acc_slots = at;
+  }
 
   // --- suffix array, BWT, rank blocks -----------------------------------------
   std::vector<uint32_t> text(prg);

@@ -39,7 +39,12 @@ struct HostIndex {
   std::vector<GmxSeed> seeds;
   std::vector<uint32_t> seed_words;
   std::vector<uint32_t> kmer_bitmap;
-  uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;
+  uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
+  uint32_t n_acc_slots = 0;                                            // length of the accumulator block
+  // logical layout (what the C ABI and the dumps use) and where each logical slot lives in the accumulator block
+  std::vector<uint32_t> l_allele_off, l_grouped_off;  // per site (l_grouped_off = GMX_GROUPED_LOG for > 5 alleles)
+  std::vector<uint32_t> l_cov_off;                    // per node (GMX_NO_COV if none)
+  std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;
 
   // introspection used by the tests (not needed on the device)
   std::vector<uint32_t> bwt;

@@ -39,7 +39,7 @@ struct GmxNode {
   int32_t allele;       // allele id or -1 (boundary / outside sites)
   uint32_t seq_len;     // number of bases
   uint32_t first_pos;   // PRG position of the first base (sequence nodes) / of the marker (boundary nodes)
-  uint32_t cov_off;     // offset into the per-base accumulator, 0xFFFFFFFF if the node owns none
+  uint32_t cov_off;     // slot of base 0 in the accumulator block (gmx_slot_*), 0xFFFFFFFF if the node owns none
   uint32_t edge_begin;  // first out-edge in edges[]; n_edges = next node's edge_begin - edge_begin
   uint32_t n_edges;     // copy of that difference, and
   uint32_t edge0;       // edges[edge_begin] (0xFFFFFFFF if none): a single-edge hop needs no second load
@@ -51,14 +51,27 @@ struct GmxSite {
   uint32_t parent_site;     // par_map[site].first, 0 when the site is level-0 (coverage_graph.cpp:193-196)
   int32_t parent_allele;    // par_map[site].second
   uint32_t n_alleles;       // edges of the bubble start
-  uint32_t allele_sum_off;  // offset of allele 0 in the allele-sum accumulator
-  uint32_t grouped_off;     // dense grouped-counts base (2^n_alleles - 1 slots) or GMX_GROUPED_LOG
+  uint32_t allele_sum_off;  // slot of the site's counter block in the accumulator block (even; see gmx_slot_*)
+  uint32_t grouped_off;     // slot of its multi-allele group counters, or GMX_GROUPED_LOG (more than 5 alleles)
   uint32_t entry_node;      // bubble start node
   uint32_t exit_node;       // bubble end node
   uint32_t ref_pos;         // coverage_Node::pos of the bubble start (first-allele coordinate; orders bubble_map)
 };
 #define GMX_GROUPED_LOG 0xFFFFFFFFu
+// ONE accumulator block holds all three coverage structures, laid out per site so that what a read touches at a
+// site sits in one cache line and the two counters every single-allele locus increments together are one 64-bit word:
+//   site block (even slot): [allele-sum(a), group {a}] for a = 0 .. A-1 | groups of 2+ alleles in mask order (A <= 5)
+//                           | per-base counters of the site's allele nodes
+// The logical arrays of the C ABI (allele_sum, per_base, grouped_dense) are gathered from it (HostIndex::phys_*).
 #define GMX_GROUPED_DENSE_MAX_ALLELES 5
+
+GMX_HD uint32_t gmx_slot_allele(const GmxSite &s, uint32_t allele) { return s.allele_sum_off + 2u * allele; }
+// slot of the group counter of allele-id set `mask` (dense sites only)
+GMX_HD uint32_t gmx_slot_grouped(const GmxSite &s, uint32_t mask) {
+  if ((mask & (mask - 1u)) == 0) return s.allele_sum_off + 2u * (31u - (uint32_t)__builtin_clz(mask)) + 1u;
+  const uint32_t bits = 32u - (uint32_t)__builtin_clz(mask);  // single-allele masks below `mask`
+  return s.grouped_off + (mask - 1u) - bits;
+}
 
 // Seed directory entry (k-mer index, build/kmer_index/build.cpp:101-131), direct-addressed by k-mer code.
 //   a <= b               : exactly one path-less state [a, b]
@@ -131,6 +144,7 @@ struct GmxIndexView {
   uint32_t n_allele_slots;   // allele-sum accumulator length
   uint32_t n_pb_slots;       // per-base accumulator length
   uint32_t n_grouped_slots;  // dense grouped accumulator length
+  uint32_t n_acc_slots;      // length of the accumulator block all three are gathered from
   uint32_t is_nested;
   const GmxRankBlock *blocks;
   const GmxHit *hits;         // [n_hits] record of the h-th marker of the PRG (text order)

@@ -90,19 +90,6 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-def device_coverage_tensors(qm):
-    """torch tensors ALIASING the engine's device accumulators (allele_sum, per_base, grouped as int32 views of
-    the uint32 totals; stats as int64). Kept for inspection; the exchange itself uses :func:`fused_coverage_tensor`."""
-    import torch
-    dc = qm.device_coverage()
-    out = []
-    for ptr, n, ts in ((dc.allele_sum, dc.n_allele_sum, "<i4"), (dc.per_base, dc.n_per_base, "<i4"),
-                       (dc.grouped, dc.n_grouped, "<i4"), (dc.stats, dc.n_stats, "<i8")):
-        if n:
-            out.append(torch.as_tensor(_DevArray(ptr, n, ts), device="cuda"))
-    return out
-
-
 def fused_coverage_tensor(qm):
     """One int32 tensor aliasing the engine's whole coverage block (allele_sum | per_base | grouped | counter limbs)."""
     import torch

@@ -167,12 +167,13 @@ typedef struct gmx_stats { /* QuasimapReadsStats, quasimap.hpp:17-24 */
   uint64_t exact_mapped_reads_count;
 } gmx_stats;
 
-/* Device pointers of the accumulators, for the RCCL all-reduce(sum) by the caller (reads shard,
- * the index is replicated, ONE exchange at the end; then gmx_coverage_fetch on every rank or on rank 0).
- * `fused` is one contiguous uint32 block holding allele_sum | per_base | grouped (each padded to 256 B) followed
- * by 32 words for the five uint64 read counters as 16-bit limbs: a single all-reduce(sum) of `n_fused` uint32
- * between gmx_coverage_reduce_begin (counters -> limbs) and gmx_coverage_reduce_end (limb sums -> counters)
- * is the whole exchange, exact for up to 65536 ranks. The per-array pointers alias the same memory. */
+/* The device side of the multi-GPU exchange (reads shard, the index is replicated, ONE exchange at the
+ * end; then gmx_coverage_fetch on every rank or on rank 0). `fused` is one contiguous uint32 block: the accumulator
+ * block (allele-sum, grouped and per-base counters interleaved per site so that a read's updates at a site share a
+ * cache line) followed by 32 words for the five uint64 read counters as 16-bit limbs. A single all-reduce(sum) of
+ * `n_fused` uint32 between gmx_coverage_reduce_begin (counters -> limbs) and gmx_coverage_reduce_end (limb sums ->
+ * counters) is the whole exchange, exact for up to 65536 ranks. The three per-array pointers are NULL (the logical
+ * arrays are not contiguous on the device; gmx_coverage_fetch gathers them); their lengths are the logical lengths. */
 typedef struct gmx_device_coverage {
   void *allele_sum;  uint64_t n_allele_sum;
   void *per_base;    uint64_t n_per_base;

@@ -101,7 +101,7 @@ struct EmuDfsCtx {
 
 struct Emu {
   gmx::HostIndex h;
-  std::vector<uint32_t> allele_sum, per_base, grouped, log;
+  std::vector<uint32_t> acc, log;  // the accumulator block (gmx_types.h) as on the device
   uint64_t stats[5] = {0, 0, 0, 0, 0};
   int rng_mode = 0;
   uint32_t first_error = 0, error_task = 0;
@@ -122,9 +122,13 @@ struct EmuEnvT {
   EmuEnvT() : scratch(GmxScratch<EmuEnvT>::total, 0xDEADBEEFu) {}
   uint32_t sget(uint32_t w) const { return scratch.at(w); }
   void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
-  void add_allele_sum(uint32_t s) { e->allele_sum.at(s)++; }
-  void add_per_base(uint32_t s) { e->per_base.at(s)++; }
-  void add_grouped_dense(uint32_t s) { e->grouped.at(s)++; }
+  void add_allele_sum(uint32_t s) { e->acc.at(s)++; }
+  void add_per_base(uint32_t s) { e->acc.at(s)++; }
+  void add_grouped_dense(uint32_t s) { e->acc.at(s)++; }
+  void add_allele_and_group(uint32_t s) {
+    e->acc.at(s)++;
+    e->acc.at(s + 1)++;
+  }
   bool log_grouped_begin(uint32_t site, uint32_t n) {
     e->log.push_back(site);
     e->log.push_back(n);
@@ -264,9 +268,7 @@ void *hostemu_create(const uint32_t *prg, uint64_t n, uint32_t k, int rng_mode, 
   try {
     Emu *e = new Emu();
     gmx::build_index(std::vector<uint32_t>(prg, prg + n), k, e->h, 1);
-    e->allele_sum.assign(e->h.n_allele_slots, 0);
-    e->per_base.assign(e->h.n_pb_slots, 0);
-    e->grouped.assign(e->h.n_grouped_slots, 0);
+    e->acc.assign(e->h.n_acc_slots, 0);
     e->rng_mode = rng_mode;
     return e;
   } catch (std::exception const &ex) {
@@ -349,18 +351,18 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
 
 void hostemu_sizes(void *p, uint64_t *out) {
   Emu *e = (Emu *)p;
-  out[0] = e->allele_sum.size();
-  out[1] = e->per_base.size();
-  out[2] = e->grouped.size();
+  out[0] = e->h.n_allele_slots;
+  out[1] = e->h.n_pb_slots;
+  out[2] = e->h.n_grouped_slots;
   out[3] = e->log.size();
   out[4] = e->n_overflow_tasks;
   out[5] = e->n_cover_overflow;
 }
 void hostemu_fetch(void *p, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, uint32_t *log, uint64_t *stats) {
   Emu *e = (Emu *)p;
-  memcpy(allele_sum, e->allele_sum.data(), e->allele_sum.size() * 4);
-  memcpy(per_base, e->per_base.data(), e->per_base.size() * 4);
-  memcpy(grouped, e->grouped.data(), e->grouped.size() * 4);
+  for (size_t i = 0; i < e->h.phys_allele.size(); ++i) allele_sum[i] = e->acc[e->h.phys_allele[i]];
+  for (size_t i = 0; i < e->h.phys_pb.size(); ++i) per_base[i] = e->acc[e->h.phys_pb[i]];
+  for (size_t i = 0; i < e->h.phys_grouped.size(); ++i) grouped[i] = e->acc[e->h.phys_grouped[i]];
   memcpy(log, e->log.data(), e->log.size() * 4);
   memcpy(stats, e->stats, sizeof(e->stats));
 }
