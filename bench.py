@@ -47,9 +47,10 @@ def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; tools/pmc_hbm.sh)."""
     try:
         with open(TRAFFIC_FILE) as fh:
-            k = json.load(fh)[kernel]
+            table = json.load(fh)
+        k = next(v for name, v in table.items() if name.startswith(kernel))  # template instances: gmx_extend_kernel<...>
         return int(k["fetch_bytes"] + k["write_bytes"])
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
 
 
@@ -63,7 +64,7 @@ def cpu_baseline(prg, reads, seeds, max_seconds=20.0):
     t0 = time.time()
     o.map_reads(reads[:n].reshape(-1), flat_offsets(n, READ_LEN), seeds[:n], threads=cores)
     rate = n / max(time.time() - t0, 1e-6)
-    n2 = int(min(reads.shape[0], max(n, rate * max_seconds * 0.6)))
+    n2 = int(min(reads.shape[0], 400_000, max(n, rate * max_seconds * 0.6)))  # OpenMP scaling is sub-linear: keep it bounded
     o.reset_coverage()
     t0 = time.time()
     o.map_reads(reads[:n2].reshape(-1), flat_offsets(n2, READ_LEN), seeds[:n2], threads=cores)
