@@ -9,7 +9,10 @@
 //   G/coverage/grouped_allele_counts_coverage.json and G/read_stats.json (parameters.cpp:94-105).
 // Host code here only parses, feeds and writes; mapping is done by the HIP engine through the C ABI (gmx.h).
 // The infer stage (genotyped.json / .vcf.gz / personalised reference) is outside this engine's scope.
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -25,6 +28,7 @@
 #include <random>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gmx.h"
@@ -154,6 +158,201 @@ bool encode_read(const std::string &s, std::vector<uint8_t> &out) {
   return true;
 }
 
+// ---- fast path: uncompressed four-line FASTQ, parsed by all host threads -------------------------------------
+// The kernels map ~800 M reads/s; one thread parsing FASTQ text feeds ~1 M reads/s. A plain FASTQ file whose
+// records are exactly four lines is memory-mapped and split into byte ranges; every thread finds the first record
+// start in its range (a line starting with '@' whose second next line starts with '+': a quality line starting
+// with '@' is followed by a header and a sequence line, never by '+') and encodes the records that start in it.
+// Anything else (gzip, FASTA, multi-line records, blank lines) returns false and takes the sequential reader.
+// Output = exactly what the sequential loop produces: bases 1..4 back to back, offsets, unencodable reads empty.
+struct ParsedReads {
+  std::vector<uint8_t> bases;
+  std::vector<uint64_t> offsets;  // n + 1
+};
+// Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
+// the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
+// Returns false on anything that is not plain four-line FASTQ.
+bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed) {
+  out.bases.clear();
+  out.offsets.assign(1, 0);
+  consumed = 0;
+  if (size == 0) return true;
+  if (d[0] != '@') return false;
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  struct Part {
+    std::vector<uint8_t> bases;
+    std::vector<uint32_t> lens;
+    bool bad = false;
+    size_t first = 0, stop = 0;  // start of the first record this range parsed, end of its last one
+  };
+  std::vector<Part> parts(T);
+  auto line_end = [&](size_t at) {  // index of the '\n' ending the line at `at`, or size
+    if (at >= size) return size;
+    const void *nl = memchr(d + at, '\n', size - at);
+    return nl ? (size_t)((const char *)nl - d) : size;
+  };
+  auto worker = [&](unsigned t) {
+    Part &p = parts[t];
+    size_t lo = size * t / T, hi = size * (t + 1) / T;
+    size_t at = lo;
+    if (t > 0) {  // first record start at or after lo (a record starting exactly at lo belongs to this range)
+      at = line_end(lo - 1) + 1;
+      for (int tries = 0; at < size; ++tries) {
+        size_t e1 = line_end(at), e2 = line_end(e1 + 1);
+        if (e2 >= size) {  // fewer than three lines left: nothing starts here that an earlier range does not own
+          at = size;
+          break;
+        }
+        if (d[at] == '@' && d[e2 + 1 < size ? e2 + 1 : e2] == '+' && e2 + 1 < size) break;
+        if (tries == 5) {
+          p.bad = true;
+          break;
+        }
+        at = e1 + 1;
+      }
+    }
+    p.bases.reserve((hi - lo) / 2 + 64);
+    p.first = at;
+    while (at < hi && at < size && !p.bad) {
+      const size_t e1 = line_end(at), s2 = e1 + 1, e2 = line_end(s2), s3 = e2 + 1, e3 = line_end(s3), s4 = e3 + 1,
+                   e4 = line_end(s4);
+      const bool complete = e3 < size && (e4 < size || (final && s4 <= size));
+      if (!complete) {
+        if (final) p.bad = true;  // truncated record
+        break;
+      }
+      size_t n = e2 - s2, nq = e4 - s4;
+      if (n && d[s2 + n - 1] == '\r') --n;
+      if (nq && d[s4 + nq - 1] == '\r') --nq;
+      if (d[at] != '@' || d[s3] != '+' || nq != n || n == 0) {  // blank / multi-line record: the sequential reader's job
+        p.bad = true;
+        break;
+      }
+      const size_t base_at = p.bases.size();
+      p.bases.resize(base_at + n);
+      bool valid = true;
+      for (size_t i = 0; i < n; ++i) {
+        uint8_t v;
+        switch (d[s2 + i]) {
+          case 'A': case 'a': v = 1; break;
+          case 'C': case 'c': v = 2; break;
+          case 'G': case 'g': v = 3; break;
+          case 'T': case 't': v = 4; break;
+          default: v = 0; valid = false; break;
+        }
+        p.bases[base_at + i] = v;
+      }
+      if (!valid) p.bases.resize(base_at);  // encode_dna_bases: the whole read is dropped (kept as an empty read)
+      p.lens.push_back(valid ? (uint32_t)n : 0u);
+      at = e4 < size ? e4 + 1 : size;
+    }
+    p.stop = at;
+  };
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
+    for (auto &th : pool) th.join();
+  }
+  for (auto &p : parts)
+    if (p.bad) return false;
+  // the ranges' records must chain into one gap-free prefix of the buffer; what follows it (an incomplete record, or
+  // records no range could recognise from inside) is left for the next block, where it sits at the start
+  size_t cursor = 0;
+  for (unsigned t = 0; t < T; ++t) {
+    if (parts[t].lens.empty()) continue;
+    if (parts[t].first != cursor) return false;
+    cursor = parts[t].stop;
+  }
+  if (final && cursor != size) return false;
+  consumed = cursor;
+  for (unsigned t = 0; t < T; ++t)  // drop what lies behind the prefix (cannot happen when the chain is intact)
+    if (!parts[t].lens.empty() && parts[t].first >= consumed) return false;
+  size_t n_reads = 0, n_bases = 0;
+  std::vector<size_t> r0(T), b0(T);
+  for (unsigned t = 0; t < T; ++t) {
+    r0[t] = n_reads;
+    b0[t] = n_bases;
+    n_reads += parts[t].lens.size();
+    n_bases += parts[t].bases.size();
+  }
+  out.bases.resize(n_bases);
+  out.offsets.resize(n_reads + 1);
+  {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; ++t)
+      pool.emplace_back([&, t]() {
+        if (!parts[t].bases.empty()) memcpy(out.bases.data() + b0[t], parts[t].bases.data(), parts[t].bases.size());
+        uint64_t off = b0[t];
+        for (size_t i = 0; i < parts[t].lens.size(); ++i) {
+          out.offsets[r0[t] + i] = off;
+          off += parts[t].lens[i];
+        }
+      });
+    for (auto &th : pool) th.join();
+  }
+  out.offsets[n_reads] = n_bases;
+  return true;
+}
+
+// A whole reads file through the fast path, block by block: plain files are memory-mapped (one block), gzip files are
+// inflated 256 MB at a time by this thread and parsed by all. `sink` receives every block's reads in file order.
+// Returns false — before anything was delivered — if the file is not plain four-line FASTQ.
+template <class Sink>
+bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  unsigned char magic[2] = {0, 0};
+  const bool gz = read(fd, magic, 2) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  struct stat sb;
+  const bool stat_ok = fstat(fd, &sb) == 0;
+  ParsedReads block;
+  size_t consumed = 0;
+  if (!gz) {
+    if (!stat_ok || sb.st_size == 0) {
+      close(fd);
+      return false;
+    }
+    const size_t size = (size_t)sb.st_size;
+    const char *d = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (d == MAP_FAILED) return false;
+    const bool ok = parse_fastq_buffer(d, size, true, threads, block, consumed);
+    munmap((void *)d, size);
+    if (ok) sink(block);
+    return ok;
+  }
+  close(fd);
+  gzFile g = gzopen(path.c_str(), "rb");
+  if (!g) return false;
+  gzbuffer(g, 1 << 20);
+  size_t kBlock = 256u << 20;
+  if (const char *eb = getenv("GMX_FASTQ_BLOCK")) kBlock = std::max<size_t>(64, (size_t)atoll(eb));  // tests: tiny blocks
+  std::vector<char> buf(kBlock + (1u << 20));
+  size_t have = 0;
+  bool first = true;
+  for (;;) {
+    while (have < kBlock) {
+      int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
+      if (got <= 0) break;
+      have += (size_t)got;
+    }
+    const bool final = gzeof(g) != 0 || have < kBlock;
+    if (!parse_fastq_buffer(buf.data(), have, final, threads, block, consumed) || (!final && consumed == 0)) {
+      gzclose(g);
+      if (first) return false;
+      die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(kBlock >> 20) +
+          " MB (multi-line or blank lines); decompress and reformat, or use a four-line FASTQ");
+    }
+    first = false;
+    sink(block);
+    memmove(buf.data(), buf.data() + consumed, have - consumed);
+    have -= consumed;
+    if (final) break;
+  }
+  gzclose(g);
+  return true;
+}
+
 struct ReadStats {  // include/genotype/read_stats.hpp
   double mean_cov_depth = -1, variance_cov_depth = -1;
   uint64_t num_sites_noCov = 0;
@@ -241,6 +440,43 @@ Args parse_sub(int argc, const char *const *argv, int from) {
   return a;
 }
 
+// `gram _parse_check FILE THREADS`: prints what each parser makes of FILE as "<name> <n_reads> <n_bases> <fnv1a>" (or
+// "fast declined"); the two lines must agree whenever the fast path accepts the file.
+int run_parse_check(const std::string &path, int threads) {
+  auto fnv = [](const ParsedReads &p) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) {
+      for (int i = 0; i < 8; ++i) {
+        h ^= (v >> (8 * i)) & 0xFF;
+        h *= 1099511628211ull;
+      }
+    };
+    for (auto o : p.offsets) mix(o);
+    for (auto b : p.bases) mix(b);
+    return h;
+  };
+  ParsedReads fast, slow;
+  fast.offsets.assign(1, 0);
+  auto collect = [&](const ParsedReads &block) {
+    const uint64_t base = fast.bases.size();
+    fast.bases.insert(fast.bases.end(), block.bases.begin(), block.bases.end());
+    for (size_t i = 1; i < block.offsets.size(); ++i) fast.offsets.push_back(base + block.offsets[i]);
+  };
+  if (parse_fastq_file(path, threads, collect))
+    std::cout << "fast " << fast.offsets.size() - 1 << " " << fast.bases.size() << " " << fnv(fast) << std::endl;
+  else
+    std::cout << "fast declined" << std::endl;
+  SeqReader reader(path);
+  SeqRecord rec;
+  slow.offsets.push_back(0);
+  while (reader.next(rec)) {
+    encode_read(rec.seq, slow.bases);
+    slow.offsets.push_back(slow.bases.size());
+  }
+  std::cout << "slow " << slow.offsets.size() - 1 << " " << slow.bases.size() << " " << fnv(slow) << std::endl;
+  return 0;
+}
+
 int run_build(const Args &a) {
   // The reference's `gram build` writes SDSL/Boost artefacts derived from gram_dir/prg (src/build/build.cpp:8-72).
   // This engine re-derives everything from `prg` at genotype time, so build only validates the PRG.
@@ -319,6 +555,25 @@ int run_genotype(const Args &a) {
   const uint64_t kChunkReads = 1u << 20;  // reads staged per engine call (multiple of 5000 not required: seeds are per read)
   uint64_t total_reads = 0;
   for (auto const &path : reads_paths) {
+    // fast path: seeds as the batch loop below draws them (5000 master draws per batch of <= 5000 reads, per file)
+    uint64_t in_file = 0;
+    std::vector<uint32_t> file_batch(kBatch), block_seeds;
+    auto sink = [&](const ParsedReads &block) {
+      const uint64_t n = block.offsets.size() - 1;
+      block_seeds.resize(n);
+      for (uint64_t i = 0; i < n; ++i, ++in_file) {
+        if (in_file % kBatch == 0)
+          for (auto &sd : file_batch) sd = (uint32_t)master();
+        block_seeds[i] = file_batch[in_file % kBatch];
+      }
+      const uint8_t *base_ptr = block.bases.empty() ? reinterpret_cast<const uint8_t *>("") : block.bases.data();
+      for (uint64_t done = 0; done < n; done += kChunkReads) {
+        const uint64_t m = std::min<uint64_t>(kChunkReads, n - done);
+        GMX_CHECK(gmx_map_reads_host(eng, base_ptr, block.offsets.data() + done, block_seeds.data() + done, m));
+      }
+      total_reads += n;
+    };
+    if (parse_fastq_file(path, max_threads, sink)) continue;
     SeqReader reader(path);
     SeqRecord rec;
     std::vector<uint8_t> bases;
@@ -493,6 +748,10 @@ int main(int argc, const char *const *argv) {
   if (help || command.empty()) {
     std::cout << kGlobalHelp << std::endl;
     return 0;
+  }
+  if (command == "_parse_check") {  // test hook: both read parsers on one file, no GPU (tests/test_gram_cli.py)
+    if (cmd_at + 2 >= argc) return 1;
+    return run_parse_check(argv[cmd_at + 1], atoi(argv[cmd_at + 2]));
   }
   if (command != "build" && command != "genotype" && command != "simulate") {
     std::cout << "Unrecognised command: " << command << std::endl;

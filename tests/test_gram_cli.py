@@ -108,3 +108,69 @@ def test_cli_files_equal_python_mirror_dumps(tmp_path):
     rs = json.loads((out / "read_stats.json").read_text())
     assert abs(rs["Read_depth"]["Mean"] - d["mean"]) < 1e-4 * max(1, d["mean"])
     assert rs["Read_depth"]["num_sites_total"] == d["num_sites_total"]
+
+
+def _parse_check(tmp_path, text, threads=4, name="r.fastq", binary=None):
+    import subprocess
+    from gramtools_amd.build import build_gram
+    path = tmp_path / name
+    path.write_bytes(binary if binary is not None else text.encode())
+    out = subprocess.run([build_gram(), "_parse_check", str(path), str(threads)], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0
+    return out.stdout.strip().splitlines()
+
+
+def test_parallel_fastq_parser_agrees_with_the_sequential_reader(tmp_path):
+    """The multi-threaded four-line FASTQ fast path of the `gram` executable against its general reader: quality
+    lines starting with '@' or '+', reads with N (dropped as a whole, kept as empty reads), CRLF line ends, a last
+    record without newline, and more threads than records."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(2000):
+        n = int(rng.integers(1, 300))
+        seq = "".join("ACGTacgtN"[int(x)] for x in rng.integers(0, 9 if i % 7 == 0 else 8, size=n))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 75, size=n))
+        if i % 5 == 0:
+            qual = "@" + qual[1:]
+        if i % 11 == 0:
+            qual = "+" + qual[1:]
+        recs.append(f"@read{i} extra\n{seq}\n+\n{qual}\n")
+    for threads in (1, 3, 16, 64):
+        lines = _parse_check(tmp_path, "".join(recs), threads)
+        assert lines[0].startswith("fast ") and lines[0][5:] == lines[1][5:], lines
+    crlf = "".join(recs[:50]).replace("\n", "\r\n")
+    lines = _parse_check(tmp_path, crlf, 4)
+    assert lines[0].startswith("fast ") and lines[0][5:] == lines[1][5:], lines
+    lines = _parse_check(tmp_path, "".join(recs[:7])[:-1], 64)  # no final newline, more threads than records
+    assert lines[0].startswith("fast ") and lines[0][5:] == lines[1][5:], lines
+
+
+def test_parallel_fastq_parser_declines_what_it_does_not_cover(tmp_path):
+    import gzip
+    fasta = ">a\nACGT\n>b\nGGCC\n"
+    assert _parse_check(tmp_path, fasta)[0] == "fast declined"
+    multi = "@a\nACGT\nACGT\n+\nIIII\nIIII\n"  # multi-line record
+    assert _parse_check(tmp_path, multi)[0] == "fast declined"
+    blank = "@a\nACGT\n+\nIIII\n\n@b\nAC\n+\nII\n"
+    assert _parse_check(tmp_path, blank, 1)[0] == "fast declined"
+    gz = gzip.compress(fasta.encode())
+    assert _parse_check(tmp_path, None, 2, name="r.fa.gz", binary=gz)[0] == "fast declined"
+
+
+def test_gzip_fastq_is_inflated_in_blocks_and_parsed_in_parallel(tmp_path, monkeypatch):
+    """Stream blocks far smaller than the file: records straddling block ends are carried over intact."""
+    import gzip
+    import numpy as np
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(3000):
+        n = int(rng.integers(1, 200))
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5 if i % 9 == 0 else 4, size=n))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 75, size=n))
+        recs.append(f"@r{i}\n{seq}\n+\n{'@' + qual[1:] if i % 4 == 0 else qual}\n")
+    gz = gzip.compress("".join(recs).encode())
+    for block in ("700", "4096", "100000"):
+        monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
+        lines = _parse_check(tmp_path, None, 5, name="r.fastq.gz", binary=gz)
+        assert lines[0].startswith("fast 3000 ") and lines[0][5:] == lines[1][5:], (block, lines)
