@@ -57,6 +57,8 @@ SYMBOLS = {
     "gmx_last_error": (C.c_char_p, []),
     "gmx_index_build": (C.c_int, [_u32p, _u64, _u32, C.c_int, C.POINTER(_vp)]),
     "gmx_index_build_from_file": (C.c_int, [C.c_char_p, _u32, C.c_int, C.POINTER(_vp)]),
+    "gmx_index_save": (C.c_int, [_vp, C.c_char_p]),
+    "gmx_index_load": (C.c_int, [C.c_char_p, C.c_char_p, _u32, C.POINTER(_vp)]),
     "gmx_index_destroy": (None, [_vp]),
     "gmx_index_get_info": (C.c_int, [_vp, C.POINTER(IndexInfo)]),
     "gmx_index_site_layout": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u32p, _i32p]),

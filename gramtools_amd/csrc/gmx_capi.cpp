@@ -88,6 +88,45 @@ int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads,
   }
 }
 
+int gmx_index_save(const gmx_index *ix, const char *path) {
+  if (!ix || !path) {
+    gmx_set_error("gmx_index_save: null argument");
+    return GMX_EINVAL;
+  }
+  try {
+    gmx::save_index(ix->h, path);
+    return GMX_OK;
+  } catch (std::exception const &e) {
+    gmx_set_error(e.what());
+    return GMX_EINVAL;
+  }
+}
+
+int gmx_index_load(const char *cache_path, const char *prg_path, uint32_t kmer_size, gmx_index **out) {
+  if (!cache_path || !prg_path || !out) {
+    gmx_set_error("gmx_index_load: null argument");
+    return GMX_EINVAL;
+  }
+  try {
+    auto prg = gmx::read_prg_file(prg_path);
+    gmx_index *ix = new gmx_index();
+    try {
+      gmx::load_index(cache_path, prg, kmer_size, ix->h);
+    } catch (...) {
+      delete ix;
+      throw;
+    }
+    *out = ix;
+    return GMX_OK;
+  } catch (std::bad_alloc const &) {
+    gmx_set_error("out of memory while loading the index cache");
+    return GMX_ENOMEM;
+  } catch (std::exception const &e) {
+    gmx_set_error(e.what());
+    return GMX_EINVAL;
+  }
+}
+
 void gmx_index_destroy(gmx_index *ix) { delete ix; }
 
 int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {

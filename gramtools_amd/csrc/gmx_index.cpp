@@ -941,4 +941,173 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code) {
   return v;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// index cache
+// ---------------------------------------------------------------------------------------
+namespace {
+const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
+const uint32_t kCacheVersion = 3;                   // bump on any change of the tables' layout or meaning
+
+uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint32_t x : v) {
+    h ^= x;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+struct Writer {
+  FILE *f;
+  void raw(const void *p, size_t n) {
+    if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("index cache: write failed");
+  }
+  template <class T>
+  void pod(const T &v) {
+    raw(&v, sizeof(T));
+  }
+  template <class T>
+  void vec(const std::vector<T> &v) {
+    pod<uint64_t>(v.size());
+    raw(v.data(), v.size() * sizeof(T));
+  }
+};
+struct Reader {
+  FILE *f;
+  void raw(void *p, size_t n) {
+    if (n && fread(p, 1, n, f) != n) throw std::runtime_error("index cache: truncated file");
+  }
+  template <class T>
+  void pod(T &v) {
+    raw(&v, sizeof(T));
+  }
+  template <class T>
+  void vec(std::vector<T> &v, uint64_t max_elems = (1ull << 36)) {
+    uint64_t n = 0;
+    pod(n);
+    if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
+    v.resize(n);
+    raw(v.data(), n * sizeof(T));
+  }
+};
+
+template <class IO, class H>
+void index_tables(IO &io, H &h) {  // one list of tables for both directions
+  io.vec(h.blocks);
+  io.vec(h.sa);
+  io.vec(h.hits);
+  io.vec(h.hit_perm);
+  io.vec(h.hit_prog);
+  io.vec(h.text);
+  io.vec(h.prog);
+  io.vec(h.pos_node);
+  io.vec(h.nodes);
+  io.vec(h.edges);
+  io.vec(h.sites);
+  io.vec(h.seeds);
+  io.vec(h.seed_words);
+  io.vec(h.kmer_bitmap);
+  io.vec(h.l_allele_off);
+  io.vec(h.l_grouped_off);
+  io.vec(h.l_cov_off);
+  io.vec(h.phys_allele);
+  io.vec(h.phys_pb);
+  io.vec(h.phys_grouped);
+  io.vec(h.bwt);
+  io.vec(h.pos_target);
+}
+}  // namespace
+
+void save_index(const HostIndex &h, const std::string &path) {
+  const std::string tmp = path + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) throw std::runtime_error("index cache: cannot write " + tmp);
+  try {
+    Writer w{f};
+    w.pod(kCacheMagic);
+    w.pod(kCacheVersion);
+    w.pod<uint64_t>(h.prg.size());
+    w.pod<uint64_t>(fnv1a_u32(h.prg));
+    w.pod(h.kmer_size);
+    w.pod(h.sentinel_pos);
+    w.raw(h.C, sizeof(h.C));
+    w.pod<uint32_t>(h.is_nested ? 1u : 0u);
+    w.pod(h.n_allele_slots);
+    w.pod(h.n_pb_slots);
+    w.pod(h.n_grouped_slots);
+    w.pod(h.n_acc_slots);
+    w.pod(h.n_seed_kmers_present);
+    w.pod(h.n_seed_states);
+    w.pod(h.n_seed_states_large);
+    index_tables(w, h);
+    // target_map: flattened (key, count, (id, deletion_allele) x count)
+    w.pod<uint64_t>(h.target_map.size());
+    for (auto const &e : h.target_map) {
+      w.pod(e.first);
+      w.vec(e.second);
+    }
+    w.pod(kCacheMagic);  // end mark
+  } catch (...) {
+    fclose(f);
+    remove(tmp.c_str());
+    throw;
+  }
+  if (fclose(f) != 0 || rename(tmp.c_str(), path.c_str()) != 0) {
+    remove(tmp.c_str());
+    throw std::runtime_error("index cache: cannot finish " + path);
+  }
+}
+
+void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) throw std::runtime_error("index cache: cannot open " + path);
+  try {
+    Reader r{f};
+    uint64_t magic = 0, n_prg = 0, hash = 0;
+    uint32_t version = 0, nested = 0;
+    r.pod(magic);
+    r.pod(version);
+    if (magic != kCacheMagic || version != kCacheVersion) throw std::runtime_error("index cache: not a version-" + std::to_string(kCacheVersion) + " cache file");
+    r.pod(n_prg);
+    r.pod(hash);
+    r.pod(out.kmer_size);
+    if (n_prg != prg.size() || hash != fnv1a_u32(prg)) throw std::runtime_error("index cache: built from a different PRG");
+    if (out.kmer_size != kmer_size) throw std::runtime_error("index cache: built for a different kmer_size");
+    r.pod(out.sentinel_pos);
+    r.raw(out.C, sizeof(out.C));
+    r.pod(nested);
+    out.is_nested = nested != 0;
+    r.pod(out.n_allele_slots);
+    r.pod(out.n_pb_slots);
+    r.pod(out.n_grouped_slots);
+    r.pod(out.n_acc_slots);
+    r.pod(out.n_seed_kmers_present);
+    r.pod(out.n_seed_states);
+    r.pod(out.n_seed_states_large);
+    index_tables(r, out);
+    uint64_t n_tm = 0;
+    r.pod(n_tm);
+    if (n_tm > prg.size() + 1) throw std::runtime_error("index cache: implausible table size");
+    out.target_map.resize(n_tm);
+    for (auto &e : out.target_map) {
+      r.pod(e.first);
+      r.vec(e.second);
+    }
+    uint64_t end = 0;
+    r.pod(end);
+    if (end != kCacheMagic) throw std::runtime_error("index cache: damaged file");
+    out.prg = prg;
+    // cheap structural checks against damage that keeps the sizes
+    if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||
+        out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
+        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots)
+      throw std::runtime_error("index cache: inconsistent tables");
+  } catch (...) {
+    fclose(f);
+    throw;
+  }
+  fclose(f);
+}
+
 }  // namespace gmx

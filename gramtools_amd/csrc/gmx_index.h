@@ -64,6 +64,12 @@ void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t>
 // kmer_size == 0 skips the seed table. threads <= 0 uses all hardware threads for the seed table.
 void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads = 0);
 
+// Index cache: everything build_index derives, as one flat file, so that `gram genotype` starts with
+// a read + H2D instead of SA construction and the seed-table enumeration. The file is tied to the PRG it was built
+// from (length + FNV-1a of the symbols) and to k; load_index throws std::runtime_error on any mismatch or damage.
+void save_index(const HostIndex &h, const std::string &path);
+void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out);
+
 // gram_dir/prg reader: little-endian uint32 per symbol (linearised_prg.cpp:8-45).
 std::vector<uint32_t> read_prg_file(const std::string &path);
 

@@ -479,15 +479,22 @@ int run_parse_check(const std::string &path, int threads) {
 
 int run_build(const Args &a) {
   // The reference's `gram build` writes SDSL/Boost artefacts derived from gram_dir/prg (src/build/build.cpp:8-72).
-  // This engine re-derives everything from `prg` at genotype time, so build only validates the PRG.
+  // This engine derives its own tables from `prg`; build validates the PRG and leaves them in gram_dir as one cache
+  // file that `gram genotype` loads instead of rebuilding (it rebuilds in memory when the file is absent or stale).
   std::string gram_dir = a.one("gram_dir");
   uint32_t k = a.has("kmer_size") ? (uint32_t)std::stoul(a.one("kmer_size")) : 0;
+  int threads = a.has("max_threads") ? std::stoi(a.one("max_threads")) : 0;
   gmx_index *ix = nullptr;
-  GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), k, 0, &ix));
+  GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), k, threads, &ix));
   gmx_index_info info;
   gmx_index_get_info(ix, &info);
   std::cout << "PRG ok: " << info.n_text - 1 << " symbols, " << info.n_sites << " variant sites, " << info.n_kmers_present
             << " indexed kmers" << std::endl;
+  if (k > 0) {
+    const std::string cache = join(gram_dir, "gmx_index.k" + std::to_string(k) + ".bin");
+    GMX_CHECK(gmx_index_save(ix, cache.c_str()));
+    std::cout << "Wrote index cache " << cache << std::endl;
+  }
   gmx_index_destroy(ix);
   return 0;
 }
@@ -530,7 +537,13 @@ int run_genotype(const Args &a) {
   auto t0 = clk::now();
   std::cout << "Loading PRG data" << std::endl;
   gmx_index *ix = nullptr;
-  GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), kmer_size, max_threads, &ix));
+  {  // the index cache `gram build` leaves in gram_dir (gmx_index.k<K>.bin); rebuilt in memory when absent or stale
+    const std::string cache = join(gram_dir, "gmx_index.k" + std::to_string(kmer_size) + ".bin");
+    if (gmx_index_load(cache.c_str(), join(gram_dir, "prg").c_str(), kmer_size, &ix) == GMX_OK)
+      std::cout << "Loaded index cache " << cache << std::endl;
+    else
+      GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), kmer_size, max_threads, &ix));
+  }
   gmx_index_info info;
   GMX_CHECK(gmx_index_get_info(ix, &info));
   std::cout << "Loading kmer index data" << std::endl;

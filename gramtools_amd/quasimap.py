@@ -50,10 +50,20 @@ def master_seeds(master_seed: int, reads_per_file) -> np.ndarray:
 class Index:
     """Everything the mapping path needs, derived from the integer PRG and the k-mer size."""
 
-    def __init__(self, prg, kmer_size: int, threads: int = 0):
+    def __init__(self, prg, kmer_size: int, threads: int = 0, cache: str = None):
+        """`prg`: integer PRG (array) or the path of gram_dir/prg. With `cache` (and a prg path) the index is loaded
+        from that cache file when it matches the PRG and k (gmx_index_load), else built."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
-        if isinstance(prg, (str, bytes)):
+        self.from_cache = False
+        if cache is not None and isinstance(prg, (str, bytes)):
+            path = prg if isinstance(prg, bytes) else prg.encode()
+            rc = self.lib.gmx_index_load(cache.encode(), path, kmer_size, C.byref(self.h))
+            self.from_cache = rc == 0
+            if rc != 0:
+                self.h = C.c_void_p()
+                check(self.lib.gmx_index_build_from_file(path, kmer_size, threads, C.byref(self.h)))
+        elif isinstance(prg, (str, bytes)):
             path = prg if isinstance(prg, bytes) else prg.encode()
             check(self.lib.gmx_index_build_from_file(path, kmer_size, threads, C.byref(self.h)))
         else:
@@ -74,6 +84,10 @@ class Index:
         check(self.lib.gmx_index_site_layout(self.h, _p(self.n_alleles, C.c_uint32), _p(self.allele_sum_off, C.c_uint32),
                                              _p(self.grouped_off, C.c_uint32), _p(self.parent_site, C.c_uint32),
                                              _p(self.parent_allele, C.c_int32)))
+
+    def save(self, path: str):
+        """Write the index cache (gmx_index_save)."""
+        check(self.lib.gmx_index_save(self.h, path.encode()))
 
     def close(self):
         if getattr(self, "h", None):

@@ -39,6 +39,12 @@ const char *gmx_last_error(void);
  * PRG (gram_dir/prg, little-endian uint32 per symbol) and the k-mer size. */
 int gmx_index_build(const uint32_t *prg, uint64_t n_symbols, uint32_t kmer_size, int threads, gmx_index **out);
 int gmx_index_build_from_file(const char *prg_path, uint32_t kmer_size, int threads, gmx_index **out);
+/* Index cache (replaces what `gram build` leaves in gram_dir for the reference: fm_index, masks, kmer
+ * index files, cov_graph — build/build.cpp:8-72). gmx_index_save writes every derived table to one file;
+ * gmx_index_load reads it back after checking that it was built from the PRG at `prg_path` (length + hash of the
+ * symbols) with the same kmer_size; any mismatch or damage is GMX_EINVAL and the caller rebuilds. */
+int gmx_index_save(const gmx_index *ix, const char *path);
+int gmx_index_load(const char *cache_path, const char *prg_path, uint32_t kmer_size, gmx_index **out);
 void gmx_index_destroy(gmx_index *ix);
 
 typedef struct gmx_index_info {

@@ -36,6 +36,10 @@ print(f"wrote {fq}: {os.path.getsize(fq) / 1e6:.0f} MB in {time.time() - t0:.1f}
 out = os.path.join(tmp, "geno")
 cmd = [gram, "genotype", "--gram_dir", gram_dir, "--reads", fq, "--sample_id", "s", "--ploidy", "haploid", "--kmer_size", "10",
        "--genotype_dir", out, "--max_threads", "16", "--seed", "42"]
+if "--cache" in sys.argv:
+    t0 = time.time()
+    b = subprocess.run([gram, "build", "--gram_dir", gram_dir, "--kmer_size", "10"], stdout=subprocess.PIPE, text=True)
+    print(b.stdout.strip().splitlines()[-1], f"({time.time() - t0:.2f} s)", flush=True)
 t0 = time.time()
 p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 dt = time.time() - t0
