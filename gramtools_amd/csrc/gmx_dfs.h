@@ -77,25 +77,6 @@ GMX_HD void gmx_dfs_push_hits(const GmxIndexView &ix, uint32_t lo, uint32_t hi, 
   }
 }
 
-// 64 raw bytes, fetched from a per-lane address; only ever indexed with constants (stays in registers)
-struct GmxLine {
-  uint32_t w[16];
-};
-GMX_HD GmxRankBlock gmx_line_as_block(const GmxLine &l) {
-  GmxRankBlock b;
-  b.cnt[0] = l.w[0];
-  b.cnt[1] = l.w[1];
-  b.cnt[2] = l.w[2];
-  b.cnt[3] = l.w[3];
-  b.lo[0] = (uint64_t)l.w[4] | ((uint64_t)l.w[5] << 32);
-  b.lo[1] = (uint64_t)l.w[6] | ((uint64_t)l.w[7] << 32);
-  b.hi[0] = (uint64_t)l.w[8] | ((uint64_t)l.w[9] << 32);
-  b.hi[1] = (uint64_t)l.w[10] | ((uint64_t)l.w[11] << 32);
-  b.mk[0] = (uint64_t)l.w[12] | ((uint64_t)l.w[13] << 32);
-  b.mk[1] = (uint64_t)l.w[14] | ((uint64_t)l.w[15] << 32);
-  return b;
-}
-
 // The lane's current entry.
 struct GmxLane {
   uint32_t a, b, tvd, tvg, pos, mode;

@@ -603,60 +603,7 @@ struct SearchOut {
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
 };
 
-// Appends `value` of every lane with `want` to a device list: the block's lanes are ranked with ballots, the
-// block reserves its range with ONE atomic (31 k blocks x 4 lists of per-wave atomics on one cache line made the
-// probe kernel atomic-bound). Must be called by all threads of the block.
-__device__ __forceinline__ void block_append(uint32_t *list, uint32_t *counter, bool want, uint32_t value) {
-  __shared__ uint32_t wave_cnt[GMX_BLOCK / 64];
-  __shared__ uint32_t block_base;
-  unsigned long long m = __ballot(want);
-  uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
-  __syncthreads();
-  uint32_t before = 0, total = 0;
-#pragma unroll
-  for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) {
-    uint32_t c = wave_cnt[w];
-    before += w < wave ? c : 0;
-    total += c;
-  }
-  if (threadIdx.x == 0 && total) block_base = atomicAdd(counter, total);
-  __syncthreads();
-  if (want) list[block_base + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
-  __syncthreads();  // block_base / wave_cnt are reused by the next call
-}
-
-// The same into one of GMX_REGIONS lists (list r at `lists + r * cap`, its counter GMX_CNT_STRIDE words after
-// the previous one): one barrier pair and one atomic per region and block.
 #define GMX_REGIONS 8
-__device__ __forceinline__ void block_append_regions(uint32_t *lists, uint32_t cap, uint32_t *counters, bool want,
-                                                     uint32_t region, uint32_t value) {
-  __shared__ uint32_t cnt[GMX_BLOCK / 64][GMX_REGIONS];
-  __shared__ uint32_t base[GMX_REGIONS];
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned long long mine = 0;
-#pragma unroll
-  for (uint32_t r = 0; r < GMX_REGIONS; ++r) {
-    const unsigned long long m = __ballot(want && region == r);
-    if (lane == 0) cnt[wave][r] = (uint32_t)__popcll(m);
-    if (region == r) mine = m;
-  }
-  __syncthreads();
-  if (threadIdx.x < GMX_REGIONS) {
-    uint32_t total = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += cnt[w][threadIdx.x];
-    base[threadIdx.x] = total ? atomicAdd(&counters[threadIdx.x * GMX_CNT_STRIDE], total) : 0;
-  }
-  __syncthreads();
-  if (want) {
-    uint32_t before = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) before += w < wave ? cnt[w][region] : 0;
-    lists[(size_t)region * cap + base[region] + before + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull))] = value;
-  }
-  __syncthreads();
-}
 
 __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
   uint32_t read = task >> 1;
@@ -1612,7 +1559,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
-  if (const char *x = getenv("GMX_EXTRA_LDS")) lds += (size_t)atoi(x);  // occupancy experiments
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));
