@@ -1,6 +1,7 @@
 // gmx_capi.cpp — host half of the C ABI: index construction, introspection, seeds, u16 finalisation.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -62,7 +63,9 @@ int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int thr
     gmx_index *ix = new gmx_index();
     std::vector<uint32_t> v(prg, prg + n);
     try {
-      gmx::build_index(v, kmer_size, ix->h, threads);
+      int k2 = -1;  // GMX_SEED_K2 in the environment: 0 disables the longer seed table, n forces its length
+      if (const char *e = getenv("GMX_SEED_K2")) k2 = atoi(e);
+      gmx::build_index(v, kmer_size, ix->h, threads, k2);
     } catch (...) {
       delete ix;
       throw;
@@ -142,7 +145,7 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
   o->n_kmers_present = h.n_seed_kmers_present;
   o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
-                   h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.nodes.size() * sizeof(GmxNode) +
+                   h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.seeds2.size() * sizeof(GmxSeed) + h.nodes.size() * sizeof(GmxNode) +
                    h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);
   return GMX_OK;
 }

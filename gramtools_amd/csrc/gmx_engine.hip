@@ -419,8 +419,9 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // CURSOR = false (engines whose index has hardly any large entry): every entry is pushed; one that does not fit
 // the stack overflows to the large-capacity pass.
 template <bool CURSOR>
-__device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, uint32_t code, FastCtx &ctx, uint32_t from) {
-  GmxSeed s = ix.seeds[code];
+__device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const GmxSeed *table, uint32_t code, FastCtx &ctx,
+                                                 uint32_t from) {
+  GmxSeed s = table[code];
   if (s.a != GMX_SEED_COMPLEX) {
     if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
     return;
@@ -745,10 +746,13 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     if (b.forward_only && r.rc) {
       status = GMX_STATUS_IGNORED;
     } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
-      const uint32_t k = ix.kmer_size;
+      // reads long enough are seeded from the longer table (gmx_index.cpp): fewer steps, and most reverse-complement
+      // tasks end here because their last k2-mer does not occur in the PRG
+      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
       const uint32_t from = r.len - k;
       const uint32_t stop = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
-      load_seed_cursor<CURSOR>(ix, last_kmer_code(r, k), ctx, from);
+      load_seed_cursor<CURSOR>(ix, longer ? ix.seeds2 : ix.seeds, last_kmer_code(r, k), ctx, from);
       run = ctx.status == GMX_TASK_MAPPED;
       status = ctx.status;
       done = stop == 0;
@@ -815,7 +819,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
     ctx.seed_left = CURSOR ? packed >> 16 : 0;
     if (ctx.seed_left) {
       ctx.seed_off = o.seed_cursor[task];
-      ctx.seed_pos = r.len - ix.kmer_size;
+      ctx.seed_pos = r.len - (ix.kmer_size2 != 0 && r.len >= ix.kmer_size2 ? ix.kmer_size2 : ix.kmer_size);
     }
     const GmxParked *parked = reinterpret_cast<const GmxParked *>(ctx.out);  // all read before the first emit overwrites them
     for (uint32_t s = 0; s < n; ++s) {
@@ -1427,6 +1431,8 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= e->upload(&v.edges, h.edges);
   rc |= e->upload(&v.sites, h.sites);
   rc |= e->upload(&v.seeds, h.seeds);
+  if (h.kmer_size2) rc |= e->upload(&v.seeds2, h.seeds2);
+  else v.seeds2 = nullptr;
   rc |= e->upload(&v.seed_words, h.seed_words);
   rc |= e->upload(&v.kmer_bitmap, h.kmer_bitmap);
   e->dview = v;

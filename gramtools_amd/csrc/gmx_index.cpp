@@ -460,12 +460,14 @@ GmxIndexView HostIndex::view() const {
   v.edges = edges.data();
   v.sites = sites.data();
   v.seeds = seeds.data();
+  v.seeds2 = seeds2.data();
+  v.kmer_size2 = kmer_size2;
   v.seed_words = seed_words.data();
   v.kmer_bitmap = kmer_bitmap.data();
   return v;
 }
 
-void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads) {
+void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads, int seed_k2) {
   out = HostIndex();
   out.prg = prg;
   out.kmer_size = kmer_size;
@@ -842,13 +844,16 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       }
   }
 
-  // --- seed table ---------------------------------------------------------------------
-  if (kmer_size > 0) {
-    if (kmer_size > 15) throw std::runtime_error("kmer_size > 15 is not supported");
-    const uint32_t k = kmer_size;
+  // --- seed tables -------------------------------------------------------------------
+  // The k-mer index of the reference (k = kmer_size) and, when it pays, the same construction continued to a longer
+  // k-mer (kmer_size2): the states after k2 matched bases are the states after k bases extended by k2 - k ordinary
+  // steps, so seeding the search from the longer table skips those steps — and a reverse-complement task whose
+  // last k2-mer does not occur in the PRG ends at the look-up. The final states of a read do not depend on k.
+  auto build_table = [&](uint32_t k, std::vector<GmxSeed> &seeds, std::vector<uint32_t> *bitmap, uint64_t &n_present,
+                         uint64_t &n_states_all, uint64_t &n_states_large) {
     const uint64_t n_kmers = 1ull << (2 * k);
-    out.seeds.assign(n_kmers, GmxSeed{1, 0});
-    out.kmer_bitmap.assign((n_kmers + 31) / 32, 0);
+    seeds.assign(n_kmers, GmxSeed{1, 0});
+    if (bitmap) bitmap->assign((n_kmers + 31) / 32, 0);
     GmxIndexView ix = out.view();
     // split the enumeration by the rightmost `split` bases
     uint32_t split = k >= 3 ? 3 : k;
@@ -894,6 +899,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       if (!e.empty()) throw std::runtime_error(e);
     // NB on the code convention: bit pair d (from the least significant end) holds the base at distance d
     // from the right end of the k-mer, i.e. the leftmost base is most significant.
+    n_present = n_states_all = n_states_large = 0;
     for (auto &vec : results)
       for (auto &o : vec) {
         GmxSeed s{o.a, o.b};
@@ -903,12 +909,28 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
           out.seed_words.insert(out.seed_words.end(), o.words.begin(), o.words.end());
           n_states = o.words.empty() ? 0 : o.words[0];
         }
-        out.n_seed_states += n_states;
-        if (n_states > 4) out.n_seed_states_large += n_states;
-        out.seeds[o.code] = s;
-        out.kmer_bitmap[o.code >> 5] |= 1u << (o.code & 31);
-        out.n_seed_kmers_present++;
+        n_states_all += n_states;
+        if (n_states > 4) n_states_large += n_states;
+        seeds[o.code] = s;
+        if (bitmap) (*bitmap)[o.code >> 5] |= 1u << (o.code & 31);
+        n_present++;
       }
+  };
+  out.kmer_size2 = 0;
+  out.seeds2.clear();
+  if (kmer_size > 0) {
+    if (kmer_size > 15) throw std::runtime_error("kmer_size > 15 is not supported");
+    build_table(kmer_size, out.seeds, &out.kmer_bitmap, out.n_seed_kmers_present, out.n_seed_states, out.n_seed_states_large);
+    // longer seeds: the smallest k2 > k whose k-mer space holds >= 8 x the PRG (a k2-mer then occurs ~0.1 times on
+    // average), if its direct-addressed table stays within 512 MB (k2 <= 13)
+    uint32_t k2 = seed_k2 < 0 ? kmer_size : (uint32_t)seed_k2;
+    if (seed_k2 < 0)
+      while (k2 < 13 && (1ull << (2 * k2)) < 8ull * (uint64_t)N) ++k2;
+    if (k2 > kmer_size && k2 <= 15) {
+      uint64_t present = 0;
+      build_table(k2, out.seeds2, nullptr, present, out.n_seed_states, out.n_seed_states_large);  // the table the kernels mostly use
+      out.kmer_size2 = k2;
+    }
     if (out.seed_words.empty()) out.seed_words.push_back(0);
   }
 }
@@ -947,7 +969,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code) {
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 3;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 4;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1006,6 +1028,7 @@ void index_tables(IO &io, H &h) {  // one list of tables for both directions
   io.vec(h.edges);
   io.vec(h.sites);
   io.vec(h.seeds);
+  io.vec(h.seeds2);
   io.vec(h.seed_words);
   io.vec(h.kmer_bitmap);
   io.vec(h.l_allele_off);
@@ -1030,6 +1053,7 @@ void save_index(const HostIndex &h, const std::string &path) {
     w.pod<uint64_t>(h.prg.size());
     w.pod<uint64_t>(fnv1a_u32(h.prg));
     w.pod(h.kmer_size);
+    w.pod(h.kmer_size2);
     w.pod(h.sentinel_pos);
     w.raw(h.C, sizeof(h.C));
     w.pod<uint32_t>(h.is_nested ? 1u : 0u);
@@ -1072,6 +1096,7 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     r.pod(n_prg);
     r.pod(hash);
     r.pod(out.kmer_size);
+    r.pod(out.kmer_size2);
     if (n_prg != prg.size() || hash != fnv1a_u32(prg)) throw std::runtime_error("index cache: built from a different PRG");
     if (out.kmer_size != kmer_size) throw std::runtime_error("index cache: built for a different kmer_size");
     r.pod(out.sentinel_pos);
@@ -1100,7 +1125,8 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     out.prg = prg;
     // cheap structural checks against damage that keeps the sizes
     if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||
-        out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
+        out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) ||
+        out.seeds2.size() != (out.kmer_size2 ? (1ull << (2 * out.kmer_size2)) : 0) || out.kmer_size2 > 15 || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
         out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots)
       throw std::runtime_error("index cache: inconsistent tables");
   } catch (...) {

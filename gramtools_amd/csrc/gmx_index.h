@@ -37,6 +37,8 @@ struct HostIndex {
   std::vector<uint32_t> edges;
   std::vector<GmxSite> sites;
   std::vector<GmxSeed> seeds;
+  uint32_t kmer_size2 = 0;      // longer seed table (0 = none): the same construction continued to k2 > kmer_size
+  std::vector<GmxSeed> seeds2;  // its 4^k2 entries; multi-state records share seed_words
   std::vector<uint32_t> seed_words;
   std::vector<uint32_t> kmer_bitmap;
   uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
@@ -62,7 +64,8 @@ void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t>
 // Builds everything. Throws std::runtime_error on an inconsistent PRG (same conditions as
 // PRG_String / cov_Graph_Builder: linearised_prg.cpp:52-80, coverage_graph.cpp:220-222,338-341).
 // kmer_size == 0 skips the seed table. threads <= 0 uses all hardware threads for the seed table.
-void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads = 0);
+// seed_k2: length of the longer seed table; -1 = choose from the PRG size, 0 (or <= kmer_size) = none.
+void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads = 0, int seed_k2 = -1);
 
 // Index cache: everything build_index derives, as one flat file, so that `gram genotype` starts with
 // a read + H2D instead of SA construction and the seed-table enumeration. The file is tied to the PRG it was built

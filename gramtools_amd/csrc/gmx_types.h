@@ -136,6 +136,7 @@ struct GmxIndexView {
   uint32_t n_prg;         // PRG length
   uint32_t sentinel_pos;  // BWT index holding the sentinel
   uint32_t kmer_size;
+  uint32_t kmer_size2;    // longer seed table (0 = none), used for reads of at least that length
   uint32_t C[8];          // C[1..4]: first SA index of each base
   uint32_t n_blocks;
   uint32_t n_hits;
@@ -158,6 +159,7 @@ struct GmxIndexView {
   const uint32_t *edges;
   const GmxSite *sites;       // [n_sites]
   const GmxSeed *seeds;       // [4^k]
+  const GmxSeed *seeds2;      // [4^k2] or null
   const uint32_t *seed_words;
   const uint32_t *kmer_bitmap;  // [4^k / 32] presence bits (all_read_kmers_occur_in_index, quasimap.cpp:212-225)
 };
