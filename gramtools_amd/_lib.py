@@ -14,7 +14,8 @@ class GmxError(RuntimeError):
 class IndexInfo(C.Structure):
     _fields_ = [("n_text", C.c_uint64), ("kmer_size", C.c_uint32), ("n_sites", C.c_uint32), ("is_nested", C.c_uint32),
                 ("n_allele_slots", C.c_uint32), ("n_per_base_slots", C.c_uint32), ("n_grouped_slots", C.c_uint32),
-                ("n_nodes", C.c_uint32), ("n_kmers_present", C.c_uint64), ("index_bytes", C.c_uint64)]
+                ("n_nodes", C.c_uint32), ("n_kmers_present", C.c_uint64), ("index_bytes", C.c_uint64),
+                ("kmer_size2", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class EngineOpts(C.Structure):
@@ -72,6 +73,7 @@ SYMBOLS = {
     "gmx_index_copy_pos_info": (C.c_int, [_vp, _i64p]),
     "gmx_index_copy_target_map": (_i64, [_vp, _i64p, _u64]),
     "gmx_index_seed_states": (_i64, [_vp, _u8p, _i64p, _u64]),
+    "gmx_index_seed_states_k": (_i64, [_vp, _u8p, _u32, _i64p, _u64]),
     "gmx_index_jump_states": (_i64, [_vp, _u32, _u32, _i64p, _u64]),
     "gmx_engine_default_opts": (None, [C.POINTER(EngineOpts)]),
     "gmx_engine_create": (C.c_int, [_vp, C.POINTER(EngineOpts), C.POINTER(_vp)]),

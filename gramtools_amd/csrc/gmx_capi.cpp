@@ -144,6 +144,7 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_grouped_slots = h.n_grouped_slots;
   o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
   o->n_kmers_present = h.n_seed_kmers_present;
+  o->kmer_size2 = h.kmer_size2;
   o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
                    h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.seeds2.size() * sizeof(GmxSeed) + h.nodes.size() * sizeof(GmxNode) +
                    h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);
@@ -355,14 +356,17 @@ int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t ca
   return (int64_t)v.size();
 }
 int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap) {
+  return gmx_index_seed_states_k(ix, kmer, ix->h.kmer_size, out, cap);
+}
+int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32_t len, int64_t *out, uint64_t cap) {
   const auto &h = ix->h;
-  if (h.kmer_size == 0) return GMX_EINVAL;
+  if (len == 0 || (len != h.kmer_size && len != h.kmer_size2)) return GMX_EINVAL;
   uint32_t code = 0;
-  for (uint32_t j = 0; j < h.kmer_size; ++j) {
+  for (uint32_t j = 0; j < len; ++j) {
     if (kmer[j] < 1 || kmer[j] > 4) return GMX_EINVAL;
     code = (code << 2) | (uint32_t)(kmer[j] - 1);
   }
-  auto v = gmx::seed_states_of(h, code);
+  auto v = gmx::seed_states_of(h, code, len != h.kmer_size);
   if (v.size() > cap) return -(int64_t)v.size();
   std::copy(v.begin(), v.end(), out);
   return (int64_t)v.size();

@@ -935,9 +935,9 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
 }
 
-std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code) {
+std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool longer_table) {
   std::vector<int64_t> v;
-  GmxSeed s = ix.seeds.at(code);
+  GmxSeed s = (longer_table ? ix.seeds2 : ix.seeds).at(code);
   if (s.a == 1 && s.b == 0) return {-1};
   if (s.a != GMX_SEED_COMPLEX) return {1, s.a, s.b, 0, 0};
   const uint32_t *p = ix.seed_words.data() + s.b;

@@ -78,6 +78,6 @@ std::vector<uint32_t> read_prg_file(const std::string &path);
 
 // Collects the k-mer index states of one k-mer from the seed table (test / debug helper).
 // Output format: [n_states, {lo, hi, n_traversed, (site, allele)*, n_traversing, (site, -1)*}*] or {-1} if absent.
-std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t kmer_code);
+std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t kmer_code, bool longer_table = false);
 
 }  // namespace gmx

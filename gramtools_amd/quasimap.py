@@ -169,9 +169,10 @@ class Index:
         return res
 
     def seed_states(self, kmer):
-        """k-mer index entry (build/kmer_index/build.cpp:101-131) or None when the k-mer is absent."""
+        """k-mer index entry (build/kmer_index/build.cpp:101-131) or None when the k-mer is absent. A k-mer of length
+        info.kmer_size2 is looked up in the longer seed table."""
         k = np.ascontiguousarray(kmer, dtype=np.uint8)
-        return self._unpack_states(self._states_call(self.lib.gmx_index_seed_states, _p(k, C.c_uint8)))
+        return self._unpack_states(self._states_call(self.lib.gmx_index_seed_states_k, _p(k, C.c_uint8), k.size))
 
     def bubble_order(self):
         out = np.zeros(max(self.n_sites, 1), dtype=np.uint32)

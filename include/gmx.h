@@ -58,6 +58,8 @@ typedef struct gmx_index_info {
   uint32_t n_nodes;
   uint64_t n_kmers_present;
   uint64_t index_bytes;      /* bytes uploaded to HBM by gmx_engine_create */
+  uint32_t kmer_size2;       /* length of the longer seed table the search is seeded from (0 = none); see DESIGN.md */
+  uint32_t reserved;
 } gmx_index_info;
 int gmx_index_get_info(const gmx_index *ix, gmx_index_info *out);
 
@@ -94,6 +96,8 @@ int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out);        /* per PR
                                                                           offset in node, target marker, target allele */
 int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t cap); /* [n, {key, n_t, (id, del)*}*] */
 int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap);
+/* the same for a k-mer of length `len` = kmer_size or kmer_size2 (the longer seed table) */
+int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32_t len, int64_t *out, uint64_t cap);
         /* k-mer index entry: [n_states, {lo, hi, n_tvd, (site, allele)*, n_tvg, (site, -1)*}*] or [-1] if absent */
 int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int64_t *out, uint64_t cap);
         /* search_state_vBWT_jumps of a path-less state [lo, hi] (vBWT_jump.cpp:134-183), same format */

@@ -224,3 +224,19 @@ def test_device_accumulators_alias_as_torch_tensors_and_allreduce_in_place():
     assert (tripled.raw_per_base == 3 * before.raw_per_base).all()
     assert (tripled.raw_grouped == 3 * before.raw_grouped).all()
     assert tripled.stats.as_dict() == {k: 3 * v for k, v in before.stats.as_dict().items()}
+
+
+@pytest.mark.parametrize("k2", ["0", "12"])
+def test_results_do_not_depend_on_the_seed_table_length(monkeypatch, k2):
+    """The search is seeded from a longer k-mer table when the PRG is large enough; without it
+    (GMX_SEED_K2=0) or with another length the coverage is the same, and equal to the oracle's."""
+    prg, reads = _snp_workload(200000, 2700, 8000, 15, multi=0.05)
+    seeds = master_seeds(11, [8000])
+    offs = flat_offsets(8000, 150)
+    want = oracle_map(prg, 10, list(reads), seeds, threads=8)
+    monkeypatch.setenv("GMX_SEED_K2", k2)
+    ix = Index(prg, 10)
+    assert ix.info.kmer_size2 == (0 if k2 == "0" else int(k2))
+    qm = Quasimapper(ix)
+    qm.map_reads(reads.reshape(-1), offs, seeds)
+    assert canonical_cov(qm.coverage()) == want

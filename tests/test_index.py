@@ -58,6 +58,15 @@ def _check_index(prg, k):
             assert (a is None) == (b is None), km
             if a is not None:
                 assert _multiset(a) == _multiset(b), km
+    # the longer seed table == the reference's k-mer index for k2 (the same construction, continued)
+    k2 = ix.info.kmer_size2
+    if k2 and k2 <= 6:
+        o2 = Oracle(list(prg), k2)
+        for km in Oracle.all_kmers(k2):
+            a, b = ix.seed_states(km), o2.kmer_states(km)
+            assert (a is None) == (b is None), km
+            if a is not None:
+                assert _multiset(a) == _multiset(b), km
 
 
 GOLDEN_PRGS = sorted({tuple(prg_ints(c["prg"])) for _, c in all_cases() if not c.get("expect_build_error")})
