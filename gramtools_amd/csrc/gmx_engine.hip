@@ -841,10 +841,13 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
 
 // Phase 3 — tasks without a final state: all_read_kmers_occur_in_index decides between the
 // missing_kmer and no_extension counters (quasimap.cpp:168-186); it never affects coverage.
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
-  uint32_t n_dead = o.counters[6 * GMX_CNT_STRIDE];
-  if (blockIdx.x * GMX_BLOCK >= n_dead) return;
-  uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
+// Two passes over the dead-task queue: pass 0 = what the probe kernel left (its count is snapshot in counter [11]
+// before the extend kernel starts appending), run beside the extend kernel; pass 1 = the extend kernel's additions.
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, BatchView b, SearchOut o, int pass) {
+  const uint32_t begin = pass ? o.counters[11 * GMX_CNT_STRIDE] : 0;
+  const uint32_t n_dead = pass ? o.counters[6 * GMX_CNT_STRIDE] : o.counters[11 * GMX_CNT_STRIDE];
+  if (begin + blockIdx.x * GMX_BLOCK >= n_dead) return;
+  uint32_t slot = begin + blockIdx.x * GMX_BLOCK + threadIdx.x;
   if (slot >= n_dead) return;
   uint32_t task = o.dead_list[slot];
   ReadRef r = task_read(b, task);
@@ -856,14 +859,15 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
 // look-up per lane. One 1024-thread block per CU, persistent over the dead-task queue.
 #define GMX_FILTER_LDS_THREADS 1024
 __global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(GmxIndexView ix, BatchView b, SearchOut o,
-                                                                                 uint32_t n_words) {
-  const uint32_t n_dead = o.counters[6 * GMX_CNT_STRIDE];
-  if (blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
+                                                                                 uint32_t n_words, int pass) {
+  const uint32_t begin = pass ? o.counters[11 * GMX_CNT_STRIDE] : 0;
+  const uint32_t n_dead = pass ? o.counters[6 * GMX_CNT_STRIDE] : o.counters[11 * GMX_CNT_STRIDE];
+  if (begin + blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
   const uint4 *src = reinterpret_cast<const uint4 *>(ix.kmer_bitmap);
   uint4 *dst = reinterpret_cast<uint4 *>(gmx_lds);
   for (uint32_t i = threadIdx.x; i < n_words / 4; i += GMX_FILTER_LDS_THREADS) dst[i] = src[i];
   __syncthreads();
-  for (uint32_t slot = blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
+  for (uint32_t slot = begin + blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
        slot += gridDim.x * GMX_FILTER_LDS_THREADS) {
     uint32_t task = o.dead_list[slot];
     ReadRef r = task_read(b, task);
@@ -1536,6 +1540,14 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   return GMX_OK;
 }
 
+static void launch_filter(gmx_engine *e, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass) {
+  if (e->filter_lds_words)
+    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
+                       e->side_stream, e->dview, b, o, e->filter_lds_words, pass);
+  else
+    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o, pass);
+}
+
 static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                         uint64_t n_reads, uint64_t total_bases, hipStream_t stream) {
   if (n_reads == 0) return GMX_OK;
@@ -1580,12 +1592,15 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   else
     hipLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
-  // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel
-  // on a side stream while the extend kernel runs
+  // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel on a
+  // side stream while the extend kernel runs, and so is the k-mer filter of the tasks the probe kernel found dead
+  // (most reverse-complement tasks): their count is snapshot before the extend kernel appends its own
+  HIP_TRY(hipMemcpyAsync(e->d_counters + 11 * GMX_CNT_STRIDE, e->d_counters + 6 * GMX_CNT_STRIDE, 4, hipMemcpyDeviceToDevice, stream));
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
+  launch_filter(e, task_grid, b, o, 0);
   if (e->seed_cursor)
     hipLaunchKernelGGL(gmx_extend_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   else
@@ -1603,13 +1618,9 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side2_stream,
                      e->dview, b, o, e->big, acc);
   HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
-  // the k-mer filter (LDS + ALU) runs beside the coverage kernels (memory + atomics) on the first side stream
+  // second filter pass: the tasks the extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
-  if (e->filter_lds_words)
-    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
-                       e->side_stream, e->dview, b, o, e->filter_lds_words);
-  else
-    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o);
+  launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
