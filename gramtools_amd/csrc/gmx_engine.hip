@@ -598,8 +598,10 @@ struct SearchOut {
   uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
   uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
-  uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter
+  uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter: the probe kernel's (counter [6])
+  uint32_t *dead2_list;      // ... and the extend kernel's (counter [12]); one filter pass each
   uint32_t *seed_cursor;     // per task: word offset into seed_words of the next seed state (when n_final's bits 16.. > 0)
+  uint32_t *error;           // [0] = first error status, [1] = its task (persist until gmx_engine_sync reads them)
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
 };
@@ -638,8 +640,8 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       }
     } else if (status == GMX_TASK_OVERFLOW) {
       over = true;
-    } else if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, status) == 0u) {
-      o.counters[3 * GMX_CNT_STRIDE] = task;
+    } else if (atomicCAS(&o.error[0], 0u, status) == 0u) {
+      o.error[1] = task;
     }
   }
   if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
@@ -692,7 +694,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
-    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? 5u : c == Q_DEAD ? 6u : 8u;
+    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? 5u : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
     q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
@@ -707,7 +709,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     } else {
       uint32_t *list = cat == Q_OVER ? (second_phase ? o.overflow2_list : o.overflow_list)
                        : cat == Q_ALIVE ? o.alive_list
-                       : cat == Q_DEAD  ? o.dead_list
+                       : cat == Q_DEAD  ? (second_phase ? o.dead2_list : o.dead_list)
                                         : o.cover_general_list;
       list[at] = task;
     }
@@ -841,15 +843,13 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
 
 // Phase 3 — tasks without a final state: all_read_kmers_occur_in_index decides between the
 // missing_kmer and no_extension counters (quasimap.cpp:168-186); it never affects coverage.
-// Two passes over the dead-task queue: pass 0 = what the probe kernel left (its count is snapshot in counter [11]
-// before the extend kernel starts appending), run beside the extend kernel; pass 1 = the extend kernel's additions.
+// Two passes: pass 0 = the probe kernel's dead tasks, run beside the extend kernel; pass 1 = the extend kernel's.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, BatchView b, SearchOut o, int pass) {
-  const uint32_t begin = pass ? o.counters[11 * GMX_CNT_STRIDE] : 0;
-  const uint32_t n_dead = pass ? o.counters[6 * GMX_CNT_STRIDE] : o.counters[11 * GMX_CNT_STRIDE];
-  if (begin + blockIdx.x * GMX_BLOCK >= n_dead) return;
-  uint32_t slot = begin + blockIdx.x * GMX_BLOCK + threadIdx.x;
+  const uint32_t n_dead = o.counters[(pass ? 12 : 6) * GMX_CNT_STRIDE];
+  if (blockIdx.x * GMX_BLOCK >= n_dead) return;
+  uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   if (slot >= n_dead) return;
-  uint32_t task = o.dead_list[slot];
+  uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
   ReadRef r = task_read(b, task);
   o.status[task] = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
 }
@@ -860,16 +860,15 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
 #define GMX_FILTER_LDS_THREADS 1024
 __global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(GmxIndexView ix, BatchView b, SearchOut o,
                                                                                  uint32_t n_words, int pass) {
-  const uint32_t begin = pass ? o.counters[11 * GMX_CNT_STRIDE] : 0;
-  const uint32_t n_dead = pass ? o.counters[6 * GMX_CNT_STRIDE] : o.counters[11 * GMX_CNT_STRIDE];
-  if (begin + blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
+  const uint32_t n_dead = o.counters[(pass ? 12 : 6) * GMX_CNT_STRIDE];
+  if (blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
   const uint4 *src = reinterpret_cast<const uint4 *>(ix.kmer_bitmap);
   uint4 *dst = reinterpret_cast<uint4 *>(gmx_lds);
   for (uint32_t i = threadIdx.x; i < n_words / 4; i += GMX_FILTER_LDS_THREADS) dst[i] = src[i];
   __syncthreads();
-  for (uint32_t slot = begin + blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
+  for (uint32_t slot = blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
        slot += gridDim.x * GMX_FILTER_LDS_THREADS) {
-    uint32_t task = o.dead_list[slot];
+    uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
     ReadRef r = task_read(b, task);
     o.status[task] = all_kmers_present(gmx_lds, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
   }
@@ -899,7 +898,7 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     uint32_t task = active ? queue[qi] : 0;
     const uint32_t slot = slot_base + qi;
     if (active && slot >= g.max_slots) {
-      if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, GMX_TASK_OVERFLOW) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
+      if (atomicCAS(&o.error[0], 0u, GMX_TASK_OVERFLOW) == 0u) o.error[1] = task;
       active = false;
     }
     BigCtx ctx;
@@ -936,8 +935,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     if (status == GMX_TASK_MAPPED) {
       nf = ctx.n_out;
       if (nf == 0) status = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
-    } else if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, status) == 0u) {
-      o.counters[3 * GMX_CNT_STRIDE] = task;
+    } else if (atomicCAS(&o.error[0], 0u, status) == 0u) {
+      o.error[1] = task;
     }
     o.status[task] = status;
     o.n_final[task] = nf;
@@ -1053,7 +1052,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     if (env.status == GMX_TASK_OVERFLOW && !BIG) {
       o.cover_overflow_list[atomicAdd(&o.counters[4 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status != GMX_TASK_MAPPED) {
-      if (atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u) o.counters[3 * GMX_CNT_STRIDE] = task;
+      if (atomicCAS(&o.error[0], 0u, env.status) == 0u) o.error[1] = task;
     }
   }
 }
@@ -1119,8 +1118,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   env.log_at = 0;
   const GmxFinalState st{env.rec.p, GMX_TEXT_MARK, env.n_trav() ? 0u : GMX_NIL, env.rec.tvg};
   gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
-  if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.counters[2 * GMX_CNT_STRIDE], 0u, env.status) == 0u)
-    o.counters[3 * GMX_CNT_STRIDE] = o.cover_rec_task[(size_t)region * o.region_cap + m];
+  if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u)
+    o.error[1] = o.cover_rec_task[(size_t)region * o.region_cap + m];
 }
 
 // QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
@@ -1295,7 +1294,8 @@ struct gmx_engine {
   uint32_t *d_fused = nullptr, *d_limbs = nullptr;  // accumulator block (n_acc words, gmx_types.h) | 32 counter-limb words
   size_t n_fused = 0, n_acc = 0;
   std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;  // logical slot -> slot of the block (gmx_coverage_fetch)
-  unsigned long long *d_stats = nullptr;
+  unsigned long long *d_stats = nullptr;  // with d_log_cursor behind the coverage block: one memset resets all of it
+  uint32_t *d_error = nullptr;
   uint32_t *d_log = nullptr, *d_log_cursor = nullptr;
   uint32_t log_cap = 0;
   uint32_t n_allele = 0, n_pb = 0, n_grouped = 0;
@@ -1305,7 +1305,7 @@ struct gmx_engine {
   uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
-  uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_seed_cursor = nullptr;
+  uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
   GmxPathNode *d_arena = nullptr;
@@ -1384,6 +1384,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_dead2, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_seed_cursor, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
@@ -1446,16 +1447,17 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   {  // one contiguous block: a single all-reduce covers the whole coverage (gmx_coverage_device)
     e->n_acc = ((size_t)h.n_acc_slots + 63) / 64 * 64;
     e->n_fused = e->n_acc + 32;
-    rc |= e->alloc(&e->d_fused, e->n_fused, true);
+    rc |= e->alloc(&e->d_fused, e->n_fused + 32, true);  // + 16 words of read counters + log cursor
     e->d_limbs = e->d_fused ? e->d_fused + e->n_acc : nullptr;
+    e->d_stats = e->d_fused ? reinterpret_cast<unsigned long long *>(e->d_fused + e->n_fused) : nullptr;
+    e->d_log_cursor = e->d_fused ? e->d_fused + e->n_fused + 16 : nullptr;
+    rc |= e->alloc(&e->d_error, 2, true);
     e->phys_allele = h.phys_allele;
     e->phys_pb = h.phys_pb;
     e->phys_grouped = h.phys_grouped;
   }
-  rc |= e->alloc(&e->d_stats, 8, true);
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
-  rc |= e->alloc(&e->d_log_cursor, 4, true);
   rc |= e->alloc(&e->d_counters, 32 * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
@@ -1524,9 +1526,8 @@ void gmx_engine_destroy(gmx_engine *e) {
 int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(e->d_fused, 0, e->n_fused * 4));
-  HIP_TRY(hipMemset(e->d_stats, 0, 8 * 8));
-  HIP_TRY(hipMemset(e->d_log_cursor, 0, 16));
+  HIP_TRY(hipMemset(e->d_fused, 0, (e->n_fused + 32) * 4));
+  HIP_TRY(hipMemset(e->d_error, 0, 8));
   HIP_TRY(hipMemset(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4));
   return GMX_OK;
 }
@@ -1534,9 +1535,7 @@ int gmx_engine_reset(gmx_engine *e) {
 int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   HIP_TRY(hipSetDevice(e->opts.device));
   hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(hipMemsetAsync(e->d_fused, 0, e->n_fused * 4, st));
-  HIP_TRY(hipMemsetAsync(e->d_stats, 0, 8 * 8, st));
-  HIP_TRY(hipMemsetAsync(e->d_log_cursor, 0, 16, st));
+  HIP_TRY(hipMemsetAsync(e->d_fused, 0, (e->n_fused + 32) * 4, st));
   return GMX_OK;
 }
 
@@ -1568,12 +1567,9 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead, e->d_seed_cursor, e->d_counters};
+              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
-  // counters[0..1] are per batch; [2..3] (first error) persist until gmx_engine_sync reads them
-  // list counters 0,1,4,5,6 are per batch; 2,3 (first error) persist until gmx_engine_sync reads them
-  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 2 * GMX_CNT_STRIDE * 4, stream));
-  HIP_TRY(hipMemsetAsync(e->d_counters + 4 * GMX_CNT_STRIDE, 0, 28 * GMX_CNT_STRIDE * 4, stream));
+  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4, stream));  // all queue counters are per batch
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -1594,8 +1590,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
   // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel on a
   // side stream while the extend kernel runs, and so is the k-mer filter of the tasks the probe kernel found dead
-  // (most reverse-complement tasks): their count is snapshot before the extend kernel appends its own
-  HIP_TRY(hipMemcpyAsync(e->d_counters + 11 * GMX_CNT_STRIDE, e->d_counters + 6 * GMX_CNT_STRIDE, 4, hipMemcpyDeviceToDevice, stream));
+  // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
@@ -1702,13 +1697,10 @@ int gmx_engine_sync(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
-  uint32_t raw[4 * GMX_CNT_STRIDE];
-  HIP_TRY(hipMemcpy(raw, e->d_counters, sizeof(raw), hipMemcpyDeviceToHost));
-  uint32_t c[4] = {raw[0], raw[GMX_CNT_STRIDE], raw[2 * GMX_CNT_STRIDE], raw[3 * GMX_CNT_STRIDE]};
+  uint32_t c[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(c + 2, e->d_error, 8, hipMemcpyDeviceToHost));
   if (c[2] != 0) {
-    uint32_t zero[2] = {0, 0};
-    HIP_TRY(hipMemcpy(e->d_counters + 2 * GMX_CNT_STRIDE, zero, 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_counters + 3 * GMX_CNT_STRIDE, zero, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(e->d_error, 0, 8));
     char msg[256];
     if (c[2] == GMX_TASK_LOGFULL) {
       gmx_set_error("the grouped-allele-count log (sites with more than 5 alleles) is full; coverage is incomplete");
@@ -1776,7 +1768,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   for (int r = 0; r < GMX_REGIONS; ++r) out->mapped += c(16 + r);
   out->mapped += c(8);
   out->alive = c(5);
-  out->dead = c(6);
+  out->dead = c(6) + c(12);
   out->overflow_probe = c(1);
   out->overflow_extend = c(9);
   out->big_mapped = c(7);
