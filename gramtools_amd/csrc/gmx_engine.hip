@@ -1213,7 +1213,17 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
   if (span <= GMX_PACK_IN_BYTES) {  // block-uniform
     const uint4 *src = reinterpret_cast<const uint4 *>(g0 - shift);
     const uint32_t n16 = (uint32_t)((span + 15) >> 4);
-    for (uint32_t i = threadIdx.x; i < n16; i += GMX_PACK_READS) in4[i] = src[i];
+    {  // four independent 16-byte loads in flight per thread and round
+      uint32_t i = threadIdx.x;
+      for (; i + 3 * GMX_PACK_READS < n16; i += 4 * GMX_PACK_READS) {
+        const uint4 v0 = src[i], v1 = src[i + GMX_PACK_READS], v2 = src[i + 2 * GMX_PACK_READS], v3 = src[i + 3 * GMX_PACK_READS];
+        in4[i] = v0;
+        in4[i + GMX_PACK_READS] = v1;
+        in4[i + 2 * GMX_PACK_READS] = v2;
+        in4[i + 3 * GMX_PACK_READS] = v3;
+      }
+      for (; i < n16; i += GMX_PACK_READS) in4[i] = src[i];
+    }
     const uint64_t po0 = pack_off(b, r0);
     const uint32_t n_out = (uint32_t)(pack_off(b, r1) - po0);
     for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) outp[i] = make_uint2(0, 0);
