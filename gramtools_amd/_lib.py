@@ -31,7 +31,7 @@ class Stats(C.Structure):
 
 class QueueCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("mapped", "alive", "dead", "overflow_probe", "overflow_extend", "big_mapped",
-                                          "cover_general", "cover_overflow", "seed_cursor")]
+                                          "cover_general", "cover_mid", "cover_overflow", "seed_cursor")]
 
 
 class Timing(C.Structure):

@@ -596,6 +596,7 @@ struct SearchOut {
   uint32_t *overflow2_list;  // the same from the extend kernel; counter [9]
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
   uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
+  uint32_t *cover_mid_list;      // general tasks whose selection did not fit the LDS scratch; counter [13]
   uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter: the probe kernel's (counter [6])
@@ -957,12 +958,8 @@ struct CoverAcc {
   uint32_t *log;        // grouped log words
   uint32_t *log_cursor; // [0] = words used
   uint32_t log_cap;
-  uint32_t *scratch;    // GmxScratch words x n_lanes (lane-strided)
-  uint32_t n_lanes;
   uint32_t *scratch_big;
   uint32_t n_lanes_big;
-  uint32_t *scratch_side;  // regular-size scratch of the instance that follows the large-capacity search
-  uint32_t n_lanes_side;
   int rng_mode;
 };
 
@@ -1004,22 +1001,37 @@ struct CoverEnvT {
   }
 };
 
+typedef CoverEnvT<4, 4, 16, 16> CoverEnvLds;          // first tier of the general pass: per-lane scratch in the block's LDS
 typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
-// Three instances over three device-side queues (LIST):
-//   0  tasks finished by the probe / extend kernels that gmx_cover_single_kernel passed on, small per-lane scratch
-//   2  tasks finished by the large-capacity search (runs on the engine's side stream), small scratch
-//   1  entries of either whose selection exceeded the small scratch (nothing has been recorded for them yet),
-//      redone with the large scratch after both
+// Four instances over four device-side queues (LIST):
+//   3  tasks finished by the probe / extend kernels that gmx_cover_single_kernel passed on; scratch sized for the
+//      few instances and loci most such tasks have
+//   0  those whose selection exceeded it, regular scratch
+//   2  tasks finished by the large-capacity search (runs on the engine's side stream), regular scratch
+//   1  entries of 0 and 2 whose selection exceeded the regular scratch, redone with the large one after both
+// An entry that exceeds a scratch has recorded nothing yet.  The per-lane scratch of 3, 0 and 2 lives in the block's
+// LDS (a dependent chain of scratch accesses per task: LDS latency, not L2 latency, sets the pace); a block runs
+// gmx_cover_lds_lanes<Env>() lanes, as many as copies of the scratch fit 64 KB.  Instance 1 uses global memory.
+template <class Env>
+constexpr uint32_t gmx_cover_lds_lanes() {
+  return GmxScratch<Env>::total * 64 * sizeof(uint32_t) <= 64 * 1024 ? 64u : 16u;
+}
 template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
   constexpr bool BIG = LIST == 1;
-  uint32_t n_mapped = o.counters[(LIST == 0 ? 8 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
-  const uint32_t *list = LIST == 0 ? o.cover_general_list : LIST == 1 ? o.cover_overflow_list : o.big_mapped_list;
-  uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
-  for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * blockDim.x) {
+  constexpr bool LDS = LIST != 1;
+  constexpr uint32_t LANES = LDS ? gmx_cover_lds_lanes<Env>() : 64u;  // active lanes of a block (blockDim.x is 64)
+  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  const uint32_t *list = LIST == 3   ? o.cover_general_list
+                         : LIST == 0 ? o.cover_mid_list
+                         : LIST == 1 ? o.cover_overflow_list
+                                     : o.big_mapped_list;
+  if (threadIdx.x >= LANES) return;
+  uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
+  for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * LANES) {
     uint32_t entry = list[m];
     uint32_t task, nf;
     const GmxFinalState *finals;
@@ -1039,8 +1051,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     uint32_t read = task >> 1;
     uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
     Env env;
-    env.scratch = (LIST == 0 ? acc.scratch : LIST == 1 ? acc.scratch_big : acc.scratch_side) + lane_id;
-    env.stride = LIST == 0 ? acc.n_lanes : LIST == 1 ? acc.n_lanes_big : acc.n_lanes_side;
+    env.scratch = LDS ? gmx_lds + threadIdx.x : acc.scratch_big + lane_id;
+    env.stride = LDS ? LANES : acc.n_lanes_big;
     env.arena = arena;
     env.acc = acc.acc;
     env.log = acc.log;
@@ -1049,7 +1061,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     env.status = GMX_TASK_MAPPED;
     env.log_at = 0;
     gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
-    if (env.status == GMX_TASK_OVERFLOW && !BIG) {
+    if (env.status == GMX_TASK_OVERFLOW && LIST == 3) {  // nothing has been recorded for it yet: next scratch size
+      o.cover_mid_list[atomicAdd(&o.counters[13 * GMX_CNT_STRIDE], 1u)] = entry;
+    } else if (env.status == GMX_TASK_OVERFLOW && !BIG) {
       o.cover_overflow_list[atomicAdd(&o.counters[4 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status != GMX_TASK_MAPPED) {
       if (atomicCAS(&o.error[0], 0u, env.status) == 0u) o.error[1] = task;
@@ -1321,9 +1335,9 @@ struct gmx_engine {
   GmxPathNode *d_arena = nullptr;
   GmxCoverRec *d_cover_recs = nullptr;
   BigOut big{};
-  uint32_t *d_scratch = nullptr, *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
-  uint32_t cover_blocks = 0, cover_big_lanes = 0, cover_side_blocks = 0;
-  uint32_t *d_scratch_side = nullptr, *d_big_mapped = nullptr, *d_cover_general = nullptr, *d_overflow2 = nullptr;
+  uint32_t *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
+  uint32_t cover_big_lanes = 0;
+  uint32_t *d_big_mapped = nullptr, *d_cover_general = nullptr, *d_cover_mid = nullptr, *d_overflow2 = nullptr;
   hipStream_t side2_stream = nullptr;
   hipEvent_t ev_fork2 = nullptr, ev_side1 = nullptr, ev_filter = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
@@ -1366,6 +1380,15 @@ struct gmx_engine {
   }
 };
 
+// A coverage instance with its scratch in LDS: one wave per block, as many blocks per CU as scratch copies fit its LDS.
+template <class Env, int LIST>
+static void launch_cover_lds(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc) {
+  const size_t lds = (size_t)GmxScratch<Env>::total * gmx_cover_lds_lanes<Env>() * sizeof(uint32_t);
+  const uint32_t per_cu = (uint32_t)(160 * 1024 / lds);
+  hipLaunchKernelGGL((gmx_cover_kernel<Env, LIST>), dim3(e->n_cus * per_cu), dim3(64), lds, stream, e->dview, b, o, e->big,
+                     acc);
+}
+
 extern "C" {
 
 void gmx_engine_default_opts(gmx_engine_opts *o) {
@@ -1392,6 +1415,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_overflow2, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_cover_mid, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_dead2, n_tasks, false))) return rc;
@@ -1478,9 +1502,6 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
   rc |= e->alloc(&e->big.n_final, e->big.max_slots, false);
   rc |= e->alloc(&e->big.task_of_slot, e->big.max_slots, false);
-  // coverage scratch
-  e->cover_blocks = 1024;
-  rc |= e->alloc(&e->d_scratch, (size_t)GmxScratch<CoverEnv>::total * e->cover_blocks * GMX_BLOCK, false);
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, opts.device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1498,8 +1519,6 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // the rare large entry goes to the large-capacity pass
   e->seed_cursor = h.n_seed_states_large * 10 > h.n_seed_states;
   if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
-  e->cover_side_blocks = 32;
-  rc |= e->alloc(&e->d_scratch_side, (size_t)GmxScratch<CoverEnv>::total * e->cover_side_blocks * GMX_BLOCK, false);
   rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
@@ -1577,7 +1596,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters};
+              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4, stream));  // all queue counters are per batch
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
@@ -1611,25 +1630,22 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   else
     hipLaunchKernelGGL(gmx_extend_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
-  CoverAcc acc{e->d_fused,           e->d_log,          e->d_log_cursor,  e->log_cap,
-               e->d_scratch,    e->cover_blocks * GMX_BLOCK, e->d_scratch_big, e->cover_big_lanes,
-               e->d_scratch_side, e->cover_side_blocks * GMX_BLOCK, e->opts.rng_mode};
+  CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 2>), dim3(e->cover_side_blocks), dim3(GMX_BLOCK), 0, e->side2_stream,
-                     e->dview, b, o, e->big, acc);
+  launch_cover_lds<CoverEnv, 2>(e, e->side2_stream, b, o, acc);
   HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
   // second filter pass: the tasks the extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
   launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnv, 0>), dim3(e->cover_blocks), dim3(GMX_BLOCK), 0, stream, e->dview, b,
-                     o, e->big, acc);
+  launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc);
+  launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
@@ -1783,6 +1799,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->overflow_extend = c(9);
   out->big_mapped = c(7);
   out->cover_general = c(8);
+  out->cover_mid = c(13);
   out->cover_overflow = c(4);
   out->seed_cursor = e->seed_cursor ? 1 : 0;
   return GMX_OK;

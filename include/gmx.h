@@ -159,8 +159,9 @@ typedef struct gmx_queue_counts {
   uint64_t overflow_probe;    /* tasks that overflowed the per-lane pools in the probe kernel */
   uint64_t overflow_extend;   /* ... in the extend kernel */
   uint64_t big_mapped;        /* large-capacity tasks with final states */
-  uint64_t cover_general;     /* mapped tasks that needed the general coverage kernel */
-  uint64_t cover_overflow;    /* ... and its large scratch */
+  uint64_t cover_general;     /* mapped tasks that needed the general coverage kernel (first tier: scratch in LDS) */
+  uint64_t cover_mid;         /* ... of which those that needed its global-memory scratch */
+  uint64_t cover_overflow;    /* ... and those (large-capacity tasks included) that needed the large scratch */
   uint64_t seed_cursor;       /* 1: the engine runs the seed-cursor kernels (index with many multi-state k-mer entries) */
 } gmx_queue_counts;
 int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out);
