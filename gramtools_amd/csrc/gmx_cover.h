@@ -419,7 +419,7 @@ GMX_HD bool gmx_item_per_base(const GmxIndexView &ix, Env &env, uint32_t it, uin
 }
 
 // ---------------------------------------------------------------------------
-// The common case, without scratch: ONE final state of interval width one on a non-nested PRG.
+// The common case, without scratch: ONE final state of interval width one (this routine: on a non-nested PRG).
 // There is one item, hence one equivalence class and total == 1 (or only a non-variant
 // instance): the draw cannot change the outcome, the loci are the state's own path plus the
 // allele under SA[lo], and one DAG walk visits each node once, so the hull is the walk itself.
@@ -487,6 +487,101 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     if (!gmx_record_locus(ix, env, env.h_site(x), env.h_allele(x))) return;
 }
 
+// The same on a nested PRG. The item's loci are the sites of its path AND their ancestors (assign_nested_locus,
+// coverage_common.cpp:34-51): every chain climbs until it meets a site the item already has, so each site appears
+// once, with the allele of the first chain that reached it — one allele per site, hence the same 64-bit update per
+// locus as above. The loci are gathered in registers BEFORE anything is recorded; more than GMX_SINGLE_LOCI of them
+// returns false with nothing recorded and the task takes the general routine.
+#define GMX_SINGLE_LOCI 8
+template <class Env>
+GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
+  const uint32_t tvd = st.traversed, tvg = st.traversing;
+  const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
+  const uint32_t node0 = ix.pos_node[p];
+  const GmxNode rec0 = ix.nodes[node0];
+  uint32_t l_site[GMX_SINGLE_LOCI];
+  int32_t l_allele[GMX_SINGLE_LOCI];
+  uint32_t n = 0;
+  bool full = false;
+  auto used = [&](uint32_t site) {
+    bool hit = false;
+#pragma unroll
+    for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i) hit = hit || (i < n && l_site[i] == site);
+    return hit;
+  };
+  auto add = [&](uint32_t site, int32_t allele) {
+    if (n >= env.single_loci()) {  // GMX_SINGLE_LOCI, or less in tests
+      full = true;
+      return;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i)
+      if (i == n) {
+        l_site[i] = site;
+        l_allele[i] = allele;
+      }
+    ++n;
+  };
+  auto climb = [&](uint32_t site, int32_t allele) {
+    while (!full && !used(site)) {
+      add(site, allele);
+      const GmxSite &s = ix.sites[(site - 5) >> 1];
+      if (s.parent_site == 0) break;
+      allele = s.parent_allele;
+      site = s.parent_site;
+    }
+  };
+  uint32_t enc_site = 0;
+  int32_t enc_allele = -1;
+  if (tvd == GMX_NIL && tvg == GMX_NIL) {
+    if (rec0.site == 0) return true;  // a non-variant instance only: nothing to record
+    enc_site = rec0.site;
+    enc_allele = rec0.allele;
+    climb(enc_site, enc_allele);
+  } else {
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {  // check_site_uniqueness (coverage_common.cpp:17-32)
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR), true;
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR), true;
+    }
+    for (uint32_t x = tvg; x != GMX_NIL; x = env.h_next(x)) {
+      uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR), true;
+    }
+    if (tvg != GMX_NIL) {  // assign_traversing_loci (:53-76): the innermost site with the allele under p, then its ancestors
+      const uint32_t seed_site = env.h_site(tvg);
+      add(seed_site, rec0.allele);
+      const GmxSite &ps = ix.sites[(seed_site - 5) >> 1];
+      if (ps.parent_site != 0) climb(ps.parent_site, ps.parent_allele);
+    }
+    uint32_t len = 0;  // assign_traversed_loci (:78-83): oldest first; the list head is the newest
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) ++len;
+    for (uint32_t d = len; d-- > 0;) {
+      uint32_t x = tvd;
+      for (uint32_t i = 0; i < d; ++i) x = env.h_next(x);
+      climb(env.h_site(x), env.h_allele(x));
+    }
+  }
+  if (full) return false;
+  GmxWalk w;
+  gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
+  for (;;) {
+    uint32_t node = gmx_walk_next(ix, env, w);
+    if (w.bad) return env.fail(GMX_TASK_ERROR), true;
+    if (node == GMX_NO_NODE) break;
+    if (w.rec.seq_len == 0) continue;
+    if (w.rec.cov_off == GMX_NO_COV) return env.fail(GMX_TASK_ERROR), true;
+    for (uint32_t i = w.start; i <= w.end; ++i) env.add_per_base(w.rec.cov_off + i);
+  }
+#pragma unroll
+  for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i)
+    if (i < n && !gmx_record_locus(ix, env, l_site[i], l_allele[i])) return true;
+  return true;
+}
+
 // ---------------------------------------------------------------------------
 // The whole recording step for one mapped task.
 // ---------------------------------------------------------------------------
@@ -494,9 +589,12 @@ template <class Env>
 GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState *finals, uint32_t n_final,
                            uint32_t read_len, uint32_t seed, int rng_mode) {
   typedef GmxScratch<Env> S;
-  if (n_final == 1 && !ix.is_nested && (finals[0].lo == finals[0].hi || gmx_text_form(finals[0].hi))) {
-    gmx_cover_single(ix, env, finals[0], read_len);
-    return;
+  if (n_final == 1 && (finals[0].lo == finals[0].hi || gmx_text_form(finals[0].hi))) {
+    if (!ix.is_nested) {
+      gmx_cover_single(ix, env, finals[0], read_len);
+      return;
+    }
+    if (gmx_cover_single_nested(ix, env, finals[0], read_len)) return;
   }
   // --- items: path-bearing states + allele-encapsulated positions (encapsulated_search.cpp:30-107) ---
   uint32_t n_items = 0;

@@ -649,7 +649,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     o.status[task] = status;
   // a mapped task with ONE text-form final state and a short path leaves as a compact record (GmxCoverRec)
   GmxCoverRec rec{0, 0, GMX_NIL, {0, 0, 0}, 0, 0};
-  bool compact = mapped && !ix.is_nested && ctx.n_out == 1 && ctx.first_pos != GMX_NIL && read_len < 0x10000u &&
+  bool compact = mapped && ctx.n_out == 1 && ctx.first_pos != GMX_NIL && read_len < 0x10000u &&
                  (ctx.first_tvg == GMX_NIL || gmx_h_inline(ctx.first_tvg));
   if (compact) {
     uint32_t n = 0, alleles[3] = {0, 0, 0};
@@ -978,6 +978,7 @@ struct CoverEnvT {
   __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
   __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
   __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+  __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
@@ -1030,8 +1031,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
                          : LIST == 1 ? o.cover_overflow_list
                                      : o.big_mapped_list;
   if (threadIdx.x >= LANES) return;
-  uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
-  for (uint32_t m = lane_id; m < n_mapped; m += gridDim.x * LANES) {
+  const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
+  // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
+  for (uint32_t m = threadIdx.x * gridDim.x + blockIdx.x; m < n_mapped; m += gridDim.x * LANES) {
     uint32_t entry = list[m];
     uint32_t task, nf;
     const GmxFinalState *finals;
@@ -1092,6 +1094,7 @@ struct CompactEnv {
     if (h & GMX_INLINE_FLAG) return GMX_NIL;
     return h + 1 < n_trav() ? h + 1 : GMX_NIL;
   }
+  __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
@@ -1116,7 +1119,7 @@ struct CompactEnv {
 };
 
 // The common case, one lane per compact record and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
-// final state of width one on a non-nested PRG. Few registers, a coalesced queue, region-local tables.
+// final state of width one. Few registers, a coalesced queue, region-local tables.
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
   const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
   const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
@@ -1131,7 +1134,11 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   env.status = GMX_TASK_MAPPED;
   env.log_at = 0;
   const GmxFinalState st{env.rec.p, GMX_TEXT_MARK, env.n_trav() ? 0u : GMX_NIL, env.rec.tvg};
-  gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
+  if (!ix.is_nested) {
+    gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
+  } else if (!gmx_cover_single_nested(ix, env, st, env.rec.len_n & 0xFFFFu)) {  // many loci: the general instance next
+    o.cover_general_list[atomicAdd(&o.counters[8 * GMX_CNT_STRIDE], 1u)] = o.cover_rec_task[(size_t)region * o.region_cap + m];
+  }
   if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u)
     o.error[1] = o.cover_rec_task[(size_t)region * o.region_cap + m];
 }

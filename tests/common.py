@@ -58,6 +58,7 @@ def _load_emu():
     lib.hostemu_create.restype = C.c_void_p
     lib.hostemu_create.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, C.c_uint64]
     lib.hostemu_destroy.argtypes = [C.c_void_p]
+    lib.hostemu_set_single_loci.argtypes = [C.c_void_p, C.c_uint32]
     lib.hostemu_map.restype = C.c_int
     lib.hostemu_map.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -69,7 +70,7 @@ def _load_emu():
 
 
 def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048,
-                return_raw=False):
+                return_raw=False, single_loci=None):
     """Runs the device headers on the host. Returns (canonical coverage, n_overflow_tasks, rc)."""
     lib = _load_emu()
     arr = np.ascontiguousarray(prg, dtype=np.uint32)
@@ -82,6 +83,8 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         if flat.size == 0:
             flat = np.zeros(1, dtype=np.uint8)
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if single_loci is not None:  # loci capacity of the nested single-instance routine (gmx_cover.h)
+            lib.hostemu_set_single_loci(h, single_loci)
         rc = lib.hostemu_map(h, flat.ctypes.data_as(C.POINTER(C.c_uint8)), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                              s.ctypes.data_as(C.POINTER(C.c_uint32)), offs.size - 1, fast_states, fast_arena, big_states,
                              big_arena)

@@ -106,6 +106,7 @@ struct Emu {
   int rng_mode = 0;
   uint32_t first_error = 0, error_task = 0;
   uint64_t n_overflow_tasks = 0, n_cover_overflow = 0;
+  uint32_t single_loci = GMX_SINGLE_LOCI;  // hostemu_set_single_loci: force the nested single-instance routine to give up
   std::string err;
 };
 
@@ -122,6 +123,7 @@ struct EmuEnvT {
   EmuEnvT() : scratch(GmxScratch<EmuEnvT>::total, 0xDEADBEEFu) {}
   uint32_t sget(uint32_t w) const { return scratch.at(w); }
   void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
+  uint32_t single_loci() const { return e->single_loci; }
   void add_allele_sum(uint32_t s) { e->acc.at(s)++; }
   void add_per_base(uint32_t s) { e->acc.at(s)++; }
   void add_grouped_dense(uint32_t s) { e->acc.at(s)++; }
@@ -282,6 +284,8 @@ void *hostemu_create(const uint32_t *prg, uint64_t n, uint32_t k, int rng_mode, 
 void hostemu_destroy(void *p) { delete (Emu *)p; }
 
 // Same two-tier flow as launch_batch(): fast pass (4 states / 24 arena nodes), large-capacity pass, cover, stats.
+void hostemu_set_single_loci(void *p, uint32_t n) { static_cast<Emu *>(p)->single_loci = n < GMX_SINGLE_LOCI ? n : GMX_SINGLE_LOCI; }
+
 int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads,
                 uint32_t fast_states, uint32_t fast_arena, uint32_t big_states, uint32_t big_arena) {
   Emu *e = (Emu *)p;

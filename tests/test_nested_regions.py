@@ -1,7 +1,8 @@
 """Nested PRGs at a size where the text-form steps, the general jump programs, parking and the tiers all take part:
 random sequence interleaved with 60-150 nested bracket regions (depth <= 3, empty alleles, adjacent sites), 100-200 bp
 reads from pre-drawn haplotypes, both orientations. Host emulation (not gpu) and the HIP path (gpu) against the
-oracle, bit-exact. Nested PRGs never take the single-instance coverage kernel."""
+oracle, bit-exact. Single-instance tasks take gmx_cover_single_nested (gmx_cover.h), which hands tasks with more loci
+than it holds to the general routine: run with capacities 0-2 as well, so that both routes are pinned."""
 import numpy as np
 import pytest
 
@@ -30,6 +31,15 @@ def test_host_emulation_matches_oracle(seed):
     assert rc == 0
     assert got == want
     assert want["stats"]["exact_mapped"] >= 250
+
+
+@pytest.mark.parametrize("single_loci", [0, 1, 2])
+def test_single_instance_routine_hands_over_to_the_general_one(single_loci):
+    prg, k, reads, seeds = _case(2, 60, 300)
+    want = oracle_map(prg, k, reads, seeds, threads=4)
+    got, _, rc = hostemu_map(prg, k, reads, seeds, single_loci=single_loci)
+    assert rc == 0
+    assert got == want
 
 
 @pytest.mark.gpu
