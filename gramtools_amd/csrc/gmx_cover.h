@@ -17,6 +17,7 @@
 //   static constexpr I_MAX, B_MAX, LOC_MAX, H_MAX                            capacities
 //   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot): +1 on a slot of the
 //        accumulator block (gmx_types.h: gmx_slot_*); add_allele_and_group(slot): +1 on slot and slot + 1 (one 64-bit add)
+//   void add_hit(uint32_t slot)                                             hit counter of a one-base allele (gmx_types.h)
 //   bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) / void log_grouped_id(int32_t) / void log_grouped_end()
 //   void fail(uint32_t status)
 //   uint32_t h_site(h) / int32_t h_allele(h) / uint32_t h_next(h)            path-list handles (arena nodes, inline handles, or a
@@ -269,8 +270,14 @@ struct GmxWalk {
   bool first;
   uint32_t start, end;
   bool bad;
+  // how the current node was reached: by consuming a traversed locus (via = its handle; n_consumed counts them), as
+  // the walk's first node (GMX_VIA_FIRST), or otherwise (GMX_VIA_OTHER)
+  uint32_t via;
+  uint32_t n_consumed;
 };
 #define GMX_NO_NODE 0xFFFFFFFFu
+#define GMX_VIA_OTHER 0xFFFFFFFFu
+#define GMX_VIA_FIRST 0xFFFFFFFEu
 
 GMX_HD void gmx_walk_init(const GmxIndexView &ix, GmxWalk &w, uint32_t p, uint32_t node, const GmxNode &rec,
                           uint32_t read_len, uint32_t tvd, uint32_t enc_site, int32_t enc_allele) {
@@ -285,6 +292,8 @@ GMX_HD void gmx_walk_init(const GmxIndexView &ix, GmxWalk &w, uint32_t p, uint32
   w.start = p - rec.first_pos;
   w.end = 0;
   w.bad = false;
+  w.via = GMX_VIA_OTHER;
+  w.n_consumed = 0;
 }
 GMX_HD void gmx_walk_update(GmxWalk &w) {  // update_coordinates :189-204
   uint32_t len = w.rec.seq_len;
@@ -302,6 +311,7 @@ GMX_HD void gmx_walk_update(GmxWalk &w) {  // update_coordinates :189-204
 template <class Env>
 GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  // go_to_next_site :168-187
   w.start = 0;
+  w.via = GMX_VIA_OTHER;
   while (w.rec.n_edges == 1) {
     if (w.remaining == 0) {
       w.node = GMX_NO_NODE;
@@ -328,6 +338,8 @@ GMX_HD void gmx_walk_next_site(const GmxIndexView &ix, Env &env, GmxWalk &w) {  
       return;
     }
     allele = env.h_allele(w.cursor);
+    w.via = w.cursor;
+    w.n_consumed++;
     w.cursor = env.h_next(w.cursor);
   }
   if (allele < 0 || (uint32_t)allele >= ne) {
@@ -345,6 +357,7 @@ GMX_HD uint32_t gmx_walk_next(const GmxIndexView &ix, Env &env, GmxWalk &w) {
     w.first = false;
     gmx_walk_update(w);
     if (w.bad) return GMX_NO_NODE;
+    w.via = GMX_VIA_FIRST;
     if (!gmx_in_bubble(w.rec)) gmx_walk_next_site(ix, env, w);
     if (w.node == GMX_NO_NODE) w.bad = true;  // the reference would dereference a null node here
     return w.bad ? GMX_NO_NODE : w.node;
@@ -468,6 +481,11 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
         if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
     }
   }
+  // A locus whose allele node carries a hit counter (gmx_types.h) is recorded by that one counter during the walk;
+  // `hit` has bit k set for the k-th traversed locus (newest first, the order the walk consumes them), bit 31 for the
+  // locus of the first node.
+  uint32_t hit = 0;
+  const uint32_t first_site = enc_site != 0 ? enc_site : tvg != GMX_NIL ? env.h_site(tvg) : 0u;
   GmxWalk w;
   gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
   for (;;) {
@@ -476,15 +494,28 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     if (node == GMX_NO_NODE) break;
     if (w.rec.seq_len == 0) continue;
     if (w.rec.cov_off == GMX_NO_COV) return env.fail(GMX_TASK_ERROR);
+    if (gmx_node_has_hit_counter(w.rec)) {
+      uint32_t bit = 0;
+      if (w.via == GMX_VIA_FIRST)
+        bit = w.rec.site == first_site ? 0x80000000u : 0u;
+      else if (w.via != GMX_VIA_OTHER && w.n_consumed <= 31 && env.h_site(w.via) == w.rec.site)
+        bit = 1u << (w.n_consumed - 1);
+      if (bit) {
+        hit |= bit;
+        env.add_hit(w.rec.cov_off + 1);
+        continue;
+      }
+    }
     for (uint32_t i = w.start; i <= w.end; ++i) env.add_per_base(w.rec.cov_off + i);
   }
   if (enc_site != 0) {
-    gmx_record_locus(ix, env, enc_site, enc_allele);
+    if (!(hit >> 31)) gmx_record_locus(ix, env, enc_site, enc_allele);
     return;
   }
-  if (tvg != GMX_NIL && !gmx_record_locus(ix, env, env.h_site(tvg), rec0.allele)) return;
-  for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x))
-    if (!gmx_record_locus(ix, env, env.h_site(x), env.h_allele(x))) return;
+  if (tvg != GMX_NIL && !(hit >> 31) && !gmx_record_locus(ix, env, env.h_site(tvg), rec0.allele)) return;
+  uint32_t k = 0;
+  for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x), ++k)
+    if (!(k < 31 && ((hit >> k) & 1u)) && !gmx_record_locus(ix, env, env.h_site(x), env.h_allele(x))) return;
 }
 
 // The same on a nested PRG. The item's loci are the sites of its path AND their ancestors (assign_nested_locus,
@@ -566,6 +597,7 @@ GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxF
     }
   }
   if (full) return false;
+  uint32_t hit = 0;  // loci recorded by a hit counter during the walk (gmx_types.h)
   GmxWalk w;
   gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
   for (;;) {
@@ -574,11 +606,22 @@ GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxF
     if (node == GMX_NO_NODE) break;
     if (w.rec.seq_len == 0) continue;
     if (w.rec.cov_off == GMX_NO_COV) return env.fail(GMX_TASK_ERROR), true;
+    if (gmx_node_has_hit_counter(w.rec)) {  // the node is its allele: its locus, if the item has it, is recorded here
+      uint32_t bit = 0;
+#pragma unroll
+      for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i)
+        if (i < n && l_site[i] == w.rec.site && l_allele[i] == w.rec.allele) bit = 1u << i;
+      if (bit & ~hit) {
+        hit |= bit;
+        env.add_hit(w.rec.cov_off + 1);
+        continue;
+      }
+    }
     for (uint32_t i = w.start; i <= w.end; ++i) env.add_per_base(w.rec.cov_off + i);
   }
 #pragma unroll
   for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i)
-    if (i < n && !gmx_record_locus(ix, env, l_site[i], l_allele[i])) return true;
+    if (i < n && !((hit >> i) & 1u) && !gmx_record_locus(ix, env, l_site[i], l_allele[i])) return true;
   return true;
 }
 

@@ -981,6 +981,7 @@ struct CoverEnvT {
   __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_hit(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
     atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
@@ -1097,6 +1098,7 @@ struct CompactEnv {
   __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
+  __device__ __forceinline__ void add_hit(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
     atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
@@ -1325,6 +1327,7 @@ struct gmx_engine {
   uint32_t *d_fused = nullptr, *d_limbs = nullptr;  // accumulator block (n_acc words, gmx_types.h) | 32 counter-limb words
   size_t n_fused = 0, n_acc = 0;
   std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;  // logical slot -> slot of the block (gmx_coverage_fetch)
+  std::vector<uint32_t> hit_fix;                             // hit counters and the logical slots they count for
   unsigned long long *d_stats = nullptr;  // with d_log_cursor behind the coverage block: one memset resets all of it
   uint32_t *d_error = nullptr;
   uint32_t *d_log = nullptr, *d_log_cursor = nullptr;
@@ -1496,6 +1499,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     e->phys_allele = h.phys_allele;
     e->phys_pb = h.phys_pb;
     e->phys_grouped = h.phys_grouped;
+    e->hit_fix = h.hit_fix;
   }
   e->log_cap = 1u << 24;
   rc |= e->alloc(&e->d_log, e->log_cap, false);
@@ -1846,6 +1850,12 @@ int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, 
   if (allele_sum) for (size_t i = 0; i < e->phys_allele.size(); ++i) allele_sum[i] = block[e->phys_allele[i]];
   if (per_base) for (size_t i = 0; i < e->phys_pb.size(); ++i) per_base[i] = block[e->phys_pb[i]];
   if (grouped) for (size_t i = 0; i < e->phys_grouped.size(); ++i) grouped[i] = block[e->phys_grouped[i]];
+  for (size_t i = 0; i + 3 < e->hit_fix.size(); i += 4) {  // a hit = one each of allele-sum, group {allele} and the base
+    const uint32_t hits = block[e->hit_fix[i]];
+    if (allele_sum) allele_sum[e->hit_fix[i + 1]] += hits;
+    if (grouped) grouped[e->hit_fix[i + 2]] += hits;
+    if (per_base) per_base[e->hit_fix[i + 3]] += hits;
+  }
   if (stats) {
     unsigned long long s[5];
     HIP_TRY(hipMemcpy(s, e->d_stats, sizeof(s), hipMemcpyDeviceToHost));

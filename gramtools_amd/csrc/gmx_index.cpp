@@ -554,6 +554,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     out.phys_allele.assign(as, 0);
     out.phys_grouped.assign(gs, 0);
     out.phys_pb.assign(pb, 0);
+    out.hit_fix.clear();
     std::vector<std::vector<uint32_t>> nodes_of_site(n_sites);
     for (size_t i = 0; i < n_nodes; ++i) {
       out.l_cov_off[i] = out.nodes[i].cov_off;
@@ -578,8 +579,25 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         for (uint32_t mask = 1; mask < (1u << A); ++mask) out.phys_grouped[s.grouped_off + mask - 1] = gmx_slot_grouped(probe, mask);
         at += (1u << A) - 1u - A;
       }
+      const GmxNode &entry = out.nodes[s.entry_node];
       for (uint32_t nd : nodes_of_site[i]) {
         GmxNode &n = out.nodes[nd];
+        // the whole allele is this one base: entry -> node -> exit
+        const bool one_base_allele = n.seq_len == 1 && multi != GMX_GROUPED_LOG && n.allele >= 0 && (uint32_t)n.allele < A &&
+                                     entry.n_edges == A && out.edges[entry.edge_begin + (uint32_t)n.allele] == nd &&
+                                     n.n_edges == 1 && n.edge0 == s.exit_node;
+        if (one_base_allele) {
+          at |= 1u;  // odd cov_off marks the node; the hit counter follows
+          out.hit_fix.push_back(at + 1);
+          out.hit_fix.push_back(out.l_allele_off[i] + (uint32_t)n.allele);
+          out.hit_fix.push_back(out.l_grouped_off[i] + (1u << n.allele) - 1u);
+          out.hit_fix.push_back(n.cov_off);
+          out.phys_pb[n.cov_off] = at;
+          n.cov_off = at;
+          at += 2;
+          continue;
+        }
+        at += at & 1u;
         for (uint32_t j = 0; j < n.seq_len; ++j) out.phys_pb[n.cov_off + j] = at + j;
         n.cov_off = at;
         at += n.seq_len;
@@ -969,7 +987,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 4;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 5;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1037,6 +1055,7 @@ void index_tables(IO &io, H &h) {  // one list of tables for both directions
   io.vec(h.phys_allele);
   io.vec(h.phys_pb);
   io.vec(h.phys_grouped);
+  io.vec(h.hit_fix);
   io.vec(h.bwt);
   io.vec(h.pos_target);
 }
@@ -1127,7 +1146,7 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||
         out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) ||
         out.seeds2.size() != (out.kmer_size2 ? (1ull << (2 * out.kmer_size2)) : 0) || out.kmer_size2 > 15 || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
-        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots)
+        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0)
       throw std::runtime_error("index cache: inconsistent tables");
   } catch (...) {
     fclose(f);

@@ -47,6 +47,8 @@ struct HostIndex {
   std::vector<uint32_t> l_allele_off, l_grouped_off;  // per site (l_grouped_off = GMX_GROUPED_LOG for > 5 alleles)
   std::vector<uint32_t> l_cov_off;                    // per node (GMX_NO_COV if none)
   std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;
+  // hit counters (gmx_types.h): {slot, logical allele-sum index, logical grouped index, logical per-base index} each
+  std::vector<uint32_t> hit_fix;
 
   // introspection used by the tests (not needed on the device)
   std::vector<uint32_t> bwt;

@@ -62,9 +62,15 @@ struct GmxSite {
 // site sits in one cache line and the two counters every single-allele locus increments together are one 64-bit word:
 //   site block (even slot): [allele-sum(a), group {a}] for a = 0 .. A-1 | groups of 2+ alleles in mask order (A <= 5)
 //                           | per-base counters of the site's allele nodes
+// An allele that is ONE base long (a SNP allele: one node between the site's entry and exit) gets a HIT counter after
+// its per-base counter: a single-instance read through it adds 1 there instead of 1 to each of allele-sum(a),
+// group {a} and the per-base counter — one atomic per SNP instead of two (the coverage kernel is bound by the rate of
+// atomics). Such a node is recognised by an ODD cov_off (all others are even); its hit counter is at
+// cov_off + 1 and is added to the three logical counters when coverage is fetched (HostIndex::hit_fix).
 // The logical arrays of the C ABI (allele_sum, per_base, grouped_dense) are gathered from it (HostIndex::phys_*).
 #define GMX_GROUPED_DENSE_MAX_ALLELES 5
 
+GMX_HD bool gmx_node_has_hit_counter(const GmxNode &n) { return n.cov_off != GMX_NO_COV && (n.cov_off & 1u); }
 GMX_HD uint32_t gmx_slot_allele(const GmxSite &s, uint32_t allele) { return s.allele_sum_off + 2u * allele; }
 // slot of the group counter of allele-id set `mask` (dense sites only)
 GMX_HD uint32_t gmx_slot_grouped(const GmxSite &s, uint32_t mask) {

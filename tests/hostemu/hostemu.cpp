@@ -126,6 +126,7 @@ struct EmuEnvT {
   uint32_t single_loci() const { return e->single_loci; }
   void add_allele_sum(uint32_t s) { e->acc.at(s)++; }
   void add_per_base(uint32_t s) { e->acc.at(s)++; }
+  void add_hit(uint32_t s) { e->acc.at(s)++; }
   void add_grouped_dense(uint32_t s) { e->acc.at(s)++; }
   void add_allele_and_group(uint32_t s) {
     e->acc.at(s)++;
@@ -367,6 +368,12 @@ void hostemu_fetch(void *p, uint32_t *allele_sum, uint32_t *per_base, uint32_t *
   for (size_t i = 0; i < e->h.phys_allele.size(); ++i) allele_sum[i] = e->acc[e->h.phys_allele[i]];
   for (size_t i = 0; i < e->h.phys_pb.size(); ++i) per_base[i] = e->acc[e->h.phys_pb[i]];
   for (size_t i = 0; i < e->h.phys_grouped.size(); ++i) grouped[i] = e->acc[e->h.phys_grouped[i]];
+  for (size_t i = 0; i + 3 < e->h.hit_fix.size(); i += 4) {
+    const uint32_t hits = e->acc[e->h.hit_fix[i]];
+    allele_sum[e->h.hit_fix[i + 1]] += hits;
+    grouped[e->h.hit_fix[i + 2]] += hits;
+    per_base[e->h.hit_fix[i + 3]] += hits;
+  }
   memcpy(log, e->log.data(), e->log.size() * 4);
   memcpy(stats, e->stats, sizeof(e->stats));
 }
