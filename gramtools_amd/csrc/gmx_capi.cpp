@@ -212,7 +212,7 @@ static std::vector<uint32_t> bubble_order(const gmx::HostIndex &h) {
   std::vector<uint32_t> order(h.sites.size());
   for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    if (h.sites[a].ref_pos != h.sites[b].ref_pos) return h.sites[a].ref_pos > h.sites[b].ref_pos;
+    if (h.site_ref_pos[a] != h.site_ref_pos[b]) return h.site_ref_pos[a] > h.site_ref_pos[b];
     return a > b;
   });
   return order;

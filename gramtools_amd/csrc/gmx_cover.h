@@ -459,8 +459,14 @@ template <class Env>
 GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
   const uint32_t tvd = st.traversed, tvg = st.traversing;
   const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
-  const uint32_t node0 = ix.pos_node[p];
-  const GmxNode rec0 = ix.nodes[node0];
+  // The first node matters when the read starts inside an allele (traversing locus, or encapsulated: no path at all).
+  const bool first_in_play = tvg != GMX_NIL || tvd == GMX_NIL;
+  uint32_t node0 = 0;
+  GmxNode rec0;
+  if (first_in_play) {
+    node0 = ix.pos_node[p];
+    rec0 = ix.nodes[node0];
+  }
   uint32_t enc_site = 0;
   int32_t enc_allele = -1;
   if (tvd == GMX_NIL && tvg == GMX_NIL) {
@@ -480,6 +486,32 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
         if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
     }
+  }
+  // Without the walk: every traversed site is walk-free (gmx_types.h: a one-base allele is its hit counter, an empty
+  // one its allele-sum/group pair) and the first node, if in play, has a hit counter. The site records are
+  // independent loads; the walk below is a chain of dependent ones.
+  {
+    const uint32_t first_site = enc_site != 0 ? enc_site : tvg != GMX_NIL ? env.h_site(tvg) : 0u;
+    bool walk_free = !first_in_play || (gmx_node_has_hit_counter(rec0) && rec0.site == first_site);
+    for (uint32_t x = tvd; x != GMX_NIL && walk_free; x = env.h_next(x))
+      walk_free = (ix.sites[(env.h_site(x) - 5) >> 1].snp_kinds & GMX_SITE_WALK_FREE) != 0;
+    if (walk_free) {
+      if (first_in_play) env.add_hit(rec0.cov_off + 1);
+      for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
+        const GmxSite &s = ix.sites[(env.h_site(x) - 5) >> 1];
+        const int32_t allele = env.h_allele(x);
+        if (allele < 0 || (uint32_t)allele >= s.n_alleles) return env.fail(GMX_TASK_ERROR);
+        if (((s.snp_kinds >> (2 * allele)) & 3u) == GMX_ALLELE_HIT)
+          env.add_hit(gmx_slot_hit(s, (uint32_t)allele));
+        else
+          env.add_allele_and_group(gmx_slot_allele(s, (uint32_t)allele));
+      }
+      return;
+    }
+  }
+  if (!first_in_play) {
+    node0 = ix.pos_node[p];
+    rec0 = ix.nodes[node0];
   }
   // A locus whose allele node carries a hit counter (gmx_types.h) is recorded by that one counter during the walk;
   // `hit` has bit k set for the k-th traversed locus (newest first, the order the walk consumes them), bit 31 for the

@@ -525,6 +525,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
   out.n_pb_slots = pb;
   uint32_t as = 0, gs = 0;
+  out.site_ref_pos.assign(out.sites.size(), 0);
   for (auto &b : g.bubbles) {
     uint32_t idx = (b.first - 5) / 2;
     GmxSite &s = out.sites[idx];
@@ -541,7 +542,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       s.grouped_off = GMX_GROUPED_LOG;
     s.entry_node = b.second.first;
     s.exit_node = b.second.second;
-    s.ref_pos = (uint32_t)g.site_ref_pos[b.first];
+    s.snp_kinds = 0;
+    out.site_ref_pos[idx] = (uint32_t)g.site_ref_pos[b.first];
   }
   out.n_allele_slots = as;
   out.n_grouped_slots = gs;
@@ -604,6 +606,26 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       }
       s.allele_sum_off = base;
       s.grouped_off = multi;
+      if (multi != GMX_GROUPED_LOG && entry.n_edges == A) {  // walk-free? (gmx_types.h)
+        uint32_t kinds = 0;
+        bool ok = true;
+        for (uint32_t a = 0; a < A && ok; ++a) {
+          const uint32_t tgt = out.edges[entry.edge_begin + a];
+          if (tgt == s.exit_node)
+            kinds |= GMX_ALLELE_EMPTY << (2 * a);
+          else if (gmx_node_has_hit_counter(out.nodes[tgt]) && out.nodes[tgt].site == 5 + 2 * i && out.nodes[tgt].allele == (int32_t)a)
+            kinds |= GMX_ALLELE_HIT << (2 * a);
+          else
+            ok = false;
+        }
+        if (ok) {
+          s.snp_kinds = kinds;
+          for (uint32_t a = 0; a < A && ok; ++a)
+            if (((kinds >> (2 * a)) & 3u) == GMX_ALLELE_HIT)
+              ok = gmx_slot_hit(s, a) == out.nodes[out.edges[entry.edge_begin + a]].cov_off + 1;
+          s.snp_kinds = ok ? (kinds | GMX_SITE_WALK_FREE) : 0u;
+        }
+      }
     }
     out.n_acc_slots = at;
   }
@@ -987,7 +1009,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 5;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 6;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1056,6 +1078,7 @@ void index_tables(IO &io, H &h) {  // one list of tables for both directions
   io.vec(h.phys_pb);
   io.vec(h.phys_grouped);
   io.vec(h.hit_fix);
+  io.vec(h.site_ref_pos);
   io.vec(h.bwt);
   io.vec(h.pos_target);
 }
@@ -1146,7 +1169,7 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||
         out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) ||
         out.seeds2.size() != (out.kmer_size2 ? (1ull << (2 * out.kmer_size2)) : 0) || out.kmer_size2 > 15 || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
-        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0)
+        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0 || out.site_ref_pos.size() != out.sites.size())
       throw std::runtime_error("index cache: inconsistent tables");
   } catch (...) {
     fclose(f);

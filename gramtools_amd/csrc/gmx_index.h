@@ -49,6 +49,7 @@ struct HostIndex {
   std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;
   // hit counters (gmx_types.h): {slot, logical allele-sum index, logical grouped index, logical per-base index} each
   std::vector<uint32_t> hit_fix;
+  std::vector<uint32_t> site_ref_pos;  // per site: coverage_Node::pos of the bubble start (first-allele coordinate; orders bubble_map)
 
   // introspection used by the tests (not needed on the device)
   std::vector<uint32_t> bwt;

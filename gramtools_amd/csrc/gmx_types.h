@@ -55,7 +55,7 @@ struct GmxSite {
   uint32_t grouped_off;     // slot of its multi-allele group counters, or GMX_GROUPED_LOG (more than 5 alleles)
   uint32_t entry_node;      // bubble start node
   uint32_t exit_node;       // bubble end node
-  uint32_t ref_pos;         // coverage_Node::pos of the bubble start (first-allele coordinate; orders bubble_map)
+  uint32_t snp_kinds;       // bit 31: every allele is one base long or empty (below); bits 2a, 2a+1: GMX_ALLELE_* of allele a
 };
 #define GMX_GROUPED_LOG 0xFFFFFFFFu
 // ONE accumulator block holds all three coverage structures, laid out per site so that what a read touches at a
@@ -71,6 +71,18 @@ struct GmxSite {
 #define GMX_GROUPED_DENSE_MAX_ALLELES 5
 
 GMX_HD bool gmx_node_has_hit_counter(const GmxNode &n) { return n.cov_off != GMX_NO_COV && (n.cov_off & 1u); }
+// A dense site whose alleles are all one base long (hit counter) or empty needs no walk to be recorded: the hit
+// counters follow the site's pair and group counters in allele order (verified when the index is built).
+#define GMX_ALLELE_LONG 0u   // needs the walk
+#define GMX_ALLELE_HIT 1u    // one base, hit counter
+#define GMX_ALLELE_EMPTY 2u  // no base: allele-sum and group {allele} only
+#define GMX_SITE_WALK_FREE 0x80000000u
+GMX_HD uint32_t gmx_slot_hit(const GmxSite &s, uint32_t allele) {  // walk-free sites, GMX_ALLELE_HIT alleles
+  const uint32_t A = s.n_alleles;
+  const uint32_t first = (s.allele_sum_off + 2u * A + ((1u << A) - 1u - A)) | 1u;
+  const uint32_t before = (uint32_t)__builtin_popcount(s.snp_kinds & 0x55555555u & ((1u << (2u * allele)) - 1u));
+  return first + 2u * before + 1u;
+}
 GMX_HD uint32_t gmx_slot_allele(const GmxSite &s, uint32_t allele) { return s.allele_sum_off + 2u * allele; }
 // slot of the group counter of allele-id set `mask` (dense sites only)
 GMX_HD uint32_t gmx_slot_grouped(const GmxSite &s, uint32_t mask) {
