@@ -859,11 +859,41 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
 // of a wave go to 64 unrelated words: from LDS that costs a few bank-conflict cycles, from L1/L2 one tag
 // look-up per lane. One 1024-thread block per CU, persistent over the dead-task queue.
 #define GMX_FILTER_LDS_THREADS 1024
+// all_kmers_present on the bit planes of the read, for the LDS kernel: a k-mer is looked up by its PLANAR code (the k low
+// bits of its bases, base j at bit j, below the k high bits) in a bitmap indexed that way (gmx_engine::d_kmer_planar), so
+// a window of 32 bases yields its 33 - k k-mers by shift and mask. The reverse complement of the read has the
+// complemented planes in reverse order: bit-reverse the inverted window and shift from the other end.
+__device__ bool all_kmers_present_planar(const uint32_t *bitmap, uint32_t k, const ReadRef &r) {
+  const uint32_t m = (1u << k) - 1u, per_window = 33u - k, n_kmers = r.len - k + 1u;
+  for (uint32_t f0 = 0; f0 < n_kmers; f0 += per_window) {
+    uint32_t lo, hi;
+    r.planes(f0, lo, hi);
+    if (r.rc) {
+      lo = __builtin_bitreverse32(~lo);
+      hi = __builtin_bitreverse32(~hi);
+    }
+    const uint32_t cnt = min(per_window, n_kmers - f0);
+    for (uint32_t j0 = 0; j0 < cnt; j0 += 8) {  // eight independent probes in flight
+      uint32_t present = 1;
+#pragma unroll
+      for (uint32_t d = 0; d < 8; ++d) {
+        const uint32_t j = min(j0 + d, cnt - 1u);
+        const uint32_t sh = r.rc ? 32u - k - j : j;
+        const uint32_t code = (((hi >> sh) & m) << k) | ((lo >> sh) & m);
+        present &= bitmap[code >> 5] >> (code & 31u);
+      }
+      if (!(present & 1u)) return false;
+    }
+  }
+  return true;
+}
+
 __global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(GmxIndexView ix, BatchView b, SearchOut o,
+                                                                                 const uint32_t *planar_bitmap,
                                                                                  uint32_t n_words, int pass) {
   const uint32_t n_dead = o.counters[(pass ? 12 : 6) * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_FILTER_LDS_THREADS >= n_dead) return;
-  const uint4 *src = reinterpret_cast<const uint4 *>(ix.kmer_bitmap);
+  const uint4 *src = reinterpret_cast<const uint4 *>(planar_bitmap);
   uint4 *dst = reinterpret_cast<uint4 *>(gmx_lds);
   for (uint32_t i = threadIdx.x; i < n_words / 4; i += GMX_FILTER_LDS_THREADS) dst[i] = src[i];
   __syncthreads();
@@ -871,7 +901,7 @@ __global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(
        slot += gridDim.x * GMX_FILTER_LDS_THREADS) {
     uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
     ReadRef r = task_read(b, task);
-    o.status[task] = all_kmers_present(gmx_lds, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+    o.status[task] = all_kmers_present_planar(gmx_lds, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
   }
 }
 
@@ -1153,14 +1183,23 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   if (threadIdx.x < 5) acc[threadIdx.x] = 0;
   __syncthreads();
   uint32_t c_all = 0, c_skip = 0, c_miss = 0, c_noext = 0, c_map = 0;
-  for (uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x; task < n_tasks; task += gridDim.x * GMX_BLOCK) {
-    uint32_t s = status[task];
+  auto tally = [&](uint32_t s) {
     c_all += s != GMX_STATUS_IGNORED;
     c_skip += s == GMX_TASK_SKIPPED;
     c_miss += s == GMX_STATUS_MISSING_KMER;
     c_noext += s == GMX_TASK_UNMAPPED;
     c_map += s == GMX_TASK_MAPPED;
+  };
+  const uint32_t n_quads = n_tasks / 4;  // the status array is 16-byte aligned
+  const uint4 *quads = reinterpret_cast<const uint4 *>(status);
+  for (uint32_t q = blockIdx.x * GMX_BLOCK + threadIdx.x; q < n_quads; q += gridDim.x * GMX_BLOCK) {
+    const uint4 s = quads[q];
+    tally(s.x);
+    tally(s.y);
+    tally(s.z);
+    tally(s.w);
   }
+  if (blockIdx.x == 0 && threadIdx.x < (n_tasks & 3u)) tally(status[n_quads * 4 + threadIdx.x]);
   for (int off = 32; off > 0; off >>= 1) {
     c_all += __shfl_down(c_all, off);
     c_skip += __shfl_down(c_skip, off);
@@ -1353,6 +1392,7 @@ struct gmx_engine {
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
+  const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
   // host staging for the _host entry point
@@ -1523,6 +1563,22 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
                             (int)(words * 4)) == hipSuccess)
       e->filter_lds_words = (uint32_t)words;
     (void)hipGetLastError();
+    if (e->filter_lds_words) {  // re-index the presence bitmap: interleaved code (first base most significant) -> planar
+      const uint32_t k = h.kmer_size;
+      std::vector<uint32_t> planar(words, 0);
+      for (uint64_t code = 0; code < (1ull << (2 * k)); ++code) {
+        if (!((h.kmer_bitmap[code >> 5] >> (code & 31)) & 1u)) continue;
+        uint32_t lo = 0, hi = 0;
+        for (uint32_t j = 0; j < k; ++j) {
+          const uint32_t base = (uint32_t)(code >> (2 * (k - 1 - j))) & 3u;
+          lo |= (base & 1u) << j;
+          hi |= (base >> 1) << j;
+        }
+        const uint32_t p = (hi << k) | lo;
+        planar[p >> 5] |= 1u << (p & 31);
+      }
+      rc |= e->upload(&e->d_kmer_planar, planar);
+    }
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
@@ -1582,7 +1638,7 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
 static void launch_filter(gmx_engine *e, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass) {
   if (e->filter_lds_words)
     hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
-                       e->side_stream, e->dview, b, o, e->filter_lds_words, pass);
+                       e->side_stream, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
   else
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o, pass);
 }
@@ -1649,19 +1705,28 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
   launch_cover_lds<CoverEnv, 2>(e, e->side2_stream, b, o, acc);
+  // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
+  // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
+  const bool general_on_side = !e->dview.is_nested;
+  if (general_on_side) {
+    launch_cover_lds<CoverEnvLds, 3>(e, e->side2_stream, b, o, acc);
+    launch_cover_lds<CoverEnv, 0>(e, e->side2_stream, b, o, acc);
+  }
   HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
   // second filter pass: the tasks the extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
   launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
-  launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc);
-  launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
+  if (!general_on_side) {
+    launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc);
+    launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
+  }
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
                      b, o, e->big, acc);
-  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK, 1024u)),
+  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks / 4 + GMX_BLOCK) / GMX_BLOCK, 512u)),
                      dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
