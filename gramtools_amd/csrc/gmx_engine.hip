@@ -147,16 +147,20 @@ extern __shared__ uint32_t gmx_lds[];
 
 // What the single-instance coverage kernel needs of a mapped task, in one 32-byte record written by the search
 // kernel that finished it: the final state's PRG position, the read length, the traversing path (inline handle or
-// nil) and up to three traversed loci, newest first. The kernel reads its queue coalesced and touches neither the
-// task's final states nor its path arena. Tasks that do not fit (several final states, an SA-form or nested final
-// state, longer paths, allele ids >= 65536, reads >= 65536 bases) go to the general coverage queue as task ids.
+// nil) and the traversed loci, newest first, in one of two forms: up to three (site, allele) pairs, or — the sites
+// along a read through a non-nested PRG are consecutive — up to GMX_REC_RUN loci as the first site and one allele byte
+// each. The kernel reads its queue coalesced and touches neither the task's final states nor its path arena. Tasks
+// that do not fit (several final states, an SA-form final state, longer or non-consecutive paths, large allele ids,
+// reads >= 65536 bases) go to the general coverage queue as task ids.
+#define GMX_REC_RUN 16u
+#define GMX_REC_RUN_FLAG 0x80000000u
 struct alignas(32) GmxCoverRec {
   uint32_t p;
-  uint32_t len_n;  // read length | number of traversed loci << 16
+  uint32_t len_n;  // read length | number of traversed loci << 16 | GMX_REC_RUN_FLAG (run form)
   uint32_t tvg;
-  uint32_t site[3];
-  uint32_t a01;    // allele 0 | allele 1 << 16
-  uint32_t a2;
+  uint32_t site[3];  // pair form: the sites; run form: site[0] = site of locus 0 (locus i: site[0] + 2 i), then allele bytes
+  uint32_t a01;    // pair form: allele 0 | allele 1 << 16; run form: allele bytes 8..11
+  uint32_t a2;     // pair form: allele 2; run form: allele bytes 12..15
 };
 
 // A pending entry of a task handed from the probe kernel to the extend kernel (overlays the task's finals[]).
@@ -664,12 +668,35 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
         x = nd.next;
         ++n;
       }
-    compact = compact && x == GMX_NIL;
     rec.p = ctx.first_pos;
-    rec.len_n = read_len | (n << 16);
     rec.tvg = ctx.first_tvg;
-    rec.a01 = alleles[0] | (alleles[1] << 16);
-    rec.a2 = alleles[2];
+    if (x == GMX_NIL) {
+      rec.len_n = read_len | (n << 16);
+      rec.a01 = alleles[0] | (alleles[1] << 16);
+      rec.a2 = alleles[2];
+    } else {  // more than three loci: the run form, if the sites are consecutive and the allele ids fit a byte
+      const uint32_t site0 = rec.site[0];
+      bool run = rec.site[1] == site0 + 2 && rec.site[2] == site0 + 4 && (alleles[0] | alleles[1] | alleles[2]) < 256u;
+      uint32_t w0 = alleles[0] | (alleles[1] << 8) | (alleles[2] << 16), w1 = 0, w2 = 0, w3 = 0;
+      while (x != GMX_NIL && n < GMX_REC_RUN && run) {
+        const GmxPathNode nd = ctx.arena[x];
+        const uint32_t a = (uint32_t)nd.allele;
+        run = nd.site == site0 + 2 * n && a < 256u;
+        const uint32_t v = a << (8 * (n & 3u));
+        w0 |= (n >> 2) == 0 ? v : 0u;
+        w1 |= (n >> 2) == 1 ? v : 0u;
+        w2 |= (n >> 2) == 2 ? v : 0u;
+        w3 |= (n >> 2) == 3 ? v : 0u;
+        x = nd.next;
+        ++n;
+      }
+      compact = compact && run && x == GMX_NIL;
+      rec.len_n = read_len | (n << 16) | GMX_REC_RUN_FLAG;
+      rec.site[1] = w0;
+      rec.site[2] = w1;
+      rec.a01 = w2;
+      rec.a2 = w3;
+    }
   }
   // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
   // queue and block). Compact mapped tasks are queued by the PRG region they map to: workgroup b of the coverage
@@ -1112,13 +1139,19 @@ struct CompactEnv {
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
-  __device__ __forceinline__ uint32_t n_trav() const { return (rec.len_n >> 16) & 3u; }
+  __device__ __forceinline__ uint32_t n_trav() const { return (rec.len_n >> 16) & 31u; }
+  __device__ __forceinline__ bool run_form() const { return (rec.len_n & GMX_REC_RUN_FLAG) != 0; }
   __device__ __forceinline__ uint32_t h_site(uint32_t h) const {
     if (h & GMX_INLINE_FLAG) return 5u + 2u * (h & ~GMX_INLINE_FLAG);
+    if (run_form()) return rec.site[0] + 2u * h;
     return h == 0 ? rec.site[0] : (h == 1 ? rec.site[1] : rec.site[2]);
   }
   __device__ __forceinline__ int32_t h_allele(uint32_t h) const {
     if (h & GMX_INLINE_FLAG) return -1;
+    if (run_form()) {
+      const uint32_t q = h >> 2, w = q == 0 ? rec.site[1] : q == 1 ? rec.site[2] : q == 2 ? rec.a01 : rec.a2;
+      return (int32_t)((w >> (8u * (h & 3u))) & 0xFFu);
+    }
     return (int32_t)(h == 0 ? (rec.a01 & 0xFFFFu) : (h == 1 ? (rec.a01 >> 16) : rec.a2));
   }
   __device__ __forceinline__ uint32_t h_next(uint32_t h) const {

@@ -116,6 +116,26 @@ def test_config1_1kb_10snps_10k_reads():
     assert got["stats"]["exact_mapped"] >= 10000
 
 
+@pytest.mark.parametrize("n_sites", [1500, 3000, 6000])
+def test_dense_sites_matches_oracle(n_sites):
+    """A SNP every 20 / 10 / 5 bp: 7, 15 and 30 loci per read. The search kernels hand single-instance tasks to the
+    coverage kernel as compact records — three (site, allele) pairs, or a run of up to 16 consecutive sites — and
+    longer paths as task ids for the general instance; all three routes must give the oracle's coverage."""
+    prg, reads = _snp_workload(30000, n_sites, 3000, 40 + n_sites, multi=0.1)
+    seeds = master_seeds(13, [3000])
+    offs = flat_offsets(3000, 150)
+    want = oracle_map(prg, 7, list(reads), seeds, threads=8)
+    qm = Quasimapper(Index(prg, 7))
+    qm.map_reads(reads.reshape(-1), offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    assert want["stats"]["exact_mapped"] >= 3000
+    counts = qm.queue_counts()
+    if n_sites == 1500:
+        assert counts["cover_general"] < counts["mapped"] // 4  # runs of up to 16 sites stay compact
+    if n_sites == 6000:  # 30 loci fit neither the record nor the per-lane path arena: large-capacity pass
+        assert counts["cover_general"] + counts["big_mapped"] > 1500
+
+
 def test_mtb_like_sample_matches_oracle():
     """A 200 kb slice of the configs[1] recipe (SNP every ~73 bp, k = 10), 20k reads, oracle-checked."""
     prg, reads = _snp_workload(200000, 2700, 20000, 5, multi=0.05)
