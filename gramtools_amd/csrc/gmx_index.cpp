@@ -962,10 +962,13 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     if (kmer_size > 15) throw std::runtime_error("kmer_size > 15 is not supported");
     build_table(kmer_size, out.seeds, &out.kmer_bitmap, out.n_seed_kmers_present, out.n_seed_states, out.n_seed_states_large);
     // longer seeds: the smallest k2 > k whose k-mer space holds >= 8 x the PRG (a k2-mer then occurs ~0.1 times on
-    // average), if its direct-addressed table stays within 512 MB (k2 <= 13)
+    // average), if its direct-addressed table stays within 8 GB (k2 <= 15: 288 GB of HBM per GPU make that cheap;
+    // chr20 scale, k = 14: k2 = 15 is +8 % reads/s for +10 GB and +12 s of build)
     uint32_t k2 = seed_k2 < 0 ? kmer_size : (uint32_t)seed_k2;
-    if (seed_k2 < 0)
-      while (k2 < 13 && (1ull << (2 * k2)) < 8ull * (uint64_t)N) ++k2;
+    if (seed_k2 < 0) {
+      while (k2 < 15 && (1ull << (2 * k2)) < 8ull * (uint64_t)N) ++k2;
+      if ((1ull << (2 * k2)) < 8ull * (uint64_t)N) k2 = kmer_size;  // still too dense to thin the tasks out: no second table
+    }
     if (k2 > kmer_size && k2 <= 15) {
       uint64_t present = 0;
       build_table(k2, out.seeds2, nullptr, present, out.n_seed_states, out.n_seed_states_large);  // the table the kernels mostly use
