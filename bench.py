@@ -152,7 +152,9 @@ def main():
         search_s = tm["search_ms"] / 1e3 / max(tm["search_launches"], 1)
         reads_per_launch = tm["reads"] / max(tm["search_launches"], 1)
         k_seed = max(KMER, int(ix.info.kmer_size2))     # the search is seeded after k2 >= k bases
-        b_alg_dominant = 128 * (READ_LEN - k_seed - PROBE_STEPS) + READ_LEN
+        # with a longer seed table there is no probe phase (gmx_seed_kernel): the extend kernel does every step
+        probe_steps = 0 if int(ix.info.kmer_size2) else PROBE_STEPS
+        b_alg_dominant = 128 * (READ_LEN - k_seed - probe_steps) + READ_LEN
         achieved = b_alg_dominant * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",

@@ -423,9 +423,7 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 // CURSOR = false (engines whose index has hardly any large entry): every entry is pushed; one that does not fit
 // the stack overflows to the large-capacity pass.
 template <bool CURSOR>
-__device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const GmxSeed *table, uint32_t code, FastCtx &ctx,
-                                                 uint32_t from) {
-  GmxSeed s = table[code];
+__device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const GmxSeed s, FastCtx &ctx, uint32_t from) {
   if (s.a != GMX_SEED_COMPLEX) {
     if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
     return;
@@ -609,6 +607,7 @@ struct SearchOut {
   uint32_t *error;           // [0] = first error status, [1] = its task (persist until gmx_engine_sync reads them)
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
+  GmxSeed *alive_seed;       // gmx_seed_kernel: the seed directory entry of alive_list[i]
 };
 
 #define GMX_REGIONS 8
@@ -782,7 +781,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
       const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
       const uint32_t from = r.len - k;
       const uint32_t stop = from > GMX_PROBE_STEPS ? from - GMX_PROBE_STEPS : 0;
-      load_seed_cursor<CURSOR>(ix, longer ? ix.seeds2 : ix.seeds, last_kmer_code(r, k), ctx, from);
+      load_seed_cursor<CURSOR>(ix, (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)], ctx, from);
       run = ctx.status == GMX_TASK_MAPPED;
       status = ctx.status;
       done = stop == 0;
@@ -817,7 +816,75 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 }
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
-template <bool CURSOR>
+// With a longer seed table the probe phase has nothing left to thin out: a reverse-complement task almost always
+// ends at the look-up (its last k2-mer does not occur in the PRG). This light kernel does only that look-up for
+// every task and queues it as alive or dead; the extend kernel then runs the alive ones from their seed states
+// (SEEDED) — no probe steps, no parking, no second pass over the tasks that die here.
+#define GMX_SEED_THREADS 1024  // large blocks: one atomic per block and queue, and the queue counters are contended
+__global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+  const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
+  const bool active = task < b.n_reads * 2;
+  bool alive = false, dead = false;
+  GmxSeed sd{1, 0};
+  if (active) {
+    const uint32_t read = task >> 1;
+    ReadRegs r;  // planes fetched on demand: one or two pairs hold the last k-mer
+    r.w = b.packed + pack_off(b, read);
+    r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+    r.rc = (task & 1) != 0;
+    r.in_regs = false;
+    if (b.forward_only && r.rc) {
+      o.status[task] = GMX_STATUS_IGNORED;
+    } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
+      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+      sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
+      if (sd.a != GMX_SEED_COMPLEX) {
+        alive = sd.a <= sd.b;
+      } else {
+        const uint32_t ns = ix.seed_words[sd.b];
+        alive = ns != 0 && ns <= 0xFFFFu;
+        if (ns > 0xFFFFu) {  // as load_seed_cursor: the large-capacity pass takes it (rare: one atomic per task)
+          o.status[task] = GMX_TASK_OVERFLOW;
+          o.overflow_list[atomicAdd(&o.counters[1 * GMX_CNT_STRIDE], 1u)] = task;
+        }
+      }
+      dead = !alive && !(sd.a == GMX_SEED_COMPLEX && ix.seed_words[sd.b] > 0xFFFFu);
+    } else {
+      o.status[task] = GMX_TASK_SKIPPED;
+    }
+  }
+  // block-aggregated appends to the alive and the dead queue
+  __shared__ uint32_t cnt[GMX_SEED_THREADS / 64][2];
+  __shared__ uint32_t base[2];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long m_alive = __ballot(alive), m_dead = __ballot(dead);
+  if (lane == 0) {
+    cnt[wave][0] = (uint32_t)__popcll(m_alive);
+    cnt[wave][1] = (uint32_t)__popcll(m_dead);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) total += cnt[w][threadIdx.x];
+    base[threadIdx.x] = total ? atomicAdd(&o.counters[(threadIdx.x ? 6 : 5) * GMX_CNT_STRIDE], total) : 0;
+  }
+  __syncthreads();
+  if (alive || dead) {
+    const uint32_t c = alive ? 0 : 1;
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += cnt[w][c];
+    const uint32_t at = base[c] + before + (uint32_t)__popcll((alive ? m_alive : m_dead) & ((1ull << lane) - 1ull));
+    if (alive) {
+      o.alive_list[at] = task;
+      o.alive_seed[at] = sd;
+    } else {
+      o.dead_list[at] = task;
+    }
+  }
+}
+
+template <bool CURSOR, bool SEEDED>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
@@ -840,7 +907,13 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
   r.clear(b.packed);
-  if (active) {
+  if (active && SEEDED) {
+    task_read_regs(b, task, r);
+    const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+    const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+    load_seed_cursor<CURSOR>(ix, o.alive_seed[slot], ctx, r.len - k);  // the entry gmx_seed_kernel looked up
+    active = ctx.status == GMX_TASK_MAPPED;
+  } else if (active) {
     task_read_regs(b, task, r);
     uint32_t packed = o.n_final[task];
     uint32_t n = packed & 0xFF;
@@ -862,7 +935,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln);
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(ix, o, active, task, ctx, status, true, true, r.len);
+  finish_lane(ix, o, slot < n_alive, task, ctx, status, true, true, r.len);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -1411,6 +1484,7 @@ struct gmx_engine {
   uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
+  GmxSeed *d_alive_seed = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
@@ -1506,6 +1580,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
   e->cap_reads = cap;
+  if ((rc = e->alloc(&e->d_alive_seed, n_tasks, false))) return rc;
   return GMX_OK;
 }
 
@@ -1696,7 +1771,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters};
+              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   HIP_TRY(hipMemsetAsync(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4, stream));  // all queue counters are per batch
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
@@ -1712,7 +1787,11 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     HIP_TRY(hipEventRecord(ev.s, stream));
   }
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
-  if (e->seed_cursor)
+  const bool seeded = e->dview.kmer_size2 != 0 && !getenv("GMX_NO_SEEDED");  // longer seed table: no probe phase (gmx_seed_kernel)
+  if (seeded)
+    hipLaunchKernelGGL(gmx_seed_kernel, dim3((n_tasks + GMX_SEED_THREADS - 1) / GMX_SEED_THREADS), dim3(GMX_SEED_THREADS), 0, stream,
+                       e->dview, b, o);
+  else if (e->seed_cursor)
     hipLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   else
     hipLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
@@ -1725,10 +1804,14 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, task_grid, b, o, 0);
-  if (e->seed_cursor)
-    hipLaunchKernelGGL(gmx_extend_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  if (seeded && e->seed_cursor)
+    hipLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  else if (seeded)
+    hipLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+  else if (e->seed_cursor)
+    hipLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   else
-    hipLaunchKernelGGL(gmx_extend_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+    hipLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
