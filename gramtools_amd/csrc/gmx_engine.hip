@@ -1370,9 +1370,12 @@ __device__ __forceinline__ uint2 pack_tail(const uint8_t *p, uint32_t rem, uint3
   }
   return out;
 }
-__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed) {
+__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters) {
   __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
   __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
+  // the queue counters are per batch: this is the batch's first kernel and everything that counts comes after it
+  if (blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_READS) counters[i] = 0;
   const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
   const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
   const uint32_t read = r0 + threadIdx.x;
@@ -1775,9 +1778,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
-  HIP_TRY(hipMemsetAsync(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4, stream));  // all queue counters are per batch
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
-                     e->d_skip, e->d_packed);
+                     e->d_skip, e->d_packed, e->d_counters);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
