@@ -846,9 +846,9 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       } else {
         const uint32_t ns = ix.seed_words[sd.b];
         alive = ns != 0 && ns <= 0xFFFFu;
-        if (ns > 0xFFFFu) {  // as load_seed_cursor: the large-capacity pass takes it (rare: one atomic per task)
-          o.status[task] = GMX_TASK_OVERFLOW;
-          o.overflow_list[atomicAdd(&o.counters[1 * GMX_CNT_STRIDE], 1u)] = task;
+        if (ns > 0xFFFFu) {  // as load_seed_cursor: the large-capacity pass takes it, with the extend kernel's
+          o.status[task] = GMX_TASK_OVERFLOW;  // overflow queue (rare: one atomic per task)
+          o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
         }
       }
       dead = !alive && !(sd.a == GMX_SEED_COMPLEX && ix.seed_words[sd.b] > 0xFFFFu);
@@ -1805,7 +1805,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
+  if (!seeded)  // gmx_seed_kernel leaves nothing in the first overflow queue
+    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, task_grid, b, o, 0);
   if (seeded && e->seed_cursor)
