@@ -608,8 +608,10 @@ struct SearchOut {
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
   GmxSeed *alive_seed;       // gmx_seed_kernel: the seed directory entry of alive_list[i]
-  // (append new members here: with this member placed before alive_list the two tiny CLI-level golden cases IT2 / IT3
-  // came out wrong on the GPU while every other test passed — not understood; tests/test_gpu_parity.py guards it)
+  // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
+  // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
+  // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
+  // pattern changes with the member order: a code generation problem is suspected. tests/test_gpu_parity.py guards it.)
 };
 
 #define GMX_REGIONS 8
