@@ -1514,6 +1514,16 @@ struct gmx_engine {
   uint64_t *d_offsets = nullptr;
   uint32_t *d_seeds = nullptr;
   uint64_t cap_bases = 0, cap_stage_reads = 0;
+  // gmx_map_reads_host, pipelined: two staging slots (device buffers + pinned offsets/seeds), a copy stream
+  struct StageSlot {
+    uint8_t *d_reads = nullptr;
+    uint64_t *d_offsets = nullptr, *h_offsets = nullptr;
+    uint32_t *d_seeds = nullptr, *h_seeds = nullptr;
+    uint64_t cap_bases = 0, cap_reads = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+  } stage[2];
+  hipStream_t copy_stream = nullptr;
   hipStream_t last_stream = nullptr;
   // optional HIP-event timing of the kernels (bench.py roofline leg)
   bool timing = false;
@@ -1730,6 +1740,13 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_filter) (void)hipEventDestroy(e->ev_filter);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  for (auto &sl : e->stage) {
+    if (sl.copied) (void)hipEventDestroy(sl.copied);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+    if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
+    if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
+  }
   for (void *p : e->allocs) (void)hipFree(p);
   delete e;
 }
@@ -1878,6 +1895,62 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
   return GMX_OK;
 }
 
+// Large calls: chunks of <= 1 M reads through two staging slots; the upload of a chunk (copy stream, from the caller's
+// buffer registered with the runtime for the duration of the call) runs beside the kernels of the one before.
+static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
+                                    uint64_t n_reads, uint64_t chunk) {
+  if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  const uint64_t first = offsets[0], total = offsets[n_reads] - first;
+  const bool registered = hipHostRegister(const_cast<uint8_t *>(reads + first), total, hipHostRegisterDefault) == hipSuccess;
+  (void)hipGetLastError();
+  int rc = GMX_OK;
+  uint64_t done = 0;
+  for (uint32_t i = 0; done < n_reads && rc == GMX_OK; ++i) {
+    gmx_engine::StageSlot &sl = e->stage[i & 1];
+    const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
+    const uint64_t b0 = offsets[done], bases = offsets[done + n] - b0;
+    if (sl.busy) {  // the chunk that used this slot two rounds ago
+      HIP_TRY(hipEventSynchronize(sl.done));
+      sl.busy = false;
+    }
+    if (!sl.copied) {
+      HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    if (bases > sl.cap_bases) {
+      const uint64_t cb = std::max<uint64_t>(bases + bases / 8, 1 << 16);
+      if ((rc = e->alloc(&sl.d_reads, cb + 16, false))) break;
+      sl.cap_bases = cb;
+    }
+    if (n > sl.cap_reads) {
+      const uint64_t cr = std::max<uint64_t>(n, 1024);
+      if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false))) break;
+      if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
+      if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h_offsets), (cr + 1) * sizeof(uint64_t), hipHostMallocDefault));
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h_seeds), cr * sizeof(uint32_t), hipHostMallocDefault));
+      sl.cap_reads = cr;
+    }
+    for (uint64_t j = 0; j <= n; ++j) sl.h_offsets[j] = offsets[done + j] - b0;
+    memcpy(sl.h_seeds, seeds + done, n * sizeof(uint32_t));
+    HIP_TRY(hipMemcpyAsync(sl.d_reads, reads + b0, bases, hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipMemcpyAsync(sl.d_seeds, sl.h_seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->copy_stream));
+    HIP_TRY(hipEventRecord(sl.copied, e->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(nullptr, sl.copied, 0));
+    rc = launch_batch(e, sl.d_reads, sl.d_offsets, sl.d_seeds, n, bases, nullptr);
+    if (rc) break;
+    HIP_TRY(hipEventRecord(sl.done, nullptr));
+    sl.busy = true;
+    done += n;
+  }
+  (void)hipDeviceSynchronize();
+  e->stage[0].busy = e->stage[1].busy = false;
+  if (registered) (void)hipHostUnregister(const_cast<uint8_t *>(reads + first));
+  (void)hipGetLastError();
+  return rc ? rc : gmx_engine_sync(e);
+}
+
 int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
                        uint64_t n_reads) {
   if (!e) {
@@ -1886,6 +1959,10 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
   }
   if (n_reads == 0) return GMX_OK;
   HIP_TRY(hipSetDevice(e->opts.device));
+  {
+    const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+    if (n_reads > chunk && !getenv("GMX_HOST_SERIAL")) return map_reads_host_pipelined(e, reads, offsets, seeds, n_reads, chunk);
+  }
   uint64_t done = 0;
   while (done < n_reads) {
     uint64_t n = std::min<uint64_t>(e->opts.max_batch_reads, n_reads - done);
