@@ -8,4 +8,4 @@ run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR S
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM
 run sq3 SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_IFETCH SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT
 python tools/pmc_summary.py gpurun_out/pmc_sq1/pmc_counter_collection.csv gpurun_out/pmc_sq2/pmc_counter_collection.csv gpurun_out/pmc_sq3/pmc_counter_collection.csv > gpurun_out/pmc_sq_summary.txt
-grep -A25 "^gmx_probe\|^gmx_extend\|^gmx_cover_single" gpurun_out/pmc_sq_summary.txt
+grep -A25 "^gmx_seed\|^gmx_extend\|^gmx_cover_single" gpurun_out/pmc_sq_summary.txt
