@@ -262,3 +262,21 @@ def test_results_do_not_depend_on_the_seed_table_length(monkeypatch, k2):
     qm = Quasimapper(ix)
     qm.map_reads(reads.reshape(-1), offs, seeds)
     assert canonical_cov(qm.coverage()) == want
+
+
+def test_probe_pipeline_behind_a_longer_seed_table(monkeypatch):
+    """With a longer seed table the engine runs gmx_seed_kernel + the seeded extend kernel; GMX_NO_SEEDED=1 keeps the
+    probe / park / extend pipeline (the one indexes without such a table use) on the same index: same coverage,
+    different queue lengths (the probe kernel also removes the tasks that die within its first steps)."""
+    prg, reads = _snp_workload(200000, 2700, 8000, 16, multi=0.05)
+    seeds = master_seeds(12, [8000])
+    offs = flat_offsets(8000, 150)
+    ix = Index(prg, 10)
+    assert ix.info.kmer_size2 > 10
+    seeded = Quasimapper(ix)
+    seeded.map_reads(reads.reshape(-1), offs, seeds)
+    monkeypatch.setenv("GMX_NO_SEEDED", "1")
+    probed = Quasimapper(ix)
+    probed.map_reads(reads.reshape(-1), offs, seeds)
+    assert canonical_cov(probed.coverage()) == canonical_cov(seeded.coverage())
+    assert canonical_cov(seeded.coverage()) == oracle_map(prg, 10, list(reads), seeds, threads=8)
