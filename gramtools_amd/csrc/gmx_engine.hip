@@ -388,8 +388,8 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
 // seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241);
 // push(lo, hi, tvd, tvg) receives every seed state
 template <class Ctx, class Push>
-__device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push push) {
-  GmxSeed s = ix.seeds[code];
+__device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t code, Ctx &ctx, Push push) {
+  GmxSeed s = table[code];
   if (s.a != GMX_SEED_COMPLEX) {
     if (s.a <= s.b) push(s.a, s.b, GMX_NIL, GMX_NIL);
     return;
@@ -425,7 +425,13 @@ __device__ void load_seed(const GmxIndexView &ix, uint32_t code, Ctx &ctx, Push 
 template <bool CURSOR>
 __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const GmxSeed s, FastCtx &ctx, uint32_t from) {
   if (s.a != GMX_SEED_COMPLEX) {
-    if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+    if (s.a < s.b && s.b != GMX_TEXT_MARK && s.b - s.a < GMX_STACK_DEPTH - 1 && from > 0) {
+      // a few occurrences (a short repeat): position by position in text form — the same results (see
+      // gmx_search_big_kernel), 32 bases per step instead of one rank block per base and 137 iterations of the wave
+      for (uint32_t i = s.a; i <= s.b; ++i) ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+    } else if (s.a <= s.b) {
+      ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+    }
     return;
   }
   const uint32_t ns = ix.seed_words[s.b];
@@ -828,7 +834,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
   const bool active = task < b.n_reads * 2;
-  bool alive = false, dead = false;
+  bool alive = false, dead = false, over = false;
   GmxSeed sd{1, 0};
   if (active) {
     const uint32_t read = task >> 1;
@@ -844,7 +850,12 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
       sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
       if (sd.a != GMX_SEED_COMPLEX) {
-        alive = sd.a <= sd.b;
+        // a k2-mer with more occurrences than the per-lane stack has entries lies in a repeat: its interval splits at
+        // the copies' own sites, the task would overflow the extend kernel after holding its wave up — straight to the
+        // large-capacity pass (with the extend kernel's overflow queue)
+        over = sd.a <= sd.b && sd.b - sd.a >= GMX_STACK_DEPTH;
+        alive = sd.a <= sd.b && !over;
+        if (over) o.status[task] = GMX_TASK_OVERFLOW;
       } else {
         const uint32_t ns = ix.seed_words[sd.b];
         alive = ns != 0 && ns <= 0xFFFFu;
@@ -853,37 +864,41 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
           o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
         }
       }
-      dead = !alive && !(sd.a == GMX_SEED_COMPLEX && ix.seed_words[sd.b] > 0xFFFFu);
+      dead = !alive && !over && !(sd.a == GMX_SEED_COMPLEX && ix.seed_words[sd.b] > 0xFFFFu);
     } else {
       o.status[task] = GMX_TASK_SKIPPED;
     }
   }
   // block-aggregated appends to the alive and the dead queue
-  __shared__ uint32_t cnt[GMX_SEED_THREADS / 64][2];
-  __shared__ uint32_t base[2];
+  __shared__ uint32_t cnt[GMX_SEED_THREADS / 64][3];
+  __shared__ uint32_t base[3];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long m_alive = __ballot(alive), m_dead = __ballot(dead);
+  const unsigned long long m_alive = __ballot(alive), m_dead = __ballot(dead), m_over = __ballot(over);
   if (lane == 0) {
     cnt[wave][0] = (uint32_t)__popcll(m_alive);
     cnt[wave][1] = (uint32_t)__popcll(m_dead);
+    cnt[wave][2] = (uint32_t)__popcll(m_over);
   }
   __syncthreads();
-  if (threadIdx.x < 2) {
+  if (threadIdx.x < 3) {
     uint32_t total = 0;
     for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) total += cnt[w][threadIdx.x];
-    base[threadIdx.x] = total ? atomicAdd(&o.counters[(threadIdx.x ? 6 : 5) * GMX_CNT_STRIDE], total) : 0;
+    const uint32_t counter = threadIdx.x == 0 ? 5u : threadIdx.x == 1 ? 6u : 9u;
+    base[threadIdx.x] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
-  if (alive || dead) {
-    const uint32_t c = alive ? 0 : 1;
+  if (alive || dead || over) {
+    const uint32_t c = alive ? 0 : dead ? 1 : 2;
     uint32_t before = 0;
     for (uint32_t w = 0; w < wave; ++w) before += cnt[w][c];
-    const uint32_t at = base[c] + before + (uint32_t)__popcll((alive ? m_alive : m_dead) & ((1ull << lane) - 1ull));
+    const uint32_t at = base[c] + before + (uint32_t)__popcll((alive ? m_alive : dead ? m_dead : m_over) & ((1ull << lane) - 1ull));
     if (alive) {
       o.alive_list[at] = task;
       o.alive_seed[at] = sd;
-    } else {
+    } else if (dead) {
       o.dead_list[at] = task;
+    } else {
+      o.overflow2_list[at] = task;
     }
   }
 }
@@ -1056,10 +1071,22 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     bool run = false;
     if (active) {
       r = task_read(b, task);
-      const uint32_t from = r.len - ix.kmer_size;
-      load_seed(ix, kmer_code(r, from, ix.kmer_size), ctx, [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-        return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
-      });
+      // seeded like the fast pass (the longer table when there is one). A path-less state over several suffix-array
+      // positions — a read inside a repeat — is taken apart into its positions in text form: the same set of
+      // (position, path) results (a marker hit concerns one position, and path-less final states are recorded position
+      // by position, encapsulated_search.cpp:30-107), but 32 bases per step and state instead of one
+      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+      const uint32_t from = r.len - k;
+      load_seed(ix, longer ? ix.seeds2 : ix.seeds, kmer_code(r, from, k), ctx,
+                [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+                  if (tvd == GMX_NIL && tvg == GMX_NIL && from > 0 && hi > lo && hi - lo < 64u) {
+                    bool ok = true;
+                    for (uint32_t i = lo; i <= hi && ok; ++i) ok = ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+                    return ok;
+                  }
+                  return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
+                });
       run = ctx.status == GMX_TASK_MAPPED;
     }
     GmxLane ln;
@@ -1138,6 +1165,7 @@ struct CoverEnvT {
 };
 
 typedef CoverEnvT<4, 4, 16, 16> CoverEnvLds;          // first tier of the general pass: per-lane scratch in the block's LDS
+typedef CoverEnvT<16, 8, 32, 32> CoverEnvMid;          // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
 typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
@@ -1152,7 +1180,9 @@ typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping
 // gmx_cover_lds_lanes<Env>() lanes, as many as copies of the scratch fit 64 KB.  Instance 1 uses global memory.
 template <class Env>
 constexpr uint32_t gmx_cover_lds_lanes() {
-  return GmxScratch<Env>::total * 64 * sizeof(uint32_t) <= 64 * 1024 ? 64u : 16u;
+  return GmxScratch<Env>::total * 64 * sizeof(uint32_t) <= 64 * 1024   ? 64u
+         : GmxScratch<Env>::total * 32 * sizeof(uint32_t) <= 64 * 1024 ? 32u
+                                                                       : 16u;
 }
 template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
@@ -1672,7 +1702,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
-  e->big.max_slots = 16384;
+  e->big.max_slots = 65536;  // x ~60 KB of pools each: 4 GB (a 1 M-read batch with 5 % of the genome in 10-copy repeats sends 34 k tasks here)
   rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
   rc |= e->alloc(&e->big.stack, (size_t)e->big.max_slots * e->big.max_states * GMX_STACK_WORDS, false);
   rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
@@ -1843,8 +1873,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(256), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
-  launch_cover_lds<CoverEnv, 2>(e, e->side2_stream, b, o, acc);
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
+  launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
   // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
   const bool general_on_side = !e->dview.is_nested;

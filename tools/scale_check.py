@@ -1,6 +1,6 @@
 """Larger configurations of BASELINE.json (configs[3] recipe: chr20 scale, k = 14) as a scale check: index build
 time and size, mapping rate, and size-independent properties (error-free reads all map in exactly one
-orientation class, counter identities, strand symmetry). Usage: python tools/scale_check.py GENOME N_SITES K N_READS"""
+orientation class, counter identities, strand symmetry). Usage: python tools/scale_check.py GENOME N_SITES K N_READS [repeats]"""
 import sys
 import time
 
@@ -16,6 +16,17 @@ from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads, sn
 G, n_sites, k, n_reads = (int(x) for x in sys.argv[1:5])
 t0 = time.time()
 ref = random_ref(G, 1)
+if "repeats" in sys.argv[5:]:  # 5 % of the reference replaced by 10 copies each of 1-5 kb segments
+    rng = np.random.default_rng(5)
+    budget = ref.size // 20
+    while budget > 0:
+        seg = int(rng.integers(1000, 5001))
+        src = int(rng.integers(0, ref.size - seg))
+        piece = ref[src:src + seg].copy()
+        for _ in range(10):
+            dst = int(rng.integers(0, ref.size - seg))
+            ref[dst:dst + seg] = piece
+        budget -= 10 * seg
 prg, pos, alts, n_alts = snp_prg(ref, n_sites, 2, multi_allelic_frac=0.05)
 print(f"PRG {prg.size} symbols, {n_sites} sites ({time.time() - t0:.1f} s)", flush=True)
 t0 = time.time()
