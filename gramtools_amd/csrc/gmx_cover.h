@@ -712,13 +712,24 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     if (n == 0xFFFFFFFFu) return;
     if (!gmx_item_key(ix, env, it, 0, n)) return;
   }
-  // number of distinct keys
+  // number of distinct keys; `first` marks the items (of the first 64) whose key no earlier item has, so that the
+  // selection below is quadratic, not cubic, in the number of items (a read inside a 10-copy repeat has 11)
   uint32_t n_classes = 0;
+  unsigned long long first = 0;
   for (uint32_t a = 0; a < n_items; ++a) {
     bool seen = false;
     for (uint32_t b = 0; b < a && !seen; ++b) seen = gmx_key_cmp(env, a, b) == 0;
-    if (!seen) ++n_classes;
+    if (!seen) {
+      ++n_classes;
+      if (a < 64) first |= 1ull << a;
+    }
   }
+  auto is_first = [&](uint32_t a) -> bool {
+    if (a < 64) return (first >> a) & 1ull;
+    bool dup = false;
+    for (uint32_t b = 0; b < a && !dup; ++b) dup = gmx_key_cmp(env, a, b) == 0;
+    return !dup;
+  };
   // --- selection (random_select_entry, coverage_common.cpp:95-108) ---
   uint32_t total = nonvariant + n_classes;
   uint32_t r;
@@ -731,16 +742,10 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
   // representative item of the class with `want` distinct keys strictly smaller
   uint32_t chosen = 0xFFFFFFFFu;
   for (uint32_t a = 0; a < n_items && chosen == 0xFFFFFFFFu; ++a) {
-    bool dup = false;
-    for (uint32_t b = 0; b < a && !dup; ++b) dup = gmx_key_cmp(env, a, b) == 0;
-    if (dup) continue;
+    if (!is_first(a)) continue;
     uint32_t smaller = 0;
-    for (uint32_t b = 0; b < n_items; ++b) {
-      if (gmx_key_cmp(env, b, a) >= 0) continue;
-      bool dupb = false;
-      for (uint32_t c = 0; c < b && !dupb; ++c) dupb = gmx_key_cmp(env, c, b) == 0;
-      if (!dupb) ++smaller;
-    }
+    for (uint32_t b = 0; b < n_items; ++b)
+      if (is_first(b) && gmx_key_cmp(env, b, a) < 0) ++smaller;
     if (smaller == want) chosen = a;
   }
   if (chosen == 0xFFFFFFFFu) {

@@ -858,8 +858,17 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         if (over) o.status[task] = GMX_TASK_OVERFLOW;
       } else {
         const uint32_t ns = ix.seed_words[sd.b];
-        alive = ns != 0 && ns <= 0xFFFFu;
-        if (ns > 0xFFFFu) {  // as load_seed_cursor: the large-capacity pass takes it, with the extend kernel's
+        // a multi-state entry with a path-less state over several positions (the k2-mer spans a site in one copy of a
+        // repeat and occurs plainly in the others): the large-capacity pass takes such a state apart, here it would
+        // step base by base
+        const uint32_t *w = ix.seed_words + sd.b + 1;
+        for (uint32_t i = 0; i < ns && i < 16u && !over; ++i) {
+          over = w[1] > w[0] && w[2] == 0 && w[3] == 0;
+          w += 4 + 2 * w[2] + w[3];
+        }
+        if (over) o.status[task] = GMX_TASK_OVERFLOW;
+        alive = ns != 0 && ns <= 0xFFFFu && !over;
+        if (ns > 0xFFFFu && !over) {  // as load_seed_cursor: the large-capacity pass takes it, with the extend kernel's
           o.status[task] = GMX_TASK_OVERFLOW;  // overflow queue (rare: one atomic per task)
           o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
         }
@@ -1702,7 +1711,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
-  e->big.max_slots = 65536;  // x ~60 KB of pools each: 4 GB (a 1 M-read batch with 5 % of the genome in 10-copy repeats sends 34 k tasks here)
+  e->big.max_slots = 131072;  // x ~60 KB of pools each: 8 GB (a 1 M-read batch with 5 % of the genome in 10-copy repeats sends 59 k tasks here)
   rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
   rc |= e->alloc(&e->big.stack, (size_t)e->big.max_slots * e->big.max_states * GMX_STACK_WORDS, false);
   rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);

@@ -53,7 +53,9 @@ def _load_emu():
     deps = srcs + [os.path.join(ROOT, "gramtools_amd", "csrc", h) for h in
                    ("gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_types.h", "gmx_index.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so] + srcs + ["-lpthread"])
+        tmp = f"{so}.{os.getpid()}.tmp"  # pytest-xdist workers may all find it stale: build aside, rename atomically
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + srcs + ["-lpthread"])
+        os.replace(tmp, so)
     lib = C.CDLL(so)
     lib.hostemu_create.restype = C.c_void_p
     lib.hostemu_create.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, C.c_uint64]
