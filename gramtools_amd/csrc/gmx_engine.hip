@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
   if (threadIdx.x < 3) {
     uint32_t total = 0;
     for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) total += cnt[w][threadIdx.x];
-    const uint32_t counter = threadIdx.x == 0 ? 5u : threadIdx.x == 1 ? 6u : 9u;
+    const uint32_t counter = threadIdx.x == 0 ? 5u : threadIdx.x == 1 ? 6u : 1u;
     base[threadIdx.x] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
@@ -907,7 +907,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     } else if (dead) {
       o.dead_list[at] = task;
     } else {
-      o.overflow2_list[at] = task;
+      o.overflow_list[at] = task;  // served beside the extend kernel (large-capacity pass 0)
     }
   }
 }
@@ -1199,15 +1199,19 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   constexpr bool BIG = LIST == 1;
   constexpr bool LDS = LIST != 1;
   constexpr uint32_t LANES = LDS ? gmx_cover_lds_lanes<Env>() : 64u;  // active lanes of a block (blockDim.x is 64)
+  // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
+  // in counter [10], 2 starts there
   uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  const uint32_t m_start = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
   const uint32_t *list = LIST == 3   ? o.cover_general_list
                          : LIST == 0 ? o.cover_mid_list
                          : LIST == 1 ? o.cover_overflow_list
                                      : o.big_mapped_list;
+  if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
   const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
   // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
-  for (uint32_t m = threadIdx.x * gridDim.x + blockIdx.x; m < n_mapped; m += gridDim.x * LANES) {
+  for (uint32_t m = m_start + threadIdx.x * gridDim.x + blockIdx.x; m < n_mapped; m += gridDim.x * LANES) {
     uint32_t entry = list[m];
     uint32_t task, nf;
     const GmxFinalState *finals;
@@ -1863,8 +1867,14 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-  if (!seeded)  // gmx_seed_kernel leaves nothing in the first overflow queue
+  CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
+  if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
+    HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
+    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 0);
+    launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
+  } else {
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
+  }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, task_grid, b, o, 0);
   if (seeded && e->seed_cursor)
@@ -1876,7 +1886,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   else
     hipLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
-  CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
