@@ -281,6 +281,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   }
 };
 
+#define GMX_BIG_LDS_DEPTH 16u  // pending entries of the large-capacity pass kept in LDS (most of its tasks need no more)
 struct BigCtx {  // the same DFS queue with everything in global memory and runtime capacities (large-capacity pass)
   __device__ __forceinline__ bool more_seeds() const { return false; }
   __device__ __forceinline__ bool next_seed(const GmxIndexView &, bool, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &,
@@ -288,7 +289,7 @@ struct BigCtx {  // the same DFS queue with everything in global memory and runt
     return false;
   }
   uint32_t sp, cap;
-  uint32_t *stack;  // cap x GMX_STACK_WORDS
+  uint32_t *stack;  // cap x GMX_STACK_WORDS; the first GMX_BIG_LDS_DEPTH entries live in LDS instead (lane-strided, 64-lane blocks)
   GmxPathNode *arena;
   uint32_t arena_n, arena_cap;
   uint32_t status;
@@ -297,23 +298,43 @@ struct BigCtx {  // the same DFS queue with everything in global memory and runt
   __device__ __forceinline__ bool pop(uint32_t &a, uint32_t &b, uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
     if (sp == 0) return false;
     --sp;
-    const uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
-    a = e[0];
-    b = e[1];
-    tvd = e[2];
-    tvg = e[3];
-    pos = e[4] & 0x3FFFFFFFu;
-    mode = e[4] >> 30;
+    uint32_t pm;
+    if (sp < GMX_BIG_LDS_DEPTH) {
+      const uint32_t *e = gmx_lds + (sp * GMX_STACK_WORDS) * 64 + (threadIdx.x & 63);
+      a = e[0];
+      b = e[64];
+      tvd = e[128];
+      tvg = e[192];
+      pm = e[256];
+    } else {
+      const uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
+      a = e[0];
+      b = e[1];
+      tvd = e[2];
+      tvg = e[3];
+      pm = e[4];
+    }
+    pos = pm & 0x3FFFFFFFu;
+    mode = pm >> 30;
     return true;
   }
   __device__ __forceinline__ bool push(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
     if (sp >= cap) return false;
-    uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
-    e[0] = a;
-    e[1] = b;
-    e[2] = tvd;
-    e[3] = tvg;
-    e[4] = pos | (mode << 30);
+    if (sp < GMX_BIG_LDS_DEPTH) {
+      uint32_t *e = gmx_lds + (sp * GMX_STACK_WORDS) * 64 + (threadIdx.x & 63);
+      e[0] = a;
+      e[64] = b;
+      e[128] = tvd;
+      e[192] = tvg;
+      e[256] = pos | (mode << 30);
+    } else {
+      uint32_t *e = stack + (size_t)sp * GMX_STACK_WORDS;
+      e[0] = a;
+      e[1] = b;
+      e[2] = tvd;
+      e[3] = tvg;
+      e[4] = pos | (mode << 30);
+    }
     ++sp;
     return true;
   }
@@ -1843,6 +1864,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
+  const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));
@@ -1870,10 +1892,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
-    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 0);
+    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 0);
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
-    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side_stream, e->dview, b, o, e->big, 0);
+    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
   }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, task_grid, b, o, 0);
@@ -1891,7 +1913,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), 0, e->side2_stream, e->dview, b, o, e->big, 1);
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
   launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
   // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
