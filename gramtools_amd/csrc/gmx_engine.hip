@@ -1660,8 +1660,17 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_seed_cursor, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
-  e->cap_reads = cap;
   if ((rc = e->alloc(&e->d_alive_seed, n_tasks, false))) return rc;
+  // large-capacity pass: one slot (~60 KB of pools at the default capacities) per task it may have to take; a 1 M-read
+  // batch with 5 % of the genome in 10-copy repeats sends 59 k of its 2 M tasks there
+  e->big.max_slots = (uint32_t)std::min<uint64_t>(n_tasks, std::min<uint64_t>(std::max<uint64_t>(n_tasks / 16, 4096), 262144));
+  if ((rc = e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false))) return rc;
+  if ((rc = e->alloc(&e->big.stack, (size_t)e->big.max_slots * e->big.max_states * GMX_STACK_WORDS, false))) return rc;
+  if ((rc = e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false))) return rc;
+  if ((rc = e->alloc(&e->big.n_final, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->big.task_of_slot, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_big_mapped, e->big.max_slots, false))) return rc;
+  e->cap_reads = cap;
   return GMX_OK;
 }
 
@@ -1736,12 +1745,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
-  e->big.max_slots = 131072;  // x ~60 KB of pools each: 8 GB (a 1 M-read batch with 5 % of the genome in 10-copy repeats sends 59 k tasks here)
-  rc |= e->alloc(&e->big.states, (size_t)e->big.max_slots * e->big.max_states, false);
-  rc |= e->alloc(&e->big.stack, (size_t)e->big.max_slots * e->big.max_states * GMX_STACK_WORDS, false);
-  rc |= e->alloc(&e->big.arena, (size_t)e->big.max_slots * e->big.max_path_nodes, false);
-  rc |= e->alloc(&e->big.n_final, e->big.max_slots, false);
-  rc |= e->alloc(&e->big.task_of_slot, e->big.max_slots, false);
+  e->big.max_slots = 0;  // its pools are sized with the batch (ensure_batch_capacity)
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, opts.device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1775,7 +1779,6 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // the rare large entry goes to the large-capacity pass
   e->seed_cursor = h.n_seed_states_large * 10 > h.n_seed_states;
   if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
-  rc |= e->alloc(&e->d_big_mapped, e->big.max_slots, false);
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;
