@@ -407,6 +407,30 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
 }
 
 // seeds the context from the k-mer index entry of the read's last k-mer (quasimap.cpp:235-241);
+// Device copies of the seed tables: in a multi-state entry (a = GMX_SEED_COMPLEX) the word offset b carries two flags
+// set once at upload (gmx_seed_mark_kernel), so that gmx_seed_kernel decides without reading the entry's words:
+//   GMX_SEEDF_BIG    the task goes to the large-capacity pass: the entry holds a path-less state over more positions
+//                    than the fast pass takes apart (a repeat), or more than 65535 states
+//   GMX_SEEDF_EMPTY  no state
+#define GMX_SEEDF_BIG 0x80000000u
+#define GMX_SEEDF_EMPTY 0x40000000u
+#define GMX_SEED_OFF(b) ((b) & 0x3FFFFFFFu)
+#define GMX_SEED_SPLIT_MAX 5u  // a path-less seed state over 2 .. 5 positions is taken apart in the fast pass (stack of 6)
+__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const GmxSeed s = seeds[i];
+    if (s.a != GMX_SEED_COMPLEX) continue;
+    const uint32_t *w = seed_words + s.b;
+    const uint32_t ns = *w++;
+    bool big = ns > 0xFFFFu;
+    for (uint32_t j = 0; j < ns && !big; ++j) {
+      big = w[1] >= w[0] + GMX_SEED_SPLIT_MAX && w[2] == 0 && w[3] == 0;
+      w += 4 + 2 * w[2] + w[3];
+    }
+    seeds[i].b = s.b | (big ? GMX_SEEDF_BIG : 0u) | (ns == 0 ? GMX_SEEDF_EMPTY : 0u);
+  }
+}
+
 // push(lo, hi, tvd, tvg) receives every seed state
 template <class Ctx, class Push>
 __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t code, Ctx &ctx, Push push) {
@@ -415,7 +439,7 @@ __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t
     if (s.a <= s.b) push(s.a, s.b, GMX_NIL, GMX_NIL);
     return;
   }
-  const uint32_t *p = ix.seed_words + s.b;
+  const uint32_t *p = ix.seed_words + GMX_SEED_OFF(s.b);
   uint32_t ns = *p++;
   for (uint32_t i = 0; i < ns; ++i) {
     uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
@@ -446,7 +470,7 @@ __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t
 template <bool CURSOR>
 __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const GmxSeed s, FastCtx &ctx, uint32_t from) {
   if (s.a != GMX_SEED_COMPLEX) {
-    if (s.a < s.b && s.b != GMX_TEXT_MARK && s.b - s.a < GMX_STACK_DEPTH - 1 && from > 0) {
+    if (s.a < s.b && s.b != GMX_TEXT_MARK && s.b - s.a < GMX_SEED_SPLIT_MAX && from > 0) {
       // a few occurrences (a short repeat): position by position in text form — the same results (see
       // gmx_search_big_kernel), 32 bases per step instead of one rank block per base and 137 iterations of the wave
       for (uint32_t i = s.a; i <= s.b; ++i) ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
@@ -455,23 +479,30 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
     }
     return;
   }
-  const uint32_t ns = ix.seed_words[s.b];
+  const uint32_t ns = ix.seed_words[GMX_SEED_OFF(s.b)];
   if (ns > 0xFFFFu) {
     ctx.fail(GMX_TASK_OVERFLOW);
     return;
   }
-  ctx.seed_off = s.b + 1;
+  ctx.seed_off = GMX_SEED_OFF(s.b) + 1;
   ctx.seed_pos = from;
   ctx.seed_left = ns;
   ctx.mark_arena = ctx.arena_n;
   ctx.mark_out = ctx.n_out;
   if (!CURSOR || ns <= GMX_SEED_PUSH_MAX) {  // all on the stack at once (no dependent index fetch between them)
     uint32_t a, b, tvd, tvg, pos, mode;
-    while (ctx.seed_left && ctx.next_seed(ix, false, a, b, tvd, tvg, pos, mode))
-      if (!ctx.push(a, b, tvd, tvg, pos, mode)) {
+    while (ctx.seed_left && ctx.next_seed(ix, false, a, b, tvd, tvg, pos, mode)) {
+      bool ok = true;
+      if (tvd == GMX_NIL && tvg == GMX_NIL && b > a && b != GMX_TEXT_MARK && b - a < GMX_SEED_SPLIT_MAX && pos > 0) {
+        for (uint32_t i = a; i <= b && ok; ++i) ok = ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, pos, mode);  // as above
+      } else {
+        ok = ctx.push(a, b, tvd, tvg, pos, mode);
+      }
+      if (!ok) {
         ctx.fail(GMX_TASK_OVERFLOW);
         ctx.seed_left = 0;
       }
+    }
   }
 }
 
@@ -874,27 +905,16 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         // a k2-mer with more occurrences than the per-lane stack has entries lies in a repeat: its interval splits at
         // the copies' own sites, the task would overflow the extend kernel after holding its wave up — straight to the
         // large-capacity pass (with the extend kernel's overflow queue)
-        over = sd.a <= sd.b && sd.b - sd.a >= GMX_STACK_DEPTH;
+        over = sd.a <= sd.b && sd.b - sd.a >= GMX_SEED_SPLIT_MAX;
         alive = sd.a <= sd.b && !over;
-        if (over) o.status[task] = GMX_TASK_OVERFLOW;
       } else {
-        const uint32_t ns = ix.seed_words[sd.b];
-        // a multi-state entry with a path-less state over several positions (the k2-mer spans a site in one copy of a
-        // repeat and occurs plainly in the others): the large-capacity pass takes such a state apart, here it would
-        // step base by base
-        const uint32_t *w = ix.seed_words + sd.b + 1;
-        for (uint32_t i = 0; i < ns && i < 16u && !over; ++i) {
-          over = w[1] > w[0] && w[2] == 0 && w[3] == 0;
-          w += 4 + 2 * w[2] + w[3];
-        }
-        if (over) o.status[task] = GMX_TASK_OVERFLOW;
-        alive = ns != 0 && ns <= 0xFFFFu && !over;
-        if (ns > 0xFFFFu && !over) {  // as load_seed_cursor: the large-capacity pass takes it, with the extend kernel's
-          o.status[task] = GMX_TASK_OVERFLOW;  // overflow queue (rare: one atomic per task)
-          o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
-        }
+        // a multi-state entry with a path-less state over many positions (the k2-mer spans a site in one copy of a
+        // repeat and occurs plainly in the others; flagged at upload): the large-capacity pass takes such a state apart
+        over = (sd.b & GMX_SEEDF_BIG) != 0;
+        alive = !over && !(sd.b & GMX_SEEDF_EMPTY);
       }
-      dead = !alive && !over && !(sd.a == GMX_SEED_COMPLEX && ix.seed_words[sd.b] > 0xFFFFu);
+      if (over) o.status[task] = GMX_TASK_OVERFLOW;
+      dead = !alive && !over;
     } else {
       o.status[task] = GMX_TASK_SKIPPED;
     }
@@ -1721,6 +1741,17 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   if (h.kmer_size2) rc |= e->upload(&v.seeds2, h.seeds2);
   else v.seeds2 = nullptr;
   rc |= e->upload(&v.seed_words, h.seed_words);
+  if (!rc) {  // flags in the multi-state entries of the device copies (GMX_SEEDF_*)
+    if (h.seed_words.size() >= (1u << 30)) {
+      gmx_set_error("the seed tables hold more than 2^30 words of multi-state entries");
+      rc = GMX_ECAP;
+    } else {
+      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words);
+      if (h.kmer_size2)
+        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words);
+      rc |= hipDeviceSynchronize() != hipSuccess;
+    }
+  }
   rc |= e->upload(&v.kmer_bitmap, h.kmer_bitmap);
   e->dview = v;
   e->n_allele = h.n_allele_slots;
