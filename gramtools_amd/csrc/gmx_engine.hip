@@ -1215,7 +1215,7 @@ struct CoverEnvT {
 };
 
 typedef CoverEnvT<4, 4, 16, 16> CoverEnvLds;          // first tier of the general pass: per-lane scratch in the block's LDS
-typedef CoverEnvT<16, 8, 32, 32> CoverEnvMid;          // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
+typedef CoverEnvT<12, 6, 24, 24> CoverEnvMid;          // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
 typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
