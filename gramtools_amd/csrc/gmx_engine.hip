@@ -1161,6 +1161,122 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
   }
 }
 
+// The seed kernel's tasks (reads in repeats: a seed over many suffix-array positions) with GMX_SPLIT lanes per task: the
+// mapping instances are independent text-form states, so lane `sub` of a task's group takes every GMX_SPLIT-th of
+// them — a tenth of the dependent iterations one lane would run. Each lane has its own part of the slot's pools
+// (pending entries, path nodes: handles stay slot-wide indices; final states in the upper half of the slot's array),
+// and the group then moves its final states together to the front of the array, where the coverage instance expects
+// them. A task one of whose lanes runs out of its part is handed to the second instance of gmx_search_big_kernel,
+// which runs it in one lane with the whole slot.
+#define GMX_SPLIT 16u
+__global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
+  const uint32_t n_over = o.counters[1 * GMX_CNT_STRIDE];
+  const uint32_t groups = 64 / GMX_SPLIT, group = threadIdx.x / GMX_SPLIT, sub = threadIdx.x % GMX_SPLIT;
+  const uint32_t per_round = gridDim.x * groups;
+  const uint32_t part_states = g.max_states / (2 * GMX_SPLIT), part_nodes = g.max_path_nodes / GMX_SPLIT,
+                 part_stack = g.max_states / GMX_SPLIT;
+  for (uint32_t base = 0; base < n_over; base += per_round) {
+    const uint32_t qi = base + group * gridDim.x + blockIdx.x;  // interleaved over the blocks
+    bool active = qi < n_over;
+    const uint32_t task = active ? o.overflow_list[qi] : 0;
+    const uint32_t slot = qi;
+    if (active && slot >= g.max_slots) {
+      if (sub == 0 && atomicCAS(&o.error[0], 0u, GMX_TASK_OVERFLOW) == 0u) o.error[1] = task;
+      active = false;
+    }
+    const size_t s0 = active ? slot : 0;
+    BigCtx ctx;
+    ctx.sp = 0;
+    ctx.cap = part_stack;
+    ctx.stack = g.stack + (s0 * g.max_states + (size_t)sub * part_stack) * GMX_STACK_WORDS;
+    ctx.arena = g.arena + s0 * g.max_path_nodes;
+    ctx.arena_n = sub * part_nodes;
+    ctx.arena_cap = (sub + 1) * part_nodes;
+    ctx.status = GMX_TASK_MAPPED;
+    GmxFinalState *const slot_states = g.states + s0 * g.max_states;
+    ctx.out = slot_states + g.max_states / 2 + sub * part_states;
+    ctx.n_out = 0;
+    ctx.out_cap = part_states;
+    ReadRef r;
+    r.w = b.packed;
+    r.len = 0;
+    r.rc = false;
+    r.cur_idx = 0xFFFFFFFFu;
+    r.cur = make_uint2(0, 0);
+    bool run = false;
+    if (active) {
+      r = task_read(b, task);
+      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+      const uint32_t from = r.len - k;
+      const GmxSeed sd = (longer ? ix.seeds2 : ix.seeds)[kmer_code(r, from, k)];
+      bool ok = true;
+      uint32_t turn = 0;  // states and positions are dealt out to the lanes of the group in turn
+      auto mine = [&]() { return (turn++ % GMX_SPLIT) == sub; };
+      auto state = [&](uint32_t lo, uint32_t hi, const uint32_t *paths, uint32_t nt, uint32_t ng) {
+        if (nt == 0 && ng == 0 && from > 0 && hi > lo && hi - lo < 4096u) {
+          for (uint32_t i = lo; i <= hi && ok; ++i)
+            if (mine()) ok = ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+          return;
+        }
+        if (!mine()) return;
+        uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
+        for (uint32_t j = 0; j < nt && ok; ++j) {
+          tvd = ctx.arena_new(paths[2 * j], (int32_t)paths[2 * j + 1], tvd);
+          ok = tvd != GMX_NIL;
+        }
+        for (uint32_t j = 0; j < ng && ok; ++j) {
+          tvg = ctx.arena_new(paths[2 * nt + j], -1, tvg);
+          ok = tvg != GMX_NIL;
+        }
+        ok = ok && ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
+      };
+      if (sd.a != GMX_SEED_COMPLEX) {
+        if (sd.a <= sd.b) state(sd.a, sd.b, nullptr, 0, 0);
+      } else {
+        const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+        const uint32_t ns = *w++;
+        for (uint32_t i = 0; i < ns && ok; ++i) {
+          state(w[0], w[1], w + 4, w[2], w[3]);
+          w += 4 + 2 * w[2] + w[3];
+        }
+      }
+      if (!ok) ctx.fail(GMX_TASK_OVERFLOW);
+      run = ctx.status == GMX_TASK_MAPPED;
+    }
+    GmxLane ln;
+    dfs_run_wave<2, false>(ix, ctx, r, 0, run, 0, ln);
+    // the group's verdict and the places of its final states (shuffles within the GMX_SPLIT lanes of the group)
+    const unsigned long long bad = __ballot(active && ctx.status != GMX_TASK_MAPPED);
+    const bool group_bad = ((bad >> (group * GMX_SPLIT)) & ((1ull << GMX_SPLIT) - 1ull)) != 0;
+    uint32_t before = 0, total = 0;
+    for (uint32_t i = 0; i < GMX_SPLIT; ++i) {
+      const uint32_t n_i = __shfl(ctx.n_out, (int)(group * GMX_SPLIT + i));
+      before += i < sub ? n_i : 0;
+      total += n_i;
+    }
+    if (!active) continue;
+    if (group_bad) {  // one lane's part did not suffice: the whole task again, in one lane with the whole slot
+      if (sub == 0) {
+        o.status[task] = GMX_TASK_OVERFLOW;
+        o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
+        g.n_final[slot] = 0;
+        g.task_of_slot[slot] = task;
+      }
+      continue;
+    }
+    for (uint32_t f = 0; f < ctx.n_out; ++f) slot_states[before + f] = ctx.out[f];  // the front half: disjoint from every part
+    if (sub != 0) continue;
+    uint32_t status = GMX_TASK_MAPPED;
+    if (total == 0) status = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+    o.status[task] = status;
+    o.n_final[task] = total;
+    g.n_final[slot] = total;
+    g.task_of_slot[slot] = task;
+    if (total > 0) o.big_mapped_list[atomicAdd(&o.counters[7 * GMX_CNT_STRIDE], 1u)] = 0x80000000u | slot;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // coverage kernel
 // ---------------------------------------------------------------------------
@@ -1926,7 +2042,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
-    hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 0);
+    hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);

@@ -16,9 +16,11 @@ from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads, sn
 G, n_sites, k, n_reads = (int(x) for x in sys.argv[1:5])
 t0 = time.time()
 ref = random_ref(G, 1)
-if "repeats" in sys.argv[5:]:  # 5 % of the reference replaced by 10 copies each of 1-5 kb segments
+rep_arg = [a for a in sys.argv[5:] if a.startswith("repeats")]
+if rep_arg:  # 5 % (or repeats=FRACTION) of the reference replaced by 10 copies each of 1-5 kb segments
     rng = np.random.default_rng(5)
-    budget = ref.size // 20
+    frac = float(rep_arg[0].split("=")[1]) if "=" in rep_arg[0] else 0.05
+    budget = int(ref.size * frac)
     while budget > 0:
         seg = int(rng.integers(1000, 5001))
         src = int(rng.integers(0, ref.size - seg))
