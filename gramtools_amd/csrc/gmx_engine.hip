@@ -666,7 +666,6 @@ struct SearchOut {
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
   GmxSeed *alive_seed;       // gmx_seed_kernel: the seed directory entry of alive_list[i]
-  uint32_t *big_mapped2_list;  // as big_mapped_list, of the large-capacity pass's second instance; counter [11]
   // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
   // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
   // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
@@ -1155,9 +1154,9 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     o.n_final[task] = nf;
     g.n_final[slot] = nf;
     g.task_of_slot[slot] = task;
-    if (status == GMX_TASK_MAPPED && nf > 0) {  // the two instances' coverage runs at different times: a queue each
-      uint32_t at = atomicAdd(&o.counters[(second ? 11 : 7) * GMX_CNT_STRIDE], 1u);
-      (second ? o.big_mapped2_list : o.big_mapped_list)[at] = 0x80000000u | slot;
+    if (status == GMX_TASK_MAPPED && nf > 0) {
+      uint32_t at = atomicAdd(&o.counters[7 * GMX_CNT_STRIDE], 1u);
+      o.big_mapped_list[at] = 0x80000000u | slot;
     }
   }
 }
@@ -1357,14 +1356,15 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   constexpr bool BIG = LIST == 1;
   constexpr bool LDS = LIST != 1;
   constexpr uint32_t LANES = LDS ? gmx_cover_lds_lanes<Env>() : 64u;  // active lanes of a block (blockDim.x is 64)
-  // LIST 4: what the large-capacity pass's first instance (or gmx_search_split_kernel) mapped; LIST 2: its second
-  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : LIST == 2 ? 11 : 7) * GMX_CNT_STRIDE];
-  const uint32_t m_start = 0u;
+  // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
+  // in counter [10], 2 starts there
+  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  const uint32_t m_start = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
   const uint32_t *list = LIST == 3   ? o.cover_general_list
                          : LIST == 0 ? o.cover_mid_list
                          : LIST == 1 ? o.cover_overflow_list
-                         : LIST == 2 ? o.big_mapped2_list
                                      : o.big_mapped_list;
+  if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
   const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
   // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
@@ -1692,9 +1692,6 @@ struct gmx_engine {
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
   GmxSeed *d_alive_seed = nullptr;
-  uint32_t *d_big_mapped2 = nullptr;
-  hipStream_t side3_stream = nullptr;  // the extend kernel's overflow queue and the general coverage instances
-  hipEvent_t ev_join3 = nullptr, ev_split = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
@@ -1809,7 +1806,6 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->big.n_final, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->big.task_of_slot, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_big_mapped, e->big.max_slots, false))) return rc;
-  if ((rc = e->alloc(&e->d_big_mapped2, e->big.max_slots, false))) return rc;
   e->cap_reads = cap;
   return GMX_OK;
 }
@@ -1932,9 +1928,6 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
-  rc |= hipStreamCreateWithFlags(&e->side3_stream, hipStreamNonBlocking) != hipSuccess;
-  rc |= hipEventCreateWithFlags(&e->ev_join3, hipEventDisableTiming) != hipSuccess;
-  rc |= hipEventCreateWithFlags(&e->ev_split, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_side1, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_filter, hipEventDisableTiming) != hipSuccess;
@@ -1956,9 +1949,6 @@ void gmx_engine_destroy(gmx_engine *e) {
   (void)hipDeviceSynchronize();
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
   if (e->side2_stream) (void)hipStreamDestroy(e->side2_stream);
-  if (e->side3_stream) (void)hipStreamDestroy(e->side3_stream);
-  if (e->ev_join3) (void)hipEventDestroy(e->ev_join3);
-  if (e->ev_split) (void)hipEventDestroy(e->ev_split);
   if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
   if (e->ev_side1) (void)hipEventDestroy(e->ev_side1);
   if (e->ev_filter) (void)hipEventDestroy(e->ev_filter);
@@ -2019,7 +2009,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed, e->d_big_mapped2};
+              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters);
@@ -2053,7 +2043,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
     hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
-    HIP_TRY(hipEventRecord(e->ev_split, e->side2_stream));  // it may still add to the second overflow queue
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
@@ -2072,24 +2061,17 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
-  // (third side stream: few, long-running tasks each — beside the coverage of the first instance's tasks on the second)
-  HIP_TRY(hipStreamWaitEvent(e->side3_stream, e->ev_fork2, 0));
-  if (seeded) {
-    HIP_TRY(hipStreamWaitEvent(e->side3_stream, e->ev_split, 0));
-  } else {  // the probe kernel's overflow tasks (first instance, side stream 1): their coverage here
-    HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
-    launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
-  }
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side3_stream, e->dview, b, o, e->big, 1);
-  launch_cover_lds<CoverEnvMid, 2>(e, e->side3_stream, b, o, acc);
+  HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
+  HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
+  launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
   // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
   const bool general_on_side = !e->dview.is_nested;
   if (general_on_side) {
-    launch_cover_lds<CoverEnvLds, 3>(e, e->side3_stream, b, o, acc);
-    launch_cover_lds<CoverEnv, 0>(e, e->side3_stream, b, o, acc);
+    launch_cover_lds<CoverEnvLds, 3>(e, e->side2_stream, b, o, acc);
+    launch_cover_lds<CoverEnv, 0>(e, e->side2_stream, b, o, acc);
   }
-  HIP_TRY(hipEventRecord(e->ev_join3, e->side3_stream));
   HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
   // second filter pass: the tasks the extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
@@ -2101,7 +2083,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
   }
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
-  HIP_TRY(hipStreamWaitEvent(stream, e->ev_join3, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
                      b, o, e->big, acc);
@@ -2312,7 +2293,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->dead = c(6) + c(12);
   out->overflow_probe = c(1);
   out->overflow_extend = c(9);
-  out->big_mapped = c(7) + c(11);
+  out->big_mapped = c(7);
   out->cover_general = c(8);
   out->cover_mid = c(13);
   out->cover_overflow = c(4);
