@@ -295,3 +295,294 @@ def nested_regions_prg(n_regions: int, seed: int, spacer_lo: int = 30, spacer_hi
                                 seq_max=int(rng.integers(2, 8))))
     parts.append("".join(letters[int(x)] for x in rng.integers(0, 4, size=spacer_hi)))
     return bracket_to_ints("".join(parts))
+
+
+# ---------------------------------------------------------------------------------------------------
+# vectorised recipes at BASELINE.json scale (SURVEY.md §8d): configs[3] (SNPs + indels + multi-allelic sites, flat)
+# and configs[2] (flat SNPs + nested "MSA regions"). Everything below is numpy index arithmetic: a 64 Mb / 1.8 M-site
+# PRG and its haplotypes are built in seconds, so the same recipe serves an oracle-checked slice and the full size.
+# ---------------------------------------------------------------------------------------------------
+def _ragged_arange(lens):
+    """[0..lens[0]), [0..lens[1]), ... concatenated, and the owner index of every element."""
+    lens = np.asarray(lens, dtype=np.int64)
+    total = int(lens.sum())
+    owner = np.repeat(np.arange(lens.size, dtype=np.int64), lens)
+    starts = np.cumsum(lens) - lens
+    return np.arange(total, dtype=np.int64) - starts[owner], owner
+
+
+class VariantSites:
+    """Flat variant sites over a reference: site s replaces ref[start[s] : start[s] + ref_len[s]] by one of its alleles
+    (allele 0 = the reference allele). Alleles are stored ragged: allele j of site s is
+    bases[a_off[a_first[s] + j] : a_off[a_first[s] + j + 1]]."""
+
+    def __init__(self, start, ref_len, n_alleles, a_first, a_off, bases):
+        self.start, self.ref_len, self.n_alleles = start, ref_len, n_alleles
+        self.a_first, self.a_off, self.bases = a_first, a_off, bases
+
+    @property
+    def n_sites(self):
+        return int(self.start.size)
+
+    def allele(self, s, j):
+        a = int(self.a_first[s]) + j
+        return self.bases[int(self.a_off[a]):int(self.a_off[a + 1])]
+
+
+def variant_sites(ref: np.ndarray, n_sites: int, seed: int, snp_frac: float = 0.9, multi_frac: float = 0.05,
+                  max_indel: int = 10) -> VariantSites:
+    """The configs[3] site mix: `snp_frac` SNPs, the rest 1..max_indel bp indels in three equal kinds (insertion behind an
+    anchor base, deletion behind an anchor base, pure deletion = an empty alternative allele); independently
+    `multi_frac` of all sites carry 3-4 alleles. Alleles of one site are pairwise different. One site per grid cell of
+    G // n_sites bases, so sites never touch (cells must be >= max_indel + 3 bases when indels are requested)."""
+    rng = np.random.default_rng(seed)
+    G = int(ref.size)
+    cell = G // max(n_sites, 1)
+    span = max_indel + 1 if snp_frac < 1.0 else 1
+    if cell < span + 2:
+        raise ValueError("too many sites for this reference")
+    start = np.arange(n_sites, dtype=np.int64) * cell + rng.integers(1, cell - span, size=n_sites)
+    kind = np.where(rng.random(n_sites) < snp_frac, 0, rng.integers(1, 4, size=n_sites))  # 0 SNP, 1 ins, 2 del, 3 pure del
+    d = rng.integers(1, max_indel + 1, size=n_sites)
+    ref_len = np.where(kind == 0, 1, np.where(kind == 1, 1, np.where(kind == 2, 1 + d, d))).astype(np.int64)
+    n_alleles = np.where(rng.random(n_sites) < multi_frac, rng.integers(3, 5, size=n_sites), 2).astype(np.int64)
+    a_first = np.cumsum(n_alleles) - n_alleles
+    j, site = _ragged_arange(n_alleles)                       # allele index within its site, owning site
+    k, dd = kind[site], d[site]
+    # lengths: allele 0 = ref_len; SNP alts 1; insertion alts 1 + d (+ j - 1 for the extra ones: pairwise different
+    # lengths); deletion-with-anchor alts 1, 2 + d, 3 + d; pure deletion alts 0, d + 1, d + 2
+    alt_len = np.where(k == 0, 1,
+               np.where(k == 1, dd + j,
+               np.where(k == 2, np.where(j == 1, 1, dd + j),
+                        np.where(j == 1, 0, dd + j - 1))))
+    a_len = np.where(j == 0, ref_len[site], alt_len).astype(np.int64)
+    a_off = np.concatenate([[0], np.cumsum(a_len)]).astype(np.int64)
+    within, owner = _ragged_arange(a_len)                      # base index within its allele, owning allele
+    bases = rng.integers(1, 5, size=int(a_len.sum()), dtype=np.uint8)
+    o_site, o_j, o_kind = site[owner], j[owner], k[owner]
+    is_ref = o_j == 0
+    bases[is_ref] = ref[start[o_site[is_ref]] + within[is_ref]]
+    snp_alt = (o_kind == 0) & ~is_ref                          # the j-th alternative of a SNP: ref base + j (cyclic)
+    bases[snp_alt] = ((ref[start[o_site[snp_alt]]].astype(np.int64) - 1 + o_j[snp_alt]) % 4 + 1).astype(np.uint8)
+    anchored = ((o_kind == 1) | (o_kind == 2)) & ~is_ref & (within == 0)  # VCF-style indels keep the anchor base
+    bases[anchored] = ref[start[o_site[anchored]]]
+    # a deletion's alternative must differ from the reference allele even when equally long: impossible by the lengths above
+    return VariantSites(start, ref_len, n_alleles, a_first, a_off, bases)
+
+
+def _splice(ref: np.ndarray, start, ref_len, piece_off, piece_bases, dtype):
+    """ref with [start[s], start[s] + ref_len[s]) replaced by piece s = piece_bases[piece_off[s] : piece_off[s + 1]].
+    Returns (out, pos_of_ref) where pos_of_ref[i] = position in `out` of reference base i (of the first base at or
+    after i that is kept, for bases inside a replaced span)."""
+    G = int(ref.size)
+    piece_len = np.diff(piece_off)
+    keep = np.ones(G, dtype=bool)
+    w, owner = _ragged_arange(ref_len)
+    keep[start[owner] + w] = False
+    grow = np.zeros(G + 1, dtype=np.int64)                     # extra output symbols emitted before reference base i
+    np.add.at(grow, start, piece_len)
+    pos_of_ref = np.cumsum(keep) - keep + np.cumsum(grow[:G])  # kept bases before i + pieces starting at or before i
+    out = np.empty(int(keep.sum() + piece_len.sum()), dtype=dtype)
+    out[pos_of_ref[keep]] = ref[keep]
+    pw, powner = _ragged_arange(piece_len)
+    piece_start = pos_of_ref[start] - piece_len                # a piece sits right before the first kept base after it
+    out[piece_start[powner] + pw] = piece_bases[piece_off[powner] + pw]
+    return out, pos_of_ref
+
+
+def variant_prg(ref: np.ndarray, sites: VariantSites):
+    """The PRG of `sites` over `ref`: ... 5 allele0 6 allele1 6 [allele2 6 ...] ... (vcf_to_prg_string.py:81-101).
+    Returns (prg uint32, pos_of_ref)."""
+    S = sites.n_sites
+    a_len = np.diff(sites.a_off)
+    n_all = sites.n_alleles
+    blk_len = 1 + np.add.reduceat(a_len, sites.a_first) + n_all if S else np.zeros(0, dtype=np.int64)
+    blk_off = np.concatenate([[0], np.cumsum(blk_len)]).astype(np.int64)
+    blk = np.empty(int(blk_off[-1]), dtype=np.uint32)
+    marker = (5 + 2 * np.arange(S, dtype=np.int64)).astype(np.uint32)
+    blk[blk_off[:-1]] = marker
+    # allele a of site s starts at blk_off[s] + 1 + (bases of earlier alleles of s) + (its index in the site)
+    j, site = _ragged_arange(n_all)
+    before = (sites.a_off[:-1] - sites.a_off[sites.a_first[site]]) + j
+    a_start = blk_off[site] + 1 + before
+    w, owner = _ragged_arange(a_len)
+    blk[a_start[owner] + w] = sites.bases[sites.a_off[owner] + w]
+    blk[a_start + a_len] = marker[site] + 1                    # separator behind every allele; the last one closes the site
+    return _splice(ref.astype(np.uint32), sites.start, sites.ref_len, blk_off, blk, np.uint32)
+
+
+def variant_haplotype(ref: np.ndarray, sites: VariantSites, seed: int, alt_prob: float = 0.5):
+    """One haplotype: at every site the reference allele with probability 1 - alt_prob, else a uniform alternative.
+    Returns (bases uint8, pos_of_ref)."""
+    rng = np.random.default_rng(seed)
+    S = sites.n_sites
+    pick = np.where(rng.random(S) < alt_prob, 1 + (rng.random(S) * (sites.n_alleles - 1)).astype(np.int64), 0)
+    a = sites.a_first + pick
+    a_len = sites.a_off[a + 1] - sites.a_off[a]
+    off = np.concatenate([[0], np.cumsum(a_len)]).astype(np.int64)
+    w, owner = _ragged_arange(a_len)
+    pieces = sites.bases[sites.a_off[a][owner] + w]
+    return _splice(ref, sites.start, sites.ref_len, off, pieces, np.uint8)
+
+
+def reads_from_haplotypes(haps, n_reads: int, read_len: int, seed: int, rc_prob: float = 0.5) -> np.ndarray:
+    """Error-free reads: a uniform haplotype, a uniform start, either strand. uint8 [n_reads, read_len]."""
+    rng = np.random.default_rng(seed)
+    which = rng.integers(0, len(haps), size=n_reads)
+    reads = np.empty((n_reads, read_len), dtype=np.uint8)
+    cols = np.arange(read_len)[None, :]
+    for h, hap in enumerate(haps):
+        sel = np.nonzero(which == h)[0]
+        st = rng.integers(0, hap.size - read_len + 1, size=sel.size)
+        reads[sel] = hap[st[:, None] + cols]
+    flip = rng.random(n_reads) < rc_prob
+    reads[flip] = (5 - reads[flip])[:, ::-1]
+    return reads
+
+
+def chr20_recipe(G: int, n_sites: int, n_reads: int, seed: int, n_haps: int = 4, read_len: int = 150):
+    """BASELINE.json configs[3] at any size: random reference of G bases, n_sites sites (90 % SNPs, 10 % 1-10 bp indels
+    incl. pure deletions, 5 % with 3-4 alleles; full size: G = 64 444 167, 1.8 M sites, k = 14), error-free reads
+    from `n_haps` haplotypes. Returns (prg, reads)."""
+    ref = random_ref(G, seed)
+    sites = variant_sites(ref, n_sites, seed + 1)
+    prg, _ = variant_prg(ref, sites)
+    haps = [variant_haplotype(ref, sites, seed + 10 + h)[0] for h in range(n_haps)]
+    return prg, reads_from_haplotypes(haps, n_reads, read_len, seed + 2)
+
+
+def msa_region(rng, target_len: int, max_depth: int = 3) -> str:
+    """One "MSA region" of the configs[2] recipe as a bracketed PRG: about `target_len` bases along its first alleles,
+    sites with 2-6 alleles, nesting up to `max_depth`, empty alleles and adjacent sites."""
+    def seq(lo, hi):
+        return "".join("acgt"[int(x)] for x in rng.integers(0, 4, size=int(rng.integers(lo, hi + 1))))
+
+    def site(depth):
+        n_alleles = int(rng.integers(2, 7))
+        alleles, seen = [], set()
+        while len(alleles) < n_alleles:
+            if rng.random() < 0.1 and "" not in seen:
+                a = ""
+            else:
+                a = seq(1, 12)
+                if depth < max_depth and rng.random() < 0.3:
+                    a += site(depth + 1)
+                    if rng.random() < 0.2:
+                        a += site(depth + 1)           # adjacent sites inside an allele
+                    a += seq(0 if rng.random() < 0.2 else 1, 8)
+            if a in seen:
+                continue
+            seen.add(a)
+            alleles.append(a)
+        return "[" + ",".join(alleles) + "]"
+
+    out, n = [], 0
+    while n < target_len:
+        s = seq(3, 25)
+        out.append(s)
+        out.append(site(1))
+        n += len(s) + 6
+        if rng.random() < 0.15:
+            out.append(site(1))                        # adjacent top-level sites
+            n += 6
+    return "".join(out)
+
+
+def _expand_region(ints, rng):
+    """One random haplotype through a (nested) region given as PRG ints."""
+    prg = [int(x) for x in ints]
+    n = len(prg)
+    last = {}
+    for i, m in enumerate(prg):
+        if m > 4 and m % 2 == 0:
+            last[m] = i
+    open_info, stack = {}, []
+    for i, m in enumerate(prg):
+        if m > 4 and m % 2 == 1:
+            stack.append([i, [i + 1]])
+        elif m > 4:
+            top = stack[-1]
+            if last[m] == i:
+                starts = top[1]
+                ends = starts[1:] + [i + 1]
+                open_info[top[0]] = ([(s, e - 1) for s, e in zip(starts, ends)], i)
+                stack.pop()
+            else:
+                top[1].append(i + 1)
+    out = []
+
+    def expand(lo, hi):
+        i = lo
+        while i < hi:
+            m = prg[i]
+            if m <= 4:
+                out.append(m)
+                i += 1
+            else:
+                alleles, close = open_info[i]
+                s, e = alleles[int(rng.integers(0, len(alleles)))]
+                expand(s, e)
+                i = close + 1
+
+    expand(0, n)
+    return np.asarray(out, dtype=np.uint8)
+
+
+def renumber_markers(prg: np.ndarray) -> np.ndarray:
+    """Site markers renumbered 5, 7, 9, ... in order of appearance of the opening (odd) marker."""
+    prg = np.asarray(prg, dtype=np.uint32)
+    is_open = (prg > 4) & (prg % 2 == 1)
+    opens = prg[is_open]
+    table = np.zeros(int(prg.max()) + 2, dtype=np.uint32)
+    table[opens] = 5 + 2 * np.arange(opens.size, dtype=np.uint32)
+    table[opens + 1] = table[opens] + 1
+    out = prg.copy()
+    mk = prg > 4
+    out[mk] = table[prg[mk]]
+    return out
+
+
+def pf3d7_recipe(G: int, n_regions: int, n_snps: int, n_reads: int, seed: int, n_haps: int = 4, read_len: int = 150,
+                 region_lo: int = 200, region_hi: int = 800):
+    """BASELINE.json configs[2] at any size: random reference of G bases with n_snps flat SNP sites, and n_regions nested
+    "MSA regions" of region_lo..region_hi bases (depth <= 3, 2-6 alleles per site, empty alleles, adjacent sites)
+    inserted between reference bases (full size: G = 23.3 Mb, 2 000 regions, 100 k SNPs, k = 10). Error-free reads from
+    `n_haps` haplotypes. Returns (prg, reads)."""
+    rng = np.random.default_rng(seed)
+    ref = random_ref(G, seed + 1)
+    sites = variant_sites(ref, n_snps, seed + 2, snp_frac=1.0, multi_frac=0.05)
+    backbone, pos_of_ref = variant_prg(ref, sites)
+    # insertion points: reference positions that are not a SNP, at least 300 bases apart
+    cell = G // max(n_regions, 1)
+    at = np.arange(n_regions, dtype=np.int64) * cell + rng.integers(10, max(cell - 300, 11), size=n_regions)
+    is_site = np.zeros(G, dtype=bool)
+    is_site[sites.start] = True
+    at += is_site[at]                                          # SNPs never touch: the next base is plain
+    regions = [bracket_to_ints(msa_region(rng, int(rng.integers(region_lo, region_hi + 1)))) for _ in range(n_regions)]
+    # shift the regions' markers past the backbone's, then renumber everything by appearance
+    base_marker = 5 + 2 * sites.n_sites
+    parts, cur = [], 0
+    for r, ints in enumerate(regions):
+        cut = int(pos_of_ref[at[r]])
+        parts.append(backbone[cur:cut])
+        shifted = ints.copy()
+        mk = shifted > 4
+        shifted[mk] += np.uint32(base_marker - 5)
+        base_marker += 2 * int(((ints > 4) & (ints % 2 == 1)).sum())
+        parts.append(shifted)
+        cur = cut
+    parts.append(backbone[cur:])
+    prg = renumber_markers(np.concatenate(parts))
+    haps = []
+    for h in range(n_haps):
+        hap, hpos = variant_haplotype(ref, sites, seed + 10 + h)
+        hrng = np.random.default_rng(seed + 100 + h)
+        hp, cur = [], 0
+        for r, ints in enumerate(regions):
+            cut = int(hpos[at[r]])
+            hp.append(hap[cur:cut])
+            hp.append(_expand_region(ints, hrng))
+            cur = cut
+        hp.append(hap[cur:])
+        haps.append(np.concatenate(hp))
+    return prg, reads_from_haplotypes(haps, n_reads, read_len, seed + 3)

@@ -209,6 +209,36 @@ class Oracle:
         if self.lib.gmo_index_kmer_diffs(self.h, _p(flat, C.c_uint8), _p(lens, C.c_uint64), len(diffs)) != 0:
             raise self._err()
 
+    def index_kmers_of_reads(self, reads2d):
+        """Index exactly the k-mers that occur in `reads2d` (uint8 [n, L], clean bases) or their reverse complements,
+        through the reference's prefix-diff construction (kmers.cpp:42-73 order, build.cpp:101-131). For these reads the
+        result equals the all-4^k index — a k-mer without search states is not stored either way — but k = 14 does not
+        need 268 M k-mer objects. Test infrastructure, as everything under oracle/."""
+        k = self.k
+        r = np.ascontiguousarray(reads2d, dtype=np.uint8)
+        n, L = r.shape
+        codes = []
+        for arr in (r, np.ascontiguousarray((5 - r)[:, ::-1])):
+            c = np.zeros((n, L - k + 1), dtype=np.uint64)
+            for j in range(k):  # base j of the k-mer has weight 4^j: sorting the codes = the reversed-k-mer order
+                c |= (arr[:, j:j + L - k + 1].astype(np.uint64) - 1) << np.uint64(2 * j)
+            codes.append(np.unique(c))
+        u = np.unique(np.concatenate(codes))
+        km = np.empty((u.size, k), dtype=np.uint8)
+        for j in range(k):
+            km[:, j] = ((u >> np.uint64(2 * j)) & np.uint64(3)).astype(np.uint8) + 1
+        lens = np.full(u.size, k, dtype=np.int64)
+        if u.size > 1:
+            neq = km[1:] != km[:-1]
+            lens[1:] = k - np.argmax(neq[:, ::-1], axis=1)          # up to the highest differing base (kmers.cpp:55-66)
+        starts = np.cumsum(lens) - lens
+        owner = np.repeat(np.arange(u.size), lens)
+        within = np.arange(int(lens.sum())) - starts[owner]
+        flat = np.ascontiguousarray(km[owner, within])
+        ln = lens.astype(np.uint64)
+        if self.lib.gmo_index_kmer_diffs(self.h, _p(flat, C.c_uint8), _p(ln, C.c_uint64), int(u.size)) != 0:
+            raise self._err()
+
     @staticmethod
     def all_kmers(k):
         out = np.empty((4 ** k, k), dtype=np.uint8)

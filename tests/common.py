@@ -22,17 +22,22 @@ def flatten_reads(reads):
 
 def canonical_oracle(o: Oracle):
     pb = {n["first_pos"]: n["cov"] for n in o.per_base_nodes()}
+    # depth: the Read_depth block of read_stats.json (read_stats.cpp:119-160) — doubles summed in bubble_map order on
+    # both sides, so equality is exact
     return dict(allele_sum=o.allele_sum(), grouped=o.grouped(), per_base=pb, stats=o.stats(),
-                allele_base=o.allele_base_non_nested())
+                allele_base=o.allele_base_non_nested(), depth=o.depth_stats())
 
 
 def canonical_cov(cov: Coverage):
     return dict(allele_sum=cov.allele_sum_coverage, grouped=cov.grouped_allele_counts, per_base=cov.per_base_by_first_pos(),
-                stats=cov.stats.as_dict(), allele_base=cov.allele_base_coverage)
+                stats=cov.stats.as_dict(), allele_base=cov.allele_base_coverage, depth=cov.depth_stats())
 
 
-def oracle_map(prg, k, reads, seeds, rng_mode=0, threads=1):
-    o = Oracle(prg, k, rng_mode=rng_mode)
+def oracle_map(prg, k, reads, seeds, rng_mode=0, threads=1, kmers_of_reads=False):
+    """kmers_of_reads: index only the k-mers of these (equal-length, clean) reads instead of all 4^k (k = 14)."""
+    o = Oracle(prg, k, all_kmers=not kmers_of_reads, rng_mode=rng_mode)
+    if kmers_of_reads:
+        o.index_kmers_of_reads(np.asarray(reads, dtype=np.uint8))
     flat, offs = flatten_reads(reads)
     o.map_reads(flat, offs, seeds, threads=threads)
     return canonical_oracle(o)

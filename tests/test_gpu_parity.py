@@ -11,7 +11,7 @@ from gramtools_amd.synth import (nested_prg, bracket_to_ints, simulate_graph_rea
 pytestmark = pytest.mark.gpu
 
 GPU_OPS = {"quasimap_read", "map_reads", "expect_allele_sum", "expect_allele_base", "expect_grouped", "expect_node_cov",
-           "expect_stats"}
+           "expect_stats", "expect_depth"}
 
 
 def _gpu_cases():
@@ -62,6 +62,10 @@ def test_golden_vectors_on_gpu(fname, case):
                     first = p - int(pi[p][2])
                     got.append(pb.get(first, []))
                 assert got == op["value"]
+            elif kind == "expect_depth":  # gmx_compute_coverage_depth against test_read_stats.cpp:140-182
+                d = cov.depth_stats()
+                assert d["mean"] == op["mean"] and d["variance"] == op["variance"], d
+                assert d["num_sites_noCov"] == op["noCov"] and d["num_sites_total"] == op["total"], d
             elif kind == "expect_stats":
                 s = cov.stats.as_dict()
                 for key, v in op["value"].items():
