@@ -14,7 +14,11 @@
 //
 // Env interface:
 //   uint32_t sget(uint32_t word) / void sset(uint32_t word, uint32_t v)   per-task scratch words
-//   static constexpr I_MAX, B_MAX, LOC_MAX, H_MAX                            capacities
+//   uint32_t i_max(), b_max(), loc_max(), h_max()                          capacities (compile-time constants for the fixed
+//                                                                          tiers, runtime values for the last, heap-backed tier)
+//   bool has_log_sites() / bool log_reserve(uint32_t words)                  grouped log of sites with more than 5 alleles: ALL
+//                                                                          words a task will append are reserved at once, before
+//                                                                          anything is recorded (a full log fails the task whole)
 //   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot): +1 on a slot of the
 //        accumulator block (gmx_types.h: gmx_slot_*); add_allele_and_group(slot): +1 on slot and slot + 1 (one 64-bit add)
 //   void add_hit(uint32_t slot)                                             hit counter of a one-base allele (gmx_types.h)
@@ -103,10 +107,15 @@ struct GmxScratch {
   // item i: lo, hi, tvd, tvg, enc_site, enc_allele
   static constexpr uint32_t ITEM_W = 6;
   static constexpr uint32_t items = 0;
-  static constexpr uint32_t keys = items + Env::I_MAX * ITEM_W;       // per item: len, B_MAX sites
-  static constexpr uint32_t loci = keys + Env::I_MAX * (1 + Env::B_MAX);  // (site, allele)
-  static constexpr uint32_t hull = loci + Env::LOC_MAX * 2;           // (node, start, end)
-  static constexpr uint32_t total = hull + Env::H_MAX * 3;
+  GMX_HD static uint32_t order(const Env &e) { return items + e.i_max() * ITEM_W; }            // item indices sorted by key
+  GMX_HD static uint32_t keys(const Env &e) { return order(e) + e.i_max(); }                  // per item: len, b_max sites
+  GMX_HD static uint32_t loci(const Env &e) { return keys(e) + e.i_max() * (1 + e.b_max()); }  // (site, allele)
+  GMX_HD static uint32_t hull(const Env &e) { return loci(e) + e.loc_max() * 2; }             // (node, start, end)
+  GMX_HD static uint32_t total_of(const Env &e) { return hull(e) + e.h_max() * 3; }
+};
+template <class Env>
+struct GmxScratchFixed {  // the fixed tiers: Env::I_MAX .. are compile-time constants
+  static constexpr uint32_t total = Env::I_MAX * (GmxScratch<Env>::ITEM_W + 1) + Env::I_MAX * (1 + Env::B_MAX) + Env::LOC_MAX * 2 + Env::H_MAX * 3;
 };
 
 GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
@@ -131,18 +140,18 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
   uint32_t n = n_loci_in;
   auto window_used = [&](uint32_t site) {
     for (uint32_t i = first; i < n; ++i)
-      if (env.sget(S::loci + 2 * i) == site) return true;
+      if (env.sget(S::loci(env) + 2 * i) == site) return true;
     return false;
   };
   auto window_add = [&](uint32_t site, int32_t allele) -> bool {
     for (uint32_t i = first; i < n; ++i)
-      if (env.sget(S::loci + 2 * i) == site && (int32_t)env.sget(S::loci + 2 * i + 1) == allele) return true;
-    if (n >= Env::LOC_MAX) {
+      if (env.sget(S::loci(env) + 2 * i) == site && (int32_t)env.sget(S::loci(env) + 2 * i + 1) == allele) return true;
+    if (n >= env.loc_max()) {
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }
-    env.sset(S::loci + 2 * n, site);
-    env.sset(S::loci + 2 * n + 1, (uint32_t)allele);
+    env.sset(S::loci(env) + 2 * n, site);
+    env.sset(S::loci(env) + 2 * n + 1, (uint32_t)allele);
     ++n;
     return true;
   };
@@ -212,10 +221,10 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
 template <class Env>
 GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t first, uint32_t n) {
   typedef GmxScratch<Env> S;
-  uint32_t kb = S::keys + it * (1 + Env::B_MAX);
+  uint32_t kb = S::keys(env) + it * (1 + env.b_max());
   uint32_t len = 0;
   for (uint32_t i = first; i < n; ++i) {
-    uint32_t site = env.sget(S::loci + 2 * i);
+    uint32_t site = env.sget(S::loci(env) + 2 * i);
     if (ix.sites[(site - 5) >> 1].parent_site != 0) continue;
     // insertion sort, distinct
     uint32_t pos = 0;
@@ -230,7 +239,7 @@ GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t
       ++pos;
     }
     if (dup) continue;
-    if (len >= Env::B_MAX) {
+    if (len >= env.b_max()) {
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }
@@ -245,7 +254,7 @@ GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t
 template <class Env>
 GMX_HD int gmx_key_cmp(Env &env, uint32_t a, uint32_t b) {
   typedef GmxScratch<Env> S;
-  uint32_t ka = S::keys + a * (1 + Env::B_MAX), kb = S::keys + b * (1 + Env::B_MAX);
+  uint32_t ka = S::keys(env) + a * (1 + env.b_max()), kb = S::keys(env) + b * (1 + env.b_max());
   uint32_t la = env.sget(ka), lb = env.sget(kb);
   uint32_t m = la < lb ? la : lb;
   for (uint32_t i = 0; i < m; ++i) {
@@ -374,19 +383,19 @@ GMX_HD bool gmx_hull_add(Env &env, uint32_t &n_hull, uint32_t node, uint32_t seq
   typedef GmxScratch<Env> S;
   if (seq_len == 0) return true;
   for (uint32_t i = 0; i < n_hull; ++i) {
-    if (env.sget(S::hull + 3 * i) != node) continue;
-    uint32_t hs = env.sget(S::hull + 3 * i + 1), he = env.sget(S::hull + 3 * i + 2);
-    if (s < hs) env.sset(S::hull + 3 * i + 1, s);
-    if (e > he) env.sset(S::hull + 3 * i + 2, e);
+    if (env.sget(S::hull(env) + 3 * i) != node) continue;
+    uint32_t hs = env.sget(S::hull(env) + 3 * i + 1), he = env.sget(S::hull(env) + 3 * i + 2);
+    if (s < hs) env.sset(S::hull(env) + 3 * i + 1, s);
+    if (e > he) env.sset(S::hull(env) + 3 * i + 2, e);
     return true;
   }
-  if (n_hull >= Env::H_MAX) {
+  if (n_hull >= env.h_max()) {
     env.fail(GMX_TASK_OVERFLOW);
     return false;
   }
-  env.sset(S::hull + 3 * n_hull, node);
-  env.sset(S::hull + 3 * n_hull + 1, s);
-  env.sset(S::hull + 3 * n_hull + 2, e);
+  env.sset(S::hull(env) + 3 * n_hull, node);
+  env.sset(S::hull(env) + 3 * n_hull + 1, s);
+  env.sset(S::hull(env) + 3 * n_hull + 2, e);
   ++n_hull;
   return true;
 }
@@ -486,6 +495,14 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
         if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR);
     }
+  }
+  if (env.has_log_sites()) {  // reserve the task's words of the grouped log before anything is recorded
+    uint32_t words = 0;
+    const uint32_t fs = enc_site != 0 ? enc_site : tvg != GMX_NIL ? env.h_site(tvg) : 0u;
+    if (fs != 0 && ix.sites[(fs - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x))
+      if (ix.sites[(env.h_site(x) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
+    if (words && !env.log_reserve(words)) return;
   }
   // Without the walk: every traversed site is walk-free (gmx_types.h: a one-base allele is its hit counter, an empty
   // one its allele-sum/group pair) and the first node, if in play, has a hit counter. The site records are
@@ -629,6 +646,13 @@ GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxF
     }
   }
   if (full) return false;
+  if (env.has_log_sites()) {  // reserve the task's words of the grouped log before anything is recorded
+    uint32_t words = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < GMX_SINGLE_LOCI; ++i)
+      if (i < n && ix.sites[(l_site[i] - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
+    if (words && !env.log_reserve(words)) return true;
+  }
   uint32_t hit = 0;  // loci recorded by a hit counter during the walk (gmx_types.h)
   GmxWalk w;
   gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
@@ -675,7 +699,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
   uint32_t n_items = 0;
   uint32_t nonvariant = 0;  // count_nonvar_search_states, coverage_common.cpp:130-141 (uint32 arithmetic)
   auto add_item = [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg, uint32_t es, int32_t ea) -> bool {
-    if (n_items >= Env::I_MAX) {
+    if (n_items >= env.i_max()) {
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }
@@ -712,24 +736,42 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     if (n == 0xFFFFFFFFu) return;
     if (!gmx_item_key(ix, env, it, 0, n)) return;
   }
-  // number of distinct keys; `first` marks the items (of the first 64) whose key no earlier item has, so that the
-  // selection below is quadratic, not cubic, in the number of items (a read inside a 10-copy repeat has 11)
-  uint32_t n_classes = 0;
-  unsigned long long first = 0;
-  for (uint32_t a = 0; a < n_items; ++a) {
-    bool seen = false;
-    for (uint32_t b = 0; b < a && !seen; ++b) seen = gmx_key_cmp(env, a, b) == 0;
-    if (!seen) {
-      ++n_classes;
-      if (a < 64) first |= 1ull << a;
+  // Classes = runs of equal keys among the items sorted by key (the reference's std::map over level-0 site sets,
+  // coverage_common.hpp:133): heap sort of the item indices, O(n log n) key comparisons — a read inside a many-copy
+  // repeat has thousands of items, and every comparison is a chain of scratch loads.
+  const uint32_t ord = S::order(env);
+  for (uint32_t i = 0; i < n_items; ++i) env.sset(ord + i, i);
+  if (n_items > 1) {
+    auto sift = [&](uint32_t root, uint32_t end) {  // max-heap on [0, end)
+      const uint32_t moving = env.sget(ord + root);
+      for (;;) {
+        uint32_t child = 2 * root + 1;
+        if (child >= end) break;
+        uint32_t cv = env.sget(ord + child);
+        if (child + 1 < end) {
+          const uint32_t rv = env.sget(ord + child + 1);
+          if (gmx_key_cmp(env, cv, rv) < 0) {
+            ++child;
+            cv = rv;
+          }
+        }
+        if (gmx_key_cmp(env, moving, cv) >= 0) break;
+        env.sset(ord + root, cv);
+        root = child;
+      }
+      env.sset(ord + root, moving);
+    };
+    for (uint32_t i = n_items / 2; i-- > 0;) sift(i, n_items);
+    for (uint32_t end = n_items - 1; end > 0; --end) {
+      const uint32_t top = env.sget(ord), last = env.sget(ord + end);
+      env.sset(ord + end, top);
+      env.sset(ord, last);
+      sift(0, end);
     }
   }
-  auto is_first = [&](uint32_t a) -> bool {
-    if (a < 64) return (first >> a) & 1ull;
-    bool dup = false;
-    for (uint32_t b = 0; b < a && !dup; ++b) dup = gmx_key_cmp(env, a, b) == 0;
-    return !dup;
-  };
+  uint32_t n_classes = 1;
+  for (uint32_t i = 1; i < n_items; ++i)
+    if (gmx_key_cmp(env, env.sget(ord + i - 1), env.sget(ord + i)) != 0) ++n_classes;
   // --- selection (random_select_entry, coverage_common.cpp:95-108) ---
   uint32_t total = nonvariant + n_classes;
   uint32_t r;
@@ -738,45 +780,61 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     return;
   }
   if (r <= nonvariant) return;
-  uint32_t want = r - nonvariant - 1;  // 0-based index in the ordered map
-  // representative item of the class with `want` distinct keys strictly smaller
-  uint32_t chosen = 0xFFFFFFFFu;
-  for (uint32_t a = 0; a < n_items && chosen == 0xFFFFFFFFu; ++a) {
-    if (!is_first(a)) continue;
-    uint32_t smaller = 0;
-    for (uint32_t b = 0; b < n_items; ++b)
-      if (is_first(b) && gmx_key_cmp(env, b, a) < 0) ++smaller;
-    if (smaller == want) chosen = a;
-  }
-  if (chosen == 0xFFFFFFFFu) {
-    env.fail(GMX_TASK_ERROR);
-    return;
+  const uint32_t want = r - nonvariant - 1;  // 0-based index in the ordered map
+  uint32_t run_begin = 0, run_end = n_items;  // the want-th run of equal keys
+  {
+    uint32_t cls = 0;
+    for (uint32_t i = 1; i < n_items; ++i)
+      if (gmx_key_cmp(env, env.sget(ord + i - 1), env.sget(ord + i)) != 0) {
+        ++cls;
+        if (cls == want) run_begin = i;
+        if (cls == want + 1) {
+          run_end = i;
+          break;
+        }
+      }
+    if (want >= n_classes) {
+      env.fail(GMX_TASK_ERROR);
+      return;
+    }
   }
   // --- loci of the class (union) + per-base hull ---
   uint32_t n_loci = 0, n_hull = 0;
-  for (uint32_t it = 0; it < n_items; ++it) {
-    if (gmx_key_cmp(env, it, chosen) != 0) continue;
+  for (uint32_t ri = run_begin; ri < run_end; ++ri) {
+    const uint32_t it = env.sget(ord + ri);
     uint32_t first = n_loci;
     uint32_t n = gmx_item_loci(ix, env, it, first);
     if (n == 0xFFFFFFFFu) return;
     // merge window [first, n) into [0, first): drop duplicates
     uint32_t w = first;
     for (uint32_t i = first; i < n; ++i) {
-      uint32_t site = env.sget(S::loci + 2 * i), al = env.sget(S::loci + 2 * i + 1);
+      uint32_t site = env.sget(S::loci(env) + 2 * i), al = env.sget(S::loci(env) + 2 * i + 1);
       bool dup = false;
       for (uint32_t j = 0; j < first && !dup; ++j)
-        dup = env.sget(S::loci + 2 * j) == site && env.sget(S::loci + 2 * j + 1) == al;
+        dup = env.sget(S::loci(env) + 2 * j) == site && env.sget(S::loci(env) + 2 * j + 1) == al;
       if (dup) continue;
-      env.sset(S::loci + 2 * w, site);
-      env.sset(S::loci + 2 * w + 1, al);
+      env.sset(S::loci(env) + 2 * w, site);
+      env.sset(S::loci(env) + 2 * w + 1, al);
       ++w;
     }
     n_loci = w;
     if (!gmx_item_per_base(ix, env, it, read_len, n_hull)) return;
   }
+  // --- every capacity check lies behind us except the grouped log: reserve all of this task's words at once ---
+  if (env.has_log_sites()) {
+    uint32_t words = 0;
+    for (uint32_t i = 0; i < n_loci; ++i) {
+      const uint32_t site = env.sget(S::loci(env) + 2 * i);
+      if (ix.sites[(site - 5) >> 1].grouped_off != GMX_GROUPED_LOG) continue;
+      bool first_of_site = true;
+      for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
+      words += first_of_site ? 3u : 1u;  // [site, n_ids, id] + one word per further id
+    }
+    if (words && !env.log_reserve(words)) return;
+  }
   // --- record (allele_base.cpp:230-244, allele_sum.cpp:31-43, grouped_allele_counts.cpp:17-49) ---
   for (uint32_t h = 0; h < n_hull; ++h) {
-    uint32_t node = env.sget(S::hull + 3 * h), s = env.sget(S::hull + 3 * h + 1), e = env.sget(S::hull + 3 * h + 2);
+    uint32_t node = env.sget(S::hull(env) + 3 * h), s = env.sget(S::hull(env) + 3 * h + 1), e = env.sget(S::hull(env) + 3 * h + 2);
     uint32_t off = ix.nodes[node].cov_off;
     if (off == GMX_NO_COV) {
       env.fail(GMX_TASK_ERROR);
@@ -785,8 +843,8 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     for (uint32_t i = s; i <= e; ++i) env.add_per_base(off + i);
   }
   for (uint32_t i = 0; i < n_loci; ++i) {
-    uint32_t site = env.sget(S::loci + 2 * i);
-    int32_t allele = (int32_t)env.sget(S::loci + 2 * i + 1);
+    uint32_t site = env.sget(S::loci(env) + 2 * i);
+    int32_t allele = (int32_t)env.sget(S::loci(env) + 2 * i + 1);
     const GmxSite &s = ix.sites[(site - 5) >> 1];
     if (allele < 0 || (uint32_t)allele >= s.n_alleles) {
       env.fail(GMX_TASK_ERROR);
@@ -795,28 +853,28 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     env.add_allele_sum(gmx_slot_allele(s, (uint32_t)allele));
   }
   for (uint32_t i = 0; i < n_loci; ++i) {
-    uint32_t site = env.sget(S::loci + 2 * i);
+    uint32_t site = env.sget(S::loci(env) + 2 * i);
     bool first_of_site = true;
-    for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci + 2 * j) != site;
+    for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
     if (!first_of_site) continue;
     const GmxSite &s = ix.sites[(site - 5) >> 1];
     if (s.grouped_off != GMX_GROUPED_LOG) {
       uint32_t mask = 0;
       for (uint32_t j = i; j < n_loci; ++j)
-        if (env.sget(S::loci + 2 * j) == site) mask |= 1u << env.sget(S::loci + 2 * j + 1);
+        if (env.sget(S::loci(env) + 2 * j) == site) mask |= 1u << env.sget(S::loci(env) + 2 * j + 1);
       env.add_grouped_dense(gmx_slot_grouped(s, mask));
     } else {
       uint32_t cnt = 0;
       for (uint32_t j = i; j < n_loci; ++j)
-        if (env.sget(S::loci + 2 * j) == site) ++cnt;
+        if (env.sget(S::loci(env) + 2 * j) == site) ++cnt;
       if (!env.log_grouped_begin((site - 5) >> 1, cnt)) return;
       // ascending allele ids (std::set<AlleleId> order, grouped_allele_counts.cpp:25-37)
       int32_t prev = -1;
       for (uint32_t k = 0; k < cnt; ++k) {
         int32_t best = 0x7fffffff;
         for (uint32_t j = i; j < n_loci; ++j)
-          if (env.sget(S::loci + 2 * j) == site) {
-            int32_t a = (int32_t)env.sget(S::loci + 2 * j + 1);
+          if (env.sget(S::loci(env) + 2 * j) == site) {
+            int32_t a = (int32_t)env.sget(S::loci(env) + 2 * j + 1);
             if (a > prev && a < best) best = a;
           }
         env.log_grouped_id(best);

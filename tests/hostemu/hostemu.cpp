@@ -113,6 +113,16 @@ struct Emu {
 template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
 struct EmuEnvT {
   static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
+  static constexpr uint32_t i_max() { return I_; }
+  static constexpr uint32_t b_max() { return B_; }
+  static constexpr uint32_t loc_max() { return LOC_; }
+  static constexpr uint32_t h_max() { return H_; }
+  bool has_log_sites() const { return true; }
+  bool log_reserve(uint32_t words) {
+    reserved += words;
+    return true;
+  }
+  uint32_t reserved = 0, appended = 0;  // the reservation must cover exactly what the task appends
   std::vector<uint32_t> scratch;
   const GmxPathNode *arena;
   uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
@@ -120,7 +130,7 @@ struct EmuEnvT {
   uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
   Emu *e;
   uint32_t status = GMX_TASK_MAPPED;
-  EmuEnvT() : scratch(GmxScratch<EmuEnvT>::total, 0xDEADBEEFu) {}
+  EmuEnvT() : scratch(GmxScratchFixed<EmuEnvT>::total, 0xDEADBEEFu) {}
   uint32_t sget(uint32_t w) const { return scratch.at(w); }
   void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
   uint32_t single_loci() const { return e->single_loci; }
@@ -135,9 +145,13 @@ struct EmuEnvT {
   bool log_grouped_begin(uint32_t site, uint32_t n) {
     e->log.push_back(site);
     e->log.push_back(n);
+    appended += 2;
     return true;
   }
-  void log_grouped_id(int32_t a) { e->log.push_back((uint32_t)a); }
+  void log_grouped_id(int32_t a) {
+    e->log.push_back((uint32_t)a);
+    ++appended;
+  }
   void log_grouped_end() {}
   void fail(uint32_t s) {
     if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
@@ -337,6 +351,7 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
       env.e = e;
       gmx_cover_task(ix, env, use.st, use.n, len, seeds[read], e->rng_mode);
       uint32_t cstatus = env.status;
+      if (cstatus == GMX_TASK_MAPPED && env.reserved != env.appended) cstatus = GMX_TASK_ERROR;  // log reservation mismatch
       if (cstatus == GMX_TASK_OVERFLOW) {  // nothing recorded yet: redo with the large scratch
         e->n_cover_overflow++;
         EmuEnvBig big_env;
@@ -344,6 +359,7 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
         big_env.e = e;
         gmx_cover_task(ix, big_env, use.st, use.n, len, seeds[read], e->rng_mode);
         cstatus = big_env.status;
+        if (cstatus == GMX_TASK_MAPPED && big_env.reserved != big_env.appended) cstatus = GMX_TASK_ERROR;
       }
       if (cstatus != GMX_TASK_MAPPED && !e->first_error) {
         e->first_error = cstatus;
