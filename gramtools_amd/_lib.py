@@ -20,7 +20,8 @@ class IndexInfo(C.Structure):
 
 class EngineOpts(C.Structure):
     _fields_ = [("device", C.c_int), ("rng_mode", C.c_int), ("max_states", C.c_uint32),
-                ("max_path_nodes", C.c_uint32), ("max_batch_reads", C.c_uint64), ("forward_only", C.c_int)]
+                ("max_path_nodes", C.c_uint32), ("max_batch_reads", C.c_uint64), ("forward_only", C.c_int),
+                ("huge_heap_bytes", C.c_uint64), ("log_cap_words", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -31,7 +32,8 @@ class Stats(C.Structure):
 
 class QueueCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("mapped", "alive", "dead", "overflow_probe", "overflow_extend", "big_mapped",
-                                          "cover_general", "cover_mid", "cover_overflow", "seed_cursor")]
+                                          "cover_general", "cover_mid", "cover_overflow", "seed_cursor", "huge_search",
+                                          "huge_cover")]
 
 
 class Timing(C.Structure):

@@ -230,15 +230,22 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
   // per-site haplogroup totals in uint16 arithmetic (get_max_cov_haplogroup, read_stats.cpp:72-92)
   std::vector<std::map<int32_t, uint16_t>> hap(h.sites.size());
   std::vector<std::map<std::vector<int32_t>, uint16_t>> logged(h.sites.size());
-  for (uint64_t i = 0; i + 1 < n_log;) {
-    uint32_t s = glog[i], n = glog[i + 1];
-    if (s >= h.sites.size() || i + 2 + n > n_log) {
+  for (uint64_t i = 0; i < n_log;) {  // records worth +1 or +count (gmx.h: gmx_coverage_fetch_grouped_log)
+    if (glog[i] == 0xFFFFFFFFu) {  // padding
+      ++i;
+      continue;
+    }
+    if (i + 2 > n_log) break;
+    const uint32_t s = glog[i], n = glog[i + 1] & ~GMX_LOG_COUNTED;
+    const uint64_t head = (glog[i + 1] & GMX_LOG_COUNTED) ? 4 : 2;
+    if (s >= h.sites.size() || i + head + n > n_log) {
       gmx_set_error("corrupt grouped log");
       return GMX_EINVAL;
     }
-    std::vector<int32_t> ids(glog + i + 2, glog + i + 2 + n);
-    logged[s][ids] = (uint16_t)(logged[s][ids] + 1);
-    i += 2 + n;
+    const uint64_t count = head == 4 ? ((uint64_t)glog[i + 2] | ((uint64_t)glog[i + 3] << 32)) : 1;
+    std::vector<int32_t> ids(glog + i + head, glog + i + head + n);
+    logged[s][ids] = (uint16_t)(logged[s][ids] + count);
+    i += head + n;
   }
   for (size_t s = 0; s < h.sites.size(); ++s) {
     const GmxSite &site = h.sites[s];

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,7 @@
 #define GMX_CNT_STRIDE 32      // device counters sit 128 B apart: same-line atomics would serialise in one L2 channel
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
+#define GMX_LOG_WORDS_PER_READ 32u     // assumed bound on what one read appends to the grouped log (drain policy, launch_batch)
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
 
 // ---------------------------------------------------------------------------
@@ -666,6 +668,9 @@ struct SearchOut {
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
   GmxSeed *alive_seed;       // gmx_seed_kernel: the seed directory entry of alive_list[i]
+  uint32_t *huge_list;       // tasks the large-capacity pass could not hold (pools or slots exhausted); counter [11]
+  uint32_t *cover_huge_list; // entries whose selection exceeded the largest fixed scratch; counter [15]
+  uint32_t *huge_retry;      // last tier: work items its 64-wide round could not finish (run again alone with the whole heap)
   // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
   // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
   // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
@@ -1097,8 +1102,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     bool active = qi < n_over;
     uint32_t task = active ? queue[qi] : 0;
     const uint32_t slot = slot_base + qi;
-    if (active && slot >= g.max_slots) {
-      if (atomicCAS(&o.error[0], 0u, GMX_TASK_OVERFLOW) == 0u) o.error[1] = task;
+    if (active && slot >= g.max_slots) {  // no slot left: the last tier takes the task
+      o.huge_list[atomicAdd(&o.counters[11 * GMX_CNT_STRIDE], 1u)] = task;
       active = false;
     }
     BigCtx ctx;
@@ -1147,6 +1152,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     if (status == GMX_TASK_MAPPED) {
       nf = ctx.n_out;
       if (nf == 0) status = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+    } else if (status == GMX_TASK_OVERFLOW) {  // these pools are too small for it: the last tier (heap-backed) takes it
+      o.huge_list[atomicAdd(&o.counters[11 * GMX_CNT_STRIDE], 1u)] = task;
     } else if (atomicCAS(&o.error[0], 0u, status) == 0u) {
       o.error[1] = task;
     }
@@ -1181,7 +1188,7 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
     const uint32_t task = active ? o.overflow_list[qi] : 0;
     const uint32_t slot = qi;
     if (active && slot >= g.max_slots) {
-      if (sub == 0 && atomicCAS(&o.error[0], 0u, GMX_TASK_OVERFLOW) == 0u) o.error[1] = task;
+      if (sub == 0) o.huge_list[atomicAdd(&o.counters[11 * GMX_CNT_STRIDE], 1u)] = task;
       active = false;
     }
     const size_t s0 = active ? slot : 0;
@@ -1288,23 +1295,38 @@ struct CoverAcc {
   uint32_t *scratch_big;
   uint32_t n_lanes_big;
   int rng_mode;
+  uint32_t log_sites;   // the index has sites with more than 5 alleles (users of the log)
+  uint32_t *heap;       // the last tier's memory (gmx_tail_stage)
+  uint64_t heap_words;
 };
 
-template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
-struct CoverEnvT {
-  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
-  uint32_t *scratch;  // already offset by the lane
-  uint32_t stride;
-  const GmxPathNode *arena;
+// The grouped log (sites with more than 5 alleles): a task reserves ALL the words it will append with one atomic add,
+// before it records anything (gmx_cover.h); a task that does not fit fails whole (GMX_TASK_LOGFULL) and fills what it
+// got of the log's tail with GMX_LOG_PAD words, which every reader skips.
+#define GMX_LOG_PAD 0xFFFFFFFFu
+struct CoverLogPart {
   uint32_t *acc, *log, *log_cursor;
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
-  __device__ __forceinline__ uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
-  __device__ __forceinline__ int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
-  __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
-  __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
-  __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+  uint32_t log_sites;  // the index has sites that use the log
+  __device__ __forceinline__ bool has_log_sites() const { return log_sites != 0; }
+  __device__ __forceinline__ bool log_reserve(uint32_t words) {
+    log_at = atomicAdd(log_cursor, words);
+    if (log_at > log_cap || words > log_cap - log_at) {
+      for (uint32_t i = log_at; i < log_cap; ++i) log[i] = GMX_LOG_PAD;
+      status = GMX_TASK_LOGFULL;
+      return false;
+    }
+    return true;
+  }
+  __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
+    log[log_at++] = site_index;
+    log[log_at++] = n_ids;
+    return true;
+  }
+  __device__ __forceinline__ void log_grouped_id(int32_t a) { log[log_at++] = (uint32_t)a; }
+  __device__ __forceinline__ void log_grouped_end() {}
   __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
   __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
   __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
@@ -1313,27 +1335,222 @@ struct CoverEnvT {
   __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
     atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
   }
-  __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
-    log_at = atomicAdd(log_cursor, n_ids + 2);
-    if (log_at + n_ids + 2 > log_cap) {
-      status = GMX_TASK_LOGFULL;  // not re-queued: part of this task's coverage is already recorded
-      return false;
-    }
-    log[log_at++] = site_index;
-    log[log_at++] = n_ids;
-    return true;
-  }
-  __device__ __forceinline__ void log_grouped_id(int32_t a) { log[log_at++] = (uint32_t)a; }
-  __device__ __forceinline__ void log_grouped_end() {}
   __device__ __forceinline__ void fail(uint32_t s) {
     if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
   }
+};
+
+template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
+struct CoverEnvT : CoverLogPart {
+  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
+  __device__ __forceinline__ static constexpr uint32_t i_max() { return I_; }
+  __device__ __forceinline__ static constexpr uint32_t b_max() { return B_; }
+  __device__ __forceinline__ static constexpr uint32_t loc_max() { return LOC_; }
+  __device__ __forceinline__ static constexpr uint32_t h_max() { return H_; }
+  uint32_t *scratch;  // already offset by the lane
+  uint32_t stride;
+  const GmxPathNode *arena;
+  __device__ __forceinline__ uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
+  __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[(size_t)w * stride]; }
+  __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[(size_t)w * stride] = v; }
+};
+
+// The last tier: capacities decided per task from what the heap slice holds (gmx_tail_stage).
+struct CoverEnvDyn : CoverLogPart {
+  uint32_t cap_i, cap_b, cap_loc, cap_h;
+  __device__ __forceinline__ uint32_t i_max() const { return cap_i; }
+  __device__ __forceinline__ uint32_t b_max() const { return cap_b; }
+  __device__ __forceinline__ uint32_t loc_max() const { return cap_loc; }
+  __device__ __forceinline__ uint32_t h_max() const { return cap_h; }
+  uint32_t *scratch;
+  const GmxPathNode *arena;
+  __device__ __forceinline__ uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
+  __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[w]; }
+  __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[w] = v; }
 };
 
 typedef CoverEnvT<4, 4, 16, 16> CoverEnvLds;          // first tier of the general pass: per-lane scratch in the block's LDS
 typedef CoverEnvT<12, 6, 24, 24> CoverEnvMid;          // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
 typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
+
+// ---------------------------------------------------------------------------
+// The last tier. Every pool above has a fixed size per task; a task that exceeds one of them — a read with thousands of
+// mapping instances, or through more nested sites than the large-capacity pools hold — ends up here, where the only
+// limit is the engine's heap (gmx_engine_opts::huge_heap_bytes): the reference has no limit either
+// (encapsulated_search.cpp:30-107 and coverage_common.cpp:85-146 simply iterate). Work items are
+//   * tasks of huge_list: searched again from the seed with pools carved from a heap slice, then recorded with a scratch
+//     sized for what the search produced (gmx_cover_task over CoverEnvDyn);
+//   * entries of cover_huge_list: their final states are where the search left them, only the scratch was too small.
+// One wave runs the stage (the last block of the batch's last coverage launch): first every lane takes work items with
+// one 64th of the heap each, then lane 0 alone redoes, with the whole heap, what did not fit. Nothing is recorded for a
+// task before all of its capacity checks have passed, so redoing is safe. A task that does not fit the whole heap is
+// reported (GMX_ECAP: raise huge_heap_bytes). Common batches have no work item and pay one counter read.
+// ---------------------------------------------------------------------------
+__device__ uint32_t gmx_count_items(const GmxIndexView &ix, const GmxFinalState *finals, uint32_t nf) {
+  uint32_t n = 0;
+  for (uint32_t f = 0; f < nf; ++f) {
+    const GmxFinalState st = finals[f];
+    if (st.traversed != GMX_NIL || st.traversing != GMX_NIL) {
+      ++n;
+      continue;
+    }
+    for (uint32_t i = st.lo;; ++i) {
+      n += ix.nodes[ix.pos_node[gmx_occ_pos(ix, st.hi, i)]].site != 0;
+      if (gmx_text_form(st.hi) || i == st.hi) break;
+    }
+  }
+  return n;
+}
+
+// returns the status of the work item: MAPPED (done), OVERFLOW (the slice was too small, nothing recorded), or an error
+__device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, const SearchOut &o, const BigOut &g, const CoverAcc &acc,
+                                  bool active, uint32_t item, uint32_t n_search, uint32_t *slice, uint64_t slice_words, bool whole_heap,
+                                  uint32_t &task_out) {
+  const bool is_search = active && item < n_search;
+  uint32_t task = 0, nf = 0;
+  const GmxFinalState *finals = nullptr;
+  const GmxPathNode *arena = nullptr;
+  uint32_t *scratch = slice;
+  uint64_t scratch_words = slice_words;
+  uint32_t status = GMX_TASK_MAPPED;
+  // --- search (all lanes of the wave take part in the loop's ballots) ---
+  BigCtx ctx;
+  const uint64_t S = std::min<uint64_t>(slice_words / 30, 0x3FFFFFFFull);  // states; half of the slice is left for the scratch
+  ctx.sp = 0;
+  ctx.cap = (uint32_t)S;
+  ctx.out = reinterpret_cast<GmxFinalState *>(slice);
+  ctx.stack = slice + 4 * S;
+  ctx.arena = reinterpret_cast<GmxPathNode *>(slice + 9 * S);
+  ctx.arena_n = 0;
+  ctx.arena_cap = (uint32_t)(2 * S);
+  ctx.status = GMX_TASK_MAPPED;
+  ctx.n_out = 0;
+  ctx.out_cap = (uint32_t)S;
+  ReadRef r;
+  r.w = b.packed;
+  r.len = 0;
+  r.rc = false;
+  r.cur_idx = 0xFFFFFFFFu;
+  r.cur = make_uint2(0, 0);
+  bool run = false;
+  if (is_search) {
+    task = o.huge_list[item];
+    r = task_read(b, task);
+    const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+    const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+    const uint32_t from = r.len - k;
+    load_seed(ix, longer ? ix.seeds2 : ix.seeds, kmer_code(r, from, k), ctx,
+              [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
+                if (tvd == GMX_NIL && tvg == GMX_NIL && from > 0 && hi > lo) {  // position by position in text form (gmx_search_big_kernel)
+                  bool ok = true;
+                  for (uint32_t i = lo; ok; ++i) {
+                    ok = ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+                    if (i == hi) break;
+                  }
+                  return ok;
+                }
+                return ctx.push(lo, hi, tvd, tvg, from, GMX_MODE_STATE);
+              });
+    run = ctx.status == GMX_TASK_MAPPED;
+  }
+  GmxLane ln;
+  dfs_run_wave<2, false>(ix, ctx, r, 0, run, 0, ln);
+  if (!active) return GMX_TASK_MAPPED;
+  uint32_t len;
+  if (is_search) {
+    task_out = task;
+    status = ctx.status;
+    if (status != GMX_TASK_MAPPED) return status;
+    nf = ctx.n_out;
+    if (nf == 0) {
+      o.status[task] = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+      o.n_final[task] = 0;
+      return GMX_TASK_MAPPED;
+    }
+    finals = ctx.out;
+    arena = ctx.arena;
+    scratch = slice + 15 * S;
+    scratch_words = slice_words - 15 * S;
+    len = r.len;
+  } else {
+    const uint32_t entry = o.cover_huge_list[item - n_search];
+    if (entry & 0x80000000u) {
+      const uint32_t slot = entry & 0x7fffffffu;
+      task = g.task_of_slot[slot];
+      nf = g.n_final[slot];
+      finals = g.states + (size_t)slot * g.max_states;
+      arena = g.arena + (size_t)slot * g.max_path_nodes;
+    } else {
+      task = entry;
+      nf = o.n_final[task] & 0xFF;
+      finals = o.finals + (size_t)task * GMX_FAST_STATES;
+      arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+    }
+    task_out = task;
+    const uint32_t read = task >> 1;
+    len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+  }
+  // --- coverage with a scratch sized for this task ---
+  CoverEnvDyn env;
+  const uint64_t n_items = std::max<uint32_t>(gmx_count_items(ix, finals, nf), 1u);
+  uint64_t cap_b = std::min<uint64_t>(std::max<uint64_t>(len + 8u, 32u), 4096u);
+  if (whole_heap) cap_b = std::max<uint64_t>(cap_b, std::min<uint64_t>(65536u, scratch_words / (4 * n_items)));
+  const uint64_t fixed = n_items * (GmxScratch<CoverEnvDyn>::ITEM_W + 2 + cap_b);
+  if (fixed + 5 * 64 > scratch_words) return GMX_TASK_OVERFLOW;
+  const uint64_t rest = std::min<uint64_t>((scratch_words - fixed) / 5, 0x0FFFFFFFull);
+  env.cap_i = (uint32_t)n_items;
+  env.cap_b = (uint32_t)cap_b;
+  env.cap_loc = env.cap_h = (uint32_t)rest;
+  env.scratch = scratch;
+  env.arena = arena;
+  env.acc = acc.acc;
+  env.log = acc.log;
+  env.log_cursor = acc.log_cursor;
+  env.log_cap = acc.log_cap;
+  env.log_sites = acc.log_sites;
+  env.status = GMX_TASK_MAPPED;
+  env.log_at = 0;
+  gmx_cover_task(ix, env, finals, nf, len, b.seeds[task >> 1], acc.rng_mode);
+  if (env.status == GMX_TASK_MAPPED && is_search) {
+    o.status[task] = GMX_TASK_MAPPED;
+    o.n_final[task] = nf;
+  }
+  return env.status;
+}
+
+__device__ void gmx_tail_stage(const GmxIndexView &ix, const BatchView &b, const SearchOut &o, const BigOut &g, const CoverAcc &acc) {
+  const uint32_t n_search = o.counters[11 * GMX_CNT_STRIDE], n_cover = o.counters[15 * GMX_CNT_STRIDE];
+  const uint32_t total = n_search + n_cover;
+  if (total == 0) return;
+  __shared__ uint32_t n_retry;
+  if (threadIdx.x == 0) n_retry = 0;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  const uint64_t slice_words = acc.heap_words / 64;
+  for (uint32_t base = 0; base < total; base += 64) {  // every lane: one work item, one 64th of the heap
+    const uint32_t item = base + lane;
+    uint32_t task = 0;
+    const uint32_t st = gmx_tail_item(ix, b, o, g, acc, item < total, item, n_search, acc.heap + (size_t)lane * slice_words, slice_words,
+                                      false, task);
+    if (item < total && st == GMX_TASK_OVERFLOW)
+      o.huge_retry[atomicAdd(&n_retry, 1u)] = item;
+    else if (item < total && st != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, st) == 0u)
+      o.error[1] = task;
+  }
+  __syncthreads();
+  __threadfence();
+  const uint32_t retries = n_retry;
+  for (uint32_t i = 0; i < retries; ++i) {  // lane 0 alone, the whole heap
+    uint32_t task = 0;
+    const uint32_t st = gmx_tail_item(ix, b, o, g, acc, lane == 0, o.huge_retry[i], n_search, acc.heap, acc.heap_words, true, task);
+    if (lane == 0 && st != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, st) == 0u) o.error[1] = task;
+  }
+}
 
 // Four instances over four device-side queues (LIST):
 //   3  tasks finished by the probe / extend kernels that gmx_cover_single_kernel passed on; scratch sized for the
@@ -1346,8 +1563,8 @@ typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping
 // gmx_cover_lds_lanes<Env>() lanes, as many as copies of the scratch fit 64 KB.  Instance 1 uses global memory.
 template <class Env>
 constexpr uint32_t gmx_cover_lds_lanes() {
-  return GmxScratch<Env>::total * 64 * sizeof(uint32_t) <= 64 * 1024   ? 64u
-         : GmxScratch<Env>::total * 32 * sizeof(uint32_t) <= 64 * 1024 ? 32u
+  return GmxScratchFixed<Env>::total * 64 * sizeof(uint32_t) <= 64 * 1024   ? 64u
+         : GmxScratchFixed<Env>::total * 32 * sizeof(uint32_t) <= 64 * 1024 ? 32u
                                                                        : 16u;
 }
 template <class Env, int LIST>
@@ -1395,6 +1612,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     env.log = acc.log;
     env.log_cursor = acc.log_cursor;
     env.log_cap = acc.log_cap;
+    env.log_sites = acc.log_sites;
     env.status = GMX_TASK_MAPPED;
     env.log_at = 0;
     gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
@@ -1402,20 +1620,28 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       o.cover_mid_list[atomicAdd(&o.counters[13 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status == GMX_TASK_OVERFLOW && !BIG) {
       o.cover_overflow_list[atomicAdd(&o.counters[4 * GMX_CNT_STRIDE], 1u)] = entry;
+    } else if (env.status == GMX_TASK_OVERFLOW) {  // beyond the largest fixed scratch: the last tier sizes one from its heap
+      o.cover_huge_list[atomicAdd(&o.counters[15 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status != GMX_TASK_MAPPED) {
       if (atomicCAS(&o.error[0], 0u, env.status) == 0u) o.error[1] = task;
+    }
+  }
+  if (BIG) {  // this instance is the batch's last search / coverage launch: whichever block finishes last serves the last tier
+    __shared__ uint32_t ticket;
+    __threadfence();
+    if (threadIdx.x == 0) ticket = atomicAdd(&o.counters[14 * GMX_CNT_STRIDE], 1u);
+    __syncthreads();
+    if (ticket == gridDim.x - 1) {
+      __threadfence();
+      gmx_tail_stage(ix, b, o, g, acc);
     }
   }
 }
 
 // Path handles of a GmxCoverRec: traversed loci are addressed by their index in the record (newest first), the
 // traversing path is an inline handle (gmx_types.h) or nil.
-struct CompactEnv {
+struct CompactEnv : CoverLogPart {
   GmxCoverRec rec;
-  uint32_t *acc, *log, *log_cursor;
-  uint32_t log_cap;
-  uint32_t status;
-  uint32_t log_at;
   __device__ __forceinline__ uint32_t n_trav() const { return (rec.len_n >> 16) & 31u; }
   __device__ __forceinline__ bool run_form() const { return (rec.len_n & GMX_REC_RUN_FLAG) != 0; }
   __device__ __forceinline__ uint32_t h_site(uint32_t h) const {
@@ -1435,29 +1661,6 @@ struct CompactEnv {
     if (h & GMX_INLINE_FLAG) return GMX_NIL;
     return h + 1 < n_trav() ? h + 1 : GMX_NIL;
   }
-  __device__ __forceinline__ uint32_t single_loci() const { return GMX_SINGLE_LOCI; }
-  __device__ __forceinline__ void add_allele_sum(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
-  __device__ __forceinline__ void add_per_base(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
-  __device__ __forceinline__ void add_hit(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
-  __device__ __forceinline__ void add_grouped_dense(uint32_t slot) { atomicAdd(&acc[slot], 1u); }
-  __device__ __forceinline__ void add_allele_and_group(uint32_t slot) {  // slot is even: both counters in one 64-bit add
-    atomicAdd(reinterpret_cast<unsigned long long *>(acc + slot), 0x100000001ull);
-  }
-  __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
-    log_at = atomicAdd(log_cursor, n_ids + 2);
-    if (log_at + n_ids + 2 > log_cap) {
-      status = GMX_TASK_LOGFULL;
-      return false;
-    }
-    log[log_at++] = site_index;
-    log[log_at++] = n_ids;
-    return true;
-  }
-  __device__ __forceinline__ void log_grouped_id(int32_t a) { log[log_at++] = (uint32_t)a; }
-  __device__ __forceinline__ void log_grouped_end() {}
-  __device__ __forceinline__ void fail(uint32_t s) {
-    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
-  }
 };
 
 // The common case, one lane per compact record and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
@@ -1473,6 +1676,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   env.log = acc.log;
   env.log_cursor = acc.log_cursor;
   env.log_cap = acc.log_cap;
+  env.log_sites = acc.log_sites;
   env.status = GMX_TASK_MAPPED;
   env.log_at = 0;
   const GmxFinalState st{env.rec.p, GMX_TEXT_MARK, env.n_trav() ? 0u : GMX_NIL, env.rec.tvg};
@@ -1701,6 +1905,14 @@ struct gmx_engine {
   uint32_t *d_scratch_big = nullptr, *d_cover_overflow = nullptr;
   uint32_t cover_big_lanes = 0;
   uint32_t *d_big_mapped = nullptr, *d_cover_general = nullptr, *d_cover_mid = nullptr, *d_overflow2 = nullptr;
+  uint32_t *d_huge = nullptr, *d_cover_huge = nullptr, *d_huge_retry = nullptr;  // the last tier's queues (gmx_tail_stage)
+  uint32_t *d_heap = nullptr;      // ... and its memory
+  uint64_t heap_words = 0;
+  bool log_sites = false;          // the index has sites with more than 5 alleles
+  // grouped log: drained into `log_counts` (records with counts) whenever the device log may run full, and at fetch time
+  std::map<std::vector<uint32_t>, uint64_t> log_counts;  // key = [site_index, ids...]
+  uint64_t log_known = 0;          // log words in use after the last drain / look ...
+  uint64_t log_reads_since = 0;    // ... and the reads enqueued since (each assumed to append at most GMX_LOG_WORDS_PER_READ)
   hipStream_t side2_stream = nullptr;
   hipEvent_t ev_fork2 = nullptr, ev_side1 = nullptr, ev_filter = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
@@ -1754,10 +1966,40 @@ struct gmx_engine {
   }
 };
 
+// Grouped log -> host. Waits for the device, adds the log's records to e->log_counts when more than `keep_below` words are in
+// use (and empties the device log), and notes how full it is. Records: [site_index, n_ids, ids...], each worth +1;
+// GMX_LOG_PAD words are padding (CoverLogPart::log_reserve).
+static int gmx_log_drain(gmx_engine *e, uint64_t keep_below) {
+  HIP_TRY(hipDeviceSynchronize());
+  uint32_t used = 0;
+  HIP_TRY(hipMemcpy(&used, e->d_log_cursor, 4, hipMemcpyDeviceToHost));
+  used = std::min(used, e->log_cap);
+  e->log_reads_since = 0;
+  e->log_known = used;
+  if (used <= keep_below) return GMX_OK;
+  std::vector<uint32_t> w(used);
+  HIP_TRY(hipMemcpy(w.data(), e->d_log, (size_t)used * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> key;
+  for (size_t i = 0; i < w.size();) {
+    if (w[i] == GMX_LOG_PAD) {
+      ++i;
+      continue;
+    }
+    if (i + 2 > w.size() || i + 2 + w[i + 1] > w.size()) break;
+    key.assign(1, w[i]);
+    key.insert(key.end(), w.begin() + i + 2, w.begin() + i + 2 + w[i + 1]);
+    e->log_counts[key] += 1;
+    i += 2 + w[i + 1];
+  }
+  HIP_TRY(hipMemset(e->d_log_cursor, 0, 4));
+  e->log_known = 0;
+  return GMX_OK;
+}
+
 // A coverage instance with its scratch in LDS: one wave per block, as many blocks per CU as scratch copies fit its LDS.
 template <class Env, int LIST>
 static void launch_cover_lds(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc) {
-  const size_t lds = (size_t)GmxScratch<Env>::total * gmx_cover_lds_lanes<Env>() * sizeof(uint32_t);
+  const size_t lds = (size_t)GmxScratchFixed<Env>::total * gmx_cover_lds_lanes<Env>() * sizeof(uint32_t);
   const uint32_t per_cu = (uint32_t)(160 * 1024 / lds);
   hipLaunchKernelGGL((gmx_cover_kernel<Env, LIST>), dim3(e->n_cus * per_cu), dim3(64), lds, stream, e->dview, b, o, e->big,
                      acc);
@@ -1772,6 +2014,8 @@ void gmx_engine_default_opts(gmx_engine_opts *o) {
   o->max_path_nodes = 2048;
   o->max_batch_reads = 4u << 20;
   o->forward_only = 0;
+  o->huge_heap_bytes = 512ull << 20;
+  o->log_cap_words = 0;
 }
 
 static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
@@ -1797,6 +2041,9 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
   if ((rc = e->alloc(&e->d_alive_seed, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_huge, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_cover_huge, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_huge_retry, 2 * n_tasks, false))) return rc;
   // large-capacity pass: one slot (~60 KB of pools at the default capacities) per task it may have to take; a 1 M-read
   // batch with 5 % of the genome in 10-copy repeats sends 59 k of its 2 M tasks there
   e->big.max_slots = (uint32_t)std::min<uint64_t>(n_tasks, std::min<uint64_t>(std::max<uint64_t>(n_tasks / 16, 4096), 262144));
@@ -1823,6 +2070,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   if (opts.max_states == 0) opts.max_states = 1024;
   if (opts.max_path_nodes == 0) opts.max_path_nodes = 2048;
   if (opts.max_batch_reads == 0) opts.max_batch_reads = 4u << 20;
+  if (opts.huge_heap_bytes == 0) opts.huge_heap_bytes = 512ull << 20;
+  if (const char *hb = getenv("GMX_HUGE_HEAP_BYTES")) opts.huge_heap_bytes = strtoull(hb, nullptr, 10);
+  opts.huge_heap_bytes = std::max<uint64_t>(opts.huge_heap_bytes, 64 * 1024);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     gmx_set_error("no HIP device available: the quasimap engine has no CPU fallback");
@@ -1886,8 +2136,18 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     e->phys_grouped = h.phys_grouped;
     e->hit_fix = h.hit_fix;
   }
-  e->log_cap = 1u << 24;
+  // The grouped log is used only by sites with more than 5 alleles. It is drained to the host before it can run full
+  // (launch_batch: GMX_LOG_WORDS_PER_READ words assumed per enqueued read), so two batches' worth is always enough.
+  for (const GmxSite &st : h.sites) e->log_sites = e->log_sites || st.grouped_off == GMX_GROUPED_LOG;
+  {
+    uint64_t cap = opts.log_cap_words ? opts.log_cap_words
+                   : e->log_sites     ? std::max<uint64_t>(1u << 24, 2 * GMX_LOG_WORDS_PER_READ * std::min<uint64_t>(opts.max_batch_reads, 4u << 20))
+                                      : 64;
+    e->log_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFF00ull);
+  }
   rc |= e->alloc(&e->d_log, e->log_cap, false);
+  e->heap_words = opts.huge_heap_bytes / 4 / 64 * 64;
+  rc |= e->alloc(&e->d_heap, e->heap_words, false);
   rc |= e->alloc(&e->d_counters, 32 * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
@@ -1934,7 +2194,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess;
   e->cover_big_lanes = 64 * 32;
-  rc |= e->alloc(&e->d_scratch_big, (size_t)GmxScratch<CoverEnvBig>::total * e->cover_big_lanes, false);
+  rc |= e->alloc(&e->d_scratch_big, (size_t)GmxScratchFixed<CoverEnvBig>::total * e->cover_big_lanes, false);
   if (rc) {
     gmx_engine_destroy(e);
     return GMX_EHIP;
@@ -1971,6 +2231,8 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipMemset(e->d_fused, 0, (e->n_fused + 32) * 4));
   HIP_TRY(hipMemset(e->d_error, 0, 8));
   HIP_TRY(hipMemset(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4));
+  e->log_counts.clear();
+  e->log_known = e->log_reads_since = 0;
   return GMX_OK;
 }
 
@@ -1978,6 +2240,8 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   HIP_TRY(hipSetDevice(e->opts.device));
   hipStream_t st = (hipStream_t)hip_stream;
   HIP_TRY(hipMemsetAsync(e->d_fused, 0, (e->n_fused + 32) * 4, st));
+  e->log_counts.clear();  // what earlier batches left in the device log goes with the cursor
+  e->log_known = e->log_reads_since = 0;
   return GMX_OK;
 }
 
@@ -1998,6 +2262,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
+  if (e->log_sites) {  // keep the grouped log from running full: look at its cursor, drain it to the host, before it may
+    if (e->log_known + (e->log_reads_since + n_reads) * GMX_LOG_WORDS_PER_READ > e->log_cap && (rc = gmx_log_drain(e, e->log_cap / 4))) return rc;
+    e->log_reads_since += n_reads;
+  }
   {
     uint64_t need = total_bases / 32 + n_reads + 16;  // pairs; the slack covers the one-pair look-ahead of planes()
     if (need > e->cap_packed) {
@@ -2009,7 +2277,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed};
+              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed,
+              e->d_huge, e->d_cover_huge, e->d_huge_retry};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters);
@@ -2039,7 +2308,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-  CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode};
+  CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode,
+               e->log_sites ? 1u : 0u, e->d_heap, e->heap_words};
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
     hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
@@ -2084,7 +2354,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), 0, stream, e->dview,
+  // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
                      b, o, e->big, acc);
   hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks / 4 + GMX_BLOCK) / GMX_BLOCK, 512u)),
                      dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
@@ -2225,14 +2496,19 @@ int gmx_engine_sync(gmx_engine *e) {
     HIP_TRY(hipMemset(e->d_error, 0, 8));
     char msg[256];
     if (c[2] == GMX_TASK_LOGFULL) {
-      gmx_set_error("the grouped-allele-count log (sites with more than 5 alleles) is full; coverage is incomplete");
+      snprintf(msg, sizeof(msg),
+               "read %u (orientation %u): the grouped-allele-count log (sites with more than 5 alleles) is full; nothing of "
+               "this read was recorded: raise gmx_engine_opts.log_cap_words (now %u) or lower max_batch_reads",
+               c[3] >> 1, c[3] & 1, e->log_cap);
+      gmx_set_error(msg);
       return GMX_ECAP;
     }
     if (c[2] == GMX_TASK_OVERFLOW) {
       snprintf(msg, sizeof(msg),
-               "read %u (orientation %u) exceeded the engine capacities (max_states=%u, max_path_nodes=%u, or a "
-               "coverage-selection limit); coverage of this batch is incomplete",
-               c[3] >> 1, c[3] & 1, e->opts.max_states, e->opts.max_path_nodes);
+               "read %u (orientation %u) needs more memory for its search states or its mapping instances than the whole "
+               "last-tier heap holds (%llu bytes); nothing of this read was recorded: raise gmx_engine_opts.huge_heap_bytes "
+               "(GMX_HUGE_HEAP_BYTES)",
+               c[3] >> 1, c[3] & 1, (unsigned long long)e->heap_words * 4);
       gmx_set_error(msg);
       return GMX_ECAP;
     }
@@ -2298,6 +2574,8 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->cover_mid = c(13);
   out->cover_overflow = c(4);
   out->seed_cursor = e->seed_cursor ? 1 : 0;
+  out->huge_search = c(11);
+  out->huge_cover = c(15);
   return GMX_OK;
 }
 
@@ -2354,14 +2632,21 @@ int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, 
 }
 
 int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words) {
-  if (hipSetDevice(e->opts.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return GMX_EHIP;
-  uint32_t used = 0;
-  if (hipMemcpy(&used, e->d_log_cursor, 4, hipMemcpyDeviceToHost) != hipSuccess) return GMX_EHIP;
-  if (used > e->log_cap) used = e->log_cap;
-  uint64_t n = std::min<uint64_t>(used, cap_words);
-  if (out && n)
-    if (hipMemcpy(out, e->d_log, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return GMX_EHIP;
-  return (int64_t)used;
+  if (hipSetDevice(e->opts.device) != hipSuccess) return GMX_EHIP;
+  if (gmx_log_drain(e, 0)) return GMX_EHIP;
+  uint64_t n = 0;
+  for (auto const &kv : e->log_counts) {  // [site_index, n_ids | GMX_LOG_COUNTED, count lo, count hi, ids...]
+    const uint64_t words = 4 + (kv.first.size() - 1);
+    if (out && n + words <= cap_words) {
+      out[n] = kv.first[0];
+      out[n + 1] = (uint32_t)(kv.first.size() - 1) | GMX_LOG_COUNTED;
+      out[n + 2] = (uint32_t)kv.second;
+      out[n + 3] = (uint32_t)(kv.second >> 32);
+      for (size_t j = 1; j < kv.first.size(); ++j) out[n + 3 + j] = kv.first[j];
+    }
+    n += words;
+  }
+  return (int64_t)n;
 }
 
 }  // extern "C"

@@ -686,11 +686,17 @@ int run_genotype(const Args &a) {
         sites[s][ids] = tot & 0xFFFFu;
       }
     }
-    for (int64_t i = 0; i + 1 < n_log;) {
-      uint32_t s = glog[i], n = glog[i + 1];
-      std::vector<int32_t> ids(glog.begin() + i + 2, glog.begin() + i + 2 + n);
-      sites[s][ids] = (sites[s][ids] + 1) & 0xFFFFu;
-      i += 2 + n;
+    for (int64_t i = 0; i + 1 < n_log;) {  // records worth +1 or +count (gmx.h: gmx_coverage_fetch_grouped_log)
+      if (glog[i] == 0xFFFFFFFFu) {
+        ++i;
+        continue;
+      }
+      const uint32_t s = glog[i], n = glog[i + 1] & ~GMX_LOG_COUNTED;
+      const int64_t head = (glog[i + 1] & GMX_LOG_COUNTED) ? 4 : 2;
+      const uint64_t count = head == 4 ? ((uint64_t)glog[i + 2] | ((uint64_t)glog[i + 3] << 32)) : 1;
+      std::vector<int32_t> ids(glog.begin() + i + head, glog.begin() + i + head + n);
+      sites[s][ids] = (sites[s][ids] + count) & 0xFFFFu;
+      i += head + n;
     }
     std::map<std::vector<int32_t>, uint64_t> group_id;
     std::vector<std::vector<int32_t>> by_id;

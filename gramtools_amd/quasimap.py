@@ -232,12 +232,8 @@ class Coverage:
                 mask = int(m) + 1
                 ids = tuple(a for a in range(n) if (mask >> a) & 1)
                 sites[s][ids] = c
-        log, i = self.raw_grouped_log, 0
-        while i < len(log):
-            s, n = int(log[i]), int(log[i + 1])
-            ids = tuple(int(np.int32(x)) for x in log[i + 2:i + 2 + n])
-            sites[s][ids] = (sites[s].get(ids, 0) + 1) & 0xFFFF
-            i += 2 + n
+        for s, ids, count in iter_grouped_log(self.raw_grouped_log):
+            sites[s][ids] = (sites[s].get(ids, 0) + count) & 0xFFFF
         return sites
 
     # SitesAlleleBaseCoverage (allele_base_non_nested, allele_base.cpp:10-38); [] for nested PRGs
@@ -300,11 +296,33 @@ def dump_grouped_allele_counts(cov: Coverage) -> str:
     return '{"grouped_allele_counts":{"allele_groups":{' + groups + '},"site_counts":[' + counts + "]}}\n"
 
 
+LOG_COUNTED = 0x80000000
+LOG_PAD = 0xFFFFFFFF
+
+
+def iter_grouped_log(log):
+    """(site_index, ids, count) of every record of a grouped log (gmx.h, gmx_coverage_fetch_grouped_log): records worth
+    +1 ``[site, n, ids...]`` or +count ``[site, n | LOG_COUNTED, count_lo, count_hi, ids...]``; the same key may recur."""
+    i, n_words = 0, len(log)
+    while i < n_words:
+        if int(log[i]) == LOG_PAD:
+            i += 1
+            continue
+        s, n = int(log[i]), int(log[i + 1])
+        head, count = 2, 1
+        if n & LOG_COUNTED:
+            n &= ~LOG_COUNTED
+            head, count = 4, int(log[i + 2]) | (int(log[i + 3]) << 32)
+        yield s, tuple(int(np.int32(x)) for x in log[i + head:i + head + n]), count
+        i += head + n
+
+
 class Quasimapper:
     """An engine on one GPU: the index resident in HBM plus zeroed coverage accumulators."""
 
     def __init__(self, index: Index, device: int = 0, rng_mode: int = RNG_LEMIRE, max_states: int = 0,
-                 max_path_nodes: int = 0, max_batch_reads: int = 0, forward_only: bool = False):
+                 max_path_nodes: int = 0, max_batch_reads: int = 0, forward_only: bool = False,
+                 huge_heap_bytes: int = 0, log_cap_words: int = 0):
         self.lib = _lib.load()
         self.index = index
         opts = _lib.EngineOpts()
@@ -318,6 +336,10 @@ class Quasimapper:
         if max_batch_reads:
             opts.max_batch_reads = max_batch_reads
         opts.forward_only = 1 if forward_only else 0
+        if huge_heap_bytes:
+            opts.huge_heap_bytes = huge_heap_bytes
+        if log_cap_words:
+            opts.log_cap_words = log_cap_words
         self.h = C.c_void_p()
         check(self.lib.gmx_engine_create(index.h, C.byref(opts), C.byref(self.h)))
 

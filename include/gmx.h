@@ -24,7 +24,7 @@ extern "C" {
 #define GMX_EINVAL (-1)   /* bad argument / inconsistent PRG (reference: std::runtime_error in PRG_String / cov_Graph_Builder) */
 #define GMX_ENODEV (-2)   /* no usable HIP device */
 #define GMX_EHIP (-3)     /* HIP runtime error */
-#define GMX_ECAP (-4)     /* a read exceeded the engine's state/path capacities (raise gmx_engine_opts) */
+#define GMX_ECAP (-4)     /* a read needs more than the last tier's heap, or the grouped log is full (raise gmx_engine_opts) */
 #define GMX_EREF (-5)     /* a read hit a condition on which the reference throws/asserts */
 #define GMX_ENOMEM (-6)
 
@@ -111,6 +111,13 @@ typedef struct gmx_engine_opts {
   uint64_t max_batch_reads;/* reads per internal launch (default 4M) */
   int forward_only;        /* 1 = map only the given orientation of each read (quasimap_read, quasimap.cpp:159-194,
                               as the reference's unit tests call it); 0 = forward + reverse complement (default) */
+  uint64_t huge_heap_bytes;/* memory of the last tier (default 512 MiB): a read whose search states or mapping instances
+                              exceed every fixed pool is redone with pools carved from this heap — the whole heap if need
+                              be — so the only limit left is this number, as memory is the reference's only limit
+                              (encapsulated_search.cpp:30-107, coverage_common.cpp:85-146). GMX_ECAP names the read that
+                              does not fit it. */
+  uint64_t log_cap_words;  /* device log of grouped counts of sites with more than 5 alleles, in uint32 words
+                              (0 = sized from max_batch_reads); it is drained to the host between batches */
 } gmx_engine_opts;
 void gmx_engine_default_opts(gmx_engine_opts *opts);
 
@@ -163,6 +170,8 @@ typedef struct gmx_queue_counts {
   uint64_t cover_mid;         /* ... of which those that needed its global-memory scratch */
   uint64_t cover_overflow;    /* ... and those (large-capacity tasks included) that needed the large scratch */
   uint64_t seed_cursor;       /* 1: the engine runs the seed-cursor kernels (index with many multi-state k-mer entries) */
+  uint64_t huge_search;       /* tasks searched again by the last tier (pools carved from the heap) */
+  uint64_t huge_cover;        /* tasks whose selection scratch the last tier sized from the heap */
 } gmx_queue_counts;
 int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out);
 
@@ -201,8 +210,13 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream);
  * saturates at 65535 (allele_base.cpp:239). gmx_finalize_u16 applies them. */
 int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped_dense,
                        gmx_stats *stats);
-/* Grouped counts of sites with more than 5 alleles are appended to a log of records
- * [site_index, n_ids, ids...]; returns the number of uint32 words (copies at most cap words). */
+/* Grouped counts of sites with more than 5 alleles (grouped_allele_counts.cpp:17-49 for sites without dense slots).
+ * Returns the number of uint32 words of the log (and copies it when it fits cap_words). The log is a sequence of records
+ *   [site_index, n_ids, ids...]                                     worth +1, or
+ *   [site_index, n_ids | GMX_LOG_COUNTED, count_lo, count_hi, ids...] worth +count,
+ * ids ascending; the same (site, ids) may appear in several records (their values add up — concatenating the logs of
+ * several engines is their sum). This function returns counted records, one per distinct (site, ids). */
+#define GMX_LOG_COUNTED 0x80000000u
 int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words);
 void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate);
 

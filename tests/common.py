@@ -95,7 +95,7 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         rc = lib.hostemu_map(h, flat.ctypes.data_as(C.POINTER(C.c_uint8)), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                              s.ctypes.data_as(C.POINTER(C.c_uint32)), offs.size - 1, fast_states, fast_arena, big_states,
                              big_arena)
-        sizes = np.zeros(6, dtype=np.uint64)
+        sizes = np.zeros(7, dtype=np.uint64)
         lib.hostemu_sizes(h, sizes.ctypes.data_as(C.POINTER(C.c_uint64)))
         a = np.zeros(max(int(sizes[0]), 1), dtype=np.uint32)
         p = np.zeros(max(int(sizes[1]), 1), dtype=np.uint32)
@@ -107,10 +107,10 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         raw = dict(allele_sum=a[:int(sizes[0])], per_base=p[:int(sizes[1])], grouped=g[:int(sizes[2])],
                    grouped_log=lg[:int(sizes[3])], stats=st)
         if return_raw:
-            return raw, (int(sizes[4]), int(sizes[5])), rc
+            return raw, (int(sizes[4]), int(sizes[5]), int(sizes[6])), rc
         ix = Index(prg, k, threads=1)
         cov = Coverage(ix, raw["allele_sum"], raw["per_base"], raw["grouped"], raw["grouped_log"],
                        QuasimapReadsStats(*(int(x) for x in st)))
-        return canonical_cov(cov), (int(sizes[4]), int(sizes[5])), rc
+        return canonical_cov(cov), (int(sizes[4]), int(sizes[5]), int(sizes[6])), rc
     finally:
         lib.hostemu_destroy(h)

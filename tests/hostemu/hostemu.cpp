@@ -105,7 +105,7 @@ struct Emu {
   uint64_t stats[5] = {0, 0, 0, 0, 0};
   int rng_mode = 0;
   uint32_t first_error = 0, error_task = 0;
-  uint64_t n_overflow_tasks = 0, n_cover_overflow = 0;
+  uint64_t n_overflow_tasks = 0, n_cover_overflow = 0, n_cover_huge = 0;
   uint32_t single_loci = GMX_SINGLE_LOCI;  // hostemu_set_single_loci: force the nested single-instance routine to give up
   std::string err;
 };
@@ -131,6 +131,53 @@ struct EmuEnvT {
   Emu *e;
   uint32_t status = GMX_TASK_MAPPED;
   EmuEnvT() : scratch(GmxScratchFixed<EmuEnvT>::total, 0xDEADBEEFu) {}
+  uint32_t sget(uint32_t w) const { return scratch.at(w); }
+  void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
+  uint32_t single_loci() const { return e->single_loci; }
+  void add_allele_sum(uint32_t s) { e->acc.at(s)++; }
+  void add_per_base(uint32_t s) { e->acc.at(s)++; }
+  void add_hit(uint32_t s) { e->acc.at(s)++; }
+  void add_grouped_dense(uint32_t s) { e->acc.at(s)++; }
+  void add_allele_and_group(uint32_t s) {
+    e->acc.at(s)++;
+    e->acc.at(s + 1)++;
+  }
+  bool log_grouped_begin(uint32_t site, uint32_t n) {
+    e->log.push_back(site);
+    e->log.push_back(n);
+    appended += 2;
+    return true;
+  }
+  void log_grouped_id(int32_t a) {
+    e->log.push_back((uint32_t)a);
+    ++appended;
+  }
+  void log_grouped_end() {}
+  void fail(uint32_t s) {
+    if (status == GMX_TASK_MAPPED || s == GMX_TASK_ERROR) status = s;
+  }
+};
+
+// Mirror of CoverEnvDyn (gmx_engine.hip): the last tier, capacities decided per task.
+struct EmuEnvDyn {
+  uint32_t cap_i, cap_b, cap_loc, cap_h;
+  uint32_t i_max() const { return cap_i; }
+  uint32_t b_max() const { return cap_b; }
+  uint32_t loc_max() const { return cap_loc; }
+  uint32_t h_max() const { return cap_h; }
+  bool has_log_sites() const { return true; }
+  bool log_reserve(uint32_t words) {
+    reserved += words;
+    return true;
+  }
+  uint32_t reserved = 0, appended = 0;
+  std::vector<uint32_t> scratch;
+  const GmxPathNode *arena;
+  uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
+  Emu *e;
+  uint32_t status = GMX_TASK_MAPPED;
   uint32_t sget(uint32_t w) const { return scratch.at(w); }
   void sset(uint32_t w, uint32_t v) { scratch.at(w) = v; }
   uint32_t single_loci() const { return e->single_loci; }
@@ -361,6 +408,31 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
         cstatus = big_env.status;
         if (cstatus == GMX_TASK_MAPPED && big_env.reserved != big_env.appended) cstatus = GMX_TASK_ERROR;
       }
+      if (cstatus == GMX_TASK_OVERFLOW) {  // the last tier (gmx_tail_item): scratch sized for this task
+        e->n_cover_huge++;
+        EmuEnvDyn dyn;
+        uint32_t n_items = 0;
+        for (uint32_t f = 0; f < use.n; ++f) {
+          const GmxFinalState &st = use.st[f];
+          if (st.traversed != GMX_NIL || st.traversing != GMX_NIL) {
+            ++n_items;
+            continue;
+          }
+          for (uint32_t i = st.lo;; ++i) {
+            n_items += ix.nodes[ix.pos_node[gmx_occ_pos(ix, st.hi, i)]].site != 0;
+            if (gmx_text_form(st.hi) || i == st.hi) break;
+          }
+        }
+        dyn.cap_i = n_items ? n_items : 1;
+        dyn.cap_b = len + 8 > 32 ? len + 8 : 32;
+        dyn.cap_loc = dyn.cap_h = 1u << 16;
+        dyn.scratch.assign(GmxScratch<EmuEnvDyn>::total_of(dyn), 0xDEADBEEFu);
+        dyn.arena = use.arena;
+        dyn.e = e;
+        gmx_cover_task(ix, dyn, use.st, use.n, len, seeds[read], e->rng_mode);
+        cstatus = dyn.status;
+        if (cstatus == GMX_TASK_MAPPED && dyn.reserved != dyn.appended) cstatus = GMX_TASK_ERROR;
+      }
       if (cstatus != GMX_TASK_MAPPED && !e->first_error) {
         e->first_error = cstatus;
         e->error_task = (uint32_t)(read * 2 + o);
@@ -378,6 +450,7 @@ void hostemu_sizes(void *p, uint64_t *out) {
   out[3] = e->log.size();
   out[4] = e->n_overflow_tasks;
   out[5] = e->n_cover_overflow;
+  out[6] = e->n_cover_huge;
 }
 void hostemu_fetch(void *p, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, uint32_t *log, uint64_t *stats) {
   Emu *e = (Emu *)p;
