@@ -7,6 +7,7 @@ interface. See DESIGN.md for the path, the boundary and the data layout.
 from .quasimap import (  # noqa: F401
     Index,
     Quasimapper,
+    QuasimapperGroup,
     Coverage,
     QuasimapReadsStats,
     quasimap_reads,

@@ -94,7 +94,19 @@ SYMBOLS = {
     "gmx_coverage_reduce_end": (C.c_int, [_vp, _vp]),
     "gmx_coverage_fetch": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
     "gmx_coverage_fetch_grouped_log": (_i64, [_vp, _u32p, _u64]),
+    "gmx_coverage_import_grouped_log": (C.c_int, [_vp, _u32p, _u64, C.c_int]),
     "gmx_finalize_u16": (None, [_u32p, _u64, C.c_int]),
+    "gmx_group_create": (C.c_int, [_vp, C.POINTER(EngineOpts), C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
+    "gmx_group_destroy": (None, [_vp]),
+    "gmx_group_size": (C.c_int, [_vp]),
+    "gmx_group_engine": (_vp, [_vp, C.c_int]),
+    "gmx_group_uses_rccl": (C.c_int, [_vp]),
+    "gmx_group_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
+    "gmx_group_allreduce": (C.c_int, [_vp]),
+    "gmx_comm_unique_id": (C.c_int, [_u8p]),
+    "gmx_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "gmx_comm_destroy": (None, [_vp]),
+    "gmx_comm_allreduce_coverage": (C.c_int, [_vp, _vp]),
 }
 
 _lib = None

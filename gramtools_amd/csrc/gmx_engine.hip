@@ -2649,4 +2649,56 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
   return (int64_t)n;
 }
 
+int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace) {
+  if (!e || (!records && n_words)) {
+    gmx_set_error("gmx_coverage_import_grouped_log: null argument");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(e->opts.device));
+  return gmx_engine_log_import(e, records, (size_t)n_words, replace != 0);
+}
+
 }  // extern "C"
+
+void gmx_engine_raw(gmx_engine *e, GmxEngineRaw *out) {
+  out->device = e->opts.device;
+  out->d_fused = e->d_fused;
+  out->n_fused = e->n_fused;
+  out->log_sites = e->log_sites;
+}
+
+int gmx_engine_log_export(gmx_engine *e, std::vector<uint32_t> &out) {
+  const int64_t n = gmx_coverage_fetch_grouped_log(e, nullptr, 0);
+  if (n < 0) return (int)n;
+  out.assign((size_t)n, 0);
+  if (n && gmx_coverage_fetch_grouped_log(e, out.data(), (uint64_t)n) < 0) return GMX_EHIP;
+  return GMX_OK;
+}
+
+int gmx_engine_log_import(gmx_engine *e, const uint32_t *w, size_t n_words, bool replace) {
+  if (replace) {
+    int rc = gmx_log_drain(e, 0);  // whatever is still on the device belongs to the totals being replaced
+    if (rc) return rc;
+    e->log_counts.clear();
+  }
+  std::vector<uint32_t> key;
+  for (size_t i = 0; i < n_words;) {
+    if (w[i] == GMX_LOG_PAD) {
+      ++i;
+      continue;
+    }
+    if (i + 2 > n_words) break;
+    const uint32_t n = w[i + 1] & ~GMX_LOG_COUNTED;
+    const size_t head = (w[i + 1] & GMX_LOG_COUNTED) ? 4 : 2;
+    if (i + head + n > n_words) {
+      gmx_set_error("corrupt grouped log");
+      return GMX_EINVAL;
+    }
+    const uint64_t count = head == 4 ? ((uint64_t)w[i + 2] | ((uint64_t)w[i + 3] << 32)) : 1;
+    key.assign(1, w[i]);
+    key.insert(key.end(), w + i + head, w + i + head + n);
+    e->log_counts[key] += count;
+    i += head + n;
+  }
+  return GMX_OK;
+}

@@ -1,0 +1,380 @@
+// gmx_multi.hip — several GPUs: reads shard, the index is replicated, ONE exchange at the end.
+//
+// The reference's unit of parallelism is one read inside an OpenMP loop (quasimap.cpp:90-118) over shared
+// coverage structures. Here every GPU owns an engine with its own accumulators; the reads of a call are dealt
+// out by global read index (the per-read seeds are the master stream's, so the result does not depend on the
+// number of GPUs), and at the end the uint32 accumulator blocks are summed: one RCCL all-reduce over xGMI of the
+// fused block (coverage + the five read counters as 16-bit limbs), plus the exchange of the grouped log of sites
+// with more than 5 alleles (counted records: small). uint16 wrap / saturation are functions of the totals, so the
+// result equals the single-thread reference.
+//
+// One exchange routine (gmx_exchange) serves both users:
+//   gmx_group  N engines in ONE process (the `gram` executable: one host thread per GPU)       — ncclCommInitAll
+//   gmx_comm   one engine per process (bench.py under torch.distributed.run, any launcher)    — ncclCommInitRank
+// RCCL is loaded with dlopen at first use: a single-GPU run never touches it. Without RCCL (or when two engines
+// of a group sit on the same device, as in the 1-GPU test) the group falls back to peer copies and an add kernel.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gmx.h"
+#include "gmx_internal.h"
+
+#define HIP_TRY(expr)                                                       \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess) {                                                 \
+      gmx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+      return GMX_EHIP;                                                      \
+    }                                                                       \
+  } while (0)
+
+namespace {
+
+struct Rccl {
+  void *so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+Rccl &rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r;
+  tried = true;
+  // a process that already holds an RCCL (torch's) gets that one through the soname
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    r.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (r.so) break;
+  }
+  if (!r.so) return r;
+  auto sym = [&](const char *n) { return dlsym(r.so, n); };
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+  r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.AllGather && r.GroupStart &&
+         r.GroupEnd && r.GetErrorString;
+  return r;
+}
+
+#define NCCL_TRY(expr)                                                                   \
+  do {                                                                                   \
+    ncclResult_t _r = (expr);                                                            \
+    if (_r != ncclSuccess) {                                                             \
+      gmx_set_error(std::string(#expr) + ": " + rccl().GetErrorString(_r));              \
+      return GMX_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+__global__ void gmx_add_u32_kernel(uint32_t *dst, const uint32_t *src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
+
+// One member of an exchange: an engine, its communicator (null = no RCCL), the stream the exchange is enqueued on.
+struct Member {
+  gmx_engine *e = nullptr;
+  ncclComm_t comm = nullptr;
+  hipStream_t stream = nullptr;
+  GmxEngineRaw raw{};
+};
+
+// The grouped log, member by member: [n_words, words...] all-gathered in two steps (sizes, then the padded
+// payloads), every member ends with the sum of all logs in its engine (gmx_engine_log_import(replace)).
+int exchange_logs_rccl(std::vector<Member> &ms, int world) {
+  Rccl &r = rccl();
+  const size_t n = ms.size();
+  std::vector<std::vector<uint32_t>> mine(n);
+  std::vector<uint64_t *> d_sizes(n, nullptr);
+  for (size_t i = 0; i < n; ++i) {
+    int rc = gmx_engine_log_export(ms[i].e, mine[i]);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ms[i].raw.device));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sizes[i]), (size_t)(world + 1) * 8));
+    const uint64_t sz = mine[i].size();
+    HIP_TRY(hipMemcpy(d_sizes[i] + world, &sz, 8, hipMemcpyHostToDevice));
+  }
+  NCCL_TRY(r.GroupStart());
+  for (size_t i = 0; i < n; ++i) NCCL_TRY(r.AllGather(d_sizes[i] + world, d_sizes[i], 1, ncclUint64, ms[i].comm, ms[i].stream));
+  NCCL_TRY(r.GroupEnd());
+  std::vector<uint64_t> sizes(world);
+  uint64_t pad = 0;
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(hipSetDevice(ms[i].raw.device));
+    HIP_TRY(hipStreamSynchronize(ms[i].stream));
+    HIP_TRY(hipMemcpy(sizes.data(), d_sizes[i], (size_t)world * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_sizes[i]));
+  }
+  for (uint64_t s : sizes) pad = std::max(pad, s);
+  if (pad == 0) return GMX_OK;
+  std::vector<uint32_t *> d_buf(n, nullptr);
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(hipSetDevice(ms[i].raw.device));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf[i]), (size_t)(world + 1) * pad * 4));
+    if (!mine[i].empty()) HIP_TRY(hipMemcpy(d_buf[i] + (size_t)world * pad, mine[i].data(), mine[i].size() * 4, hipMemcpyHostToDevice));
+  }
+  NCCL_TRY(r.GroupStart());
+  for (size_t i = 0; i < n; ++i)
+    NCCL_TRY(r.AllGather(d_buf[i] + (size_t)world * pad, d_buf[i], pad, ncclUint32, ms[i].comm, ms[i].stream));
+  NCCL_TRY(r.GroupEnd());
+  std::vector<uint32_t> all((size_t)world * pad);
+  for (size_t i = 0; i < n; ++i) {
+    HIP_TRY(hipSetDevice(ms[i].raw.device));
+    HIP_TRY(hipStreamSynchronize(ms[i].stream));
+    HIP_TRY(hipMemcpy(all.data(), d_buf[i], all.size() * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_buf[i]));
+    for (int rk = 0; rk < world; ++rk) {
+      int rc = gmx_engine_log_import(ms[i].e, all.data() + (size_t)rk * pad, sizes[rk], rk == 0);
+      if (rc) return rc;
+    }
+  }
+  return GMX_OK;
+}
+
+// THE exchange. RCCL: counters -> limbs, one in-place all-reduce(sum) of the fused block per member, limbs -> counters;
+// then the grouped logs when the index has sites that use them.
+int gmx_exchange(std::vector<Member> &ms, int world) {
+  Rccl &r = rccl();
+  for (auto &m : ms) {
+    int rc = gmx_coverage_reduce_begin(m.e, m.stream);
+    if (rc) return rc;
+  }
+  NCCL_TRY(r.GroupStart());
+  for (auto &m : ms) NCCL_TRY(r.AllReduce(m.raw.d_fused, m.raw.d_fused, m.raw.n_fused, ncclUint32, ncclSum, m.comm, m.stream));
+  NCCL_TRY(r.GroupEnd());
+  for (auto &m : ms) {
+    int rc = gmx_coverage_reduce_end(m.e, m.stream);
+    if (rc) return rc;
+  }
+  if (ms[0].raw.log_sites) return exchange_logs_rccl(ms, world);
+  return GMX_OK;
+}
+
+// Without RCCL (single process only): gather onto member 0 with peer copies and an add kernel, copy the totals back.
+int gmx_exchange_peer(std::vector<Member> &ms) {
+  const size_t n = ms.size();
+  for (auto &m : ms) {
+    int rc = gmx_coverage_reduce_begin(m.e, m.stream);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(m.raw.device));
+    HIP_TRY(hipStreamSynchronize(m.stream));
+  }
+  const int root = ms[0].raw.device;
+  HIP_TRY(hipSetDevice(root));
+  uint32_t *tmp = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), ms[0].raw.n_fused * 4));
+  for (size_t i = 1; i < n; ++i) {
+    HIP_TRY(hipMemcpyPeer(tmp, root, ms[i].raw.d_fused, ms[i].raw.device, ms[0].raw.n_fused * 4));
+    hipLaunchKernelGGL(gmx_add_u32_kernel, dim3(1024), dim3(256), 0, ms[0].stream, ms[0].raw.d_fused, tmp, ms[0].raw.n_fused);
+    HIP_TRY(hipStreamSynchronize(ms[0].stream));
+  }
+  HIP_TRY(hipFree(tmp));
+  for (size_t i = 1; i < n; ++i) HIP_TRY(hipMemcpyPeer(ms[i].raw.d_fused, ms[i].raw.device, ms[0].raw.d_fused, root, ms[0].raw.n_fused * 4));
+  for (auto &m : ms) {
+    int rc = gmx_coverage_reduce_end(m.e, m.stream);
+    if (rc) return rc;
+  }
+  if (ms[0].raw.log_sites) {  // host merge of the counted records
+    std::vector<std::vector<uint32_t>> logs(n);
+    for (size_t i = 0; i < n; ++i) {
+      int rc = gmx_engine_log_export(ms[i].e, logs[i]);
+      if (rc) return rc;
+    }
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < n; ++j) {
+        int rc = gmx_engine_log_import(ms[i].e, logs[j].data(), logs[j].size(), j == 0);
+        if (rc) return rc;
+      }
+  }
+  return GMX_OK;
+}
+
+}  // namespace
+
+struct gmx_group {
+  std::vector<Member> ms;
+  bool use_rccl = false;
+};
+
+struct gmx_comm {
+  Member m;
+  int world = 1, rank = 0;
+};
+
+extern "C" {
+
+int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const int *devices, int n_devices, gmx_group **out) {
+  if (!ix || !devices || n_devices <= 0 || !out) {
+    gmx_set_error("gmx_group_create: bad argument");
+    return GMX_EINVAL;
+  }
+  gmx_group *g = new gmx_group();
+  gmx_engine_opts opts;
+  if (opts_in)
+    opts = *opts_in;
+  else
+    gmx_engine_default_opts(&opts);
+  bool distinct = true;
+  for (int i = 0; i < n_devices; ++i) {
+    for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
+    opts.device = devices[i];
+    Member m;
+    int rc = gmx_engine_create(ix, &opts, &m.e);
+    if (rc) {
+      gmx_group_destroy(g);
+      return rc;
+    }
+    gmx_engine_raw(m.e, &m.raw);
+    g->ms.push_back(m);
+  }
+  if (n_devices > 1 && distinct && !getenv("GMX_NO_RCCL") && rccl().ok) {
+    std::vector<ncclComm_t> comms(n_devices);
+    if (rccl().CommInitAll(comms.data(), n_devices, devices) == ncclSuccess) {
+      for (int i = 0; i < n_devices; ++i) g->ms[i].comm = comms[i];
+      g->use_rccl = true;
+    }
+  }
+  *out = g;
+  return GMX_OK;
+}
+
+void gmx_group_destroy(gmx_group *g) {
+  if (!g) return;
+  for (auto &m : g->ms) {
+    if (m.comm) (void)rccl().CommDestroy(m.comm);
+    if (m.e) gmx_engine_destroy(m.e);
+  }
+  delete g;
+}
+
+int gmx_group_size(const gmx_group *g) { return g ? (int)g->ms.size() : 0; }
+gmx_engine *gmx_group_engine(gmx_group *g, int i) { return g && i >= 0 && i < (int)g->ms.size() ? g->ms[i].e : nullptr; }
+int gmx_group_uses_rccl(const gmx_group *g) { return g && g->use_rccl ? 1 : 0; }
+
+int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads) {
+  if (!g || g->ms.empty()) {
+    gmx_set_error("null group");
+    return GMX_EINVAL;
+  }
+  const size_t n = g->ms.size();
+  if (n == 1) return gmx_map_reads_host(g->ms[0].e, reads, offsets, seeds, n_reads);
+  std::vector<int> rcs(n, GMX_OK);
+  std::vector<std::string> errs(n);
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < n; ++i) {  // contiguous ranges of the global read index; the seeds are the global stream's
+    const uint64_t base = n_reads / n, rem = n_reads % n;
+    const uint64_t lo = i * base + std::min<uint64_t>(i, rem), cnt = base + (i < rem ? 1 : 0);
+    th.emplace_back([=, &rcs, &errs]() {
+      if (cnt == 0) return;
+      rcs[i] = gmx_map_reads_host(g->ms[i].e, reads, offsets + lo, seeds + lo, cnt);
+      if (rcs[i]) errs[i] = gmx_last_error();
+    });
+  }
+  for (auto &t : th) t.join();
+  for (size_t i = 0; i < n; ++i)
+    if (rcs[i]) {
+      gmx_set_error("device " + std::to_string(g->ms[i].raw.device) + ": " + errs[i]);
+      return rcs[i];
+    }
+  return GMX_OK;
+}
+
+int gmx_group_allreduce(gmx_group *g) {
+  if (!g || g->ms.empty()) {
+    gmx_set_error("null group");
+    return GMX_EINVAL;
+  }
+  if (g->ms.size() == 1) return GMX_OK;
+  for (auto &m : g->ms) {
+    int rc = gmx_engine_sync(m.e);
+    if (rc) return rc;
+  }
+  int rc = g->use_rccl ? gmx_exchange(g->ms, (int)g->ms.size()) : gmx_exchange_peer(g->ms);
+  if (rc) return rc;
+  for (auto &m : g->ms) {
+    HIP_TRY(hipSetDevice(m.raw.device));
+    HIP_TRY(hipStreamSynchronize(m.stream));
+  }
+  return GMX_OK;
+}
+
+int gmx_comm_unique_id(uint8_t *out128) {
+  if (!rccl().ok) {
+    gmx_set_error("RCCL (librccl.so) could not be loaded");
+    return GMX_ENODEV;
+  }
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  NCCL_TRY(rccl().GetUniqueId(&id));
+  memcpy(out128, &id, 128);
+  return GMX_OK;
+}
+
+int gmx_comm_create(const uint8_t *id128, int world, int rank, gmx_engine *e, gmx_comm **out) {
+  if (!id128 || !e || !out || world <= 0 || rank < 0 || rank >= world) {
+    gmx_set_error("gmx_comm_create: bad argument");
+    return GMX_EINVAL;
+  }
+  if (!rccl().ok) {
+    gmx_set_error("RCCL (librccl.so) could not be loaded");
+    return GMX_ENODEV;
+  }
+  gmx_comm *c = new gmx_comm();
+  c->world = world;
+  c->rank = rank;
+  c->m.e = e;
+  gmx_engine_raw(e, &c->m.raw);
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  if (hipSetDevice(c->m.raw.device) != hipSuccess) {
+    delete c;
+    gmx_set_error("hipSetDevice failed");
+    return GMX_EHIP;
+  }
+  ncclResult_t r = rccl().CommInitRank(&c->m.comm, world, id, rank);
+  if (r != ncclSuccess) {
+    gmx_set_error(std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+    delete c;
+    return GMX_EHIP;
+  }
+  *out = c;
+  return GMX_OK;
+}
+
+void gmx_comm_destroy(gmx_comm *c) {
+  if (!c) return;
+  if (c->m.comm) (void)rccl().CommDestroy(c->m.comm);
+  delete c;
+}
+
+int gmx_comm_allreduce_coverage(gmx_comm *c, void *hip_stream) {
+  if (!c) {
+    gmx_set_error("null communicator");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(c->m.raw.device));
+  c->m.stream = (hipStream_t)hip_stream;
+  std::vector<Member> ms(1, c->m);
+  return gmx_exchange(ms, c->world);
+}
+
+}  // extern "C"

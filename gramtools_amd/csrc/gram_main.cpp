@@ -54,6 +54,7 @@ const char *kGenotypeHelp =
     "  --seed arg                  seed for pseudo-random selection of multi-mapping reads. a random seed is\n"
     "                              generated if this option is not used.\n"
     "  --device arg (=0)           HIP device ordinal (engine extension)\n"
+    "  --devices arg               several GPUs, e.g. 0-7 or 0,2,5: reads sharded, coverage summed (engine extension)\n"
     "  --rng_compat arg (=gcc11)   uniform_int_distribution flavour of the reference build to reproduce:\n"
     "                              gcc11 (libstdc++ >= 11) or gcc10 (libstdc++ <= 10) (engine extension)\n";
 
@@ -510,7 +511,31 @@ int run_genotype(const Args &a) {
   uint32_t kmer_size = (uint32_t)std::stoul(a.one("kmer_size"));
   std::string run_dir = a.one("genotype_dir");
   int max_threads = a.has("max_threads") ? std::stoi(a.one("max_threads")) : 1;
-  int device = a.has("device") ? std::stoi(a.one("device")) : 0;
+  // --device N, or --devices 0-7 / 0,2,5: one engine and one host thread per listed GPU, reads dealt by read index,
+  // coverage summed at the end (gmx.h: gmx_group_*). The result does not depend on the number of GPUs.
+  std::vector<int> devices;
+  if (a.has("devices")) {
+    std::string spec = a.one("devices");
+    size_t i = 0;
+    while (i < spec.size()) {
+      size_t j = spec.find(',', i);
+      std::string part = spec.substr(i, j == std::string::npos ? std::string::npos : j - i);
+      size_t dash = part.find('-');
+      try {
+        if (dash == std::string::npos)
+          devices.push_back(std::stoi(part));
+        else
+          for (int d = std::stoi(part.substr(0, dash)); d <= std::stoi(part.substr(dash + 1)); ++d) devices.push_back(d);
+      } catch (std::exception const &) {
+        die("--devices takes a list like 0-7 or 0,2,5");
+      }
+      if (j == std::string::npos) break;
+      i = j + 1;
+    }
+    if (devices.empty()) die("--devices takes a list like 0-7 or 0,2,5");
+  } else {
+    devices.push_back(a.has("device") ? std::stoi(a.one("device")) : 0);
+  }
   int rng_mode = 0;
   if (a.has("rng_compat")) {
     std::string m = a.one("rng_compat");
@@ -549,10 +574,10 @@ int run_genotype(const Args &a) {
   std::cout << "Loading kmer index data" << std::endl;
   gmx_engine_opts opts;
   gmx_engine_default_opts(&opts);
-  opts.device = device;
   opts.rng_mode = rng_mode;
-  gmx_engine *eng = nullptr;
-  GMX_CHECK(gmx_engine_create(ix, &opts, &eng));
+  gmx_group *grp = nullptr;
+  GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
+  gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
   std::cout << "Running quasimap" << std::endl;
@@ -565,7 +590,7 @@ int run_genotype(const Args &a) {
   // One master mt19937(seed) for all files; 5000 draws per batch of <= 5000 reads (quasimap.cpp:120-141).
   std::mt19937 master(seed);
   const uint64_t kBatch = 5000;
-  const uint64_t kChunkReads = 1u << 20;  // reads staged per engine call (multiple of 5000 not required: seeds are per read)
+  const uint64_t kChunkReads = (uint64_t)(1u << 20) * devices.size();  // reads staged per call: 1 M per engine (multiple of 5000 not required: seeds are per read)
   uint64_t total_reads = 0;
   for (auto const &path : reads_paths) {
     // fast path: seeds as the batch loop below draws them (5000 master draws per batch of <= 5000 reads, per file)
@@ -582,7 +607,7 @@ int run_genotype(const Args &a) {
       const uint8_t *base_ptr = block.bases.empty() ? reinterpret_cast<const uint8_t *>("") : block.bases.data();
       for (uint64_t done = 0; done < n; done += kChunkReads) {
         const uint64_t m = std::min<uint64_t>(kChunkReads, n - done);
-        GMX_CHECK(gmx_map_reads_host(eng, base_ptr, block.offsets.data() + done, block_seeds.data() + done, m));
+        GMX_CHECK(gmx_group_map_reads_host(grp, base_ptr, block.offsets.data() + done, block_seeds.data() + done, m));
       }
       total_reads += n;
     };
@@ -596,7 +621,7 @@ int run_genotype(const Args &a) {
     auto flush = [&]() {
       if (offsets.size() > 1) {
         if (bases.empty()) bases.push_back(0);
-        GMX_CHECK(gmx_map_reads_host(eng, bases.data(), offsets.data(), seeds.data(), offsets.size() - 1));
+        GMX_CHECK(gmx_group_map_reads_host(grp, bases.data(), offsets.data(), seeds.data(), offsets.size() - 1));
       }
       bases.clear();
       offsets.assign(1, 0);
@@ -615,6 +640,7 @@ int run_genotype(const Args &a) {
     }
     flush();
   }
+  GMX_CHECK(gmx_group_allreduce(grp));  // the one exchange (a single engine: nothing to do)
   GMX_CHECK(gmx_engine_sync(eng));
   double t_map = std::chrono::duration<double>(clk::now() - t0).count();
 
@@ -743,7 +769,7 @@ int run_genotype(const Args &a) {
             << "Genotyping (infer stage) is not part of the MI355X quasimap engine: " << geno_dir
             << " is left empty; see INTEGRATION.md." << std::endl;
   (void)sample_id;
-  gmx_engine_destroy(eng);
+  gmx_group_destroy(grp);
   gmx_index_destroy(ix);
   return 0;
 }

@@ -98,9 +98,50 @@ def fused_coverage_tensor(qm):
 
 
 def allreduce_device_coverage(qm, dist, tensor=None, stream=None):
-    """THE exchange of the multi-GPU path: one RCCL all-reduce(sum), in place on the engine's coverage block
-    (uint32 totals wrap exactly like int32 sums; the uint64 read counters travel as 16-bit limbs)."""
+    """The exchange through torch.distributed (RCCL): one all-reduce(sum), in place on the engine's coverage block
+    (uint32 totals wrap exactly like int32 sums; the uint64 read counters travel as 16-bit limbs), and — when the PRG
+    has sites with more than 5 alleles — an all-gather of the grouped logs (counted records: one per distinct
+    (site, allele set), small), after which every rank's engine holds the sum of all logs.
+    :class:`CoverageComm` does the same inside the library (the implementation `gram --devices` uses)."""
     t = fused_coverage_tensor(qm) if tensor is None else tensor
     qm.reduce_begin(stream)
     dist.all_reduce(t)
     qm.reduce_end(stream)
+    if qm.index.uses_grouped_log and dist.get_world_size() > 1:
+        logs = [None] * dist.get_world_size()
+        dist.all_gather_object(logs, qm.grouped_log())
+        for r, log in enumerate(logs):
+            qm.import_grouped_log(np.asarray(log, dtype=np.uint32), replace=(r == 0))
+
+
+class CoverageComm:
+    """The library's own exchange (gmx.h: gmx_comm_*; RCCL called from C++, the code path `gram --devices` uses) for
+    one engine per process. The 128-byte RCCL id is made on rank 0 and broadcast over the launcher's process group."""
+
+    def __init__(self, qm, dist):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        self.qm = qm
+        world, rank = dist.get_world_size(), dist.get_rank()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(self.lib.gmx_comm_unique_id(ident))
+        box = [bytes(ident)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self.h = C.c_void_p()
+        _lib.check(self.lib.gmx_comm_create(ident, world, rank, qm.h, C.byref(self.h)))
+
+    def allreduce(self, stream=None):
+        import ctypes as C
+        from . import _lib
+        _lib.check(self.lib.gmx_comm_allreduce_coverage(self.h, C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close

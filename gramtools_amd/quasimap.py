@@ -85,6 +85,11 @@ class Index:
                                              _p(self.grouped_off, C.c_uint32), _p(self.parent_site, C.c_uint32),
                                              _p(self.parent_allele, C.c_int32)))
 
+    @property
+    def uses_grouped_log(self):
+        """Some site has more than 5 alleles: its grouped counts live in the log, not in dense slots."""
+        return bool((self.grouped_off == GROUPED_LOG).any())
+
     def save(self, path: str):
         """Write the index cache (gmx_index_save)."""
         check(self.lib.gmx_index_save(self.h, path.encode()))
@@ -404,6 +409,19 @@ class Quasimapper:
         """After the all-reduce: limb sums -> read counters."""
         check(self.lib.gmx_coverage_reduce_end(self.h, C.c_void_p(stream) if stream else None))
 
+    def import_grouped_log(self, records, replace=False):
+        """Adds (or, with `replace`, substitutes) grouped-log records to this engine's totals (log exchanges done in Python)."""
+        r = np.ascontiguousarray(records, dtype=np.uint32)
+        check(self.lib.gmx_coverage_import_grouped_log(self.h, _p(r if r.size else np.zeros(1, np.uint32), C.c_uint32), r.size,
+                                                       1 if replace else 0))
+
+    def grouped_log(self):
+        n = check(self.lib.gmx_coverage_fetch_grouped_log(self.h, None, 0))
+        log = np.zeros(max(n, 1), dtype=np.uint32)
+        if n:
+            check(self.lib.gmx_coverage_fetch_grouped_log(self.h, _p(log, C.c_uint32), n))
+        return log[:n]
+
     def coverage(self) -> Coverage:
         info = self.index.info
         a = np.zeros(max(info.n_allele_slots, 1), dtype=np.uint32)
@@ -418,6 +436,55 @@ class Quasimapper:
         stats = QuasimapReadsStats(st.all_reads_count, st.skipped_reads_count, st.missing_kmer_reads_count,
                                    st.no_extension_reads_count, st.exact_mapped_reads_count)
         return Coverage(self.index, a[:info.n_allele_slots], p[:info.n_per_base_slots], g[:info.n_grouped_slots], log[:n], stats)
+
+
+class QuasimapperGroup:
+    """Several GPUs of one node in one process (gmx.h: gmx_group_*): an engine per listed device, reads dealt by
+    read index, one exchange at the end. ``devices`` may repeat an ordinal (two engines on one GPU: the exchange then
+    runs over peer copies instead of RCCL) — which is how the path is tested on a one-GPU box."""
+
+    def __init__(self, index: Index, devices, rng_mode: int = RNG_LEMIRE, **opts_kw):
+        self.lib = _lib.load()
+        self.index = index
+        opts = _lib.EngineOpts()
+        self.lib.gmx_engine_default_opts(C.byref(opts))
+        opts.rng_mode = rng_mode
+        for k, v in opts_kw.items():
+            setattr(opts, k, v)
+        dev = (C.c_int * len(devices))(*devices)
+        self.h = C.c_void_p()
+        check(self.lib.gmx_group_create(index.h, C.byref(opts), dev, len(devices), C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_group_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    @property
+    def uses_rccl(self):
+        return bool(self.lib.gmx_group_uses_rccl(self.h))
+
+    def map_reads(self, reads_flat, offsets, seeds):
+        r = np.ascontiguousarray(reads_flat, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if r.size == 0:
+            r = np.zeros(1, dtype=np.uint8)
+        check(self.lib.gmx_group_map_reads_host(self.h, _p(r, C.c_uint8), _p(o, C.c_uint64), _p(s, C.c_uint32), o.size - 1))
+
+    def allreduce(self):
+        check(self.lib.gmx_group_allreduce(self.h))
+
+    def coverage(self, member: int = 0) -> Coverage:
+        """Coverage held by engine `member` (after :meth:`allreduce`: the totals of the whole job, on every member)."""
+        view = Quasimapper.__new__(Quasimapper)
+        view.lib, view.index, view.h = self.lib, self.index, C.c_void_p(self.lib.gmx_group_engine(self.h, member))
+        try:
+            return view.coverage()
+        finally:
+            view.h = None  # the group owns the engine
 
 
 def quasimap_reads(index: Index, read_files, seed: int, device: int = 0, rng_mode: int = RNG_LEMIRE) -> Coverage:

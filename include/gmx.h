@@ -218,7 +218,36 @@ int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, 
  * several engines is their sum). This function returns counted records, one per distinct (site, ids). */
 #define GMX_LOG_COUNTED 0x80000000u
 int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words);
+/* Adds the records of a grouped log (either form) to the engine's totals, after emptying them when `replace`: the
+ * receiving end of a log exchange done outside the library (gramtools_amd/distributed.py under torch.distributed). */
+int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace);
 void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate);
+
+/* ---- several GPUs: reads shard, the index is replicated, one exchange at the end ----------------------
+ * Replaces the OpenMP loop over reads with shared coverage structures (quasimap.cpp:90-118; omp atomic / omp critical
+ * in coverage/allele_sum.cpp:31-43 and grouped_allele_counts.cpp:17-49). Every GPU has an engine of its own; after the
+ * last read the uint32 totals are summed: ONE RCCL all-reduce of each engine's fused block (the five read counters ride
+ * in it as 16-bit limbs) plus the exchange of the grouped log (counted records) when the PRG has sites with more than
+ * 5 alleles. Afterwards every engine holds the totals of the whole job: gmx_coverage_fetch on any of them. */
+typedef struct gmx_group gmx_group; /* N engines in ONE process, one per listed device (the `gram` executable) */
+int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts, const int *devices, int n_devices, gmx_group **out);
+void gmx_group_destroy(gmx_group *g);
+int gmx_group_size(const gmx_group *g);
+gmx_engine *gmx_group_engine(gmx_group *g, int i);
+int gmx_group_uses_rccl(const gmx_group *g); /* 0: peer copies + add kernel (no RCCL, or two engines on one device) */
+/* Deals the reads of this call out by read index — engine i maps a contiguous range, one host thread per engine — with
+ * the caller's per-read seeds (the master stream is global, so the result does not depend on the number of GPUs). */
+int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
+                             uint64_t n_reads);
+int gmx_group_allreduce(gmx_group *g); /* the exchange; synchronises every engine first */
+
+typedef struct gmx_comm gmx_comm; /* one engine per PROCESS (torch.distributed.run, mpirun, ...): rank 0 makes the id,
+                                     the launcher's own channel broadcasts its 128 bytes, every rank creates its comm */
+int gmx_comm_unique_id(uint8_t *out128);
+int gmx_comm_create(const uint8_t *id128, int world_size, int rank, gmx_engine *e, gmx_comm **out);
+void gmx_comm_destroy(gmx_comm *c);
+/* The same exchange, enqueued on hip_stream (the log part, if any, synchronises that stream). */
+int gmx_comm_allreduce_coverage(gmx_comm *c, void *hip_stream);
 
 #ifdef __cplusplus
 }

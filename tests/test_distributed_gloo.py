@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 from common import oracle_map, hostemu_map, canonical_cov, flatten_reads
 from gramtools_amd import Index
 from gramtools_amd.distributed import quasimap_reads_sharded, shard_range, global_seeds
-from gramtools_amd.synth import nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, snp_prg, simulate_snp_reads
+from gramtools_amd.synth import (nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, snp_prg, simulate_snp_reads,
+                                 mixed_variant_prg, simulate_haplotype_reads)
 
 
 def _free_port():
@@ -80,3 +81,16 @@ def test_two_ranks_equal_single_process_oracle_nested_repeats():
     want = oracle_map(prg, 3, reads, global_seeds(7, [len(reads)]))
     got = _run(prg, 3, reads, 7)
     assert got[0] == want and got[1] == want
+
+
+def test_two_ranks_exchange_the_grouped_log_of_many_allele_sites():
+    """Sites with 6-7 alleles keep their grouped counts in the append log, which every rank must receive from every
+    other: the totals equal the single-process oracle and the log really was in play."""
+    ref = random_ref(4000, 11)
+    prg, sites = mixed_variant_prg(ref, 80, 12, max_alleles=7)
+    assert any(len(al) >= 6 for _, _, al in sites)
+    reads = simulate_haplotype_reads(ref, sites, 500, 60, 150, 13)
+    want = oracle_map(prg, 6, reads, global_seeds(42, [len(reads)]))
+    got = _run(prg, 6, reads, 42)
+    assert got[0] == want and got[1] == want
+    assert any(len(ids) >= 1 and max(ids) >= 5 for site in want["grouped"] for ids in site)
