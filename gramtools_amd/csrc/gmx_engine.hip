@@ -476,6 +476,10 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
       // a few occurrences (a short repeat): position by position in text form — the same results (see
       // gmx_search_big_kernel), 32 bases per step instead of one rank block per base and 137 iterations of the wave
       for (uint32_t i = s.a; i <= s.b; ++i) ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
+    } else if (s.a == s.b && from > 0) {
+      // one occurrence: text form right away (this look-up is the CONVERT step of the wave loop, done here with every
+      // lane of the wave taking part instead of costing the lane its first iteration)
+      ctx.push(ix.sa[s.a], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
     } else if (s.a <= s.b) {
       ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
     }
@@ -543,9 +547,14 @@ extern "C" int gmx_debug_loop_stats(unsigned long long *out, int reset) {
 #endif
 // GMX_KIND_SHARE: a heavier kind runs in an iteration when it holds at least 1/GMX_KIND_SHARE of the heavy lanes.
 // Measured on MI355X: the loop is latency-bound, so running every kind present (64) beats gathering lanes (4).
+// `fuse`: transitions that need no fetch of their own do not cost the lane an iteration. A resolved marker hit (or a
+// converted width-one interval) that continues in text form takes its text step in the SAME iteration (one more fetch
+// for those lanes, the compare code runs once for all), and a state that died or reached the stop position is replaced
+// by the lane's next pending entry at the end of the iteration. A lane's chain shrinks from (text steps + marker hits +
+// emits + pops) iterations to about its text steps; the wave runs as long as its slowest lane.
 template <int KID, bool CURSOR, class Ctx, class Reader>
 __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint32_t stop, bool active, uint32_t budget,
-                             GmxLane &ln) {
+                             GmxLane &ln, bool fuse = false) {
   ln.a = ln.b = ln.tvd = ln.tvg = ln.pos = ln.mode = 0;
   ln.have = active && ctx.pop(ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
   bool wait_slow = false;
@@ -611,12 +620,41 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
           ln.have = ctx.next_seed(ix, true, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
         }
       }
-      if (run_text && kind == GMX_FAST_TEXT)
-        gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
-      if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+      if (!fuse) {
+        if (run_text && kind == GMX_FAST_TEXT)
+          gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+        if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+      } else {
+        // marker hits first: what they continue as takes its text step below
+        if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
+        bool text_now = run_text && kind == GMX_FAST_TEXT;
+        const bool late = !wait_slow && (kind == GMX_FAST_HIT || kind == GMX_FAST_CONVERT) &&
+                          gmx_dfs_fast_kind(ln, stop) == GMX_FAST_TEXT;
+        if (__ballot(late)) {
+          if (late) {
+            q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+            uint32_t start;
+            gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+            rd.planes(start, xlo, xhi);
+            text_now = true;
+          }
+        }
+        if (text_now) gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+      }
       if (run_wide && kind == GMX_FAST_WIDE) {
         const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
         if (!gmx_dfs_fast_wide(ix, rd, ln, w)) wait_slow = true;
+      }
+      if (fuse) {  // a state that died or reached the stop position: the lane's next pending entry, now
+        const uint32_t k2 = wait_slow || !(kind == GMX_FAST_TEXT || kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE || kind == GMX_FAST_CONVERT)
+                                ? GMX_FAST_NONE
+                                : gmx_dfs_fast_kind(ln, stop);
+        if (__ballot(k2 == GMX_FAST_EMIT || k2 == GMX_FAST_POP)) {
+          if (k2 == GMX_FAST_EMIT)
+            gmx_dfs_emit(ctx, ln);
+          else if (k2 == GMX_FAST_POP)
+            gmx_dfs_pop(ctx, ln);
+        }
       }
     }
     if ((mf | ms) == 0) break;
@@ -959,7 +997,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
 }
 
 template <bool CURSOR, bool SEEDED>
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse) {
   uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   const long long t0 = GMX_CLK();
@@ -1006,7 +1044,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   }
   const long long t1 = GMX_CLK();
   GmxLane ln;
-  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln);
+  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln, fuse != 0);
   status = ctx.status;
   const long long t2 = GMX_CLK();
   finish_lane(ix, o, slot < n_alive, task, ctx, status, true, true, r.len);
@@ -1921,6 +1959,7 @@ struct gmx_engine {
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
+  uint32_t fuse = 1;  // fused transitions in the extend kernel's wave loop (GMX_NO_FUSE=1 in the environment: off, for A/B runs)
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
   uint64_t *d_offsets = nullptr;
@@ -2181,6 +2220,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     }
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
+  if (getenv("GMX_NO_FUSE")) e->fuse = 0;
   // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
   // more than 10 % of the seed states the kernels take them one state at a time (seed cursor, a few % slower), else
   // the rare large entry goes to the large-capacity pass
@@ -2320,13 +2360,13 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, task_grid, b, o, 0);
   if (seeded && e->seed_cursor)
-    hipLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+    hipLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
   else if (seeded)
-    hipLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+    hipLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
   else if (e->seed_cursor)
-    hipLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+    hipLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
   else
-    hipLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o);
+    hipLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
   if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
