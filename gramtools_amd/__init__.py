@@ -11,6 +11,8 @@ from .quasimap import (  # noqa: F401
     Coverage,
     QuasimapReadsStats,
     quasimap_reads,
+    Genotyped,
+    genotyping_model,
     master_seeds,
     encode_dna_bases,
     dump_allele_sum,

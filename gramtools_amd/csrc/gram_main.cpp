@@ -765,10 +765,23 @@ int run_genotype(const Args &a) {
             << "Timer report (wall seconds)" << std::endl
             << "  Load data (index build + upload): " << t_load << std::endl
             << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl;
-  std::cout << "====================" << std::endl
-            << "Genotyping (infer stage) is not part of the MI355X quasimap engine: " << geno_dir
-            << " is left empty; see INTEGRATION.md." << std::endl;
-  (void)sample_id;
+  // ---- infer (genotype.cpp:72-118): level genotyping on the host from the coverage just recorded -----------------
+  std::cout << "====================" << std::endl << "Running genotyping" << std::endl;
+  auto t_inf = clk::now();
+  std::cout << "Running genotyping model" << std::endl;
+  gmx_infer *inf = nullptr;
+  GMX_CHECK(gmx_infer_run(ix, per_base.data(), grouped.data(), glog.data(), (uint64_t)n_log, rs.mean_cov_depth, rs.variance_cov_depth,
+                          rs.mean_pb_error, ploidy == "haploid" ? 1 : 2, &inf));
+  const std::string coords = join(gram_dir, "prg_coords.tsv");
+  std::cout << "Producing json vcf" << std::endl;
+  GMX_CHECK(gmx_infer_write_json(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.json").c_str()));
+  std::cout << "Producing personalised reference" << std::endl;
+  const std::string desc = sample_id + " personalised reference made by gramtools genotype";
+  GMX_CHECK(gmx_infer_write_fasta(inf, coords.c_str(), desc.c_str(), join(geno_dir, "personalised_reference.fasta").c_str()));
+  std::cout << "Producing vcf" << std::endl;
+  GMX_CHECK(gmx_infer_write_vcf(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.vcf.gz").c_str()));
+  gmx_infer_destroy(inf);
+  std::cout << "  Genotyping: " << std::chrono::duration<double>(clk::now() - t_inf).count() << std::endl;
   gmx_group_destroy(grp);
   gmx_index_destroy(ix);
   return 0;

@@ -487,6 +487,77 @@ class QuasimapperGroup:
             view.h = None  # the group owns the engine
 
 
+class Genotyped:
+    """The infer stage (gmx.h: gmx_infer_*; LevelGenotyper + writers, src/genotype/genotype.cpp:72-118) on a Coverage:
+    level genotyping of every site from the recorded coverage. Host work."""
+
+    def __init__(self, cov: Coverage, mean_pb_error: float, ploidy: str = "haploid", depth=None):
+        import json as _json
+        self._json = _json
+        self.lib = _lib.load()
+        self.index = cov.index
+        d = depth if depth is not None else cov.depth_stats()
+        pb = np.ascontiguousarray(cov.raw_per_base if cov.raw_per_base.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        g = np.ascontiguousarray(cov.raw_grouped if cov.raw_grouped.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        lg = np.ascontiguousarray(cov.raw_grouped_log if cov.raw_grouped_log.size else np.zeros(1, np.uint32), dtype=np.uint32)
+        self.h = C.c_void_p()
+        check(self.lib.gmx_infer_run(self.index.h, _p(pb, C.c_uint32), _p(g, C.c_uint32), _p(lg, C.c_uint32),
+                                     cov.raw_grouped_log.size, d["mean"], d["variance"], mean_pb_error,
+                                     1 if ploidy == "haploid" else 2, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_infer_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def site(self, i: int) -> dict:
+        n = check(self.lib.gmx_infer_site_json(self.h, i, None, 0))
+        buf = C.create_string_buffer(n + 1)
+        check(self.lib.gmx_infer_site_json(self.h, i, buf, n + 1))
+        return self._json.loads(buf.value.decode())
+
+    def called_alleles(self, i: int):
+        """Sequences of the distinct genotyped alleles of site i ([] when null genotyped)."""
+        s = self.site(i)
+        if s["GT"][0][0] is None:
+            return []
+        return [s["ALS"][g] for g in sorted(set(s["GT"][0]))]
+
+    def write(self, genotype_dir: str, sample_id: str, coords_path: str = None):
+        import os
+        cp = coords_path.encode() if coords_path else None
+        check(self.lib.gmx_infer_write_json(self.h, cp, sample_id.encode(), os.path.join(genotype_dir, "genotyped.json").encode()))
+        check(self.lib.gmx_infer_write_vcf(self.h, cp, sample_id.encode(), os.path.join(genotype_dir, "genotyped.vcf.gz").encode()))
+        desc = f"{sample_id} personalised reference made by gramtools genotype"
+        check(self.lib.gmx_infer_write_fasta(self.h, cp, desc.encode(),
+                                             os.path.join(genotype_dir, "personalised_reference.fasta").encode()))
+
+
+def genotyping_model(alleles, grouped_counts, ploidy, mean_cov, var_cov, mean_pb_error) -> dict:
+    """LevelGenotyperModel on explicit data (gmx_infer_model): alleles = [(sequence, [per-base cov], haplogroup, callable)],
+    grouped_counts = {(ids...): count}."""
+    import json as _json
+    lib = _lib.load()
+    n = len(alleles)
+    seqs = (C.c_char_p * n)(*[a[0].encode() for a in alleles])
+    pb_off = np.concatenate([[0], np.cumsum([len(a[1]) for a in alleles])]).astype(np.uint32)
+    pb = np.asarray([c for a in alleles for c in a[1]] or [0], dtype=np.uint32)
+    hap = np.asarray([a[2] for a in alleles], dtype=np.int32)
+    call = np.asarray([1 if (len(a) < 4 or a[3]) else 0 for a in alleles], dtype=np.uint8)
+    keys = list(grouped_counts)
+    g_off = np.concatenate([[0], np.cumsum([len(k) for k in keys])]).astype(np.uint32)
+    g_ids = np.asarray([i for k in keys for i in k] or [0], dtype=np.int32)
+    g_cnt = np.asarray([grouped_counts[k] for k in keys] or [0], dtype=np.uint32)
+    args = (n, seqs, _p(pb_off, C.c_uint32), _p(pb, C.c_uint32), _p(hap, C.c_int32), _p(call, C.c_uint8), len(keys),
+            _p(g_off, C.c_uint32), _p(g_ids, C.c_int32), _p(g_cnt, C.c_uint32), ploidy, mean_cov, var_cov, mean_pb_error)
+    size = check(lib.gmx_infer_model(*args, None, 0))
+    buf = C.create_string_buffer(size + 1)
+    check(lib.gmx_infer_model(*args, buf, size + 1))
+    return _json.loads(buf.value.decode())
+
+
 def quasimap_reads(index: Index, read_files, seed: int, device: int = 0, rng_mode: int = RNG_LEMIRE) -> Coverage:
     """quasimap_reads (quasimap.cpp:16-57) over already-parsed reads.
 

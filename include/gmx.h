@@ -223,6 +223,31 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
 int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace);
 void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate);
 
+/* ---- infer stage: genotyping from the recorded coverage, on the host ------------------------------
+ * Replaces LevelGenotyper + the three writers `gram genotype` runs after quasimap (src/genotype/genotype.cpp:72-118,
+ * src/genotype/infer/): level genotyping of every site, most nested first, with the reference's likelihood model,
+ * genotype confidence percentiles (lib/GCP/GCP.h), nested-site invalidation and the AMBIG filter. Inputs are the raw
+ * totals of gmx_coverage_fetch (+ the grouped log); uint16 semantics are applied inside. ploidy is 1 or 2. */
+typedef struct gmx_infer gmx_infer;
+int gmx_infer_run(const gmx_index *ix, const uint32_t *per_base_raw, const uint32_t *grouped_dense_raw,
+                  const uint32_t *grouped_log, uint64_t n_log_words, double mean_cov_depth, double variance_cov_depth,
+                  double mean_pb_error, int ploidy, gmx_infer **out);
+void gmx_infer_destroy(gmx_infer *inf);
+/* genotype/genotyped.json (jVCF; output_specs/make_json.cpp), genotype/genotyped.vcf.gz (BGZF; output_specs/make_vcf.cpp:
+ * level-1 sites) and genotype/personalised_reference.fasta (personalised_reference.cpp; deduplicated by sequence as
+ * genotype.cpp:16-21). coords_path = gram_dir/prg_coords.tsv (segment names and sizes) or NULL for one segment. */
+int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path);
+int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path);
+int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const char *description, const char *out_path);
+/* One site as its jVCF object (POS 1-based in PRG coordinates); returns the length, copies when it fits cap. */
+int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out, uint64_t cap);
+/* The likelihood model on explicit alleles and grouped counts (the known answers of tests/genotype/infer/
+ * level_genotyping/test_model.cpp): the resulting site as JSON with the model's extra alleles and thresholds. */
+int64_t gmx_infer_model(uint32_t n_alleles, const char *const *seqs, const uint32_t *pb_off, const uint32_t *pb_cov,
+                        const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
+                        const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
+                        double mean_pb_error, char *out, uint64_t cap);
+
 /* ---- several GPUs: reads shard, the index is replicated, one exchange at the end ----------------------
  * Replaces the OpenMP loop over reads with shared coverage structures (quasimap.cpp:90-118; omp atomic / omp critical
  * in coverage/allele_sum.cpp:31-43 and grouped_allele_counts.cpp:17-49). Every GPU has an engine of its own; after the

@@ -77,7 +77,14 @@ def test_integration_cases_through_the_cli(tmp_path, case, gz):
     rs = json.loads((out / "read_stats.json").read_text())
     assert rs["Max_read_length"] == max(len(x) for x in reads)
     assert abs(rs["Quality"]["Error_rate_mean"] - 0.01) < 1e-9 and rs["Quality"]["Num_bases"] == sum(len(x) for x in reads)
-    assert (out / "genotype").is_dir()
+    # infer stage (genotype.cpp:72-118): the three files the unmodified front-end reads afterwards (genotype.py:131-145)
+    geno = out / "genotype"
+    j = json.loads((geno / "genotyped.json").read_text())
+    assert j["Model"] == "LevelGenotyping" and len(j["Sites"]) == len(gp["site_counts"])
+    vcf = gzip.decompress((geno / "genotyped.vcf.gz").read_bytes()).decode().splitlines()
+    assert vcf[0] == "##fileformat=VCFv4.2" and vcf[-1].split("\t")[0] == "gramtools_prg"
+    fa = (geno / "personalised_reference.fasta").read_text().splitlines()
+    assert fa[0].startswith(">gramtools_prg test personalised reference made by gramtools genotype") and set("".join(fa[1:])) <= set("ACGT")
 
 
 @pytest.mark.gpu
