@@ -1012,7 +1012,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 6;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 7;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1023,10 +1023,31 @@ uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   return h;
 }
 
+// Checksum of everything written / read (four interleaved multiplicative lanes over 64-bit words: memory speed): a
+// damaged cache whose table sizes still match would otherwise hand unchecked indices to the host and the device.
+struct Checksum {
+  uint64_t lane[4] = {1, 2, 3, 4};
+  uint64_t n = 0;
+  void add(const void *p, size_t bytes) {
+    const unsigned char *c = static_cast<const unsigned char *>(p);
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+      uint64_t w[4];
+      memcpy(w, c + i, 32);
+      for (int k = 0; k < 4; ++k) lane[k] = lane[k] * 0x9E3779B97F4A7C15ull + w[k];
+    }
+    for (; i < bytes; ++i) lane[i & 3] = lane[i & 3] * 0x100000001B3ull + c[i];
+    n += bytes;
+  }
+  uint64_t value() const { return (lane[0] ^ (lane[1] << 1) ^ (lane[2] << 2) ^ (lane[3] << 3)) + n; }
+};
+
 struct Writer {
   FILE *f;
+  Checksum sum;
   void raw(const void *p, size_t n) {
     if (n && fwrite(p, 1, n, f) != n) throw std::runtime_error("index cache: write failed");
+    sum.add(p, n);
   }
   template <class T>
   void pod(const T &v) {
@@ -1040,8 +1061,10 @@ struct Writer {
 };
 struct Reader {
   FILE *f;
+  Checksum sum;
   void raw(void *p, size_t n) {
     if (n && fread(p, 1, n, f) != n) throw std::runtime_error("index cache: truncated file");
+    sum.add(p, n);
   }
   template <class T>
   void pod(T &v) {
@@ -1116,7 +1139,8 @@ void save_index(const HostIndex &h, const std::string &path) {
       w.pod(e.first);
       w.vec(e.second);
     }
-    w.pod(kCacheMagic);  // end mark
+    w.pod<uint64_t>(w.sum.value());  // of every byte before it
+    w.pod(kCacheMagic);              // end mark
   } catch (...) {
     fclose(f);
     remove(tmp.c_str());
@@ -1164,9 +1188,11 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
       r.pod(e.first);
       r.vec(e.second);
     }
-    uint64_t end = 0;
+    const uint64_t computed = r.sum.value();
+    uint64_t stored = 0, end = 0;
+    r.pod(stored);
     r.pod(end);
-    if (end != kCacheMagic) throw std::runtime_error("index cache: damaged file");
+    if (end != kCacheMagic || stored != computed) throw std::runtime_error("index cache: damaged file (checksum)");
     out.prg = prg;
     // cheap structural checks against damage that keeps the sizes
     if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||

@@ -71,6 +71,15 @@ void mkdirs(const std::string &path) {
     }
     if (i < path.size()) cur += path[i];
   }
+  struct stat st;
+  if (stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) die("gram: cannot create directory " + path);
+}
+
+// every output file is checked after its last write: a full disk must not leave a truncated file behind an exit code 0
+void close_checked(std::ofstream &o, const std::string &path) {
+  o.flush();
+  if (!o.good()) die("gram: error writing " + path);
+  o.close();
 }
 
 std::string join(const std::string &dir, const std::string &name) {
@@ -134,6 +143,11 @@ class SeqReader {
       if (n && buf[n - 1] == '\r') --n;
       out.append(buf, n);
       if (eol) return true;
+    }
+    if (!gzeof(gz_)) {  // gzgets stopped before the end of the file: a damaged or truncated gzip stream
+      int err = 0;
+      const char *msg = gzerror(gz_, &err);
+      if (err != Z_OK && err != Z_STREAM_END) die(std::string("gram: error reading the reads file: ") + (msg ? msg : "zlib error"));
     }
     return any;
   }
@@ -334,7 +348,12 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   for (;;) {
     while (have < kBlock) {
       int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
-      if (got <= 0) break;
+      if (got < 0) {  // a damaged or truncated gzip stream must not pass for the end of the reads
+        int err = 0;
+        const char *msg = gzerror(g, &err);
+        die("gram: " + path + ": " + (msg ? msg : "zlib error"));
+      }
+      if (got == 0) break;
       have += (size_t)got;
     }
     const bool final = gzeof(g) != 0 || have < kBlock;
@@ -404,6 +423,7 @@ void write_read_stats(const std::string &path, const ReadStats &rs) {  // ReadSt
   o << "\n    \"Num_bases\": " << rs.num_bases_processed << ",";
   o << "\n    \"No_qual_reads\": " << rs.no_qual_reads;
   o << "\n    }}\n";
+  close_checked(o, path);
 }
 
 #define GMX_CHECK(expr)                                                        \
@@ -673,6 +693,7 @@ int run_genotype(const Args &a) {
       }
       o << "\n";
     }
+    close_checked(o, join(cov_dir, "allele_sum_coverage"));
   }
   {  // coverage::dump::allele_base (allele_base.cpp:49-107): saturating uint16; [] for nested PRGs
     std::ofstream o(join(cov_dir, "allele_base_coverage.json"));
@@ -697,6 +718,7 @@ int run_genotype(const Args &a) {
       }
     }
     o << "]}\n";
+    close_checked(o, join(cov_dir, "allele_base_coverage.json"));
   }
   {  // coverage::dump::grouped_allele_counts (grouped_allele_counts.cpp:51-110): uint16 wrap, arbitrary group ids
     std::vector<std::map<std::vector<int32_t>, uint32_t>> sites(info.n_sites);
@@ -749,6 +771,7 @@ int run_genotype(const Args &a) {
       o << "}" << (s + 1 < info.n_sites ? "," : "");
     }
     o << "]}}\n";
+    close_checked(o, join(cov_dir, "grouped_allele_counts_coverage.json"));
   }
   std::string rs_path = join(run_dir, "read_stats.json");
   std::cout << "Writing read stats to " << rs_path << std::endl;

@@ -56,6 +56,10 @@ def test_stale_or_damaged_cache_is_refused(tmp_path):
     data = open(cache, "rb").read()
     open(cache, "wb").write(data[: len(data) // 2])
     assert lib.gmx_index_load(cache.encode(), prg_path.encode(), 5, C.byref(h)) != 0      # truncated
+    flipped = bytearray(data)                      # same length, same table sizes, one bit of one table flipped
+    flipped[len(flipped) // 3] ^= 0x10
+    open(cache, "wb").write(bytes(flipped))
+    assert lib.gmx_index_load(cache.encode(), prg_path.encode(), 5, C.byref(h)) != 0      # checksum
     open(cache, "wb").write(b"not a cache")
     assert lib.gmx_index_load(cache.encode(), prg_path.encode(), 5, C.byref(h)) != 0
     ix = Index(prg_path, 5, cache=cache)  # falls back to building
