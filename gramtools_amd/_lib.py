@@ -69,6 +69,7 @@ SYMBOLS = {
     "gmx_index_allele_base_layout": (C.c_int, [_vp, _u32p, _u32p]),
     "gmx_compute_coverage_depth": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u64, C.POINTER(DepthStats)]),
     "gmx_index_bubble_order": (C.c_int, [_vp, _u32p]),
+    "gmx_debug_suffix_array_u16": (C.c_int, [C.POINTER(C.c_uint16), _u64, C.POINTER(C.c_uint16)]),
     "gmx_index_copy_sa": (C.c_int, [_vp, _u32p]),
     "gmx_index_copy_bwt": (C.c_int, [_vp, _u32p]),
     "gmx_index_rank": (_u32, [_vp, _u32, _u32]),

@@ -323,6 +323,16 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
   return GMX_OK;
 }
 
+int gmx_debug_suffix_array_u16(const uint16_t *text, uint64_t n, uint16_t *out) {
+  try {
+    gmx::debug_suffix_array_u16(text, (size_t)n, out);
+    return GMX_OK;
+  } catch (std::exception const &ex) {
+    gmx_set_error(ex.what());
+    return GMX_EINVAL;
+  }
+}
+
 int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out) {
   memcpy(out, ix->h.sa.data(), ix->h.sa.size() * 4);
   return GMX_OK;

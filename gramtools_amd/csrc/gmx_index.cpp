@@ -2,6 +2,7 @@
 #include "gmx_index.h"
 
 #include <algorithm>
+#include <limits>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -22,13 +23,15 @@ namespace gmx {
 // ===========================================================================
 namespace {
 
-typedef int32_t sidx;
-
+// Index type I is unsigned: uint32_t for real texts — the reference's SA_Index (search/types.hpp:19), good for every
+// text shorter than 2^32 - 1, which whole-human PRGs (3.46 G symbols) need — and uint16_t in the test hook
+// gmx_debug_suffix_array_u16, which runs the same code on texts longer than 2^15 so that every comparison and loop is
+// exercised with the top bit of I in use. EMPTY (all ones) marks a free slot; valid entries are < n <= EMPTY - 1.
 struct TypeBits {
   std::vector<uint8_t> b;
   explicit TypeBits(size_t n) : b((n + 7) / 8, 0) {}
-  bool get(sidx i) const { return (b[i >> 3] >> (i & 7)) & 1; }
-  void set(sidx i, bool v) {
+  bool get(size_t i) const { return (b[i >> 3] >> (i & 7)) & 1; }
+  void set(size_t i, bool v) {
     if (v)
       b[i >> 3] |= (uint8_t)(1u << (i & 7));
     else
@@ -36,36 +39,47 @@ struct TypeBits {
   }
 };
 
-inline bool is_lms(const TypeBits &t, sidx i) { return i > 0 && t.get(i) && !t.get(i - 1); }
+inline bool is_lms(const TypeBits &t, size_t i) { return i > 0 && t.get(i) && !t.get(i - 1); }
 
-void get_buckets(const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K, bool end) {
-  std::fill(bkt.begin(), bkt.end(), 0);
-  for (sidx i = 0; i < n; ++i) bkt[s[i]]++;
-  sidx sum = 0;
-  for (sidx i = 0; i <= K; ++i) {
+template <class I>
+void get_buckets(const I *s, std::vector<I> &bkt, size_t n, size_t K, bool end) {
+  std::fill(bkt.begin(), bkt.end(), (I)0);
+  for (size_t i = 0; i < n; ++i) bkt[s[i]]++;
+  size_t sum = 0;
+  for (size_t i = 0; i <= K; ++i) {
     sum += bkt[i];
-    bkt[i] = end ? sum : sum - bkt[i];
+    bkt[i] = (I)(end ? sum : sum - bkt[i]);
   }
 }
 
-void induce_l(const TypeBits &t, sidx *SA, const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K) {
+template <class I>
+void induce_l(const TypeBits &t, I *SA, const I *s, std::vector<I> &bkt, size_t n, size_t K) {
+  const I EMPTY = std::numeric_limits<I>::max();
   get_buckets(s, bkt, n, K, false);
-  for (sidx i = 0; i < n; ++i) {
-    sidx j = SA[i] - 1;
-    if (SA[i] > 0 && !t.get(j)) SA[bkt[s[j]]++] = j;
+  for (size_t i = 0; i < n; ++i) {
+    const I v = SA[i];
+    if (v == EMPTY || v == 0) continue;
+    const size_t j = (size_t)v - 1;
+    if (!t.get(j)) SA[bkt[s[j]]++] = (I)j;
   }
 }
 
-void induce_s(const TypeBits &t, sidx *SA, const sidx *s, std::vector<sidx> &bkt, sidx n, sidx K) {
+template <class I>
+void induce_s(const TypeBits &t, I *SA, const I *s, std::vector<I> &bkt, size_t n, size_t K) {
+  const I EMPTY = std::numeric_limits<I>::max();
   get_buckets(s, bkt, n, K, true);
-  for (sidx i = n - 1; i >= 0; --i) {
-    sidx j = SA[i] - 1;
-    if (SA[i] > 0 && t.get(j)) SA[--bkt[s[j]]] = j;
+  for (size_t i = n; i-- > 0;) {
+    const I v = SA[i];
+    if (v == EMPTY || v == 0) continue;
+    const size_t j = (size_t)v - 1;
+    if (t.get(j)) SA[--bkt[s[j]]] = (I)j;
   }
 }
 
 // s[n-1] must be 0 and unique smallest. K = largest symbol.
-void sais(const sidx *s, sidx *SA, sidx n, sidx K) {
+template <class I>
+void sais(const I *s, I *SA, size_t n, size_t K) {
+  const I EMPTY = std::numeric_limits<I>::max();
   if (n == 1) {
     SA[0] = 0;
     return;
@@ -73,26 +87,27 @@ void sais(const sidx *s, sidx *SA, sidx n, sidx K) {
   TypeBits t(n);
   t.set(n - 1, true);
   t.set(n - 2, false);
-  for (sidx i = n - 3; i >= 0; --i) t.set(i, s[i] < s[i + 1] || (s[i] == s[i + 1] && t.get(i + 1)));
+  for (size_t i = n - 2; i-- > 0;) t.set(i, s[i] < s[i + 1] || (s[i] == s[i + 1] && t.get(i + 1)));
 
-  std::vector<sidx> bkt((size_t)K + 1);
+  std::vector<I> bkt(K + 1);
   get_buckets(s, bkt, n, K, true);
-  for (sidx i = 0; i < n; ++i) SA[i] = -1;
-  for (sidx i = 1; i < n; ++i)
-    if (is_lms(t, i)) SA[--bkt[s[i]]] = i;
+  for (size_t i = 0; i < n; ++i) SA[i] = EMPTY;
+  for (size_t i = 1; i < n; ++i)
+    if (is_lms(t, i)) SA[--bkt[s[i]]] = (I)i;
   induce_l(t, SA, s, bkt, n, K);
   induce_s(t, SA, s, bkt, n, K);
 
-  sidx n1 = 0;
-  for (sidx i = 0; i < n; ++i)
-    if (is_lms(t, SA[i])) SA[n1++] = SA[i];
-  for (sidx i = n1; i < n; ++i) SA[i] = -1;
-  sidx name = 0, prev = -1;
-  for (sidx i = 0; i < n1; ++i) {
-    sidx pos = SA[i];
+  size_t n1 = 0;
+  for (size_t i = 0; i < n; ++i)
+    if (is_lms(t, SA[i])) SA[n1++] = SA[i];  // after both passes every slot holds a suffix
+  for (size_t i = n1; i < n; ++i) SA[i] = EMPTY;
+  size_t name = 0, prev = 0;
+  bool have_prev = false;
+  for (size_t i = 0; i < n1; ++i) {
+    const size_t pos = SA[i];
     bool diff = false;
-    for (sidx d = 0; d < n; ++d) {
-      if (prev == -1 || s[pos + d] != s[prev + d] || t.get(pos + d) != t.get(prev + d)) {
+    for (size_t d = 0; d < n; ++d) {
+      if (!have_prev || s[pos + d] != s[prev + d] || t.get(pos + d) != t.get(prev + d)) {
         diff = true;
         break;
       } else if (d > 0 && (is_lms(t, pos + d) || is_lms(t, prev + d)))
@@ -101,26 +116,27 @@ void sais(const sidx *s, sidx *SA, sidx n, sidx K) {
     if (diff) {
       name++;
       prev = pos;
+      have_prev = true;
     }
-    SA[n1 + pos / 2] = name - 1;
+    SA[n1 + pos / 2] = (I)(name - 1);
   }
-  for (sidx i = n - 1, j = n - 1; i >= n1; --i)
-    if (SA[i] >= 0) SA[j--] = SA[i];
+  for (size_t i = n, j = n; i-- > n1;)
+    if (SA[i] != EMPTY) SA[--j] = SA[i];
 
-  sidx *SA1 = SA, *s1 = SA + n - n1;
+  I *SA1 = SA, *s1 = SA + n - n1;
   if (name < n1)
-    sais(s1, SA1, n1, name - 1);
+    sais<I>(s1, SA1, n1, name - 1);
   else
-    for (sidx i = 0; i < n1; ++i) SA1[s1[i]] = i;
+    for (size_t i = 0; i < n1; ++i) SA1[s1[i]] = (I)i;
 
   get_buckets(s, bkt, n, K, true);
-  for (sidx i = 1, j = 0; i < n; ++i)
-    if (is_lms(t, i)) s1[j++] = i;
-  for (sidx i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
-  for (sidx i = n1; i < n; ++i) SA[i] = -1;
-  for (sidx i = n1 - 1; i >= 0; --i) {
-    sidx j = SA[i];
-    SA[i] = -1;
+  for (size_t i = 1, j = 0; i < n; ++i)
+    if (is_lms(t, i)) s1[j++] = (I)i;
+  for (size_t i = 0; i < n1; ++i) SA1[i] = s1[SA1[i]];
+  for (size_t i = n1; i < n; ++i) SA[i] = EMPTY;
+  for (size_t i = n1; i-- > 0;) {
+    const I j = SA[i];
+    SA[i] = EMPTY;
     SA[--bkt[s[j]]] = j;
   }
   induce_l(t, SA, s, bkt, n, K);
@@ -129,32 +145,37 @@ void sais(const sidx *s, sidx *SA, sidx n, sidx K) {
 
 }  // namespace
 
+void debug_suffix_array_u16(const uint16_t *text, size_t n, uint16_t *sa) {
+  if (n == 0 || n >= 0xFFFFu || text[n - 1] != 0) throw std::runtime_error("u16 suffix array: 0 < n < 65535 and a final sentinel 0");
+  size_t K = 0;
+  for (size_t i = 0; i < n; ++i) K = std::max<size_t>(K, text[i]);
+  sais<uint16_t>(text, sa, n, K);
+}
+
 void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa) {
   size_t n = text.size();
   if (n == 0) {
     sa.clear();
     return;
   }
-  if (n >= (size_t)0x7fffffff) throw std::runtime_error("text too long for the 32-bit suffix array builder");
+  // indices are uint32 (SA_Index, search/types.hpp:19); 0xFFFFFFFF marks a free slot, 0xFFFFFFFE a text-form state
+  if (n >= (size_t)0xFFFFFFFEull) throw std::runtime_error("text too long for 32-bit suffix array indices (2^32 - 2 symbols at most)");
   if (text[n - 1] != 0) throw std::runtime_error("text must end with the sentinel 0");
-  // compact the alphabet
-  std::vector<uint32_t> sorted(text);
-  std::sort(sorted.begin(), sorted.end());
-  sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
-  std::vector<sidx> s(n);
-  {
-    // symbols 0..4 (sentinel + bases) through a small table, markers through binary search
-    sidx low[5];
-    for (uint32_t c = 0; c <= 4; ++c) low[c] = (sidx)(std::lower_bound(sorted.begin(), sorted.end(), c) - sorted.begin());
-    for (size_t i = 0; i < n; ++i)
-      s[i] = text[i] <= 4 ? low[text[i]] : (sidx)(std::lower_bound(sorted.begin(), sorted.end(), text[i]) - sorted.begin());
-  }
   for (size_t i = 0; i + 1 < n; ++i)
     if (text[i] == 0) throw std::runtime_error("sentinel 0 inside the text");
-  std::vector<sidx> SA(n);
-  sais(s.data(), SA.data(), (sidx)n, (sidx)sorted.size() - 1);
-  sa.resize(n);
-  for (size_t i = 0; i < n; ++i) sa[i] = (uint32_t)SA[i];
+  // compact the alphabet: rank of every symbol among the symbols present (no sorted copy of the text: 14 GB at 3.46 G)
+  uint32_t max_sym = 0;
+  for (size_t i = 0; i < n; ++i) max_sym = std::max(max_sym, text[i]);
+  std::vector<uint32_t> rank((size_t)max_sym + 2, 0);
+  for (size_t i = 0; i < n; ++i) rank[(size_t)text[i] + 1] = 1;
+  for (size_t c = 1; c < rank.size(); ++c) rank[c] += rank[c - 1];  // rank[c] = symbols present below c
+  const size_t K = rank.back() - 1;
+  sa.assign(n, 0);
+  {
+    std::vector<uint32_t> s(n);
+    for (size_t i = 0; i < n; ++i) s[i] = rank[text[i]];
+    sais<uint32_t>(s.data(), sa.data(), n, K);
+  }
 }
 
 std::vector<uint32_t> read_prg_file(const std::string &path) {

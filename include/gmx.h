@@ -89,6 +89,10 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
 int gmx_index_bubble_order(const gmx_index *ix, uint32_t *site_markers_out);
 
 /* Introspection (tests, debugging): copies of the derived structures. */
+/* The suffix-array builder instantiated with 16-bit indices (text of n < 65535 symbols ending in the only 0): texts
+ * longer than 2^15 drive it with the index type's top bit in use, as whole-human PRGs (> 2^31 symbols) drive the
+ * 32-bit instance the index uses (SA_Index is uint32_t in the reference, search/types.hpp:19). */
+int gmx_debug_suffix_array_u16(const uint16_t *text, uint64_t n, uint16_t *out);
 int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out);             /* n_text entries (fm_index[i]) */
 int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out);            /* n_text entries */
 uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base); /* dna_bwt_rank, BWT_search.cpp:8-22 */

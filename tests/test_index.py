@@ -106,3 +106,25 @@ def test_suffix_array_on_larger_snp_prg():
     ix = Index(prg, 5, threads=2)
     assert (ix.sa() == o.sa()).all()
     assert ix.info.n_kmers_present > 900
+
+
+def test_suffix_array_builder_with_the_index_types_top_bit_in_use():
+    """configs[4] (whole human, 3.46 G symbols) needs suffix-array indices above 2^31: the builder is templated on an
+    UNSIGNED index type (uint32_t in the index, as the reference's SA_Index). Instantiated with uint16_t it is run on
+    texts of 33 000 .. 65 000 symbols — every index comparison, free-slot mark and loop bound then works above the
+    signed range — against a plain sort of the suffixes."""
+    import ctypes as C
+    from gramtools_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    for n, alphabet in ((33000, 4), (50000, 2), (65533, 6)):
+        text = rng.integers(1, alphabet + 1, size=n, dtype=np.uint16)
+        # a few long repeats so that the recursion (names < LMS count) is taken more than once
+        text[1000:9000] = text[20000:28000]
+        text[-1] = 0
+        out = np.zeros(n, dtype=np.uint16)
+        assert lib.gmx_debug_suffix_array_u16(text.ctypes.data_as(C.POINTER(C.c_uint16)), n,
+                                              out.ctypes.data_as(C.POINTER(C.c_uint16))) == 0
+        raw = text.astype(np.uint8).tobytes()
+        want = sorted(range(n), key=lambda i: raw[i:])
+        assert out.astype(np.int64).tolist() == want
