@@ -494,7 +494,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   out.kmer_size = kmer_size;
   const size_t N = prg.size();
   if (N == 0) throw std::runtime_error("empty PRG");
-  if (N >= 0x7ffffff0ull) throw std::runtime_error("PRG too long for this build (2^31 limit)");
+  if (N >= 0xFFFFFFF0ull) throw std::runtime_error("PRG too long: positions are 32-bit (SA_Index, search/types.hpp:19), 2^32 - 16 symbols at most");
 
   // --- graph ---------------------------------------------------------------
   GraphBuild g;
@@ -663,15 +663,19 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     if (p == 0) out.sentinel_pos = (uint32_t)i;
   }
   // symbol -> first SA index (FM-index C array over the compacted alphabet)
-  std::map<uint32_t, uint32_t> sym_count;
-  for (auto s : text) sym_count[s]++;
   std::map<uint32_t, uint32_t> sym_first;
+  std::vector<uint32_t> sym_count;  // a flat array: one map look-up per symbol costs minutes at 10^9 symbols
   {
+    uint32_t max_sym = 0;
+    for (auto s : text) max_sym = std::max(max_sym, s);
+    sym_count.assign((size_t)max_sym + 1, 0);
+    for (auto s : text) sym_count[s]++;
     uint32_t acc = 0;
-    for (auto &e : sym_count) {
-      sym_first[e.first] = acc;
-      acc += e.second;
-    }
+    for (size_t c = 0; c < sym_count.size(); ++c)
+      if (sym_count[c]) {
+        sym_first[(uint32_t)c] = acc;
+        acc += sym_count[c];
+      }
   }
   for (uint32_t c = 1; c <= 4; ++c) {
     // char2comp of an absent symbol is 0 in SDSL, C[0] = 0; an absent base never yields a valid interval
