@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1336,6 +1337,9 @@ struct CoverAcc {
   uint32_t log_sites;   // the index has sites with more than 5 alleles (users of the log)
   uint32_t *heap;       // the last tier's memory (gmx_tail_stage)
   uint64_t heap_words;
+  const uint32_t *status;      // per task, for the read counters tallied by the batch's last launch
+  uint32_t n_tasks;
+  unsigned long long *stats;   // QuasimapReadsStats counters
 };
 
 // The grouped log (sites with more than 5 alleles): a task reserves ALL the words it will append with one atomic add,
@@ -1506,7 +1510,9 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     if (status != GMX_TASK_MAPPED) return status;
     nf = ctx.n_out;
     if (nf == 0) {
-      o.status[task] = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+      // the task's status word stays GMX_TASK_OVERFLOW (counted as a read, in no category, by the tally that runs beside
+      // this stage): its category is added here
+      atomicAdd(&acc.stats[all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? 3 : 2], 1ull);
       o.n_final[task] = 0;
       return GMX_TASK_MAPPED;
     }
@@ -1555,7 +1561,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
   env.log_at = 0;
   gmx_cover_task(ix, env, finals, nf, len, b.seeds[task >> 1], acc.rng_mode);
   if (env.status == GMX_TASK_MAPPED && is_search) {
-    o.status[task] = GMX_TASK_MAPPED;
+    atomicAdd(&acc.stats[4], 1ull);  // exact_mapped (the status word stays GMX_TASK_OVERFLOW, see above)
     o.n_final[task] = nf;
   }
   return env.status;
@@ -1605,6 +1611,8 @@ constexpr uint32_t gmx_cover_lds_lanes() {
          : GmxScratchFixed<Env>::total * 32 * sizeof(uint32_t) <= 64 * 1024 ? 32u
                                                                        : 16u;
 }
+__device__ void gmx_stats_tally(const uint32_t *status, uint32_t n_tasks, unsigned long long *stats);
+
 template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
@@ -1622,8 +1630,12 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
   const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
+  // LIST 1 is the batch's last launch and also tallies the read counters: its grid is larger than the blocks that own a
+  // lane of the global scratch; the others go straight to the tally
+  const uint32_t work_blocks = BIG ? acc.n_lanes_big / 64u : gridDim.x;
+  if (BIG && blockIdx.x >= work_blocks) n_mapped = 0;
   // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
-  for (uint32_t m = m_start + threadIdx.x * gridDim.x + blockIdx.x; m < n_mapped; m += gridDim.x * LANES) {
+  for (uint32_t m = m_start + threadIdx.x * work_blocks + blockIdx.x; m < n_mapped; m += work_blocks * LANES) {
     uint32_t entry = list[m];
     uint32_t task, nf;
     const GmxFinalState *finals;
@@ -1666,13 +1678,18 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   }
   if (BIG) {  // this instance is the batch's last search / coverage launch: whichever block finishes last serves the last tier
     __shared__ uint32_t ticket;
-    __threadfence();
-    if (threadIdx.x == 0) ticket = atomicAdd(&o.counters[14 * GMX_CNT_STRIDE], 1u);
-    __syncthreads();
-    if (ticket == gridDim.x - 1) {
+    if (blockIdx.x < work_blocks) {
       __threadfence();
-      gmx_tail_stage(ix, b, o, g, acc);
+      if (threadIdx.x == 0) ticket = atomicAdd(&o.counters[14 * GMX_CNT_STRIDE], 1u);
+      __syncthreads();
+      if (ticket == work_blocks - 1) {
+        __threadfence();
+        gmx_tail_stage(ix, b, o, g, acc);
+      }
     }
+    // QuasimapReadsStats: every status word is final by now — the filter passes were waited for, and the last tier
+    // adds the categories of its tasks itself (their words stay GMX_TASK_OVERFLOW: a read, in no category)
+    gmx_stats_tally(acc.status, acc.n_tasks, acc.stats);
   }
 }
 
@@ -1729,8 +1746,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
 
 // QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
 // Grid-stride over the task statuses, per-thread tallies, one LDS reduction and five atomics per block.
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *status, uint32_t n_tasks,
-                                                              unsigned long long *stats) {
+__device__ void gmx_stats_tally(const uint32_t *status, uint32_t n_tasks, unsigned long long *stats) {
   __shared__ uint32_t acc[5];
   if (threadIdx.x < 5) acc[threadIdx.x] = 0;
   __syncthreads();
@@ -1744,7 +1760,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   };
   const uint32_t n_quads = n_tasks / 4;  // the status array is 16-byte aligned
   const uint4 *quads = reinterpret_cast<const uint4 *>(status);
-  for (uint32_t q = blockIdx.x * GMX_BLOCK + threadIdx.x; q < n_quads; q += gridDim.x * GMX_BLOCK) {
+  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += gridDim.x * blockDim.x) {
     const uint4 s = quads[q];
     tally(s.x);
     tally(s.y);
@@ -1768,6 +1784,10 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *st
   }
   __syncthreads();
   if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
+}
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *status, uint32_t n_tasks,
+                                                              unsigned long long *stats) {
+  gmx_stats_tally(status, n_tasks, stats);
 }
 
 // The five uint64 read counters <-> 16-bit limbs in uint32 words, so that they travel inside the one uint32
@@ -2349,7 +2369,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipEventRecord(e->ev_fork, stream));
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
   CoverAcc acc{e->d_fused, e->d_log, e->d_log_cursor, e->log_cap, e->d_scratch_big, e->cover_big_lanes, e->opts.rng_mode,
-               e->log_sites ? 1u : 0u, e->d_heap, e->heap_words};
+               e->log_sites ? 1u : 0u, e->d_heap, e->heap_words, e->d_status, (uint32_t)n_reads * 2u, e->d_stats};
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
     hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
@@ -2395,10 +2415,9 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
-                     b, o, e->big, acc);
-  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks / 4 + GMX_BLOCK) / GMX_BLOCK, 512u)),
-                     dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>),
+                     dim3(std::max<uint32_t>(e->cover_big_lanes / 64, std::min<uint32_t>(n_tasks / 1024 + 1, 2048u))), dim3(64),
+                     big_lds, stream, e->dview, b, o, e->big, acc);
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
     e->pending.push_back(ev);
@@ -2524,6 +2543,38 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
     done += n;
   }
   return gmx_engine_sync(e);
+}
+
+// page-locked allocations are remembered so that gmx_host_free knows which call returns them
+static std::mutex g_host_mu;
+static std::map<void *, bool> g_host_pinned;
+void *gmx_host_alloc(uint64_t bytes) {
+  void *p = nullptr;
+  bool pinned = hipHostMalloc(&p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault) == hipSuccess && p;
+  if (!pinned) {
+    (void)hipGetLastError();
+    p = malloc(std::max<uint64_t>(bytes, 1));
+  }
+  if (p) {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    g_host_pinned[p] = pinned;
+  }
+  return p;
+}
+void gmx_host_free(void *p) {
+  if (!p) return;
+  bool pinned = false;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host_pinned.find(p);
+    if (it == g_host_pinned.end()) return;
+    pinned = it->second;
+    g_host_pinned.erase(it);
+  }
+  if (pinned)
+    (void)hipHostFree(p);
+  else
+    free(p);
 }
 
 int gmx_engine_sync(gmx_engine *e) {

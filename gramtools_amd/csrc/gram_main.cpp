@@ -24,7 +24,11 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <sstream>
 #include <string>
@@ -180,16 +184,77 @@ bool encode_read(const std::string &s, std::vector<uint8_t> &out) {
 // with '@' is followed by a header and a sequence line, never by '+') and encodes the records that start in it.
 // Anything else (gzip, FASTA, multi-line records, blank lines) returns false and takes the sequential reader.
 // Output = exactly what the sequential loop produces: bases 1..4 back to back, offsets, unencodable reads empty.
-struct ParsedReads {
-  std::vector<uint8_t> bases;
-  std::vector<uint64_t> offsets;  // n + 1
+// Host buffers the engine can DMA from directly (gmx_host_alloc: page-locked memory): an upload from pageable memory is
+// staged by the runtime through small pinned chunks at a fraction of the PCIe rate. Contents are not kept on growth.
+template <class T>
+struct HostBuf {
+  T *p = nullptr;
+  size_t n = 0, cap = 0;
+  HostBuf() = default;
+  HostBuf(const HostBuf &) = delete;
+  HostBuf &operator=(const HostBuf &) = delete;
+  ~HostBuf() {
+    if (p) gmx_host_free(p);
+  }
+  void resize(size_t count) {
+    if (count > cap) {
+      if (p) gmx_host_free(p);
+      cap = count + count / 8 + 64;
+      p = static_cast<T *>(gmx_host_alloc(cap * sizeof(T)));
+      if (!p) die("gram: out of memory");
+    }
+    n = count;
+  }
+  void clear() { n = 0; }
+  bool empty() const { return n == 0; }
+  size_t size() const { return n; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
 };
+
+struct ParsedReads {
+  HostBuf<uint8_t> bases;
+  HostBuf<uint64_t> offsets;  // n + 1
+  HostBuf<uint32_t> seeds;    // filled by the consumer
+  void reset() {
+    bases.clear();
+    offsets.resize(1);
+    offsets[0] = 0;
+  }
+};
+
+// encode_dna_bases (common/utils.cpp:73-92) as a table: A,C,G,T (either case) -> 1..4, anything else 0
+struct BaseTable {
+  uint8_t v[256];
+  BaseTable() {
+    memset(v, 0, sizeof(v));
+    v[(unsigned char)'A'] = v[(unsigned char)'a'] = 1;
+    v[(unsigned char)'C'] = v[(unsigned char)'c'] = 2;
+    v[(unsigned char)'G'] = v[(unsigned char)'g'] = 3;
+    v[(unsigned char)'T'] = v[(unsigned char)'t'] = 4;
+  }
+};
+static const BaseTable kBaseTable;
+
+// fn(t) for t = 0 .. T-1 on T threads
+template <class F>
+void parallel_for(unsigned T, F fn) {
+  if (T <= 1) {
+    fn(0u);
+    return;
+  }
+  std::vector<std::thread> pool;
+  pool.reserve(T);
+  for (unsigned t = 0; t < T; ++t) pool.emplace_back(fn, t);
+  for (auto &th : pool) th.join();
+}
 // Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
 // the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
 // Returns false on anything that is not plain four-line FASTQ.
 bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed) {
-  out.bases.clear();
-  out.offsets.assign(1, 0);
+  out.reset();
   consumed = 0;
   if (size == 0) return true;
   if (d[0] != '@') return false;
@@ -245,29 +310,22 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
       }
       const size_t base_at = p.bases.size();
       p.bases.resize(base_at + n);
-      bool valid = true;
+      uint8_t *dst = p.bases.data() + base_at;
+      const unsigned char *src = reinterpret_cast<const unsigned char *>(d + s2);
+      uint8_t all = 0xFF;
       for (size_t i = 0; i < n; ++i) {
-        uint8_t v;
-        switch (d[s2 + i]) {
-          case 'A': case 'a': v = 1; break;
-          case 'C': case 'c': v = 2; break;
-          case 'G': case 'g': v = 3; break;
-          case 'T': case 't': v = 4; break;
-          default: v = 0; valid = false; break;
-        }
-        p.bases[base_at + i] = v;
+        const uint8_t v = kBaseTable.v[src[i]];
+        dst[i] = v;
+        all = v ? all : 0;
       }
+      const bool valid = all != 0;
       if (!valid) p.bases.resize(base_at);  // encode_dna_bases: the whole read is dropped (kept as an empty read)
       p.lens.push_back(valid ? (uint32_t)n : 0u);
       at = e4 < size ? e4 + 1 : size;
     }
     p.stop = at;
   };
-  {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < T; ++t) pool.emplace_back(worker, t);
-    for (auto &th : pool) th.join();
-  }
+  parallel_for(T, worker);
   for (auto &p : parts)
     if (p.bad) return false;
   // the ranges' records must chain into one gap-free prefix of the buffer; what follows it (an incomplete record, or
@@ -290,86 +348,172 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
     n_reads += parts[t].lens.size();
     n_bases += parts[t].bases.size();
   }
-  out.bases.resize(n_bases);
+  out.bases.resize(std::max<size_t>(n_bases, 1));
+  out.bases.n = n_bases;
   out.offsets.resize(n_reads + 1);
-  {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < T; ++t)
-      pool.emplace_back([&, t]() {
-        if (!parts[t].bases.empty()) memcpy(out.bases.data() + b0[t], parts[t].bases.data(), parts[t].bases.size());
-        uint64_t off = b0[t];
-        for (size_t i = 0; i < parts[t].lens.size(); ++i) {
-          out.offsets[r0[t] + i] = off;
-          off += parts[t].lens[i];
-        }
-      });
-    for (auto &th : pool) th.join();
-  }
+  parallel_for(T, [&](unsigned t) {
+    if (!parts[t].bases.empty()) memcpy(out.bases.data() + b0[t], parts[t].bases.data(), parts[t].bases.size());
+    uint64_t off = b0[t];
+    for (size_t i = 0; i < parts[t].lens.size(); ++i) {
+      out.offsets[r0[t] + i] = off;
+      off += parts[t].lens[i];
+    }
+  });
   out.offsets[n_reads] = n_bases;
   return true;
 }
 
-// A whole reads file through the fast path, block by block: plain files are memory-mapped (one block), gzip files are
-// inflated 256 MB at a time by this thread and parsed by all. `sink` receives every block's reads in file order.
+// Two parsed blocks in flight: while the consumer thread hands block i to the engine (seeds, upload, kernels), the
+// caller's thread and the parser threads work on block i + 1. Blocks are consumed in file order.
+struct BlockPipe {
+  ParsedReads slot[2];
+  int state[2] = {0, 0};  // 0 free, 1 filled
+  std::mutex m;
+  std::condition_variable cv;
+  bool closing = false;
+  std::thread consumer;
+  uint64_t produced = 0;
+  explicit BlockPipe(std::function<void(ParsedReads &)> sink) {
+    consumer = std::thread([this, sink]() {
+      for (uint64_t k = 0;; ++k) {
+        ParsedReads *blk;
+        {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return state[k & 1] == 1 || (closing && k >= produced); });
+          if (state[k & 1] != 1) return;
+          blk = &slot[k & 1];
+        }
+        sink(*blk);
+        {
+          std::lock_guard<std::mutex> lk(m);
+          state[k & 1] = 0;
+        }
+        cv.notify_all();
+      }
+    });
+  }
+  ParsedReads &acquire() {  // the slot the next block is parsed into (waits until the consumer is done with it)
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return state[produced & 1] == 0; });
+    return slot[produced & 1];
+  }
+  void submit() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      state[produced & 1] = 1;
+      ++produced;
+    }
+    cv.notify_all();
+  }
+  void finish() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      closing = true;
+    }
+    cv.notify_all();
+    if (consumer.joinable()) consumer.join();
+  }
+  ~BlockPipe() { finish(); }
+};
+
+// A whole reads file through the fast path, block by block (GMX_FASTQ_BLOCK bytes, 96 MB by default): a plain file is
+// read with parallel pread calls, a gzip file is inflated by this thread; every block is parsed by all threads while the
+// engine works on the block before it (BlockPipe). `sink` receives every block's reads in file order, on another thread.
 // Returns false — before anything was delivered — if the file is not plain four-line FASTQ.
 template <class Sink>
 bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   int fd = open(path.c_str(), O_RDONLY);
   if (fd < 0) return false;
   unsigned char magic[2] = {0, 0};
-  const bool gz = read(fd, magic, 2) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
   struct stat sb;
   const bool stat_ok = fstat(fd, &sb) == 0;
-  ParsedReads block;
-  size_t consumed = 0;
-  if (!gz) {
-    if (!stat_ok || sb.st_size == 0) {
-      close(fd);
-      return false;
-    }
-    const size_t size = (size_t)sb.st_size;
-    const char *d = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (d == MAP_FAILED) return false;
-    const bool ok = parse_fastq_buffer(d, size, true, threads, block, consumed);
-    munmap((void *)d, size);
-    if (ok) sink(block);
-    return ok;
-  }
-  close(fd);
-  gzFile g = gzopen(path.c_str(), "rb");
-  if (!g) return false;
-  gzbuffer(g, 1 << 20);
-  size_t kBlock = 256u << 20;
+  size_t kBlock = 96u << 20;
   if (const char *eb = getenv("GMX_FASTQ_BLOCK")) kBlock = std::max<size_t>(64, (size_t)atoll(eb));  // tests: tiny blocks
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
   std::vector<char> buf(kBlock + (1u << 20));
-  size_t have = 0;
+  size_t have = 0, consumed = 0;
   bool first = true;
+  gzFile g = nullptr;
+  size_t file_at = 0;
+  const size_t file_size = stat_ok ? (size_t)sb.st_size : 0;
+  if (gz) {
+    close(fd);
+    fd = -1;
+    g = gzopen(path.c_str(), "rb");
+    if (!g) return false;
+    gzbuffer(g, 1 << 20);
+  } else if (!stat_ok || file_size == 0) {
+    close(fd);
+    return false;
+  }
+  auto shut = [&]() {
+    if (g) gzclose(g);
+    if (fd >= 0) close(fd);
+  };
+  std::unique_ptr<BlockPipe> pipe;  // started with the first good block
   for (;;) {
-    while (have < kBlock) {
-      int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
-      if (got < 0) {  // a damaged or truncated gzip stream must not pass for the end of the reads
-        int err = 0;
-        const char *msg = gzerror(g, &err);
-        die("gram: " + path + ": " + (msg ? msg : "zlib error"));
+    bool final;
+    if (g) {
+      while (have < kBlock) {
+        int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
+        if (got < 0) {  // a damaged or truncated gzip stream must not pass for the end of the reads
+          int err = 0;
+          const char *msg = gzerror(g, &err);
+          die("gram: " + path + ": " + (msg ? msg : "zlib error"));
+        }
+        if (got == 0) break;
+        have += (size_t)got;
       }
-      if (got == 0) break;
-      have += (size_t)got;
+      final = gzeof(g) != 0 || have < kBlock;
+    } else {
+      const size_t want = std::min(kBlock - std::min(kBlock, have), file_size - file_at);
+      std::vector<int> bad(T, 0);
+      parallel_for(T, [&](unsigned t) {  // page cache -> buffer at memory speed
+        size_t lo = want * t / T, hi = want * (t + 1) / T;
+        while (lo < hi) {
+          ssize_t got = pread(fd, buf.data() + have + lo, hi - lo, (off_t)(file_at + lo));
+          if (got <= 0) {
+            bad[t] = 1;
+            return;
+          }
+          lo += (size_t)got;
+        }
+      });
+      for (int b : bad)
+        if (b) die("gram: " + path + ": read error");
+      have += want;
+      file_at += want;
+      final = file_at >= file_size;
     }
-    const bool final = gzeof(g) != 0 || have < kBlock;
+    ParsedReads scratch;
+    ParsedReads &block = pipe ? pipe->acquire() : scratch;
     if (!parse_fastq_buffer(buf.data(), have, final, threads, block, consumed) || (!final && consumed == 0)) {
-      gzclose(g);
-      if (first) return false;
-      die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(kBlock >> 20) +
+      if (first) {
+        shut();
+        return false;
+      }
+      die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(file_at >> 20) +
           " MB (multi-line or blank lines); decompress and reformat, or use a four-line FASTQ");
     }
-    first = false;
-    sink(block);
+    if (first) {  // the file is what this path covers: from here on blocks go through the pipe
+      first = false;
+      pipe.reset(new BlockPipe([&](ParsedReads &b) { sink(b); }));
+      ParsedReads &slot0 = pipe->acquire();
+      std::swap(slot0.bases.p, scratch.bases.p);
+      std::swap(slot0.bases.n, scratch.bases.n);
+      std::swap(slot0.bases.cap, scratch.bases.cap);
+      std::swap(slot0.offsets.p, scratch.offsets.p);
+      std::swap(slot0.offsets.n, scratch.offsets.n);
+      std::swap(slot0.offsets.cap, scratch.offsets.cap);
+    }
+    pipe->submit();
     memmove(buf.data(), buf.data() + consumed, have - consumed);
     have -= consumed;
     if (final) break;
   }
-  gzclose(g);
+  pipe->finish();
+  shut();
   return true;
 }
 
@@ -464,7 +608,11 @@ Args parse_sub(int argc, const char *const *argv, int from) {
 // `gram _parse_check FILE THREADS`: prints what each parser makes of FILE as "<name> <n_reads> <n_bases> <fnv1a>" (or
 // "fast declined"); the two lines must agree whenever the fast path accepts the file.
 int run_parse_check(const std::string &path, int threads) {
-  auto fnv = [](const ParsedReads &p) {
+  struct Flat {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> offsets{0};
+  };
+  auto fnv = [](const Flat &p) {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](uint64_t v) {
       for (int i = 0; i < 8; ++i) {
@@ -476,11 +624,10 @@ int run_parse_check(const std::string &path, int threads) {
     for (auto b : p.bases) mix(b);
     return h;
   };
-  ParsedReads fast, slow;
-  fast.offsets.assign(1, 0);
+  Flat fast, slow;
   auto collect = [&](const ParsedReads &block) {
     const uint64_t base = fast.bases.size();
-    fast.bases.insert(fast.bases.end(), block.bases.begin(), block.bases.end());
+    fast.bases.insert(fast.bases.end(), block.bases.data(), block.bases.data() + block.bases.size());
     for (size_t i = 1; i < block.offsets.size(); ++i) fast.offsets.push_back(base + block.offsets[i]);
   };
   if (parse_fastq_file(path, threads, collect))
@@ -489,7 +636,6 @@ int run_parse_check(const std::string &path, int threads) {
     std::cout << "fast declined" << std::endl;
   SeqReader reader(path);
   SeqRecord rec;
-  slow.offsets.push_back(0);
   while (reader.next(rec)) {
     encode_read(rec.seq, slow.bases);
     slow.offsets.push_back(slow.bases.size());
@@ -615,19 +761,19 @@ int run_genotype(const Args &a) {
   for (auto const &path : reads_paths) {
     // fast path: seeds as the batch loop below draws them (5000 master draws per batch of <= 5000 reads, per file)
     uint64_t in_file = 0;
-    std::vector<uint32_t> file_batch(kBatch), block_seeds;
-    auto sink = [&](const ParsedReads &block) {
+    std::vector<uint32_t> file_batch(kBatch);
+    auto sink = [&](ParsedReads &block) {  // runs on the pipe's consumer thread, block after block in file order
       const uint64_t n = block.offsets.size() - 1;
-      block_seeds.resize(n);
+      block.seeds.resize(std::max<uint64_t>(n, 1));
       for (uint64_t i = 0; i < n; ++i, ++in_file) {
         if (in_file % kBatch == 0)
           for (auto &sd : file_batch) sd = (uint32_t)master();
-        block_seeds[i] = file_batch[in_file % kBatch];
+        block.seeds[i] = file_batch[in_file % kBatch];
       }
-      const uint8_t *base_ptr = block.bases.empty() ? reinterpret_cast<const uint8_t *>("") : block.bases.data();
+      const uint8_t *base_ptr = block.bases.data() ? block.bases.data() : reinterpret_cast<const uint8_t *>("");
       for (uint64_t done = 0; done < n; done += kChunkReads) {
         const uint64_t m = std::min<uint64_t>(kChunkReads, n - done);
-        GMX_CHECK(gmx_group_map_reads_host(grp, base_ptr, block.offsets.data() + done, block_seeds.data() + done, m));
+        GMX_CHECK(gmx_group_map_reads_host(grp, base_ptr, block.offsets.data() + done, block.seeds.data() + done, m));
       }
       total_reads += n;
     };

@@ -146,6 +146,11 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
                        uint64_t n_reads);
 int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                          uint64_t n_reads, uint64_t total_bases, void *hip_stream);
+/* Page-locked host memory for the buffers handed to gmx_map_reads_host: the upload is then one DMA at the PCIe rate
+ * instead of being staged through small pinned chunks by the runtime. Falls back to plain memory without a device (the
+ * parsers also run in tests without one). gmx_host_free takes only pointers gmx_host_alloc returned. */
+void *gmx_host_alloc(uint64_t bytes);
+void gmx_host_free(void *p);
 /* Waits for enqueued work and reports a read that overflowed / errored (GMX_ECAP, GMX_EREF). */
 int gmx_engine_sync(gmx_engine *e);
 
