@@ -631,7 +631,9 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
         bool text_now = run_text && kind == GMX_FAST_TEXT;
         const bool late = !wait_slow && (kind == GMX_FAST_HIT || kind == GMX_FAST_CONVERT) &&
                           gmx_dfs_fast_kind(ln, stop) == GMX_FAST_TEXT;
-        if (__ballot(late)) {
+        const unsigned long long m_late = __ballot(late);
+        GMX_STAT(6, __popcll(m_late));  // text steps taken in the iteration that resolved their marker hit
+        if (m_late) {
           if (late) {
             q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
             uint32_t start;
@@ -650,7 +652,9 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
         const uint32_t k2 = wait_slow || !(kind == GMX_FAST_TEXT || kind == GMX_FAST_HIT || kind == GMX_FAST_WIDE || kind == GMX_FAST_CONVERT)
                                 ? GMX_FAST_NONE
                                 : gmx_dfs_fast_kind(ln, stop);
-        if (__ballot(k2 == GMX_FAST_EMIT || k2 == GMX_FAST_POP)) {
+        const unsigned long long m_tail = __ballot(k2 == GMX_FAST_EMIT || k2 == GMX_FAST_POP);
+        GMX_STAT(9, __popcll(m_tail));
+        if (m_tail) {
           if (k2 == GMX_FAST_EMIT)
             gmx_dfs_emit(ctx, ln);
           else if (k2 == GMX_FAST_POP)
@@ -1510,8 +1514,8 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     if (status != GMX_TASK_MAPPED) return status;
     nf = ctx.n_out;
     if (nf == 0) {
-      // the task's status word stays GMX_TASK_OVERFLOW (counted as a read, in no category, by the tally that runs beside
-      // this stage): its category is added here
+      // the task's status word stays GMX_TASK_OVERFLOW (a read, in no category, for gmx_stats_kernel): its category is
+      // added here
       atomicAdd(&acc.stats[all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? 3 : 2], 1ull);
       o.n_final[task] = 0;
       return GMX_TASK_MAPPED;
@@ -1630,10 +1634,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
   const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
-  // LIST 1 is the batch's last launch and also tallies the read counters: its grid is larger than the blocks that own a
-  // lane of the global scratch; the others go straight to the tally
-  const uint32_t work_blocks = BIG ? acc.n_lanes_big / 64u : gridDim.x;
-  if (BIG && blockIdx.x >= work_blocks) n_mapped = 0;
+  const uint32_t work_blocks = gridDim.x;
   // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
   for (uint32_t m = m_start + threadIdx.x * work_blocks + blockIdx.x; m < n_mapped; m += work_blocks * LANES) {
     uint32_t entry = list[m];
@@ -1678,18 +1679,13 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   }
   if (BIG) {  // this instance is the batch's last search / coverage launch: whichever block finishes last serves the last tier
     __shared__ uint32_t ticket;
-    if (blockIdx.x < work_blocks) {
+    __threadfence();
+    if (threadIdx.x == 0) ticket = atomicAdd(&o.counters[14 * GMX_CNT_STRIDE], 1u);
+    __syncthreads();
+    if (ticket == work_blocks - 1) {
       __threadfence();
-      if (threadIdx.x == 0) ticket = atomicAdd(&o.counters[14 * GMX_CNT_STRIDE], 1u);
-      __syncthreads();
-      if (ticket == work_blocks - 1) {
-        __threadfence();
-        gmx_tail_stage(ix, b, o, g, acc);
-      }
+      gmx_tail_stage(ix, b, o, g, acc);
     }
-    // QuasimapReadsStats: every status word is final by now — the filter passes were waited for, and the last tier
-    // adds the categories of its tasks itself (their words stay GMX_TASK_OVERFLOW: a read, in no category)
-    gmx_stats_tally(acc.status, acc.n_tasks, acc.stats);
   }
 }
 
@@ -2415,9 +2411,11 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>),
-                     dim3(std::max<uint32_t>(e->cover_big_lanes / 64, std::min<uint32_t>(n_tasks / 1024 + 1, 2048u))), dim3(64),
-                     big_lds, stream, e->dview, b, o, e->big, acc);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
+                     b, o, e->big, acc);
+  // (measured: tallying inside the launch above, with a grid large enough for it, took 35 us against 8 + 9 for the two)
+  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks / 4 + GMX_BLOCK) / GMX_BLOCK, 512u)),
+                     dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
     e->pending.push_back(ev);

@@ -238,17 +238,78 @@ struct BaseTable {
 };
 static const BaseTable kBaseTable;
 
-// fn(t) for t = 0 .. T-1 on T threads
+// fn(t) for t = 0 .. T-1 on a pool of waiting threads: a 96 MB block goes through three such phases, and starting 64
+// threads for each of them cost more than the parsing (measured: 88 ms of 160 for 4 M reads)
+class WorkerPool {
+ public:
+  static WorkerPool &get() {
+    static WorkerPool p;
+    return p;
+  }
+  void run(unsigned T, const std::function<void(unsigned)> &fn) {
+    if (T <= 1) {
+      fn(0u);
+      return;
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    while (threads_.size() < T - 1) {
+      const unsigned id = (unsigned)threads_.size() + 1;
+      threads_.emplace_back([this, id]() { loop(id); });
+    }
+    fn_ = &fn;
+    width_ = T;
+    pending_ = T - 1;
+    ++generation_;
+    lk.unlock();
+    cv_.notify_all();
+    fn(0u);
+    lk.lock();
+    done_.wait(lk, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+      ++generation_;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+
+ private:
+  void loop(unsigned id) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(unsigned)> *fn;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        if (id >= width_) continue;
+        fn = fn_;
+      }
+      (*fn)(id);
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        --pending_;
+      }
+      done_.notify_one();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;
+  const std::function<void(unsigned)> *fn_ = nullptr;
+  unsigned width_ = 0, pending_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
 template <class F>
 void parallel_for(unsigned T, F fn) {
-  if (T <= 1) {
-    fn(0u);
-    return;
-  }
-  std::vector<std::thread> pool;
-  pool.reserve(T);
-  for (unsigned t = 0; t < T; ++t) pool.emplace_back(fn, t);
-  for (auto &th : pool) th.join();
+  const std::function<void(unsigned)> f = fn;
+  WorkerPool::get().run(T, f);
 }
 // Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
 // the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
@@ -363,6 +424,13 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
   return true;
 }
 
+// where the feed's wall time goes (printed with the timer report): reading, parsing, and the consumer's engine calls
+struct FeedTimes {
+  double read_s = 0, parse_s = 0, map_s = 0, wait_slot_s = 0;
+};
+static FeedTimes g_feed;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 // Two parsed blocks in flight: while the consumer thread hands block i to the engine (seeds, upload, kernels), the
 // caller's thread and the parser threads work on block i + 1. Blocks are consumed in file order.
 struct BlockPipe {
@@ -383,7 +451,9 @@ struct BlockPipe {
           if (state[k & 1] != 1) return;
           blk = &slot[k & 1];
         }
+        const double t0 = now_s();
         sink(*blk);
+        g_feed.map_s += now_s() - t0;
         {
           std::lock_guard<std::mutex> lk(m);
           state[k & 1] = 0;
@@ -393,8 +463,10 @@ struct BlockPipe {
     });
   }
   ParsedReads &acquire() {  // the slot the next block is parsed into (waits until the consumer is done with it)
+    const double t0 = now_s();
     std::unique_lock<std::mutex> lk(m);
     cv.wait(lk, [&] { return state[produced & 1] == 0; });
+    g_feed.wait_slot_s += now_s() - t0;
     return slot[produced & 1];
   }
   void submit() {
@@ -454,6 +526,7 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   std::unique_ptr<BlockPipe> pipe;  // started with the first good block
   for (;;) {
     bool final;
+    const double t_read = now_s();
     if (g) {
       while (have < kBlock) {
         int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
@@ -486,9 +559,13 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
       file_at += want;
       final = file_at >= file_size;
     }
+    g_feed.read_s += now_s() - t_read;
     ParsedReads scratch;
     ParsedReads &block = pipe ? pipe->acquire() : scratch;
-    if (!parse_fastq_buffer(buf.data(), have, final, threads, block, consumed) || (!final && consumed == 0)) {
+    const double t_parse = now_s();
+    const bool parsed = parse_fastq_buffer(buf.data(), have, final, threads, block, consumed);
+    g_feed.parse_s += now_s() - t_parse;
+    if (!parsed || (!final && consumed == 0)) {
       if (first) {
         shut();
         return false;
@@ -933,7 +1010,9 @@ int run_genotype(const Args &a) {
   std::cout << std::endl
             << "Timer report (wall seconds)" << std::endl
             << "  Load data (index build + upload): " << t_load << std::endl
-            << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl;
+            << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl
+            << "    feed: read " << g_feed.read_s << ", parse " << g_feed.parse_s << ", waiting for a free block " << g_feed.wait_slot_s
+            << "; engine calls (beside the parser) " << g_feed.map_s << std::endl;
   // ---- infer (genotype.cpp:72-118): level genotyping on the host from the coverage just recorded -----------------
   std::cout << "====================" << std::endl << "Running genotyping" << std::endl;
   auto t_inf = clk::now();
