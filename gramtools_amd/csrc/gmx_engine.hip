@@ -176,6 +176,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint32_t sp;
   GmxPathNode *arena;
   uint32_t arena_n;
+  uint32_t arena_stride;  // tasks the table was allocated for (SearchOut::arena_stride)
   uint32_t status;
   GmxFinalState *out;
   uint32_t n_out, out_cap;
@@ -251,6 +252,17 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     ++sp;
     return true;
   }
+  // The first final state of a task stays in registers when it is a text-form one (defer_first: extend kernel, flat
+  // PRG): almost every task ends with exactly that one state and leaves as a compact record, which carries all the
+  // coverage kernel needs — its copy in finals[] would be one scattered store per task that nobody reads. It is written
+  // when a second state arrives (flush_first) or when the task turns out not to be compact (finish_lane).
+  bool defer_first, first_deferred;
+  __device__ __forceinline__ void flush_first() {
+    if (first_deferred) {
+      out[0] = GmxFinalState{first_pos, GMX_TEXT_MARK, first_tvd, first_tvg};
+      first_deferred = false;
+    }
+  }
   __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
     if (parking) return park(lo, hi, tvd, tvg, park_pos, GMX_MODE_STATE);
     if (n_out >= out_cap) return false;
@@ -258,14 +270,25 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
       first_pos = lo;
       first_tvd = tvd;
       first_tvg = tvg;
+      if (defer_first) {
+        first_deferred = true;
+        n_out = 1;
+        return true;
+      }
     }
+    flush_first();
     out[n_out++] = GmxFinalState{lo, hi, tvd, tvg};
     return true;
   }
   __device__ __forceinline__ uint32_t alloc_node(uint32_t site, int32_t allele, uint32_t next) {
     if (arena_n >= GMX_FAST_ARENA) return GMX_NIL;
-    arena[arena_n] = GmxPathNode{site, allele, next};
-    return arena_n++;
+    // node k of a task lives at arena[k * stride], arena = the table's base + task: node k of neighbouring tasks share
+    // cache lines (a wave's 64 first-node stores touch ~24 lines instead of 64), and the handle is the offset itself, so
+    // every reader keeps indexing arena[handle] from the task's base
+    const uint32_t h = arena_n * arena_stride;
+    arena[h] = GmxPathNode{site, allele, next};
+    ++arena_n;
+    return h;
   }
   __device__ __forceinline__ uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
     if (allele == -1) {  // traversing path: a single entered site stays inline in the handle (no node, no load to pop)
@@ -419,10 +442,16 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
 #define GMX_SEEDF_EMPTY 0x40000000u
 #define GMX_SEED_OFF(b) ((b) & 0x3FFFFFFFu)
 #define GMX_SEED_SPLIT_MAX 5u  // a path-less seed state over 2 .. 5 positions is taken apart in the fast pass (stack of 6)
-__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words) {
+// A single path-less state over ONE suffix-array position is stored in text form — a = its PRG position, b =
+// GMX_TEXT_MARK — in the device copies: the search needs no suffix-array look-up to start (one dependent, always-missing
+// fetch per task less: 64 MB of the extend kernel's 390 MB of fabric-side fetch at config[1]).
+__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words, const uint32_t *sa) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const GmxSeed s = seeds[i];
-    if (s.a != GMX_SEED_COMPLEX) continue;
+    if (s.a != GMX_SEED_COMPLEX) {
+      if (s.a == s.b) seeds[i] = GmxSeed{sa[s.a], GMX_TEXT_MARK};
+      continue;
+    }
     const uint32_t *w = seed_words + s.b;
     const uint32_t ns = *w++;
     bool big = ns > 0xFFFFu;
@@ -477,11 +506,7 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
       // a few occurrences (a short repeat): position by position in text form — the same results (see
       // gmx_search_big_kernel), 32 bases per step instead of one rank block per base and 137 iterations of the wave
       for (uint32_t i = s.a; i <= s.b; ++i) ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
-    } else if (s.a == s.b && from > 0) {
-      // one occurrence: text form right away (this look-up is the CONVERT step of the wave loop, done here with every
-      // lane of the wave taking part instead of costing the lane its first iteration)
-      ctx.push(ix.sa[s.a], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
-    } else if (s.a <= s.b) {
+    } else if (s.a <= s.b) {  // (one occurrence: already in text form in the device copy, gmx_seed_mark_kernel)
       ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
     }
     return;
@@ -692,7 +717,7 @@ struct SearchOut {
   uint32_t *status;          // per task
   uint32_t *n_final;         // per task
   GmxFinalState *finals;     // per task x GMX_FAST_STATES
-  GmxPathNode *arena;        // per task x GMX_FAST_ARENA
+  GmxPathNode *arena;        // GMX_FAST_ARENA x arena_stride: node k of task t at [k * arena_stride + t] (FastCtx::alloc_node)
   GmxCoverRec *cover_recs;   // GMX_REGIONS queues x region_cap records of single-instance mapped tasks, by PRG region;
   uint32_t *cover_rec_task;  // their task ids (error reporting); counters [16 + r]
   uint32_t region_cap;       // capacity of one region list
@@ -714,6 +739,7 @@ struct SearchOut {
   uint32_t *huge_list;       // tasks the large-capacity pass could not hold (pools or slots exhausted); counter [11]
   uint32_t *cover_huge_list; // entries whose selection exceeded the largest fixed scratch; counter [15]
   uint32_t *huge_retry;      // last tier: work items its 64-wide round could not finish (run again alone with the whole heap)
+  uint32_t arena_stride;     // tasks the per-task tables were allocated for
   // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
   // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
   // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
@@ -807,6 +833,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       rec.a2 = w3;
     }
   }
+  if (mapped && !compact) ctx.flush_first();  // the general coverage routine reads finals[]
   // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
   // queue and block). Compact mapped tasks are queued by the PRG region they map to: workgroup b of the coverage
   // kernel serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the
@@ -868,12 +895,14 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.sp = 0;
   ctx.arena_n = 0;
   ctx.status = GMX_TASK_MAPPED;
-  ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  ctx.arena = o.arena + task;
+  ctx.arena_stride = o.arena_stride;
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
   ctx.parking = true;
   ctx.park_pos = 0;
+  ctx.defer_first = ctx.first_deferred = false;
   ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
@@ -953,7 +982,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         // a k2-mer with more occurrences than the per-lane stack has entries lies in a repeat: its interval splits at
         // the copies' own sites, the task would overflow the extend kernel after holding its wave up — straight to the
         // large-capacity pass (with the extend kernel's overflow queue)
-        over = sd.a <= sd.b && sd.b - sd.a >= GMX_SEED_SPLIT_MAX;
+        over = sd.a <= sd.b && sd.b != GMX_TEXT_MARK && sd.b - sd.a >= GMX_SEED_SPLIT_MAX;
         alive = sd.a <= sd.b && !over;
       } else {
         // a multi-state entry with a path-less state over many positions (the k2-mer spans a site in one copy of a
@@ -1014,12 +1043,15 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.sp = 0;
   ctx.arena_n = 0;
   ctx.status = GMX_TASK_MAPPED;
-  ctx.arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+  ctx.arena = o.arena + task;
+  ctx.arena_stride = o.arena_stride;
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_FAST_STATES;
   ctx.parking = false;
   ctx.park_pos = 0;
+  ctx.defer_first = !ix.is_nested;  // (on a nested PRG the single-instance kernel may hand a task on to the general one)
+  ctx.first_deferred = false;
   ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
   ReadRegs r;
@@ -1492,7 +1524,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     const uint32_t from = r.len - k;
     load_seed(ix, longer ? ix.seeds2 : ix.seeds, kmer_code(r, from, k), ctx,
               [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-                if (tvd == GMX_NIL && tvg == GMX_NIL && from > 0 && hi > lo) {  // position by position in text form (gmx_search_big_kernel)
+                if (tvd == GMX_NIL && tvg == GMX_NIL && from > 0 && hi > lo && hi != GMX_TEXT_MARK) {  // position by position in text form (gmx_search_big_kernel)
                   bool ok = true;
                   for (uint32_t i = lo; ok; ++i) {
                     ok = ctx.push(ix.sa[i], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
@@ -1537,7 +1569,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
       task = entry;
       nf = o.n_final[task] & 0xFF;
       finals = o.finals + (size_t)task * GMX_FAST_STATES;
-      arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+      arena = o.arena + task;  // handles are offsets from the task's base (FastCtx::alloc_node)
     }
     task_out = task;
     const uint32_t read = task >> 1;
@@ -1651,7 +1683,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       task = entry;
       nf = o.n_final[task] & 0xFF;
       finals = o.finals + (size_t)task * GMX_FAST_STATES;
-      arena = o.arena + (size_t)task * GMX_FAST_ARENA;
+      arena = o.arena + task;  // handles are offsets from the task's base (FastCtx::alloc_node)
     }
     uint32_t read = task >> 1;
     uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
@@ -2167,9 +2199,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       gmx_set_error("the seed tables hold more than 2^30 words of multi-state entries");
       rc = GMX_ECAP;
     } else {
-      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words);
+      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words, v.sa);
       if (h.kmer_size2)
-        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words);
+        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words, v.sa);
       rc |= hipDeviceSynchronize() != hipSuccess;
     }
   }
@@ -2312,8 +2344,8 @@ static void launch_filter(gmx_engine *e, dim3 task_grid, const BatchView &b, con
 static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                         uint64_t n_reads, uint64_t total_bases, hipStream_t stream) {
   if (n_reads == 0) return GMX_OK;
-  if (n_reads > 0x3fffffffull) {
-    gmx_set_error("batch too large");
+  if (n_reads > (0x7fffffffull / GMX_FAST_ARENA) / 2) {  // path-node handles (offsets into the arena table) stay below 2^31
+    gmx_set_error("batch too large: at most 44 M reads per launch (lower gmx_engine_opts.max_batch_reads)");
     return GMX_EINVAL;
   }
   int rc = ensure_batch_capacity(e, n_reads);
@@ -2334,7 +2366,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed,
-              e->d_huge, e->d_cover_huge, e->d_huge_retry};
+              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2)};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters);
