@@ -15,7 +15,7 @@
 //   gmx_filter[_lds]_kernel  all_read_kmers_occur_in_index for tasks without final state (quasimap.cpp:212-225)
 //   gmx_cover_single_kernel  coverage::record::search_states (coverage_common.cpp:179-197) for single-instance tasks
 //   gmx_cover_kernel         the same in general (classes, seeded selection, hull), two scratch sizes
-//   gmx_stats_kernel         QuasimapReadsStats counters (quasimap.hpp:17-24)
+//   (QuasimapReadsStats, quasimap.hpp:17-24, are counted by the kernels that decide each task: SearchOut::stats)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -740,6 +740,9 @@ struct SearchOut {
   uint32_t *cover_huge_list; // entries whose selection exceeded the largest fixed scratch; counter [15]
   uint32_t *huge_retry;      // last tier: work items its 64-wide round could not finish (run again alone with the whole heap)
   uint32_t arena_stride;     // tasks the per-task tables were allocated for
+  unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
+                             // [0] all (pack kernel) [1] skipped (seed / probe kernel) [2] missing_kmer [3] no_extension
+                             // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
   // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
   // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
   // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
@@ -747,6 +750,17 @@ struct SearchOut {
 };
 
 #define GMX_REGIONS 8
+
+// stats[idx] += number of threads of the block with `flag` (one global atomic per block). Every thread of the block
+// must call it. `scratch` is one uint32 of LDS per call site.
+__device__ __forceinline__ void gmx_block_count(unsigned long long *stats, uint32_t idx, bool flag, uint32_t *scratch) {
+  if (threadIdx.x == 0) *scratch = 0;
+  __syncthreads();
+  const unsigned long long m = __ballot(flag);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(scratch, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && *scratch) atomicAdd(&stats[idx], (unsigned long long)*scratch);
+}
 
 __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) {
   uint32_t read = task >> 1;
@@ -774,7 +788,6 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       if (ctx.n_out == 0 && ctx.seed_left == 0)
         dead = true;
       else {
-        o.n_final[task] = ctx.n_out | (ctx.arena_n << 8) | (ctx.seed_left << 16);
         mapped = done;
         alive = !done;
       }
@@ -784,8 +797,11 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       o.error[1] = task;
     }
   }
-  if (active && (mapped || over || status == GMX_TASK_SKIPPED || status == GMX_STATUS_IGNORED || status == GMX_TASK_ERROR))
-    o.status[task] = status;
+  {  // read counters: a skipped read (probe pipeline: the seed kernel counts its own) and every task mapped here
+    __shared__ uint32_t n_skip, n_map;
+    gmx_block_count(o.stats, 1, active && status == GMX_TASK_SKIPPED, &n_skip);
+    gmx_block_count(o.stats, 4, mapped, &n_map);
+  }
   // a mapped task with ONE text-form final state and a short path leaves as a compact record (GmxCoverRec)
   GmxCoverRec rec{0, 0, GMX_NIL, {0, 0, 0}, 0, 0};
   bool compact = mapped && ctx.n_out == 1 && ctx.first_pos != GMX_NIL && read_len < 0x10000u &&
@@ -834,6 +850,9 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     }
   }
   if (mapped && !compact) ctx.flush_first();  // the general coverage routine reads finals[]
+  // the state counts of a task are read by the extend kernel (parked tasks) and by the general coverage routine; a
+  // compact record needs neither (on a nested PRG the single-instance kernel may still hand the task on)
+  if (alive || (mapped && (!compact || ix.is_nested))) o.n_final[task] = ctx.n_out | (ctx.arena_n << 8) | (ctx.seed_left << 16);
   // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
   // queue and block). Compact mapped tasks are queued by the PRG region they map to: workgroup b of the coverage
   // kernel serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the
@@ -963,7 +982,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
   const bool active = task < b.n_reads * 2;
-  bool alive = false, dead = false, over = false;
+  bool alive = false, dead = false, over = false, skipped = false;
   GmxSeed sd{1, 0};
   if (active) {
     const uint32_t read = task >> 1;
@@ -973,7 +992,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     r.rc = (task & 1) != 0;
     r.in_regs = false;
     if (b.forward_only && r.rc) {
-      o.status[task] = GMX_STATUS_IGNORED;
+      // not mapped, not counted
     } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
       const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
       const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
@@ -990,11 +1009,14 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         over = (sd.b & GMX_SEEDF_BIG) != 0;
         alive = !over && !(sd.b & GMX_SEEDF_EMPTY);
       }
-      if (over) o.status[task] = GMX_TASK_OVERFLOW;
       dead = !alive && !over;
     } else {
-      o.status[task] = GMX_TASK_SKIPPED;
+      skipped = true;
     }
+  }
+  {
+    __shared__ uint32_t n_skip;
+    gmx_block_count(o.stats, 1, skipped, &n_skip);
   }
   // block-aggregated appends to the alive and the dead queue
   __shared__ uint32_t cnt[GMX_SEED_THREADS / 64][3];
@@ -1098,10 +1120,16 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
   const uint32_t n_dead = o.counters[(pass ? 12 : 6) * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_dead) return;
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
-  if (slot >= n_dead) return;
-  uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
-  ReadRef r = task_read(b, task);
-  o.status[task] = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+  bool present = false, missing = false;
+  if (slot < n_dead) {
+    uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
+    ReadRef r = task_read(b, task);
+    present = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r);
+    missing = !present;
+  }
+  __shared__ uint32_t n_miss, n_noext;
+  gmx_block_count(o.stats, 2, missing, &n_miss);
+  gmx_block_count(o.stats, 3, present, &n_noext);
 }
 
 // The same with the presence bitmap staged in LDS (k <= 10: 4^k bits <= 128 KB of the CU's 160 KB). The probes
@@ -1146,12 +1174,30 @@ __global__ void __launch_bounds__(GMX_FILTER_LDS_THREADS) gmx_filter_lds_kernel(
   uint4 *dst = reinterpret_cast<uint4 *>(gmx_lds);
   for (uint32_t i = threadIdx.x; i < n_words / 4; i += GMX_FILTER_LDS_THREADS) dst[i] = src[i];
   __syncthreads();
+  uint32_t c_miss = 0, c_noext = 0;
   for (uint32_t slot = blockIdx.x * GMX_FILTER_LDS_THREADS + threadIdx.x; slot < n_dead;
        slot += gridDim.x * GMX_FILTER_LDS_THREADS) {
     uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
     ReadRef r = task_read(b, task);
-    o.status[task] = all_kmers_present_planar(gmx_lds, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
+    if (all_kmers_present_planar(gmx_lds, ix.kmer_size, r))
+      ++c_noext;
+    else
+      ++c_miss;
   }
+  // one atomic per counter and block
+  for (int off = 32; off > 0; off >>= 1) {
+    c_miss += __shfl_down(c_miss, off);
+    c_noext += __shfl_down(c_noext, off);
+  }
+  __shared__ uint32_t tot[2];
+  if (threadIdx.x < 2) tot[threadIdx.x] = 0;
+  __syncthreads();  // (also: every probe of the bitmap in LDS is done)
+  if ((threadIdx.x & 63) == 0) {
+    if (c_miss) atomicAdd(&tot[0], c_miss);
+    if (c_noext) atomicAdd(&tot[1], c_noext);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && tot[threadIdx.x]) atomicAdd(&o.stats[2 + threadIdx.x], (unsigned long long)tot[threadIdx.x]);
 }
 
 struct BigOut {
@@ -1232,7 +1278,8 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
     } else if (atomicCAS(&o.error[0], 0u, status) == 0u) {
       o.error[1] = task;
     }
-    o.status[task] = status;
+    if (status == GMX_TASK_MAPPED || status == GMX_TASK_UNMAPPED || status == GMX_STATUS_MISSING_KMER)
+      atomicAdd(&o.stats[status == GMX_TASK_MAPPED ? 4 : status == GMX_TASK_UNMAPPED ? 3 : 2], 1ull);  // few tasks: one atomic each
     o.n_final[task] = nf;
     g.n_final[slot] = nf;
     g.task_of_slot[slot] = task;
@@ -1340,7 +1387,6 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
     if (!active) continue;
     if (group_bad) {  // one lane's part did not suffice: the whole task again, in one lane with the whole slot
       if (sub == 0) {
-        o.status[task] = GMX_TASK_OVERFLOW;
         o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
         g.n_final[slot] = 0;
         g.task_of_slot[slot] = task;
@@ -1351,7 +1397,7 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
     if (sub != 0) continue;
     uint32_t status = GMX_TASK_MAPPED;
     if (total == 0) status = all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? GMX_TASK_UNMAPPED : GMX_STATUS_MISSING_KMER;
-    o.status[task] = status;
+    atomicAdd(&o.stats[status == GMX_TASK_MAPPED ? 4 : status == GMX_TASK_UNMAPPED ? 3 : 2], 1ull);
     o.n_final[task] = total;
     g.n_final[slot] = total;
     g.task_of_slot[slot] = task;
@@ -1546,8 +1592,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     if (status != GMX_TASK_MAPPED) return status;
     nf = ctx.n_out;
     if (nf == 0) {
-      // the task's status word stays GMX_TASK_OVERFLOW (a read, in no category, for gmx_stats_kernel): its category is
-      // added here
+      // its read counter
       atomicAdd(&acc.stats[all_kmers_present(ix.kmer_bitmap, ix.kmer_size, r) ? 3 : 2], 1ull);
       o.n_final[task] = 0;
       return GMX_TASK_MAPPED;
@@ -1597,7 +1642,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
   env.log_at = 0;
   gmx_cover_task(ix, env, finals, nf, len, b.seeds[task >> 1], acc.rng_mode);
   if (env.status == GMX_TASK_MAPPED && is_search) {
-    atomicAdd(&acc.stats[4], 1ull);  // exact_mapped (the status word stays GMX_TASK_OVERFLOW, see above)
+    atomicAdd(&acc.stats[4], 1ull);  // exact_mapped
     o.n_final[task] = nf;
   }
   return env.status;
@@ -1647,8 +1692,6 @@ constexpr uint32_t gmx_cover_lds_lanes() {
          : GmxScratchFixed<Env>::total * 32 * sizeof(uint32_t) <= 64 * 1024 ? 32u
                                                                        : 16u;
 }
-__device__ void gmx_stats_tally(const uint32_t *status, uint32_t n_tasks, unsigned long long *stats);
-
 template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
                                                               CoverAcc acc) {
@@ -1772,52 +1815,6 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
     o.error[1] = o.cover_rec_task[(size_t)region * o.region_cap + m];
 }
 
-// QuasimapReadsStats (quasimap.hpp:17-24; increments at quasimap.cpp:104,110,173,183,191).
-// Grid-stride over the task statuses, per-thread tallies, one LDS reduction and five atomics per block.
-__device__ void gmx_stats_tally(const uint32_t *status, uint32_t n_tasks, unsigned long long *stats) {
-  __shared__ uint32_t acc[5];
-  if (threadIdx.x < 5) acc[threadIdx.x] = 0;
-  __syncthreads();
-  uint32_t c_all = 0, c_skip = 0, c_miss = 0, c_noext = 0, c_map = 0;
-  auto tally = [&](uint32_t s) {
-    c_all += s != GMX_STATUS_IGNORED;
-    c_skip += s == GMX_TASK_SKIPPED;
-    c_miss += s == GMX_STATUS_MISSING_KMER;
-    c_noext += s == GMX_TASK_UNMAPPED;
-    c_map += s == GMX_TASK_MAPPED;
-  };
-  const uint32_t n_quads = n_tasks / 4;  // the status array is 16-byte aligned
-  const uint4 *quads = reinterpret_cast<const uint4 *>(status);
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_quads; q += gridDim.x * blockDim.x) {
-    const uint4 s = quads[q];
-    tally(s.x);
-    tally(s.y);
-    tally(s.z);
-    tally(s.w);
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n_tasks & 3u)) tally(status[n_quads * 4 + threadIdx.x]);
-  for (int off = 32; off > 0; off >>= 1) {
-    c_all += __shfl_down(c_all, off);
-    c_skip += __shfl_down(c_skip, off);
-    c_miss += __shfl_down(c_miss, off);
-    c_noext += __shfl_down(c_noext, off);
-    c_map += __shfl_down(c_map, off);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&acc[0], c_all);
-    atomicAdd(&acc[1], c_skip);
-    atomicAdd(&acc[2], c_miss);
-    atomicAdd(&acc[3], c_noext);
-    atomicAdd(&acc[4], c_map);
-  }
-  __syncthreads();
-  if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&stats[threadIdx.x], (unsigned long long)acc[threadIdx.x]);
-}
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_stats_kernel(const uint32_t *status, uint32_t n_tasks,
-                                                              unsigned long long *stats) {
-  gmx_stats_tally(status, n_tasks, stats);
-}
-
 // The five uint64 read counters <-> 16-bit limbs in uint32 words, so that they travel inside the one uint32
 // all-reduce(sum) of the coverage block: limb sums of up to 65536 ranks cannot overflow (gmx_coverage_reduce_*).
 __global__ void gmx_stats_limbs_kernel(unsigned long long *stats, uint32_t *limbs, int recombine) {
@@ -1862,12 +1859,16 @@ __device__ __forceinline__ uint2 pack_tail(const uint8_t *p, uint32_t rem, uint3
   }
   return out;
 }
-__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters) {
+__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters,
+                                                                  unsigned long long *stats) {
   __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
   __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
   // the queue counters are per batch: this is the batch's first kernel and everything that counts comes after it
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0) {
     for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_READS) counters[i] = 0;
+    // all_reads_count (quasimap.cpp:104): both orientations of every read, or the one a forward_only engine maps
+    if (threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
+  }
   const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
   const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
   const uint32_t read = r0 + threadIdx.x;
@@ -2366,10 +2367,10 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed,
-              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2)};
+              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2), e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
-                     e->d_skip, e->d_packed, e->d_counters);
+                     e->d_skip, e->d_packed, e->d_counters, e->d_stats);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
@@ -2445,9 +2446,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
                      b, o, e->big, acc);
-  // (measured: tallying inside the launch above, with a grid large enough for it, took 35 us against 8 + 9 for the two)
-  hipLaunchKernelGGL(gmx_stats_kernel, dim3(std::min<uint32_t>((n_tasks / 4 + GMX_BLOCK) / GMX_BLOCK, 512u)),
-                     dim3(GMX_BLOCK), 0, stream, e->d_status, n_tasks, e->d_stats);
+  // (no pass over per-task status words: the read counters are added where each task's fate is decided, SearchOut::stats)
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
     e->pending.push_back(ev);
