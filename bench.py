@@ -39,9 +39,9 @@ READS_PER_GPU = 1_000_000
 B_NOMINAL_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070 B/read at k = 10
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (DESIGN.md §8 derives each term):
-# queue entry 4 + seed directory entry 8 + packed read planes 48 + suffix-array entry of the seed 4 + PRG text records
-# 6 x 16 + marker sub-records 3 x 16 + final state 16 + path nodes 2 x 12 + coverage record 32 + task id 4
-B_DESIGN_PER_READ = 4 + 8 + 48 + 4 + 6 * 16 + 3 * 16 + 16 + 2 * 12 + 32 + 4
+# queue entry 4 + seed directory entry 8 + packed read planes 48 + PRG text records 6 x 16 + marker sub-records 3 x 16 +
+# path nodes 2 x 12 + coverage record 32 + task id 4
+B_DESIGN_PER_READ = 4 + 8 + 48 + 6 * 16 + 3 * 16 + 2 * 12 + 32 + 4
 PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
 
 
@@ -279,7 +279,8 @@ def main():
                          "alg_bytes_model": "text-form states: 16 B of PRG per 32 bases + one 16 B sub-record per marker (DESIGN.md §8)",
                          "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
                          "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
-                         "what_bounds_it": "instruction issue and dependent-fetch latency, not HBM bandwidth (the index is cache resident)",
+                         "what_bounds_it": "the rate of 64-byte transactions behind the XCD L2 (scattered 12-16 byte payloads), not HBM "
+                                           "bandwidth and not instruction issue (DESIGN.md §4)",
                          "issue": {"valu_busy": sq.get("valu_busy"), "active_lane_share": sq.get("active_lane_share"),
                                    "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
                                    "iterations_per_wave": sq.get("iterations_per_wave"),

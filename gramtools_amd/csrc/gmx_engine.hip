@@ -548,6 +548,7 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
 // Debug build only (-DGMX_LOOP_STATS): iteration mix of the wave loop, summed over all kernels using it.
 //   [0] fast iterations  [1] heavy TEXT  [2] heavy HIT  [3] heavy WIDE  [4] light only  [5] slow iterations
 //   [6] lanes served by fast heavy kinds  [7] lanes served by slow iterations  [8] waves  [9] light lanes
+//   [10..12] clocks of prologue / loop / epilogue  [13] lanes holding a state, summed over the fast iterations
 __device__ unsigned long long gmx_loop_stats[48];  // x3: probe, extend, large-capacity kernel
 extern "C" int gmx_debug_loop_stats(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_loop_stats), sizeof(gmx_loop_stats)) != hipSuccess) return -1;
@@ -610,6 +611,7 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
       const bool run_text = n_text && n_text * GMX_KIND_SHARE >= n_heavy, run_hit = n_hit && n_hit * GMX_KIND_SHARE >= n_heavy,
                  run_wide = n_wide && n_wide * GMX_KIND_SHARE >= n_heavy;
       GMX_STAT(0, 1);
+      GMX_STAT(13, __popcll(__ballot(ln.have)));  // lanes that hold a search state in this iteration
       GMX_STAT(1, run_text);
       GMX_STAT(2, run_hit);
       GMX_STAT(3, run_wide);

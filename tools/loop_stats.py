@@ -28,9 +28,9 @@ qm.sync()
 lib.gmx_debug_loop_stats(buf, 1)
 names = ["fast iterations", "heavy TEXT", "heavy HIT", "heavy WIDE", "light only", "slow iterations",
          "lanes in heavy kinds", "lanes in slow iterations", "waves", "lanes in light kinds",
-         "clk prologue", "clk loop", "clk epilogue"]
+         "clk prologue", "clk loop", "clk epilogue", "live lanes (sum over iterations)"]
 for k, kern in enumerate(["probe", "extend", "large-capacity"]):
-    v = np.array(buf[k * 16:k * 16 + 13], dtype=np.float64)
+    v = np.array(buf[k * 16:k * 16 + 14], dtype=np.float64)
     waves = max(v[8], 1)
     print(kern, f"waves={int(v[8])}")
     for n, x in zip(names, v):

@@ -2,7 +2,7 @@
 SIMDs, active-lane share of the wave loop, iterations per wave — the `roofline.issue` object of bench.py.
   valu_busy         = SQ_INSTS_VALU x 4 cycles (a wave64 VALU instruction occupies its SIMD16 for 4 cycles)
                       / (kernel duration x SIMD clock x number of SIMDs)
-  active_lane_share = lane-steps the loop needs (heavy + light kinds served) / (iterations x 64 lanes)"""
+  active_lane_share = lanes holding a search state, summed over the loop's iterations / (iterations x 64 lanes)"""
 import csv
 import json
 import re
@@ -32,7 +32,7 @@ for line in open(f"{d}/loop_stats.txt"):
         if m:
             loop[m.group(1).strip()] = (float(m.group(2)), float(m.group(3)))
 iters = loop["fast iterations"][1] + loop["slow iterations"][1]
-lane_steps = loop["lanes in heavy kinds"][1] + loop["lanes in light kinds"][1] + loop["lanes in slow iterations"][1]
+live = loop.get("live lanes (sum over iterations)", (0.0, 0.0))[1]
 out = {
     "kernel": "gmx_extend_kernel", "avg_duration_ns": dur_ns,
     "valu_insts_per_launch": sq.get("SQ_INSTS_VALU"), "salu_insts_per_launch": sq.get("SQ_INSTS_SALU"),
@@ -41,6 +41,6 @@ out = {
     "valu_busy": sq["SQ_INSTS_VALU"] * 4 / (dur_ns * 1e-9 * CLOCK_HZ * N_SIMD),
     "wait_share_of_wave_cycles": sq.get("SQ_WAIT_ANY", 0) / max(sq.get("SQ_WAVE_CYCLES", 1), 1),
     "iterations_per_wave": iters, "heavy_steps_per_lane": loop["lanes in heavy kinds"][1] / 64,
-    "active_lane_share": lane_steps / (iters * 64),
+    "active_lane_share": live / (loop["fast iterations"][1] * 64),
 }
 print(json.dumps(out, indent=1))
