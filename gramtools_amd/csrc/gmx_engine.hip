@@ -177,6 +177,12 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   GmxPathNode *arena;
   uint32_t arena_n;
   uint32_t arena_stride;  // tasks the table was allocated for (SearchOut::arena_stride)
+  uint32_t arena_first;   // handle of this lane's node 0 (0; instance lanes: their part of the task's slot pool)
+  // Instance lanes (gmx_extend_inst_kernel): one of several lanes searching the same task. Final states go straight into
+  // the task's large-capacity slot, each at a position drawn from the slot's counter.
+  GmxFinalState *inst_states;  // non-null: instance mode
+  uint32_t *inst_count;
+  uint32_t inst_cap;
   uint32_t status;
   GmxFinalState *out;
   uint32_t n_out, out_cap;
@@ -257,14 +263,35 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   // coverage kernel needs — its copy in finals[] would be one scattered store per task that nobody reads. It is written
   // when a second state arrives (flush_first) or when the task turns out not to be compact (finish_lane).
   bool defer_first, first_deferred;
-  __device__ __forceinline__ void flush_first() {
+  __device__ __forceinline__ bool inst_put(const GmxFinalState &st) {
+    const uint32_t at = atomicAdd(inst_count, 1u);
+    if (at >= inst_cap) return false;
+    inst_states[at] = st;
+    return true;
+  }
+  __device__ __forceinline__ bool flush_first() {
     if (first_deferred) {
-      out[0] = GmxFinalState{first_pos, GMX_TEXT_MARK, first_tvd, first_tvg};
       first_deferred = false;
+      const GmxFinalState st{first_pos, GMX_TEXT_MARK, first_tvd, first_tvg};
+      if (inst_states) return inst_put(st);
+      out[0] = st;
     }
+    return true;
   }
   __device__ __forceinline__ bool emit(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
     if (parking) return park(lo, hi, tvd, tvg, park_pos, GMX_MODE_STATE);
+    if (inst_states) {  // the first text-form state waits in registers like everywhere; the others go to the slot at once
+      if (n_out == 0 && hi == GMX_TEXT_MARK) {
+        first_pos = lo;
+        first_tvd = tvd;
+        first_tvg = tvg;
+        first_deferred = true;
+        n_out = 1;
+        return true;
+      }
+      ++n_out;
+      return flush_first() && inst_put(GmxFinalState{lo, hi, tvd, tvg});
+    }
     if (n_out >= out_cap) return false;
     if (n_out == 0 && hi == GMX_TEXT_MARK) {
       first_pos = lo;
@@ -285,7 +312,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     // node k of a task lives at arena[k * stride], arena = the table's base + task: node k of neighbouring tasks share
     // cache lines (a wave's 64 first-node stores touch ~24 lines instead of 64), and the handle is the offset itself, so
     // every reader keeps indexing arena[handle] from the task's base
-    const uint32_t h = arena_n * arena_stride;
+    const uint32_t h = arena_first + arena_n * arena_stride;
     arena[h] = GmxPathNode{site, allele, next};
     ++arena_n;
     return h;
@@ -611,7 +638,10 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
       const bool run_text = n_text && n_text * GMX_KIND_SHARE >= n_heavy, run_hit = n_hit && n_hit * GMX_KIND_SHARE >= n_heavy,
                  run_wide = n_wide && n_wide * GMX_KIND_SHARE >= n_heavy;
       GMX_STAT(0, 1);
-      GMX_STAT(13, __popcll(__ballot(ln.have)));  // lanes that hold a search state in this iteration
+      {
+        const uint32_t n_live = (uint32_t)__popcll(__ballot(ln.have));  // lanes that hold a search state in this iteration
+        GMX_STAT(13, n_live);
+      }
       GMX_STAT(1, run_text);
       GMX_STAT(2, run_hit);
       GMX_STAT(3, run_wide);
@@ -742,6 +772,23 @@ struct SearchOut {
   uint32_t *cover_huge_list; // entries whose selection exceeded the largest fixed scratch; counter [15]
   uint32_t *huge_retry;      // last tier: work items its 64-wide round could not finish (run again alone with the whole heap)
   uint32_t arena_stride;     // tasks the per-task tables were allocated for
+  // Reads in short repeats: a path-less seed over 6 .. 64 suffix-array positions is taken apart into one INSTANCE per
+  // position (gmx_seed_kernel), each searched by a lane of its own like any other task (gmx_extend_inst_kernel); the task
+  // owns a large-capacity slot in which the instances' final states and path nodes meet. Counter [24] = instances.
+  uint32_t *inst_list;       // per instance: slot << 6 | index of the instance within its task
+  uint32_t *inst_sa;         // per instance: suffix-array index of its occurrence
+  uint32_t *inst_remaining;  // per slot: instances still running; bit 31: one of them failed (pools exceeded)
+  uint32_t inst_cap;         // capacity of inst_list / inst_sa
+  uint32_t inst_slots;       // slots available (BigOut::max_slots)
+  uint32_t *slot_n_final, *slot_task;  // BigOut::n_final / task_of_slot
+  uint32_t *inst_mapped_list;          // GMX_ENTRY_INST | slot of the instance-searched tasks with final states; counter [25]
+  // the instances' own pools, dense in the instance index (a task's instances are consecutive): GMX_FAST_ARENA path
+  // nodes and GMX_INST_STATES final states per instance. (In the large-capacity slots — 40 KB apart, gigabytes of address
+  // space — every lane paid TLB misses: an instance lane took ten times as long as a regular one.)
+  GmxPathNode *inst_arena;
+  GmxFinalState *inst_states;
+  uint32_t *inst_first;                // per slot: instance index of the task's first instance
+  uint32_t *inst_remaining_width;      // per slot: number of instances
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
                              // [0] all (pack kernel) [1] skipped (seed / probe kernel) [2] missing_kmer [3] no_extension
                              // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
@@ -918,6 +965,10 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
   ctx.status = GMX_TASK_MAPPED;
   ctx.arena = o.arena + task;
   ctx.arena_stride = o.arena_stride;
+  ctx.arena_first = 0;
+  ctx.inst_states = nullptr;
+  ctx.inst_count = nullptr;
+  ctx.inst_cap = 0;
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_STACK_DEPTH;  // parked entries must fit the extend kernel's stack
@@ -980,6 +1031,12 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 // ends at the look-up (its last k2-mer does not occur in the PRG). This light kernel does only that look-up for
 // every task and queues it as alive or dead; the extend kernel then runs the alive ones from their seed states
 // (SEEDED) — no probe steps, no parking, no second pass over the tasks that die here.
+#define GMX_INST_MAX 64u          // a path-less seed over up to this many positions becomes that many instance lanes
+#define GMX_INST_STATES 2u   // final states an instance may add (per task: its instances x this)
+#define GMX_ENTRY_BIG 0x80000000u   // coverage queue entry: a large-capacity slot
+#define GMX_ENTRY_INST 0xC0000000u  // ... the slot of an instance-searched task (its states and nodes are in the instance pools)
+#define GMX_INST_COMPLEX 0x80000000u  // inst_sa entry: (state index << 8 | occurrence) within a multi-state seed entry
+#define GMX_INST_FLAG 0x80000000u  // overflow_list entry: the task was taken apart into instances (the split search skips it)
 #define GMX_SEED_THREADS 1024  // large blocks: one atomic per block and queue, and the queue counters are contended
 __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
@@ -1038,6 +1095,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     base[threadIdx.x] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
+  uint32_t over_at = 0;
   if (alive || dead || over) {
     const uint32_t c = alive ? 0 : dead ? 1 : 2;
     uint32_t before = 0;
@@ -1049,9 +1107,176 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     } else if (dead) {
       o.dead_list[at] = task;
     } else {
-      o.overflow_list[at] = task;  // served beside the extend kernel (large-capacity pass 0)
+      over_at = at;
     }
   }
+  // Instances of the tasks sent to the large-capacity pass whose seed is one path-less interval of at most 64 positions:
+  // block-wide exclusive scan of the instance counts, one atomic per block for the instance list.
+  uint32_t width = 0;  // instances the task splits into (0: not this way)
+  if (over && sd.a != GMX_SEED_COMPLEX) {
+    width = sd.b - sd.a + 1u;
+  } else if (over) {  // multi-state entry: one instance per occurrence of its path-less states, one per path-bearing state
+    const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+    const uint32_t ns = *w++;
+    bool fits = ns <= GMX_INST_MAX;
+    for (uint32_t q = 0; q < ns && fits; ++q) {
+      const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
+      fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * w[2] + w[3] + 2 <= GMX_FAST_ARENA;
+      width += n_q;
+      w += 4 + 2 * w[2] + w[3];
+    }
+    if (!fits) width = 0;
+  }
+  bool expand = over && width != 0 && width <= GMX_INST_MAX && over_at < o.inst_slots;
+  {
+    __shared__ uint32_t wsum[GMX_SEED_THREADS / 64];
+    __shared__ uint32_t inst_base;
+    uint32_t incl = expand ? width : 0u;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(incl, d);
+      if ((int)lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) {
+        const uint32_t t = wsum[w];
+        wsum[w] = total;
+        total += t;
+      }
+      uint32_t got = total ? atomicAdd(&o.counters[24 * GMX_CNT_STRIDE], total) : 0u;
+      if (got + total > o.inst_cap) {  // no room: this block's tasks stay with the split search
+        if (total) atomicSub(&o.counters[24 * GMX_CNT_STRIDE], total);
+        got = 0xFFFFFFFFu;
+      }
+      inst_base = got;
+    }
+    __syncthreads();
+    if (inst_base == 0xFFFFFFFFu) expand = false;
+    if (expand) {
+      const uint32_t first = inst_base + wsum[wave] + incl - width;
+      if (sd.a != GMX_SEED_COMPLEX) {
+        for (uint32_t j = 0; j < width; ++j) {
+          o.inst_list[first + j] = (over_at << 6) | j;
+          o.inst_sa[first + j] = sd.a + j;
+        }
+      } else {
+        const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+        const uint32_t ns = *w++;
+        uint32_t j = 0;
+        for (uint32_t q = 0; q < ns; ++q) {
+          const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
+          for (uint32_t i = 0; i < n_q; ++i, ++j) {
+            o.inst_list[first + j] = (over_at << 6) | j;
+            o.inst_sa[first + j] = GMX_INST_COMPLEX | (q << 8) | i;
+          }
+          w += 4 + 2 * w[2] + w[3];
+        }
+      }
+      o.inst_remaining[over_at] = width;
+      o.inst_remaining_width[over_at] = width;
+      o.inst_first[over_at] = first;
+      o.slot_n_final[over_at] = 0;
+      o.slot_task[over_at] = task;
+    }
+  }
+  if (over) o.overflow_list[over_at] = task | (expand ? GMX_INST_FLAG : 0u);  // unflagged: the split search serves it
+}
+
+// One lane per instance (above): the search of gmx_extend_kernel for ONE text-form seed state, with the path nodes in the
+// instance's part of the task's slot and the final states in the slot's array. The lane that finishes a task's last
+// instance queues the task for the coverage instance of the large-capacity pass — or, if one of them ran out of its
+// part, for the one-lane large-capacity search, which redoes the whole task.
+struct InstPools {  // (unused members kept out: the pools are SearchOut::inst_arena / inst_states)
+  uint32_t reserved;
+};
+// (A kernel of its own: run by the idle half of gmx_extend_kernel's grid it cost that kernel 18 VGPRs — a wave per SIMD,
+// 3 % of the repeat-free headline.) Block `first` of `n_blocks`.
+__device__ void gmx_inst_rounds(const GmxIndexView &ix, const BatchView &b, const SearchOut &o, const InstPools &pools, uint32_t first,
+                                uint32_t n_blocks) {
+  (void)pools;
+  const uint32_t n_inst = min(o.counters[24 * GMX_CNT_STRIDE], o.inst_cap);
+  for (uint32_t base = first * GMX_BLOCK; base < n_inst; base += n_blocks * GMX_BLOCK) {
+    const uint32_t idx = base + threadIdx.x;
+    const bool active = idx < n_inst;
+    const uint32_t entry = active ? o.inst_list[idx] : 0u;
+    const uint32_t slot = entry >> 6, j = entry & 63u;
+    const uint32_t task = active ? o.slot_task[slot] : 0u;
+    const uint32_t first = active ? o.inst_first[slot] : 0u;  // == idx - j
+    FastCtx ctx;
+    ctx.sp = 0;
+    ctx.arena_n = 0;
+    ctx.status = GMX_TASK_MAPPED;
+    ctx.arena = o.inst_arena + (size_t)first * GMX_FAST_ARENA;  // the task's base: handles are j * GMX_FAST_ARENA + n
+    ctx.arena_stride = 1;
+    ctx.arena_first = j * GMX_FAST_ARENA;
+    ctx.out = nullptr;
+    ctx.n_out = 0;
+    ctx.out_cap = 0;
+    ctx.parking = false;
+    ctx.park_pos = 0;
+    ctx.defer_first = true;
+    ctx.first_deferred = false;
+    ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
+    ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
+    ctx.inst_states = o.inst_states + (size_t)first * GMX_INST_STATES;
+    ctx.inst_count = o.slot_n_final + slot;
+    ctx.inst_cap = active ? (o.inst_remaining_width[slot] * GMX_INST_STATES) : 0u;
+    ReadRegs r;
+    r.clear(b.packed);
+    if (active) {
+      task_read_regs(b, task, r);
+      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+      const uint32_t what = o.inst_sa[idx];
+      if (!(what & GMX_INST_COMPLEX)) {  // occurrence `what` of a path-less seed interval
+        ctx.push(ix.sa[what], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
+      } else {  // state (what >> 8) of a multi-state seed entry; occurrence (what & 255) of it when it is path-less
+        const GmxSeed sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
+        const uint32_t *p = ix.seed_words + GMX_SEED_OFF(sd.b) + 1;
+        for (uint32_t st = (what >> 8) & 0x7FFFFFu; st > 0; --st) p += 4 + 2 * p[2] + p[3];
+        const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+        p += 4;
+        if (nt == 0 && ng == 0) {
+          ctx.push(ix.sa[lo + (what & 255u)], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
+        } else {
+          uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
+          bool ok = true;
+          for (uint32_t q = 0; q < nt && ok; ++q, p += 2) ok = (tvd = ctx.arena_new(p[0], (int32_t)p[1], tvd)) != GMX_NIL;
+          for (uint32_t q = 0; q < ng && ok; ++q, ++p) ok = (tvg = ctx.arena_new(p[0], -1, tvg)) != GMX_NIL;
+          if (!ok || !ctx.push(lo, hi, tvd, tvg, r.len - k, GMX_MODE_STATE)) ctx.fail(GMX_TASK_OVERFLOW);
+        }
+      }
+    }
+    GmxLane ln;
+    dfs_run_wave<1, false>(ix, ctx, r, 0, active && ctx.status == GMX_TASK_MAPPED, 0, ln, true);
+    if (!active) continue;
+    bool failed = ctx.status != GMX_TASK_MAPPED;
+    if (!failed && !ctx.flush_first()) failed = true;
+    if (ctx.status == GMX_TASK_ERROR && atomicCAS(&o.error[0], 0u, (uint32_t)GMX_TASK_ERROR) == 0u) o.error[1] = task;
+    // (no fence: nobody reads the instances' states or nodes before this kernel ends; the counters are device-scope
+    // atomics. A release fence per wave here wrote back the XCD's L2 over and over and slowed every kernel beside it.)
+    if (failed) atomicOr(&o.inst_remaining[slot], 0x80000000u);
+    const uint32_t before = atomicSub(&o.inst_remaining[slot], 1u);
+    if ((before & 0x7FFFFFFFu) != 1u) continue;  // the task's last instance goes on
+    if ((before >> 31) || failed) {
+      if (ctx.status != GMX_TASK_ERROR) o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
+      continue;
+    }
+    const uint32_t total = atomicAdd(&o.slot_n_final[slot], 0u);
+    if (total > 0) {
+      atomicAdd(&o.stats[4], 1ull);
+      o.inst_mapped_list[atomicAdd(&o.counters[25 * GMX_CNT_STRIDE], 1u)] = GMX_ENTRY_INST | slot;
+    } else {
+      ReadRef rr = task_read(b, task);
+      atomicAdd(&o.stats[all_kmers_present(ix.kmer_bitmap, ix.kmer_size, rr) ? 3 : 2], 1ull);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_inst_kernel(GmxIndexView ix, BatchView b, SearchOut o, InstPools pools) {
+  gmx_inst_rounds(ix, b, o, pools, blockIdx.x, gridDim.x);
 }
 
 template <bool CURSOR, bool SEEDED>
@@ -1069,6 +1294,10 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, 
   ctx.status = GMX_TASK_MAPPED;
   ctx.arena = o.arena + task;
   ctx.arena_stride = o.arena_stride;
+  ctx.arena_first = 0;
+  ctx.inst_states = nullptr;
+  ctx.inst_count = nullptr;
+  ctx.inst_cap = 0;
   ctx.out = o.finals + (size_t)task * GMX_FAST_STATES;
   ctx.n_out = 0;
   ctx.out_cap = GMX_FAST_STATES;
@@ -1309,7 +1538,11 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
   for (uint32_t base = 0; base < n_over; base += per_round) {
     const uint32_t qi = base + group * gridDim.x + blockIdx.x;  // interleaved over the blocks
     bool active = qi < n_over;
-    const uint32_t task = active ? o.overflow_list[qi] : 0;
+    uint32_t task = active ? o.overflow_list[qi] : 0;
+    if (task & GMX_INST_FLAG) {  // searched by instance lanes (gmx_extend_inst_kernel)
+      active = false;
+      task = 0;
+    }
     const uint32_t slot = qi;
     if (active && slot >= g.max_slots) {
       if (sub == 0) o.huge_list[atomicAdd(&o.counters[11 * GMX_CNT_STRIDE], 1u)] = task;
@@ -1517,6 +1750,36 @@ typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping
 // task before all of its capacity checks have passed, so redoing is safe. A task that does not fit the whole heap is
 // reported (GMX_ECAP: raise huge_heap_bytes). Common batches have no work item and pay one counter read.
 // ---------------------------------------------------------------------------
+// What a coverage queue entry stands for: a task finished by the fast pass (its id), a large-capacity slot, or the slot
+// of an instance-searched task.
+struct GmxTaskStates {
+  uint32_t task, nf;
+  const GmxFinalState *finals;
+  const GmxPathNode *arena;
+};
+__device__ __forceinline__ GmxTaskStates gmx_entry_states(uint32_t entry, const SearchOut &o, const BigOut &g) {
+  GmxTaskStates t;
+  if ((entry & GMX_ENTRY_INST) == GMX_ENTRY_INST) {
+    const uint32_t slot = entry & 0x3fffffffu, first = o.inst_first[slot];
+    t.task = o.slot_task[slot];
+    t.nf = o.slot_n_final[slot];
+    t.finals = o.inst_states + (size_t)first * GMX_INST_STATES;
+    t.arena = o.inst_arena + (size_t)first * GMX_FAST_ARENA;
+  } else if (entry & GMX_ENTRY_BIG) {
+    const uint32_t slot = entry & 0x7fffffffu;
+    t.task = g.task_of_slot[slot];
+    t.nf = g.n_final[slot];
+    t.finals = g.states + (size_t)slot * g.max_states;
+    t.arena = g.arena + (size_t)slot * g.max_path_nodes;
+  } else {
+    t.task = entry;
+    t.nf = o.n_final[entry] & 0xFF;
+    t.finals = o.finals + (size_t)entry * GMX_FAST_STATES;
+    t.arena = o.arena + entry;  // handles are offsets from the task's base (FastCtx::alloc_node)
+  }
+  return t;
+}
+
 __device__ uint32_t gmx_count_items(const GmxIndexView &ix, const GmxFinalState *finals, uint32_t nf) {
   uint32_t n = 0;
   for (uint32_t f = 0; f < nf; ++f) {
@@ -1605,19 +1868,11 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     scratch_words = slice_words - 15 * S;
     len = r.len;
   } else {
-    const uint32_t entry = o.cover_huge_list[item - n_search];
-    if (entry & 0x80000000u) {
-      const uint32_t slot = entry & 0x7fffffffu;
-      task = g.task_of_slot[slot];
-      nf = g.n_final[slot];
-      finals = g.states + (size_t)slot * g.max_states;
-      arena = g.arena + (size_t)slot * g.max_path_nodes;
-    } else {
-      task = entry;
-      nf = o.n_final[task] & 0xFF;
-      finals = o.finals + (size_t)task * GMX_FAST_STATES;
-      arena = o.arena + task;  // handles are offsets from the task's base (FastCtx::alloc_node)
-    }
+    const GmxTaskStates ts = gmx_entry_states(o.cover_huge_list[item - n_search], o, g);
+    task = ts.task;
+    nf = ts.nf;
+    finals = ts.finals;
+    arena = ts.arena;
     task_out = task;
     const uint32_t read = task >> 1;
     len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
@@ -1702,11 +1957,12 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   constexpr uint32_t LANES = LDS ? gmx_cover_lds_lanes<Env>() : 64u;  // active lanes of a block (blockDim.x is 64)
   // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
   // in counter [10], 2 starts there
-  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : 7) * GMX_CNT_STRIDE];
+  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : LIST == 5 ? 25 : 7) * GMX_CNT_STRIDE];
   const uint32_t m_start = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
   const uint32_t *list = LIST == 3   ? o.cover_general_list
                          : LIST == 0 ? o.cover_mid_list
                          : LIST == 1 ? o.cover_overflow_list
+                         : LIST == 5 ? o.inst_mapped_list
                                      : o.big_mapped_list;
   if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
@@ -1718,17 +1974,12 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     uint32_t task, nf;
     const GmxFinalState *finals;
     const GmxPathNode *arena;
-    if (entry & 0x80000000u) {
-      uint32_t slot = entry & 0x7fffffffu;
-      task = g.task_of_slot[slot];
-      nf = g.n_final[slot];
-      finals = g.states + (size_t)slot * g.max_states;
-      arena = g.arena + (size_t)slot * g.max_path_nodes;
-    } else {
-      task = entry;
-      nf = o.n_final[task] & 0xFF;
-      finals = o.finals + (size_t)task * GMX_FAST_STATES;
-      arena = o.arena + task;  // handles are offsets from the task's base (FastCtx::alloc_node)
+    {
+      const GmxTaskStates ts = gmx_entry_states(entry, o, g);
+      task = ts.task;
+      nf = ts.nf;
+      finals = ts.finals;
+      arena = ts.arena;
     }
     uint32_t read = task >> 1;
     uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
@@ -1995,6 +2246,11 @@ struct gmx_engine {
   uint32_t cover_big_lanes = 0;
   uint32_t *d_big_mapped = nullptr, *d_cover_general = nullptr, *d_cover_mid = nullptr, *d_overflow2 = nullptr;
   uint32_t *d_huge = nullptr, *d_cover_huge = nullptr, *d_huge_retry = nullptr;  // the last tier's queues (gmx_tail_stage)
+  uint32_t *d_inst_list = nullptr, *d_inst_sa = nullptr, *d_inst_remaining = nullptr, *d_inst_mapped = nullptr;  // instance lanes (gmx_extend_inst_kernel)
+  uint32_t inst_cap = 0;
+  GmxPathNode *d_inst_arena = nullptr;
+  GmxFinalState *d_inst_states = nullptr;
+  uint32_t *d_inst_first = nullptr, *d_inst_width = nullptr;
   uint32_t *d_heap = nullptr;      // ... and its memory
   uint64_t heap_words = 0;
   bool log_sites = false;          // the index has sites with more than 5 alleles
@@ -2143,6 +2399,15 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->big.n_final, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->big.task_of_slot, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_big_mapped, e->big.max_slots, false))) return rc;
+  e->inst_cap = (uint32_t)std::min<uint64_t>(n_tasks, 1u << 23);  // instance lanes of reads in short repeats (320 B of pools each)
+  if ((rc = e->alloc(&e->d_inst_list, e->inst_cap, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_sa, e->inst_cap, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_remaining, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_mapped, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_first, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_width, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_arena, (size_t)e->inst_cap * GMX_FAST_ARENA, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_states, (size_t)e->inst_cap * GMX_INST_STATES, false))) return rc;
   e->cap_reads = cap;
   return GMX_OK;
 }
@@ -2369,7 +2634,11 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
               e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed,
-              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2), e->d_stats};
+              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2),
+              e->d_inst_list, e->d_inst_sa, e->d_inst_remaining, e->inst_cap,
+              !getenv("GMX_NO_INST") ? e->big.max_slots : 0u,
+              e->big.n_final, e->big.task_of_slot, e->d_inst_mapped, e->d_inst_arena, e->d_inst_states, e->d_inst_first, e->d_inst_width,
+              e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters, e->d_stats);
@@ -2403,6 +2672,12 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
                e->log_sites ? 1u : 0u, e->d_heap, e->heap_words, e->d_status, (uint32_t)n_reads * 2u, e->d_stats};
   if (seeded) {  // what gmx_seed_kernel sent to the large-capacity pass (reads in repeats), and its coverage: on side 2
     HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork, 0));
+    const InstPools pools{0};
+    // one lane per mapping instance of the reads in short repeats, then their coverage. (On a stream of its own this pair
+    // gained nothing: the runtime then put two of the four streams on one hardware queue, and filter and extend kernel
+    // ran one after the other.)
+    hipLaunchKernelGGL(gmx_extend_inst_kernel, dim3(e->n_cus * 2), dim3(GMX_BLOCK), lds, e->side2_stream, e->dview, b, o, pools);
+    launch_cover_lds<CoverEnvMid, 5>(e, e->side2_stream, b, o, acc);
     hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
@@ -2429,13 +2704,15 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
   // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
   const bool general_on_side = !e->dview.is_nested;
-  if (general_on_side) {
-    launch_cover_lds<CoverEnvLds, 3>(e, e->side2_stream, b, o, acc);
-    launch_cover_lds<CoverEnv, 0>(e, e->side2_stream, b, o, acc);
-  }
   HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
-  // second filter pass: the tasks the extend kernel found dead, beside the coverage kernels
+  // side 1: the general instances of the regular tasks (not behind the large-capacity pass's chain of few-lane kernels:
+  // with reads in repeats that chain is the longest path of the batch), then the second filter pass: the tasks the
+  // extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
+  if (general_on_side) {
+    launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc);
+    launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);
+  }
   launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
@@ -2696,6 +2973,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->cover_mid = c(13);
   out->cover_overflow = c(4);
   out->seed_cursor = e->seed_cursor ? 1 : 0;
+  out->inst_mapped = c(25);
   out->huge_search = c(11);
   out->huge_cover = c(15);
   return GMX_OK;

@@ -180,6 +180,7 @@ typedef struct gmx_queue_counts {
   uint64_t cover_overflow;    /* ... and those (large-capacity tasks included) that needed the large scratch */
   uint64_t seed_cursor;       /* 1: the engine runs the seed-cursor kernels (index with many multi-state k-mer entries) */
   uint64_t huge_search;       /* tasks searched again by the last tier (pools carved from the heap) */
+  uint64_t inst_mapped;       /* tasks of reads in short repeats searched as one lane per mapping instance */
   uint64_t huge_cover;        /* tasks whose selection scratch the last tier sized from the heap */
 } gmx_queue_counts;
 int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out);

@@ -13,6 +13,17 @@ from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads, sn
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 ref = random_ref(bench.GENOME, 1)
+if len(sys.argv) > 2:  # fraction of the genome replaced by 10 copies each of 1-5 kb segments
+    rng = np.random.default_rng(5)
+    budget = int(ref.size * float(sys.argv[2]))
+    while budget > 0:
+        seg = int(rng.integers(1000, 5001))
+        src = int(rng.integers(0, ref.size - seg))
+        piece = ref[src:src + seg].copy()
+        for _ in range(10):
+            dst = int(rng.integers(0, ref.size - seg))
+            ref[dst:dst + seg] = piece
+        budget -= 10 * seg
 prg, pos, alts, n_alts = snp_prg(ref, bench.N_SITES, 2)
 ix = Index(prg, bench.KMER)
 reads = simulate_snp_reads(ref, pos, alts, n_alts, n, bench.READ_LEN, 1000)
@@ -25,6 +36,7 @@ lib.gmx_debug_loop_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 48)()
 qm.map_reads(reads.reshape(-1), offsets, seeds)
 qm.sync()
+print("queues:", qm.queue_counts())
 lib.gmx_debug_loop_stats(buf, 1)
 names = ["fast iterations", "heavy TEXT", "heavy HIT", "heavy WIDE", "light only", "slow iterations",
          "lanes in heavy kinds", "lanes in slow iterations", "waves", "lanes in light kinds",
