@@ -102,6 +102,10 @@ GMX_HD bool gmx_uniform_1_to_n(uint32_t seed, uint32_t n, int mode, uint32_t &re
 // ---------------------------------------------------------------------------
 // scratch layout (words)
 // ---------------------------------------------------------------------------
+#ifndef GMX_COVER_PROF
+#define GMX_COVER_PROF(env, k) do { } while (0)
+#endif
+#define GMX_PATH_CACHE 8u  // (site, allele) pairs of an item's traversed list kept in scratch (gmx_item_loci)
 template <class Env>
 struct GmxScratch {
   // item i: lo, hi, tvd, tvg, enc_site, enc_allele
@@ -111,11 +115,12 @@ struct GmxScratch {
   GMX_HD static uint32_t keys(const Env &e) { return order(e) + e.i_max(); }                  // per item: len, b_max sites
   GMX_HD static uint32_t loci(const Env &e) { return keys(e) + e.i_max() * (1 + e.b_max()); }  // (site, allele)
   GMX_HD static uint32_t hull(const Env &e) { return loci(e) + e.loc_max() * 2; }             // (node, start, end)
-  GMX_HD static uint32_t total_of(const Env &e) { return hull(e) + e.h_max() * 3; }
+  GMX_HD static uint32_t path(const Env &e) { return hull(e) + e.h_max() * 3; }              // copy of an item's traversed list
+  GMX_HD static uint32_t total_of(const Env &e) { return path(e) + 2 * GMX_PATH_CACHE; }
 };
 template <class Env>
 struct GmxScratchFixed {  // the fixed tiers: Env::I_MAX .. are compile-time constants
-  static constexpr uint32_t total = Env::I_MAX * (GmxScratch<Env>::ITEM_W + 1) + Env::I_MAX * (1 + Env::B_MAX) + Env::LOC_MAX * 2 + Env::H_MAX * 3;
+  static constexpr uint32_t total = Env::I_MAX * (GmxScratch<Env>::ITEM_W + 1) + Env::I_MAX * (1 + Env::B_MAX) + Env::LOC_MAX * 2 + Env::H_MAX * 3 + 2 * GMX_PATH_CACHE;
 };
 
 GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
@@ -159,6 +164,7 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     for (;;) {
       if (window_used(site)) return true;
       if (!window_add(site, allele)) return false;
+      if (!ix.is_nested) return true;  // every site is a level-0 site
       const GmxSite &s = ix.sites[(site - 5) >> 1];
       if (s.parent_site == 0) return true;
       allele = s.parent_allele;
@@ -168,19 +174,53 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
   if (enc_site != 0) {
     if (!nested(enc_site, enc_allele)) return 0xFFFFFFFFu;
   } else {
-    // check_site_uniqueness over traversed + traversing
+    // The traversed list is copied to scratch once (newest first, up to GMX_PATH_CACHE entries): every handle step is a
+    // dependent load from the arena, and the checks and the oldest-first pass below would repeat them many times over.
+    // Longer lists are walked by handle.
+    const uint32_t pc = S::path(env);
+    uint32_t nt = 0;
+    bool cached = true;
     for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
-      uint32_t sx = env.h_site(x);
-      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
-        if (env.h_site(y) == sx) {
-          env.fail(GMX_TASK_ERROR);
-          return 0xFFFFFFFFu;
-        }
-      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
-        if (env.h_site(y) == sx) {
-          env.fail(GMX_TASK_ERROR);
-          return 0xFFFFFFFFu;
-        }
+      if (nt == GMX_PATH_CACHE) {
+        cached = false;
+        break;
+      }
+      env.sset(pc + 2 * nt, env.h_site(x));
+      env.sset(pc + 2 * nt + 1, (uint32_t)env.h_allele(x));
+      ++nt;
+    }
+    // check_site_uniqueness over traversed + traversing
+    if (cached) {
+      for (uint32_t i = 0; i < nt; ++i) {
+        const uint32_t sx = env.sget(pc + 2 * i);
+        for (uint32_t j = i + 1; j < nt; ++j)
+          if (env.sget(pc + 2 * j) == sx) {
+            env.fail(GMX_TASK_ERROR);
+            return 0xFFFFFFFFu;
+          }
+      }
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y)) {
+        const uint32_t sy = env.h_site(y);
+        for (uint32_t i = 0; i < nt; ++i)
+          if (env.sget(pc + 2 * i) == sy) {
+            env.fail(GMX_TASK_ERROR);
+            return 0xFFFFFFFFu;
+          }
+      }
+    } else {
+      for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
+        uint32_t sx = env.h_site(x);
+        for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+          if (env.h_site(y) == sx) {
+            env.fail(GMX_TASK_ERROR);
+            return 0xFFFFFFFFu;
+          }
+        for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
+          if (env.h_site(y) == sx) {
+            env.fail(GMX_TASK_ERROR);
+            return 0xFFFFFFFFu;
+          }
+      }
     }
     for (uint32_t x = tvg; x != GMX_NIL; x = env.h_next(x)) {
       uint32_t sx = env.h_site(x);
@@ -201,17 +241,23 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
       }
       // assign_nested_locus(new_locus): the seed site itself is not yet in used_sites (unique_loci and
       // used_sites are separate sets in the reference), so the walk continues with its parent chain.
-      const GmxSite &ps = ix.sites[(parent_seed - 5) >> 1];
-      if (ps.parent_site != 0 && !nested(ps.parent_site, ps.parent_allele)) return 0xFFFFFFFFu;
+      if (ix.is_nested) {
+        const GmxSite &ps = ix.sites[(parent_seed - 5) >> 1];
+        if (ps.parent_site != 0 && !nested(ps.parent_site, ps.parent_allele)) return 0xFFFFFFFFu;
+      }
     }
     // assign_traversed_loci (:78-83): push order = oldest first; the list head is the newest.
-    // Process oldest-first by walking to each depth (paths are short).
-    uint32_t len = 0;
-    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) ++len;
-    for (uint32_t d = len; d-- > 0;) {
-      uint32_t x = tvd;
-      for (uint32_t s = 0; s < d; ++s) x = env.h_next(x);
-      if (!nested(env.h_site(x), env.h_allele(x))) return 0xFFFFFFFFu;
+    if (cached) {
+      for (uint32_t d = nt; d-- > 0;)
+        if (!nested(env.sget(pc + 2 * d), (int32_t)env.sget(pc + 2 * d + 1))) return 0xFFFFFFFFu;
+    } else {  // by walking to each depth
+      uint32_t len = 0;
+      for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) ++len;
+      for (uint32_t d = len; d-- > 0;) {
+        uint32_t x = tvd;
+        for (uint32_t s = 0; s < d; ++s) x = env.h_next(x);
+        if (!nested(env.h_site(x), env.h_allele(x))) return 0xFFFFFFFFu;
+      }
     }
   }
   return n;
@@ -225,7 +271,7 @@ GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t
   uint32_t len = 0;
   for (uint32_t i = first; i < n; ++i) {
     uint32_t site = env.sget(S::loci(env) + 2 * i);
-    if (ix.sites[(site - 5) >> 1].parent_site != 0) continue;
+    if (ix.is_nested && ix.sites[(site - 5) >> 1].parent_site != 0) continue;
     // insertion sort, distinct
     uint32_t pos = 0;
     bool dup = false;
@@ -681,6 +727,116 @@ GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxF
   return true;
 }
 
+// One member item of the chosen class: its loci merged into the class's set [0, n_loci) (a set union: the order of the
+// members does not matter), its per-base hull into [0, n_hull). False: a capacity was exceeded or an error found
+// (env.status), nothing recorded.
+template <class Env>
+GMX_HD bool gmx_class_add_item(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t read_len, uint32_t &n_loci, uint32_t &n_hull) {
+  typedef GmxScratch<Env> S;
+  uint32_t first = n_loci;
+  uint32_t n = gmx_item_loci(ix, env, it, first);
+  if (n == 0xFFFFFFFFu) return false;
+  // merge window [first, n) into [0, first): drop duplicates
+  uint32_t w = first;
+  for (uint32_t i = first; i < n; ++i) {
+    uint32_t site = env.sget(S::loci(env) + 2 * i), al = env.sget(S::loci(env) + 2 * i + 1);
+    bool dup = false;
+    for (uint32_t j = 0; j < first && !dup; ++j)
+      dup = env.sget(S::loci(env) + 2 * j) == site && env.sget(S::loci(env) + 2 * j + 1) == al;
+    if (dup) continue;
+    env.sset(S::loci(env) + 2 * w, site);
+    env.sset(S::loci(env) + 2 * w + 1, al);
+    ++w;
+  }
+  n_loci = w;
+  return gmx_item_per_base(ix, env, it, read_len, n_hull);
+}
+
+// The chosen class's loci and hull recorded (allele_base.cpp:230-244, allele_sum.cpp:31-43, grouped_allele_counts.cpp:17-49).
+template <class Env>
+GMX_HD void gmx_class_record(const GmxIndexView &ix, Env &env, uint32_t n_loci, uint32_t n_hull) {
+  typedef GmxScratch<Env> S;
+  // --- every capacity check lies behind us except the grouped log: reserve all of this task's words at once ---
+  if (env.has_log_sites()) {
+    uint32_t words = 0;
+    for (uint32_t i = 0; i < n_loci; ++i) {
+      const uint32_t site = env.sget(S::loci(env) + 2 * i);
+      if (ix.sites[(site - 5) >> 1].grouped_off != GMX_GROUPED_LOG) continue;
+      bool first_of_site = true;
+      for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
+      words += first_of_site ? 3u : 1u;  // [site, n_ids, id] + one word per further id
+    }
+    if (words && !env.log_reserve(words)) return;
+  }
+  // --- record (allele_base.cpp:230-244, allele_sum.cpp:31-43, grouped_allele_counts.cpp:17-49) ---
+  // Two passes. First every table lookup and every check, the accumulator slots noted in scratch (the words of the item
+  // records, orders and keys are dead by now); then the increments, back to back. Interleaved, each lookup waits for
+  // the increments issued before it, and a device-scope atomic completes at the memory side: microseconds under load.
+  const uint32_t pend = S::items, pend_cap = S::loci(env) - S::items;
+  uint32_t n_as = 0, n_gr = 0;  // allele-sum slots from the front, grouped slots from the back
+  auto flush = [&]() {
+    for (uint32_t i = 0; i < n_as; ++i) env.add_allele_sum(env.sget(pend + i));
+    for (uint32_t i = 0; i < n_gr; ++i) env.add_grouped_dense(env.sget(pend + pend_cap - 1 - i));
+    n_as = n_gr = 0;
+  };
+  for (uint32_t h = 0; h < n_hull; ++h) {
+    const uint32_t off = ix.nodes[env.sget(S::hull(env) + 3 * h)].cov_off;
+    if (off == GMX_NO_COV) {
+      env.fail(GMX_TASK_ERROR);
+      return;
+    }
+    env.sset(S::hull(env) + 3 * h, off);  // the entry is now (first slot of the node, start, end)
+  }
+  for (uint32_t i = 0; i < n_loci; ++i) {
+    uint32_t site = env.sget(S::loci(env) + 2 * i);
+    int32_t allele = (int32_t)env.sget(S::loci(env) + 2 * i + 1);
+    const GmxSite &s = ix.sites[(site - 5) >> 1];
+    if (allele < 0 || (uint32_t)allele >= s.n_alleles) {
+      env.fail(GMX_TASK_ERROR);
+      return;
+    }
+    if (n_as + n_gr == pend_cap) flush();
+    env.sset(pend + n_as++, gmx_slot_allele(s, (uint32_t)allele));
+  }
+  for (uint32_t i = 0; i < n_loci; ++i) {
+    uint32_t site = env.sget(S::loci(env) + 2 * i);
+    bool first_of_site = true;
+    for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
+    if (!first_of_site) continue;
+    const GmxSite &s = ix.sites[(site - 5) >> 1];
+    if (s.grouped_off != GMX_GROUPED_LOG) {
+      uint32_t mask = 0;
+      for (uint32_t j = i; j < n_loci; ++j)
+        if (env.sget(S::loci(env) + 2 * j) == site) mask |= 1u << env.sget(S::loci(env) + 2 * j + 1);
+      if (n_as + n_gr == pend_cap) flush();
+      env.sset(pend + pend_cap - 1 - n_gr++, gmx_slot_grouped(s, mask));
+    } else {
+      uint32_t cnt = 0;
+      for (uint32_t j = i; j < n_loci; ++j)
+        if (env.sget(S::loci(env) + 2 * j) == site) ++cnt;
+      if (!env.log_grouped_begin((site - 5) >> 1, cnt)) return;
+      // ascending allele ids (std::set<AlleleId> order, grouped_allele_counts.cpp:25-37)
+      int32_t prev = -1;
+      for (uint32_t k = 0; k < cnt; ++k) {
+        int32_t best = 0x7fffffff;
+        for (uint32_t j = i; j < n_loci; ++j)
+          if (env.sget(S::loci(env) + 2 * j) == site) {
+            int32_t a = (int32_t)env.sget(S::loci(env) + 2 * j + 1);
+            if (a > prev && a < best) best = a;
+          }
+        env.log_grouped_id(best);
+        prev = best;
+      }
+      env.log_grouped_end();
+    }
+  }
+  for (uint32_t h = 0; h < n_hull; ++h) {
+    const uint32_t off = env.sget(S::hull(env) + 3 * h), s = env.sget(S::hull(env) + 3 * h + 1), e = env.sget(S::hull(env) + 3 * h + 2);
+    for (uint32_t i = s; i <= e; ++i) env.add_per_base(off + i);
+  }
+  flush();
+}
+
 // ---------------------------------------------------------------------------
 // The whole recording step for one mapped task.
 // ---------------------------------------------------------------------------
@@ -728,6 +884,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
       if (gmx_text_form(st.hi) || i == st.hi) break;
     }
   }
+  GMX_COVER_PROF(env, 0);
   if (n_items == 0) return;  // usps.size() == 0: nothing recorded, no draw (coverage_common.cpp:96-97)
 
   // --- class keys ---
@@ -736,6 +893,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     if (n == 0xFFFFFFFFu) return;
     if (!gmx_item_key(ix, env, it, 0, n)) return;
   }
+  GMX_COVER_PROF(env, 1);
   // Classes = runs of equal keys among the items sorted by key (the reference's std::map over level-0 site sets,
   // coverage_common.hpp:133): heap sort of the item indices, O(n log n) key comparisons — a read inside a many-copy
   // repeat has thousands of items, and every comparison is a chain of scratch loads.
@@ -779,6 +937,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     env.fail(GMX_TASK_ERROR);
     return;
   }
+  GMX_COVER_PROF(env, 2);
   if (r <= nonvariant) return;
   const uint32_t want = r - nonvariant - 1;  // 0-based index in the ordered map
   uint32_t run_begin = 0, run_end = n_items;  // the want-th run of equal keys
@@ -800,87 +959,8 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
   }
   // --- loci of the class (union) + per-base hull ---
   uint32_t n_loci = 0, n_hull = 0;
-  for (uint32_t ri = run_begin; ri < run_end; ++ri) {
-    const uint32_t it = env.sget(ord + ri);
-    uint32_t first = n_loci;
-    uint32_t n = gmx_item_loci(ix, env, it, first);
-    if (n == 0xFFFFFFFFu) return;
-    // merge window [first, n) into [0, first): drop duplicates
-    uint32_t w = first;
-    for (uint32_t i = first; i < n; ++i) {
-      uint32_t site = env.sget(S::loci(env) + 2 * i), al = env.sget(S::loci(env) + 2 * i + 1);
-      bool dup = false;
-      for (uint32_t j = 0; j < first && !dup; ++j)
-        dup = env.sget(S::loci(env) + 2 * j) == site && env.sget(S::loci(env) + 2 * j + 1) == al;
-      if (dup) continue;
-      env.sset(S::loci(env) + 2 * w, site);
-      env.sset(S::loci(env) + 2 * w + 1, al);
-      ++w;
-    }
-    n_loci = w;
-    if (!gmx_item_per_base(ix, env, it, read_len, n_hull)) return;
-  }
-  // --- every capacity check lies behind us except the grouped log: reserve all of this task's words at once ---
-  if (env.has_log_sites()) {
-    uint32_t words = 0;
-    for (uint32_t i = 0; i < n_loci; ++i) {
-      const uint32_t site = env.sget(S::loci(env) + 2 * i);
-      if (ix.sites[(site - 5) >> 1].grouped_off != GMX_GROUPED_LOG) continue;
-      bool first_of_site = true;
-      for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
-      words += first_of_site ? 3u : 1u;  // [site, n_ids, id] + one word per further id
-    }
-    if (words && !env.log_reserve(words)) return;
-  }
-  // --- record (allele_base.cpp:230-244, allele_sum.cpp:31-43, grouped_allele_counts.cpp:17-49) ---
-  for (uint32_t h = 0; h < n_hull; ++h) {
-    uint32_t node = env.sget(S::hull(env) + 3 * h), s = env.sget(S::hull(env) + 3 * h + 1), e = env.sget(S::hull(env) + 3 * h + 2);
-    uint32_t off = ix.nodes[node].cov_off;
-    if (off == GMX_NO_COV) {
-      env.fail(GMX_TASK_ERROR);
-      return;
-    }
-    for (uint32_t i = s; i <= e; ++i) env.add_per_base(off + i);
-  }
-  for (uint32_t i = 0; i < n_loci; ++i) {
-    uint32_t site = env.sget(S::loci(env) + 2 * i);
-    int32_t allele = (int32_t)env.sget(S::loci(env) + 2 * i + 1);
-    const GmxSite &s = ix.sites[(site - 5) >> 1];
-    if (allele < 0 || (uint32_t)allele >= s.n_alleles) {
-      env.fail(GMX_TASK_ERROR);
-      return;
-    }
-    env.add_allele_sum(gmx_slot_allele(s, (uint32_t)allele));
-  }
-  for (uint32_t i = 0; i < n_loci; ++i) {
-    uint32_t site = env.sget(S::loci(env) + 2 * i);
-    bool first_of_site = true;
-    for (uint32_t j = 0; j < i && first_of_site; ++j) first_of_site = env.sget(S::loci(env) + 2 * j) != site;
-    if (!first_of_site) continue;
-    const GmxSite &s = ix.sites[(site - 5) >> 1];
-    if (s.grouped_off != GMX_GROUPED_LOG) {
-      uint32_t mask = 0;
-      for (uint32_t j = i; j < n_loci; ++j)
-        if (env.sget(S::loci(env) + 2 * j) == site) mask |= 1u << env.sget(S::loci(env) + 2 * j + 1);
-      env.add_grouped_dense(gmx_slot_grouped(s, mask));
-    } else {
-      uint32_t cnt = 0;
-      for (uint32_t j = i; j < n_loci; ++j)
-        if (env.sget(S::loci(env) + 2 * j) == site) ++cnt;
-      if (!env.log_grouped_begin((site - 5) >> 1, cnt)) return;
-      // ascending allele ids (std::set<AlleleId> order, grouped_allele_counts.cpp:25-37)
-      int32_t prev = -1;
-      for (uint32_t k = 0; k < cnt; ++k) {
-        int32_t best = 0x7fffffff;
-        for (uint32_t j = i; j < n_loci; ++j)
-          if (env.sget(S::loci(env) + 2 * j) == site) {
-            int32_t a = (int32_t)env.sget(S::loci(env) + 2 * j + 1);
-            if (a > prev && a < best) best = a;
-          }
-        env.log_grouped_id(best);
-        prev = best;
-      }
-      env.log_grouped_end();
-    }
-  }
+  for (uint32_t ri = run_begin; ri < run_end; ++ri)
+    if (!gmx_class_add_item(ix, env, env.sget(ord + ri), read_len, n_loci, n_hull)) return;
+  GMX_COVER_PROF(env, 3);
+  gmx_class_record(ix, env, n_loci, n_hull);
 }

@@ -29,6 +29,9 @@
 
 #include "../../include/gmx.h"
 #include "gmx_core.h"
+#ifdef GMX_LOOP_STATS  // debug build: wall time of the coverage routine's phases (tools/cover_stats.py)
+#define GMX_COVER_PROF(env, k) (env).prof(k)
+#endif
 #include "gmx_cover.h"
 #include "gmx_dfs.h"
 #include "gmx_index.h"
@@ -789,6 +792,9 @@ struct SearchOut {
   GmxFinalState *inst_states;
   uint32_t *inst_first;                // per slot: instance index of the task's first instance
   uint32_t *inst_remaining_width;      // per slot: number of instances
+  uint32_t *inst_serial_list;          // entries of inst_mapped_list the cooperative coverage kernel left to the serial one; counter [26]
+  uint32_t *general_serial_list;       // the same for cover_general_list; counter [27]
+  uint32_t *big_serial_list;           // ... and for the second part of big_mapped_list (coverage instance 2); counter [28]
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
                              // [0] all (pack kernel) [1] skipped (seed / probe kernel) [2] missing_kmer [3] no_extension
                              // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
@@ -1663,7 +1669,29 @@ struct CoverAcc {
 // before it records anything (gmx_cover.h); a task that does not fit fails whole (GMX_TASK_LOGFULL) and fills what it
 // got of the log's tail with GMX_LOG_PAD words, which every reader skips.
 #define GMX_LOG_PAD 0xFFFFFFFFu
+#ifdef GMX_LOOP_STATS
+// per coverage instance (LIST): [0..7] wall time (10 ns units) per phase summed over tasks, [8..15] its maximum
+__device__ unsigned long long gmx_cover_stats[6 * 16];
+extern "C" int gmx_debug_cover_stats(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_cover_stats), sizeof(gmx_cover_stats)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[6 * 16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gmx_cover_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 struct CoverLogPart {
+#ifdef GMX_LOOP_STATS
+  long long prof_t = 0;
+  int prof_list = 0;
+  __device__ void prof(int k) {
+    const long long t = wall_clock64();
+    atomicAdd(&gmx_cover_stats[prof_list * 16 + k], (unsigned long long)(t - prof_t));
+    atomicMax(&gmx_cover_stats[prof_list * 16 + 8 + k], (unsigned long long)(t - prof_t));
+    prof_t = t;
+  }
+#endif
   uint32_t *acc, *log, *log_cursor;
   uint32_t log_cap;
   uint32_t status;
@@ -1882,7 +1910,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
   const uint64_t n_items = std::max<uint32_t>(gmx_count_items(ix, finals, nf), 1u);
   uint64_t cap_b = std::min<uint64_t>(std::max<uint64_t>(len + 8u, 32u), 4096u);
   if (whole_heap) cap_b = std::max<uint64_t>(cap_b, std::min<uint64_t>(65536u, scratch_words / (4 * n_items)));
-  const uint64_t fixed = n_items * (GmxScratch<CoverEnvDyn>::ITEM_W + 2 + cap_b);
+  const uint64_t fixed = n_items * (GmxScratch<CoverEnvDyn>::ITEM_W + 2 + cap_b) + 2 * GMX_PATH_CACHE;
   if (fixed + 5 * 64 > scratch_words) return GMX_TASK_OVERFLOW;
   const uint64_t rest = std::min<uint64_t>((scratch_words - fixed) / 5, 0x0FFFFFFFull);
   env.cap_i = (uint32_t)n_items;
@@ -1951,21 +1979,31 @@ constexpr uint32_t gmx_cover_lds_lanes() {
 }
 template <class Env, int LIST>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g,
-                                                              CoverAcc acc) {
+                                                              CoverAcc acc, uint32_t lanes_rt, uint32_t after_coop) {
   constexpr bool BIG = LIST == 1;
   constexpr bool LDS = LIST != 1;
-  constexpr uint32_t LANES = LDS ? gmx_cover_lds_lanes<Env>() : 64u;  // active lanes of a block (blockDim.x is 64)
+  const uint32_t LANES = LDS ? lanes_rt : 64u;  // active lanes of a block (blockDim.x is 64)
   // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
   // in counter [10], 2 starts there
-  uint32_t n_mapped = o.counters[(LIST == 3 ? 8 : LIST == 0 ? 13 : LIST == 1 ? 4 : LIST == 5 ? 25 : 7) * GMX_CNT_STRIDE];
-  const uint32_t m_start = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
-  const uint32_t *list = LIST == 3   ? o.cover_general_list
+  // (instances 3, 5 and 2 after the cooperative kernel: only what that one left, reject lists and counters [27], [26], [28])
+  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : 8)
+                                 : LIST == 0 ? 13
+                                 : LIST == 1 ? 4
+                                 : LIST == 5 ? (after_coop ? 26 : 25)
+                                 : LIST == 2 ? (after_coop ? 28 : 7)
+                                             : 7) * GMX_CNT_STRIDE];
+  const uint32_t m_start = LIST == 2 && !after_coop ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
+  const uint32_t *list = LIST == 3   ? (after_coop ? o.general_serial_list : o.cover_general_list)
                          : LIST == 0 ? o.cover_mid_list
                          : LIST == 1 ? o.cover_overflow_list
-                         : LIST == 5 ? o.inst_mapped_list
+                         : LIST == 5 ? (after_coop ? o.inst_serial_list : o.inst_mapped_list)
+                         : LIST == 2 ? (after_coop ? o.big_serial_list : o.big_mapped_list)
                                      : o.big_mapped_list;
   if (LIST == 4 && blockIdx.x == 0 && threadIdx.x == 0) o.counters[10 * GMX_CNT_STRIDE] = n_mapped;  // read by LIST 2 only
   if (threadIdx.x >= LANES) return;
+#ifdef GMX_LOOP_STATS
+  long long t_kernel = wall_clock64();
+#endif
   const uint32_t lane_id = blockIdx.x * LANES + threadIdx.x;
   const uint32_t work_blocks = gridDim.x;
   // interleaved: a short queue spreads over all waves (few diverging lanes each) instead of filling the first ones
@@ -1994,7 +2032,17 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     env.log_sites = acc.log_sites;
     env.status = GMX_TASK_MAPPED;
     env.log_at = 0;
+#ifdef GMX_LOOP_STATS
+    env.prof_list = LIST;
+    env.prof_t = t_kernel;
+    env.prof(6);  // from the start of the kernel (first task of the lane) or the end of the lane's previous task
+    atomicAdd(&gmx_cover_stats[LIST * 16 + 7], 1ull);
+#endif
     gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
+#ifdef GMX_LOOP_STATS
+    env.prof(5);
+    t_kernel = env.prof_t;
+#endif
     if (env.status == GMX_TASK_OVERFLOW && LIST == 3) {  // nothing has been recorded for it yet: next scratch size
       o.cover_mid_list[atomicAdd(&o.counters[13 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status == GMX_TASK_OVERFLOW && !BIG) {
@@ -2014,6 +2062,189 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       __threadfence();
       gmx_tail_stage(ix, b, o, g, acc);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The general routine, cooperatively: 16 lanes per task, one lane per item. The serial instances above spend one lane
+// on a whole task — a read with ten mapping instances is ten items' worth of loci, keys, a sort and a class search in
+// one lane, and a wave of such lanes executes the union of all their branches: the SIMDs, not memory, set the pace.
+// Here the items of a task are spread over lanes that all run the same short code:
+//   units    a path-bearing final state is one unit (an item); a pathless one has one unit per occurrence, each a
+//            non-variant instance or an allele-encapsulated item (encapsulated_search.cpp:30-107). Lanes load one final
+//            state each, a prefix sum of the widths assigns units to lanes.
+//   keys     every item lane runs gmx_item_loci + gmx_item_key on its own LDS scratch (capacity one item).
+//   classes  every item lane compares its key with the group's other keys: the lanes whose key has no equal at a lower
+//            lane lead a class; the rank of a class = the number of leaders with smaller keys (std::map order,
+//            coverage_common.hpp:133).
+//   draw     one seeded draw over non-variant instances + classes (coverage_common.cpp:95-108).
+//   record   the leader of the drawn class merges its members' loci and hulls in the group's class scratch
+//            (gmx_class_add_item: a set union, the order of the members is immaterial) and records.
+// Tasks with more than 16 units, or exceeding a scratch capacity (nothing recorded by then), go to the serial instance
+// of the same queue through a reject list. One wave per block, four tasks per wave, persistent over the queue.
+// ---------------------------------------------------------------------------
+typedef CoverEnvT<1, 6, 12, 1> CoopItemEnv;    // one item: its record, key and loci window
+typedef CoverEnvT<1, 6, 24, 24> CoopClassEnv;  // the drawn class: union of loci, hull
+#define GMX_COOP_LDS_WORDS (64u * GmxScratchFixed<CoopItemEnv>::total + 4u * GmxScratchFixed<CoopClassEnv>::total)
+
+template <int LIST>
+__global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, CoverAcc acc) {
+  typedef GmxScratch<CoopItemEnv> SI;
+  typedef GmxScratch<CoopClassEnv> SC;
+  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : 8) * GMX_CNT_STRIDE];
+  const uint32_t n_first = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;  // instance 2 starts where instance 4 stopped
+  const uint32_t *list = LIST == 5 ? o.inst_mapped_list : LIST == 2 ? o.big_mapped_list : o.cover_general_list;
+  uint32_t *reject = LIST == 5 ? o.inst_serial_list : LIST == 2 ? o.big_serial_list : o.general_serial_list;
+  uint32_t *reject_n = &o.counters[(LIST == 5 ? 26 : LIST == 2 ? 28 : 27) * GMX_CNT_STRIDE];
+  const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15u, gbase = grp << 4;
+  CoopItemEnv ie;
+  ie.scratch = gmx_lds + lane;
+  ie.stride = 64;
+  CoopClassEnv ce;
+  ce.scratch = gmx_lds + 64u * GmxScratchFixed<CoopItemEnv>::total + grp;
+  ce.stride = 4;
+  ie.acc = ce.acc = acc.acc;
+  ie.log = ce.log = acc.log;
+  ie.log_cursor = ce.log_cursor = acc.log_cursor;
+  ie.log_cap = ce.log_cap = acc.log_cap;
+  ie.log_sites = ce.log_sites = acc.log_sites;
+  ie.log_at = ce.log_at = 0;
+  const uint32_t kofs = SI::keys(ie);  // key word t of lane L: gmx_lds[(kofs + t) * 64 + L]
+  for (uint32_t m0 = n_first + blockIdx.x * 4u; m0 < n; m0 += gridDim.x * 4u) {  // wave-uniform: every lane takes part in the shuffles
+    const uint32_t m = m0 + grp;
+    const bool have = m < n;
+    const uint32_t entry = have ? list[m] : 0u;
+    GmxTaskStates ts{0u, 0u, nullptr, nullptr};
+    if (have) ts = gmx_entry_states(entry, o, g);
+    bool rejected = ts.nf > 16u;
+    // --- units ---
+    GmxFinalState st{0u, 0u, GMX_NIL, GMX_NIL};
+    uint32_t w = 0;
+    if (have && !rejected && gl < ts.nf) {
+      st = ts.finals[gl];
+      w = (st.traversed != GMX_NIL || st.traversing != GMX_NIL || gmx_text_form(st.hi)) ? 1u : min(st.hi - st.lo, 16u) + 1u;
+    }
+    uint32_t incl = w;
+#pragma unroll
+    for (uint32_t d = 1; d < 16; d <<= 1) {
+      const uint32_t v = __shfl_up(incl, d, 16);
+      if (gl >= d) incl += v;
+    }
+    const uint32_t start = incl - w, n_units = __shfl(incl, 15, 16);
+    rejected = rejected || n_units > 16u;
+    uint32_t f_lo = 0, f_hi = 0, f_tvd = GMX_NIL, f_tvg = GMX_NIL, f_start = 0;
+    bool unit = false;
+#pragma unroll 4
+    for (uint32_t f = 0; f < 16; ++f) {
+      const uint32_t s = __shfl(start, f, 16), ww = __shfl(w, f, 16);
+      const uint32_t lo = __shfl(st.lo, f, 16), hi = __shfl(st.hi, f, 16), tvd = __shfl(st.traversed, f, 16), tvg = __shfl(st.traversing, f, 16);
+      if (gl >= s && gl < s + ww) {
+        unit = true;
+        f_lo = lo;
+        f_hi = hi;
+        f_tvd = tvd;
+        f_tvg = tvg;
+        f_start = s;
+      }
+    }
+    unit = unit && have && !rejected;
+    bool is_item = false, nonvar = false;
+    uint32_t i_lo = 0, i_hi = 0, enc_site = 0;
+    int32_t enc_allele = -1;
+    if (unit) {
+      if (f_tvd != GMX_NIL || f_tvg != GMX_NIL) {
+        is_item = true;
+        i_lo = f_lo;
+        i_hi = f_hi;
+      } else {
+        const uint32_t i = f_lo + (gl - f_start);
+        const GmxNode &nd = ix.nodes[ix.pos_node[gmx_occ_pos(ix, f_hi, i)]];
+        if (nd.site == 0) {
+          nonvar = true;
+        } else {
+          is_item = true;
+          i_lo = i;
+          i_hi = gmx_text_form(f_hi) ? f_hi : i;
+          enc_site = nd.site;
+          enc_allele = nd.allele;
+        }
+      }
+    }
+    const uint32_t items16 = (uint32_t)(__ballot(is_item) >> gbase) & 0xFFFFu;
+    const uint32_t nonvariant = __popc((uint32_t)(__ballot(nonvar) >> gbase) & 0xFFFFu);
+    // --- loci and key of the lane's item ---
+    ie.arena = ts.arena;
+    ie.status = GMX_TASK_MAPPED;
+    if (is_item) {
+      ie.sset(SI::items + 0, i_lo);
+      ie.sset(SI::items + 1, i_hi);
+      ie.sset(SI::items + 2, f_tvd);
+      ie.sset(SI::items + 3, f_tvg);
+      ie.sset(SI::items + 4, enc_site);
+      ie.sset(SI::items + 5, (uint32_t)enc_allele);
+      const uint32_t nl = gmx_item_loci(ix, ie, 0, 0);
+      if (nl != 0xFFFFFFFFu) gmx_item_key(ix, ie, 0, 0, nl);
+    }
+    uint32_t err = (is_item && ie.status != GMX_TASK_MAPPED && ie.status != GMX_TASK_OVERFLOW) ? ie.status : 0u;
+    rejected = rejected || (((uint32_t)(__ballot(is_item && ie.status == GMX_TASK_OVERFLOW) >> gbase) & 0xFFFFu) != 0u);
+    bool failed = (((uint32_t)(__ballot(err != 0u) >> gbase) & 0xFFFFu) != 0u);
+    __syncthreads();  // the keys are in LDS
+    // --- classes ---
+    uint32_t lt = 0, eq = 0;
+    if (is_item && !rejected && !failed) {
+      const uint32_t la = gmx_lds[kofs * 64u + lane];
+      for (uint32_t rest = items16 & ~(1u << gl); rest; rest &= rest - 1u) {
+        const uint32_t j = (uint32_t)__ffs(rest) - 1u, other = gbase + j;
+        const uint32_t lb = gmx_lds[kofs * 64u + other];
+        const uint32_t mlen = min(la, lb);
+        int cmp = 0;  // sign of (other's key - mine)
+        for (uint32_t t = 0; t < mlen && cmp == 0; ++t) {
+          const uint32_t va = gmx_lds[(kofs + 1u + t) * 64u + lane], vb = gmx_lds[(kofs + 1u + t) * 64u + other];
+          cmp = vb < va ? -1 : (vb > va ? 1 : 0);
+        }
+        if (cmp == 0) cmp = lb < la ? -1 : (lb > la ? 1 : 0);
+        if (cmp < 0) lt |= 1u << j;
+        if (cmp == 0) eq |= 1u << j;
+      }
+    }
+    const bool leader = is_item && !rejected && !failed && (eq & ((1u << gl) - 1u)) == 0u;
+    const uint32_t leaders16 = (uint32_t)(__ballot(leader) >> gbase) & 0xFFFFu;
+    const uint32_t n_classes = __popc(leaders16), rank = __popc(lt & leaders16);
+    // --- the draw ---
+    bool member = false;
+    if (have && !rejected && !failed && items16 != 0u) {
+      uint32_t r = 0;
+      if (!gmx_uniform_1_to_n(b.seeds[ts.task >> 1], nonvariant + n_classes, acc.rng_mode, r)) {
+        err = GMX_TASK_ERROR;
+      } else if (r > nonvariant) {
+        member = is_item && rank == r - nonvariant - 1u;
+      }
+    }
+    const uint32_t members16 = (uint32_t)(__ballot(member) >> gbase) & 0xFFFFu;
+    // --- the drawn class: its first lane merges the members and records ---
+    bool class_overflow = false;
+    if (member && gl == (uint32_t)__ffs(members16) - 1u) {
+      const uint32_t read = ts.task >> 1;
+      const uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+      ce.arena = ts.arena;
+      ce.status = GMX_TASK_MAPPED;
+      ce.log_at = 0;
+      uint32_t n_loci = 0, n_hull = 0;
+      bool ok = true;
+      for (uint32_t rest = members16; rest && ok; rest &= rest - 1u) {
+        const uint32_t other = gbase + (uint32_t)__ffs(rest) - 1u;
+#pragma unroll
+        for (uint32_t t = 0; t < SI::ITEM_W; ++t) ce.sset(SC::items + t, gmx_lds[(SI::items + t) * 64u + other]);
+        ok = gmx_class_add_item(ix, ce, 0, len, n_loci, n_hull);
+      }
+      if (ok) gmx_class_record(ix, ce, n_loci, n_hull);
+      class_overflow = ce.status == GMX_TASK_OVERFLOW;
+      if (ce.status != GMX_TASK_MAPPED && !class_overflow) err = ce.status;
+    }
+    rejected = rejected || (((uint32_t)(__ballot(class_overflow) >> gbase) & 0xFFFFu) != 0u);
+    if (have && gl == 0 && rejected) reject[atomicAdd(reject_n, 1u)] = entry;
+    if (err != 0u && atomicCAS(&o.error[0], 0u, err) == 0u) o.error[1] = ts.task;
+    __syncthreads();  // the scratch is reused by the next round
   }
 }
 
@@ -2251,6 +2482,8 @@ struct gmx_engine {
   GmxPathNode *d_inst_arena = nullptr;
   GmxFinalState *d_inst_states = nullptr;
   uint32_t *d_inst_first = nullptr, *d_inst_width = nullptr;
+  uint32_t *d_inst_serial = nullptr, *d_general_serial = nullptr, *d_big_serial = nullptr;  // what gmx_cover_coop_kernel leaves to the serial instances
+  bool coop = true;  // GMX_NO_COOP=1 in the environment: serial coverage instances only (A/B runs)
   uint32_t *d_heap = nullptr;      // ... and its memory
   uint64_t heap_words = 0;
   bool log_sites = false;          // the index has sites with more than 5 alleles
@@ -2344,11 +2577,21 @@ static int gmx_log_drain(gmx_engine *e, uint64_t keep_below) {
 
 // A coverage instance with its scratch in LDS: one wave per block, as many blocks per CU as scratch copies fit its LDS.
 template <class Env, int LIST>
-static void launch_cover_lds(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc) {
-  const size_t lds = (size_t)GmxScratchFixed<Env>::total * gmx_cover_lds_lanes<Env>() * sizeof(uint32_t);
-  const uint32_t per_cu = (uint32_t)(160 * 1024 / lds);
+static void launch_cover_lds(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc,
+                             bool after_coop = false) {
+  static const uint32_t lanes_env = getenv("GMX_COVER_LANES") ? (uint32_t)atoi(getenv("GMX_COVER_LANES")) : 0u;
+  const uint32_t lanes = lanes_env ? std::min(lanes_env, gmx_cover_lds_lanes<Env>()) : gmx_cover_lds_lanes<Env>();
+  const size_t lds = (size_t)GmxScratchFixed<Env>::total * lanes * sizeof(uint32_t);
+  const uint32_t per_cu = std::min<uint32_t>((uint32_t)(160 * 1024 / lds), 32u);
   hipLaunchKernelGGL((gmx_cover_kernel<Env, LIST>), dim3(e->n_cus * per_cu), dim3(64), lds, stream, e->dview, b, o, e->big,
-                     acc);
+                     acc, lanes, after_coop ? 1u : 0u);
+}
+
+template <int LIST>
+static void launch_cover_coop(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc) {
+  const size_t lds = (size_t)GMX_COOP_LDS_WORDS * sizeof(uint32_t);
+  const uint32_t per_cu = std::min<uint32_t>((uint32_t)(160 * 1024 / lds), 16u);
+  hipLaunchKernelGGL((gmx_cover_coop_kernel<LIST>), dim3(e->n_cus * per_cu), dim3(64), lds, stream, e->dview, b, o, e->big, acc);
 }
 
 extern "C" {
@@ -2406,6 +2649,9 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_inst_mapped, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_first, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_width, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_inst_serial, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_general_serial, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_big_serial, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_arena, (size_t)e->inst_cap * GMX_FAST_ARENA, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_states, (size_t)e->inst_cap * GMX_INST_STATES, false))) return rc;
   e->cap_reads = cap;
@@ -2537,6 +2783,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   if (getenv("GMX_NO_FUSE")) e->fuse = 0;
+  if (getenv("GMX_NO_COOP")) e->coop = false;
   // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
   // more than 10 % of the seed states the kernels take them one state at a time (seed cursor, a few % slower), else
   // the rare large entry goes to the large-capacity pass
@@ -2638,7 +2885,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
               e->d_inst_list, e->d_inst_sa, e->d_inst_remaining, e->inst_cap,
               !getenv("GMX_NO_INST") ? e->big.max_slots : 0u,
               e->big.n_final, e->big.task_of_slot, e->d_inst_mapped, e->d_inst_arena, e->d_inst_states, e->d_inst_first, e->d_inst_width,
-              e->d_stats};
+              e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters, e->d_stats);
@@ -2677,7 +2924,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     // gained nothing: the runtime then put two of the four streams on one hardware queue, and filter and extend kernel
     // ran one after the other.)
     hipLaunchKernelGGL(gmx_extend_inst_kernel, dim3(e->n_cus * 2), dim3(GMX_BLOCK), lds, e->side2_stream, e->dview, b, o, pools);
-    launch_cover_lds<CoverEnvMid, 5>(e, e->side2_stream, b, o, acc);
+    if (e->coop) launch_cover_coop<5>(e, e->side2_stream, b, o, acc);
+    launch_cover_lds<CoverEnvMid, 5>(e, e->side2_stream, b, o, acc, e->coop);
     hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
@@ -2700,7 +2948,8 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
-  launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc);
+  if (e->coop) launch_cover_coop<2>(e, e->side2_stream, b, o, acc);
+  launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc, e->coop);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
   // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
   const bool general_on_side = !e->dview.is_nested;
@@ -2710,21 +2959,23 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
   if (general_on_side) {
-    launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc);
+    if (e->coop) launch_cover_coop<3>(e, e->side_stream, b, o, acc);
+    launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);
   }
   launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   if (!general_on_side) {
-    launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc);
+    if (e->coop) launch_cover_coop<3>(e, stream, b, o, acc);
+    launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
   }
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
   // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
-                     b, o, e->big, acc);
+                     b, o, e->big, acc, 64u, 0u);
   // (no pass over per-task status words: the read counters are added where each task's fate is decided, SearchOut::stats)
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
