@@ -2848,12 +2848,12 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   return GMX_OK;
 }
 
-static void launch_filter(gmx_engine *e, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass) {
+static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass) {
   if (e->filter_lds_words)
     hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
-                       e->side_stream, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
+                       st, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
   else
-    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, e->side_stream, e->dview, b, o, pass);
+    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
 }
 
 static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
@@ -2932,7 +2932,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
   }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
-  launch_filter(e, task_grid, b, o, 0);
+  launch_filter(e, e->side_stream, task_grid, b, o, 0);
   if (seeded && e->seed_cursor)
     hipLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
   else if (seeded)
@@ -2947,35 +2947,42 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_fork2, 0));
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
+  // the second filter pass (the tasks the extend kernel found dead) comes first here: side 1 is busy with the first pass
+  // for most of the batch, and behind the few-lane kernels below it would end after the main stream's last kernel
+  launch_filter(e, e->side2_stream, task_grid, b, o, 1);
   hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
   if (e->coop) launch_cover_coop<2>(e, e->side2_stream, b, o, acc);
   launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc, e->coop);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is
-  // nested (there gmx_cover_single_kernel hands tasks over), so they run here, off the main stream
+  // nested (there gmx_cover_single_kernel hands tasks over), so they run on side 1, off the main stream (and not behind
+  // the large-capacity pass's chain of few-lane kernels: with reads in repeats that chain is the batch's longest path)
   const bool general_on_side = !e->dview.is_nested;
-  HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
-  // side 1: the general instances of the regular tasks (not behind the large-capacity pass's chain of few-lane kernels:
-  // with reads in repeats that chain is the longest path of the batch), then the second filter pass: the tasks the
-  // extend kernel found dead, beside the coverage kernels
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
   if (general_on_side) {
     if (e->coop) launch_cover_coop<3>(e, e->side_stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);
   }
-  launch_filter(e, task_grid, b, o, 1);
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  // The batch's last coverage instance (1: what exceeded the regular scratch; its last block also serves the last tier,
+  // whose search keeps its first pending entries in LDS) needs every other instance done except gmx_cover_single_kernel,
+  // which queues nothing on a non-nested PRG: there it runs at the end of side 2, beside that kernel.
+  hipStream_t last = general_on_side ? e->side2_stream : stream;
   if (!general_on_side) {
     if (e->coop) launch_cover_coop<3>(e, stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);
+    HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
   }
-  HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
-  HIP_TRY(hipStreamWaitEvent(stream, e->ev_filter, 0));
-  // (the last block of this launch also serves the last tier, whose search keeps its first pending entries in LDS)
-  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, stream, e->dview,
+  HIP_TRY(hipStreamWaitEvent(last, e->ev_filter, 0));
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), big_lds, last, e->dview,
                      b, o, e->big, acc, 64u, 0u);
+  if (general_on_side) {
+    HIP_TRY(hipEventRecord(e->ev_join, e->side2_stream));
+    HIP_TRY(hipStreamWaitEvent(stream, e->ev_join, 0));
+  }
   // (no pass over per-task status words: the read counters are added where each task's fate is decided, SearchOut::stats)
   if (e->timing) {
     HIP_TRY(hipEventRecord(ev.c, stream));
