@@ -85,6 +85,7 @@ SYMBOLS = {
     "gmx_engine_reset_async": (C.c_int, [_vp, _vp]),
     "gmx_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
     "gmx_map_reads_device": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
+    "gmx_engine_reserve": (C.c_int, [_vp, _u64, _u64]),
     "gmx_host_alloc": (_vp, [_u64]),
     "gmx_host_free": (None, [_vp]),
     "gmx_engine_sync": (C.c_int, [_vp]),

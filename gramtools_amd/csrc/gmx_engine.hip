@@ -3111,36 +3111,89 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
   return gmx_engine_sync(e);
 }
 
-// page-locked allocations are remembered so that gmx_host_free knows which call returns them
+// page-locked allocations are remembered so that gmx_host_free knows which call returns them. Freed page-locked blocks
+// of 1 MB or more are kept (up to 16 of them) and handed out again: pinning and unpinning 100 MB costs 10-20 ms each
+// way, which a reads feed would otherwise pay at its start and again at its end.
 static std::mutex g_host_mu;
-static std::map<void *, bool> g_host_pinned;
+struct HostBlock {
+  uint64_t bytes;
+  bool pinned;
+};
+static std::map<void *, HostBlock> g_host_live;
+static std::vector<std::pair<void *, uint64_t>> g_host_spare;  // pinned blocks waiting for reuse
 void *gmx_host_alloc(uint64_t bytes) {
+  bytes = std::max<uint64_t>(bytes, 1);
+  {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    size_t best = g_host_spare.size();
+    for (size_t i = 0; i < g_host_spare.size(); ++i)
+      if (g_host_spare[i].second >= bytes && g_host_spare[i].second <= 2 * bytes + (1u << 20) &&
+          (best == g_host_spare.size() || g_host_spare[i].second < g_host_spare[best].second))
+        best = i;
+    if (best != g_host_spare.size()) {
+      void *p = g_host_spare[best].first;
+      g_host_live[p] = HostBlock{g_host_spare[best].second, true};
+      g_host_spare.erase(g_host_spare.begin() + (long)best);
+      return p;
+    }
+  }
   void *p = nullptr;
-  bool pinned = hipHostMalloc(&p, std::max<uint64_t>(bytes, 1), hipHostMallocDefault) == hipSuccess && p;
+  bool pinned = hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p;
   if (!pinned) {
     (void)hipGetLastError();
-    p = malloc(std::max<uint64_t>(bytes, 1));
+    p = malloc(bytes);
   }
   if (p) {
     std::lock_guard<std::mutex> lk(g_host_mu);
-    g_host_pinned[p] = pinned;
+    g_host_live[p] = HostBlock{bytes, pinned};
   }
   return p;
 }
 void gmx_host_free(void *p) {
   if (!p) return;
-  bool pinned = false;
+  HostBlock blk{0, false};
   {
     std::lock_guard<std::mutex> lk(g_host_mu);
-    auto it = g_host_pinned.find(p);
-    if (it == g_host_pinned.end()) return;
-    pinned = it->second;
-    g_host_pinned.erase(it);
+    auto it = g_host_live.find(p);
+    if (it == g_host_live.end()) return;
+    blk = it->second;
+    g_host_live.erase(it);
+    if (blk.pinned && blk.bytes >= (1u << 20) && g_host_spare.size() < 16) {
+      g_host_spare.emplace_back(p, blk.bytes);
+      return;
+    }
   }
-  if (pinned)
+  if (blk.pinned)
     (void)hipHostFree(p);
   else
     free(p);
+}
+
+// Sizes the batch workspace and the staging buffers of the _host entry point ahead of the first call (otherwise the first
+// call allocates them, and a later, larger call allocates them again).
+int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(e->opts.device));
+  n_reads = std::min<uint64_t>(n_reads, e->opts.max_batch_reads);
+  int rc = ensure_batch_capacity(e, n_reads);
+  if (rc) return rc;
+  const uint64_t need = n_bases / 32 + n_reads + 16;
+  if (need > e->cap_packed) {
+    if ((rc = e->alloc(&e->d_packed, need, false))) return rc;
+    e->cap_packed = need;
+  }
+  if (n_bases > e->cap_bases) {
+    if ((rc = e->alloc(&e->d_reads, n_bases + 16, false))) return rc;
+    e->cap_bases = n_bases;
+  }
+  if (n_reads > e->cap_stage_reads) {
+    if ((rc = e->alloc(&e->d_offsets, n_reads + 1, false)) || (rc = e->alloc(&e->d_seeds, n_reads, false))) return rc;
+    e->cap_stage_reads = n_reads;
+  }
+  return GMX_OK;
 }
 
 int gmx_engine_sync(gmx_engine *e) {

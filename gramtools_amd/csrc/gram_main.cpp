@@ -319,7 +319,7 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
   consumed = 0;
   if (size == 0) return true;
   if (d[0] != '@') return false;
-  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
   struct Part {
     std::vector<uint8_t> bases;
     std::vector<uint32_t> lens;
@@ -430,6 +430,14 @@ struct FeedTimes {
 };
 static FeedTimes g_feed;
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// GMX_FEED_TRACE=1 in the environment: the feed's events with their times on stderr
+static double g_trace_t0 = 0;
+static const bool g_trace = getenv("GMX_FEED_TRACE") != nullptr;
+static inline void feed_trace(const char *what) {
+  if (!g_trace) return;
+  if (g_trace_t0 == 0) g_trace_t0 = now_s();
+  fprintf(stderr, "[feed %8.2f ms] %s\n", (now_s() - g_trace_t0) * 1e3, what);
+}
 
 // Two parsed blocks in flight: while the consumer thread hands block i to the engine (seeds, upload, kernels), the
 // caller's thread and the parser threads work on block i + 1. Blocks are consumed in file order.
@@ -452,7 +460,9 @@ struct BlockPipe {
           blk = &slot[k & 1];
         }
         const double t0 = now_s();
+        feed_trace("consumer: block taken");
         sink(*blk);
+        feed_trace("consumer: block mapped");
         g_feed.map_s += now_s() - t0;
         {
           std::lock_guard<std::mutex> lk(m);
@@ -488,6 +498,10 @@ struct BlockPipe {
   ~BlockPipe() { finish(); }
 };
 
+// the file block being parsed (kept between files; `gram genotype` allocates and touches it beside the index load)
+static std::unique_ptr<char[]> g_block_mem;
+static size_t g_block_cap = 0;
+
 // A whole reads file through the fast path, block by block (GMX_FASTQ_BLOCK bytes, 96 MB by default): a plain file is
 // read with parallel pread calls, a gzip file is inflated by this thread; every block is parsed by all threads while the
 // engine works on the block before it (BlockPipe). `sink` receives every block's reads in file order, on another thread.
@@ -502,8 +516,18 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   const bool stat_ok = fstat(fd, &sb) == 0;
   size_t kBlock = 96u << 20;
   if (const char *eb = getenv("GMX_FASTQ_BLOCK")) kBlock = std::max<size_t>(64, (size_t)atoll(eb));  // tests: tiny blocks
-  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
-  std::vector<char> buf(kBlock + (1u << 20));
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
+  feed_trace("file opened");
+  // (not value-initialised: the pages are first touched by the parallel reads below; kept for the next file)
+  if (g_block_cap < kBlock + (1u << 20)) {
+    g_block_cap = kBlock + (1u << 20);
+    g_block_mem.reset(new char[g_block_cap]);
+  }
+  struct {
+    char *p;
+    char *data() const { return p; }
+  } buf{g_block_mem.get()};
+  feed_trace("block buffer allocated");
   size_t have = 0, consumed = 0;
   bool first = true;
   gzFile g = nullptr;
@@ -560,11 +584,13 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
       final = file_at >= file_size;
     }
     g_feed.read_s += now_s() - t_read;
+    feed_trace("block read");
     ParsedReads scratch;
     ParsedReads &block = pipe ? pipe->acquire() : scratch;
     const double t_parse = now_s();
     const bool parsed = parse_fastq_buffer(buf.data(), have, final, threads, block, consumed);
     g_feed.parse_s += now_s() - t_parse;
+    feed_trace("block parsed");
     if (!parsed || (!final && consumed == 0)) {
       if (first) {
         shut();
@@ -590,6 +616,7 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     if (final) break;
   }
   pipe->finish();
+  feed_trace("pipe drained");
   shut();
   return true;
 }
@@ -803,6 +830,21 @@ int run_genotype(const Args &a) {
   compute_base_error_rate(reads_paths[0], rs);  // genotype.cpp:32-34
 
   auto t0 = clk::now();
+  // Beside the index load: the page-locked buffers the reads feed will ask for (two parsed blocks in flight: bases,
+  // offsets, seeds, sized for 150 bp reads in blocks of GMX_FASTQ_BLOCK bytes; other sizes are allocated when needed).
+  // Freed right away, they wait in the library's cache of page-locked blocks.
+  std::thread prewarm([]() {
+    size_t block = 96u << 20;
+    if (const char *eb = getenv("GMX_FASTQ_BLOCK")) block = std::max<size_t>(64, (size_t)atoll(eb));
+    if (block < (8u << 20)) return;
+    void *p[6];
+    const size_t sizes[3] = {block / 5 * 3, block / 24, block / 48};
+    for (int i = 0; i < 6; ++i) p[i] = gmx_host_alloc(sizes[i % 3]);
+    for (int i = 0; i < 6; ++i) gmx_host_free(p[i]);
+    g_block_cap = block + (1u << 20);  // ... and the file block buffer, its pages touched
+    g_block_mem.reset(new char[g_block_cap]);
+    memset(g_block_mem.get(), 0, g_block_cap);
+  });
   std::cout << "Loading PRG data" << std::endl;
   gmx_index *ix = nullptr;
   {  // the index cache `gram build` leaves in gram_dir (gmx_index.k<K>.bin); rebuilt in memory when absent or stale
@@ -821,6 +863,9 @@ int run_genotype(const Args &a) {
   gmx_group *grp = nullptr;
   GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
+  // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
+  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve(gmx_group_engine(grp, d), 1u << 20, 160ull << 20));
+  if (prewarm.joinable()) prewarm.join();
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
   std::cout << "Running quasimap" << std::endl;
@@ -830,6 +875,7 @@ int run_genotype(const Args &a) {
   std::cout << "Maximum thread count: " << max_threads << std::endl;
   std::cout << "Processing reads:" << std::endl;
   t0 = clk::now();
+  feed_trace("quasimap stage starts");
   // One master mt19937(seed) for all files; 5000 draws per batch of <= 5000 reads (quasimap.cpp:120-141).
   std::mt19937 master(seed);
   const uint64_t kBatch = 5000;
@@ -885,6 +931,7 @@ int run_genotype(const Args &a) {
   }
   GMX_CHECK(gmx_group_allreduce(grp));  // the one exchange (a single engine: nothing to do)
   GMX_CHECK(gmx_engine_sync(eng));
+  feed_trace("engine synchronised");
   double t_map = std::chrono::duration<double>(clk::now() - t0).count();
 
   // ---- coverage read-back + uint16 semantics --------------------------------------------------------------

@@ -151,6 +151,9 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
  * parsers also run in tests without one). gmx_host_free takes only pointers gmx_host_alloc returned. */
 void *gmx_host_alloc(uint64_t bytes);
 void gmx_host_free(void *p);
+/* Sizes the engine's batch workspace (and the device staging buffers of gmx_map_reads_host) for calls of up to n_reads
+ * reads / n_bases bases ahead of the first call. Optional: the first call does it otherwise. */
+int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases);
 /* Waits for enqueued work and reports a read that overflowed / errored (GMX_ECAP, GMX_EREF). */
 int gmx_engine_sync(gmx_engine *e);
 
