@@ -2343,19 +2343,20 @@ __device__ __forceinline__ uint2 pack_tail(const uint8_t *p, uint32_t rem, uint3
   }
   return out;
 }
-__global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters,
-                                                                  unsigned long long *stats) {
+#define GMX_PACK_THREADS (2 * GMX_PACK_READS)  // two threads per read: twice the loads and stores in flight per LDS window
+__global__ void __launch_bounds__(GMX_PACK_THREADS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters,
+                                                                    unsigned long long *stats) {
   __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
   __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
   // the queue counters are per batch: this is the batch's first kernel and everything that counts comes after it
   if (blockIdx.x == 0) {
-    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_READS) counters[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_THREADS) counters[i] = 0;
     // all_reads_count (quasimap.cpp:104): both orientations of every read, or the one a forward_only engine maps
     if (threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
   }
   const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
   const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
-  const uint32_t read = r0 + threadIdx.x;
+  const uint32_t read = r0 + (threadIdx.x >> 1), half = threadIdx.x & 1u;  // the two threads of a read are neighbours
   const uint64_t s0 = b.offsets[r0], s1 = b.offsets[r1];
   const uintptr_t g0 = reinterpret_cast<uintptr_t>(b.reads + s0);
   const uint32_t shift = (uint32_t)(g0 & 15u);
@@ -2363,20 +2364,19 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
   if (span <= GMX_PACK_IN_BYTES) {  // block-uniform
     const uint4 *src = reinterpret_cast<const uint4 *>(g0 - shift);
     const uint32_t n16 = (uint32_t)((span + 15) >> 4);
-    {  // four independent 16-byte loads in flight per thread and round
+    {  // independent 16-byte loads in flight per thread and round
       uint32_t i = threadIdx.x;
-      for (; i + 3 * GMX_PACK_READS < n16; i += 4 * GMX_PACK_READS) {
-        const uint4 v0 = src[i], v1 = src[i + GMX_PACK_READS], v2 = src[i + 2 * GMX_PACK_READS], v3 = src[i + 3 * GMX_PACK_READS];
+      for (; i + 2 * GMX_PACK_THREADS < n16; i += 3 * GMX_PACK_THREADS) {
+        const uint4 v0 = src[i], v1 = src[i + GMX_PACK_THREADS], v2 = src[i + 2 * GMX_PACK_THREADS];
         in4[i] = v0;
-        in4[i + GMX_PACK_READS] = v1;
-        in4[i + 2 * GMX_PACK_READS] = v2;
-        in4[i + 3 * GMX_PACK_READS] = v3;
+        in4[i + GMX_PACK_THREADS] = v1;
+        in4[i + 2 * GMX_PACK_THREADS] = v2;
       }
-      for (; i < n16; i += GMX_PACK_READS) in4[i] = src[i];
+      for (; i < n16; i += GMX_PACK_THREADS) in4[i] = src[i];
     }
     const uint64_t po0 = pack_off(b, r0);
     const uint32_t n_out = (uint32_t)(pack_off(b, r1) - po0);
-    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) outp[i] = make_uint2(0, 0);
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_THREADS) outp[i] = make_uint2(0, 0);
     __syncthreads();
     if (read < r1) {
       const uint64_t s = b.offsets[read];
@@ -2385,12 +2385,13 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
       const uint32_t *w = reinterpret_cast<const uint32_t *>(in4);
       const uint8_t *bytes = reinterpret_cast<const uint8_t *>(in4);
       uint2 *out = outp + (uint32_t)(pack_off(b, read) - po0);
-      uint32_t idx = q >> 2;
+      const uint32_t full = len >> 5, first_half = (full + 1u) >> 1;
+      const uint32_t c0 = half ? first_half : 0u, c1 = half ? full : first_half;  // this thread's pairs
+      uint32_t idx = (q >> 2) + 8u * c0;
       const uint32_t sh = q & 3u;
       uint32_t bad = 0;
-      const uint32_t full = len >> 5;
       uint32_t carry = w[idx];
-      for (uint32_t c = 0; c < full; ++c) {
+      for (uint32_t c = c0; c < c1; ++c) {
         uint2 pair = make_uint2(0, 0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -2403,14 +2404,15 @@ __global__ void __launch_bounds__(GMX_PACK_READS) gmx_pack_kernel(BatchView b, u
         out[c] = pair;
       }
       const uint32_t rem = len & 31u;
-      if (rem) out[full] = pack_tail(bytes + q + full * 32, rem, bad);
-      skip[read] = bad ? 1 : 0;
+      if (half && rem) out[full] = pack_tail(bytes + q + full * 32, rem, bad);
+      bad |= (uint32_t)__shfl_xor((int)bad, 1);
+      if (!half) skip[read] = bad ? 1 : 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_READS) packed[po0 + i] = outp[i];
+    for (uint32_t i = threadIdx.x; i < n_out; i += GMX_PACK_THREADS) packed[po0 + i] = outp[i];
     return;
   }
-  if (read >= r1) return;
+  if (read >= r1 || half) return;
   uint64_t s = b.offsets[read], e = b.offsets[read + 1];
   uint32_t len = (uint32_t)(e - s);
   const uint8_t *p = b.reads + s;
@@ -2887,7 +2889,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
               e->big.n_final, e->big.task_of_slot, e->d_inst_mapped, e->d_inst_arena, e->d_inst_states, e->d_inst_first, e->d_inst_width,
               e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
-  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_READS), 0, stream, b,
+  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters, e->d_stats);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
