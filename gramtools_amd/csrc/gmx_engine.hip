@@ -795,6 +795,8 @@ struct SearchOut {
   uint32_t *inst_serial_list;          // entries of inst_mapped_list the cooperative coverage kernel left to the serial one; counter [26]
   uint32_t *general_serial_list;       // the same for cover_general_list; counter [27]
   uint32_t *big_serial_list;           // ... and for the second part of big_mapped_list (coverage instance 2); counter [28]
+  uint32_t *overflow3_list;            // tasks one lane has to search with a whole large-capacity slot (a group's parts did not suffice); counter [29]
+  uint32_t split_twice;                // the extend kernel's overflow queue goes through the split search as well
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
                              // [0] all (pack kernel) [1] skipped (seed / probe kernel) [2] missing_kmer [3] no_extension
                              // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
@@ -1449,10 +1451,12 @@ struct BigOut {
 // Large-capacity pass: one lane per task that overflowed the LDS stack / parked-state / arena limits, whole read
 // from the seed, same DFS loop with global-memory pools. Persistent over the device-side overflow list.
 __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, int second) {
-  // instance 0 serves the probe kernel's overflow queue, instance 1 the extend kernel's (slots after instance 0's)
-  const uint32_t n_over = o.counters[(second ? 9 : 1) * GMX_CNT_STRIDE];
-  const uint32_t slot_base = second ? o.counters[1 * GMX_CNT_STRIDE] : 0;
-  const uint32_t *queue = second ? o.overflow2_list : o.overflow_list;
+  // instance 0 serves the probe kernel's overflow queue (index without a longer seed table); instance 1 what the
+  // 16-lane split search could not finish within a group's parts of a slot (slots after both of its instances')
+  // (second == 1, A/B runs without the second split search: the extend kernel's queue itself)
+  const uint32_t n_over = o.counters[(second == 2 ? 29 : second ? 9 : 1) * GMX_CNT_STRIDE];
+  const uint32_t slot_base = second == 2 ? o.counters[1 * GMX_CNT_STRIDE] + o.counters[9 * GMX_CNT_STRIDE] : second ? o.counters[1 * GMX_CNT_STRIDE] : 0;
+  const uint32_t *queue = second == 2 ? o.overflow3_list : second ? o.overflow2_list : o.overflow_list;
   uint32_t rounds = (n_over + gridDim.x * 64 - 1) / (gridDim.x * 64);
   for (uint32_t rd = 0; rd < rounds; ++rd) {
     // interleaved: a short queue spreads over all waves (few active lanes each) instead of filling the first ones
@@ -1535,8 +1539,12 @@ __global__ void __launch_bounds__(64) gmx_search_big_kernel(GmxIndexView ix, Bat
 // them. A task one of whose lanes runs out of its part is handed to the second instance of gmx_search_big_kernel,
 // which runs it in one lane with the whole slot.
 #define GMX_SPLIT 16u
-__global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g) {
-  const uint32_t n_over = o.counters[1 * GMX_CNT_STRIDE];
+__global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, int second) {
+  // instance 0: what gmx_seed_kernel sent here (reads in repeats); instance 1: the extend kernel's overflow queue and the
+  // tasks whose instance lanes ran out of their pools (slots after instance 0's)
+  const uint32_t n_over = o.counters[(second ? 9 : 1) * GMX_CNT_STRIDE];
+  const uint32_t slot_base = second ? o.counters[1 * GMX_CNT_STRIDE] : 0u;
+  const uint32_t *queue = second ? o.overflow2_list : o.overflow_list;
   const uint32_t groups = 64 / GMX_SPLIT, group = threadIdx.x / GMX_SPLIT, sub = threadIdx.x % GMX_SPLIT;
   const uint32_t per_round = gridDim.x * groups;
   const uint32_t part_states = g.max_states / (2 * GMX_SPLIT), part_nodes = g.max_path_nodes / GMX_SPLIT,
@@ -1544,12 +1552,12 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
   for (uint32_t base = 0; base < n_over; base += per_round) {
     const uint32_t qi = base + group * gridDim.x + blockIdx.x;  // interleaved over the blocks
     bool active = qi < n_over;
-    uint32_t task = active ? o.overflow_list[qi] : 0;
-    if (task & GMX_INST_FLAG) {  // searched by instance lanes (gmx_extend_inst_kernel)
+    uint32_t task = active ? queue[qi] : 0;
+    if (!second && (task & GMX_INST_FLAG)) {  // searched by instance lanes (gmx_extend_inst_kernel)
       active = false;
       task = 0;
     }
-    const uint32_t slot = qi;
+    const uint32_t slot = slot_base + qi;
     if (active && slot >= g.max_slots) {
       if (sub == 0) o.huge_list[atomicAdd(&o.counters[11 * GMX_CNT_STRIDE], 1u)] = task;
       active = false;
@@ -1628,7 +1636,10 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
     if (!active) continue;
     if (group_bad) {  // one lane's part did not suffice: the whole task again, in one lane with the whole slot
       if (sub == 0) {
-        o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
+        if (o.split_twice)
+          o.overflow3_list[atomicAdd(&o.counters[29 * GMX_CNT_STRIDE], 1u)] = task;
+        else
+          o.overflow2_list[atomicAdd(&o.counters[9 * GMX_CNT_STRIDE], 1u)] = task;
         g.n_final[slot] = 0;
         g.task_of_slot[slot] = task;
       }
@@ -2484,7 +2495,7 @@ struct gmx_engine {
   GmxPathNode *d_inst_arena = nullptr;
   GmxFinalState *d_inst_states = nullptr;
   uint32_t *d_inst_first = nullptr, *d_inst_width = nullptr;
-  uint32_t *d_inst_serial = nullptr, *d_general_serial = nullptr, *d_big_serial = nullptr;  // what gmx_cover_coop_kernel leaves to the serial instances
+  uint32_t *d_inst_serial = nullptr, *d_general_serial = nullptr, *d_big_serial = nullptr, *d_overflow3 = nullptr;  // what gmx_cover_coop_kernel leaves to the serial instances
   bool coop = true;  // GMX_NO_COOP=1 in the environment: serial coverage instances only (A/B runs)
   uint32_t *d_heap = nullptr;      // ... and its memory
   uint64_t heap_words = 0;
@@ -2654,6 +2665,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_inst_serial, e->big.max_slots, false))) return rc;
   if ((rc = e->alloc(&e->d_general_serial, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_big_serial, e->big.max_slots, false))) return rc;
+  if ((rc = e->alloc(&e->d_overflow3, 2 * n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_arena, (size_t)e->inst_cap * GMX_FAST_ARENA, false))) return rc;
   if ((rc = e->alloc(&e->d_inst_states, (size_t)e->inst_cap * GMX_INST_STATES, false))) return rc;
   e->cap_reads = cap;
@@ -2887,7 +2899,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
               e->d_inst_list, e->d_inst_sa, e->d_inst_remaining, e->inst_cap,
               !getenv("GMX_NO_INST") ? e->big.max_slots : 0u,
               e->big.n_final, e->big.task_of_slot, e->d_inst_mapped, e->d_inst_arena, e->d_inst_states, e->d_inst_first, e->d_inst_width,
-              e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_stats};
+              e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_overflow3, getenv("GMX_NO_SPLIT2") ? 0u : 1u, e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
                      e->d_skip, e->d_packed, e->d_counters, e->d_stats);
@@ -2928,7 +2940,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     hipLaunchKernelGGL(gmx_extend_inst_kernel, dim3(e->n_cus * 2), dim3(GMX_BLOCK), lds, e->side2_stream, e->dview, b, o, pools);
     if (e->coop) launch_cover_coop<5>(e, e->side2_stream, b, o, acc);
     launch_cover_lds<CoverEnvMid, 5>(e, e->side2_stream, b, o, acc, e->coop);
-    hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big);
+    hipLaunchKernelGGL(gmx_search_split_kernel, dim3(4096), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 0);
     launch_cover_lds<CoverEnvMid, 4>(e, e->side2_stream, b, o, acc);
   } else {
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
@@ -2952,7 +2964,11 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   // the second filter pass (the tasks the extend kernel found dead) comes first here: side 1 is busy with the first pass
   // for most of the batch, and behind the few-lane kernels below it would end after the main stream's last kernel
   launch_filter(e, e->side2_stream, task_grid, b, o, 1);
-  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
+  // the extend kernel's overflow queue (and the tasks whose instances ran out of their pools): the 16-lane split search
+  // first, one lane with a whole slot for what that leaves
+  static const bool split2 = getenv("GMX_NO_SPLIT2") == nullptr;
+  if (split2) hipLaunchKernelGGL(gmx_search_split_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, 1);
+  hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side2_stream, e->dview, b, o, e->big, split2 ? 2 : 1);
   if (e->coop) launch_cover_coop<2>(e, e->side2_stream, b, o, acc);
   launch_cover_lds<CoverEnvMid, 2>(e, e->side2_stream, b, o, acc, e->coop);
   // the general instances of the regular tasks: their queue is complete after the extend kernel unless the PRG is

@@ -67,15 +67,16 @@ d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
 d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
 d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(torch.int32).cuda()
 qm3 = Quasimapper(ix)
+stream = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
-    qm3.reset()
-    qm3.map_reads_device(d_reads, d_offs, d_seeds, n_reads)
+    qm3.reset(stream=stream)  # queued like everything else (bench.py's step)
+    qm3.map_reads_device(d_reads, d_offs, d_seeds, n_reads, stream=stream)
 qm3.sync()
 t0 = time.perf_counter()
-steps = 5
+steps = 10
 for _ in range(steps):
-    qm3.reset()
-    qm3.map_reads_device(d_reads, d_offs, d_seeds, n_reads)
+    qm3.reset(stream=stream)
+    qm3.map_reads_device(d_reads, d_offs, d_seeds, n_reads, stream=stream)
 qm3.sync()
 dt = (time.perf_counter() - t0) / steps
 print(f"device-resident: {dt * 1e3:.2f} ms per {n_reads} reads = {n_reads / dt / 1e6:.0f} M reads/s", flush=True)
