@@ -965,6 +965,7 @@ template <bool CURSOR>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t probe_iters) {
   uint32_t task = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = task < b.n_reads * 2;
+  if (task == 0) atomicAdd(&o.stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));  // all_reads_count
   uint32_t status = GMX_TASK_SKIPPED;
   bool done = false;
   FastCtx ctx;
@@ -1049,6 +1050,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
   const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
   const bool active = task < b.n_reads * 2;
+  // all_reads_count (quasimap.cpp:104): both orientations of every read, or the one a forward_only engine maps
+  if (task == 0) atomicAdd(&o.stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
   bool alive = false, dead = false, over = false, skipped = false;
   GmxSeed sd{1, 0};
   if (active) {
@@ -2356,15 +2359,15 @@ __device__ __forceinline__ uint2 pack_tail(const uint8_t *p, uint32_t rem, uint3
 }
 #define GMX_PACK_THREADS (2 * GMX_PACK_READS)  // two threads per read: twice the loads and stores in flight per LDS window
 __global__ void __launch_bounds__(GMX_PACK_THREADS) gmx_pack_kernel(BatchView b, uint8_t *skip, uint2 *packed, uint32_t *counters,
-                                                                    unsigned long long *stats) {
+                                                                    uint32_t *zero, uint32_t zero_words) {
   __shared__ uint4 in4[GMX_PACK_IN_BYTES / 16 + 2];
   __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
   // the queue counters are per batch: this is the batch's first kernel and everything that counts comes after it
-  if (blockIdx.x == 0) {
+  if (blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_THREADS) counters[i] = 0;
-    // all_reads_count (quasimap.cpp:104): both orientations of every read, or the one a forward_only engine maps
-    if (threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
-  }
+  // a reset queued just ahead of this batch (gmx_engine_reset_async): the accumulator block, read counters and log
+  // cursor zeroed here instead of by a memset of their own (nothing in this kernel touches them otherwise)
+  for (uint32_t i = blockIdx.x * GMX_PACK_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * GMX_PACK_THREADS) zero[i] = 0;
   const uint32_t r0 = blockIdx.x * GMX_PACK_READS;
   const uint32_t r1 = min(r0 + GMX_PACK_READS, b.n_reads);
   const uint32_t read = r0 + (threadIdx.x >> 1), half = threadIdx.x & 1u;  // the two threads of a read are neighbours
@@ -2504,6 +2507,11 @@ struct gmx_engine {
   std::map<std::vector<uint32_t>, uint64_t> log_counts;  // key = [site_index, ids...]
   uint64_t log_known = 0;          // log words in use after the last drain / look ...
   uint64_t log_reads_since = 0;    // ... and the reads enqueued since (each assumed to append at most GMX_LOG_WORDS_PER_READ)
+  // gmx_engine_reset_async leaves its memset pending: the next batch's pack kernel zeroes the block when it is launched
+  // on the same stream (one command and one dependent-launch gap less per job); every other reader of the accumulators
+  // issues the memset first (flush_reset)
+  bool reset_pending = false;
+  hipStream_t reset_stream = nullptr;
   hipStream_t side2_stream = nullptr;
   hipEvent_t ev_fork2 = nullptr, ev_side1 = nullptr, ev_filter = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
@@ -2558,10 +2566,19 @@ struct gmx_engine {
   }
 };
 
+static int flush_reset(gmx_engine *e) {
+  if (!e->reset_pending) return GMX_OK;
+  e->reset_pending = false;
+  HIP_TRY(hipMemsetAsync(e->d_fused, 0, (e->n_fused + 32) * 4, e->reset_stream));
+  return GMX_OK;
+}
+
 // Grouped log -> host. Waits for the device, adds the log's records to e->log_counts when more than `keep_below` words are in
 // use (and empties the device log), and notes how full it is. Records: [site_index, n_ids, ids...], each worth +1;
 // GMX_LOG_PAD words are padding (CoverLogPart::log_reserve).
 static int gmx_log_drain(gmx_engine *e, uint64_t keep_below) {
+  int frc = flush_reset(e);
+  if (frc) return frc;
   HIP_TRY(hipDeviceSynchronize());
   uint32_t used = 0;
   HIP_TRY(hipMemcpy(&used, e->d_log_cursor, 4, hipMemcpyDeviceToHost));
@@ -2844,6 +2861,7 @@ void gmx_engine_destroy(gmx_engine *e) {
 
 int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
+  e->reset_pending = false;
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(e->d_fused, 0, (e->n_fused + 32) * 4));
   HIP_TRY(hipMemset(e->d_error, 0, 8));
@@ -2856,7 +2874,10 @@ int gmx_engine_reset(gmx_engine *e) {
 int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   HIP_TRY(hipSetDevice(e->opts.device));
   hipStream_t st = (hipStream_t)hip_stream;
-  HIP_TRY(hipMemsetAsync(e->d_fused, 0, (e->n_fused + 32) * 4, st));
+  int frc = flush_reset(e);  // (an earlier one still pending, on whatever stream it named)
+  if (frc) return frc;
+  e->reset_pending = true;
+  e->reset_stream = st;
   e->log_counts.clear();  // what earlier batches left in the device log goes with the cursor
   e->log_known = e->log_reads_since = 0;
   return GMX_OK;
@@ -2879,8 +2900,17 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
+  const bool fold_reset = e->reset_pending && e->reset_stream == stream;
+  if (e->reset_pending && !fold_reset && (rc = flush_reset(e))) return rc;
+  e->reset_pending = false;
   if (e->log_sites) {  // keep the grouped log from running full: look at its cursor, drain it to the host, before it may
-    if (e->log_known + (e->log_reads_since + n_reads) * GMX_LOG_WORDS_PER_READ > e->log_cap && (rc = gmx_log_drain(e, e->log_cap / 4))) return rc;
+    if (e->log_known + (e->log_reads_since + n_reads) * GMX_LOG_WORDS_PER_READ > e->log_cap) {
+      if (fold_reset) {  // (cannot happen right after a reset: log_known and log_reads_since are zero then)
+        gmx_set_error("internal: log drain with a reset pending");
+        return GMX_EINVAL;
+      }
+      if ((rc = gmx_log_drain(e, e->log_cap / 4))) return rc;
+    }
     e->log_reads_since += n_reads;
   }
   {
@@ -2902,7 +2932,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
               e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_overflow3, getenv("GMX_NO_SPLIT2") ? 0u : 1u, e->d_stats};
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
-                     e->d_skip, e->d_packed, e->d_counters, e->d_stats);
+                     e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
@@ -3216,6 +3246,10 @@ int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) {
 
 int gmx_engine_sync(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
   uint32_t c[4] = {0, 0, 0, 0};
@@ -3309,6 +3343,10 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
 }
 
 int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   out->allele_sum = out->per_base = out->grouped = nullptr;  // interleaved in the block: use `fused`, or gmx_coverage_fetch
   out->n_allele_sum = e->n_allele;
   out->n_per_base = e->n_pb;
@@ -3321,6 +3359,10 @@ int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
 }
 
 int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   HIP_TRY(hipSetDevice(e->opts.device));
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 0);
   HIP_TRY(hipGetLastError());
@@ -3328,6 +3370,10 @@ int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
 }
 
 int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   HIP_TRY(hipSetDevice(e->opts.device));
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 1);
   HIP_TRY(hipGetLastError());
@@ -3335,6 +3381,10 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
 }
 
 int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
   std::vector<uint32_t> block(std::max<size_t>(e->n_acc, 1));
@@ -3379,6 +3429,10 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
 }
 
 int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   if (!e || (!records && n_words)) {
     gmx_set_error("gmx_coverage_import_grouped_log: null argument");
     return GMX_EINVAL;
@@ -3390,6 +3444,7 @@ int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint
 }  // extern "C"
 
 void gmx_engine_raw(gmx_engine *e, GmxEngineRaw *out) {
+  (void)flush_reset(e);
   out->device = e->opts.device;
   out->d_fused = e->d_fused;
   out->n_fused = e->n_fused;
@@ -3397,6 +3452,10 @@ void gmx_engine_raw(gmx_engine *e, GmxEngineRaw *out) {
 }
 
 int gmx_engine_log_export(gmx_engine *e, std::vector<uint32_t> &out) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   const int64_t n = gmx_coverage_fetch_grouped_log(e, nullptr, 0);
   if (n < 0) return (int)n;
   out.assign((size_t)n, 0);
@@ -3405,6 +3464,10 @@ int gmx_engine_log_export(gmx_engine *e, std::vector<uint32_t> &out) {
 }
 
 int gmx_engine_log_import(gmx_engine *e, const uint32_t *w, size_t n_words, bool replace) {
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
+  }
   if (replace) {
     int rc = gmx_log_drain(e, 0);  // whatever is still on the device belongs to the totals being replaced
     if (rc) return rc;

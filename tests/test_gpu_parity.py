@@ -182,6 +182,33 @@ def test_device_resident_entry_point_matches_host_entry_point():
     assert canonical_cov(a.coverage()) == canonical_cov(b.coverage())
 
 
+def test_async_reset_is_applied_before_the_next_batch_and_before_any_read_back():
+    """gmx_engine_reset_async leaves its memset pending for the next batch's first kernel (same stream) or for whoever
+    reads the accumulators first: either way nothing of the batches before the reset may show."""
+    import torch
+    prg, reads = _snp_workload(50000, 600, 3000, 29)
+    seeds = master_seeds(9, [3000])
+    ix = Index(prg, 8)
+    first, second = slice(0, 1500), slice(1500, 3000)
+    ref = Quasimapper(ix)
+    ref.map_reads(reads[second].reshape(-1), flat_offsets(1500, 150), seeds[second])
+    want = canonical_cov(ref.coverage())
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = [(torch.from_numpy(reads[s].reshape(-1).copy()).cuda(), torch.from_numpy(flat_offsets(1500, 150).astype(np.int64)).cuda(),
+            torch.from_numpy(seeds[s].astype(np.int64)).to(torch.int32).cuda()) for s in (first, second)]
+    qm = Quasimapper(ix)
+    qm.map_reads_device(*dev[0], 1500, stream=stream)
+    qm.reset(stream=stream)  # folded into the next launch
+    qm.map_reads_device(*dev[1], 1500, stream=stream)
+    qm.sync()
+    assert canonical_cov(qm.coverage()) == want
+    qm.reset(stream=stream)  # nothing follows: the read-back has to issue it
+    st = qm.coverage().stats.as_dict()
+    assert st["all"] == 0 and st["exact_mapped"] == 0
+    qm.map_reads(reads[second].reshape(-1), flat_offsets(1500, 150), seeds[second])  # host entry point after a pending reset
+    assert canonical_cov(qm.coverage()) == want
+
+
 def test_full_size_properties_mtb_scale():
     """configs[1] scale (4.4 Mb, 60k SNPs, k = 10): too large for the oracle in seconds, so check
     size-independent properties: every error-free read maps exactly once per read (one orientation),
