@@ -209,14 +209,23 @@ def main():
             cov_t = fused_coverage_tensor(qm)
             exchange = "torch.distributed all_reduce on the aliased block"
 
-    def step():
-        # a step is a whole job: zeroed accumulators -> map the rank's reads -> one sum-exchange of the coverage
-        qm.reset(stream=stream)
-        qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
+    def exchange_coverage():
         if comm is not None:
             comm.allreduce(stream)
         elif cov_t is not None:
             allreduce_device_coverage(qm, dist, cov_t, stream)
+
+    def job(steps, exchange_every_step=False):
+        # the job of BASELINE.json: zeroed accumulators -> `steps` batches of the rank's reads (a step = one batch through
+        # the whole kernel pipeline) -> ONE sum-exchange of the coverage at the end, as `gram genotype --devices` does it
+        qm.reset(stream=stream)
+        for _ in range(steps):
+            qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
+            if exchange_every_step:
+                exchange_coverage()
+                qm.reset(stream=stream)
+        if not exchange_every_step:
+            exchange_coverage()
 
     def fence():
         qm.sync()
@@ -224,11 +233,10 @@ def main():
         if world > 1:
             dist.barrier()
 
-    def timed(steps):
+    def timed(steps, exchange_every_step=False):
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        job(steps, exchange_every_step)
         fence()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -237,16 +245,16 @@ def main():
             dt = float(tt.item())
         return dt
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        job(args.warmup)
     dt = timed(args.steps)                       # THE timed region: exactly `steps` steps, max over ranks
     st = qm.coverage().stats.as_dict() if rank == 0 else None
+    dt_each = timed(args.steps, exchange_every_step=True)  # side figure: every step a job of its own (reset + exchange per step)
 
     # ---- roofline leg: the kernels bracketed by HIP events inside the library (a few extra, untimed steps) ----
     qm.enable_timing(True)
     fence()
-    for _ in range(5):
-        step()
+    job(5)
     fence()
     tm = qm.timing()
     qm.enable_timing(False)
@@ -290,7 +298,9 @@ def main():
                                      "achieved": b_nominal_kernel * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0,
                                      "note": "SURVEY §8(d) prices a 128 B rank block per base (the reference's algorithm); "
                                              "exceeds the HBM peak because the kernel does not move those bytes"}},
-            "stats_last_step": st,
+            "stats_job": st,
+            "every_step_its_own_job": {"value": total_reads / dt_each, "unit": "reads/s",
+                                       "note": "the same steps with zeroed accumulators before and a coverage exchange after EVERY step"},
         }
     if world == 1 and not args.no_extras:
         # ---- sustained: the same loop for >= 1 s --------------------------------------------------------------
