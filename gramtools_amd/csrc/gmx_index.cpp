@@ -4,7 +4,10 @@
 #include <algorithm>
 #include <limits>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <functional>
+#include <memory>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -384,59 +387,78 @@ struct HostCtx {
   void fail(uint32_t s) { status = s; }
 };
 
-struct SeedOut {
-  uint32_t code;
-  std::vector<uint32_t> words;  // empty => simple (a, b) stored separately
-  uint32_t a, b;
+// What one task of the seed-table enumeration produces beside the simple entries it writes straight into the tables:
+// the words of its multi-state entries (both tables, in enumeration order) and where each such entry's words start.
+struct SeedTask {
+  std::vector<uint32_t> words;
+  struct Complex {
+    uint32_t code, table, off;  // table 0: k, 1: k2; off: into `words`
+  };
+  std::vector<Complex> complex;
+  uint64_t n_present[2] = {0, 0}, n_states_all[2] = {0, 0}, n_states_large[2] = {0, 0};
+  std::vector<std::pair<uint32_t, int32_t>> tmp;
+  std::vector<std::vector<HostCtx::St>> saved;  // per depth: the states before the four extensions (no allocation per node)
 };
 
-void serialize_states(const HostCtx &ctx, SeedOut &o) {
-  bool simple = ctx.n == 1 && ctx.st[0].tvd == GMX_NIL && ctx.st[0].tvg == GMX_NIL;
+// The tasks of the enumeration differ in the RIGHTMOST bases of their k-mers, the low bits of the table index: written
+// in place, neighbouring entries would belong to different threads (every store a contended cache line). Each task
+// therefore fills a dense table of its own, indexed by the remaining high bits; a parallel pass interleaves them.
+struct SeedTables {
+  uint32_t k, k2;  // k2 = 0: no longer table
+  uint32_t shift;  // 2 x bases fixed per task
+  GmxSeed *sub, *sub2;  // this task's tables: 4^(k - split) and 4^(k2 - split) entries
+};
+
+// the entry of `code` in table `t` from the states of `ctx`
+void seed_emit(const HostCtx &ctx, uint32_t code, uint32_t t, const SeedTables &tb, SeedTask &task) {
+  GmxSeed *table = t ? tb.sub2 : tb.sub;
+  task.n_present[t]++;
+  const bool simple = ctx.n == 1 && ctx.st[0].tvd == GMX_NIL && ctx.st[0].tvg == GMX_NIL;
   if (simple) {
-    o.a = ctx.st[0].lo;
-    o.b = ctx.st[0].hi;
+    table[code >> tb.shift] = GmxSeed{ctx.st[0].lo, ctx.st[0].hi};
+    task.n_states_all[t] += 1;
     return;
   }
-  o.a = GMX_SEED_COMPLEX;
-  o.b = 0;
-  o.words.push_back(ctx.n);
-  std::vector<std::pair<uint32_t, int32_t>> tmp;
+  table[code >> tb.shift] = GmxSeed{GMX_SEED_COMPLEX, 0};  // (the word offset follows when the tasks' words are joined)
+  task.complex.push_back(SeedTask::Complex{code, t, (uint32_t)task.words.size()});
+  task.n_states_all[t] += ctx.n;
+  if (ctx.n > 4) task.n_states_large[t] += ctx.n;
+  std::vector<uint32_t> &w = task.words;
+  w.push_back(ctx.n);
   for (uint32_t s = 0; s < ctx.n; ++s) {
     auto const &st = ctx.st[s];
-    o.words.push_back(st.lo);
-    o.words.push_back(st.hi);
-    size_t at = o.words.size();
-    o.words.push_back(0);
-    o.words.push_back(0);
-    tmp.clear();
-    for (uint32_t x = st.tvd; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, ctx.arena[x].allele});
-    o.words[at] = (uint32_t)tmp.size();
-    for (size_t i = tmp.size(); i-- > 0;) {
-      o.words.push_back(tmp[i].first);
-      o.words.push_back((uint32_t)tmp[i].second);
+    w.push_back(st.lo);
+    w.push_back(st.hi);
+    size_t at = w.size();
+    w.push_back(0);
+    w.push_back(0);
+    task.tmp.clear();
+    for (uint32_t x = st.tvd; x != GMX_NIL; x = ctx.arena[x].next) task.tmp.push_back({ctx.arena[x].site, ctx.arena[x].allele});
+    w[at] = (uint32_t)task.tmp.size();
+    for (size_t i = task.tmp.size(); i-- > 0;) {
+      w.push_back(task.tmp[i].first);
+      w.push_back((uint32_t)task.tmp[i].second);
     }
-    tmp.clear();
-    for (uint32_t x = st.tvg; x != GMX_NIL; x = ctx.arena[x].next) tmp.push_back({ctx.arena[x].site, -1});
-    o.words[at + 1] = (uint32_t)tmp.size();
-    for (size_t i = tmp.size(); i-- > 0;) o.words.push_back(tmp[i].first);
+    task.tmp.clear();
+    for (uint32_t x = st.tvg; x != GMX_NIL; x = ctx.arena[x].next) task.tmp.push_back({ctx.arena[x].site, -1});
+    w[at + 1] = (uint32_t)task.tmp.size();
+    for (size_t i = task.tmp.size(); i-- > 0;) w.push_back(task.tmp[i].first);
   }
 }
 
 // Depth-first enumeration of all k-mers sharing suffixes (the reference shares them through a cache of
-// prefix diffs, build.cpp:55-86). `depth` bases (the rightmost ones) have been processed in `ctx`.
-void seed_dfs(const GmxIndexView &ix, uint32_t k, uint32_t depth, uint32_t code, HostCtx &ctx, std::vector<SeedOut> &out) {
+// prefix diffs, build.cpp:55-86). `depth` bases (the rightmost ones) have been processed in `ctx`. One walk serves
+// both tables: the states after k bases are the k table's entry, the walk goes on to k2.
+void seed_dfs(const GmxIndexView &ix, const SeedTables &tb, uint32_t depth, uint32_t code, HostCtx &ctx, SeedTask &task) {
   if (ctx.n == 0) return;  // every longer k-mer with this suffix is absent too
-  if (depth == k) {
-    SeedOut o;
-    o.code = code;
-    serialize_states(ctx, o);
-    out.push_back(std::move(o));
-    return;
-  }
+  if (depth == tb.k) seed_emit(ctx, code, 0, tb, task);
+  if (depth == tb.k2 && tb.k2 > tb.k) seed_emit(ctx, code, 1, tb, task);
+  if (depth >= (tb.k2 > tb.k ? tb.k2 : tb.k)) return;
   // snapshot
-  std::vector<HostCtx::St> saved(ctx.st.begin(), ctx.st.begin() + ctx.n);
-  uint32_t saved_n = ctx.n;
-  size_t saved_arena = ctx.arena.size();
+  std::vector<HostCtx::St> &saved = task.saved[depth];
+  saved.assign(ctx.st.begin(), ctx.st.begin() + ctx.n);
+  const uint32_t saved_n = ctx.n;
+  const size_t saved_arena = ctx.arena.size();
   for (uint32_t b = 1; b <= 4; ++b) {
     if (b > 1) {
       if (ctx.st.size() < saved_n) ctx.st.resize(saved_n);
@@ -446,7 +468,7 @@ void seed_dfs(const GmxIndexView &ix, uint32_t k, uint32_t depth, uint32_t code,
     }
     gmx_extend(ix, b, ctx, depth == 0);
     if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
-    seed_dfs(ix, k, depth + 1, code | ((b - 1) << (2 * depth)), ctx, out);
+    seed_dfs(ix, tb, depth + 1, code | ((b - 1) << (2 * depth)), ctx, task);
   }
 }
 
@@ -488,7 +510,18 @@ GmxIndexView HostIndex::view() const {
   return v;
 }
 
+// GMX_BUILD_TRACE=1 in the environment: the builder's phases with their wall times on stderr
+static void build_trace(const char *what) {
+  static const bool on = getenv("GMX_BUILD_TRACE") != nullptr;
+  static auto t_last = std::chrono::steady_clock::now();
+  if (!on) return;
+  const auto now = std::chrono::steady_clock::now();
+  fprintf(stderr, "[build %8.2f s] %s\n", std::chrono::duration<double>(now - t_last).count(), what);
+  t_last = now;
+}
+
 void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads, int seed_k2) {
+  build_trace("start");
   out = HostIndex();
   out.prg = prg;
   out.kmer_size = kmer_size;
@@ -568,6 +601,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
   out.n_allele_slots = as;
   out.n_grouped_slots = gs;
+  build_trace("graph + sites");
   // --- logical layout -> accumulator block (gmx_types.h) ---------------------------------
   {
     const size_t n_sites = out.sites.size(), n_nodes = g.nodes.size();
@@ -651,6 +685,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     out.n_acc_slots = at;
   }
 
+  build_trace("accumulator layout");
   // --- suffix array, BWT, rank blocks -----------------------------------------
   std::vector<uint32_t> text(prg);
   text.push_back(0);
@@ -715,6 +750,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     }
   }
 
+  build_trace("suffix array, BWT, rank blocks");
   // --- jump programs --------------------------------------------------------------
   // marker SA intervals: site marker -> single index; allele marker -> [C[m], C[next symbol] - 1]
   auto marker_first = [&](uint32_t m) -> uint32_t {
@@ -857,6 +893,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       out.hits.push_back(hit);
     }
   }
+  build_trace("jump programs + hit records");
   // --- PRG text records; hit records re-ordered from BWT order to text order ---------------
   {
     out.text.assign(N / 32 + 1, GmxTextRec{0, 0, 0, 0});
@@ -909,97 +946,169 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       }
   }
 
+  build_trace("text records");
   // --- seed tables -------------------------------------------------------------------
   // The k-mer index of the reference (k = kmer_size) and, when it pays, the same construction continued to a longer
   // k-mer (kmer_size2): the states after k2 matched bases are the states after k bases extended by k2 - k ordinary
   // steps, so seeding the search from the longer table skips those steps — and a reverse-complement task whose
   // last k2-mer does not occur in the PRG ends at the look-up. The final states of a read do not depend on k.
-  auto build_table = [&](uint32_t k, std::vector<GmxSeed> &seeds, std::vector<uint32_t> *bitmap, uint64_t &n_present,
-                         uint64_t &n_states_all, uint64_t &n_states_large) {
-    const uint64_t n_kmers = 1ull << (2 * k);
-    seeds.assign(n_kmers, GmxSeed{1, 0});
-    if (bitmap) bitmap->assign((n_kmers + 31) / 32, 0);
-    GmxIndexView ix = out.view();
-    // split the enumeration by the rightmost `split` bases
-    uint32_t split = k >= 3 ? 3 : k;
-    uint32_t n_tasks = 1u << (2 * split);
-    unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
-    hw = std::min<unsigned>(hw, n_tasks);
-    std::vector<std::vector<SeedOut>> results(n_tasks);
-    std::vector<std::string> errors(n_tasks);
-    auto run_task = [&](uint32_t task) {
-      try {
-        HostCtx ctx;
-        ctx.push(0, (uint32_t)n - 1, GMX_NIL, GMX_NIL);  // get_initial_cache_element, build.cpp:35-46
-        uint32_t code = 0;
-        bool alive = true;
-        for (uint32_t d = 0; d < split && alive; ++d) {
-          uint32_t b = ((task >> (2 * d)) & 3) + 1;
-          gmx_extend(ix, b, ctx, d == 0);
-          code |= (b - 1) << (2 * d);
-          if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
-          if (ctx.n == 0) alive = false;
-        }
-        if (alive) seed_dfs(ix, k, split, code, ctx, results[task]);
-      } catch (std::exception const &e) {
-        errors[task] = e.what();
-      }
-    };
-    if (hw <= 1) {
-      for (uint32_t t = 0; t < n_tasks; ++t) run_task(t);
-    } else {
-      std::vector<std::thread> pool;
-      std::atomic<uint32_t> next{0};
-      for (unsigned w = 0; w < hw; ++w)
-        pool.emplace_back([&]() {
-          for (;;) {
-            uint32_t t = next.fetch_add(1);
-            if (t >= n_tasks) break;
-            run_task(t);
-          }
-        });
-      for (auto &th : pool) th.join();
-    }
-    for (auto &e : errors)
-      if (!e.empty()) throw std::runtime_error(e);
-    // NB on the code convention: bit pair d (from the least significant end) holds the base at distance d
-    // from the right end of the k-mer, i.e. the leftmost base is most significant.
-    n_present = n_states_all = n_states_large = 0;
-    for (auto &vec : results)
-      for (auto &o : vec) {
-        GmxSeed s{o.a, o.b};
-        uint64_t n_states = 1;
-        if (o.a == GMX_SEED_COMPLEX) {
-          s.b = (uint32_t)out.seed_words.size();
-          out.seed_words.insert(out.seed_words.end(), o.words.begin(), o.words.end());
-          n_states = o.words.empty() ? 0 : o.words[0];
-        }
-        n_states_all += n_states;
-        if (n_states > 4) n_states_large += n_states;
-        seeds[o.code] = s;
-        if (bitmap) (*bitmap)[o.code >> 5] |= 1u << (o.code & 31);
-        n_present++;
-      }
-  };
   out.kmer_size2 = 0;
   out.seeds2.clear();
   if (kmer_size > 0) {
     if (kmer_size > 15) throw std::runtime_error("kmer_size > 15 is not supported");
-    build_table(kmer_size, out.seeds, &out.kmer_bitmap, out.n_seed_kmers_present, out.n_seed_states, out.n_seed_states_large);
     // longer seeds: the smallest k2 > k whose k-mer space holds >= 8 x the PRG (a k2-mer then occurs ~0.1 times on
     // average), if its direct-addressed table stays within 8 GB (k2 <= 15: 288 GB of HBM per GPU make that cheap;
-    // chr20 scale, k = 14: k2 = 15 is +8 % reads/s for +10 GB and +12 s of build)
+    // chr20 scale, k = 14: k2 = 15 is +8 % reads/s for +10 GB)
     uint32_t k2 = seed_k2 < 0 ? kmer_size : (uint32_t)seed_k2;
     if (seed_k2 < 0) {
       while (k2 < 15 && (1ull << (2 * k2)) < 8ull * (uint64_t)N) ++k2;
       if ((1ull << (2 * k2)) < 8ull * (uint64_t)N) k2 = kmer_size;  // still too dense to thin the tasks out: no second table
     }
-    if (k2 > kmer_size && k2 <= 15) {
-      uint64_t present = 0;
-      build_table(k2, out.seeds2, nullptr, present, out.n_seed_states, out.n_seed_states_large);  // the table the kernels mostly use
-      out.kmer_size2 = k2;
+    if (!(k2 > kmer_size && k2 <= 15)) k2 = 0;
+    const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    const uint64_t n_k = 1ull << (2 * kmer_size), n_k2 = k2 ? 1ull << (2 * k2) : 0;
+    // the enumeration is split by the rightmost `split` bases: 64 tasks, 256 on a host with more threads than that
+    const uint32_t split = std::min<uint32_t>(kmer_size, hw > 64 ? 4u : 3u);
+    const uint32_t n_tasks = 1u << (2 * split);
+    const uint64_t per_task = n_k >> (2 * split), per_task2 = n_k2 >> (2 * split);
+    // the final tables are sized (value-initialised: one thread, 8.6 GB for k2 = 15) beside the enumeration
+    std::thread sizing([&]() {
+      out.seeds.resize(n_k);
+      out.seeds2.resize(n_k2);
+      out.kmer_bitmap.assign((n_k + 31) / 32, 0);
+    });
+    std::unique_ptr<GmxSeed[]> sub(new GmxSeed[n_k]), sub2(new GmxSeed[std::max<uint64_t>(n_k2, 1)]);  // not initialised: every task fills its part
+    GmxIndexView ix = out.view();
+    std::vector<SeedTask> tasks(n_tasks);
+    std::vector<std::string> errors(n_tasks);
+    std::vector<std::vector<HostCtx>> level;
+    auto parallel = [&](uint32_t n_items, std::function<void(uint32_t)> fn) {
+      std::vector<std::thread> pool;
+      std::atomic<uint32_t> next{0};
+      for (unsigned w = 0; w < std::min<unsigned>(hw, n_items); ++w)
+        pool.emplace_back([&]() {
+          for (;;) {
+            uint32_t t = next.fetch_add(1);
+            if (t >= n_items) break;
+            fn(t);
+          }
+        });
+      for (auto &th : pool) th.join();
+    };
+    std::vector<double> t_fill(n_tasks, 0), t_prefix(n_tasks, 0), t_dfs(n_tasks, 0);
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto run_task = [&](uint32_t task) {
+      try {
+        const double ta = now();
+        SeedTask &tk = tasks[task];
+        tk.saved.resize((k2 ? k2 : kmer_size) + 1);
+        const SeedTables tb{kmer_size, k2, 2 * split, sub.get() + task * per_task, sub2.get() + task * per_task2};
+        std::fill(tb.sub, tb.sub + per_task, GmxSeed{1, 0});
+        std::fill(tb.sub2, tb.sub2 + per_task2, GmxSeed{1, 0});
+        const double tc = now();
+        t_fill[task] = tc - ta;
+        HostCtx ctx;  // the states after the task's `split` rightmost bases (computed below, level by level), in memory of this thread's own
+        {
+          const HostCtx &src = level[split][task];
+          ctx.st.assign(src.st.begin(), src.st.begin() + src.n);
+          ctx.n = src.n;
+          ctx.arena = src.arena;
+        }
+        if (ctx.n != 0) seed_dfs(ix, tb, split, task, ctx, tk);
+        t_dfs[task] = now() - tc;
+      } catch (std::exception const &e) {
+        errors[task] = e.what();
+      }
+    };
+    // The first `split` bases, level by level: the states after the rightmost base (LF only over the whole suffix array,
+    // then a marker pass over a quarter of all markers) are shared by every task with that base — computed per task they
+    // cost more than the rest of the walk (chr20 scale: 1350 of 3770 CPU seconds).
+    level.assign(split + 1, std::vector<HostCtx>());
+    level[0].resize(1);
+    level[0][0].push(0, (uint32_t)n - 1, GMX_NIL, GMX_NIL);  // get_initial_cache_element, build.cpp:35-46
+    {
+      const double t0 = now();
+      for (uint32_t d = 0; d < split; ++d) {
+        level[d + 1].resize((size_t)1 << (2 * (d + 1)));
+        parallel(1u << (2 * (d + 1)), [&](uint32_t child) {
+          try {
+            const uint32_t parent = child & ((1u << (2 * d)) - 1u), b = (child >> (2 * d)) + 1;
+            HostCtx ctx = level[d][parent];
+            if (ctx.n != 0) {
+              gmx_extend(ix, b, ctx, d == 0);
+              if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
+            }
+            level[d + 1][child] = std::move(ctx);
+          } catch (std::exception const &e) {
+            errors[child % n_tasks] = e.what();
+          }
+        });
+        level[d].clear();
+      }
+      t_prefix[0] = now() - t0;
     }
+    parallel(n_tasks, run_task);
+    level.clear();
+    sizing.join();
+    for (auto &e : errors)
+      if (!e.empty()) throw std::runtime_error(e);
+    build_trace("  k-mers enumerated");
+    if (getenv("GMX_BUILD_TRACE")) {
+      auto stat = [&](const char *name, const std::vector<double> &v) {
+        double sum = 0, mx = 0;
+        for (double x : v) {
+          sum += x;
+          mx = std::max(mx, x);
+        }
+        fprintf(stderr, "    %s: sum %.2f s over %u tasks, max %.2f s\n", name, sum, n_tasks, mx);
+      };
+      stat("fill", t_fill);
+      stat("first bases", t_prefix);
+      stat("walk", t_dfs);
+    }
+    {  // the tasks' tables interleaved into the final ones: entry c comes from task c mod 4^split, place c / 4^split
+      const uint32_t mask = n_tasks - 1, shift = 2 * split;
+      const uint32_t chunks = 1024;
+      parallel(chunks, [&](uint32_t ch) {
+        for (int t = 0; t < 2; ++t) {
+          const uint64_t total = t ? n_k2 : n_k, per = t ? per_task2 : per_task;
+          const GmxSeed *src = t ? sub2.get() : sub.get();
+          GmxSeed *dst = t ? out.seeds2.data() : out.seeds.data();
+          uint64_t c0 = total * ch / chunks / 32 * 32, c1 = ch + 1 == chunks ? total : total * (ch + 1) / chunks / 32 * 32;
+          for (uint64_t c = c0; c < c1; ++c) {
+            const GmxSeed sd = src[(c & mask) * per + (c >> shift)];
+            dst[c] = sd;
+            if (t == 0 && !(sd.a == 1 && sd.b == 0)) out.kmer_bitmap[c >> 5] |= 1u << (c & 31);  // whole words per chunk
+          }
+        }
+      });
+      sub.reset();
+      sub2.reset();
+    }
+    build_trace("  tables interleaved");
+    // NB on the code convention: bit pair d (from the least significant end) holds the base at distance d
+    // from the right end of the k-mer, i.e. the leftmost base is most significant.
+    // multi-state entries: the tasks' words one after the other, the entries pointed at theirs
+    uint64_t total_words = 0;
+    for (auto &tk : tasks) total_words += tk.words.size();
+    out.seed_words.reserve(total_words + 1);
+    out.n_seed_kmers_present = 0;
+    uint64_t all[2] = {0, 0}, large[2] = {0, 0};
+    for (auto &tk : tasks) {
+      const uint32_t base = (uint32_t)out.seed_words.size();
+      out.seed_words.insert(out.seed_words.end(), tk.words.begin(), tk.words.end());
+      for (auto const &c : tk.complex) (c.table ? out.seeds2 : out.seeds)[c.code] = GmxSeed{GMX_SEED_COMPLEX, base + c.off};
+      out.n_seed_kmers_present += tk.n_present[0];
+      for (int t = 0; t < 2; ++t) {
+        all[t] += tk.n_states_all[t];
+        large[t] += tk.n_states_large[t];
+      }
+    }
+    out.kmer_size2 = k2;
+    out.n_seed_states = all[k2 ? 1 : 0];  // of the table the kernels mostly use
+    out.n_seed_states_large = large[k2 ? 1 : 0];
     if (out.seed_words.empty()) out.seed_words.push_back(0);
+    build_trace("seed tables");
   }
 }
 

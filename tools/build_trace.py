@@ -1,0 +1,16 @@
+"""Index build phases at a given scale (GMX_BUILD_TRACE=1). Usage: python tools/build_trace.py GENOME N_SITES K"""
+import os
+import sys
+import time
+
+os.environ["GMX_BUILD_TRACE"] = "1"
+sys.path.insert(0, ".")
+from gramtools_amd import Index  # noqa: E402
+from gramtools_amd.synth import random_ref, snp_prg  # noqa: E402
+
+G, n_sites, k = (int(x) for x in sys.argv[1:4])
+ref = random_ref(G, 1)
+prg, pos, alts, n_alts = snp_prg(ref, n_sites, 2, multi_allelic_frac=0.05)
+t0 = time.time()
+ix = Index(prg, k)
+print(f"index: {time.time() - t0:.1f} s, {ix.info.index_bytes / 1e9:.2f} GB, k2 = {ix.info.kmer_size2}")
