@@ -52,3 +52,49 @@ def test_gpu_matches_oracle(seed):
     qm.map_reads(flat, offs, seeds)
     assert canonical_cov(qm.coverage()) == want
     assert want["stats"]["exact_mapped"] >= 2500
+
+
+def _repeated_nested_prg(seed, copies):
+    """The same block (spacer + nested region + spacer) pasted `copies` times between random spacers: a read inside
+    it has that many mapping instances, each crossing nested sites of its own copy."""
+    from gramtools_amd.synth import bracket_to_ints, nested_prg
+    rng = np.random.default_rng(seed)
+    letters = "acgt"
+
+    def spacer(n):
+        return "".join(letters[int(x)] for x in rng.integers(0, 4, size=n))
+
+    block = spacer(90) + nested_prg(seed * 31 + 1, n_top=2, max_depth=3, seq_max=5) + spacer(90)
+    parts = []
+    for _ in range(copies):
+        parts.append(spacer(int(rng.integers(150, 400))))
+        parts.append(block)
+    parts.append(spacer(300))
+    return bracket_to_ints("".join(parts))
+
+
+@pytest.mark.parametrize("seed,copies", [(1, 3), (2, 8)])
+def test_host_emulation_matches_oracle_on_repeated_nested_blocks(seed, copies):
+    prg = _repeated_nested_prg(seed, copies)
+    reads = [r for r in simulate_graph_reads(prg, 400, 70, seed + 5, n_haps=8) if len(r) >= 7]
+    seeds = (np.arange(len(reads), dtype=np.uint64) * 7919 + seed).astype(np.uint32)
+    want = oracle_map(prg, 7, reads, seeds, threads=4)
+    got, _, rc = hostemu_map(prg, 7, reads, seeds)
+    assert rc == 0
+    assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,copies", [(3, 4), (4, 9), (5, 20), (6, 70)])
+def test_gpu_matches_oracle_on_repeated_nested_blocks(seed, copies):
+    """Multi-instance tasks whose items carry nested loci: instance lanes, the cooperative coverage instance (up to 16
+    items), the one-lane instances and the split search behind them."""
+    prg = _repeated_nested_prg(seed, copies)
+    reads = [r for r in simulate_graph_reads(prg, 4000, 80, seed + 5, n_haps=8) if len(r) >= 8]
+    seeds = (np.arange(len(reads), dtype=np.uint64) * 7919 + seed).astype(np.uint32)
+    want = oracle_map(prg, 8, reads, seeds, rng_mode=seed % 2, threads=8)
+    qm = Quasimapper(Index(prg, 8), rng_mode=seed % 2)
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    assert want["stats"]["exact_mapped"] >= 2000

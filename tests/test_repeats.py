@@ -41,3 +41,22 @@ def test_gpu_matches_oracle(seed, mode):
     qm = Quasimapper(Index(prg, 10), rng_mode=mode)
     qm.map_reads(reads.reshape(-1), flat_offsets(20000, 150), seeds)
     assert canonical_cov(qm.coverage()) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("copies", [5, 17, 40, 63, 64, 70])
+def test_gpu_routes_by_number_of_copies(copies):
+    """The routes a read inside a repeat can take, by its number of mapping instances: up to 5 on the lane's own stack,
+    6..64 as instance lanes (up to 16 of them recorded by the cooperative coverage instance, more by the one-lane
+    instances up to their scratch sizes, then the large scratch), more than 64 through the split search."""
+    prg, reads = _repeat_workload(400000, 5000, 6000, 40 + copies, copies=copies - 1, seg=2000)  # the source + its pastes
+    seeds = master_seeds(copies, [6000])
+    want = oracle_map(prg, 10, list(reads), seeds, threads=8)
+    qm = Quasimapper(Index(prg, 10))
+    qm.map_reads(reads.reshape(-1), flat_offsets(6000, 150), seeds)
+    assert canonical_cov(qm.coverage()) == want
+    q = qm.queue_counts()
+    if 6 <= copies <= 64:
+        assert q["inst_mapped"] > 0, q
+    if copies > 64:
+        assert q["big_mapped"] > 0, q
