@@ -1046,100 +1046,139 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
 #define GMX_ENTRY_INST 0xC0000000u  // ... the slot of an instance-searched task (its states and nodes are in the instance pools)
 #define GMX_INST_COMPLEX 0x80000000u  // inst_sa entry: (state index << 8 | occurrence) within a multi-state seed entry
 #define GMX_INST_FLAG 0x80000000u  // overflow_list entry: the task was taken apart into instances (the split search skips it)
-#define GMX_SEED_THREADS 1024  // large blocks: one atomic per block and queue, and the queue counters are contended
+#define GMX_SEED_THREADS 1024  // large blocks: one atomic per block and queue, and the queue counters are contended ...
+#define GMX_SEED_CHUNKS 4      // ... so every thread takes four tasks (1024 apart): 512 reservations per queue and batch of 1 M
+                               // reads instead of 2048 (each costs 5-10 ns of the kernel's time: 60 -> 110 us with 256-thread blocks)
 __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView ix, BatchView b, SearchOut o) {
-  const uint32_t task = blockIdx.x * GMX_SEED_THREADS + threadIdx.x;
-  const bool active = task < b.n_reads * 2;
+  constexpr uint32_t CH = GMX_SEED_CHUNKS;
+  const uint32_t task0 = blockIdx.x * (GMX_SEED_THREADS * CH) + threadIdx.x;  // chunk j: task0 + j * GMX_SEED_THREADS
   // all_reads_count (quasimap.cpp:104): both orientations of every read, or the one a forward_only engine maps
-  if (task == 0) atomicAdd(&o.stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
-  bool alive = false, dead = false, over = false, skipped = false;
-  GmxSeed sd{1, 0};
-  if (active) {
-    const uint32_t read = task >> 1;
-    ReadRegs r;  // planes fetched on demand: one or two pairs hold the last k-mer
-    r.w = b.packed + pack_off(b, read);
-    r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
-    r.rc = (task & 1) != 0;
-    r.in_regs = false;
-    if (b.forward_only && r.rc) {
-      // not mapped, not counted
-    } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
-      const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
-      const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
-      sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
-      if (sd.a != GMX_SEED_COMPLEX) {
-        // a k2-mer with more occurrences than the per-lane stack has entries lies in a repeat: its interval splits at
-        // the copies' own sites, the task would overflow the extend kernel after holding its wave up — straight to the
-        // large-capacity pass (with the extend kernel's overflow queue)
-        over = sd.a <= sd.b && sd.b != GMX_TEXT_MARK && sd.b - sd.a >= GMX_SEED_SPLIT_MAX;
-        alive = sd.a <= sd.b && !over;
+  if (task0 == 0) atomicAdd(&o.stats[0], (unsigned long long)b.n_reads * (b.forward_only ? 1ull : 2ull));
+  enum : uint32_t { C_ALIVE = 0, C_DEAD = 1, C_OVER = 2, C_NONE = 3 };
+  uint32_t cat[CH];
+  GmxSeed sds[CH];
+  uint32_t n_skipped = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < CH; ++j) {
+    const uint32_t task = task0 + j * GMX_SEED_THREADS;
+    const bool active = task < b.n_reads * 2;
+    bool alive = false, dead = false, over = false;
+    GmxSeed sd{1, 0};
+    if (active) {
+      const uint32_t read = task >> 1;
+      ReadRegs r;  // planes fetched on demand: one or two pairs hold the last k-mer
+      r.w = b.packed + pack_off(b, read);
+      r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+      r.rc = (task & 1) != 0;
+      r.in_regs = false;
+      if (b.forward_only && r.rc) {
+        // not mapped, not counted
+      } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
+        const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
+        const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
+        sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
+        if (sd.a != GMX_SEED_COMPLEX) {
+          // a k2-mer with more occurrences than the per-lane stack has entries lies in a repeat: its interval splits at
+          // the copies' own sites, the task would overflow the extend kernel after holding its wave up — straight to the
+          // large-capacity pass (with the extend kernel's overflow queue)
+          over = sd.a <= sd.b && sd.b != GMX_TEXT_MARK && sd.b - sd.a >= GMX_SEED_SPLIT_MAX;
+          alive = sd.a <= sd.b && !over;
+        } else {
+          // a multi-state entry with a path-less state over many positions (the k2-mer spans a site in one copy of a
+          // repeat and occurs plainly in the others; flagged at upload): the large-capacity pass takes such a state apart
+          over = (sd.b & GMX_SEEDF_BIG) != 0;
+          alive = !over && !(sd.b & GMX_SEEDF_EMPTY);
+        }
+        dead = !alive && !over;
       } else {
-        // a multi-state entry with a path-less state over many positions (the k2-mer spans a site in one copy of a
-        // repeat and occurs plainly in the others; flagged at upload): the large-capacity pass takes such a state apart
-        over = (sd.b & GMX_SEEDF_BIG) != 0;
-        alive = !over && !(sd.b & GMX_SEEDF_EMPTY);
+        ++n_skipped;
       }
-      dead = !alive && !over;
-    } else {
-      skipped = true;
     }
+    cat[j] = alive ? C_ALIVE : dead ? C_DEAD : over ? C_OVER : C_NONE;
+    sds[j] = sd;
   }
-  {
-    __shared__ uint32_t n_skip;
-    gmx_block_count(o.stats, 1, skipped, &n_skip);
-  }
-  // block-aggregated appends to the alive and the dead queue
-  __shared__ uint32_t cnt[GMX_SEED_THREADS / 64][3];
-  __shared__ uint32_t base[3];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long m_alive = __ballot(alive), m_dead = __ballot(dead), m_over = __ballot(over);
-  if (lane == 0) {
-    cnt[wave][0] = (uint32_t)__popcll(m_alive);
-    cnt[wave][1] = (uint32_t)__popcll(m_dead);
-    cnt[wave][2] = (uint32_t)__popcll(m_over);
+  {  // skipped tasks (reads with a non-ACGT symbol, or shorter than k): rare, one atomic per block that has any
+    __shared__ uint32_t n_skip;
+    if (threadIdx.x == 0) n_skip = 0;
+    __syncthreads();
+    if (n_skipped) atomicAdd(&n_skip, n_skipped);
+    __syncthreads();
+    if (threadIdx.x == 0 && n_skip) atomicAdd(&o.stats[1], (unsigned long long)n_skip);
+  }
+  // block-aggregated appends to the alive, the dead and the large-capacity queue: one reservation per queue and block
+  __shared__ uint32_t cnt[CH][GMX_SEED_THREADS / 64][3];
+  __shared__ uint32_t chunk_base[CH][3];  // of a chunk's entries within the block's reservation
+  __shared__ uint32_t base[3];
+  unsigned long long mine[CH];
+#pragma unroll
+  for (uint32_t j = 0; j < CH; ++j) {
+    const unsigned long long m0 = __ballot(cat[j] == C_ALIVE), m1 = __ballot(cat[j] == C_DEAD), m2 = __ballot(cat[j] == C_OVER);
+    if (lane == 0) {
+      cnt[j][wave][0] = (uint32_t)__popcll(m0);
+      cnt[j][wave][1] = (uint32_t)__popcll(m1);
+      cnt[j][wave][2] = (uint32_t)__popcll(m2);
+    }
+    mine[j] = cat[j] == C_ALIVE ? m0 : cat[j] == C_DEAD ? m1 : m2;
   }
   __syncthreads();
   if (threadIdx.x < 3) {
     uint32_t total = 0;
-    for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) total += cnt[w][threadIdx.x];
+    for (uint32_t j = 0; j < CH; ++j) {
+      chunk_base[j][threadIdx.x] = total;
+      for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) total += cnt[j][w][threadIdx.x];
+    }
     const uint32_t counter = threadIdx.x == 0 ? 5u : threadIdx.x == 1 ? 6u : 1u;
     base[threadIdx.x] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
-  uint32_t over_at = 0;
-  if (alive || dead || over) {
-    const uint32_t c = alive ? 0 : dead ? 1 : 2;
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; ++w) before += cnt[w][c];
-    const uint32_t at = base[c] + before + (uint32_t)__popcll((alive ? m_alive : dead ? m_dead : m_over) & ((1ull << lane) - 1ull));
-    if (alive) {
+  uint32_t over_at[CH];
+#pragma unroll
+  for (uint32_t j = 0; j < CH; ++j) {
+    over_at[j] = 0;
+    const uint32_t c = cat[j];
+    if (c == C_NONE) continue;
+    const uint32_t task = task0 + j * GMX_SEED_THREADS;
+    uint32_t before = chunk_base[j][c];
+    for (uint32_t w = 0; w < wave; ++w) before += cnt[j][w][c];
+    const uint32_t at = base[c] + before + (uint32_t)__popcll(mine[j] & ((1ull << lane) - 1ull));
+    if (c == C_ALIVE) {
       o.alive_list[at] = task;
-      o.alive_seed[at] = sd;
-    } else if (dead) {
+      o.alive_seed[at] = sds[j];
+    } else if (c == C_DEAD) {
       o.dead_list[at] = task;
     } else {
-      over_at = at;
+      over_at[j] = at;
     }
   }
   // Instances of the tasks sent to the large-capacity pass whose seed is one path-less interval of at most 64 positions:
-  // block-wide exclusive scan of the instance counts, one atomic per block for the instance list.
-  uint32_t width = 0;  // instances the task splits into (0: not this way)
-  if (over && sd.a != GMX_SEED_COMPLEX) {
-    width = sd.b - sd.a + 1u;
-  } else if (over) {  // multi-state entry: one instance per occurrence of its path-less states, one per path-bearing state
-    const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
-    const uint32_t ns = *w++;
-    bool fits = ns <= GMX_INST_MAX;
-    for (uint32_t q = 0; q < ns && fits; ++q) {
-      const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
-      fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * w[2] + w[3] + 2 <= GMX_FAST_ARENA;
-      width += n_q;
-      w += 4 + 2 * w[2] + w[3];
+  // block-wide exclusive scan of the instance counts, one atomic per block for the instance list. (A chunk without
+  // such a task — every chunk of a repeat-free batch — skips this: block-uniform test.)
+  for (uint32_t j = 0; j < CH; ++j) {
+    {
+      uint32_t any = 0;
+      for (uint32_t w = 0; w < GMX_SEED_THREADS / 64; ++w) any += cnt[j][w][2];
+      if (any == 0) continue;
     }
-    if (!fits) width = 0;
-  }
-  bool expand = over && width != 0 && width <= GMX_INST_MAX && over_at < o.inst_slots;
-  {
+    const uint32_t task = task0 + j * GMX_SEED_THREADS;
+    const bool over = cat[j] == C_OVER;
+    const GmxSeed sd = sds[j];
+    uint32_t width = 0;  // instances the task splits into (0: not this way)
+    if (over && sd.a != GMX_SEED_COMPLEX) {
+      width = sd.b - sd.a + 1u;
+    } else if (over) {  // multi-state entry: one instance per occurrence of its path-less states, one per path-bearing state
+      const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+      const uint32_t ns = *w++;
+      bool fits = ns <= GMX_INST_MAX;
+      for (uint32_t q = 0; q < ns && fits; ++q) {
+        const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
+        fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * w[2] + w[3] + 2 <= GMX_FAST_ARENA;
+        width += n_q;
+        w += 4 + 2 * w[2] + w[3];
+      }
+      if (!fits) width = 0;
+    }
+    bool expand = over && width != 0 && width <= GMX_INST_MAX && over_at[j] < o.inst_slots;
     __shared__ uint32_t wsum[GMX_SEED_THREADS / 64];
     __shared__ uint32_t inst_base;
     uint32_t incl = expand ? width : 0u;
@@ -1147,6 +1186,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       const uint32_t up = __shfl_up(incl, d);
       if ((int)lane >= d) incl += up;
     }
+    __syncthreads();  // (the chunk before is done with wsum and inst_base)
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1168,31 +1208,31 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     if (expand) {
       const uint32_t first = inst_base + wsum[wave] + incl - width;
       if (sd.a != GMX_SEED_COMPLEX) {
-        for (uint32_t j = 0; j < width; ++j) {
-          o.inst_list[first + j] = (over_at << 6) | j;
-          o.inst_sa[first + j] = sd.a + j;
+        for (uint32_t i = 0; i < width; ++i) {
+          o.inst_list[first + i] = (over_at[j] << 6) | i;
+          o.inst_sa[first + i] = sd.a + i;
         }
       } else {
         const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
         const uint32_t ns = *w++;
-        uint32_t j = 0;
+        uint32_t i = 0;
         for (uint32_t q = 0; q < ns; ++q) {
           const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
-          for (uint32_t i = 0; i < n_q; ++i, ++j) {
-            o.inst_list[first + j] = (over_at << 6) | j;
-            o.inst_sa[first + j] = GMX_INST_COMPLEX | (q << 8) | i;
+          for (uint32_t x = 0; x < n_q; ++x, ++i) {
+            o.inst_list[first + i] = (over_at[j] << 6) | i;
+            o.inst_sa[first + i] = GMX_INST_COMPLEX | (q << 8) | x;
           }
           w += 4 + 2 * w[2] + w[3];
         }
       }
-      o.inst_remaining[over_at] = width;
-      o.inst_remaining_width[over_at] = width;
-      o.inst_first[over_at] = first;
-      o.slot_n_final[over_at] = 0;
-      o.slot_task[over_at] = task;
+      o.inst_remaining[over_at[j]] = width;
+      o.inst_remaining_width[over_at[j]] = width;
+      o.inst_first[over_at[j]] = first;
+      o.slot_n_final[over_at[j]] = 0;
+      o.slot_task[over_at[j]] = task;
     }
+    if (over) o.overflow_list[over_at[j]] = task | (expand ? GMX_INST_FLAG : 0u);  // unflagged: the split search serves it
   }
-  if (over) o.overflow_list[over_at] = task | (expand ? GMX_INST_FLAG : 0u);  // unflagged: the split search serves it
 }
 
 // One lane per instance (above): the search of gmx_extend_kernel for ONE text-form seed state, with the path nodes in the
@@ -2947,7 +2987,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
   const bool seeded = e->dview.kmer_size2 != 0 && !getenv("GMX_NO_SEEDED");  // longer seed table: no probe phase (gmx_seed_kernel)
   if (seeded)
-    hipLaunchKernelGGL(gmx_seed_kernel, dim3((n_tasks + GMX_SEED_THREADS - 1) / GMX_SEED_THREADS), dim3(GMX_SEED_THREADS), 0, stream,
+    hipLaunchKernelGGL(gmx_seed_kernel, dim3((n_tasks + GMX_SEED_THREADS * GMX_SEED_CHUNKS - 1) / (GMX_SEED_THREADS * GMX_SEED_CHUNKS)), dim3(GMX_SEED_THREADS), 0, stream,
                        e->dview, b, o);
   else if (e->seed_cursor)
     hipLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
