@@ -40,7 +40,7 @@
 #define GMX_BLOCK 256
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
 #ifndef GMX_STACK_DEPTH
-#define GMX_STACK_DEPTH 6
+#define GMX_STACK_DEPTH 5
 #endif
 // GMX_STACK_DEPTH: pending entries (sibling states, unresolved marker hits) per lane, in LDS
 #define GMX_STACK_WORDS 5
@@ -471,7 +471,7 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
 #define GMX_SEEDF_BIG 0x80000000u
 #define GMX_SEEDF_EMPTY 0x40000000u
 #define GMX_SEED_OFF(b) ((b) & 0x3FFFFFFFu)
-#define GMX_SEED_SPLIT_MAX 5u  // a path-less seed state over 2 .. 5 positions is taken apart in the fast pass (stack of 6)
+#define GMX_SEED_SPLIT_MAX ((uint32_t)GMX_STACK_DEPTH - 1u)  // a path-less seed state over 2 .. 4 positions is taken apart in the fast pass (stack of 5)
 // A single path-less state over ONE suffix-array position is stored in text form — a = its PRG position, b =
 // GMX_TEXT_MARK — in the device copies: the search needs no suffix-array look-up to start (one dependent, always-missing
 // fetch per task less: 64 MB of the extend kernel's 390 MB of fabric-side fetch at config[1]).
@@ -1330,8 +1330,15 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_inst_kernel(GmxIndexView
   gmx_inst_rounds(ix, b, o, pools, blockIdx.x, gridDim.x);
 }
 
+// Six waves per SIMD: 80 VGPRs (four values spilled) and, with a stack of five entries per lane, six 25 KB blocks per CU
+// instead of five of each: the kernel is bound by its lanes' chains of dependent fetches, 24 waves per CU hide more of
+// them than 20 (0.175 -> 0.162 ms; A/B on one box, whole step: +1.1 %).
+#ifndef GMX_EXTEND_WAVES
+#define GMX_EXTEND_WAVES 6
+#endif
+#define GMX_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(GMX_EXTEND_WAVES)))
 template <bool CURSOR, bool SEEDED>
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse) {
+__global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse) {
   uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   const long long t0 = GMX_CLK();
