@@ -17,6 +17,7 @@
 //   gmx_cover_kernel         the same in general (classes, seeded selection, hull), two scratch sizes
 //   (QuasimapReadsStats, quasimap.hpp:17-24, are counted by the kernels that decide each task: SearchOut::stats)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -3000,7 +3001,6 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     hipLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
   else
     hipLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
-  if (e->timing) HIP_TRY(hipEventRecord(ev.a, stream));
   // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel on a
   // side stream while the extend kernel runs, and so is the k-mer filter of the tasks the probe kernel found dead
   // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
@@ -3024,15 +3024,17 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
   }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
   launch_filter(e, e->side_stream, task_grid, b, o, 0);
+  // (timing leg: the events are attached to this very dispatch — its own start and end, as a kernel trace sees them —
+  // instead of being recorded around it, where they add the gap to the kernel before and two barrier packets)
+  hipEvent_t k0 = e->timing ? ev.a : nullptr, k1 = e->timing ? ev.b : nullptr;
   if (seeded && e->seed_cursor)
-    hipLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
   else if (seeded)
-    hipLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
   else if (e->seed_cursor)
-    hipLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
   else
-    hipLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->fuse);
-  if (e->timing) HIP_TRY(hipEventRecord(ev.b, stream));
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));

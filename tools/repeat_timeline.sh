@@ -5,7 +5,7 @@ set -u
 export TMPDIR=/tmp
 FRAC=${1:-0.002}; OUT=${2:-gpurun_out/rep}; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$FRAC -o trace -- python tools/scale_check.py 4411532 60000 10 1000000 repeats=$FRAC > $OUT/scale_$FRAC.txt 2>&1
-tail -4 $OUT/scale_$FRAC.txt
+grep "device-resident\|queues of the last" $OUT/scale_$FRAC.txt | cut -c1-400
 python - <<PY
 import csv
 rows = sorted(csv.DictReader(open("$OUT/trace_$FRAC/trace_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
