@@ -105,6 +105,9 @@ GMX_HD bool gmx_uniform_1_to_n(uint32_t seed, uint32_t n, int mode, uint32_t &re
 #ifndef GMX_COVER_PROF
 #define GMX_COVER_PROF(env, k) do { } while (0)
 #endif
+#ifndef GMX_COVER_WHY  // debug build: which capacity a task exceeded (0 loci, 1 key sites, 2 hull, 3 items)
+#define GMX_COVER_WHY(env, k) do { } while (0)
+#endif
 #define GMX_PATH_CACHE 8u  // (site, allele) pairs of an item's traversed list kept in scratch (gmx_item_loci)
 template <class Env>
 struct GmxScratch {
@@ -152,6 +155,7 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     for (uint32_t i = first; i < n; ++i)
       if (env.sget(S::loci(env) + 2 * i) == site && (int32_t)env.sget(S::loci(env) + 2 * i + 1) == allele) return true;
     if (n >= env.loc_max()) {
+      GMX_COVER_WHY(env, 0);
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }
@@ -286,6 +290,7 @@ GMX_HD bool gmx_item_key(const GmxIndexView &ix, Env &env, uint32_t it, uint32_t
     }
     if (dup) continue;
     if (len >= env.b_max()) {
+      GMX_COVER_WHY(env, 1);
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }
@@ -436,6 +441,7 @@ GMX_HD bool gmx_hull_add(Env &env, uint32_t &n_hull, uint32_t node, uint32_t seq
     return true;
   }
   if (n_hull >= env.h_max()) {
+    GMX_COVER_WHY(env, 2);
     env.fail(GMX_TASK_OVERFLOW);
     return false;
   }
@@ -856,6 +862,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
   uint32_t nonvariant = 0;  // count_nonvar_search_states, coverage_common.cpp:130-141 (uint32 arithmetic)
   auto add_item = [&](uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg, uint32_t es, int32_t ea) -> bool {
     if (n_items >= env.i_max()) {
+      GMX_COVER_WHY(env, 3);
       env.fail(GMX_TASK_OVERFLOW);
       return false;
     }

@@ -32,6 +32,7 @@
 #include "gmx_core.h"
 #ifdef GMX_LOOP_STATS  // debug build: wall time of the coverage routine's phases (tools/cover_stats.py)
 #define GMX_COVER_PROF(env, k) (env).prof(k)
+#define GMX_COVER_WHY(env, k) (env).why(k)
 #endif
 #include "gmx_cover.h"
 #include "gmx_dfs.h"
@@ -1734,6 +1735,15 @@ struct CoverAcc {
 #ifdef GMX_LOOP_STATS
 // per coverage instance (LIST): [0..7] wall time (10 ns units) per phase summed over tasks, [8..15] its maximum
 __device__ unsigned long long gmx_cover_stats[6 * 16];
+__device__ unsigned long long gmx_cover_why[8 * 4];  // per coverage instance (6, 7: cooperative item / class scratch): tasks that exceeded loci / key sites / hull / items
+extern "C" int gmx_debug_cover_why(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_cover_why), sizeof(gmx_cover_why)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8 * 4] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gmx_cover_why), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 extern "C" int gmx_debug_cover_stats(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_cover_stats), sizeof(gmx_cover_stats)) != hipSuccess) return -1;
   if (reset) {
@@ -1747,6 +1757,7 @@ struct CoverLogPart {
 #ifdef GMX_LOOP_STATS
   long long prof_t = 0;
   int prof_list = 0;
+  __device__ void why(int k) { atomicAdd(&gmx_cover_why[(prof_list & 7) * 4 + (k & 3)], 1ull); }
   __device__ void prof(int k) {
     const long long t = wall_clock64();
     atomicAdd(&gmx_cover_stats[prof_list * 16 + k], (unsigned long long)(t - prof_t));
@@ -1822,9 +1833,9 @@ struct CoverEnvDyn : CoverLogPart {
   __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[w] = v; }
 };
 
-typedef CoverEnvT<4, 4, 16, 16> CoverEnvLds;          // first tier of the general pass: per-lane scratch in the block's LDS
-typedef CoverEnvT<12, 6, 24, 24> CoverEnvMid;          // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
-typedef CoverEnvT<32, 8, 64, 64> CoverEnv;            // per-lane scratch of the regular pass
+typedef CoverEnvT<4, 12, 24, 24> CoverEnvLds;         // first tier of the general pass: per-lane scratch in the block's LDS
+typedef CoverEnvT<12, 12, 32, 32> CoverEnvMid;         // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
+typedef CoverEnvT<24, 16, 64, 64> CoverEnv;           // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
 // ---------------------------------------------------------------------------
@@ -2145,12 +2156,28 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
 // Tasks with more than 16 units, or exceeding a scratch capacity (nothing recorded by then), go to the serial instance
 // of the same queue through a reject list. One wave per block, four tasks per wave, persistent over the queue.
 // ---------------------------------------------------------------------------
-typedef CoverEnvT<1, 6, 12, 1> CoopItemEnv;    // one item: its record, key and loci window
-typedef CoverEnvT<1, 6, 24, 24> CoopClassEnv;  // the drawn class: union of loci, hull
-#define GMX_COOP_LDS_WORDS (64u * GmxScratchFixed<CoopItemEnv>::total + 4u * GmxScratchFixed<CoopClassEnv>::total)
+// Scratch sizes per instance. An item's key holds its level-0 sites: a 150-base read inside an MSA region of configs[2]
+// (a site every ~20 bases) has 9-12 of them — with room for 6, two thirds of that workload's tasks fell through to the
+// one-lane instances (whose keys were as short: the last, global-memory one then took 9 of the batch's 15 ms).
+template <int LIST>
+struct CoopSizes {  // instances 5 and 2: reads in repeats
+  typedef CoverEnvT<1, 8, 12, 1> Item;     // one item: its record, key and loci window
+  typedef CoverEnvT<1, 1, 24, 24> Class;   // the drawn class: union of loci, hull (no keys)
+};
+template <>
+struct CoopSizes<3> {  // the regular tasks' general instance
+  typedef CoverEnvT<1, 16, 24, 1> Item;
+  typedef CoverEnvT<1, 1, 48, 48> Class;
+};
+template <int LIST>
+constexpr uint32_t gmx_coop_lds_words() {
+  return 64u * GmxScratchFixed<typename CoopSizes<LIST>::Item>::total + 4u * GmxScratchFixed<typename CoopSizes<LIST>::Class>::total;
+}
 
 template <int LIST>
 __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, CoverAcc acc) {
+  typedef typename CoopSizes<LIST>::Item CoopItemEnv;
+  typedef typename CoopSizes<LIST>::Class CoopClassEnv;
   typedef GmxScratch<CoopItemEnv> SI;
   typedef GmxScratch<CoopClassEnv> SC;
   const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : 8) * GMX_CNT_STRIDE];
@@ -2171,6 +2198,10 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
   ie.log_cap = ce.log_cap = acc.log_cap;
   ie.log_sites = ce.log_sites = acc.log_sites;
   ie.log_at = ce.log_at = 0;
+#ifdef GMX_LOOP_STATS
+  ie.prof_list = 6;
+  ce.prof_list = 7;
+#endif
   const uint32_t kofs = SI::keys(ie);  // key word t of lane L: gmx_lds[(kofs + t) * 64 + L]
   for (uint32_t m0 = n_first + blockIdx.x * 4u; m0 < n; m0 += gridDim.x * 4u) {  // wave-uniform: every lane takes part in the shuffles
     const uint32_t m = m0 + grp;
@@ -2194,6 +2225,9 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
     }
     const uint32_t start = incl - w, n_units = __shfl(incl, 15, 16);
     rejected = rejected || n_units > 16u;
+#ifdef GMX_LOOP_STATS
+    if (have && gl == 0 && rejected) ie.why(3);  // more than 16 units
+#endif
     uint32_t f_lo = 0, f_hi = 0, f_tvd = GMX_NIL, f_tvg = GMX_NIL, f_start = 0;
     bool unit = false;
 #pragma unroll 4
@@ -2667,7 +2701,7 @@ static void launch_cover_lds(gmx_engine *e, hipStream_t stream, const BatchView 
 
 template <int LIST>
 static void launch_cover_coop(gmx_engine *e, hipStream_t stream, const BatchView &b, const SearchOut &o, const CoverAcc &acc) {
-  const size_t lds = (size_t)GMX_COOP_LDS_WORDS * sizeof(uint32_t);
+  const size_t lds = (size_t)gmx_coop_lds_words<LIST>() * sizeof(uint32_t);
   const uint32_t per_cu = std::min<uint32_t>((uint32_t)(160 * 1024 / lds), 16u);
   hipLaunchKernelGGL((gmx_cover_coop_kernel<LIST>), dim3(e->n_cus * per_cu), dim3(64), lds, stream, e->dview, b, o, e->big, acc);
 }
