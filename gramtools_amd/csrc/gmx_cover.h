@@ -27,6 +27,7 @@
 //   uint32_t h_site(h) / int32_t h_allele(h) / uint32_t h_next(h)            path-list handles (arena nodes, inline handles, or a
 //                                                                            compact record's entries: gmx_engine.hip CompactEnv)
 #pragma once
+#include <type_traits>
 #include "gmx_types.h"
 
 #define GMX_RNG_LEMIRE 0    // libstdc++ >= 11 uniform_int_distribution (default: the toolchain of this image)
@@ -108,7 +109,16 @@ GMX_HD bool gmx_uniform_1_to_n(uint32_t seed, uint32_t n, int mode, uint32_t &re
 #ifndef GMX_COVER_WHY  // debug build: which capacity a task exceeded (0 loci, 1 key sites, 2 hull, 3 items)
 #define GMX_COVER_WHY(env, k) do { } while (0)
 #endif
-#define GMX_PATH_CACHE 8u  // (site, allele) pairs of an item's traversed list kept in scratch (gmx_item_loci)
+#define GMX_PATH_CACHE 8u  // (site, allele) pairs of an item's traversed list kept in scratch (gmx_item_loci) ...
+// ... unless the Env says otherwise (Env::P_MAX): a read inside an MSA region of configs[2] has traversed 10-15 sites
+template <class Env, class = void>
+struct GmxPathMax {
+  static constexpr uint32_t value = GMX_PATH_CACHE;
+};
+template <class Env>
+struct GmxPathMax<Env, std::void_t<decltype(Env::P_MAX)>> {
+  static constexpr uint32_t value = Env::P_MAX;
+};
 template <class Env>
 struct GmxScratch {
   // item i: lo, hi, tvd, tvg, enc_site, enc_allele
@@ -119,11 +129,11 @@ struct GmxScratch {
   GMX_HD static uint32_t loci(const Env &e) { return keys(e) + e.i_max() * (1 + e.b_max()); }  // (site, allele)
   GMX_HD static uint32_t hull(const Env &e) { return loci(e) + e.loc_max() * 2; }             // (node, start, end)
   GMX_HD static uint32_t path(const Env &e) { return hull(e) + e.h_max() * 3; }              // copy of an item's traversed list
-  GMX_HD static uint32_t total_of(const Env &e) { return path(e) + 2 * GMX_PATH_CACHE; }
+  GMX_HD static uint32_t total_of(const Env &e) { return path(e) + 2 * GmxPathMax<Env>::value + 1; }  // + the copy's length
 };
 template <class Env>
 struct GmxScratchFixed {  // the fixed tiers: Env::I_MAX .. are compile-time constants
-  static constexpr uint32_t total = Env::I_MAX * (GmxScratch<Env>::ITEM_W + 1) + Env::I_MAX * (1 + Env::B_MAX) + Env::LOC_MAX * 2 + Env::H_MAX * 3 + 2 * GMX_PATH_CACHE;
+  static constexpr uint32_t total = Env::I_MAX * (GmxScratch<Env>::ITEM_W + 1) + Env::I_MAX * (1 + Env::B_MAX) + Env::LOC_MAX * 2 + Env::H_MAX * 3 + 2 * GmxPathMax<Env>::value + 1;
 };
 
 GMX_HD bool gmx_in_bubble(const GmxNode &n) { return n.allele != -1 && n.site != 0; }
@@ -185,7 +195,7 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
     uint32_t nt = 0;
     bool cached = true;
     for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
-      if (nt == GMX_PATH_CACHE) {
+      if (nt == GmxPathMax<Env>::value) {
         cached = false;
         break;
       }
@@ -193,6 +203,7 @@ GMX_HD uint32_t gmx_item_loci(const GmxIndexView &ix, Env &env, uint32_t it, uin
       env.sset(pc + 2 * nt + 1, (uint32_t)env.h_allele(x));
       ++nt;
     }
+    env.sset(pc + 2 * GmxPathMax<Env>::value, cached ? nt : 0xFFFFFFFFu);  // (read by the cooperative instance's class phase)
     // check_site_uniqueness over traversed + traversing
     if (cached) {
       for (uint32_t i = 0; i < nt; ++i) {

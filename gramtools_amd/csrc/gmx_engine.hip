@@ -1735,6 +1735,15 @@ struct CoverAcc {
 #ifdef GMX_LOOP_STATS
 // per coverage instance (LIST): [0..7] wall time (10 ns units) per phase summed over tasks, [8..15] its maximum
 __device__ unsigned long long gmx_cover_stats[6 * 16];
+__device__ unsigned long long gmx_coop_stats[6 * 8];  // cooperative instances: wave-level wall time of the four phases, [7] rounds
+extern "C" int gmx_debug_coop_stats(unsigned long long *out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_coop_stats), sizeof(gmx_coop_stats)) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[6 * 8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gmx_coop_stats), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
 __device__ unsigned long long gmx_cover_why[8 * 4];  // per coverage instance (6, 7: cooperative item / class scratch): tasks that exceeded loci / key sites / hull / items
 extern "C" int gmx_debug_cover_why(unsigned long long *out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gmx_cover_why), sizeof(gmx_cover_why)) != hipSuccess) return -1;
@@ -1800,9 +1809,9 @@ struct CoverLogPart {
   }
 };
 
-template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_>
+template <uint32_t I_, uint32_t B_, uint32_t LOC_, uint32_t H_, uint32_t P_ = GMX_PATH_CACHE>
 struct CoverEnvT : CoverLogPart {
-  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_;
+  static constexpr uint32_t I_MAX = I_, B_MAX = B_, LOC_MAX = LOC_, H_MAX = H_, P_MAX = P_;
   __device__ __forceinline__ static constexpr uint32_t i_max() { return I_; }
   __device__ __forceinline__ static constexpr uint32_t b_max() { return B_; }
   __device__ __forceinline__ static constexpr uint32_t loc_max() { return LOC_; }
@@ -1834,7 +1843,7 @@ struct CoverEnvDyn : CoverLogPart {
 };
 
 typedef CoverEnvT<4, 12, 24, 24> CoverEnvLds;         // first tier of the general pass: per-lane scratch in the block's LDS
-typedef CoverEnvT<12, 12, 32, 32> CoverEnvMid;         // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
+typedef CoverEnvT<12, 12, 48, 48> CoverEnvMid;         // the large-capacity pass's tasks (a read in a 10-copy repeat has ~11 items)
 typedef CoverEnvT<24, 16, 64, 64> CoverEnv;           // per-lane scratch of the regular pass
 typedef CoverEnvT<1024, 32, 1024, 1024> CoverEnvBig;  // reads with many mapping instances (repeats)
 
@@ -1983,7 +1992,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
   const uint64_t n_items = std::max<uint32_t>(gmx_count_items(ix, finals, nf), 1u);
   uint64_t cap_b = std::min<uint64_t>(std::max<uint64_t>(len + 8u, 32u), 4096u);
   if (whole_heap) cap_b = std::max<uint64_t>(cap_b, std::min<uint64_t>(65536u, scratch_words / (4 * n_items)));
-  const uint64_t fixed = n_items * (GmxScratch<CoverEnvDyn>::ITEM_W + 2 + cap_b) + 2 * GMX_PATH_CACHE;
+  const uint64_t fixed = n_items * (GmxScratch<CoverEnvDyn>::ITEM_W + 2 + cap_b) + 2 * GMX_PATH_CACHE + 1;
   if (fixed + 5 * 64 > scratch_words) return GMX_TASK_OVERFLOW;
   const uint64_t rest = std::min<uint64_t>((scratch_words - fixed) / 5, 0x0FFFFFFFull);
   env.cap_i = (uint32_t)n_items;
@@ -2160,18 +2169,19 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
 // (a site every ~20 bases) has 9-12 of them — with room for 6, two thirds of that workload's tasks fell through to the
 // one-lane instances (whose keys were as short: the last, global-memory one then took 9 of the batch's 15 ms).
 template <int LIST>
-struct CoopSizes {  // instances 5 and 2: reads in repeats
-  typedef CoverEnvT<1, 8, 12, 1> Item;     // one item: its record, key and loci window
-  typedef CoverEnvT<1, 1, 24, 24> Class;   // the drawn class: union of loci, hull (no keys)
+struct CoopSizes {  // instances 3 and 2: the regular tasks' general instance, and what the large-capacity search mapped
+  typedef CoverEnvT<1, 16, 24, 1, 24> Item;    // one item: its record, key, loci window (and the copy of its traversed list)
+  typedef CoverEnvT<1, 1, 48, 48, 8> Class;    // the drawn class: union of loci, hull (no keys; the loci come from the members' windows)
 };
 template <>
-struct CoopSizes<3> {  // the regular tasks' general instance
-  typedef CoverEnvT<1, 16, 24, 1> Item;
-  typedef CoverEnvT<1, 1, 48, 48> Class;
+struct CoopSizes<5> {  // instance 5: the instance-searched reads in repeats (many items, short paths)
+  typedef CoverEnvT<1, 8, 12, 1> Item;
+  typedef CoverEnvT<1, 1, 24, 24> Class;
 };
 template <int LIST>
-constexpr uint32_t gmx_coop_lds_words() {
-  return 64u * GmxScratchFixed<typename CoopSizes<LIST>::Item>::total + 4u * GmxScratchFixed<typename CoopSizes<LIST>::Class>::total;
+constexpr uint32_t gmx_coop_lds_words() {  // + per group: the drawn item's traversed list as path nodes (the walk's handles)
+  return 64u * GmxScratchFixed<typename CoopSizes<LIST>::Item>::total + 4u * GmxScratchFixed<typename CoopSizes<LIST>::Class>::total +
+         4u * 3u * CoopSizes<LIST>::Item::P_MAX;
 }
 
 template <int LIST>
@@ -2206,6 +2216,13 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
   for (uint32_t m0 = n_first + blockIdx.x * 4u; m0 < n; m0 += gridDim.x * 4u) {  // wave-uniform: every lane takes part in the shuffles
     const uint32_t m = m0 + grp;
     const bool have = m < n;
+#ifdef GMX_LOOP_STATS  // wave-level phase times of this instance: [0] units, [1] loci + keys, [2] classes + draw, [3] class merge + record; [7] rounds
+    long long tp = wall_clock64();
+#define GMX_COOP_PHASE(k) do { const long long tq = wall_clock64(); if (lane == 0) atomicAdd(&gmx_coop_stats[LIST * 8 + (k)], (unsigned long long)(tq - tp)); tp = tq; } while (0)
+    if (lane == 0) atomicAdd(&gmx_coop_stats[LIST * 8 + 7], 1ull);
+#else
+#define GMX_COOP_PHASE(k) do { } while (0)
+#endif
     const uint32_t entry = have ? list[m] : 0u;
     GmxTaskStates ts{0u, 0u, nullptr, nullptr};
     if (have) ts = gmx_entry_states(entry, o, g);
@@ -2268,6 +2285,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
     }
     const uint32_t items16 = (uint32_t)(__ballot(is_item) >> gbase) & 0xFFFFu;
     const uint32_t nonvariant = __popc((uint32_t)(__ballot(nonvar) >> gbase) & 0xFFFFu);
+    GMX_COOP_PHASE(0);
     // --- loci and key of the lane's item ---
     ie.arena = ts.arena;
     ie.status = GMX_TASK_MAPPED;
@@ -2279,12 +2297,16 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
       ie.sset(SI::items + 4, enc_site);
       ie.sset(SI::items + 5, (uint32_t)enc_allele);
       const uint32_t nl = gmx_item_loci(ix, ie, 0, 0);
-      if (nl != 0xFFFFFFFFu) gmx_item_key(ix, ie, 0, 0, nl);
+      if (nl != 0xFFFFFFFFu) {
+        gmx_item_key(ix, ie, 0, 0, nl);
+        ie.sset(SI::order(ie), nl);  // (the order word is free with one item: the class's first lane reads the window's length here)
+      }
     }
     uint32_t err = (is_item && ie.status != GMX_TASK_MAPPED && ie.status != GMX_TASK_OVERFLOW) ? ie.status : 0u;
     rejected = rejected || (((uint32_t)(__ballot(is_item && ie.status == GMX_TASK_OVERFLOW) >> gbase) & 0xFFFFu) != 0u);
     bool failed = (((uint32_t)(__ballot(err != 0u) >> gbase) & 0xFFFFu) != 0u);
     __syncthreads();  // the keys are in LDS
+    GMX_COOP_PHASE(1);
     // --- classes ---
     uint32_t lt = 0, eq = 0;
     if (is_item && !rejected && !failed) {
@@ -2317,6 +2339,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
       }
     }
     const uint32_t members16 = (uint32_t)(__ballot(member) >> gbase) & 0xFFFFu;
+    GMX_COOP_PHASE(2);
     // --- the drawn class: its first lane merges the members and records ---
     bool class_overflow = false;
     if (member && gl == (uint32_t)__ffs(members16) - 1u) {
@@ -2331,8 +2354,40 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
         const uint32_t other = gbase + (uint32_t)__ffs(rest) - 1u;
 #pragma unroll
         for (uint32_t t = 0; t < SI::ITEM_W; ++t) ce.sset(SC::items + t, gmx_lds[(SI::items + t) * 64u + other]);
-        ok = gmx_class_add_item(ix, ce, 0, len, n_loci, n_hull);
+        // the member's loci window as its lane left it (gmx_class_add_item would run gmx_item_loci again): set union
+        const uint32_t nl_m = gmx_lds[SI::order(ie) * 64u + other], first = n_loci;
+        for (uint32_t i = 0; i < nl_m && ok; ++i) {
+          const uint32_t site = gmx_lds[(SI::loci(ie) + 2u * i) * 64u + other], al = gmx_lds[(SI::loci(ie) + 2u * i + 1u) * 64u + other];
+          bool dup = false;
+          for (uint32_t j = 0; j < first && !dup; ++j) dup = ce.sget(SC::loci(ce) + 2u * j) == site && ce.sget(SC::loci(ce) + 2u * j + 1u) == al;
+          if (dup) continue;
+          if (n_loci >= ce.loc_max()) {
+            ce.fail(GMX_TASK_OVERFLOW);
+            ok = false;
+            break;
+          }
+          ce.sset(SC::loci(ce) + 2u * n_loci, site);
+          ce.sset(SC::loci(ce) + 2u * n_loci + 1u, al);
+          ++n_loci;
+        }
+        // The walk consumes the member's traversed list newest first, a dependent arena load per locus (the fast
+        // pass's arena keeps a task's nodes n_tasks entries apart: every one a miss). The member's lane has copied
+        // the list to its scratch: laid out as path nodes in LDS, handle = index, the walk never leaves the CU for it.
+        const uint32_t nt_m = gmx_lds[(SI::path(ie) + 2u * CoopItemEnv::P_MAX) * 64u + other];
+        if (nt_m != 0xFFFFFFFFu && nt_m != 0u && ce.sget(SC::items + 2) != GMX_NIL) {
+          GmxPathNode *ln = reinterpret_cast<GmxPathNode *>(gmx_lds + 64u * GmxScratchFixed<CoopItemEnv>::total +
+                                                            4u * GmxScratchFixed<CoopClassEnv>::total + grp * 3u * CoopItemEnv::P_MAX);
+          for (uint32_t i = 0; i < nt_m; ++i)
+            ln[i] = GmxPathNode{gmx_lds[(SI::path(ie) + 2u * i) * 64u + other], (int32_t)gmx_lds[(SI::path(ie) + 2u * i + 1u) * 64u + other],
+                                i + 1u < nt_m ? i + 1u : GMX_NIL};
+          ce.arena = ln;
+          ce.sset(SC::items + 2, 0u);
+        } else {
+          ce.arena = ts.arena;
+        }
+        ok = ok && gmx_item_per_base(ix, ce, 0, len, n_hull);
       }
+      ce.arena = ts.arena;
       if (ok) gmx_class_record(ix, ce, n_loci, n_hull);
       class_overflow = ce.status == GMX_TASK_OVERFLOW;
       if (ce.status != GMX_TASK_MAPPED && !class_overflow) err = ce.status;
@@ -2341,7 +2396,9 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
     if (have && gl == 0 && rejected) reject[atomicAdd(reject_n, 1u)] = entry;
     if (err != 0u && atomicCAS(&o.error[0], 0u, err) == 0u) o.error[1] = ts.task;
     __syncthreads();  // the scratch is reused by the next round
+    GMX_COOP_PHASE(3);
   }
+#undef GMX_COOP_PHASE
 }
 
 // Path handles of a GmxCoverRec: traversed loci are addressed by their index in the record (newest first), the

@@ -17,22 +17,25 @@ seeds = master_seeds(42, [n])
 offs = flat_offsets(n, reads.shape[1])
 qm = Quasimapper(ix)
 lib = _lib.load()
-for name, size in (("gmx_debug_cover_why", 32), ("gmx_debug_cover_stats", 96)):
+for name, size in (("gmx_debug_cover_why", 32), ("gmx_debug_cover_stats", 96), ("gmx_debug_coop_stats", 48)):
     getattr(lib, name).restype = C.c_int
     getattr(lib, name).argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 why = (C.c_ulonglong * 32)()
 stats = (C.c_ulonglong * 96)()
+cstats = (C.c_ulonglong * 48)()
 flat = np.ascontiguousarray(reads).reshape(-1)
 qm.map_reads(flat, offs, seeds)
 qm.sync()
 lib.gmx_debug_cover_why(why, 1)
 lib.gmx_debug_cover_stats(stats, 1)
+lib.gmx_debug_coop_stats(cstats, 1)
 qm.reset()
 qm.map_reads(flat, offs, seeds)
 qm.sync()
 print("queues:", qm.queue_counts())
 lib.gmx_debug_cover_why(why, 1)
 lib.gmx_debug_cover_stats(stats, 1)
+lib.gmx_debug_coop_stats(cstats, 1)
 names = {0: "one lane, regular scratch", 1: "one lane, large scratch (global memory)", 2: "one lane, large-capacity tasks",
          3: "one lane, first scratch", 4: "one lane, large-capacity tasks, first part", 5: "one lane, instance tasks",
          6: "cooperative: item scratch", 7: "cooperative: class scratch"}
@@ -46,3 +49,9 @@ for lst in range(6):
     if v[7] == 0:
         continue
     print(f"instance {lst}: {int(v[7])} tasks; mean us per task: " + ", ".join(f"{ph[k]} {v[k] / v[7] / 100:.1f}" for k in (0, 1, 2, 3, 5)))
+coop = ["units", "loci + keys", "classes + draw", "class merge + record"]
+print("cooperative instances (wave-level wall time, us per round of 4 tasks):")
+for lst in (2, 3, 5):
+    v = np.array(cstats[lst * 8:lst * 8 + 8], dtype=np.float64)
+    if v[7]:
+        print(f"  instance {lst}: {int(v[7])} rounds; " + ", ".join(f"{coop[k]} {v[k] / v[7] / 100:.1f}" for k in range(4)))
