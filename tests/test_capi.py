@@ -39,3 +39,42 @@ def test_engine_fails_loudly_without_gpu():
     with pytest.raises(GmxError) as e:
         Quasimapper(ix)
     assert e.value.code in (-2, -3)  # GMX_ENODEV / GMX_EHIP: no CPU fallback exists
+
+
+@pytest.mark.gpu
+def test_page_locked_blocks_are_kept_and_handed_out_again():
+    """gmx_host_alloc / gmx_host_free: a freed page-locked block of 1 MB or more serves the next request it fits (the
+    reads feed allocates its block buffers per file); small blocks are really freed."""
+    lib = _lib.load()
+    a = lib.gmx_host_alloc(8 << 20)
+    assert a
+    lib.gmx_host_free(a)
+    b = lib.gmx_host_alloc(6 << 20)  # fits the spare block (at most twice the request + 1 MB)
+    assert b == a
+    c = lib.gmx_host_alloc(6 << 20)  # no spare left: a new block
+    assert c and c != b
+    lib.gmx_host_free(b)
+    lib.gmx_host_free(c)
+    d = lib.gmx_host_alloc(1 << 10)  # far smaller than any spare: not served from them
+    assert d and d not in (b, c)
+    lib.gmx_host_free(d)
+
+
+@pytest.mark.gpu
+def test_reserve_sizes_the_workspace_ahead_of_the_first_call():
+    import ctypes as C
+    from gramtools_amd import Index, Quasimapper, master_seeds
+    from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads, snp_prg
+    from common import canonical_cov
+    ref = random_ref(20000, 3)
+    prg, pos, alts, n_alts = snp_prg(ref, 200, 4)
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, 3000, 150, 5)
+    seeds = master_seeds(1, [3000])
+    ix = Index(prg, 7)
+    a = Quasimapper(ix)
+    a.map_reads(reads.reshape(-1), flat_offsets(3000, 150), seeds)
+    b = Quasimapper(ix)
+    assert b.lib.gmx_engine_reserve(b.h, 5000, 5000 * 150) == 0
+    assert b.lib.gmx_engine_reserve(b.h, 100, 100) == 0  # smaller: nothing to do
+    b.map_reads(reads.reshape(-1), flat_offsets(3000, 150), seeds)
+    assert canonical_cov(a.coverage()) == canonical_cov(b.coverage())
