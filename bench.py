@@ -2,19 +2,27 @@
 """bench.py — 150 bp reads quasimapped per second (BASELINE.json metric), whole job over N GPUs.
 
 Workload (config.workload): BASELINE.json configs[1] — M. tuberculosis scale: 4 411 532 bp random reference +
-60 000 SNP sites written as a PRG, k = 10, 1 M x 150 bp error-free reads per GPU (50 % reverse strand), synthetic
-(no real genomes offline). One "step" = one pass of the hot path (search + selection + coverage atomics, forward and
-reverse complement) over the rank's 1 M reads, which are resident in HBM (one byte per base, the reference's
-encode_dna_bases form) before the timed region starts; for N > 1 every step ends with the exchange of the coverage
-(one RCCL all-reduce of the fused block, driven from inside the library: gmx_comm_allreduce_coverage — the routine
-`gram genotype --devices` uses).
+60 000 SNP sites written as a PRG, k = 10, 1 M x 150 bp error-free reads per GPU and step (50 % reverse strand),
+synthetic (no real genomes offline).
 
-`value` is a KERNEL-PIPELINE rate: no PCIe, no parsing, no file output. What a user of `gram genotype` sees is in the
-extra keys (rank 0, N = 1 only):
-  host_inclusive   SURVEY.md §8(d)'s timed region: host buffers in (H2D of the reads), coverage arrays final on the
-                   host out (D2H + gather), through gmx_map_reads_host / gmx_coverage_fetch
-  sustained        the `value` loop run for >= 1 s (clocks and thermals settle; thousands of steps)
-  cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + exchange + the three coverage files
+TIMED REGION (since round 3) = SURVEY.md §8(d)'s: host buffers in -> coverage arrays final on the host. A job is
+  zeroed accumulators -> K steps -> (N > 1) ONE exchange of the coverage (RCCL all-reduce of the fused block, driven from
+  inside the library: gmx_comm_allreduce_coverage, the routine `gram genotype --devices` uses) -> D2H of the accumulator
+  block + gather into the three coverage arrays (gmx_coverage_fetch).
+A step = one batch of DISTINCT reads (8 batches are cycled: 320 MB of packed reads, more than the 256 MiB Infinity Cache)
+handed over as 2-bit bit planes in page-locked host memory (gmx_map_reads_packed_host, the form the FASTQ parser threads of
+`gram` emit; SURVEY.md §7 "pre-encoded (2-bit packed ...) pinned-host" input): H2D of 44 B per read on a copy stream beside
+the kernels of the batches before, then the whole kernel pipeline (seed look-up, search, k-mer filter, selection, coverage
+atomics; forward and reverse complement). FASTQ parsing and the index build are outside (reported separately).
+Rounds 1 and 2 timed a narrower region as `value` (reads resident in HBM, one batch replayed, coverage left in HBM): that
+figure is still on the line as `kernel_pipeline` — the two are NOT comparable.
+
+Extra keys (rank 0; the side legs run at N = 1 only unless noted):
+  kernel_pipeline  reads resident in HBM (one byte per base), the same batch every step, coverage left in HBM
+  sustained        the `value` loop for >= 1 s
+  exchange_ms      (N > 1) the coverage exchange alone, timed between fences after the job
+  per_rank_s       (N > 1) every rank's own time for the timed job
+  cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + the three coverage files
   cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): all host threads and one thread
   roofline         gmx_extend_kernel, the dominant kernel: see DESIGN.md §8 for the byte model
 """
@@ -25,6 +33,7 @@ import subprocess
 import sys
 import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -36,31 +45,34 @@ N_SITES = 60000
 KMER = 10
 READ_LEN = 150
 READS_PER_GPU = 1_000_000
+N_BATCHES = 8                                              # distinct batches cycled by the timed loop
 B_NOMINAL_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070 B/read at k = 10
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
 # Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (DESIGN.md §8 derives each term):
 # queue entry 4 + seed directory entry 8 + packed read planes 48 + PRG text records 6 x 16 + marker sub-records 3 x 16 +
 # path nodes 2 x 12 + coverage record 32 + task id 4
 B_DESIGN_PER_READ = 4 + 8 + 48 + 6 * 16 + 3 * 16 + 2 * 12 + 32 + 4
-PROFILE_DIR = os.path.join(ROOT, "profiles", "round2")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
 
 
 def profile_json(name):
-    try:
-        with open(os.path.join(PROFILE_DIR, name)) as fh:
-            return json.load(fh)
-    except (OSError, ValueError):
-        return None
+    for d in PROFILE_DIRS:
+        try:
+            with open(os.path.join(d, name)) as fh:
+                return json.load(fh), os.path.relpath(os.path.join(d, name), ROOT)
+        except (OSError, ValueError):
+            continue
+    return None, None
 
 
 def measured_traffic(kernel):
     """HBM-side bytes per launch of `kernel` (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; tools/pmc_hbm.sh)."""
-    table = profile_json("hbm_traffic.json")
+    table, src = profile_json("hbm_traffic.json")
     try:
         k = next(v for name, v in table.items() if name.startswith(kernel))  # template instances: gmx_extend_kernel<...>
-        return int(k["fetch_bytes"] + k["write_bytes"])
+        return int(k["fetch_bytes"] + k["write_bytes"]), src
     except (TypeError, KeyError, AttributeError, StopIteration):
-        return None
+        return None, src
 
 
 def cpu_baseline(prg, reads, seeds, max_seconds=12.0):
@@ -89,38 +101,42 @@ def cpu_baseline(prg, reads, seeds, max_seconds=12.0):
     o.map_reads(reads[:n2].reshape(-1), flat_offsets(n2, READ_LEN), seeds[:n2], threads=cores)
     dt = time.time() - t0
     return {"value": n2 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n2} of the rank-0 reads, same PRG/k/seeds, OpenMP over reads ({cores} threads), {dt:.1f} s",
+            "sample": f"first {n2} of the rank-0 reads of batch 0, same PRG/k/seeds, OpenMP over reads ({cores} threads), {dt:.1f} s",
             "single_thread": {"value": n1 / dt1, "unit": "reads/s", "cores": 1, "sample": f"first {n1} reads, {dt1:.1f} s"}}
 
 
-def write_fastq(path, reads):
+def write_fastq(path, batches):
     """Four-line FASTQ of uint8 reads (1..4), fixed-width names, quality 'I': numpy only."""
-    n, L = reads.shape
     name_w = 10
-    row = np.empty((n, 1 + name_w + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
-    row[:, 0] = ord("@")
-    idx = np.arange(n)
-    for d in range(name_w):
-        row[:, 1 + d] = (idx // 10 ** (name_w - 1 - d)) % 10 + ord("0")
-    row[:, 1 + name_w] = ord("\n")
-    row[:, 2 + name_w:2 + name_w + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[reads - 1]
-    o = 2 + name_w + L
-    row[:, o] = ord("\n")
-    row[:, o + 1] = ord("+")
-    row[:, o + 2] = ord("\n")
-    row[:, o + 3:o + 3 + L] = ord("I")
-    row[:, o + 3 + L] = ord("\n")
-    row.tofile(path)
+    first = 0
+    with open(path, "wb") as fh:
+        for reads in batches:
+            n, L = reads.shape
+            row = np.empty((n, 1 + name_w + 1 + L + 1 + 2 + L + 1), dtype=np.uint8)
+            row[:, 0] = ord("@")
+            idx = np.arange(first, first + n)
+            for d in range(name_w):
+                row[:, 1 + d] = (idx // 10 ** (name_w - 1 - d)) % 10 + ord("0")
+            row[:, 1 + name_w] = ord("\n")
+            row[:, 2 + name_w:2 + name_w + L] = np.frombuffer(b"ACGT", dtype=np.uint8)[reads - 1]
+            o = 2 + name_w + L
+            row[:, o] = ord("\n")
+            row[:, o + 1] = ord("+")
+            row[:, o + 2] = ord("\n")
+            row[:, o + 3:o + 3 + L] = ord("I")
+            row[:, o + 3 + L] = ord("\n")
+            row.tofile(fh)
+            first += n
 
 
-def cli_end_to_end(prg, reads, threads):
+def cli_end_to_end(prg, batches, threads):
     """`gram build` + `gram genotype` on a FASTQ of these reads: what the Python front-end's subprocess call costs."""
     from gramtools_amd.build import build_gram
     gram = build_gram()
     with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as d:
         np.asarray(prg, dtype="<u4").tofile(os.path.join(d, "prg"))
         fq = os.path.join(d, "reads.fastq")
-        write_fastq(fq, reads)
+        write_fastq(fq, batches)
         t0 = time.time()
         b = subprocess.run([gram, "build", "--gram_dir", d, "--kmer_size", str(KMER), "--max_threads", str(threads)],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -133,16 +149,20 @@ def cli_end_to_end(prg, reads, threads):
         if b.returncode or g.returncode:
             return {"error": (b.stdout + g.stdout)[-400:]}
         t_map = t_load = None
+        feed = None
         for line in g.stdout.splitlines():
             if "Quasimap (parse + map" in line:
                 t_map = float(line.rsplit(":", 1)[1])
             if "Load data" in line:
                 t_load = float(line.rsplit(":", 1)[1])
-        n = reads.shape[0]
+            if line.strip().startswith("feed:"):
+                feed = line.strip()
+        n = sum(r.shape[0] for r in batches)
         return {"reads": n, "fastq_bytes": os.path.getsize(fq), "host_threads": threads,
                 "parse_and_map_s": t_map, "value": n / t_map if t_map else None, "unit": "reads/s",
                 "whole_call_s": t_all, "whole_call_reads_per_s": n / t_all, "index_load_s": t_load, "gram_build_s": t_build,
-                "note": "plain four-line FASTQ -> coverage files; parse_and_map = parser threads + H2D + kernels"}
+                "feed": feed,
+                "note": "plain four-line FASTQ -> coverage files; parse_and_map = parser threads (2-bit planes) + H2D + kernels"}
 
 
 def main():
@@ -150,16 +170,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step")
+    ap.add_argument("--reads", type=int, default=READS_PER_GPU, help="reads per GPU per step (weak scaling)")
+    ap.add_argument("--total-reads", type=int, default=0,
+                    help="strong scaling: this many reads per step for the WHOLE job, split over the GPUs")
+    ap.add_argument("--batches", type=int, default=N_BATCHES, help="distinct batches of reads cycled by the timed loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / sustained / cli_end_to_end")
+    ap.add_argument("--no-extras", action="store_true", help="skip kernel_pipeline / sustained / cli_end_to_end / roofline leg")
+    ap.add_argument("--cli-reads", type=int, default=4_000_000, help="reads in the FASTQ of the cli_end_to_end leg")
     ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce through torch.distributed instead of the library")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from gramtools_amd import Index, Quasimapper, master_seeds
-    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads, flat_offsets
+    from gramtools_amd import Index, Quasimapper, master_seeds, pack_reads, PinnedArray
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads_fast, flat_offsets
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -177,16 +201,27 @@ def main():
     prg, pos, alts, n_alts = snp_prg(ref, N_SITES, 2)
     ix = Index(prg, KMER)
     t_index = time.time() - t0
-    n = args.reads
-    reads = simulate_snp_reads(ref, pos, alts, n_alts, n, READ_LEN, 1000 + rank)
-    all_seeds = master_seeds(42, [n * world])          # one master stream for the whole job
-    seeds = all_seeds[rank * n:(rank + 1) * n]          # identical whatever the GPU count
+    strong = args.total_reads > 0
+    n = args.total_reads // world if strong else args.reads
+    NB = max(1, args.batches)
+    t0 = time.time()
+    threads = min(os.cpu_count() or 8, 64)
+    with ThreadPoolExecutor(max_workers=min(NB, max(1, threads // max(world, 1)))) as ex:
+        # batch j of this rank: its own random stream (distinct reads in every batch and on every rank)
+        raw = list(ex.map(lambda j: simulate_snp_reads_fast(ref, pos, alts, n_alts, n, READ_LEN, 1000 + 97 * j + rank), range(NB)))
     offs = flat_offsets(n, READ_LEN)
+    all_seeds = master_seeds(42, [n * world * NB])      # one master stream for the whole job ...
+    batches = []
+    for j in range(NB):                                 # ... read i of batch j of rank r is global read (j * world + r) * n + i
+        pk = pack_reads(raw[j].reshape(-1), offs, uniform_len=READ_LEN, threads=max(1, threads // max(world, 1)), pinned=True)
+        sd = PinnedArray(n, np.uint32)
+        sd.array[:] = all_seeds[(j * world + rank) * n:(j * world + rank + 1) * n]
+        batches.append((pk, sd))
+    t_reads = time.time() - t0
+    reads = raw[0]
+    seeds = batches[0][1].array
     qm = Quasimapper(ix, device=local_rank)
-    d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
-    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
-    d_seeds = torch.from_numpy(seeds.astype(np.int64)).to(torch.int32).cuda()
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream().cuda_stream   # the default stream: the one the host feed launches on
     from gramtools_amd.distributed import allreduce_device_coverage, fused_coverage_tensor, CoverageComm
     exchange = "none"
     comm = cov_t = None
@@ -215,52 +250,75 @@ def main():
         elif cov_t is not None:
             allreduce_device_coverage(qm, dist, cov_t, stream)
 
-    def job(steps, exchange_every_step=False):
-        # the job of BASELINE.json: zeroed accumulators -> `steps` batches of the rank's reads (a step = one batch through
-        # the whole kernel pipeline) -> ONE sum-exchange of the coverage at the end, as `gram genotype --devices` does it
-        qm.reset(stream=stream)
-        for _ in range(steps):
-            qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
-            if exchange_every_step:
-                exchange_coverage()
-                qm.reset(stream=stream)
-        if not exchange_every_step:
-            exchange_coverage()
-
     def fence():
         qm.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    def timed(steps, exchange_every_step=False):
+    def job(steps, first=0):
+        """THE job: zeroed accumulators -> `steps` batches from host memory -> one exchange -> coverage arrays on the host."""
+        qm.reset()
+        for s in range(first, first + steps):
+            pk, sd = batches[s % NB]
+            qm.map_reads_packed(pk, sd.array, use_skip=False)   # asynchronous: H2D on the copy stream beside the kernels
+        exchange_coverage()
+        return qm.coverage()                                      # waits, D2H of the accumulator block, gather
+
+    def timed(fn, *a):
         fence()
         t0 = time.perf_counter()
-        job(steps, exchange_every_step)
+        out = fn(*a)
         fence()
-        dt = time.perf_counter() - t0
+        own = time.perf_counter() - t0
+        dt = own
         if world > 1:
-            tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([own], device="cuda", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt
+        return dt, own, out
 
     # ---- side legs first (the device has idled through the index build: they also bring its clocks up) ----
-    # roofline leg: the kernels bracketed by HIP events inside the library (a few extra steps, not part of the timed region)
-    job(10)
+    extras = world == 1 and not args.no_extras
+    side = {}
+    tm = None
+    d_reads = torch.from_numpy(reads.reshape(-1)).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_seeds = torch.from_numpy(np.asarray(seeds).astype(np.int64)).to(torch.int32).cuda()
+
+    def kernel_job(steps):  # rounds 1-2's region: reads resident in HBM, the same batch every step, coverage left in HBM
+        qm.reset(stream=stream)
+        for _ in range(steps):
+            qm.map_reads_device(d_reads, d_offs, d_seeds, n, stream=stream)
+        exchange_coverage()
+
+    # roofline leg: the dominant kernel bracketed by HIP events attached to its dispatch inside the library
+    kernel_job(10)
     qm.enable_timing(True)
     fence()
-    job(5)
+    kernel_job(5)
     fence()
     tm = qm.timing()
     qm.enable_timing(False)
-    dt_each = timed(args.steps, exchange_every_step=True)  # side figure: every step a job of its own (reset + exchange per step)
+    if extras:
+        dtk, _, _ = timed(kernel_job, args.steps)
+        side["kernel_pipeline"] = {"value": n * args.steps / dtk, "unit": "reads/s", "ms_per_step": dtk / args.steps * 1e3,
+                                   "note": "rounds 1-2's `value`: reads resident in HBM (1 byte per base, gmx_pack_kernel in the "
+                                           "pipeline), ONE batch replayed, coverage left in HBM"}
 
     # ---- W warm-up steps, then THE timed region: exactly `steps` steps, max over ranks ----
     if args.warmup:
         job(args.warmup)
-    dt = timed(args.steps)
-    st = qm.coverage().stats.as_dict() if rank == 0 else None
+    dt, own, cov = timed(job, args.steps, args.warmup)
+    st = cov.stats.as_dict() if rank == 0 else None
+    per_rank = None
+    exchange_ms = None
+    if world > 1:
+        gathered = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([own], device="cuda", dtype=torch.float64))
+        per_rank = [float(g.item()) for g in gathered]
+        dte, _, _ = timed(exchange_coverage)   # the exchange alone (the block holds the job's totals: sums again, unused)
+        exchange_ms = dte * 1e3
 
     total_reads = n * world * args.steps
     value = total_reads / dt
@@ -271,24 +329,37 @@ def main():
         achieved = B_DESIGN_PER_READ * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0
         k_seed = max(KMER, int(ix.info.kmer_size2))
         b_nominal_kernel = 128 * (READ_LEN - k_seed) + READ_LEN  # the part of the nominal figure this kernel is credited with
-        sq = profile_json("sq_extend.json") or {}
+        sq, sq_src = profile_json("sq_extend.json")
+        sq = sq or {}
+        traffic, traffic_src = measured_traffic("gmx_extend_kernel")
+        h2d_per_read = 8 * ((READ_LEN + 31) // 32) + 4
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32", "data": "synthetic",
-            "value_is": "kernel-pipeline rate: reads resident in HBM, coverage left in HBM (see host_inclusive, cli_end_to_end)",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "value_is": "SURVEY §8(d) region: host buffers in (2-bit planes, page-locked) -> H2D -> kernels -> (N > 1: one exchange) "
+                        "-> D2H: coverage arrays final on the host; distinct reads every step",
+            "timed_region": "changed in round 3: rounds 1-2 timed the kernel pipeline only (reads resident in HBM, one batch replayed, "
+                            "coverage left in HBM; that figure is the key `kernel_pipeline`), and N > 1 jobs do ONE exchange at the "
+                            "end of the job, not one per step: values of different rounds are not comparable",
             "config": {"workload": "configs[1]: M. tuberculosis scale, 4411532 bp random ref + 60000 SNP PRG, k=10, "
-                                   f"{n} x 150 bp reads per GPU per step, fwd+rc, reads resident in HBM",
-                       "reads_per_gpu": n, "read_len": READ_LEN, "kmer_size": KMER, "parallelism": f"reads sharded x{world}, "
-                       "index replicated, one RCCL all-reduce of coverage per step", "exchange": exchange,
-                       "index_build_s": round(t_index, 2), "index_bytes": int(ix.info.index_bytes)},
+                                   f"{n} x 150 bp reads per GPU per step, fwd+rc, {NB} distinct batches cycled, reads handed over as "
+                                   "2-bit planes in page-locked host memory",
+                       "reads_per_gpu": n, "read_len": READ_LEN, "kmer_size": KMER, "distinct_batches": NB,
+                       "h2d_bytes_per_read": h2d_per_read,
+                       "parallelism": f"reads sharded x{world} by global read index, index replicated, one RCCL all-reduce of the "
+                                      "coverage block per JOB (after the last step), then D2H",
+                       "exchange": exchange, "index_build_s": round(t_index, 2), "reads_generation_s": round(t_reads, 2),
+                       "index_bytes": int(ix.info.index_bytes)},
+            "h2d_rate_GBps": h2d_per_read * value / world / 1e9,
             "roofline": {"bound": "hbm", "kernel": "gmx_extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic("gmx_extend_kernel"),
-                         "traffic_source": "profiles/round2/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
                          "alg_bytes_per_read": B_DESIGN_PER_READ,
                          "alg_bytes_model": "text-form states: 16 B of PRG per 32 bases + one 16 B sub-record per marker (DESIGN.md §8)",
                          "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
+                         "measured": "HIP events attached to the dispatch (hipExtLaunchKernelGGL), reads resident in HBM leg",
                          "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
                          "what_bounds_it": "the rate of 64-byte transactions behind the XCD L2 (scattered 12-16 byte payloads), not HBM "
                                            "bandwidth and not instruction issue (DESIGN.md §4)",
@@ -296,41 +367,29 @@ def main():
                                    "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
                                    "iterations_per_wave": sq.get("iterations_per_wave"),
                                    "heavy_steps_per_lane": sq.get("heavy_steps_per_lane"),
-                                   "source": "profiles/round2/sq_extend.json (rocprofv3 --pmc SQ counters + GMX_LOOP_STATS build)"},
+                                   "source": f"{sq_src} (rocprofv3 --pmc SQ counters + GMX_LOOP_STATS build)"},
                          "nominal": {"bytes_per_read": b_nominal_kernel, "bytes_per_read_whole_path": B_NOMINAL_PER_READ,
                                      "achieved": b_nominal_kernel * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0,
                                      "note": "SURVEY §8(d) prices a 128 B rank block per base (the reference's algorithm); "
                                              "exceeds the HBM peak because the kernel does not move those bytes"}},
             "stats_job": st,
-            "every_step_its_own_job": {"value": total_reads / dt_each, "unit": "reads/s",
-                                       "note": "the same steps with zeroed accumulators before and a coverage exchange after EVERY step"},
         }
-    if world == 1 and not args.no_extras:
+        out.update(side)
+        if per_rank is not None:
+            out["per_rank_s"] = per_rank
+            out["exchange_ms"] = exchange_ms
+    if extras:
         # ---- sustained: the same loop for >= 1 s --------------------------------------------------------------
         per_step = dt / args.steps
         k = max(int(1.25 / per_step), args.steps)
-        dts = timed(k)
+        dts, _, _ = timed(job, k)
         out["sustained"] = {"seconds": dts, "steps": k, "reads": k * n, "value": k * n / dts, "unit": "reads/s"}
-        # ---- host inclusive (SURVEY §8(d) timed region): host buffers -> coverage arrays on the host --------------
-        flat = np.ascontiguousarray(reads.reshape(-1))
-        qm.reset()
-        qm.map_reads(flat, offs, seeds)              # warm-up (staging buffers, registration)
-        reps = 4
-        qm.reset()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            qm.map_reads(flat, offs, seeds)
-        cov = qm.coverage()                           # D2H of the accumulator block + gather into the three arrays
-        dth = time.perf_counter() - t0
-        out["host_inclusive"] = {"value": reps * n / dth, "unit": "reads/s", "reads": reps * n, "seconds": dth,
-                                 "includes": "H2D of 1 byte per base (pageable numpy -> staged), kernels, D2H of the coverage block",
-                                 "exact_mapped": cov.stats.as_dict()["exact_mapped"]}
         # ---- the executable on a FASTQ file -----------------------------------------------------------------------
-        big = reads if n >= 2_000_000 else np.concatenate([reads, simulate_snp_reads(ref, pos, alts, n_alts, n, READ_LEN, 77)])
-        out["cli_end_to_end"] = cli_end_to_end(prg, big, min(os.cpu_count() or 8, 64))
+        n_cli = max(1, min(NB, -(-args.cli_reads // n)))
+        out["cli_end_to_end"] = cli_end_to_end(prg, raw[:n_cli], min(os.cpu_count() or 8, 64))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prg, reads, seeds)
+            out["cpu_baseline"] = cpu_baseline(prg, reads, np.asarray(seeds))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

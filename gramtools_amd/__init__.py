@@ -7,6 +7,9 @@ interface. See DESIGN.md for the path, the boundary and the data layout.
 from .quasimap import (  # noqa: F401
     Index,
     Quasimapper,
+    PackedReads,
+    PinnedArray,
+    pack_reads,
     QuasimapperGroup,
     Coverage,
     QuasimapReadsStats,

@@ -85,6 +85,10 @@ SYMBOLS = {
     "gmx_engine_reset_async": (C.c_int, [_vp, _vp]),
     "gmx_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
     "gmx_map_reads_device": (C.c_int, [_vp, _vp, _vp, _vp, _u64, _u64, _vp]),
+    "gmx_map_reads_packed_host": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u64]),
+    "gmx_engine_sync_uploads": (C.c_int, [_vp]),
+    "gmx_packed_pairs": (_u64, [_u64p, _u32, _u64]),
+    "gmx_pack_reads": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
     "gmx_engine_reserve": (C.c_int, [_vp, _u64, _u64]),
     "gmx_host_alloc": (_vp, [_u64]),
     "gmx_host_free": (None, [_vp]),
@@ -114,6 +118,8 @@ SYMBOLS = {
     "gmx_group_engine": (_vp, [_vp, C.c_int]),
     "gmx_group_uses_rccl": (C.c_int, [_vp]),
     "gmx_group_map_reads_host": (C.c_int, [_vp, _u8p, _u64p, _u32p, _u64]),
+    "gmx_group_map_reads_packed_host": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u64]),
+    "gmx_group_sync_uploads": (C.c_int, [_vp]),
     "gmx_group_allreduce": (C.c_int, [_vp]),
     "gmx_comm_unique_id": (C.c_int, [_u8p]),
     "gmx_comm_create": (C.c_int, [_u8p, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
@@ -129,11 +135,12 @@ def load(build=True):
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB):
-        if not build:
-            raise ImportError(f"{LIB} is missing: run `python -m gramtools_amd.build` (needs hipcc)")
+    path = os.environ.get("GMX_LIB", LIB)  # (tests: another build of the same sources, e.g. lib/libgmx_alt.so)
+    if not os.path.exists(path):
+        if not build or path != LIB:
+            raise ImportError(f"{path} is missing: run `python -m gramtools_amd.build` (needs hipcc)")
         build_library()
-    lib = C.CDLL(LIB)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         f = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
         f.restype = res

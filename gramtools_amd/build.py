@@ -39,6 +39,23 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+LIB_ALT = os.path.join(LIB_DIR, "libgmx_alt.so")
+
+
+def build_library_alt(force=False, verbose=False):
+    """Test build with -DGMX_SEARCHOUT_ALT: SearchOut in the member order that made the round-2 compiler emit a wrong
+    gmx_probe_kernel. tests/test_searchout_layout.py runs the probe pipeline with both builds."""
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(LIB_ALT, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [HIPCC] + FLAGS + ["-DGMX_SEARCHOUT_ALT", "-shared", "-o", LIB_ALT] + srcs + ["-lpthread", "-ldl", "-lz"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB_ALT
+
+
 def build_gram(force=False, verbose=False):
     src = os.path.join(CSRC, "gram_main.cpp")
     if not os.path.exists(src):
@@ -57,6 +74,7 @@ def build_gram(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_library_alt(force="--force" in sys.argv, verbose=True))
     g = build_gram(force="--force" in sys.argv, verbose=True)
     if g:
         print(g)

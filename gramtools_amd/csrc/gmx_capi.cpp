@@ -6,6 +6,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gmx_core.h"
@@ -446,6 +447,91 @@ int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint6
         uint32_t s = next();
         if (start + i < reads_per_file[f]) out[o++] = s;
       }
+  return GMX_OK;
+}
+
+// ---- bit planes of encoded reads on the host (the form gmx_map_reads_packed_host uploads as it is) -------------------
+uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) {
+  if (uniform_len) return n_reads * (uint64_t)((uniform_len + 31u) / 32u);
+  if (!offsets) return 0;
+  return ((offsets[n_reads] >> 5) - (offsets[0] >> 5)) + n_reads;
+}
+
+namespace {
+// 8 encoded bases (bytes 1..4, base j in byte j) -> 8 bits of each plane; flags bytes outside 1..4 (gmx_pack_kernel's pack4)
+inline void pack8(uint64_t x, uint32_t &lo, uint32_t &hi, uint64_t &bad) {
+  const uint64_t y = x - 0x0101010101010101ull;
+  bad |= (y & ~x & 0x8080808080808080ull) | (y & 0xFCFCFCFCFCFCFCFCull);
+  lo = (uint32_t)(((y & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+  hi = (uint32_t)((((y >> 1) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+}
+// one read: ceil(len / 32) pairs at out; returns true when it holds a byte outside 1..4
+inline bool pack_read(const uint8_t *p, uint32_t len, uint64_t *out) {
+  uint64_t bad = 0;
+  uint32_t i = 0, pair = 0;
+  for (; i + 32 <= len; i += 32, ++pair) {
+    uint32_t lo = 0, hi = 0;
+    for (int j = 0; j < 4; ++j) {
+      uint64_t x;
+      memcpy(&x, p + i + 8 * j, 8);
+      uint32_t l, h;
+      pack8(x, l, h, bad);
+      lo |= l << (8 * j);
+      hi |= h << (8 * j);
+    }
+    out[pair] = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  if (i < len) {
+    uint32_t lo = 0, hi = 0;
+    for (uint32_t j = 0; i + j < len; ++j) {
+      const uint32_t x = p[i + j];
+      if (x < 1 || x > 4) bad = 1;
+      lo |= ((x - 1u) & 1u) << j;
+      hi |= (((x - 1u) >> 1) & 1u) << j;
+    }
+    out[pair] = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  return bad != 0;
+}
+}  // namespace
+
+int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *planes,
+                   uint8_t *skip, int threads) {
+  if ((!reads && n_reads) || !offsets || !planes) {
+    gmx_set_error("gmx_pack_reads: null argument");
+    return GMX_EINVAL;
+  }
+  if (uniform_len)
+    for (uint64_t r = 0; r < n_reads; ++r)
+      if (offsets[r + 1] - offsets[r] != uniform_len) {
+        gmx_set_error("gmx_pack_reads: uniform_len given but read " + std::to_string(r) + " has another length");
+        return GMX_EINVAL;
+      }
+  const uint64_t n_pairs = gmx_packed_pairs(offsets, uniform_len, n_reads);
+  const uint32_t ppr = (uniform_len + 31u) / 32u;
+  const unsigned T = (unsigned)std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 256));
+  auto work = [&](unsigned t) {
+    const uint64_t r0 = n_reads * t / T, r1 = n_reads * (t + 1) / T;
+    for (uint64_t r = r0; r < r1; ++r) {
+      const uint64_t at = uniform_len ? r * ppr : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r;
+      const uint64_t next = uniform_len ? (r + 1) * ppr : ((offsets[r + 1] >> 5) - (offsets[0] >> 5)) + r + 1;
+      const uint32_t len = (uint32_t)(offsets[r + 1] - offsets[r]);
+      const bool bad = pack_read(reads + offsets[r], len, planes + at);
+      for (uint64_t q = at + (len + 31u) / 32u; q < next; ++q) planes[q] = 0;  // the gap pairs of the offsets form
+      if (skip) skip[r] = bad ? 1 : 0;
+    }
+  };
+  if (T == 1 || n_reads < 4096) {
+    const unsigned keep = T;
+    (void)keep;
+    for (unsigned t = 0; t < T; ++t) work(t);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  (void)n_pairs;
   return GMX_OK;
 }
 

@@ -738,17 +738,28 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
 }
 
 struct BatchView {
-  const uint8_t *reads;      // caller's buffer: one byte per base
-  const uint64_t *offsets;
+  const uint8_t *reads;      // caller's buffer: one byte per base (null when the caller handed over bit planes)
+  const uint64_t *offsets;   // n_reads + 1 base offsets; null when uniform_len != 0
   const uint32_t *seeds;
-  const uint8_t *skip;       // per read: holds a non-ACGT byte
-  const uint2 *packed;       // bit-plane copy written by gmx_pack_kernel; read r starts at pair pack_off(r)
+  const uint8_t *skip;       // per read: holds a non-ACGT byte (null: no such read in the batch)
+  const uint2 *packed;       // bit planes: written by gmx_pack_kernel, or uploaded as they are (gmx_map_reads_packed_host);
+                             // read r starts at pair pack_off(r)
   uint32_t n_reads;
   uint32_t forward_only;
+  uint32_t uniform_len;      // != 0: every read has this many bases and starts at pair r * pairs_per_read (no offsets)
+  uint32_t pairs_per_read;   // ceil(uniform_len / 32)
 };
+// Layout of the bit planes (include/gmx.h, gmx_pack_reads): P(r) = (offsets[r] >> 5) + r pairs from P(0) — ceil(len/32)
+// pairs fit between consecutive starts whatever the offsets are, and a sub-range of a packed batch is again a packed
+// batch (the host feed uploads chunks of one); reads of one length are packed back to back.
 __device__ __forceinline__ uint64_t pack_off(const BatchView &b, uint32_t read) {
-  return ((b.offsets[read] - b.offsets[0]) >> 5) + read;  // ceil(len/32) pairs fit between consecutive starts
+  if (b.uniform_len) return (uint64_t)read * b.pairs_per_read;
+  return ((b.offsets[read] >> 5) - (b.offsets[0] >> 5)) + read;
 }
+__device__ __forceinline__ uint32_t read_len(const BatchView &b, uint32_t read) {
+  return b.uniform_len ? b.uniform_len : (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+}
+__device__ __forceinline__ bool read_skipped(const BatchView &b, uint32_t read) { return b.skip && b.skip[read]; }
 
 struct SearchOut {
   uint32_t *status;          // per task
@@ -759,12 +770,22 @@ struct SearchOut {
   uint32_t *cover_rec_task;  // their task ids (error reporting); counters [16 + r]
   uint32_t region_cap;       // capacity of one region list
   uint32_t region_inv;       // ceil(2^32 * GMX_REGIONS / n_prg): region = umulhi(position, region_inv)
+  // The six task-id queues finish_lane appends to are slices of ONE allocation, `task_lists` (slice q at q * list_stride,
+  // GMX_TL_*), and finish_lane addresses them as base + integer index: a lane-divergent chain of selects between six
+  // queue POINTERS held in spilled SGPRs is what the compiler got wrong in round 2 (the VGPR copy of the
+  // cover_general_list pointer was emitted in a sibling block, under another exec mask). The named members below point
+  // into the same allocation for the kernels that read one queue.
+  uint32_t *task_lists;
+  uint32_t list_stride;
   uint32_t *overflow_list;   // task ids to re-run with large capacities (from the probe kernel); counter [1]
   uint32_t *overflow2_list;  // the same from the extend kernel; counter [9]
   uint32_t *cover_overflow_list;  // mapped_list entries whose selection needs the large scratch
   uint32_t *big_mapped_list;  // big-pass slots with final states (bit 31 set); counter [7]
   uint32_t *cover_mid_list;      // general tasks whose selection did not fit the LDS scratch; counter [13]
   uint32_t *cover_general_list;  // mapped_list entries that are not single-instance tasks; counter [8]
+#ifdef GMX_SEARCHOUT_ALT  // test build (tools/searchout_alt.sh): the member order that broke gmx_probe_kernel in round 2
+  unsigned long long *stats;
+#endif
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter: the probe kernel's (counter [6])
   uint32_t *dead2_list;      // ... and the extend kernel's (counter [12]); one filter pass each
@@ -799,16 +820,15 @@ struct SearchOut {
   uint32_t *big_serial_list;           // ... and for the second part of big_mapped_list (coverage instance 2); counter [28]
   uint32_t *overflow3_list;            // tasks one lane has to search with a whole large-capacity slot (a group's parts did not suffice); counter [29]
   uint32_t split_twice;                // the extend kernel's overflow queue goes through the split search as well
+#ifndef GMX_SEARCHOUT_ALT
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
+#endif
                              // [0] all (pack kernel) [1] skipped (seed / probe kernel) [2] missing_kmer [3] no_extension
                              // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
-  // (append new members here. With this member placed before alive_list, gmx_probe_kernel appended mapped tasks to
-  // dead_list and dead tasks past it — IT2 / IT3 of the golden vectors caught it — although its kernarg loads were
-  // right for that layout; the queue pointers live in spilled SGPRs (v_readlane) in that kernel, and the spill
-  // pattern changes with the member order: a code generation problem is suspected. tests/test_gpu_parity.py guards it.)
 };
 
 #define GMX_REGIONS 8
+enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_N };
 
 // stats[idx] += number of threads of the block with `flag` (one global atomic per block). Every thread of the block
 // must call it. `scratch` is one uint32 of LDS per call site.
@@ -825,7 +845,7 @@ __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) 
   uint32_t read = task >> 1;
   ReadRef r;
   r.w = b.packed + pack_off(b, read);
-  r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+  r.len = read_len(b, read);
   r.rc = task & 1;
   r.cur_idx = 0xFFFFFFFFu;
   r.cur = make_uint2(0, 0);
@@ -834,7 +854,7 @@ __device__ __forceinline__ ReadRef task_read(const BatchView &b, uint32_t task) 
 
 __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task, ReadRegs &r) {
   const uint32_t read = task >> 1;
-  r.load(b.packed + pack_off(b, read), (uint32_t)(b.offsets[read + 1] - b.offsets[read]), (task & 1) != 0);
+  r.load(b.packed + pack_off(b, read), read_len(b, read), (task & 1) != 0);
 }
 
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
@@ -949,11 +969,11 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       o.cover_recs[(size_t)cat * o.region_cap + at] = rec;
       o.cover_rec_task[(size_t)cat * o.region_cap + at] = task;
     } else {
-      uint32_t *list = cat == Q_OVER ? (second_phase ? o.overflow2_list : o.overflow_list)
-                       : cat == Q_ALIVE ? o.alive_list
-                       : cat == Q_DEAD  ? (second_phase ? o.dead2_list : o.dead_list)
-                                        : o.cover_general_list;
-      list[at] = task;
+      const uint32_t q = cat == Q_OVER ? (second_phase ? GMX_TL_OVERFLOW2 : GMX_TL_OVERFLOW)
+                         : cat == Q_ALIVE ? GMX_TL_ALIVE
+                         : cat == Q_DEAD  ? (second_phase ? GMX_TL_DEAD2 : GMX_TL_DEAD)
+                                          : GMX_TL_GENERAL;
+      o.task_lists[(size_t)q * o.list_stride + at] = task;
     }
   }
 }
@@ -996,7 +1016,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     task_read_regs(b, task, r);
     if (b.forward_only && r.rc) {
       status = GMX_STATUS_IGNORED;
-    } else if (!b.skip[task >> 1] && r.len >= ix.kmer_size && r.len > 0) {
+    } else if (!read_skipped(b, task >> 1) && r.len >= ix.kmer_size && r.len > 0) {
       // reads long enough are seeded from the longer table (gmx_index.cpp): fewer steps, and most reverse-complement
       // tasks end here because their last k2-mer does not occur in the PRG
       const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
@@ -1070,12 +1090,12 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       const uint32_t read = task >> 1;
       ReadRegs r;  // planes fetched on demand: one or two pairs hold the last k-mer
       r.w = b.packed + pack_off(b, read);
-      r.len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+      r.len = read_len(b, read);
       r.rc = (task & 1) != 0;
       r.in_regs = false;
       if (b.forward_only && r.rc) {
         // not mapped, not counted
-      } else if (!b.skip[read] && r.len >= ix.kmer_size && r.len > 0) {
+      } else if (!read_skipped(b, read) && r.len >= ix.kmer_size && r.len > 0) {
         const bool longer = ix.kmer_size2 != 0 && r.len >= ix.kmer_size2;
         const uint32_t k = longer ? ix.kmer_size2 : ix.kmer_size;
         sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
@@ -1985,7 +2005,7 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
     arena = ts.arena;
     task_out = task;
     const uint32_t read = task >> 1;
-    len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+    len = read_len(b, read);
   }
   // --- coverage with a scratch sized for this task ---
   CoverEnvDyn env;
@@ -2102,7 +2122,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       arena = ts.arena;
     }
     uint32_t read = task >> 1;
-    uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+    uint32_t len = read_len(b, read);
     Env env;
     env.scratch = LDS ? gmx_lds + threadIdx.x : acc.scratch_big + lane_id;
     env.stride = LDS ? LANES : acc.n_lanes_big;
@@ -2344,7 +2364,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
     bool class_overflow = false;
     if (member && gl == (uint32_t)__ffs(members16) - 1u) {
       const uint32_t read = ts.task >> 1;
-      const uint32_t len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+      const uint32_t len = read_len(b, read);
       ce.arena = ts.arena;
       ce.status = GMX_TASK_MAPPED;
       ce.log_at = 0;
@@ -2621,6 +2641,7 @@ struct gmx_engine {
   uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
+  uint32_t *d_task_lists = nullptr;  // SearchOut::task_lists: d_overflow, d_overflow2, d_alive, d_dead, d_dead2, d_cover_general are its slices
   GmxSeed *d_alive_seed = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
@@ -2676,6 +2697,29 @@ struct gmx_engine {
   } stage[2];
   hipStream_t copy_stream = nullptr;
   hipStream_t last_stream = nullptr;
+  // gmx_map_reads_packed_host: three slots of device buffers for bit planes, offsets, seeds and skip flags; the upload of
+  // a chunk (copy stream, straight from the caller's page-locked buffers) runs beside the kernels of the chunks before
+  struct PackSlot {
+    uint2 *d_planes = nullptr;
+    uint64_t *d_offsets = nullptr;
+    uint32_t *d_seeds = nullptr;
+    uint8_t *d_skip = nullptr;
+    uint64_t cap_pairs = 0, cap_reads = 0;
+    hipEvent_t copied = nullptr, done = nullptr;
+    bool busy = false;
+  } pslot[3];
+  uint32_t pslot_next = 0;
+  // releases a device buffer obtained from alloc() before the engine is destroyed (superseded staging buffers)
+  void release(void *q) {
+    if (!q) return;
+    for (size_t i = 0; i < allocs.size(); ++i)
+      if (allocs[i] == q) {
+        allocs[i] = allocs.back();
+        allocs.pop_back();
+        (void)hipFree(q);
+        return;
+      }
+  }
   // optional HIP-event timing of the kernels (bench.py roofline leg)
   bool timing = false;
   struct EvTriple { hipEvent_t s, a, b, c; uint64_t reads; };
@@ -2787,14 +2831,15 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if ((rc = e->alloc(&e->d_n_final, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_recs, n_tasks * GMX_REGIONS, false))) return rc;
   if ((rc = e->alloc(&e->d_mapped, n_tasks * GMX_REGIONS, false))) return rc;
-  if ((rc = e->alloc(&e->d_overflow, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_overflow2, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_task_lists, (size_t)GMX_TL_N * n_tasks, false))) return rc;
+  e->d_overflow = e->d_task_lists + (size_t)GMX_TL_OVERFLOW * n_tasks;
+  e->d_overflow2 = e->d_task_lists + (size_t)GMX_TL_OVERFLOW2 * n_tasks;
+  e->d_alive = e->d_task_lists + (size_t)GMX_TL_ALIVE * n_tasks;
+  e->d_dead = e->d_task_lists + (size_t)GMX_TL_DEAD * n_tasks;
+  e->d_dead2 = e->d_task_lists + (size_t)GMX_TL_DEAD2 * n_tasks;
+  e->d_cover_general = e->d_task_lists + (size_t)GMX_TL_GENERAL * n_tasks;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_cover_general, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_cover_mid, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_alive, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_dead, n_tasks, false))) return rc;
-  if ((rc = e->alloc(&e->d_dead2, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_seed_cursor, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
   if ((rc = e->alloc(&e->d_arena, n_tasks * GMX_FAST_ARENA, false))) return rc;
@@ -2988,6 +3033,10 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  for (auto &sl : e->pslot) {
+    if (sl.copied) (void)hipEventDestroy(sl.copied);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   for (auto &sl : e->stage) {
     if (sl.copied) (void)hipEventDestroy(sl.copied);
     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -3030,8 +3079,27 @@ static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const B
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
 }
 
-static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
-                        uint64_t n_reads, uint64_t total_bases, hipStream_t stream) {
+// One batch as the kernels see it: reads as bytes (d_reads + d_offsets: gmx_pack_kernel makes the bit planes) or as bit
+// planes already (d_planes; gmx_map_reads_packed_host).
+struct BatchInput {
+  const uint8_t *d_reads = nullptr;
+  const uint64_t *d_offsets = nullptr;  // null with uniform_len
+  const uint32_t *d_seeds = nullptr;
+  const uint2 *d_planes = nullptr;      // non-null: packed input, no pack kernel
+  const uint8_t *d_skip = nullptr;      // packed input: per-read skip flags, or null
+  uint32_t uniform_len = 0;
+  uint64_t n_reads = 0, total_bases = 0;
+};
+
+// first kernel of a batch whose reads arrive packed: what gmx_pack_kernel does besides packing (queue counters, a queued reset)
+__global__ void gmx_batch_begin_kernel(uint32_t *counters, uint32_t *zero, uint32_t zero_words) {
+  if (blockIdx.x == 0)
+    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += blockDim.x) counters[i] = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero[i] = 0;
+}
+
+static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream) {
+  const uint64_t n_reads = in.n_reads, total_bases = in.total_bases;
   if (n_reads == 0) return GMX_OK;
   if (n_reads > (0x7fffffffull / GMX_FAST_ARENA) / 2) {  // path-node handles (offsets into the arena table) stay below 2^31
     gmx_set_error("batch too large: at most 44 M reads per launch (lower gmx_engine_opts.max_batch_reads)");
@@ -3052,7 +3120,7 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
     }
     e->log_reads_since += n_reads;
   }
-  {
+  if (!in.d_planes) {
     uint64_t need = total_bases / 32 + n_reads + 16;  // pairs; the slack covers the one-pair look-ahead of planes()
     if (need > e->cap_packed) {
       rc = e->alloc(&e->d_packed, need, false);
@@ -3060,18 +3128,62 @@ static int launch_batch(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d
       e->cap_packed = need;
     }
   }
-  BatchView b{d_reads, d_offsets, d_seeds, e->d_skip, e->d_packed, (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0)};
+  BatchView b{in.d_reads, in.d_offsets, in.d_seeds, in.d_planes ? in.d_skip : e->d_skip, in.d_planes ? in.d_planes : e->d_packed,
+              (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0), in.uniform_len, (in.uniform_len + 31u) / 32u};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
-  SearchOut o{e->d_status, e->d_n_final, e->d_finals, e->d_arena, e->d_cover_recs, e->d_mapped, (uint32_t)(e->cap_reads * 2), region_inv, e->d_overflow, e->d_overflow2, e->d_cover_overflow,
-              e->d_big_mapped, e->d_cover_mid, e->d_cover_general, e->d_alive,  e->d_dead, e->d_dead2, e->d_seed_cursor, e->d_error, e->d_counters, e->d_alive_seed,
-              e->d_huge, e->d_cover_huge, e->d_huge_retry, (uint32_t)(e->cap_reads * 2),
-              e->d_inst_list, e->d_inst_sa, e->d_inst_remaining, e->inst_cap,
-              !getenv("GMX_NO_INST") ? e->big.max_slots : 0u,
-              e->big.n_final, e->big.task_of_slot, e->d_inst_mapped, e->d_inst_arena, e->d_inst_states, e->d_inst_first, e->d_inst_width,
-              e->d_inst_serial, e->d_general_serial, e->d_big_serial, e->d_overflow3, getenv("GMX_NO_SPLIT2") ? 0u : 1u, e->d_stats};
+  SearchOut o{};  // (member by member: the struct's order is not part of any contract)
+  o.status = e->d_status;
+  o.n_final = e->d_n_final;
+  o.finals = e->d_finals;
+  o.arena = e->d_arena;
+  o.cover_recs = e->d_cover_recs;
+  o.cover_rec_task = e->d_mapped;
+  o.region_cap = (uint32_t)(e->cap_reads * 2);
+  o.region_inv = region_inv;
+  o.task_lists = e->d_task_lists;
+  o.list_stride = (uint32_t)(e->cap_reads * 2);
+  o.overflow_list = e->d_overflow;
+  o.overflow2_list = e->d_overflow2;
+  o.cover_overflow_list = e->d_cover_overflow;
+  o.big_mapped_list = e->d_big_mapped;
+  o.cover_mid_list = e->d_cover_mid;
+  o.cover_general_list = e->d_cover_general;
+  o.alive_list = e->d_alive;
+  o.dead_list = e->d_dead;
+  o.dead2_list = e->d_dead2;
+  o.seed_cursor = e->d_seed_cursor;
+  o.error = e->d_error;
+  o.counters = e->d_counters;
+  o.alive_seed = e->d_alive_seed;
+  o.huge_list = e->d_huge;
+  o.cover_huge_list = e->d_cover_huge;
+  o.huge_retry = e->d_huge_retry;
+  o.arena_stride = (uint32_t)(e->cap_reads * 2);
+  o.inst_list = e->d_inst_list;
+  o.inst_sa = e->d_inst_sa;
+  o.inst_remaining = e->d_inst_remaining;
+  o.inst_cap = e->inst_cap;
+  o.inst_slots = !getenv("GMX_NO_INST") ? e->big.max_slots : 0u;
+  o.slot_n_final = e->big.n_final;
+  o.slot_task = e->big.task_of_slot;
+  o.inst_mapped_list = e->d_inst_mapped;
+  o.inst_arena = e->d_inst_arena;
+  o.inst_states = e->d_inst_states;
+  o.inst_first = e->d_inst_first;
+  o.inst_remaining_width = e->d_inst_width;
+  o.inst_serial_list = e->d_inst_serial;
+  o.general_serial_list = e->d_general_serial;
+  o.big_serial_list = e->d_big_serial;
+  o.overflow3_list = e->d_overflow3;
+  o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
+  o.stats = e->d_stats;
   uint32_t n_tasks = (uint32_t)n_reads * 2;
-  hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
-                     e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
+  if (in.d_planes)
+    hipLaunchKernelGGL(gmx_batch_begin_kernel, dim3(fold_reset ? 256 : 1), dim3(1024), 0, stream, e->d_counters,
+                       fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
+  else
+    hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
+                       e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
@@ -3192,11 +3304,27 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
   uint64_t done = 0;
   while (done < n_reads) {
     uint64_t n = std::min<uint64_t>(e->opts.max_batch_reads, n_reads - done);
-    int rc = launch_batch(e, d_reads, d_offsets + done, d_seeds + done, n, total_bases, stream);
+    BatchInput in;
+    in.d_reads = d_reads;
+    in.d_offsets = d_offsets + done;
+    in.d_seeds = d_seeds + done;
+    in.n_reads = n;
+    in.total_bases = total_bases;
+    int rc = launch_batch(e, in, stream);
     if (rc) return rc;
     done += n;
   }
   return GMX_OK;
+}
+
+// Is [p, p + bytes) page-locked memory the runtime can DMA from asynchronously (gmx_host_alloc, hipHostMalloc, registered)?
+static bool gmx_is_pinned(const void *p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
 }
 
 // Large calls: chunks of <= 1 M reads through two staging slots; the upload of a chunk (copy stream, from the caller's
@@ -3205,49 +3333,79 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
                                     uint64_t n_reads, uint64_t chunk) {
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   const uint64_t first = offsets[0], total = offsets[n_reads] - first;
-  const bool registered = hipHostRegister(const_cast<uint8_t *>(reads + first), total, hipHostRegisterDefault) == hipSuccess;
+  const bool registered = !gmx_is_pinned(reads + first) &&
+                          hipHostRegister(const_cast<uint8_t *>(reads + first), total, hipHostRegisterDefault) == hipSuccess;
   (void)hipGetLastError();
   int rc = GMX_OK;
+  auto hip_ok = [&](hipError_t err, const char *what) {  // (no early return: the epilogue below always runs)
+    if (err == hipSuccess) return true;
+    gmx_set_error(std::string(what) + ": " + hipGetErrorString(err));
+    rc = GMX_EHIP;
+    return false;
+  };
   uint64_t done = 0;
   for (uint32_t i = 0; done < n_reads && rc == GMX_OK; ++i) {
     gmx_engine::StageSlot &sl = e->stage[i & 1];
     const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
     const uint64_t b0 = offsets[done], bases = offsets[done + n] - b0;
     if (sl.busy) {  // the chunk that used this slot two rounds ago
-      HIP_TRY(hipEventSynchronize(sl.done));
+      if (!hip_ok(hipEventSynchronize(sl.done), "hipEventSynchronize")) break;
       sl.busy = false;
     }
     if (!sl.copied) {
-      HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate") ||
+          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate"))
+        break;
     }
-    if (bases > sl.cap_bases) {
+    if (bases > sl.cap_bases) {  // (the slot is idle: its superseded buffer can go at once)
       const uint64_t cb = std::max<uint64_t>(bases + bases / 8, 1 << 16);
+      e->release(sl.d_reads);
+      sl.d_reads = nullptr;
+      sl.cap_bases = 0;
       if ((rc = e->alloc(&sl.d_reads, cb + 16, false))) break;
       sl.cap_bases = cb;
     }
     if (n > sl.cap_reads) {
       const uint64_t cr = std::max<uint64_t>(n, 1024);
+      e->release(sl.d_offsets);
+      e->release(sl.d_seeds);
+      sl.d_offsets = nullptr;
+      sl.d_seeds = nullptr;
+      sl.cap_reads = 0;
       if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false))) break;
       if (sl.h_offsets) (void)hipHostFree(sl.h_offsets);
       if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h_offsets), (cr + 1) * sizeof(uint64_t), hipHostMallocDefault));
-      HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sl.h_seeds), cr * sizeof(uint32_t), hipHostMallocDefault));
+      sl.h_offsets = nullptr;
+      sl.h_seeds = nullptr;
+      if (!hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sl.h_offsets), (cr + 1) * sizeof(uint64_t), hipHostMallocDefault), "hipHostMalloc") ||
+          !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sl.h_seeds), cr * sizeof(uint32_t), hipHostMallocDefault), "hipHostMalloc"))
+        break;
       sl.cap_reads = cr;
     }
     for (uint64_t j = 0; j <= n; ++j) sl.h_offsets[j] = offsets[done + j] - b0;
     memcpy(sl.h_seeds, seeds + done, n * sizeof(uint32_t));
-    HIP_TRY(hipMemcpyAsync(sl.d_reads, reads + b0, bases, hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipMemcpyAsync(sl.d_seeds, sl.h_seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->copy_stream));
-    HIP_TRY(hipEventRecord(sl.copied, e->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(nullptr, sl.copied, 0));
-    rc = launch_batch(e, sl.d_reads, sl.d_offsets, sl.d_seeds, n, bases, nullptr);
+    if (!hip_ok(hipMemcpyAsync(sl.d_reads, reads + b0, bases, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(reads)") ||
+        !hip_ok(hipMemcpyAsync(sl.d_offsets, sl.h_offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(offsets)") ||
+        !hip_ok(hipMemcpyAsync(sl.d_seeds, sl.h_seeds, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(seeds)") ||
+        !hip_ok(hipEventRecord(sl.copied, e->copy_stream), "hipEventRecord") ||
+        !hip_ok(hipStreamWaitEvent(nullptr, sl.copied, 0), "hipStreamWaitEvent"))
+      break;
+    {
+      BatchInput in;
+      in.d_reads = sl.d_reads;
+      in.d_offsets = sl.d_offsets;
+      in.d_seeds = sl.d_seeds;
+      in.n_reads = n;
+      in.total_bases = bases;
+      rc = launch_batch(e, in, nullptr);
+    }
     if (rc) break;
-    HIP_TRY(hipEventRecord(sl.done, nullptr));
+    if (!hip_ok(hipEventRecord(sl.done, nullptr), "hipEventRecord")) break;
     sl.busy = true;
     done += n;
   }
+  // common epilogue, error or not: nothing in flight reads the caller's buffer, the slots are idle, the buffer is unregistered
+  (void)hipStreamSynchronize(e->copy_stream);
   (void)hipDeviceSynchronize();
   e->stage[0].busy = e->stage[1].busy = false;
   if (registered) (void)hipHostUnregister(const_cast<uint8_t *>(reads + first));
@@ -3291,12 +3449,130 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
     HIP_TRY(hipMemcpy(e->d_reads, reads + b0, bases, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_offsets, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(e->d_seeds, seeds + done, n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    int rc = launch_batch(e, e->d_reads, e->d_offsets, e->d_seeds, n, bases, nullptr);
+    BatchInput in;
+    in.d_reads = e->d_reads;
+    in.d_offsets = e->d_offsets;
+    in.d_seeds = e->d_seeds;
+    in.n_reads = n;
+    in.total_bases = bases;
+    int rc = launch_batch(e, in, nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));  // staging buffers are reused by the next batch
     done += n;
   }
   return gmx_engine_sync(e);
+}
+
+int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
+                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+  if (!e || !planes || !seeds || (!offsets && !uniform_len)) {
+    gmx_set_error("gmx_map_reads_packed_host: null argument (offsets may be null only with uniform_len)");
+    return GMX_EINVAL;
+  }
+  if (n_reads == 0) return GMX_OK;
+  HIP_TRY(hipSetDevice(e->opts.device));
+  if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  const uint32_t ppr = (uniform_len + 31u) / 32u;
+  auto pair_at = [&](uint64_t r) -> uint64_t {  // pairs from the call's first read to read r (gmx.h: layout of `planes`)
+    return uniform_len ? r * ppr : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r;
+  };
+  // buffers the runtime cannot DMA from are registered for the duration of the call, which then waits for its uploads
+  struct Reg { const void *p; bool on; };
+  Reg regs[4] = {{planes, false}, {offsets, false}, {seeds, false}, {skip, false}};
+  const uint64_t reg_bytes[4] = {pair_at(n_reads) * 8, (n_reads + 1) * 8, n_reads * 4, n_reads};
+  bool all_pinned = true;
+  for (int i = 0; i < 4; ++i) {
+    if (!regs[i].p || gmx_is_pinned(regs[i].p)) continue;
+    regs[i].on = hipHostRegister(const_cast<void *>(regs[i].p), reg_bytes[i], hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    all_pinned = false;
+  }
+  const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+  int rc = GMX_OK;
+  auto hip_ok = [&](hipError_t err, const char *what) {
+    if (err == hipSuccess) return true;
+    gmx_set_error(std::string(what) + ": " + hipGetErrorString(err));
+    rc = GMX_EHIP;
+    return false;
+  };
+  for (uint64_t done = 0; done < n_reads && rc == GMX_OK;) {
+    gmx_engine::PackSlot &sl = e->pslot[e->pslot_next];
+    e->pslot_next = (e->pslot_next + 1) % 3;
+    const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
+    const uint64_t p0 = pair_at(done), pairs = pair_at(done + n) - p0;
+    if (sl.busy) {  // the batch that used this slot three chunks ago
+      if (!hip_ok(hipEventSynchronize(sl.done), "hipEventSynchronize")) break;
+      sl.busy = false;
+    }
+    if (!sl.copied) {
+      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate") ||
+          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate"))
+        break;
+    }
+    if (pairs + 16 > sl.cap_pairs) {  // (+ slack: the kernels fetch whole 16-byte pieces and one pair ahead)
+      const uint64_t cp = pairs + pairs / 8 + 64;
+      e->release(sl.d_planes);
+      sl.d_planes = nullptr;
+      sl.cap_pairs = 0;
+      if ((rc = e->alloc(&sl.d_planes, cp, false))) break;
+      sl.cap_pairs = cp;
+    }
+    if (n > sl.cap_reads) {
+      const uint64_t cr = std::max<uint64_t>(n, 1024);
+      e->release(sl.d_offsets);
+      e->release(sl.d_seeds);
+      e->release(sl.d_skip);
+      sl.d_offsets = nullptr;
+      sl.d_seeds = nullptr;
+      sl.d_skip = nullptr;
+      sl.cap_reads = 0;
+      if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false)) || (rc = e->alloc(&sl.d_skip, cr, false))) break;
+      sl.cap_reads = cr;
+    }
+    if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, pairs * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(planes)")) break;
+    if (!uniform_len &&
+        !hip_ok(hipMemcpyAsync(sl.d_offsets, offsets + done, (n + 1) * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(offsets)"))
+      break;
+    if (!hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(seeds)")) break;
+    if (skip && !hip_ok(hipMemcpyAsync(sl.d_skip, skip + done, n, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(skip)")) break;
+    if (!hip_ok(hipEventRecord(sl.copied, e->copy_stream), "hipEventRecord") ||
+        !hip_ok(hipStreamWaitEvent(nullptr, sl.copied, 0), "hipStreamWaitEvent"))
+      break;
+    BatchInput in;
+    in.d_offsets = uniform_len ? nullptr : sl.d_offsets;
+    in.d_seeds = sl.d_seeds;
+    in.d_planes = sl.d_planes;
+    in.d_skip = skip ? sl.d_skip : nullptr;
+    in.uniform_len = uniform_len;
+    in.n_reads = n;
+    in.total_bases = uniform_len ? n * (uint64_t)uniform_len : offsets[done + n] - offsets[done];
+    if ((rc = launch_batch(e, in, nullptr))) break;
+    if (!hip_ok(hipEventRecord(sl.done, nullptr), "hipEventRecord")) break;
+    sl.busy = true;
+    done += n;
+  }
+  // common epilogue: a failed call, or one that registered memory, leaves nothing in flight that reads the caller's buffers
+  if (rc != GMX_OK || !all_pinned) {
+    (void)hipStreamSynchronize(e->copy_stream);
+    if (rc != GMX_OK) {
+      (void)hipDeviceSynchronize();
+      for (auto &sl : e->pslot) sl.busy = false;
+    }
+  }
+  for (int i = 0; i < 4; ++i)
+    if (regs[i].on) (void)hipHostUnregister(const_cast<void *>(regs[i].p));
+  (void)hipGetLastError();
+  return rc;
+}
+
+int gmx_engine_sync_uploads(gmx_engine *e) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(e->opts.device));
+  if (e->copy_stream) HIP_TRY(hipStreamSynchronize(e->copy_stream));
+  return GMX_OK;
 }
 
 // page-locked allocations are remembered so that gmx_host_free knows which call returns them. Freed page-locked blocks

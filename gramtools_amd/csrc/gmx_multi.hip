@@ -298,6 +298,57 @@ int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t 
   return GMX_OK;
 }
 
+// The packed form, dealt the same way: engine i takes a contiguous range of the read index, its planes start at that
+// range's first pair (gmx.h: a sub-range of a packed batch is a packed batch). Every engine's call returns once its
+// chunks are enqueued (page-locked buffers), so the host threads are short-lived; gmx_group_sync_uploads waits for all.
+int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
+                                    const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+  if (!g || g->ms.empty()) {
+    gmx_set_error("null group");
+    return GMX_EINVAL;
+  }
+  const size_t n = g->ms.size();
+  if (n == 1) return gmx_map_reads_packed_host(g->ms[0].e, planes, offsets, uniform_len, seeds, skip, n_reads);
+  if (!planes || !seeds || (!offsets && !uniform_len)) {
+    gmx_set_error("gmx_group_map_reads_packed_host: null argument");
+    return GMX_EINVAL;
+  }
+  std::vector<int> rcs(n, GMX_OK);
+  std::vector<std::string> errs(n);
+  std::vector<std::thread> th;
+  const uint64_t ppr = (uniform_len + 31u) / 32u;
+  for (size_t i = 0; i < n; ++i) {
+    const uint64_t base = n_reads / n, rem = n_reads % n;
+    const uint64_t lo = i * base + std::min<uint64_t>(i, rem), cnt = base + (i < rem ? 1 : 0);
+    const uint64_t p0 = uniform_len ? lo * ppr : ((offsets[lo] >> 5) - (offsets[0] >> 5)) + lo;
+    th.emplace_back([=, &rcs, &errs]() {
+      if (cnt == 0) return;
+      rcs[i] = gmx_map_reads_packed_host(g->ms[i].e, planes + p0, offsets ? offsets + lo : nullptr, uniform_len, seeds + lo,
+                                         skip ? skip + lo : nullptr, cnt);
+      if (rcs[i]) errs[i] = gmx_last_error();
+    });
+  }
+  for (auto &t : th) t.join();
+  for (size_t i = 0; i < n; ++i)
+    if (rcs[i]) {
+      gmx_set_error("device " + std::to_string(g->ms[i].raw.device) + ": " + errs[i]);
+      return rcs[i];
+    }
+  return GMX_OK;
+}
+
+int gmx_group_sync_uploads(gmx_group *g) {
+  if (!g) {
+    gmx_set_error("null group");
+    return GMX_EINVAL;
+  }
+  for (auto &m : g->ms) {
+    int rc = gmx_engine_sync_uploads(m.e);
+    if (rc) return rc;
+  }
+  return GMX_OK;
+}
+
 int gmx_group_allreduce(gmx_group *g) {
   if (!g || g->ms.empty()) {
     gmx_set_error("null group");

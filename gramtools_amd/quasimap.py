@@ -47,6 +47,74 @@ def master_seeds(master_seed: int, reads_per_file) -> np.ndarray:
     return out
 
 
+class PinnedArray:
+    """A numpy array in page-locked host memory (gmx_host_alloc): what gmx_map_reads_packed_host uploads from
+    asynchronously, at the PCIe rate. Freed (returned to the library's cache of page-locked blocks) on close()."""
+
+    def __init__(self, shape, dtype):
+        self.lib = _lib.load()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+        self.nbytes = max(n * dt.itemsize, 1)
+        self.ptr = self.lib.gmx_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("gmx_host_alloc failed")
+        buf = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.gmx_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = close
+
+
+class PackedReads:
+    """Reads as bit planes in host memory (include/gmx.h, gmx_map_reads_packed_host): ``planes`` (uint64 per 32 bases),
+    ``offsets`` (None when ``uniform_len``), ``skip`` (uint8 per read or None), ``n_reads``."""
+
+    def __init__(self, planes, offsets, uniform_len, skip, n_reads, keep=()):
+        self.planes, self.offsets, self.uniform_len, self.skip, self.n_reads = planes, offsets, uniform_len, skip, n_reads
+        self._keep = keep  # the PinnedArray objects behind the arrays
+
+    def close(self):
+        for k in self._keep:
+            k.close()
+        self._keep = ()
+
+
+def pack_reads(reads_flat, offsets, uniform_len: int = 0, threads: int = 0, pinned: bool = False) -> PackedReads:
+    """Encoded reads (one byte per base, 1..4) -> bit planes on the host (gmx_pack_reads). With ``uniform_len`` every read
+    must have that length and the reads are packed back to back (no offsets needed by the engine). ``pinned``: the
+    result lives in page-locked memory, from which the engine uploads asynchronously."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(reads_flat, dtype=np.uint8)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = o.size - 1
+    if r.size == 0:
+        r = np.zeros(1, dtype=np.uint8)
+    n_pairs = int(lib.gmx_packed_pairs(_p(o, C.c_uint64), uniform_len, n))
+    keep = []
+    if pinned:
+        pa, sk = PinnedArray(n_pairs + 8, np.uint64), PinnedArray(max(n, 1), np.uint8)
+        keep = [pa, sk]
+        planes, skip = pa.array, sk.array
+        planes[n_pairs:] = 0
+        off_out = None
+        if not uniform_len:
+            po = PinnedArray(n + 1, np.uint64)
+            keep.append(po)
+            po.array[:] = o
+            off_out = po.array
+    else:
+        planes, skip = np.zeros(n_pairs + 8, dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint8)
+        off_out = None if uniform_len else o
+    check(lib.gmx_pack_reads(r.ctypes.data, o.ctypes.data, uniform_len, n, planes.ctypes.data, skip.ctypes.data, threads))
+    return PackedReads(planes, off_out, uniform_len, skip, n, tuple(keep))
+
+
 class Index:
     """Everything the mapping path needs, derived from the integer PRG and the k-mer size."""
 
@@ -371,6 +439,20 @@ class Quasimapper:
             r = np.zeros(1, dtype=np.uint8)
         check(self.lib.gmx_map_reads_host(self.h, _p(r, C.c_uint8), _p(o, C.c_uint64), _p(s, C.c_uint32), o.size - 1))
 
+    def map_reads_packed(self, packed: "PackedReads", seeds, use_skip=True):
+        """Reads already packed to bit planes on the host (gmx_map_reads_packed_host). Asynchronous when the arrays are
+        page-locked (pack_reads(..., pinned=True), PinnedArray): keep them untouched until sync_uploads() / sync()."""
+        s = seeds if isinstance(seeds, np.ndarray) and seeds.dtype == np.uint32 and seeds.flags.c_contiguous else \
+            np.ascontiguousarray(seeds, dtype=np.uint32)
+        skip = packed.skip if use_skip else None
+        check(self.lib.gmx_map_reads_packed_host(
+            self.h, packed.planes.ctypes.data, None if packed.offsets is None else packed.offsets.ctypes.data,
+            packed.uniform_len, s.ctypes.data, None if skip is None else skip.ctypes.data, packed.n_reads))
+        self._last_seeds = s  # (kept alive while the upload may be in flight)
+
+    def sync_uploads(self):
+        check(self.lib.gmx_engine_sync_uploads(self.h))
+
     def map_reads_device(self, d_reads, d_offsets, d_seeds, n_reads, stream=None):
         """Device-resident buffers (torch CUDA tensors: uint8 / int64-or-uint64 / int32-or-uint32). Asynchronous."""
         sp = C.c_void_p(stream) if stream else None
@@ -473,6 +555,15 @@ class QuasimapperGroup:
         if r.size == 0:
             r = np.zeros(1, dtype=np.uint8)
         check(self.lib.gmx_group_map_reads_host(self.h, _p(r, C.c_uint8), _p(o, C.c_uint64), _p(s, C.c_uint32), o.size - 1))
+
+    def map_reads_packed(self, packed: "PackedReads", seeds, use_skip=True):
+        s = np.ascontiguousarray(seeds, dtype=np.uint32)
+        skip = packed.skip if use_skip else None
+        check(self.lib.gmx_group_map_reads_packed_host(
+            self.h, packed.planes.ctypes.data, None if packed.offsets is None else packed.offsets.ctypes.data,
+            packed.uniform_len, s.ctypes.data, None if skip is None else skip.ctypes.data, packed.n_reads))
+        self._last_seeds = s
+        check(self.lib.gmx_group_sync_uploads(self.h))
 
     def allreduce(self):
         check(self.lib.gmx_group_allreduce(self.h))

@@ -146,6 +146,31 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
                        uint64_t n_reads);
 int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
                          uint64_t n_reads, uint64_t total_bases, void *hip_stream);
+/* The same from reads that are ALREADY bit planes in host memory ("pre-encoded (2-bit packed ...) pinned-host"
+ * input; replaces get_reads_buffer + encode_dna_bases, quasimap.cpp:65-76 / common/utils.cpp:73-92, whose result the
+ * reference hands to handle_reads_buffer): a quarter of the bytes over PCIe and no packing pass on the device.
+ *   planes : one uint64 per 32 bases, low word = bit 0 of the base codes (A,C,G,T = 0,1,2,3: encoded value - 1), high word =
+ *            bit 1; base j of the 32 at bit j; bits past a read's end are ignored. Read r of the call starts at pair
+ *              P(r) = r * ceil(uniform_len / 32)                        when uniform_len != 0 (every read that long), else
+ *              P(r) = (offsets[r] >> 5) - (offsets[0] >> 5) + r         (ceil(len / 32) pairs always fit before P(r + 1);
+ *            a sub-range of a packed batch is again a packed batch: pass planes + P(first), offsets + first).
+ *            gmx_packed_pairs() gives the length of the array, gmx_pack_reads() makes it from encoded bytes.
+ *   offsets: n_reads + 1 base offsets (only their differences and the layout above matter), or NULL with uniform_len
+ *   skip   : per read, non-zero = the read holds a non-ACGT symbol: both orientations count as skipped
+ *            (encode_dna_bases semantics); NULL = no such read
+ * ASYNCHRONOUS when the buffers are page-locked (gmx_host_alloc): the call returns once every chunk is enqueued — uploads
+ * on a copy stream beside the kernels of the chunks before — and the buffers must stay untouched until
+ * gmx_engine_sync_uploads (uploads done; kernels may still run) or gmx_engine_sync / gmx_coverage_fetch. Pageable buffers
+ * are registered for the duration of the call, which then waits for its uploads. */
+int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
+                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads);
+int gmx_engine_sync_uploads(gmx_engine *e);
+uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads);
+/* Encoded reads (one byte per base, 1..4; the input of gmx_map_reads_host) -> bit planes in the layout above, on `threads`
+ * host threads (0 = all). skip[r] (may be NULL) = read r holds a byte outside 1..4. With uniform_len every read must be
+ * that long (GMX_EINVAL otherwise). */
+int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *planes,
+                   uint8_t *skip, int threads);
 /* Page-locked host memory for the buffers handed to gmx_map_reads_host: the upload is then one DMA at the PCIe rate
  * instead of being staged through small pinned chunks by the runtime. Falls back to plain memory without a device (the
  * parsers also run in tests without one). gmx_host_free takes only pointers gmx_host_alloc returned. */
@@ -277,6 +302,9 @@ int gmx_group_uses_rccl(const gmx_group *g); /* 0: peer copies + add kernel (no 
  * the caller's per-read seeds (the master stream is global, so the result does not depend on the number of GPUs). */
 int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
                              uint64_t n_reads);
+int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
+                                    const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads);
+int gmx_group_sync_uploads(gmx_group *g);
 int gmx_group_allreduce(gmx_group *g); /* the exchange; synchronises every engine first */
 
 typedef struct gmx_comm gmx_comm; /* one engine per PROCESS (torch.distributed.run, mpirun, ...): rank 0 makes the id,
