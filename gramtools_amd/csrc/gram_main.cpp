@@ -9,6 +9,9 @@
 //   G/coverage/grouped_allele_counts_coverage.json and G/read_stats.json (parameters.cpp:94-105).
 // Host code here only parses, feeds and writes; mapping is done by the HIP engine through the C ABI (gmx.h).
 // The infer stage (genotyped.json / .vcf.gz / personalised reference) is outside this engine's scope.
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -214,15 +217,29 @@ struct HostBuf {
   const T &operator[](size_t i) const { return p[i]; }
 };
 
+// One parsed block of a reads file in the form the engine uploads as it is (gmx.h: gmx_map_reads_packed_host): bit
+// planes of the base codes, one uint64 per 32 bases; reads of one length back to back (uniform_len != 0, no offsets),
+// else read r at pair (offsets[r] >> 5) + r. A read with a non-ACGT symbol keeps its place and its seed and is flagged
+// in `skip` (encode_dna_bases, common/utils.cpp:73-92: the whole read is dropped; quasimap.cpp:109-113 counts it).
 struct ParsedReads {
-  HostBuf<uint8_t> bases;
-  HostBuf<uint64_t> offsets;  // n + 1
+  HostBuf<uint64_t> planes;
+  HostBuf<uint64_t> offsets;  // n + 1 base offsets (valid when uniform_len == 0)
+  HostBuf<uint8_t> skip;      // n
   HostBuf<uint32_t> seeds;    // filled by the consumer
+  uint32_t uniform_len = 0;
+  size_t n_reads = 0;
+  uint64_t n_bases = 0;
+  bool any_skip = false;
   void reset() {
-    bases.clear();
-    offsets.resize(1);
-    offsets[0] = 0;
+    n_reads = 0;
+    n_bases = 0;
+    uniform_len = 0;
+    any_skip = false;
   }
+  uint64_t pair_of(size_t r) const {
+    return uniform_len ? (uint64_t)r * ((uniform_len + 31u) / 32u) : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r;
+  }
+  uint32_t len_of(size_t r) const { return uniform_len ? uniform_len : (uint32_t)(offsets[r + 1] - offsets[r]); }
 };
 
 // encode_dna_bases (common/utils.cpp:73-92) as a table: A,C,G,T (either case) -> 1..4, anything else 0
@@ -237,6 +254,62 @@ struct BaseTable {
   }
 };
 static const BaseTable kBaseTable;
+
+// n ASCII bases -> ceil(n / 32) plane pairs (low word = bit 0 of the codes A,C,G,T = 0..3, high word = bit 1; base j of a
+// pair at bit j). Returns false when a symbol is not one of ACGTacgt. From the letters' own bits: bit 2 of the ASCII
+// code is the high bit of the base code, bit 1 XOR bit 2 the low one ('A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54).
+static bool pack_ascii_scalar(const unsigned char *src, size_t n, uint64_t *out) {
+  bool ok = true;
+  for (size_t i = 0; i < n; i += 32) {
+    uint32_t lo = 0, hi = 0;
+    const size_t m = std::min<size_t>(32, n - i);
+    for (size_t j = 0; j < m; ++j) {
+      const uint8_t v = kBaseTable.v[src[i + j]];
+      ok = ok && v != 0;
+      const uint32_t c = (uint32_t)(v - 1u) & 3u;
+      lo |= (c & 1u) << j;
+      hi |= (c >> 1) << j;
+    }
+    out[i >> 5] = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  return ok;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static bool pack_ascii_avx2(const unsigned char *src, size_t n, uint64_t *out) {
+  const __m256i upper = _mm256_set1_epi8((char)0xDF);
+  const __m256i cA = _mm256_set1_epi8(0x41), cC = _mm256_set1_epi8(0x43), cG = _mm256_set1_epi8(0x47), cT = _mm256_set1_epi8(0x54);
+  uint32_t all_ok = 0xFFFFFFFFu;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+    const __m256i u = _mm256_and_si256(v, upper);
+    const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                       _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+    all_ok &= (uint32_t)_mm256_movemask_epi8(ok);
+    const uint32_t hi = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 5));
+    const uint32_t lo = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(v, 6)) ^ hi;
+    out[i >> 5] = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+  bool ok = all_ok == 0xFFFFFFFFu;
+  if (i < n) {
+    alignas(32) unsigned char tail[32];
+    memset(tail, 'A', 32);
+    memcpy(tail, src + i, n - i);
+    uint64_t w;
+    ok = pack_ascii_avx2(tail, 32, &w) && ok;
+    const uint32_t keep = (uint32_t)((1ull << (n - i)) - 1ull);
+    out[i >> 5] = (uint64_t)((uint32_t)w & keep) | ((uint64_t)((uint32_t)(w >> 32) & keep) << 32);
+  }
+  return ok;
+}
+static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool kHaveAvx2 = false;
+static bool pack_ascii_avx2(const unsigned char *src, size_t n, uint64_t *out) { return pack_ascii_scalar(src, n, out); }
+#endif
+static inline bool pack_ascii(const unsigned char *src, size_t n, uint64_t *out) {
+  return kHaveAvx2 && !getenv("GMX_NO_AVX2") ? pack_ascii_avx2(src, n, out) : pack_ascii_scalar(src, n, out);
+}
 
 // fn(t) for t = 0 .. T-1 on a pool of waiting threads: a 96 MB block goes through three such phases, and starting 64
 // threads for each of them cost more than the parsing (measured: 88 ms of 160 for 4 M reads)
@@ -314,26 +387,43 @@ void parallel_for(unsigned T, F fn) {
 // Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
 // the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
 // Returns false on anything that is not plain four-line FASTQ.
+// Two parallel phases: every thread finds the records that start in its byte range (sequence start + length each);
+// then, with the reads' places known (prefix sums; one length for all or not), every thread packs its records' letters
+// straight into the block's page-locked output (no per-thread copies to merge).
 bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed) {
   out.reset();
   consumed = 0;
   if (size == 0) return true;
   if (d[0] != '@') return false;
   const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
+  struct Rec {
+    uint64_t at;   // start of the sequence line in d
+    uint32_t len;
+  };
   struct Part {
-    std::vector<uint8_t> bases;
-    std::vector<uint32_t> lens;
+    std::vector<Rec> recs;
     bool bad = false;
     size_t first = 0, stop = 0;  // start of the first record this range parsed, end of its last one
+    uint64_t bases = 0;
+    uint32_t len0 = 0;
+    bool one_len = true;
+    bool any_skip = false;
   };
-  std::vector<Part> parts(T);
+  static std::vector<Part> parts;  // (kept between blocks: the record vectors keep their capacity)
+  parts.resize(T);
   auto line_end = [&](size_t at) {  // index of the '\n' ending the line at `at`, or size
     if (at >= size) return size;
     const void *nl = memchr(d + at, '\n', size - at);
     return nl ? (size_t)((const char *)nl - d) : size;
   };
-  auto worker = [&](unsigned t) {
+  auto scan = [&](unsigned t) {
     Part &p = parts[t];
+    p.recs.clear();
+    p.bad = false;
+    p.bases = 0;
+    p.len0 = 0;
+    p.one_len = true;
+    p.any_skip = false;
     size_t lo = size * t / T, hi = size * (t + 1) / T;
     size_t at = lo;
     if (t > 0) {  // first record start at or after lo (a record starting exactly at lo belongs to this range)
@@ -352,7 +442,6 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
         at = e1 + 1;
       }
     }
-    p.bases.reserve((hi - lo) / 2 + 64);
     p.first = at;
     while (at < hi && at < size && !p.bad) {
       const size_t e1 = line_end(at), s2 = e1 + 1, e2 = line_end(s2), s3 = e2 + 1, e3 = line_end(s3), s4 = e3 + 1,
@@ -365,62 +454,78 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
       size_t n = e2 - s2, nq = e4 - s4;
       if (n && d[s2 + n - 1] == '\r') --n;
       if (nq && d[s4 + nq - 1] == '\r') --nq;
-      if (d[at] != '@' || d[s3] != '+' || nq != n || n == 0) {  // blank / multi-line record: the sequential reader's job
+      if (d[at] != '@' || d[s3] != '+' || nq != n || n == 0 || n > 0x7FFFFFFFu) {  // blank / multi-line record: the sequential reader's job
         p.bad = true;
         break;
       }
-      const size_t base_at = p.bases.size();
-      p.bases.resize(base_at + n);
-      uint8_t *dst = p.bases.data() + base_at;
-      const unsigned char *src = reinterpret_cast<const unsigned char *>(d + s2);
-      uint8_t all = 0xFF;
-      for (size_t i = 0; i < n; ++i) {
-        const uint8_t v = kBaseTable.v[src[i]];
-        dst[i] = v;
-        all = v ? all : 0;
-      }
-      const bool valid = all != 0;
-      if (!valid) p.bases.resize(base_at);  // encode_dna_bases: the whole read is dropped (kept as an empty read)
-      p.lens.push_back(valid ? (uint32_t)n : 0u);
+      if (p.recs.empty()) p.len0 = (uint32_t)n;
+      p.one_len = p.one_len && (uint32_t)n == p.len0;
+      p.recs.push_back(Rec{(uint64_t)s2, (uint32_t)n});
+      p.bases += n;
       at = e4 < size ? e4 + 1 : size;
     }
     p.stop = at;
   };
-  parallel_for(T, worker);
-  for (auto &p : parts)
-    if (p.bad) return false;
+  parallel_for(T, scan);
+  for (unsigned t = 0; t < T; ++t)
+    if (parts[t].bad) return false;
   // the ranges' records must chain into one gap-free prefix of the buffer; what follows it (an incomplete record, or
   // records no range could recognise from inside) is left for the next block, where it sits at the start
   size_t cursor = 0;
   for (unsigned t = 0; t < T; ++t) {
-    if (parts[t].lens.empty()) continue;
+    if (parts[t].recs.empty()) continue;
     if (parts[t].first != cursor) return false;
     cursor = parts[t].stop;
   }
   if (final && cursor != size) return false;
   consumed = cursor;
   for (unsigned t = 0; t < T; ++t)  // drop what lies behind the prefix (cannot happen when the chain is intact)
-    if (!parts[t].lens.empty() && parts[t].first >= consumed) return false;
-  size_t n_reads = 0, n_bases = 0;
-  std::vector<size_t> r0(T), b0(T);
+    if (!parts[t].recs.empty() && parts[t].first >= consumed) return false;
+  size_t n_reads = 0;
+  uint64_t n_bases = 0;
+  std::vector<size_t> r0(T);
+  std::vector<uint64_t> b0(T);
+  bool uniform = true;
+  uint32_t len0 = 0;
   for (unsigned t = 0; t < T; ++t) {
     r0[t] = n_reads;
     b0[t] = n_bases;
-    n_reads += parts[t].lens.size();
-    n_bases += parts[t].bases.size();
+    if (!parts[t].recs.empty()) {
+      if (n_reads == 0) len0 = parts[t].len0;
+      uniform = uniform && parts[t].one_len && parts[t].len0 == len0;
+    }
+    n_reads += parts[t].recs.size();
+    n_bases += parts[t].bases;
   }
-  out.bases.resize(std::max<size_t>(n_bases, 1));
-  out.bases.n = n_bases;
+  out.n_reads = n_reads;
+  out.n_bases = n_bases;
+  out.uniform_len = uniform && n_reads ? len0 : 0u;
+  const uint64_t ppr = (out.uniform_len + 31u) / 32u;
+  const uint64_t n_pairs = out.uniform_len ? n_reads * ppr : (n_bases >> 5) + n_reads;
+  out.planes.resize(n_pairs + 8);  // (+ slack: the device fetches whole 16-byte pieces)
+  out.skip.resize(std::max<size_t>(n_reads, 1));
   out.offsets.resize(n_reads + 1);
   parallel_for(T, [&](unsigned t) {
-    if (!parts[t].bases.empty()) memcpy(out.bases.data() + b0[t], parts[t].bases.data(), parts[t].bases.size());
+    Part &p = parts[t];
     uint64_t off = b0[t];
-    for (size_t i = 0; i < parts[t].lens.size(); ++i) {
-      out.offsets[r0[t] + i] = off;
-      off += parts[t].lens[i];
+    for (size_t i = 0; i < p.recs.size(); ++i) {
+      const size_t r = r0[t] + i;
+      const uint64_t at = out.uniform_len ? r * ppr : (off >> 5) + r;
+      const uint32_t len = p.recs[i].len;
+      const bool ok = pack_ascii(reinterpret_cast<const unsigned char *>(d) + p.recs[i].at, len, out.planes.data() + at);
+      if (!out.uniform_len) {
+        out.offsets[r] = off;
+        const uint64_t next = ((off + len) >> 5) + r + 1;
+        for (uint64_t q = at + (len + 31u) / 32u; q < next; ++q) out.planes[q] = 0;  // gap pair of the offsets form
+      }
+      out.skip[r] = ok ? 0 : 1;
+      p.any_skip = p.any_skip || !ok;
+      off += len;
     }
   });
   out.offsets[n_reads] = n_bases;
+  for (unsigned t = 0; t < T; ++t) out.any_skip = out.any_skip || parts[t].any_skip;
+  for (uint64_t q = n_pairs; q < n_pairs + 8; ++q) out.planes[q] = 0;
   return true;
 }
 
@@ -603,12 +708,18 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
       first = false;
       pipe.reset(new BlockPipe([&](ParsedReads &b) { sink(b); }));
       ParsedReads &slot0 = pipe->acquire();
-      std::swap(slot0.bases.p, scratch.bases.p);
-      std::swap(slot0.bases.n, scratch.bases.n);
-      std::swap(slot0.bases.cap, scratch.bases.cap);
-      std::swap(slot0.offsets.p, scratch.offsets.p);
-      std::swap(slot0.offsets.n, scratch.offsets.n);
-      std::swap(slot0.offsets.cap, scratch.offsets.cap);
+      auto swap_buf = [](auto &x, auto &y) {
+        std::swap(x.p, y.p);
+        std::swap(x.n, y.n);
+        std::swap(x.cap, y.cap);
+      };
+      swap_buf(slot0.planes, scratch.planes);
+      swap_buf(slot0.offsets, scratch.offsets);
+      swap_buf(slot0.skip, scratch.skip);
+      std::swap(slot0.uniform_len, scratch.uniform_len);
+      std::swap(slot0.n_reads, scratch.n_reads);
+      std::swap(slot0.n_bases, scratch.n_bases);
+      std::swap(slot0.any_skip, scratch.any_skip);
     }
     pipe->submit();
     memmove(buf.data(), buf.data() + consumed, have - consumed);
@@ -729,10 +840,18 @@ int run_parse_check(const std::string &path, int threads) {
     return h;
   };
   Flat fast, slow;
-  auto collect = [&](const ParsedReads &block) {
-    const uint64_t base = fast.bases.size();
-    fast.bases.insert(fast.bases.end(), block.bases.data(), block.bases.data() + block.bases.size());
-    for (size_t i = 1; i < block.offsets.size(); ++i) fast.offsets.push_back(base + block.offsets[i]);
+  auto collect = [&](const ParsedReads &block) {  // planes back to one byte per base; an unencodable read as the empty read
+    for (size_t r = 0; r < block.n_reads; ++r) {
+      if (!block.skip[r]) {
+        const uint64_t at = block.pair_of(r);
+        const uint32_t len = block.len_of(r);
+        for (uint32_t i = 0; i < len; ++i) {
+          const uint64_t w = block.planes[at + (i >> 5)];
+          fast.bases.push_back((uint8_t)(1u + ((w >> (i & 31u)) & 1u) + 2u * ((w >> (32u + (i & 31u))) & 1u)));
+        }
+      }
+      fast.offsets.push_back(fast.bases.size());
+    }
   };
   if (parse_fastq_file(path, threads, collect))
     std::cout << "fast " << fast.offsets.size() - 1 << " " << fast.bases.size() << " " << fnv(fast) << std::endl;
@@ -837,10 +956,10 @@ int run_genotype(const Args &a) {
     size_t block = 96u << 20;
     if (const char *eb = getenv("GMX_FASTQ_BLOCK")) block = std::max<size_t>(64, (size_t)atoll(eb));
     if (block < (8u << 20)) return;
-    void *p[6];
-    const size_t sizes[3] = {block / 5 * 3, block / 24, block / 48};
-    for (int i = 0; i < 6; ++i) p[i] = gmx_host_alloc(sizes[i % 3]);
-    for (int i = 0; i < 6; ++i) gmx_host_free(p[i]);
+    void *p[8];
+    const size_t sizes[4] = {block / 6, block / 24, block / 48, block / 192};  // planes, offsets, seeds, skip flags
+    for (int i = 0; i < 8; ++i) p[i] = gmx_host_alloc(sizes[i % 4]);
+    for (int i = 0; i < 8; ++i) gmx_host_free(p[i]);
     g_block_cap = block + (1u << 20);  // ... and the file block buffer, its pages touched
     g_block_mem.reset(new char[g_block_cap]);
     memset(g_block_mem.get(), 0, g_block_cap);
@@ -864,7 +983,7 @@ int run_genotype(const Args &a) {
   GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
-  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve(gmx_group_engine(grp, d), 1u << 20, 160ull << 20));
+  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve(gmx_group_engine(grp, d), 1u << 20, 0));
   if (prewarm.joinable()) prewarm.join();
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
@@ -886,17 +1005,19 @@ int run_genotype(const Args &a) {
     uint64_t in_file = 0;
     std::vector<uint32_t> file_batch(kBatch);
     auto sink = [&](ParsedReads &block) {  // runs on the pipe's consumer thread, block after block in file order
-      const uint64_t n = block.offsets.size() - 1;
+      const uint64_t n = block.n_reads;
       block.seeds.resize(std::max<uint64_t>(n, 1));
       for (uint64_t i = 0; i < n; ++i, ++in_file) {
         if (in_file % kBatch == 0)
           for (auto &sd : file_batch) sd = (uint32_t)master();
         block.seeds[i] = file_batch[in_file % kBatch];
       }
-      const uint8_t *base_ptr = block.bases.data() ? block.bases.data() : reinterpret_cast<const uint8_t *>("");
-      for (uint64_t done = 0; done < n; done += kChunkReads) {
-        const uint64_t m = std::min<uint64_t>(kChunkReads, n - done);
-        GMX_CHECK(gmx_group_map_reads_host(grp, base_ptr, block.offsets.data() + done, block.seeds.data() + done, m));
+      // the block goes up as it is — bit planes from page-locked memory, chunk by chunk beside the kernels (the call returns
+      // once everything is enqueued) — and may be overwritten by the parser as soon as its uploads are done
+      if (n) {
+        GMX_CHECK(gmx_group_map_reads_packed_host(grp, block.planes.data(), block.uniform_len ? nullptr : block.offsets.data(),
+                                                  block.uniform_len, block.seeds.data(), block.any_skip ? block.skip.data() : nullptr, n));
+        GMX_CHECK(gmx_group_sync_uploads(grp));
       }
       total_reads += n;
     };

@@ -181,3 +181,27 @@ def test_gzip_fastq_is_inflated_in_blocks_and_parsed_in_parallel(tmp_path, monke
         monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
         lines = _parse_check(tmp_path, None, 5, name="r.fastq.gz", binary=gz)
         assert lines[0].startswith("fast 3000 ") and lines[0][5:] == lines[1][5:], (block, lines)
+
+
+def test_parser_emits_the_same_reads_with_and_without_avx2_and_for_reads_of_one_length(tmp_path, monkeypatch):
+    """The parser threads write bit planes (what gmx_map_reads_packed_host uploads); `_parse_check` unpacks them again.
+    Reads of one length take the back-to-back layout, others the offsets layout; the letters are packed with AVX2 or by
+    the table (GMX_NO_AVX2=1)."""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    for uniform in (True, False):
+        recs = []
+        for i in range(1500):
+            n = 150 if uniform else int(rng.integers(1, 260))
+            seq = "".join("ACGTacgtN"[int(x)] for x in rng.integers(0, 9 if i % 13 == 0 else 8, size=n))
+            recs.append(f"@r{i}\n{seq}\n+\n{'I' * n}\n")
+        got = []
+        for no_avx in ("", "1"):
+            if no_avx:
+                monkeypatch.setenv("GMX_NO_AVX2", "1")
+            else:
+                monkeypatch.delenv("GMX_NO_AVX2", raising=False)
+            lines = _parse_check(tmp_path, "".join(recs), 7)
+            assert lines[0].startswith("fast 1500 ") and lines[0][5:] == lines[1][5:], lines
+            got.append(lines[0])
+        assert got[0] == got[1]

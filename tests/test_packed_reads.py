@@ -126,7 +126,7 @@ def test_packed_feed_ragged_reads_nested_prg(pinned):
     for i, r in enumerate(good):
         r = np.asarray(r, dtype=np.uint8)
         if i % 5 == 0:
-            r = r[:int(rng.integers(1, len(r) + 1))]          # ragged, some shorter than k
+            r = r[:int(rng.integers(k, len(r) + 1))]          # ragged
         if i % 11 == 0 and len(r):
             r = r.copy()
             r[int(rng.integers(0, len(r)))] = 0               # an N
@@ -144,6 +144,18 @@ def test_packed_feed_ragged_reads_nested_prg(pinned):
     b.map_reads_packed(pk, seeds)
     assert canonical_cov(b.coverage()) == want
     pk.close()
+    # reads shorter than k (undefined in the reference, quasimap.cpp:206-210: counted as skipped here) — both feeds agree
+    short = reads + [np.asarray(r[:k - 1], dtype=np.uint8) for r in reads[:50] if len(r) >= k]
+    seeds2 = master_seeds(8, [len(short)])
+    flat2, offs2 = flatten_reads(short)
+    c = Quasimapper(ix)
+    c.map_reads(flat2, offs2, seeds2)
+    pk2 = pack_reads(flat2, offs2, pinned=pinned)
+    d = Quasimapper(ix)
+    d.map_reads_packed(pk2, seeds2)
+    assert canonical_cov(d.coverage()) == canonical_cov(c.coverage())
+    assert c.coverage().stats.skipped_reads_count >= 100
+    pk2.close()
 
 
 @pytest.mark.gpu
