@@ -18,6 +18,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -307,8 +308,9 @@ static const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
 static const bool kHaveAvx2 = false;
 static bool pack_ascii_avx2(const unsigned char *src, size_t n, uint64_t *out) { return pack_ascii_scalar(src, n, out); }
 #endif
+static const bool kUseAvx2 = kHaveAvx2 && !getenv("GMX_NO_AVX2");  // (GMX_NO_AVX2=1: the table path, for the tests)
 static inline bool pack_ascii(const unsigned char *src, size_t n, uint64_t *out) {
-  return kHaveAvx2 && !getenv("GMX_NO_AVX2") ? pack_ascii_avx2(src, n, out) : pack_ascii_scalar(src, n, out);
+  return kUseAvx2 ? pack_ascii_avx2(src, n, out) : pack_ascii_scalar(src, n, out);
 }
 
 // fn(t) for t = 0 .. T-1 on a pool of waiting threads: a 96 MB block goes through three such phases, and starting 64
@@ -384,24 +386,41 @@ void parallel_for(unsigned T, F fn) {
   const std::function<void(unsigned)> f = fn;
   WorkerPool::get().run(T, f);
 }
+// where the feed's wall time goes (printed with the timer report): reading, parsing, and the consumer's engine calls
+struct FeedTimes {
+  double read_s = 0, parse_s = 0, map_s = 0, wait_slot_s = 0, scan_s = 0, pack_s = 0, seeds_s = 0;
+};
+static FeedTimes g_feed;
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
 // the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
 // Returns false on anything that is not plain four-line FASTQ.
-// Two parallel phases: every thread finds the records that start in its byte range (sequence start + length each);
-// then, with the reads' places known (prefix sums; one length for all or not), every thread packs its records' letters
-// straight into the block's page-locked output (no per-thread copies to merge).
-bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed) {
+// Two parallel phases: every thread finds the records that start in its byte range and packs their letters at once
+// (the text is read once, while it is in cache) into planes of its own; then, with the reads' places known (prefix sums;
+// one length for all or not), every thread copies its planes (40 bytes per 150-base read) into the block's page-locked output.
+// `fill` (plain files): the bytes d[fill->have, size) are not there yet — thread t of the scan first reads its slice of them
+// from the file (pread, straight from the page cache) and then parses its range of the buffer, waiting for a neighbour's
+// slice only where a record of its range reaches into it: the file is read and parsed in ONE pass over memory, by the same
+// core, instead of a read phase and a parse phase with a barrier between them.
+struct BlockFill {
+  int fd = -1;
+  size_t have = 0;      // bytes of d already valid (the tail of the block before)
+  size_t file_at = 0;   // file offset of d[have]
+  std::atomic<int> *loaded = nullptr;  // per slice: 0 = being read, 1 = there, -1 = read error
+  bool io_error = false;
+};
+bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed,
+                        BlockFill *fill = nullptr) {
   out.reset();
   consumed = 0;
   if (size == 0) return true;
+  if (fill && fill->have == 0 && pread(fill->fd, const_cast<char *>(d), 1, (off_t)fill->file_at) != 1) return false;  // (d[0] ahead of the slices)
   if (d[0] != '@') return false;
   const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
-  struct Rec {
-    uint64_t at;   // start of the sequence line in d
-    uint32_t len;
-  };
   struct Part {
-    std::vector<Rec> recs;
+    std::vector<uint64_t> planes;  // ceil(len / 32) pairs per read, back to back
+    std::vector<uint32_t> lens;
+    std::vector<uint8_t> skip;
     bool bad = false;
     size_t first = 0, stop = 0;  // start of the first record this range parsed, end of its last one
     uint64_t bases = 0;
@@ -409,16 +428,58 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
     bool one_len = true;
     bool any_skip = false;
   };
-  static std::vector<Part> parts;  // (kept between blocks: the record vectors keep their capacity)
+  static std::vector<Part> parts;  // (kept between blocks: the vectors keep their capacity and their touched pages)
   parts.resize(T);
-  auto line_end = [&](size_t at) {  // index of the '\n' ending the line at `at`, or size
-    if (at >= size) return size;
-    const void *nl = memchr(d + at, '\n', size - at);
-    return nl ? (size_t)((const char *)nl - d) : size;
-  };
+  const size_t fill_have = fill ? fill->have : size, fill_want = size - fill_have;
+  auto slice_at = [&](unsigned j) { return fill_have + fill_want * j / T; };  // slice j = d[slice_at(j), slice_at(j + 1))
+  std::atomic<bool> io_error{false};
   auto scan = [&](unsigned t) {
     Part &p = parts[t];
-    p.recs.clear();
+    // --- this thread's slice of the file ---
+    if (fill) {
+      size_t lo = slice_at(t), hi = slice_at(t + 1);
+      bool ok = true;
+      while (lo < hi && ok) {
+        const ssize_t got = pread(fill->fd, const_cast<char *>(d) + lo, hi - lo, (off_t)(fill->file_at + (lo - fill_have)));
+        if (got <= 0) ok = false; else lo += (size_t)got;
+      }
+      if (!ok) io_error.store(true);
+      fill->loaded[t].store(ok ? 1 : -1, std::memory_order_release);
+    }
+    // --- bytes of the buffer this thread may look at: [.., avail), grown slice by slice as its records need them ---
+    size_t avail = fill ? fill_have : size;
+    unsigned next_slice = 0;
+    bool aborted = false;
+    auto grow = [&]() {  // waits for the next slice; false when there is none (or its read failed)
+      if (next_slice >= T) return false;
+      int v;
+      while ((v = fill->loaded[next_slice].load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+      if (v < 0) {
+        aborted = true;
+        return false;
+      }
+      ++next_slice;
+      avail = slice_at(next_slice);
+      return true;
+    };
+    auto ensure = [&](size_t end) {  // d[0, min(end, size)) readable
+      while (avail < end && avail < size)
+        if (!grow()) break;
+    };
+    auto line_end = [&](size_t at) {  // index of the '\n' ending the line at `at`, or size
+      for (size_t from = at;;) {
+        if (from >= size) return size;
+        ensure(from + 1);
+        if (aborted) return size;
+        const void *nl = memchr(d + from, '\n', avail - from);
+        if (nl) return (size_t)((const char *)nl - d);
+        if (avail >= size) return size;
+        from = avail;
+      }
+    };
+    p.planes.clear();
+    p.lens.clear();
+    p.skip.clear();
     p.bad = false;
     p.bases = 0;
     p.len0 = 0;
@@ -434,6 +495,7 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
           at = size;
           break;
         }
+        ensure(e2 + 2);
         if (d[at] == '@' && d[e2 + 1 < size ? e2 + 1 : e2] == '+' && e2 + 1 < size) break;
         if (tries == 5) {
           p.bad = true;
@@ -443,6 +505,7 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
       }
     }
     p.first = at;
+    if (p.planes.capacity() < (hi - lo) / 6 + 64) p.planes.reserve((hi - lo) / 6 + 64);
     while (at < hi && at < size && !p.bad) {
       const size_t e1 = line_end(at), s2 = e1 + 1, e2 = line_end(s2), s3 = e2 + 1, e3 = line_end(s3), s4 = e3 + 1,
                    e4 = line_end(s4);
@@ -458,29 +521,38 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
         p.bad = true;
         break;
       }
-      if (p.recs.empty()) p.len0 = (uint32_t)n;
+      if (p.lens.empty()) p.len0 = (uint32_t)n;
       p.one_len = p.one_len && (uint32_t)n == p.len0;
-      p.recs.push_back(Rec{(uint64_t)s2, (uint32_t)n});
+      const size_t pairs = (n + 31) / 32, had = p.planes.size();
+      p.planes.resize(had + pairs);
+      const bool ok = pack_ascii(reinterpret_cast<const unsigned char *>(d) + s2, n, p.planes.data() + had);
+      p.lens.push_back((uint32_t)n);
+      p.skip.push_back(ok ? 0 : 1);
+      p.any_skip = p.any_skip || !ok;
       p.bases += n;
       at = e4 < size ? e4 + 1 : size;
     }
     p.stop = at;
+    if (aborted) p.bad = true;
   };
+  const double t_scan = now_s();
   parallel_for(T, scan);
+  g_feed.scan_s += now_s() - t_scan;
+  if (fill) fill->io_error = io_error.load();
   for (unsigned t = 0; t < T; ++t)
     if (parts[t].bad) return false;
   // the ranges' records must chain into one gap-free prefix of the buffer; what follows it (an incomplete record, or
   // records no range could recognise from inside) is left for the next block, where it sits at the start
   size_t cursor = 0;
   for (unsigned t = 0; t < T; ++t) {
-    if (parts[t].recs.empty()) continue;
+    if (parts[t].lens.empty()) continue;
     if (parts[t].first != cursor) return false;
     cursor = parts[t].stop;
   }
   if (final && cursor != size) return false;
   consumed = cursor;
   for (unsigned t = 0; t < T; ++t)  // drop what lies behind the prefix (cannot happen when the chain is intact)
-    if (!parts[t].recs.empty() && parts[t].first >= consumed) return false;
+    if (!parts[t].lens.empty() && parts[t].first >= consumed) return false;
   size_t n_reads = 0;
   uint64_t n_bases = 0;
   std::vector<size_t> r0(T);
@@ -490,11 +562,12 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
   for (unsigned t = 0; t < T; ++t) {
     r0[t] = n_reads;
     b0[t] = n_bases;
-    if (!parts[t].recs.empty()) {
+    if (!parts[t].lens.empty()) {
       if (n_reads == 0) len0 = parts[t].len0;
       uniform = uniform && parts[t].one_len && parts[t].len0 == len0;
+      out.any_skip = out.any_skip || parts[t].any_skip;
     }
-    n_reads += parts[t].recs.size();
+    n_reads += parts[t].lens.size();
     n_bases += parts[t].bases;
   }
   out.n_reads = n_reads;
@@ -505,36 +578,34 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
   out.planes.resize(n_pairs + 8);  // (+ slack: the device fetches whole 16-byte pieces)
   out.skip.resize(std::max<size_t>(n_reads, 1));
   out.offsets.resize(n_reads + 1);
+  const double t_pack = now_s();
   parallel_for(T, [&](unsigned t) {
-    Part &p = parts[t];
+    const Part &p = parts[t];
+    if (p.lens.empty()) return;
+    memcpy(out.skip.data() + r0[t], p.skip.data(), p.skip.size());
+    if (out.uniform_len) {
+      memcpy(out.planes.data() + r0[t] * ppr, p.planes.data(), p.planes.size() * sizeof(uint64_t));
+      return;
+    }
     uint64_t off = b0[t];
-    for (size_t i = 0; i < p.recs.size(); ++i) {
+    size_t from = 0;
+    for (size_t i = 0; i < p.lens.size(); ++i) {
       const size_t r = r0[t] + i;
-      const uint64_t at = out.uniform_len ? r * ppr : (off >> 5) + r;
-      const uint32_t len = p.recs[i].len;
-      const bool ok = pack_ascii(reinterpret_cast<const unsigned char *>(d) + p.recs[i].at, len, out.planes.data() + at);
-      if (!out.uniform_len) {
-        out.offsets[r] = off;
-        const uint64_t next = ((off + len) >> 5) + r + 1;
-        for (uint64_t q = at + (len + 31u) / 32u; q < next; ++q) out.planes[q] = 0;  // gap pair of the offsets form
-      }
-      out.skip[r] = ok ? 0 : 1;
-      p.any_skip = p.any_skip || !ok;
+      const uint32_t len = p.lens[i];
+      const uint64_t at = (off >> 5) + r, pairs = (len + 31u) / 32u, next = ((off + len) >> 5) + r + 1;
+      memcpy(out.planes.data() + at, p.planes.data() + from, pairs * sizeof(uint64_t));
+      for (uint64_t q = at + pairs; q < next; ++q) out.planes[q] = 0;  // gap pair of the offsets form
+      out.offsets[r] = off;
+      from += pairs;
       off += len;
     }
   });
+  g_feed.pack_s += now_s() - t_pack;
   out.offsets[n_reads] = n_bases;
-  for (unsigned t = 0; t < T; ++t) out.any_skip = out.any_skip || parts[t].any_skip;
   for (uint64_t q = n_pairs; q < n_pairs + 8; ++q) out.planes[q] = 0;
   return true;
 }
 
-// where the feed's wall time goes (printed with the timer report): reading, parsing, and the consumer's engine calls
-struct FeedTimes {
-  double read_s = 0, parse_s = 0, map_s = 0, wait_slot_s = 0;
-};
-static FeedTimes g_feed;
-static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // GMX_FEED_TRACE=1 in the environment: the feed's events with their times on stderr
 static double g_trace_t0 = 0;
 static const bool g_trace = getenv("GMX_FEED_TRACE") != nullptr;
@@ -653,6 +724,9 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     if (fd >= 0) close(fd);
   };
   std::unique_ptr<BlockPipe> pipe;  // started with the first good block
+  BlockFill fill;
+  bool use_fill = false;
+  std::unique_ptr<std::atomic<int>[]> loaded(new std::atomic<int>[T]);
   for (;;) {
     bool final;
     const double t_read = now_s();
@@ -669,21 +743,14 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
       }
       final = gzeof(g) != 0 || have < kBlock;
     } else {
+      // (plain file: the parser's threads read the block themselves, each its slice, and parse it at once: BlockFill)
       const size_t want = std::min(kBlock - std::min(kBlock, have), file_size - file_at);
-      std::vector<int> bad(T, 0);
-      parallel_for(T, [&](unsigned t) {  // page cache -> buffer at memory speed
-        size_t lo = want * t / T, hi = want * (t + 1) / T;
-        while (lo < hi) {
-          ssize_t got = pread(fd, buf.data() + have + lo, hi - lo, (off_t)(file_at + lo));
-          if (got <= 0) {
-            bad[t] = 1;
-            return;
-          }
-          lo += (size_t)got;
-        }
-      });
-      for (int b : bad)
-        if (b) die("gram: " + path + ": read error");
+      fill.fd = fd;
+      fill.have = have;
+      fill.file_at = file_at;
+      for (unsigned t = 0; t < T; ++t) loaded[t].store(0, std::memory_order_relaxed);
+      fill.loaded = loaded.get();
+      use_fill = true;
       have += want;
       file_at += want;
       final = file_at >= file_size;
@@ -693,7 +760,8 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     ParsedReads scratch;
     ParsedReads &block = pipe ? pipe->acquire() : scratch;
     const double t_parse = now_s();
-    const bool parsed = parse_fastq_buffer(buf.data(), have, final, threads, block, consumed);
+    const bool parsed = parse_fastq_buffer(buf.data(), have, final, threads, block, consumed, use_fill ? &fill : nullptr);
+    if (use_fill && fill.io_error) die("gram: " + path + ": read error");
     g_feed.parse_s += now_s() - t_parse;
     feed_trace("block parsed");
     if (!parsed || (!final && consumed == 0)) {
@@ -864,6 +932,24 @@ int run_parse_check(const std::string &path, int threads) {
     slow.offsets.push_back(slow.bases.size());
   }
   std::cout << "slow " << slow.offsets.size() - 1 << " " << slow.bases.size() << " " << fnv(slow) << std::endl;
+  return 0;
+}
+
+// `gram _parse_bench FILE THREADS [REPEATS]`: the parallel FASTQ parser alone (no engine): wall time per pass and where it went
+int run_parse_bench(const std::string &path, int threads, int repeats) {
+  for (int rep = 0; rep < repeats; ++rep) {
+    g_feed = FeedTimes{};
+    uint64_t n = 0, bases = 0;
+    const double t0 = now_s();
+    const bool ok = parse_fastq_file(path, threads, [&](ParsedReads &b) {
+      n += b.n_reads;
+      bases += b.n_bases;
+    });
+    const double dt = now_s() - t0;
+    std::cout << (ok ? "parsed " : "declined ") << n << " reads, " << bases << " bases in " << dt << " s = " << n / dt / 1e6
+              << " M reads/s: read " << g_feed.read_s << ", parse " << g_feed.parse_s << " (scan " << g_feed.scan_s << ", pack "
+              << g_feed.pack_s << "), slot wait " << g_feed.wait_slot_s << std::endl;
+  }
   return 0;
 }
 
@@ -1179,7 +1265,7 @@ int run_genotype(const Args &a) {
             << "Timer report (wall seconds)" << std::endl
             << "  Load data (index build + upload): " << t_load << std::endl
             << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl
-            << "    feed: read " << g_feed.read_s << ", parse " << g_feed.parse_s << ", waiting for a free block " << g_feed.wait_slot_s
+            << "    feed: read " << g_feed.read_s << ", parse " << g_feed.parse_s << " (scan " << g_feed.scan_s << ", pack " << g_feed.pack_s << "), waiting for a free block " << g_feed.wait_slot_s
             << "; engine calls (beside the parser) " << g_feed.map_s << std::endl;
   // ---- infer (genotype.cpp:72-118): level genotyping on the host from the coverage just recorded -----------------
   std::cout << "====================" << std::endl << "Running genotyping" << std::endl;
@@ -1222,6 +1308,10 @@ int main(int argc, const char *const *argv) {
   if (help || command.empty()) {
     std::cout << kGlobalHelp << std::endl;
     return 0;
+  }
+  if (command == "_parse_bench") {  // the parallel reads parser alone, timed (tools/parse_bench.sh)
+    if (argc < cmd_at + 3) die("usage: gram _parse_bench FILE THREADS [REPEATS]");
+    return run_parse_bench(argv[cmd_at + 1], atoi(argv[cmd_at + 2]), argc > cmd_at + 3 ? atoi(argv[cmd_at + 3]) : 3);
   }
   if (command == "_parse_check") {  // test hook: both read parsers on one file, no GPU (tests/test_gram_cli.py)
     if (cmd_at + 2 >= argc) return 1;

@@ -205,3 +205,20 @@ def test_parser_emits_the_same_reads_with_and_without_avx2_and_for_reads_of_one_
             assert lines[0].startswith("fast 1500 ") and lines[0][5:] == lines[1][5:], lines
             got.append(lines[0])
         assert got[0] == got[1]
+
+
+def test_plain_fastq_read_and_parsed_in_one_pass_with_tiny_blocks(tmp_path, monkeypatch):
+    """Plain files: every parser thread reads its slice of the block from the file and parses at once, waiting for a
+    neighbour's slice where a record reaches into it. Blocks and slices far smaller than a record exercise every wait."""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    recs = []
+    for i in range(1200):
+        n = int(rng.integers(1, 400))
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5 if i % 10 == 0 else 4, size=n))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 75, size=n))
+        recs.append(f"@r{i}\n{seq}\n+\n{'@' + qual[1:] if i % 3 == 0 else qual}\n")
+    for block, threads in (("900", 16), ("3000", 64), ("65536", 5)):
+        monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
+        lines = _parse_check(tmp_path, "".join(recs), threads)
+        assert lines[0].startswith("fast 1200 ") and lines[0][5:] == lines[1][5:], (block, lines)

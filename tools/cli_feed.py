@@ -21,7 +21,7 @@ reads = simulate_snp_reads(ref, pos, alts, n_alts, n, 150, 1000)
 gram = build_gram()
 with tempfile.TemporaryDirectory(dir="/tmp") as d:
     np.asarray(prg, dtype="<u4").tofile(os.path.join(d, "prg"))
-    write_fastq(os.path.join(d, "r.fq"), reads)
+    write_fastq(os.path.join(d, "r.fq"), [reads])
     subprocess.run([gram, "build", "--gram_dir", d, "--kmer_size", str(KMER), "--max_threads", threads], stdout=subprocess.DEVNULL)
     for rep in range(2):
         t0 = time.time()
