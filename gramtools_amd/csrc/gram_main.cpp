@@ -408,13 +408,14 @@ struct BlockFill {
   size_t file_at = 0;   // file offset of d[have]
   std::atomic<int> *loaded = nullptr;  // per slice: 0 = being read, 1 = there, -1 = read error
   bool io_error = false;
+  int populate = 0;     // memory-mapped file (fd < 0): 1 = every thread maps its range's pages in one call first (MADV_POPULATE_READ)
 };
 bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, ParsedReads &out, size_t &consumed,
                         BlockFill *fill = nullptr) {
   out.reset();
   consumed = 0;
   if (size == 0) return true;
-  if (fill && fill->have == 0 && pread(fill->fd, const_cast<char *>(d), 1, (off_t)fill->file_at) != 1) return false;  // (d[0] ahead of the slices)
+  if (fill && fill->fd >= 0 && fill->have == 0 && pread(fill->fd, const_cast<char *>(d), 1, (off_t)fill->file_at) != 1) return false;  // (d[0] ahead of the slices)
   if (d[0] != '@') return false;
   const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
   struct Part {
@@ -430,13 +431,21 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
   };
   static std::vector<Part> parts;  // (kept between blocks: the vectors keep their capacity and their touched pages)
   parts.resize(T);
-  const size_t fill_have = fill ? fill->have : size, fill_want = size - fill_have;
+  const bool filling = fill && fill->fd >= 0;  // (a memory-mapped block is all there)
+  const size_t fill_have = filling ? fill->have : size, fill_want = size - fill_have;
   auto slice_at = [&](unsigned j) { return fill_have + fill_want * j / T; };  // slice j = d[slice_at(j), slice_at(j + 1))
   std::atomic<bool> io_error{false};
   auto scan = [&](unsigned t) {
     Part &p = parts[t];
     // --- this thread's slice of the file ---
-    if (fill) {
+    if (fill && !filling && fill->populate) {
+#ifdef MADV_POPULATE_READ
+      const uintptr_t lo = (reinterpret_cast<uintptr_t>(d) + size * t / T) & ~(uintptr_t)4095,
+                      hi = (reinterpret_cast<uintptr_t>(d) + size * (t + 1) / T + 4095) & ~(uintptr_t)4095;
+      if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_READ);
+#endif
+    }
+    if (filling) {
       size_t lo = slice_at(t), hi = slice_at(t + 1);
       bool ok = true;
       while (lo < hi && ok) {
@@ -447,7 +456,7 @@ bool parse_fastq_buffer(const char *d, size_t size, bool final, int threads, Par
       fill->loaded[t].store(ok ? 1 : -1, std::memory_order_release);
     }
     // --- bytes of the buffer this thread may look at: [.., avail), grown slice by slice as its records need them ---
-    size_t avail = fill ? fill_have : size;
+    size_t avail = filling ? fill_have : size;
     unsigned next_slice = 0;
     bool aborted = false;
     auto grow = [&]() {  // waits for the next slice; false when there is none (or its read failed)
@@ -723,6 +732,17 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     if (g) gzclose(g);
     if (fd >= 0) close(fd);
   };
+  // GMX_FASTQ_MMAP=1: plain files are memory-mapped and parsed in place (no copy out of the page cache); =2: each thread
+  // also maps its range's pages in one call first
+  const char *mm_env = getenv("GMX_FASTQ_MMAP");
+  const int mm_mode = (!gz && mm_env) ? atoi(mm_env) : 0;
+  const char *map = nullptr;
+  size_t map_pos = 0;
+  if (mm_mode) {
+    void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
+    if (m == MAP_FAILED) die("gram: " + path + ": mmap failed");
+    map = static_cast<const char *>(m);
+  }
   std::unique_ptr<BlockPipe> pipe;  // started with the first good block
   BlockFill fill;
   bool use_fill = false;
@@ -742,6 +762,12 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
         have += (size_t)got;
       }
       final = gzeof(g) != 0 || have < kBlock;
+    } else if (map) {
+      have = std::min(kBlock, file_size - map_pos);
+      final = map_pos + have >= file_size;
+      fill.fd = -1;
+      fill.populate = mm_mode >= 2;
+      use_fill = true;
     } else {
       // (plain file: the parser's threads read the block themselves, each its slice, and parse it at once: BlockFill)
       const size_t want = std::min(kBlock - std::min(kBlock, have), file_size - file_at);
@@ -760,7 +786,7 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     ParsedReads scratch;
     ParsedReads &block = pipe ? pipe->acquire() : scratch;
     const double t_parse = now_s();
-    const bool parsed = parse_fastq_buffer(buf.data(), have, final, threads, block, consumed, use_fill ? &fill : nullptr);
+    const bool parsed = parse_fastq_buffer(map ? map + map_pos : buf.data(), have, final, threads, block, consumed, use_fill ? &fill : nullptr);
     if (use_fill && fill.io_error) die("gram: " + path + ": read error");
     g_feed.parse_s += now_s() - t_parse;
     feed_trace("block parsed");
@@ -790,12 +816,18 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
       std::swap(slot0.any_skip, scratch.any_skip);
     }
     pipe->submit();
-    memmove(buf.data(), buf.data() + consumed, have - consumed);
-    have -= consumed;
+    if (map) {
+      map_pos += consumed;
+      have = 0;
+    } else {
+      memmove(buf.data(), buf.data() + consumed, have - consumed);
+      have -= consumed;
+    }
     if (final) break;
   }
   pipe->finish();
   feed_trace("pipe drained");
+  if (map && !getenv("GMX_FASTQ_KEEP_MAP")) munmap(const_cast<char *>(map), file_size);
   shut();
   return true;
 }
