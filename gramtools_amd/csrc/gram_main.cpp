@@ -732,16 +732,17 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     if (g) gzclose(g);
     if (fd >= 0) close(fd);
   };
-  // GMX_FASTQ_MMAP=1: plain files are memory-mapped and parsed in place (no copy out of the page cache); =2: each thread
-  // also maps its range's pages in one call first
+  // Plain files are memory-mapped and parsed in place: one pass over the page cache's own pages (measured on the GPU
+  // box, 4 M reads, 64 threads: 16 ms against 25-33 ms for pread into a block buffer + parse, whose copy triples the
+  // memory traffic). GMX_FASTQ_MMAP=0: the pread path (also taken when the file cannot be mapped); =2: every thread maps
+  // its range's pages in one call first (no gain measured).
   const char *mm_env = getenv("GMX_FASTQ_MMAP");
-  const int mm_mode = (!gz && mm_env) ? atoi(mm_env) : 0;
+  const int mm_mode = gz ? 0 : (mm_env ? atoi(mm_env) : 1);
   const char *map = nullptr;
   size_t map_pos = 0;
   if (mm_mode) {
     void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
-    if (m == MAP_FAILED) die("gram: " + path + ": mmap failed");
-    map = static_cast<const char *>(m);
+    if (m != MAP_FAILED) map = static_cast<const char *>(m);
   }
   std::unique_ptr<BlockPipe> pipe;  // started with the first good block
   BlockFill fill;
@@ -827,7 +828,7 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   }
   pipe->finish();
   feed_trace("pipe drained");
-  if (map && !getenv("GMX_FASTQ_KEEP_MAP")) munmap(const_cast<char *>(map), file_size);
+  if (map) std::thread([map, file_size]() { munmap(const_cast<char *>(map), file_size); }).detach();  // (4 ms per GB: off the caller's path)
   shut();
   return true;
 }
@@ -1007,6 +1008,68 @@ int run_build(const Args &a) {
   return 0;
 }
 
+// The master generator's raw draws (RandomInclusiveInt's mt19937, random.cpp:4-19: operator() = the raw 32-bit output),
+// produced ahead of the reads on a thread of its own in chunks of 1 M draws: 2.5 ns a draw on the feed's consumer
+// thread was half of that thread's time. copy() waits for the chunks it needs; at most kAhead chunks are drawn beyond
+// the last one asked for.
+class SeedStream {
+ public:
+  uint64_t base = 0;  // draw index of the current file's first read
+  explicit SeedStream(uint32_t seed) : gen_(seed) {
+    worker_ = std::thread([this]() { run(); });
+  }
+  ~SeedStream() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    worker_.join();
+  }
+  void copy(uint64_t first, uint64_t n, uint32_t *out) {
+    for (uint64_t done = 0; done < n;) {
+      const uint64_t at = first + done, c = at / kChunk, in = at % kChunk, take = std::min<uint64_t>(n - done, kChunk - in);
+      const uint32_t *src;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        want_ = std::max(want_, c);
+        cv_.notify_all();
+        cv_.wait(lk, [&] { return chunks_.size() > c; });
+        src = chunks_[c].get();
+        for (; freed_ < c; ++freed_) chunks_[freed_].reset();  // (requests only move forward: the chunks behind are done)
+      }
+      memcpy(out + done, src + in, take * sizeof(uint32_t));
+      done += take;
+    }
+  }
+
+ private:
+  static constexpr uint64_t kChunk = 1u << 20, kAhead = 16;
+  void run() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return stop_ || chunks_.size() <= want_ + kAhead; });
+        if (stop_) return;
+      }
+      std::unique_ptr<uint32_t[]> c(new uint32_t[kChunk]);
+      for (uint64_t i = 0; i < kChunk; ++i) c[i] = (uint32_t)gen_();
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        chunks_.push_back(std::move(c));
+      }
+      cv_.notify_all();
+    }
+  }
+  std::mt19937 gen_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<std::unique_ptr<uint32_t[]>> chunks_;
+  uint64_t want_ = 0, freed_ = 0;
+  bool stop_ = false;
+  std::thread worker_;
+};
+
 int run_genotype(const Args &a) {
   using clk = std::chrono::steady_clock;
   std::string gram_dir = a.one("gram_dir");
@@ -1115,21 +1178,22 @@ int run_genotype(const Args &a) {
   feed_trace("quasimap stage starts");
   // One master mt19937(seed) for all files; 5000 draws per batch of <= 5000 reads (quasimap.cpp:120-141).
   std::mt19937 master(seed);
+  SeedStream seed_stream(seed);  // the same stream, drawn ahead on a thread of its own (fast path)
   const uint64_t kBatch = 5000;
   const uint64_t kChunkReads = (uint64_t)(1u << 20) * devices.size();  // reads staged per call: 1 M per engine (multiple of 5000 not required: seeds are per read)
   uint64_t total_reads = 0;
   for (auto const &path : reads_paths) {
-    // fast path: seeds as the batch loop below draws them (5000 master draws per batch of <= 5000 reads, per file)
+    // fast path: seeds as the batch loop below draws them (5000 master draws per batch of <= 5000 reads, per file): read i
+    // of the file takes draw file_base + i of the master stream, and the file uses up ceil(n / 5000) * 5000 draws
     uint64_t in_file = 0;
-    std::vector<uint32_t> file_batch(kBatch);
+    const uint64_t file_base = seed_stream.base;
     auto sink = [&](ParsedReads &block) {  // runs on the pipe's consumer thread, block after block in file order
       const uint64_t n = block.n_reads;
       block.seeds.resize(std::max<uint64_t>(n, 1));
-      for (uint64_t i = 0; i < n; ++i, ++in_file) {
-        if (in_file % kBatch == 0)
-          for (auto &sd : file_batch) sd = (uint32_t)master();
-        block.seeds[i] = file_batch[in_file % kBatch];
-      }
+      const double t_seeds = now_s();
+      seed_stream.copy(file_base + in_file, n, block.seeds.data());
+      g_feed.seeds_s += now_s() - t_seeds;
+      in_file += n;
       // the block goes up as it is — bit planes from page-locked memory, chunk by chunk beside the kernels (the call returns
       // once everything is enqueued) — and may be overwritten by the parser as soon as its uploads are done
       if (n) {
@@ -1139,7 +1203,14 @@ int run_genotype(const Args &a) {
       }
       total_reads += n;
     };
-    if (parse_fastq_file(path, max_threads, sink)) continue;
+    if (parse_fastq_file(path, max_threads, sink)) {
+      seed_stream.base = file_base + (in_file + kBatch - 1) / kBatch * kBatch;
+      continue;
+    }
+    // (the general reader below draws from `master`: bring it to where the stream stands)
+    master.seed(seed);
+    master.discard(seed_stream.base);
+    const uint64_t reads_before = total_reads;
     SeqReader reader(path);
     SeqRecord rec;
     std::vector<uint8_t> bases;
@@ -1167,6 +1238,7 @@ int run_genotype(const Args &a) {
       if (offsets.size() - 1 >= kChunkReads && in_batch == 0) flush();
     }
     flush();
+    seed_stream.base += (total_reads - reads_before + kBatch - 1) / kBatch * kBatch;
   }
   GMX_CHECK(gmx_group_allreduce(grp));  // the one exchange (a single engine: nothing to do)
   GMX_CHECK(gmx_engine_sync(eng));
@@ -1298,7 +1370,7 @@ int run_genotype(const Args &a) {
             << "  Load data (index build + upload): " << t_load << std::endl
             << "  Quasimap (parse + map " << total_reads << " reads): " << t_map << std::endl
             << "    feed: read " << g_feed.read_s << ", parse " << g_feed.parse_s << " (scan " << g_feed.scan_s << ", pack " << g_feed.pack_s << "), waiting for a free block " << g_feed.wait_slot_s
-            << "; engine calls (beside the parser) " << g_feed.map_s << std::endl;
+            << "; engine calls (beside the parser) " << g_feed.map_s << " (seeds " << g_feed.seeds_s << ")" << std::endl;
   // ---- infer (genotype.cpp:72-118): level genotyping on the host from the coverage just recorded -----------------
   std::cout << "====================" << std::endl << "Running genotyping" << std::endl;
   auto t_inf = clk::now();
