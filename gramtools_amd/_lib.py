@@ -33,7 +33,7 @@ class Stats(C.Structure):
 class QueueCounts(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("mapped", "alive", "dead", "overflow_probe", "overflow_extend", "big_mapped",
                                           "cover_general", "cover_mid", "cover_overflow", "seed_cursor", "huge_search",
-                                          "inst_mapped", "huge_cover")]
+                                          "inst_mapped", "huge_cover", "log_replays", "log_replayed_entries")]
 
 
 class Timing(C.Structure):

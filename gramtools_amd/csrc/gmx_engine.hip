@@ -47,9 +47,13 @@
 // GMX_STACK_DEPTH: pending entries (sibling states, unresolved marker hits) per lane, in LDS
 #define GMX_STACK_WORDS 5
 #define GMX_CNT_STRIDE 32      // device counters sit 128 B apart: same-line atomics would serialise in one L2 channel
+#define GMX_N_COUNTERS 40      // per-batch queue counters (SearchOut::counters)
+#define GMX_CNT_LOG_RETRY 30u       // entries of log_retry_list: coverage queue entries whose task found the grouped log full
+#define GMX_CNT_LOG_RETRY_RECS 31u  // ... compact records (log_retry_recs: index into cover_recs)
+#define GMX_CNT_LOG_RETRY_HUGE 33u  // ... tasks the last tier has to search again (log_retry_huge)
+#define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
-#define GMX_LOG_WORDS_PER_READ 32u     // assumed bound on what one read appends to the grouped log (drain policy, launch_batch)
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
 
 // ---------------------------------------------------------------------------
@@ -820,6 +824,11 @@ struct SearchOut {
   uint32_t *big_serial_list;           // ... and for the second part of big_mapped_list (coverage instance 2); counter [28]
   uint32_t *overflow3_list;            // tasks one lane has to search with a whole large-capacity slot (a group's parts did not suffice); counter [29]
   uint32_t split_twice;                // the extend kernel's overflow queue goes through the split search as well
+  // A task that finds the grouped log full (sites with more than 5 alleles) has recorded nothing: its queue entry goes
+  // to one of these lists, the host drains the log after the batch and has the entries redone (launch_log_replay).
+  uint32_t *log_retry_list;            // coverage queue entries (task / large-capacity slot / instance slot); counter [30]
+  uint32_t *log_retry_recs;            // compact records, as index into cover_recs; counter [31]
+  uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
 #ifndef GMX_SEARCHOUT_ALT
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
 #endif
@@ -1798,16 +1807,25 @@ struct CoverLogPart {
   uint32_t log_cap;
   uint32_t status;
   uint32_t log_at;
+  uint32_t log_end = 0;  // end of this task's reservation
   uint32_t log_sites;  // the index has sites that use the log
   __device__ __forceinline__ bool has_log_sites() const { return log_sites != 0; }
   __device__ __forceinline__ bool log_reserve(uint32_t words) {
     log_at = atomicAdd(log_cursor, words);
     if (log_at > log_cap || words > log_cap - log_at) {
       for (uint32_t i = log_at; i < log_cap; ++i) log[i] = GMX_LOG_PAD;
+      log_end = log_at;
       status = GMX_TASK_LOGFULL;
       return false;
     }
+    log_end = log_at + words;
     return true;
+  }
+  // a task that failed AFTER its reservation (a condition on which the reference throws) leaves no unwritten words behind
+  __device__ __forceinline__ void log_abandon() {
+    if (status != GMX_TASK_MAPPED && status != GMX_TASK_LOGFULL)
+      for (uint32_t i = log_at; i < log_end && i < log_cap; ++i) log[i] = GMX_LOG_PAD;
+    log_at = log_end = 0;
   }
   __device__ __forceinline__ bool log_grouped_begin(uint32_t site_index, uint32_t n_ids) {
     log[log_at++] = site_index;
@@ -2028,11 +2046,20 @@ __device__ uint32_t gmx_tail_item(const GmxIndexView &ix, const BatchView &b, co
   env.status = GMX_TASK_MAPPED;
   env.log_at = 0;
   gmx_cover_task(ix, env, finals, nf, len, b.seeds[task >> 1], acc.rng_mode);
+  env.log_abandon();
   if (env.status == GMX_TASK_MAPPED && is_search) {
     atomicAdd(&acc.stats[4], 1ull);  // exact_mapped
     o.n_final[task] = nf;
   }
   return env.status;
+}
+
+// a work item of the last tier that found the grouped log full: redone after the host has drained the log
+__device__ __forceinline__ void gmx_tail_log_retry(const SearchOut &o, uint32_t item, uint32_t n_search) {
+  if (item < n_search)
+    o.log_retry_huge[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY_HUGE * GMX_CNT_STRIDE], 1u)] = o.huge_list[item];
+  else
+    o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = o.cover_huge_list[item - n_search];
 }
 
 __device__ void gmx_tail_stage(const GmxIndexView &ix, const BatchView &b, const SearchOut &o, const BigOut &g, const CoverAcc &acc) {
@@ -2051,6 +2078,8 @@ __device__ void gmx_tail_stage(const GmxIndexView &ix, const BatchView &b, const
                                       false, task);
     if (item < total && st == GMX_TASK_OVERFLOW)
       o.huge_retry[atomicAdd(&n_retry, 1u)] = item;
+    else if (item < total && st == GMX_TASK_LOGFULL)
+      gmx_tail_log_retry(o, item, n_search);
     else if (item < total && st != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, st) == 0u)
       o.error[1] = task;
   }
@@ -2060,7 +2089,10 @@ __device__ void gmx_tail_stage(const GmxIndexView &ix, const BatchView &b, const
   for (uint32_t i = 0; i < retries; ++i) {  // lane 0 alone, the whole heap
     uint32_t task = 0;
     const uint32_t st = gmx_tail_item(ix, b, o, g, acc, lane == 0, o.huge_retry[i], n_search, acc.heap, acc.heap_words, true, task);
-    if (lane == 0 && st != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, st) == 0u) o.error[1] = task;
+    if (lane == 0 && st == GMX_TASK_LOGFULL)
+      gmx_tail_log_retry(o, o.huge_retry[i], n_search);
+    else if (lane == 0 && st != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, st) == 0u)
+      o.error[1] = task;
   }
 }
 
@@ -2141,6 +2173,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
     atomicAdd(&gmx_cover_stats[LIST * 16 + 7], 1ull);
 #endif
     gmx_cover_task(ix, env, finals, nf, len, b.seeds[read], acc.rng_mode);
+    env.log_abandon();
 #ifdef GMX_LOOP_STATS
     env.prof(5);
     t_kernel = env.prof_t;
@@ -2151,6 +2184,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
       o.cover_overflow_list[atomicAdd(&o.counters[4 * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status == GMX_TASK_OVERFLOW) {  // beyond the largest fixed scratch: the last tier sizes one from its heap
       o.cover_huge_list[atomicAdd(&o.counters[15 * GMX_CNT_STRIDE], 1u)] = entry;
+    } else if (env.status == GMX_TASK_LOGFULL) {  // nothing recorded: again once the host has drained the log
+      o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = entry;
     } else if (env.status != GMX_TASK_MAPPED) {
       if (atomicCAS(&o.error[0], 0u, env.status) == 0u) o.error[1] = task;
     }
@@ -2361,7 +2396,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
     const uint32_t members16 = (uint32_t)(__ballot(member) >> gbase) & 0xFFFFu;
     GMX_COOP_PHASE(2);
     // --- the drawn class: its first lane merges the members and records ---
-    bool class_overflow = false;
+    bool class_overflow = false, class_logfull = false;
     if (member && gl == (uint32_t)__ffs(members16) - 1u) {
       const uint32_t read = ts.task >> 1;
       const uint32_t len = read_len(b, read);
@@ -2410,9 +2445,14 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
       ce.arena = ts.arena;
       if (ok) gmx_class_record(ix, ce, n_loci, n_hull);
       class_overflow = ce.status == GMX_TASK_OVERFLOW;
-      if (ce.status != GMX_TASK_MAPPED && !class_overflow) err = ce.status;
+      class_logfull = ce.status == GMX_TASK_LOGFULL;
+      if (ce.status != GMX_TASK_MAPPED && !class_overflow && !class_logfull) err = ce.status;
+      ce.log_abandon();
     }
     rejected = rejected || (((uint32_t)(__ballot(class_overflow) >> gbase) & 0xFFFFu) != 0u);
+    const bool logfull = (((uint32_t)(__ballot(class_logfull) >> gbase) & 0xFFFFu) != 0u);
+    if (have && gl == 0 && logfull)
+      o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = entry;
     if (have && gl == 0 && rejected) reject[atomicAdd(reject_n, 1u)] = entry;
     if (err != 0u && atomicCAS(&o.error[0], 0u, err) == 0u) o.error[1] = ts.task;
     __syncthreads();  // the scratch is reused by the next round
@@ -2448,13 +2488,10 @@ struct CompactEnv : CoverLogPart {
 
 // The common case, one lane per compact record and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
 // final state of width one. Few registers, a coalesced queue, region-local tables.
-__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
-  const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
-  const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
-  const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
-  if (m >= n_mapped) return;
+__device__ __forceinline__ void gmx_cover_single_rec(const GmxIndexView &ix, const SearchOut &o, const CoverAcc &acc, size_t rec_idx,
+                                                     uint32_t *handoff_list, uint32_t handoff_counter) {
   CompactEnv env;
-  env.rec = o.cover_recs[(size_t)region * o.region_cap + m];
+  env.rec = o.cover_recs[rec_idx];
   env.acc = acc.acc;
   env.log = acc.log;
   env.log_cursor = acc.log_cursor;
@@ -2466,10 +2503,48 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   if (!ix.is_nested) {
     gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
   } else if (!gmx_cover_single_nested(ix, env, st, env.rec.len_n & 0xFFFFu)) {  // many loci: the general instance next
-    o.cover_general_list[atomicAdd(&o.counters[8 * GMX_CNT_STRIDE], 1u)] = o.cover_rec_task[(size_t)region * o.region_cap + m];
+    handoff_list[atomicAdd(&o.counters[handoff_counter * GMX_CNT_STRIDE], 1u)] = o.cover_rec_task[rec_idx];
   }
-  if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u)
-    o.error[1] = o.cover_rec_task[(size_t)region * o.region_cap + m];
+  if (env.status == GMX_TASK_LOGFULL) {  // nothing recorded: again once the host has drained the log
+    o.log_retry_recs[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY_RECS * GMX_CNT_STRIDE], 1u)] = (uint32_t)rec_idx;
+  } else if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u) {
+    o.error[1] = o.cover_rec_task[rec_idx];
+  }
+  env.log_abandon();
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
+  const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
+  const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
+  const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
+  if (m >= n_mapped) return;
+  gmx_cover_single_rec(ix, o, acc, (size_t)region * o.region_cap + m, o.cover_general_list, 8u);
+}
+
+// ---- grouped log full: the batch's failed entries again, after the host has drained the log (launch_log_replay) ----
+// moves the retry lists' lengths to where the replay kernels read them and empties the retry lists for this round
+__global__ void gmx_log_replay_setup_kernel(SearchOut o, const uint32_t *retry_huge_in) {
+  uint32_t *c = o.counters;
+  const uint32_t n_entries = c[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], n_recs = c[GMX_CNT_LOG_RETRY_RECS * GMX_CNT_STRIDE],
+                 n_huge = c[GMX_CNT_LOG_RETRY_HUGE * GMX_CNT_STRIDE];
+  for (uint32_t i = threadIdx.x; i < n_huge; i += blockDim.x) o.huge_list[i] = retry_huge_in[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    c[4 * GMX_CNT_STRIDE] = n_entries;                 // gmx_cover_kernel<CoverEnvBig, 1> reads its queue length here
+    c[GMX_CNT_REPLAY_RECS * GMX_CNT_STRIDE] = n_recs;
+    c[11 * GMX_CNT_STRIDE] = n_huge;                   // the last tier's search items
+    c[15 * GMX_CNT_STRIDE] = 0;
+    c[14 * GMX_CNT_STRIDE] = 0;                        // the ticket counter of the last-tier stage
+    c[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE] = 0;
+    c[GMX_CNT_LOG_RETRY_RECS * GMX_CNT_STRIDE] = 0;
+    c[GMX_CNT_LOG_RETRY_HUGE * GMX_CNT_STRIDE] = 0;
+  }
+}
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_replay_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc,
+                                                                            const uint32_t *recs_in) {
+  const uint32_t n = o.counters[GMX_CNT_REPLAY_RECS * GMX_CNT_STRIDE];
+  for (uint32_t i = blockIdx.x * GMX_BLOCK + threadIdx.x; i < n; i += gridDim.x * GMX_BLOCK)
+    gmx_cover_single_rec(ix, o, acc, recs_in[i], o.cover_overflow_list, 4u);  // (nested, many loci: the large scratch, which runs next)
 }
 
 // The five uint64 read counters <-> 16-bit limbs in uint32 words, so that they travel inside the one uint32
@@ -2523,7 +2598,7 @@ __global__ void __launch_bounds__(GMX_PACK_THREADS) gmx_pack_kernel(BatchView b,
   __shared__ uint2 outp[GMX_PACK_OUT_PAIRS];
   // the queue counters are per batch: this is the batch's first kernel and everything that counts comes after it
   if (blockIdx.x == 0)
-    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += GMX_PACK_THREADS) counters[i] = 0;
+    for (uint32_t i = threadIdx.x; i < GMX_N_COUNTERS * GMX_CNT_STRIDE; i += GMX_PACK_THREADS) counters[i] = 0;
   // a reset queued just ahead of this batch (gmx_engine_reset_async): the accumulator block, read counters and log
   // cursor zeroed here instead of by a memset of their own (nothing in this kernel touches them otherwise)
   for (uint32_t i = blockIdx.x * GMX_PACK_THREADS + threadIdx.x; i < zero_words; i += gridDim.x * GMX_PACK_THREADS) zero[i] = 0;
@@ -2665,8 +2740,22 @@ struct gmx_engine {
   bool log_sites = false;          // the index has sites with more than 5 alleles
   // grouped log: drained into `log_counts` (records with counts) whenever the device log may run full, and at fetch time
   std::map<std::vector<uint32_t>, uint64_t> log_counts;  // key = [site_index, ids...]
+  // Exact accounting (round 3): after every batch of an engine whose index uses the log, the log cursor and the lengths
+  // of the three retry lists are copied to page-locked words; before the next batch (and before any reader of the
+  // coverage) log_settle() looks at them: entries that found the log full are redone after a drain (launch_log_replay),
+  // and the log is drained once it is half full. No assumed bound on what a read appends.
+  uint32_t *h_log_state = nullptr;     // [cursor, retry entries, retry records, retry last-tier tasks]
+  hipEvent_t ev_log_state = nullptr;
+  bool log_state_pending = false;
+  uint32_t *d_log_retry[2] = {nullptr, nullptr}, *d_log_retry_recs[2] = {nullptr, nullptr}, *d_log_retry_huge[2] = {nullptr, nullptr};
+  int log_retry_side = 0;              // which of the two sets the kernels append to
+  BatchView last_b{};
+  SearchOut last_o{};
+  CoverAcc last_acc{};
+  size_t last_big_lds = 0;
+  uint64_t log_replays = 0, log_replayed_entries = 0;  // statistics (tests)
   uint64_t log_known = 0;          // log words in use after the last drain / look ...
-  uint64_t log_reads_since = 0;    // ... and the reads enqueued since (each assumed to append at most GMX_LOG_WORDS_PER_READ)
+  uint64_t log_reads_since = 0;    // (unused since round 3: the fill is read back after every batch)
   // gmx_engine_reset_async leaves its memset pending: the next batch's pack kernel zeroes the block when it is launched
   // on the same stream (one command and one dependent-launch gap less per job); every other reader of the accumulators
   // issues the memset first (flush_reset)
@@ -2759,6 +2848,7 @@ static int flush_reset(gmx_engine *e) {
 // Grouped log -> host. Waits for the device, adds the log's records to e->log_counts when more than `keep_below` words are in
 // use (and empties the device log), and notes how full it is. Records: [site_index, n_ids, ids...], each worth +1;
 // GMX_LOG_PAD words are padding (CoverLogPart::log_reserve).
+static int log_settle(gmx_engine *e);
 static int gmx_log_drain(gmx_engine *e, uint64_t keep_below) {
   int frc = flush_reset(e);
   if (frc) return frc;
@@ -2839,6 +2929,12 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   e->d_dead2 = e->d_task_lists + (size_t)GMX_TL_DEAD2 * n_tasks;
   e->d_cover_general = e->d_task_lists + (size_t)GMX_TL_GENERAL * n_tasks;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
+  if (e->log_sites)
+    for (int side = 0; side < 2; ++side) {
+      if ((rc = e->alloc(&e->d_log_retry[side], n_tasks, false))) return rc;
+      if ((rc = e->alloc(&e->d_log_retry_recs[side], n_tasks, false))) return rc;
+      if ((rc = e->alloc(&e->d_log_retry_huge[side], n_tasks, false))) return rc;
+    }
   if ((rc = e->alloc(&e->d_cover_mid, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_seed_cursor, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_finals, n_tasks * GMX_FAST_STATES, false))) return rc;
@@ -2952,19 +3048,19 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     e->phys_grouped = h.phys_grouped;
     e->hit_fix = h.hit_fix;
   }
-  // The grouped log is used only by sites with more than 5 alleles. It is drained to the host before it can run full
-  // (launch_batch: GMX_LOG_WORDS_PER_READ words assumed per enqueued read), so two batches' worth is always enough.
+  // The grouped log is used only by sites with more alleles than get dense group counters (gmx_index.cpp: 8). Between
+  // batches the engine looks at its real fill (log_settle): drained when half full; entries that found it full are redone.
   for (const GmxSite &st : h.sites) e->log_sites = e->log_sites || st.grouped_off == GMX_GROUPED_LOG;
   {
     uint64_t cap = opts.log_cap_words ? opts.log_cap_words
-                   : e->log_sites     ? std::max<uint64_t>(1u << 24, 2 * GMX_LOG_WORDS_PER_READ * std::min<uint64_t>(opts.max_batch_reads, 4u << 20))
+                   : e->log_sites     ? (1ull << 26)  // 256 MB; a batch that fills it is settled by drain + replay (log_settle)
                                       : 64;
     e->log_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFF00ull);
   }
   rc |= e->alloc(&e->d_log, e->log_cap, false);
   e->heap_words = opts.huge_heap_bytes / 4 / 64 * 64;
   rc |= e->alloc(&e->d_heap, e->heap_words, false);
-  rc |= e->alloc(&e->d_counters, 32 * GMX_CNT_STRIDE, true);
+  rc |= e->alloc(&e->d_counters, GMX_N_COUNTERS * GMX_CNT_STRIDE, true);
   // large-capacity pass
   e->big.max_states = opts.max_states;
   e->big.max_path_nodes = opts.max_path_nodes;
@@ -3033,6 +3129,8 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->h_log_state) (void)hipHostFree(e->h_log_state);
+  if (e->ev_log_state) (void)hipEventDestroy(e->ev_log_state);
   for (auto &sl : e->pslot) {
     if (sl.copied) (void)hipEventDestroy(sl.copied);
     if (sl.done) (void)hipEventDestroy(sl.done);
@@ -3053,9 +3151,10 @@ int gmx_engine_reset(gmx_engine *e) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemset(e->d_fused, 0, (e->n_fused + 32) * 4));
   HIP_TRY(hipMemset(e->d_error, 0, 8));
-  HIP_TRY(hipMemset(e->d_counters, 0, 32 * GMX_CNT_STRIDE * 4));
+  HIP_TRY(hipMemset(e->d_counters, 0, GMX_N_COUNTERS * GMX_CNT_STRIDE * 4));
   e->log_counts.clear();
   e->log_known = e->log_reads_since = 0;
+  e->log_state_pending = false;
   return GMX_OK;
 }
 
@@ -3068,6 +3167,7 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   e->reset_stream = st;
   e->log_counts.clear();  // what earlier batches left in the device log goes with the cursor
   e->log_known = e->log_reads_since = 0;
+  e->log_state_pending = false;
   return GMX_OK;
 }
 
@@ -3077,6 +3177,72 @@ static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const B
                        st, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
   else
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
+}
+
+// ---- grouped log: exact accounting between batches (engines whose index has sites with more than 5 alleles) ----------
+static int log_state_enqueue(gmx_engine *e, hipStream_t stream) {
+  if (!e->h_log_state) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_log_state), 4 * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_log_state, hipEventDisableTiming));
+  }
+  HIP_TRY(hipMemcpyAsync(e->h_log_state + 0, e->d_log_cursor, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(e->h_log_state + 1, e->d_counters + GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(e->h_log_state + 2, e->d_counters + GMX_CNT_LOG_RETRY_RECS * GMX_CNT_STRIDE, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(e->h_log_state + 3, e->d_counters + GMX_CNT_LOG_RETRY_HUGE * GMX_CNT_STRIDE, 4, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipEventRecord(e->ev_log_state, stream));
+  e->log_state_pending = true;
+  return GMX_OK;
+}
+
+// The entries of the last batch that found the log full, again: setup (list lengths where the kernels read them), the
+// compact records, then the large-scratch coverage instance, whose last block also serves the last tier.
+static int launch_log_replay(gmx_engine *e, hipStream_t stream) {
+  const int in = e->log_retry_side, out = in ^ 1;
+  SearchOut o = e->last_o;
+  o.log_retry_list = e->d_log_retry[out];
+  o.log_retry_recs = e->d_log_retry_recs[out];
+  o.log_retry_huge = e->d_log_retry_huge[out];
+  o.cover_overflow_list = e->d_log_retry[in];  // the queue of gmx_cover_kernel<CoverEnvBig, 1>: this round's entries
+  hipLaunchKernelGGL(gmx_log_replay_setup_kernel, dim3(1), dim3(1024), 0, stream, o, e->d_log_retry_huge[in]);
+  hipLaunchKernelGGL(gmx_cover_single_replay_kernel, dim3(e->n_cus * 4), dim3(GMX_BLOCK), 0, stream, e->dview, e->last_b, o, e->last_acc,
+                     e->d_log_retry_recs[in]);
+  hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), e->last_big_lds, stream, e->dview,
+                     e->last_b, o, e->big, e->last_acc, 64u, 0u);
+  HIP_TRY(hipGetLastError());
+  e->log_retry_side = out;
+  e->last_o.log_retry_list = o.log_retry_list;
+  e->last_o.log_retry_recs = o.log_retry_recs;
+  e->last_o.log_retry_huge = o.log_retry_huge;
+  return log_state_enqueue(e, stream);
+}
+
+static int log_settle(gmx_engine *e) {
+  if (!e->log_state_pending) return GMX_OK;
+  uint64_t before = ~0ull;
+  for (int round = 0;; ++round) {
+    HIP_TRY(hipEventSynchronize(e->ev_log_state));
+    e->log_state_pending = false;
+    const uint32_t used = std::min(e->h_log_state[0], e->log_cap);
+    const uint64_t retries = (uint64_t)e->h_log_state[1] + e->h_log_state[2] + e->h_log_state[3];
+    if (retries == 0) {
+      if (used > e->log_cap / 2) return gmx_log_drain(e, 0);
+      e->log_known = used;
+      return GMX_OK;
+    }
+    if (round > 0 && retries >= before) {  // (every round starts with an empty log: each must get at least one entry through)
+      // an emptied log did not hold one task's records: only more memory helps (gmx_engine_sync reports the read)
+      HIP_TRY(hipDeviceSynchronize());
+      const uint32_t err[2] = {GMX_TASK_LOGFULL, 0};
+      HIP_TRY(hipMemcpy(e->d_error, err, 8, hipMemcpyHostToDevice));
+      return GMX_OK;
+    }
+    before = retries;
+    int rc = gmx_log_drain(e, 0);
+    if (rc) return rc;
+    e->log_replays++;
+    e->log_replayed_entries += retries;
+    if ((rc = launch_log_replay(e, e->last_stream))) return rc;
+  }
 }
 
 // One batch as the kernels see it: reads as bytes (d_reads + d_offsets: gmx_pack_kernel makes the bit planes) or as bit
@@ -3094,7 +3260,7 @@ struct BatchInput {
 // first kernel of a batch whose reads arrive packed: what gmx_pack_kernel does besides packing (queue counters, a queued reset)
 __global__ void gmx_batch_begin_kernel(uint32_t *counters, uint32_t *zero, uint32_t zero_words) {
   if (blockIdx.x == 0)
-    for (uint32_t i = threadIdx.x; i < 32 * GMX_CNT_STRIDE; i += blockDim.x) counters[i] = 0;
+    for (uint32_t i = threadIdx.x; i < GMX_N_COUNTERS * GMX_CNT_STRIDE; i += blockDim.x) counters[i] = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero[i] = 0;
 }
 
@@ -3107,19 +3273,10 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   }
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
+  if (e->log_sites && (rc = log_settle(e))) return rc;  // the batch before: redo what found the log full, drain when half full
   const bool fold_reset = e->reset_pending && e->reset_stream == stream;
   if (e->reset_pending && !fold_reset && (rc = flush_reset(e))) return rc;
   e->reset_pending = false;
-  if (e->log_sites) {  // keep the grouped log from running full: look at its cursor, drain it to the host, before it may
-    if (e->log_known + (e->log_reads_since + n_reads) * GMX_LOG_WORDS_PER_READ > e->log_cap) {
-      if (fold_reset) {  // (cannot happen right after a reset: log_known and log_reads_since are zero then)
-        gmx_set_error("internal: log drain with a reset pending");
-        return GMX_EINVAL;
-      }
-      if ((rc = gmx_log_drain(e, e->log_cap / 4))) return rc;
-    }
-    e->log_reads_since += n_reads;
-  }
   if (!in.d_planes) {
     uint64_t need = total_bases / 32 + n_reads + 16;  // pairs; the slack covers the one-pair look-ahead of planes()
     if (need > e->cap_packed) {
@@ -3176,6 +3333,9 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.big_serial_list = e->d_big_serial;
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
+  o.log_retry_list = e->d_log_retry[e->log_retry_side];
+  o.log_retry_recs = e->d_log_retry_recs[e->log_retry_side];
+  o.log_retry_huge = e->d_log_retry_huge[e->log_retry_side];
   o.stats = e->d_stats;
   uint32_t n_tasks = (uint32_t)n_reads * 2;
   if (in.d_planes)
@@ -3290,6 +3450,13 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   }
   HIP_TRY(hipGetLastError());
   e->last_stream = stream;
+  if (e->log_sites) {  // what log_settle() looks at before the next batch, and what a replay needs of this one
+    e->last_b = b;
+    e->last_o = o;
+    e->last_acc = acc;
+    e->last_big_lds = big_lds;
+    if ((rc = log_state_enqueue(e, stream))) return rc;
+  }
   return GMX_OK;
 }
 
@@ -3665,6 +3832,7 @@ int gmx_engine_sync(gmx_engine *e) {
   {
     int frc = flush_reset(e);
     if (frc) return frc;
+    if ((frc = log_settle(e))) return frc;
   }
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -3737,7 +3905,7 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
 int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
-  uint32_t raw[32 * GMX_CNT_STRIDE];
+  uint32_t raw[GMX_N_COUNTERS * GMX_CNT_STRIDE];
   HIP_TRY(hipMemcpy(raw, e->d_counters, sizeof(raw), hipMemcpyDeviceToHost));
   auto c = [&](int i) { return (uint64_t)raw[i * GMX_CNT_STRIDE]; };
   out->mapped = 0;
@@ -3755,6 +3923,8 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->inst_mapped = c(25);
   out->huge_search = c(11);
   out->huge_cover = c(15);
+  out->log_replays = e->log_replays;
+  out->log_replayed_entries = e->log_replayed_entries;
   return GMX_OK;
 }
 
@@ -3775,9 +3945,14 @@ int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
 }
 
 int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
   {
     int frc = flush_reset(e);
     if (frc) return frc;
+    if ((frc = log_settle(e))) return frc;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 0);
@@ -3786,6 +3961,10 @@ int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
 }
 
 int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
   {
     int frc = flush_reset(e);
     if (frc) return frc;
@@ -3797,9 +3976,14 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
 }
 
 int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
   {
     int frc = flush_reset(e);
     if (frc) return frc;
+    if ((frc = log_settle(e))) return frc;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
@@ -3827,7 +4011,9 @@ int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, 
 }
 
 int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words) {
+  if (!e) return GMX_EINVAL;
   if (hipSetDevice(e->opts.device) != hipSuccess) return GMX_EHIP;
+  if (log_settle(e)) return GMX_EHIP;
   if (gmx_log_drain(e, 0)) return GMX_EHIP;
   uint64_t n = 0;
   for (auto const &kv : e->log_counts) {  // [site_index, n_ids | GMX_LOG_COUNTED, count lo, count hi, ids...]
@@ -3845,13 +4031,13 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
 }
 
 int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace) {
-  {
-    int frc = flush_reset(e);
-    if (frc) return frc;
-  }
   if (!e || (!records && n_words)) {
     gmx_set_error("gmx_coverage_import_grouped_log: null argument");
     return GMX_EINVAL;
+  }
+  {
+    int frc = flush_reset(e);
+    if (frc) return frc;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
   return gmx_engine_log_import(e, records, (size_t)n_words, replace != 0);
@@ -3871,6 +4057,7 @@ int gmx_engine_log_export(gmx_engine *e, std::vector<uint32_t> &out) {
   {
     int frc = flush_reset(e);
     if (frc) return frc;
+    if ((frc = log_settle(e))) return frc;
   }
   const int64_t n = gmx_coverage_fetch_grouped_log(e, nullptr, 0);
   if (n < 0) return (int)n;

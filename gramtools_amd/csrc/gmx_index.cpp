@@ -579,6 +579,10 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
   out.n_pb_slots = pb;
   uint32_t as = 0, gs = 0;
+  // sites of up to `dense_max` alleles get 2^A - 1 dense group counters; wider ones use the engine's append log, which costs
+  // a drain to the host now and then. GMX_DENSE_MAX_ALLELES (1 .. 10) overrides: the tests force the log with 5.
+  uint32_t dense_max = GMX_GROUPED_DENSE_MAX_ALLELES;
+  if (const char *dm = getenv("GMX_DENSE_MAX_ALLELES")) dense_max = (uint32_t)std::min(10, std::max(1, atoi(dm)));
   out.site_ref_pos.assign(out.sites.size(), 0);
   for (auto &b : g.bubbles) {
     uint32_t idx = (b.first - 5) / 2;
@@ -589,7 +593,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     s.n_alleles = (uint32_t)g.nodes[b.second.first].next.size();
     s.allele_sum_off = as;
     as += s.n_alleles;
-    if (s.n_alleles <= GMX_GROUPED_DENSE_MAX_ALLELES) {
+    if (s.n_alleles <= dense_max) {
       s.grouped_off = gs;
       gs += (1u << s.n_alleles) - 1u;
     } else

@@ -52,7 +52,7 @@ struct GmxSite {
   int32_t parent_allele;    // par_map[site].second
   uint32_t n_alleles;       // edges of the bubble start
   uint32_t allele_sum_off;  // slot of the site's counter block in the accumulator block (even; see gmx_slot_*)
-  uint32_t grouped_off;     // slot of its multi-allele group counters, or GMX_GROUPED_LOG (more than 5 alleles)
+  uint32_t grouped_off;     // slot of its multi-allele group counters, or GMX_GROUPED_LOG (more than 8 alleles)
   uint32_t entry_node;      // bubble start node
   uint32_t exit_node;       // bubble end node
   uint32_t snp_kinds;       // bit 31: every allele is one base long or empty (below); bits 2a, 2a+1: GMX_ALLELE_* of allele a
@@ -60,7 +60,7 @@ struct GmxSite {
 #define GMX_GROUPED_LOG 0xFFFFFFFFu
 // ONE accumulator block holds all three coverage structures, laid out per site so that what a read touches at a
 // site sits in one cache line and the two counters every single-allele locus increments together are one 64-bit word:
-//   site block (even slot): [allele-sum(a), group {a}] for a = 0 .. A-1 | groups of 2+ alleles in mask order (A <= 5)
+//   site block (even slot): [allele-sum(a), group {a}] for a = 0 .. A-1 | groups of 2+ alleles in mask order (A <= 8)
 //                           | per-base counters of the site's allele nodes
 // An allele that is ONE base long (a SNP allele: one node between the site's entry and exit) gets a HIT counter after
 // its per-base counter: a single-instance read through it adds 1 there instead of 1 to each of allele-sum(a),
@@ -68,7 +68,7 @@ struct GmxSite {
 // atomics). Such a node is recognised by an ODD cov_off (all others are even); its hit counter is at
 // cov_off + 1 and is added to the three logical counters when coverage is fetched (HostIndex::hit_fix).
 // The logical arrays of the C ABI (allele_sum, per_base, grouped_dense) are gathered from it (HostIndex::phys_*).
-#define GMX_GROUPED_DENSE_MAX_ALLELES 5
+#define GMX_GROUPED_DENSE_MAX_ALLELES 8  // default; the index builder reads GMX_DENSE_MAX_ALLELES (gmx_index.cpp)
 
 GMX_HD bool gmx_node_has_hit_counter(const GmxNode &n) { return n.cov_off != GMX_NO_COV && (n.cov_off & 1u); }
 // A dense site whose alleles are all one base long (hit counter) or empty needs no walk to be recorded: the hit

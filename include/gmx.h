@@ -24,7 +24,7 @@ extern "C" {
 #define GMX_EINVAL (-1)   /* bad argument / inconsistent PRG (reference: std::runtime_error in PRG_String / cov_Graph_Builder) */
 #define GMX_ENODEV (-2)   /* no usable HIP device */
 #define GMX_EHIP (-3)     /* HIP runtime error */
-#define GMX_ECAP (-4)     /* a read needs more than the last tier's heap, or the grouped log is full (raise gmx_engine_opts) */
+#define GMX_ECAP (-4)     /* a read needs more than the last tier's heap, or more of the grouped log than the whole log (raise gmx_engine_opts) */
 #define GMX_EREF (-5)     /* a read hit a condition on which the reference throws/asserts */
 #define GMX_ENOMEM (-6)
 
@@ -120,8 +120,10 @@ typedef struct gmx_engine_opts {
                               be — so the only limit left is this number, as memory is the reference's only limit
                               (encapsulated_search.cpp:30-107, coverage_common.cpp:85-146). GMX_ECAP names the read that
                               does not fit it. */
-  uint64_t log_cap_words;  /* device log of grouped counts of sites with more than 5 alleles, in uint32 words
-                              (0 = sized from max_batch_reads); it is drained to the host between batches */
+  uint64_t log_cap_words;  /* device log of grouped counts of sites with more than 8 alleles, in uint32 words (0 = 2^26). Between
+                              batches the engine reads its fill back: drained to the host when half full; tasks that found it
+                              full (nothing of theirs recorded) are redone after a drain. GMX_ECAP only when ONE task's
+                              records exceed the whole log */
 } gmx_engine_opts;
 void gmx_engine_default_opts(gmx_engine_opts *opts);
 
@@ -210,6 +212,8 @@ typedef struct gmx_queue_counts {
   uint64_t huge_search;       /* tasks searched again by the last tier (pools carved from the heap) */
   uint64_t inst_mapped;       /* tasks of reads in short repeats searched as one lane per mapping instance */
   uint64_t huge_cover;        /* tasks whose selection scratch the last tier sized from the heap */
+  uint64_t log_replays;       /* since the engine was created: rounds in which entries that found the grouped log full were redone */
+  uint64_t log_replayed_entries; /* ... and how many entries those rounds redid */
 } gmx_queue_counts;
 int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out);
 

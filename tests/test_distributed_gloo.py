@@ -83,9 +83,11 @@ def test_two_ranks_equal_single_process_oracle_nested_repeats():
     assert got[0] == want and got[1] == want
 
 
-def test_two_ranks_exchange_the_grouped_log_of_many_allele_sites():
-    """Sites with 6-7 alleles keep their grouped counts in the append log, which every rank must receive from every
-    other: the totals equal the single-process oracle and the log really was in play."""
+def test_two_ranks_exchange_the_grouped_log_of_many_allele_sites(monkeypatch):
+    """Sites with 6-7 alleles keep their grouped counts in the append log (index built with the round-2 limit of 5 dense
+    alleles), which every rank must receive from every other: the totals equal the single-process oracle
+    and the log really was in play."""
+    monkeypatch.setenv("GMX_DENSE_MAX_ALLELES", "5")
     ref = random_ref(4000, 11)
     prg, sites = mixed_variant_prg(ref, 80, 12, max_alleles=7)
     assert any(len(al) >= 6 for _, _, al in sites)
