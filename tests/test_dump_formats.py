@@ -46,7 +46,8 @@ def test_grouped_json_layout():
     assert " " not in dump_grouped_allele_counts(cov)
 
 
-def test_grouped_log_sites_with_many_alleles():
+def test_grouped_log_sites_with_many_alleles(monkeypatch):
+    monkeypatch.setenv("GMX_DENSE_MAX_ALLELES", "5")  # (sites of up to 8 alleles have dense group counters by default)
     ix, cov = _cov(prg_string_to_ints("a[a,c,g,t,aa,cc]t"), log=[0, 2, 1, 4, 0, 2, 1, 4, 0, 1, 5])
     assert int(ix.grouped_off[0]) == 0xFFFFFFFF
     assert cov.grouped_allele_counts == [{(1, 4): 2, (5,): 1}]
