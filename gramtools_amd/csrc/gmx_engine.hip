@@ -1757,9 +1757,10 @@ struct CoverAcc {
   unsigned long long *stats;   // QuasimapReadsStats counters
 };
 
-// The grouped log (sites with more than 5 alleles): a task reserves ALL the words it will append with one atomic add,
-// before it records anything (gmx_cover.h); a task that does not fit fails whole (GMX_TASK_LOGFULL) and fills what it
-// got of the log's tail with GMX_LOG_PAD words, which every reader skips.
+// The grouped log (sites without dense group counters): a task reserves ALL the words it will append with one atomic add,
+// before it records anything (gmx_cover.h); a task that does not fit fails whole (GMX_TASK_LOGFULL), gives its words back
+// and is redone after the host has drained the log (log_settle). GMX_LOG_PAD words (a reservation abandoned on an error)
+// are skipped by every reader.
 #define GMX_LOG_PAD 0xFFFFFFFFu
 #ifdef GMX_LOOP_STATS
 // per coverage instance (LIST): [0..7] wall time (10 ns units) per phase summed over tasks, [8..15] its maximum
@@ -1813,8 +1814,10 @@ struct CoverLogPart {
   __device__ __forceinline__ bool log_reserve(uint32_t words) {
     log_at = atomicAdd(log_cursor, words);
     if (log_at > log_cap || words > log_cap - log_at) {
-      for (uint32_t i = log_at; i < log_cap; ++i) log[i] = GMX_LOG_PAD;
-      log_end = log_at;
+      // (given back: the cursor is above the capacity until then, so every reservation in between fails as well and the
+      // successful ones stay contiguous; a task that fails only because of such a moment is redone like the others)
+      atomicSub(log_cursor, words);
+      log_at = log_end = 0;
       status = GMX_TASK_LOGFULL;
       return false;
     }
@@ -3843,9 +3846,9 @@ int gmx_engine_sync(gmx_engine *e) {
     char msg[256];
     if (c[2] == GMX_TASK_LOGFULL) {
       snprintf(msg, sizeof(msg),
-               "read %u (orientation %u): the grouped-allele-count log (sites with more than 5 alleles) is full; nothing of "
-               "this read was recorded: raise gmx_engine_opts.log_cap_words (now %u) or lower max_batch_reads",
-               c[3] >> 1, c[3] & 1, e->log_cap);
+               "a read's records exceed the whole grouped-allele-count log (sites without dense group counters; %u words): "
+               "nothing of it was recorded: raise gmx_engine_opts.log_cap_words",
+               e->log_cap);
       gmx_set_error(msg);
       return GMX_ECAP;
     }

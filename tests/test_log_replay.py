@@ -42,7 +42,7 @@ def test_tiny_log_nested_prg_with_multi_mapping(seed):
     reads = simulate_graph_reads(prg, 600, 14, seed)
     seeds = master_seeds(seed, [len(reads)])
     want = oracle_map(prg, 3, reads, seeds)
-    qm = Quasimapper(Index(prg, 3), log_cap_words=24, max_batch_reads=250)
+    qm = Quasimapper(Index(prg, 3), log_cap_words=96, max_batch_reads=250)
     flat, offs = flatten_reads(reads)
     qm.map_reads(flat, offs, seeds)
     assert canonical_cov(qm.coverage()) == want
