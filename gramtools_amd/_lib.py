@@ -90,6 +90,7 @@ SYMBOLS = {
     "gmx_packed_pairs": (_u64, [_u64p, _u32, _u64]),
     "gmx_pack_reads": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
     "gmx_engine_reserve": (C.c_int, [_vp, _u64, _u64]),
+    "gmx_engine_reserve_packed": (C.c_int, [_vp, _u64, _u64]),
     "gmx_host_alloc": (_vp, [_u64]),
     "gmx_host_free": (None, [_vp]),
     "gmx_engine_sync": (C.c_int, [_vp]),

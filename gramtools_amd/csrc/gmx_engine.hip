@@ -3830,6 +3830,48 @@ int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) {
   return GMX_OK;
 }
 
+// The same for gmx_map_reads_packed_host: the batch workspace, the copy stream and the three upload slots (bit planes,
+// offsets, seeds, skip flags) for chunks of up to n_reads reads / n_pairs plane pairs.
+int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  HIP_TRY(hipSetDevice(e->opts.device));
+  n_reads = std::min<uint64_t>(std::min<uint64_t>(n_reads, e->opts.max_batch_reads), 1u << 20);
+  int rc = ensure_batch_capacity(e, n_reads);
+  if (rc) return rc;
+  if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  for (auto &sl : e->pslot) {
+    if (sl.busy) continue;
+    if (!sl.copied) {
+      HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    if (n_pairs + 16 > sl.cap_pairs) {
+      e->release(sl.d_planes);
+      sl.d_planes = nullptr;
+      sl.cap_pairs = 0;
+      if ((rc = e->alloc(&sl.d_planes, n_pairs + 64, false))) return rc;
+      sl.cap_pairs = n_pairs + 64;
+    }
+    if (n_reads > sl.cap_reads) {
+      e->release(sl.d_offsets);
+      e->release(sl.d_seeds);
+      e->release(sl.d_skip);
+      sl.d_offsets = nullptr;
+      sl.d_seeds = nullptr;
+      sl.d_skip = nullptr;
+      sl.cap_reads = 0;
+      if ((rc = e->alloc(&sl.d_offsets, n_reads + 1, false)) || (rc = e->alloc(&sl.d_seeds, n_reads, false)) ||
+          (rc = e->alloc(&sl.d_skip, n_reads, false)))
+        return rc;
+      sl.cap_reads = n_reads;
+    }
+  }
+  return GMX_OK;
+}
+
 int gmx_engine_sync(gmx_engine *e) {
   HIP_TRY(hipSetDevice(e->opts.device));
   {

@@ -703,16 +703,10 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   if (const char *eb = getenv("GMX_FASTQ_BLOCK")) kBlock = std::max<size_t>(64, (size_t)atoll(eb));  // tests: tiny blocks
   const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
   feed_trace("file opened");
-  // (not value-initialised: the pages are first touched by the parallel reads below; kept for the next file)
-  if (g_block_cap < kBlock + (1u << 20)) {
-    g_block_cap = kBlock + (1u << 20);
-    g_block_mem.reset(new char[g_block_cap]);
-  }
   struct {
     char *p;
     char *data() const { return p; }
-  } buf{g_block_mem.get()};
-  feed_trace("block buffer allocated");
+  } buf{nullptr};
   size_t have = 0, consumed = 0;
   bool first = true;
   gzFile g = nullptr;
@@ -744,6 +738,14 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
     if (m != MAP_FAILED) map = static_cast<const char *>(m);
   }
+  if (!map) {  // (not value-initialised: the pages are first touched by the parallel reads below; kept for the next file)
+    if (g_block_cap < kBlock + (1u << 20)) {
+      g_block_cap = kBlock + (1u << 20);
+      g_block_mem.reset(new char[g_block_cap]);
+    }
+    buf.p = g_block_mem.get();
+  }
+  feed_trace("block source ready");
   std::unique_ptr<BlockPipe> pipe;  // started with the first good block
   BlockFill fill;
   bool use_fill = false;
@@ -1141,10 +1143,12 @@ int run_genotype(const Args &a) {
     const size_t sizes[4] = {block / 6, block / 24, block / 48, block / 192};  // planes, offsets, seeds, skip flags
     for (int i = 0; i < 8; ++i) p[i] = gmx_host_alloc(sizes[i % 4]);
     for (int i = 0; i < 8; ++i) gmx_host_free(p[i]);
-    g_block_cap = block + (1u << 20);  // ... and the file block buffer, its pages touched
-    g_block_mem.reset(new char[g_block_cap]);
-    memset(g_block_mem.get(), 0, g_block_cap);
+    // (the file block buffer is needed by gzip and unmappable files only: parse_fastq_file allocates it then)
   });
+  {  // ... and the parser's threads, started and parked (63 thread starts cost the first block 3 ms)
+    const unsigned T = (unsigned)std::max(1, std::min(max_threads, 128));
+    parallel_for(T, [](unsigned) {});
+  }
   std::cout << "Loading PRG data" << std::endl;
   gmx_index *ix = nullptr;
   {  // the index cache `gram build` leaves in gram_dir (gmx_index.k<K>.bin); rebuilt in memory when absent or stale
@@ -1164,7 +1168,7 @@ int run_genotype(const Args &a) {
   GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
-  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve(gmx_group_engine(grp, d), 1u << 20, 0));
+  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), 1u << 20, (6ull << 20) + 64));
   if (prewarm.joinable()) prewarm.join();
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
@@ -1240,7 +1244,9 @@ int run_genotype(const Args &a) {
     flush();
     seed_stream.base += (total_reads - reads_before + kBatch - 1) / kBatch * kBatch;
   }
+  feed_trace("files done");
   GMX_CHECK(gmx_group_allreduce(grp));  // the one exchange (a single engine: nothing to do)
+  feed_trace("exchange done");
   GMX_CHECK(gmx_engine_sync(eng));
   feed_trace("engine synchronised");
   double t_map = std::chrono::duration<double>(clk::now() - t0).count();

@@ -181,6 +181,9 @@ void gmx_host_free(void *p);
 /* Sizes the engine's batch workspace (and the device staging buffers of gmx_map_reads_host) for calls of up to n_reads
  * reads / n_bases bases ahead of the first call. Optional: the first call does it otherwise. */
 int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases);
+/* The same ahead of gmx_map_reads_packed_host: workspace, copy stream and upload slots for chunks of up to n_reads reads
+ * whose bit planes take up to n_pairs uint64. */
+int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs);
 /* Waits for enqueued work and reports a read that overflowed / errored (GMX_ECAP, GMX_EREF). */
 int gmx_engine_sync(gmx_engine *e);
 
