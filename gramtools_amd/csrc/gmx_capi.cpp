@@ -146,6 +146,11 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
   o->n_kmers_present = h.n_seed_kmers_present;
   o->kmer_size2 = h.kmer_size2;
+  {
+    uint64_t n_inline = 0;
+    for (const GmxTextRec &r : h.text) n_inline += (uint64_t)__builtin_popcountll(r.mk & r.hi);
+    o->n_inline_sites = (uint32_t)n_inline;
+  }
   o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
                    h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.seeds2.size() * sizeof(GmxSeed) + h.nodes.size() * sizeof(GmxNode) +
                    h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);

@@ -175,7 +175,7 @@ GMX_HD void gmx_dfs_slow_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
 // The FAST iterations cover what makes up almost every step of a read on a flat PRG. A lane is in exactly one
 // of three situations (gmx_dfs_fast_kind), each costing one small fetch and register arithmetic:
 //   CONVERT  a width-one interval [i, i]: the state switches to TEXT FORM (a = SA[i], b = GMX_TEXT_MARK);
-//   TEXT     a text-form state compares up to 32 read bases against one GmxTextRec. Equivalent to that many
+//   TEXT     a text-form state compares up to 64 read bases against one GmxTextRec (and resolves inline sites). Equivalent to that many
 //            backward steps of the reference: for a single SA position i the LF step with base c succeeds iff
 //            BWT[i] == c, BWT[i] = PRG[SA[i] - 1], and the next position is SA[i] - 1 (BWT_search.cpp:28-76);
 //            a variant marker left of the position is the marker hit left_markers_search would report
@@ -220,14 +220,16 @@ GMX_HD uint32_t gmx_bitrev32(uint32_t v) {
   return __builtin_bswap32(v);
 #endif
 }
-// TEXT: which record and which 32 raw read bases the iteration needs.
+GMX_HD uint64_t gmx_bitrev64(uint64_t v) { return ((uint64_t)gmx_bitrev32((uint32_t)v) << 32) | gmx_bitrev32((uint32_t)(v >> 32)); }
+GMX_HD uint64_t gmx_below64(uint32_t s) { return s >= 64u ? ~0ull : ((1ull << s) - 1ull); }  // bits of slots < s
+// TEXT: which record and which 64 raw read bases the iteration needs.
 //   q = a - 1 is the PRG position left of the state, t its slot in the record. Slot s (<= t) is compared with
 //   oriented read base pos - 1 - (t - s).
 //   forward read: that is raw base (pos - 1 - t) + s   -> window from max(pos - 1 - t, 0), shifted up by `shift`
 //   reverse-complement read: raw base (len - pos) + (t - s), complemented -> window from len - pos, bit-reversed
-GMX_HD uint32_t gmx_dfs_text_rec(const GmxLane &ln) { return (ln.a ? ln.a - 1u : 0u) >> 5; }
+GMX_HD uint32_t gmx_dfs_text_rec(const GmxLane &ln) { return (ln.a ? ln.a - 1u : 0u) >> GMX_TEXT_SHIFT; }
 GMX_HD void gmx_dfs_text_window(const GmxLane &ln, uint32_t len, bool rc, uint32_t &start, uint32_t &shift) {
-  const uint32_t t = (ln.a ? ln.a - 1u : 0u) & 31u;
+  const uint32_t t = (ln.a ? ln.a - 1u : 0u) & GMX_TEXT_MASK;
   if (rc) {
     start = len - ln.pos;
     shift = 0;
@@ -239,40 +241,83 @@ GMX_HD void gmx_dfs_text_window(const GmxLane &ln, uint32_t len, bool rc, uint32
     shift = t + 1u - ln.pos;
   }
 }
-// xlo/xhi: bit planes of raw read bases start .. start + 31 (bits past the read's end are ignored)
-GMX_HD void gmx_dfs_text_apply(GmxLane &ln, uint32_t stop, bool rc, const GmxTextRec &rec, uint32_t xlo, uint32_t xhi,
-                               uint32_t shift) {
-  if (ln.a == 0) {  // PRG start: BWT holds the sentinel, no base extends the match
-    ln.mode = GMX_MODE_DEAD;
-    return;
-  }
-  const uint32_t t = (ln.a - 1u) & 31u;
-  const uint32_t avail = ln.pos - stop;
-  const uint32_t n = avail < t + 1u ? avail : t + 1u;
-  uint32_t rlo, rhi;
-  if (rc) {
-    rlo = ~(gmx_bitrev32(xlo) >> (31u - t));
-    rhi = ~(gmx_bitrev32(xhi) >> (31u - t));
+// the read's planes aligned with the record: bit s = oriented read base pos - 1 - (t - s) (bits outside the read: anything)
+template <class Reader>
+GMX_HD void gmx_dfs_text_read_planes(const GmxLane &ln, Reader &rd, uint64_t &rlo, uint64_t &rhi) {
+  uint32_t start, shift, l0, h0, l1, h1;
+  gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
+  rd.planes(start, l0, h0);
+  rd.planes(start + 32u, l1, h1);
+  const uint64_t xlo = (uint64_t)l0 | ((uint64_t)l1 << 32), xhi = (uint64_t)h0 | ((uint64_t)h1 << 32);
+  if (rd.rc) {
+    const uint32_t t = (ln.a - 1u) & GMX_TEXT_MASK;
+    rlo = ~(gmx_bitrev64(xlo) >> (63u - t));
+    rhi = ~(gmx_bitrev64(xhi) >> (63u - t));
   } else {
     rlo = xlo << shift;
     rhi = xhi << shift;
   }
-  const uint32_t range = (n == 32u ? ~0u : ((1u << n) - 1u)) << (t + 1u - n);
-  const uint32_t events = (((rec.lo ^ rlo) | (rec.hi ^ rhi)) | rec.mk) & range;
-  if (events == 0) {
-    ln.a -= n;
-    ln.pos -= n;
-    return;
+}
+// One text iteration on record `rec` (the record of ln.a - 1): compares up to 64 bases, resolves the inline sites met on
+// the way (gmx_types.h) and stops at the first mismatch (state dead), at a marker that needs its record (the lane becomes
+// that marker's pending hit), at the record's lower end or at the stop position. Returns false — lane untouched since the
+// last inline site it finished — when a path node could not be allocated (the general iteration reports the overflow).
+template <class Ctx, class Reader>
+GMX_HD bool gmx_dfs_text_apply(Ctx &ctx, GmxLane &ln, uint32_t stop, Reader &rd, const GmxTextRec &rec) {
+  if (ln.a == 0) {  // PRG start: BWT holds the sentinel, no base extends the match
+    ln.mode = GMX_MODE_DEAD;
+    return true;
   }
-  const uint32_t e = 31u - (uint32_t)__builtin_clz(events);  // nearest slot with a marker or a mismatch
-  ln.a -= t - e;
-  ln.pos -= t - e;
-  if ((rec.mk >> e) & 1u) {
-    ln.a = rec.mrank + (uint32_t)__builtin_popcount(rec.mk & ((1u << e) - 1u));
+  for (;;) {
+    uint64_t rlo, rhi;
+    gmx_dfs_text_read_planes(ln, rd, rlo, rhi);
+    const uint32_t t = (ln.a - 1u) & GMX_TEXT_MASK;
+    const uint32_t avail = ln.pos - stop;
+    const uint32_t n = avail < t + 1u ? avail : t + 1u;
+    const uint64_t range = gmx_below64(n) << (t + 1u - n);
+    const uint64_t events = (((rec.lo ^ rlo) | (rec.hi ^ rhi)) | rec.mk) & range;
+    if (events == 0) {
+      ln.a -= n;
+      ln.pos -= n;
+      return true;
+    }
+    const uint32_t e = 63u - (uint32_t)__builtin_clzll(events);  // nearest slot with a marker or a mismatch
+    ln.a -= t - e;
+    ln.pos -= t - e;
+    if (!((rec.mk >> e) & 1ull)) {
+      ln.mode = GMX_MODE_DEAD;
+      return true;
+    }
+    if (((rec.hi >> e) & 1ull) && ln.pos - 1u > stop) {  // closing marker of an inline site, bases left behind the allele
+      const uint64_t opens = rec.mk & rec.lo & gmx_below64(e);
+      const uint32_t o = 63u - (uint32_t)__builtin_clzll(opens);  // its opening marker (in this record by construction)
+      const uint64_t clo = ((rlo >> e) & 1ull) ? ~0ull : 0ull, chi = ((rhi >> e) & 1ull) ? ~0ull : 0ull;  // the next read base
+      const uint64_t alleles = ~rec.mk & gmx_below64(e) & ~gmx_below64(o + 1u);
+      const uint64_t match = ~((rec.lo ^ clo) | (rec.hi ^ chi)) & alleles;
+      if (match == 0) {
+        ln.mode = GMX_MODE_DEAD;  // no allele of the site is that base (every sub-record of the marker is a dead ENTER)
+        --ln.pos;
+        return true;
+      }
+      const uint32_t s = (uint32_t)__builtin_ctzll(match);
+      const uint32_t site = 5u + 2u * (rec.srank + (uint32_t)__builtin_popcountll(rec.mk & rec.lo & gmx_below64(o)));
+      const uint32_t nn = ctx.arena_new(site, (int32_t)((s - o - 1u) >> 1), ln.tvd);
+      if (nn == GMX_NIL) {  // as a pending hit: the general iteration finds the arena full and reports it
+        ln.a = rec.mrank + (uint32_t)__builtin_popcountll(rec.mk & gmx_below64(e));
+        ln.b = 0;
+        ln.mode = GMX_MODE_HIT;
+        return false;
+      }
+      ln.tvd = nn;
+      ln.a -= e - o + 1u;  // left of the opening marker
+      --ln.pos;
+      if (o == 0 || ln.pos <= stop) return true;  // the record is used up (or the read: cannot be, two bases were left)
+      continue;
+    }
+    ln.a = rec.mrank + (uint32_t)__builtin_popcountll(rec.mk & gmx_below64(e));
     ln.b = 0;
     ln.mode = GMX_MODE_HIT;
-  } else {
-    ln.mode = GMX_MODE_DEAD;
+    return true;
   }
 }
 
@@ -373,13 +418,8 @@ GMX_HD bool gmx_dfs_fast_iter(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint
     case GMX_FAST_POP:
       gmx_dfs_pop(ctx, ln);
       return true;
-    default: {
-      uint32_t start, shift, xlo, xhi;
-      gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-      rd.planes(start, xlo, xhi);
-      gmx_dfs_text_apply(ln, stop, rd.rc, ix.text[gmx_dfs_text_rec(ln)], xlo, xhi, shift);
-      return true;
-    }
+    default:
+      return gmx_dfs_text_apply(ctx, ln, stop, rd, ix.text[gmx_dfs_text_rec(ln)]);
   }
 }
 

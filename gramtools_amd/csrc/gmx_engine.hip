@@ -42,7 +42,7 @@
 #define GMX_BLOCK 256
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
 #ifndef GMX_STACK_DEPTH
-#define GMX_STACK_DEPTH 5
+#define GMX_STACK_DEPTH 6
 #endif
 // GMX_STACK_DEPTH: pending entries (sibling states, unresolved marker hits) per lane, in LDS
 #define GMX_STACK_WORDS 5
@@ -659,13 +659,12 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
       GMX_STAT(9, __popcll(m_light));
       // all fetches of the iteration are issued before any of them is consumed
       uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-      uint32_t xlo = 0, xhi = 0, shift = 0, sa_val = 0;
+      uint32_t sa_val = 0;
       if (m_light && kind == GMX_FAST_CONVERT) sa_val = ix.sa[ln.a];
-      if (run_text && kind == GMX_FAST_TEXT) {
-        q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
-        uint32_t start;
-        gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-        rd.planes(start, xlo, xhi);
+      if (run_text && kind == GMX_FAST_TEXT) {  // one 32-byte record: 64 symbols of the PRG
+        const uint4 *src = reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+        q0 = src[0];
+        q1 = src[1];
       }
       if (run_hit && kind == GMX_FAST_HIT) q0 = *reinterpret_cast<const uint4 *>(gmx_dfs_hit_sub(ix, rd, ln));
       if (run_wide && kind == GMX_FAST_WIDE) {
@@ -687,9 +686,12 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
           ln.have = ctx.next_seed(ix, true, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
         }
       }
+      auto text_rec = [&]() {
+        return GmxTextRec{(uint64_t)q0.x | ((uint64_t)q0.y << 32), (uint64_t)q0.z | ((uint64_t)q0.w << 32),
+                          (uint64_t)q1.x | ((uint64_t)q1.y << 32), q1.z, q1.w};
+      };
       if (!fuse) {
-        if (run_text && kind == GMX_FAST_TEXT)
-          gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+        if (run_text && kind == GMX_FAST_TEXT && !gmx_dfs_text_apply(ctx, ln, stop, rd, text_rec())) wait_slow = true;
         if (run_hit && kind == GMX_FAST_HIT && !gmx_dfs_fast_hit(ctx, ln, stop, GmxHitSub{q0.x, q0.y, q0.z, q0.w})) wait_slow = true;
       } else {
         // marker hits first: what they continue as takes its text step below
@@ -701,14 +703,13 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
         GMX_STAT(6, __popcll(m_late));  // text steps taken in the iteration that resolved their marker hit
         if (m_late) {
           if (late) {
-            q0 = *reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
-            uint32_t start;
-            gmx_dfs_text_window(ln, rd.len, rd.rc, start, shift);
-            rd.planes(start, xlo, xhi);
+            const uint4 *src = reinterpret_cast<const uint4 *>(ix.text + gmx_dfs_text_rec(ln));
+            q0 = src[0];
+            q1 = src[1];
             text_now = true;
           }
         }
-        if (text_now) gmx_dfs_text_apply(ln, stop, rd.rc, GmxTextRec{q0.x, q0.y, q0.z, q0.w}, xlo, xhi, shift);
+        if (text_now && !gmx_dfs_text_apply(ctx, ln, stop, rd, text_rec())) wait_slow = true;
       }
       if (run_wide && kind == GMX_FAST_WIDE) {
         const uint32_t w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
@@ -1361,11 +1362,11 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_inst_kernel(GmxIndexView
   gmx_inst_rounds(ix, b, o, pools, blockIdx.x, gridDim.x);
 }
 
-// Six waves per SIMD: 80 VGPRs (four values spilled) and, with a stack of five entries per lane, six 25 KB blocks per CU
-// instead of five of each: the kernel is bound by its lanes' chains of dependent fetches, 24 waves per CU hide more of
-// them than 20 (0.175 -> 0.162 ms; A/B on one box, whole step: +1.1 %).
+// Five waves per SIMD (96 VGPRs) since the text step compares 64 symbols at a time and resolves inline sites in registers
+// (round 3: at six waves - 80 VGPRs - 51 values spilled and the kernel lost 6 %; A/B in profiles/round3/ab_text64_inline.txt).
+// Round 2 ran six (80 VGPRs, four spills) with the 32-symbol step. Five blocks per CU leave LDS for a six-entry stack.
 #ifndef GMX_EXTEND_WAVES
-#define GMX_EXTEND_WAVES 6
+#define GMX_EXTEND_WAVES 5
 #endif
 #define GMX_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(GMX_EXTEND_WAVES)))
 template <bool CURSOR, bool SEEDED>

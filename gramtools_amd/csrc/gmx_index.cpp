@@ -900,21 +900,31 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   build_trace("jump programs + hit records");
   // --- PRG text records; hit records re-ordered from BWT order to text order ---------------
   {
-    out.text.assign(N / 32 + 1, GmxTextRec{0, 0, 0, 0});
-    uint32_t markers = 0;
+    out.text.assign(N / 64 + 1, GmxTextRec{0, 0, 0, 0, 0});
+    uint32_t markers = 0, opens = 0;
     for (uint32_t q = 0; q < N; ++q) {
-      GmxTextRec &r = out.text[q >> 5];
-      if ((q & 31u) == 0) r.mrank = markers;
+      GmxTextRec &r = out.text[q >> GMX_TEXT_SHIFT];
+      if ((q & GMX_TEXT_MASK) == 0) {
+        r.mrank = markers;
+        r.srank = opens;
+      }
       uint32_t sym = prg[q];
       if (sym > 4) {
-        r.mk |= 1u << (q & 31u);
+        r.mk |= 1ull << (q & GMX_TEXT_MASK);
         ++markers;
+        if (sym & 1u) {  // opens a site: flagged in the low plane (gmx_types.h)
+          r.lo |= 1ull << (q & GMX_TEXT_MASK);
+          ++opens;
+        }
       } else {
-        r.lo |= ((sym - 1u) & 1u) << (q & 31u);
-        r.hi |= (((sym - 1u) >> 1) & 1u) << (q & 31u);
+        r.lo |= (uint64_t)((sym - 1u) & 1u) << (q & GMX_TEXT_MASK);
+        r.hi |= (uint64_t)(((sym - 1u) >> 1) & 1u) << (q & GMX_TEXT_MASK);
       }
     }
-    out.text[N >> 5].mrank = (N & 31u) == 0 ? markers : out.text[N >> 5].mrank;
+    if ((N & GMX_TEXT_MASK) == 0) {
+      out.text[N >> GMX_TEXT_SHIFT].mrank = markers;
+      out.text[N >> GMX_TEXT_SHIFT].srank = opens;
+    }
     if (markers != out.hits.size()) throw std::runtime_error("internal: marker count mismatch");
     std::vector<GmxHit> by_text(out.hits.size());
     out.hit_perm.assign(out.hits.size(), 0);
@@ -923,8 +933,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     for (size_t i = 0; i < n; ++i) {
       if (out.bwt[i] <= 4) continue;
       uint32_t q = out.sa[i] - 1;  // the marker's PRG position
-      const GmxTextRec &r = out.text[q >> 5];
-      uint32_t t = r.mrank + (uint32_t)__builtin_popcount(r.mk & ((1u << (q & 31u)) - 1u));
+      const GmxTextRec &r = out.text[q >> GMX_TEXT_SHIFT];
+      uint32_t t = r.mrank + (uint32_t)__builtin_popcountll(r.mk & ((1ull << (q & GMX_TEXT_MASK)) - 1ull));
       by_text[t] = out.hits[rank];
       out.hit_prog[t] = progs_bwt[rank];
       out.hit_perm[rank] = t;
@@ -933,8 +943,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     out.hits.swap(by_text);
     // ENTER + EXIT of a one-base allele -> FUSED (gmx_types.h)
     auto text_rank = [&](uint32_t q) {
-      const GmxTextRec &r = out.text[q >> 5];
-      return r.mrank + (uint32_t)__builtin_popcount(r.mk & ((1u << (q & 31u)) - 1u));
+      const GmxTextRec &r = out.text[q >> GMX_TEXT_SHIFT];
+      return r.mrank + (uint32_t)__builtin_popcountll(r.mk & ((1ull << (q & GMX_TEXT_MASK)) - 1ull));
     };
     for (auto &hit : out.hits)
       for (auto &sub : hit.sub) {
@@ -948,6 +958,47 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         sub.head = GMX_HIT_FUSED | GMX_HITF_ALIVE | GMX_HITF_TEXT | ((p1 - open_pos) << 4);
         sub.y = ex.y;
       }
+    // Inline sites (gmx_types.h): one-base alleles with distinct bases, the whole site inside one text record, the site's
+    // id = its ordinal among the opening markers — and the closing marker's four sub-records say exactly what the
+    // in-register resolution does (FUSED into the allele with that base, dead for every other base).
+    if (!getenv("GMX_NO_INLINE_SITES")) {
+      uint32_t ordinal = 0;
+      uint64_t n_inline = 0;
+      for (uint32_t q = 0; q < N; ++q) {
+        const uint32_t sym = prg[q];
+        if (sym <= 4 || !(sym & 1u)) continue;
+        const uint32_t my_ordinal = ordinal++;
+        if (sym != 5u + 2u * my_ordinal) continue;
+        uint32_t A = 0, base_of[4] = {0, 0, 0, 0};  // allele whose base is c (index c - 1), + 1
+        bool ok = true;
+        for (uint32_t p2 = q + 1; p2 + 1 < N && prg[p2] <= 4 && prg[p2 + 1] == sym + 1u; p2 += 2) {  // `base marker` pairs
+          if (A >= 4 || base_of[prg[p2] - 1u]) {
+            ok = false;
+            break;
+          }
+          base_of[prg[p2] - 1u] = ++A;
+        }
+        // all of the site's alleles are among them (the last pair's marker closes the site), at least two
+        if (!ok || A < 2 || out.sites[(sym - 5u) >> 1].n_alleles != A) continue;
+        const uint32_t q_close = q + 2u * A;
+        if ((q_close >> GMX_TEXT_SHIFT) != (q >> GMX_TEXT_SHIFT)) continue;
+        const GmxHit &hit = out.hits[text_rank(q_close)];
+        for (uint32_t c = 1; c <= 4 && ok; ++c) {
+          const GmxHitSub &sub = hit.sub[c - 1];
+          if (base_of[c - 1]) {
+            const uint32_t j = base_of[c - 1] - 1u, x = q + 1u + 2u * j;
+            ok = (sub.head & 3u) == GMX_HIT_FUSED && (sub.head & GMX_HITF_ALIVE) && (sub.head & GMX_HITF_TEXT) && sub.site == sym &&
+                 sub.y == j && sub.x == x && (sub.head >> 4) == x - q;
+          } else {
+            ok = (sub.head & 3u) == GMX_HIT_ENTER && !(sub.head & GMX_HITF_ALIVE);
+          }
+        }
+        if (!ok) continue;
+        out.text[q_close >> GMX_TEXT_SHIFT].hi |= 1ull << (q_close & GMX_TEXT_MASK);
+        ++n_inline;
+      }
+      build_trace(("inline sites: " + std::to_string(n_inline)).c_str());
+    }
   }
 
   build_trace("text records");
@@ -1150,7 +1201,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 7;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 8;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1333,7 +1384,7 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     if (end != kCacheMagic || stored != computed) throw std::runtime_error("index cache: damaged file (checksum)");
     out.prg = prg;
     // cheap structural checks against damage that keeps the sizes
-    if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 32 + 1 ||
+    if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 64 + 1 ||
         out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) ||
         out.seeds2.size() != (out.kmer_size2 ? (1ull << (2 * out.kmer_size2)) : 0) || out.kmer_size2 > 15 || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
         out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0 || out.site_ref_pos.size() != out.sites.size())

@@ -136,16 +136,29 @@ struct alignas(64) GmxHit {
 #define GMX_HIT_EXIT 1u
 #define GMX_HIT_ENTER 2u
 
-// The PRG itself, 32 symbols per 16-byte record, as the search consumes it once a state has narrowed to ONE
+// The PRG itself, 64 symbols per 32-byte record, as the search consumes it once a state has narrowed to ONE
 // suffix-array position i: its next backward step is decided by the symbol left of PRG position SA[i] alone
 // (the LF step succeeds iff BWT[i] equals the read base, and BWT[i] = PRG[SA[i] - 1]; a marker there is the
-// marker hit). Such a state is kept in TEXT FORM (a = PRG position, b = GMX_TEXT_MARK) and compares up to 32
+// marker hit). Such a state is kept in TEXT FORM (a = PRG position, b = GMX_TEXT_MARK) and compares up to 64
 // read bases per record against the PRG instead of fetching one rank block per base.
-struct alignas(16) GmxTextRec {
-  uint32_t lo, hi;  // bit planes of the base codes (A,C,G,T = 0..3); 0 at marker positions
-  uint32_t mk;      // 1 = variant marker
+//
+// INLINE sites (round 3). At marker positions the base planes are free; they carry two flags:
+//   lo bit = the marker OPENS a site (an odd symbol);
+//   hi bit = the marker CLOSES an inline site: every allele of the site is ONE base, the bases differ from each other,
+//            the whole site (opening marker .. closing marker) lies inside this record, and the site's id is its ordinal
+//            among the PRG's opening markers (5 + 2 * (srank + opening markers of the record below it)).
+// Reaching such a closing marker with at least two read bases left, the search needs no marker record: the allele whose
+// base equals the next read base is found in the planes (none: the state is dead), `traversed` gets (site, allele), and
+// the state continues left of the opening marker — exactly what the pre-resolved FUSED sub-record of that marker says
+// (the builder flags a site only where all four sub-records agree with this; gmx_index.cpp), without its fetch.
+struct alignas(32) GmxTextRec {
+  uint64_t lo, hi;  // bit planes of the base codes (A,C,G,T = 0..3); flags at marker positions (above)
+  uint64_t mk;      // 1 = variant marker
   uint32_t mrank;   // markers of the PRG before this record (= index of its first marker in hits[])
+  uint32_t srank;   // site-opening markers of the PRG before this record
 };
+#define GMX_TEXT_SHIFT 6
+#define GMX_TEXT_MASK 63u
 #define GMX_TEXT_MARK 0xFFFFFFFEu
 
 // The device/host view of the index. All pointers are device pointers on the GPU side.
@@ -169,7 +182,7 @@ struct GmxIndexView {
   const GmxHit *hits;         // [n_hits] record of the h-th marker of the PRG (text order)
   const uint32_t *hit_perm;   // [n_hits] BWT marker rank -> index into hits[]
   const uint32_t *hit_prog;   // [n_hits] jump program of each record
-  const GmxTextRec *text;     // [n_prg / 32 + 1]
+  const GmxTextRec *text;     // [n_prg / 64 + 1]
   const uint32_t *prog;       // jump programs
   const uint32_t *sa;         // [n]
   const uint32_t *pos_node;   // [n_prg]

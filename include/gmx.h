@@ -59,7 +59,8 @@ typedef struct gmx_index_info {
   uint64_t n_kmers_present;
   uint64_t index_bytes;      /* bytes uploaded to HBM by gmx_engine_create */
   uint32_t kmer_size2;       /* length of the longer seed table the search is seeded from (0 = none); see DESIGN.md */
-  uint32_t reserved;
+  uint32_t n_inline_sites;   /* sites the text-form search resolves without their marker record (one-base alleles inside one
+                                text record; gmx_types.h) */
 } gmx_index_info;
 int gmx_index_get_info(const gmx_index *ix, gmx_index_info *out);
 

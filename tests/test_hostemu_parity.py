@@ -44,3 +44,32 @@ def test_device_logic_on_snp_prg_150bp():
     got, _, rc = hostemu_map(prg, 7, list(reads), seeds)
     assert rc == 0 and got == want
     assert want["stats"]["exact_mapped"] == 300
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_inline_sites_dense_snps_short_reads(seed, monkeypatch):
+    """Sites whose alleles are single bases are resolved inside the text record, without their marker record (gmx_types.h:
+    INLINE sites). Dense bi- to quad-allelic SNPs (a site every ~8 bases, many per 64-symbol record, some straddling
+    record ends), reads of 12-70 bases that start, end and seed inside sites: the device logic with inline sites, the same
+    with them switched off (GMX_NO_INLINE_SITES) and the oracle agree."""
+    from gramtools_amd import Index
+    rng = np.random.default_rng(seed)
+    ref = random_ref(int(rng.integers(300, 1500)), seed + 40)
+    prg, pos, alts, n_alts = snp_prg(ref, ref.size // int(rng.integers(6, 12)), seed + 41, multi_allelic_frac=0.4)
+    L, k = int(rng.integers(12, 70)), int(rng.integers(2, 8))
+    reads = list(simulate_snp_reads(ref, pos, alts, n_alts, 150, L, seed + 42))
+    # reads that start / end exactly at allele bases and next to markers
+    for p in pos[:20]:
+        for s0 in (int(p) - L + 1, int(p), int(p) - 1, int(p) + 1 - L // 2):
+            if 0 <= s0 and s0 + L <= ref.size:
+                reads.append(ref[s0:s0 + L].copy())
+    seeds = rng.integers(0, 2 ** 32, size=len(reads), dtype=np.uint64).astype(np.uint32)
+    want = oracle_map(prg, k, reads, seeds)
+    ix = Index(prg, k)
+    assert ix.info.n_inline_sites > 0.5 * ix.n_sites
+    got, _, rc = hostemu_map(prg, k, reads, seeds)
+    assert rc == 0 and got == want
+    monkeypatch.setenv("GMX_NO_INLINE_SITES", "1")
+    assert Index(prg, k).info.n_inline_sites == 0
+    got2, _, rc = hostemu_map(prg, k, reads, seeds)
+    assert rc == 0 and got2 == want
