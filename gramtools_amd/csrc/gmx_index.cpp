@@ -155,7 +155,108 @@ void debug_suffix_array_u16(const uint16_t *text, size_t n, uint16_t *sa) {
   sais<uint16_t>(text, sa, n, K);
 }
 
-void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa) {
+// fn(i) for i in [0, n_items) on `threads` threads, items handed out in order (dynamic)
+template <class F>
+static void par_for(size_t n_items, unsigned threads, F fn) {
+  threads = (unsigned)std::min<size_t>(std::max(1u, threads), std::max<size_t>(n_items, 1));
+  if (threads <= 1) {
+    for (size_t i = 0; i < n_items; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> pool;
+  for (unsigned w = 0; w < threads; ++w)
+    pool.emplace_back([&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n_items) break;
+        fn(i);
+      }
+    });
+  for (auto &t : pool) t.join();
+}
+
+// Parallel suffix sort for the PRG texts of this engine (round 3): suffixes are bucketed by the class of their first eight
+// symbols — A, C, G, T or "marker" (after which the key stops; the sentinel counts as the smallest digit) — with a parallel
+// counting sort, a key that never contradicts the suffix order, and every bucket is sorted with a plain suffix comparison.
+// On DNA with variant markers the comparisons end after a few symbols (markers are all but unique), so the work is
+// n log(bucket) short comparisons spread over all threads; SA-IS (one thread, O(n)) took 8 of the 40 s of a chr20-scale
+// build and ten minutes at 3.46 G symbols. Long repeats make comparisons long: a budget of symbol comparisons guards
+// against that — when it is spent the function gives up and the caller runs SA-IS. The result is THE suffix array either
+// way (unique for a text with a unique smallest sentinel).
+static bool parallel_suffix_sort(const uint32_t *text, size_t n, uint32_t *sa, unsigned threads) {
+  constexpr unsigned L = 8;
+  constexpr uint32_t NB = 390625;  // 5^8
+  auto key_of = [&](size_t i) -> uint32_t {
+    uint32_t key = 0;
+    unsigned j = 0;
+    for (; j < L && i + j < n; ++j) {
+      const uint32_t c = text[i + j];
+      if (c == 0 || c > 4) {  // the sentinel: smallest digit; a marker: the largest, and the key ends here
+        key = key * 5u + (c == 0 ? 0u : 4u);
+        ++j;
+        break;
+      }
+      key = key * 5u + (c - 1u);
+    }
+    for (; j < L; ++j) key *= 5u;
+    return key;
+  };
+  const unsigned T = std::max(1u, std::min(threads, 256u));
+  const size_t per = (n + T - 1) / T;
+  std::vector<std::vector<uint32_t>> hist(T);
+  par_for(T, T, [&](size_t t) {
+    hist[t].assign(NB, 0);
+    const size_t lo = t * per, hi = std::min(n, lo + per);
+    for (size_t i = lo; i < hi; ++i) hist[t][key_of(i)]++;
+  });
+  std::vector<uint64_t> bucket_start(NB + 1, 0);
+  {
+    uint64_t acc = 0;
+    for (uint32_t b = 0; b < NB; ++b) {
+      bucket_start[b] = acc;
+      for (unsigned t = 0; t < T; ++t) {
+        const uint32_t c = hist[t][b];
+        hist[t][b] = (uint32_t)acc;  // where thread t writes its first suffix of bucket b (n < 2^32)
+        acc += c;
+      }
+    }
+    bucket_start[NB] = acc;
+  }
+  par_for(T, T, [&](size_t t) {
+    const size_t lo = t * per, hi = std::min(n, lo + per);
+    for (size_t i = lo; i < hi; ++i) sa[hist[t][key_of(i)]++] = (uint32_t)i;
+  });
+  hist.clear();
+  std::atomic<uint64_t> budget_left{(uint64_t)n * 400ull + (1ull << 24)};
+  std::atomic<bool> gave_up{false};
+  const uint32_t chunk = 64;
+  par_for((NB + chunk - 1) / chunk, T, [&](size_t ci) {
+    if (gave_up.load(std::memory_order_relaxed)) return;
+    uint64_t used = 0;
+    auto less = [&](uint32_t a, uint32_t b) {
+      size_t j = 0;
+      const size_t lim = n - std::max(a, b);  // the shorter suffix ends with the sentinel: a difference comes first
+      while (j < lim && text[a + j] == text[b + j]) ++j;
+      used += j + 1;
+      return j < lim ? text[a + j] < text[b + j] : a > b;
+    };
+    for (uint32_t b = (uint32_t)ci * chunk; b < std::min<uint32_t>(NB, ((uint32_t)ci + 1) * chunk); ++b) {
+      const uint64_t lo = bucket_start[b], hi = bucket_start[b + 1];
+      if (hi - lo < 2) continue;
+      std::sort(sa + lo, sa + hi, less);
+      if (used > (1ull << 22)) {
+        if (budget_left.fetch_sub(used) < used) gave_up.store(true);
+        used = 0;
+        if (gave_up.load(std::memory_order_relaxed)) return;
+      }
+    }
+    if (used && budget_left.fetch_sub(used) < used) gave_up.store(true);
+  });
+  return !gave_up.load();
+}
+
+void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa, int threads) {
   size_t n = text.size();
   if (n == 0) {
     sa.clear();
@@ -166,14 +267,18 @@ void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t>
   if (text[n - 1] != 0) throw std::runtime_error("text must end with the sentinel 0");
   for (size_t i = 0; i + 1 < n; ++i)
     if (text[i] == 0) throw std::runtime_error("sentinel 0 inside the text");
-  // compact the alphabet: rank of every symbol among the symbols present (no sorted copy of the text: 14 GB at 3.46 G)
+  sa.assign(n, 0);
+  const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+  size_t min_n = 1u << 16;  // (below that SA-IS takes milliseconds; GMX_PSORT_MIN: the tests run the parallel sort on small texts)
+  if (const char *mn = getenv("GMX_PSORT_MIN")) min_n = (size_t)atoll(mn);
+  if (hw > 1 && n >= min_n && !getenv("GMX_SAIS") && parallel_suffix_sort(text.data(), n, sa.data(), hw)) return;
+  // SA-IS on the compacted alphabet: rank of every symbol among the symbols present (no sorted copy of the text: 14 GB at 3.46 G)
   uint32_t max_sym = 0;
   for (size_t i = 0; i < n; ++i) max_sym = std::max(max_sym, text[i]);
   std::vector<uint32_t> rank((size_t)max_sym + 2, 0);
   for (size_t i = 0; i < n; ++i) rank[(size_t)text[i] + 1] = 1;
   for (size_t c = 1; c < rank.size(); ++c) rank[c] += rank[c - 1];  // rank[c] = symbols present below c
   const size_t K = rank.back() - 1;
-  sa.assign(n, 0);
   {
     std::vector<uint32_t> s(n);
     for (size_t i = 0; i < n; ++i) s[i] = rank[text[i]];
@@ -694,12 +799,20 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   std::vector<uint32_t> text(prg);
   text.push_back(0);
   const size_t n = text.size();
-  build_suffix_array(text, out.sa);
+  build_suffix_array(text, out.sa, threads);
   out.bwt.resize(n);
-  for (size_t i = 0; i < n; ++i) {
-    uint32_t p = out.sa[i];
-    out.bwt[i] = p == 0 ? 0u : text[p - 1];
-    if (p == 0) out.sentinel_pos = (uint32_t)i;
+  {
+    const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    const size_t piece = 1u << 22;
+    std::atomic<uint32_t> sentinel{0};
+    par_for((n + piece - 1) / piece, hw, [&](size_t c) {  // (a random look-up per position: spread over the threads)
+      for (size_t i = c * piece; i < std::min(n, (c + 1) * piece); ++i) {
+        uint32_t p = out.sa[i];
+        out.bwt[i] = p == 0 ? 0u : text[p - 1];
+        if (p == 0) sentinel.store((uint32_t)i);
+      }
+    });
+    out.sentinel_pos = sentinel.load();
   }
   // symbol -> first SA index (FM-index C array over the compacted alphabet)
   std::map<uint32_t, uint32_t> sym_first;
@@ -770,8 +883,10 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   };
   out.prog.clear();
   out.prog.push_back(0);  // program 0: no outputs (marker positions that are never scanned)
-  std::map<std::pair<uint32_t, int32_t>, uint32_t> prog_of;
-  auto make_program = [&](uint32_t marker0, int32_t allele0) -> uint32_t {
+  // (programs are built chunk by chunk of the marker list, on all threads: `prog` and `prog_of` are a chunk's own, its
+  // offsets are rebased when the chunks are joined; a program shared by markers of two chunks is simply built twice)
+  typedef std::map<std::pair<uint32_t, int32_t>, uint32_t> ProgMemo;
+  auto make_program = [&](std::vector<uint32_t> &prog, ProgMemo &prog_of, uint32_t marker0, int32_t allele0) -> uint32_t {
     auto key = std::make_pair(marker0, allele0);
     auto f = prog_of.find(key);
     if (f != prog_of.end()) return f->second;
@@ -823,13 +938,13 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
           }
       }
     }
-    uint32_t off = (uint32_t)out.prog.size();
-    out.prog.push_back((uint32_t)outputs.size());
+    uint32_t off = (uint32_t)prog.size();
+    prog.push_back((uint32_t)outputs.size());
     for (auto &o : outputs) {
-      out.prog.push_back((uint32_t)(o.first.size() / 3));
-      out.prog.insert(out.prog.end(), o.first.begin(), o.first.end());
-      out.prog.push_back(o.second.first);
-      out.prog.push_back(o.second.second);
+      prog.push_back((uint32_t)(o.first.size() / 3));
+      prog.insert(prog.end(), o.first.begin(), o.first.end());
+      prog.push_back(o.second.first);
+      prog.push_back(o.second.second);
     }
     prog_of[key] = off;
     return off;
@@ -838,64 +953,118 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   std::vector<uint32_t> progs_bwt;
   {
     GmxIndexView hv = out.view();  // blocks are in place: the LF steps below only need them and C[]
-    for (size_t i = 0; i < n; ++i) {
-      if (out.bwt[i] <= 4) continue;
-      uint32_t p = out.sa[i];
-      GmxHit hit;
-      memset(&hit, 0, sizeof(hit));
-      uint32_t prog_off = 0;
-      if (p < N && prg[p] <= 4) {
-        // left_markers_search, vBWT_jump.cpp:94-117
-        uint32_t m = g.pos_target[p].first;
-        int32_t a = g.pos_target[p].second;
-        if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
-        prog_off = make_program(m, a);
-      }
-      for (auto &sub : hit.sub) {
-        sub.head = GMX_HIT_PROG;
-        sub.site = prog_off;
-      }
-      const uint32_t *pw = out.prog.data() + prog_off;
-      if (prog_off != 0 && pw[0] == 1 && pw[1] == 1) {  // one output, one op: pre-resolve it together with its LF step
-        uint32_t op = pw[2], site = pw[3], lo = pw[5], hi = pw[6];
-        if (op == GMX_OP_EXIT && lo == hi) {
-          uint32_t b0 = out.bwt[lo];
-          for (uint32_t c = 1; c <= 4; ++c) {
-            GmxHitSub &sub = hit.sub[c - 1];
-            sub.head = GMX_HIT_EXIT;
-            sub.site = site;
-            sub.y = pw[4];
-            if (b0 == c) {
-              uint32_t l2 = lo, h2 = hi;
-              const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
-              if (!gmx_lf(hv, c, l2, h2, blk) || l2 != h2) throw std::runtime_error("internal: exit LF precomputation failed");
-              sub.head |= GMX_HITF_ALIVE | GMX_HITF_TEXT;
-              sub.x = out.sa[l2];
-            }
+    const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    // the BWT positions holding a marker, in BWT order
+    const size_t piece = 1u << 22, n_pieces = (n + piece - 1) / piece;
+    std::vector<size_t> piece_count(n_pieces + 1, 0);
+    par_for(n_pieces, hw, [&](size_t c) {
+      size_t k = 0;
+      for (size_t i = c * piece; i < std::min(n, (c + 1) * piece); ++i) k += out.bwt[i] > 4;
+      piece_count[c + 1] = k;
+    });
+    for (size_t c = 0; c < n_pieces; ++c) piece_count[c + 1] += piece_count[c];
+    const size_t n_markers = piece_count[n_pieces];
+    std::vector<uint32_t> marker_at(n_markers);
+    par_for(n_pieces, hw, [&](size_t c) {
+      size_t k = piece_count[c];
+      for (size_t i = c * piece; i < std::min(n, (c + 1) * piece); ++i)
+        if (out.bwt[i] > 4) marker_at[k++] = (uint32_t)i;
+    });
+    struct Chunk {
+      std::vector<uint32_t> prog;  // local offsets start at 1 (0 = no program, as in the joined array)
+      std::string error;
+    };
+    const size_t chunk_markers = 1u << 14, n_chunks = (n_markers + chunk_markers - 1) / chunk_markers;
+    std::vector<Chunk> chunks(n_chunks);
+    out.hits.resize(n_markers);
+    progs_bwt.assign(n_markers, 0);
+    par_for(n_chunks, hw, [&](size_t ci) {
+      Chunk &ck = chunks[ci];
+      ck.prog.push_back(0);
+      ProgMemo memo;
+      try {
+        for (size_t mi = ci * chunk_markers; mi < std::min(n_markers, (ci + 1) * chunk_markers); ++mi) {
+          const size_t i = marker_at[mi];
+          uint32_t p = out.sa[i];
+          GmxHit hit;
+          memset(&hit, 0, sizeof(hit));
+          uint32_t prog_off = 0;
+          if (p < N && prg[p] <= 4) {
+            // left_markers_search, vBWT_jump.cpp:94-117
+            uint32_t m = g.pos_target[p].first;
+            int32_t a = g.pos_target[p].second;
+            if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
+            prog_off = make_program(ck.prog, memo, m, a);
           }
-        } else if (op == GMX_OP_ENTER) {
-          for (uint32_t c = 1; c <= 4; ++c) {
-            GmxHitSub &sub = hit.sub[c - 1];
-            sub.head = GMX_HIT_ENTER;
-            sub.site = site;
-            uint32_t l2 = lo, h2 = hi;
-            const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
-            if (gmx_lf(hv, c, l2, h2, blk)) {
-              sub.head |= GMX_HITF_ALIVE;
-              if (l2 == h2) {
-                sub.head |= GMX_HITF_TEXT;
-                sub.x = out.sa[l2];
-              } else {
-                sub.x = l2;
-                sub.y = h2;
+          for (auto &sub : hit.sub) {
+            sub.head = GMX_HIT_PROG;
+            sub.site = prog_off;  // (chunk-local: rebased below)
+          }
+          const uint32_t *pw = ck.prog.data() + prog_off;
+          if (prog_off != 0 && pw[0] == 1 && pw[1] == 1) {  // one output, one op: pre-resolve it together with its LF step
+            uint32_t op = pw[2], site = pw[3], lo = pw[5], hi = pw[6];
+            if (op == GMX_OP_EXIT && lo == hi) {
+              uint32_t b0 = out.bwt[lo];
+              for (uint32_t c = 1; c <= 4; ++c) {
+                GmxHitSub &sub = hit.sub[c - 1];
+                sub.head = GMX_HIT_EXIT;
+                sub.site = site;
+                sub.y = pw[4];
+                if (b0 == c) {
+                  uint32_t l2 = lo, h2 = hi;
+                  const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
+                  if (!gmx_lf(hv, c, l2, h2, blk) || l2 != h2) throw std::runtime_error("internal: exit LF precomputation failed");
+                  sub.head |= GMX_HITF_ALIVE | GMX_HITF_TEXT;
+                  sub.x = out.sa[l2];
+                }
+              }
+            } else if (op == GMX_OP_ENTER) {
+              for (uint32_t c = 1; c <= 4; ++c) {
+                GmxHitSub &sub = hit.sub[c - 1];
+                sub.head = GMX_HIT_ENTER;
+                sub.site = site;
+                uint32_t l2 = lo, h2 = hi;
+                const GmxRankBlock blk = hv.blocks[l2 >> GMX_BLK_SHIFT];
+                if (gmx_lf(hv, c, l2, h2, blk)) {
+                  sub.head |= GMX_HITF_ALIVE;
+                  if (l2 == h2) {
+                    sub.head |= GMX_HITF_TEXT;
+                    sub.x = out.sa[l2];
+                  } else {
+                    sub.x = l2;
+                    sub.y = h2;
+                  }
+                }
               }
             }
           }
+          progs_bwt[mi] = prog_off;
+          out.hits[mi] = hit;
         }
+      } catch (std::exception const &e) {
+        ck.error = e.what();
       }
-      progs_bwt.push_back(prog_off);
-      out.hits.push_back(hit);
+    });
+    // join the chunks' programs and rebase the offsets (a chunk's offset o > 0 becomes base + o - 1)
+    std::vector<uint64_t> base(n_chunks + 1, 0);
+    base[0] = out.prog.size();
+    for (size_t ci = 0; ci < n_chunks; ++ci) {
+      if (!chunks[ci].error.empty()) throw std::runtime_error(chunks[ci].error);
+      base[ci + 1] = base[ci] + chunks[ci].prog.size() - 1;
     }
+    if (base[n_chunks] >= 0xFFFFFFFFull) throw std::runtime_error("the jump programs exceed 2^32 words");
+    out.prog.resize(base[n_chunks]);
+    par_for(n_chunks, hw, [&](size_t ci) {
+      const Chunk &ck = chunks[ci];
+      if (ck.prog.size() > 1) memcpy(out.prog.data() + base[ci], ck.prog.data() + 1, (ck.prog.size() - 1) * sizeof(uint32_t));
+      for (size_t mi = ci * chunk_markers; mi < std::min(n_markers, (ci + 1) * chunk_markers); ++mi) {
+        if (progs_bwt[mi] == 0) continue;
+        const uint32_t off = (uint32_t)(base[ci] + progs_bwt[mi] - 1);
+        for (auto &sub : out.hits[mi].sub)
+          if ((sub.head & 3u) == GMX_HIT_PROG && sub.site == progs_bwt[mi]) sub.site = off;
+        progs_bwt[mi] = off;
+      }
+    });
   }
   build_trace("jump programs + hit records");
   // --- PRG text records; hit records re-ordered from BWT order to text order ---------------

@@ -62,7 +62,7 @@ struct HostIndex {
 };
 
 // Suffix array of `text` (last symbol must be the unique smallest symbol 0). SA-IS, O(n).
-void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa);
+void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa, int threads = 1);
 // The same code with 16-bit indices (test hook: texts longer than 2^15 use the index type's top bit, as texts longer
 // than 2^31 do with the 32-bit indices of the product).
 void debug_suffix_array_u16(const uint16_t *text, size_t n, uint16_t *sa);
