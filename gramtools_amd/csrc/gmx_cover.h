@@ -744,6 +744,112 @@ GMX_HD bool gmx_cover_single_nested(const GmxIndexView &ix, Env &env, const GmxF
   return true;
 }
 
+// The same for single-instance tasks with MORE loci than the register slots hold (a read through an MSA region crosses
+// ten to fifteen nested sites): loci and a copy of the traversed list live in the env's per-lane scratch (LDS: sget/sset),
+// at most GMX_WIDE_LOCI each. One item, hence one class and no draw that could change the outcome — none of the general
+// routine's keys, sort, class search and merge. Returns false, nothing recorded, when the task does not fit.
+//   scratch words: [0, 2 C) loci (site, allele) | [2 C, 4 C) traversed list, newest first (site, allele);  C = GMX_WIDE_LOCI
+#define GMX_WIDE_LOCI 32u
+template <class Env>
+GMX_HD bool gmx_cover_single_nested_wide(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
+  constexpr uint32_t C = GMX_WIDE_LOCI, L0 = 0, P0 = 2 * C;
+  const uint32_t tvd = st.traversed, tvg = st.traversing;
+  const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
+  const uint32_t node0 = ix.pos_node[p];
+  const GmxNode rec0 = ix.nodes[node0];
+  uint32_t n = 0;
+  bool full = false;
+  auto used = [&](uint32_t site) {
+    for (uint32_t i = 0; i < n; ++i)
+      if (env.sget(L0 + 2 * i) == site) return true;
+    return false;
+  };
+  auto climb = [&](uint32_t site, int32_t allele) {  // assign_nested_locus, coverage_common.cpp:34-51
+    while (!full && !used(site)) {
+      if (n >= C) {
+        full = true;
+        return;
+      }
+      env.sset(L0 + 2 * n, site);
+      env.sset(L0 + 2 * n + 1, (uint32_t)allele);
+      ++n;
+      const GmxSite &s = ix.sites[(site - 5) >> 1];
+      if (s.parent_site == 0) break;
+      allele = s.parent_allele;
+      site = s.parent_site;
+    }
+  };
+  uint32_t enc_site = 0;
+  int32_t enc_allele = -1;
+  if (tvd == GMX_NIL && tvg == GMX_NIL) {
+    if (rec0.site == 0) return true;  // a non-variant instance only: nothing to record
+    enc_site = rec0.site;
+    enc_allele = rec0.allele;
+    climb(enc_site, enc_allele);
+  } else {
+    uint32_t nt = 0;  // the traversed list, copied once (every handle step is a dependent load from the arena)
+    for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x), ++nt) {
+      if (nt >= C) return false;
+      env.sset(P0 + 2 * nt, env.h_site(x));
+      env.sset(P0 + 2 * nt + 1, (uint32_t)env.h_allele(x));
+    }
+    // check_site_uniqueness (coverage_common.cpp:17-32)
+    for (uint32_t i = 0; i < nt; ++i) {
+      const uint32_t sx = env.sget(P0 + 2 * i);
+      for (uint32_t j = i + 1; j < nt; ++j)
+        if (env.sget(P0 + 2 * j) == sx) return env.fail(GMX_TASK_ERROR), true;
+      for (uint32_t y = tvg; y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR), true;
+    }
+    for (uint32_t x = tvg; x != GMX_NIL; x = env.h_next(x)) {
+      const uint32_t sx = env.h_site(x);
+      for (uint32_t y = env.h_next(x); y != GMX_NIL; y = env.h_next(y))
+        if (env.h_site(y) == sx) return env.fail(GMX_TASK_ERROR), true;
+    }
+    if (tvg != GMX_NIL) {  // assign_traversing_loci (:53-76): the innermost site with the allele under p, then its ancestors
+      const uint32_t seed_site = env.h_site(tvg);
+      env.sset(L0, seed_site);
+      env.sset(L0 + 1, (uint32_t)rec0.allele);
+      n = 1;
+      const GmxSite &ps = ix.sites[(seed_site - 5) >> 1];
+      if (ps.parent_site != 0) climb(ps.parent_site, ps.parent_allele);
+    }
+    for (uint32_t d = nt; d-- > 0;)  // assign_traversed_loci (:78-83): oldest first; the copy's head is the newest
+      climb(env.sget(P0 + 2 * d), (int32_t)env.sget(P0 + 2 * d + 1));
+  }
+  if (full) return false;
+  if (env.has_log_sites()) {  // reserve the task's words of the grouped log before anything is recorded
+    uint32_t words = 0;
+    for (uint32_t i = 0; i < n; ++i)
+      if (ix.sites[(env.sget(L0 + 2 * i) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
+    if (words && !env.log_reserve(words)) return true;
+  }
+  uint32_t hit = 0;  // loci recorded by a hit counter during the walk (gmx_types.h); n <= 32
+  GmxWalk w;
+  gmx_walk_init(ix, w, p, node0, rec0, read_len, tvd, enc_site, enc_allele);
+  for (;;) {
+    uint32_t node = gmx_walk_next(ix, env, w);
+    if (w.bad) return env.fail(GMX_TASK_ERROR), true;
+    if (node == GMX_NO_NODE) break;
+    if (w.rec.seq_len == 0) continue;
+    if (w.rec.cov_off == GMX_NO_COV) return env.fail(GMX_TASK_ERROR), true;
+    if (gmx_node_has_hit_counter(w.rec)) {  // the node is its allele: its locus, if the item has it, is recorded here
+      uint32_t bit = 0;
+      for (uint32_t i = 0; i < n; ++i)
+        if (env.sget(L0 + 2 * i) == w.rec.site && (int32_t)env.sget(L0 + 2 * i + 1) == w.rec.allele) bit = 1u << i;
+      if (bit & ~hit) {
+        hit |= bit;
+        env.add_hit(w.rec.cov_off + 1);
+        continue;
+      }
+    }
+    for (uint32_t i = w.start; i <= w.end; ++i) env.add_per_base(w.rec.cov_off + i);
+  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (!((hit >> i) & 1u) && !gmx_record_locus(ix, env, env.sget(L0 + 2 * i), (int32_t)env.sget(L0 + 2 * i + 1))) return true;
+  return true;
+}
+
 // One member item of the chosen class: its loci merged into the class's set [0, n_loci) (a set union: the order of the
 // members does not matter), its per-base hull into [0, n_hull). False: a capacity was exceeded or an error found
 // (env.status), nothing recorded.

@@ -40,7 +40,9 @@
 #include "gmx_internal.h"
 
 #define GMX_BLOCK 256
+#ifndef GMX_FAST_STATES
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
+#endif
 #ifndef GMX_STACK_DEPTH
 #define GMX_STACK_DEPTH 6
 #endif
@@ -51,8 +53,11 @@
 #define GMX_CNT_LOG_RETRY 30u       // entries of log_retry_list: coverage queue entries whose task found the grouped log full
 #define GMX_CNT_LOG_RETRY_RECS 31u  // ... compact records (log_retry_recs: index into cover_recs)
 #define GMX_CNT_LOG_RETRY_HUGE 33u  // ... tasks the last tier has to search again (log_retry_huge)
+#define GMX_CNT_GENERAL_REST 34u    // entries gmx_cover_one_kernel left to the general instances (general_rest_list)
 #define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
+#ifndef GMX_FAST_ARENA
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
+#endif
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
 
@@ -830,6 +835,7 @@ struct SearchOut {
   uint32_t *log_retry_list;            // coverage queue entries (task / large-capacity slot / instance slot); counter [30]
   uint32_t *log_retry_recs;            // compact records, as index into cover_recs; counter [31]
   uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
+  uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
 #ifndef GMX_SEARCHOUT_ALT
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
 #endif
@@ -2124,14 +2130,14 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
   // in counter [10], 2 starts there
   // (instances 3, 5 and 2 after the cooperative kernel: only what that one left, reject lists and counters [27], [26], [28])
-  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : 8)
+  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : GMX_CNT_GENERAL_REST)
                                  : LIST == 0 ? 13
                                  : LIST == 1 ? 4
                                  : LIST == 5 ? (after_coop ? 26 : 25)
                                  : LIST == 2 ? (after_coop ? 28 : 7)
                                              : 7) * GMX_CNT_STRIDE];
   const uint32_t m_start = LIST == 2 && !after_coop ? o.counters[10 * GMX_CNT_STRIDE] : 0u;
-  const uint32_t *list = LIST == 3   ? (after_coop ? o.general_serial_list : o.cover_general_list)
+  const uint32_t *list = LIST == 3   ? (after_coop ? o.general_serial_list : o.general_rest_list)
                          : LIST == 0 ? o.cover_mid_list
                          : LIST == 1 ? o.cover_overflow_list
                          : LIST == 5 ? (after_coop ? o.inst_serial_list : o.inst_mapped_list)
@@ -2207,6 +2213,58 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
 }
 
 // ---------------------------------------------------------------------------
+// Single-instance tasks the compact path could not take — a nested traversing path, traversed sites that are not
+// consecutive (children inside an MSA region), or more loci than the register slots of gmx_cover_single_nested hold —
+// one lane per task with the loci in LDS (gmx_cover_single_nested_wide): no keys, no sort, no class merge, no draw.
+// The general instances (cooperative, then serial) spent 0.8 ms of wall time per round on such tasks at configs[2]
+// (profiles/round3/coop_phases_config2.txt): a single state of width one has ONE item, hence one class, and the draw
+// cannot change the outcome (coverage_common.cpp:166-177 with one class and no non-variant instance selects it whatever
+// the number drawn). What does not fit (several final states, wide intervals, more than 32 loci) goes on to them.
+// ---------------------------------------------------------------------------
+#define GMX_ONE_THREADS 64
+struct OneEnv : CoverLogPart {
+  uint32_t *scratch;  // this lane's words, GMX_ONE_THREADS apart
+  const GmxPathNode *arena;
+  __device__ __forceinline__ uint32_t h_site(uint32_t h) const { return gmx_h_site(arena, h); }
+  __device__ __forceinline__ int32_t h_allele(uint32_t h) const { return gmx_h_allele(arena, h); }
+  __device__ __forceinline__ uint32_t h_next(uint32_t h) const { return gmx_h_next(arena, h); }
+  __device__ __forceinline__ uint32_t sget(uint32_t w) const { return scratch[w * GMX_ONE_THREADS]; }
+  __device__ __forceinline__ void sset(uint32_t w, uint32_t v) { scratch[w * GMX_ONE_THREADS] = v; }
+};
+__global__ void __launch_bounds__(GMX_ONE_THREADS) gmx_cover_one_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, CoverAcc acc,
+                                                                        uint32_t enabled) {
+  const uint32_t n = o.counters[8 * GMX_CNT_STRIDE];
+  for (uint32_t m = blockIdx.x * GMX_ONE_THREADS + threadIdx.x; m < n; m += gridDim.x * GMX_ONE_THREADS) {
+    const uint32_t entry = o.cover_general_list[m];
+    const GmxTaskStates ts = gmx_entry_states(entry, o, g);
+    bool taken = false;
+    if (enabled && ts.nf == 1) {
+      const GmxFinalState st = ts.finals[0];
+      if (gmx_text_form(st.hi) || st.lo == st.hi) {
+        OneEnv env;
+        env.scratch = gmx_lds + threadIdx.x;
+        env.arena = ts.arena;
+        env.acc = acc.acc;
+        env.log = acc.log;
+        env.log_cursor = acc.log_cursor;
+        env.log_cap = acc.log_cap;
+        env.log_sites = acc.log_sites;
+        env.status = GMX_TASK_MAPPED;
+        env.log_at = 0;
+        taken = gmx_cover_single_nested_wide(ix, env, st, read_len(b, ts.task >> 1));
+        if (env.status == GMX_TASK_LOGFULL) {
+          o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = entry;
+        } else if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u) {
+          o.error[1] = ts.task;
+        }
+        env.log_abandon();
+      }
+    }
+    if (!taken) o.general_rest_list[atomicAdd(&o.counters[GMX_CNT_GENERAL_REST * GMX_CNT_STRIDE], 1u)] = entry;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The general routine, cooperatively: 16 lanes per task, one lane per item. The serial instances above spend one lane
 // on a whole task — a read with ten mapping instances is ten items' worth of loci, keys, a sort and a class search in
 // one lane, and a wave of such lanes executes the union of all their branches: the SIMDs, not memory, set the pace.
@@ -2249,9 +2307,9 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
   typedef typename CoopSizes<LIST>::Class CoopClassEnv;
   typedef GmxScratch<CoopItemEnv> SI;
   typedef GmxScratch<CoopClassEnv> SC;
-  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : 8) * GMX_CNT_STRIDE];
+  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : GMX_CNT_GENERAL_REST) * GMX_CNT_STRIDE];
   const uint32_t n_first = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;  // instance 2 starts where instance 4 stopped
-  const uint32_t *list = LIST == 5 ? o.inst_mapped_list : LIST == 2 ? o.big_mapped_list : o.cover_general_list;
+  const uint32_t *list = LIST == 5 ? o.inst_mapped_list : LIST == 2 ? o.big_mapped_list : o.general_rest_list;
   uint32_t *reject = LIST == 5 ? o.inst_serial_list : LIST == 2 ? o.big_serial_list : o.general_serial_list;
   uint32_t *reject_n = &o.counters[(LIST == 5 ? 26 : LIST == 2 ? 28 : 27) * GMX_CNT_STRIDE];
   const uint32_t lane = threadIdx.x, grp = lane >> 4, gl = lane & 15u, gbase = grp << 4;
@@ -2720,6 +2778,7 @@ struct gmx_engine {
   uint2 *d_packed = nullptr;
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
+  uint32_t *d_general_rest = nullptr;
   uint32_t *d_task_lists = nullptr;  // SearchOut::task_lists: d_overflow, d_overflow2, d_alive, d_dead, d_dead2, d_cover_general are its slices
   GmxSeed *d_alive_seed = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
@@ -2933,6 +2992,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   e->d_dead2 = e->d_task_lists + (size_t)GMX_TL_DEAD2 * n_tasks;
   e->d_cover_general = e->d_task_lists + (size_t)GMX_TL_GENERAL * n_tasks;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_general_rest, n_tasks, false))) return rc;
   if (e->log_sites)
     for (int side = 0; side < 2; ++side) {
       if ((rc = e->alloc(&e->d_log_retry[side], n_tasks, false))) return rc;
@@ -3337,6 +3397,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.big_serial_list = e->d_big_serial;
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
+  o.general_rest_list = e->d_general_rest;
   o.log_retry_list = e->d_log_retry[e->log_retry_side];
   o.log_retry_recs = e->d_log_retry_recs[e->log_retry_side];
   o.log_retry_huge = e->d_log_retry_huge[e->log_retry_side];
@@ -3422,7 +3483,13 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   // the large-capacity pass's chain of few-lane kernels: with reads in repeats that chain is the batch's longest path)
   const bool general_on_side = !e->dview.is_nested;
   HIP_TRY(hipStreamWaitEvent(e->side_stream, e->ev_fork2, 0));
+  const size_t one_lds = (size_t)4 * GMX_WIDE_LOCI * GMX_ONE_THREADS * sizeof(uint32_t);
+  const bool one = !getenv("GMX_NO_COVER_ONE");
+  auto launch_one = [&](hipStream_t st) {  // (with GMX_NO_COVER_ONE the kernel only passes its queue on: A/B runs)
+    hipLaunchKernelGGL(gmx_cover_one_kernel, dim3(e->n_cus * 4), dim3(GMX_ONE_THREADS), one_lds, st, e->dview, b, o, e->big, acc, one ? 1u : 0u);
+  };
   if (general_on_side) {
+    launch_one(e->side_stream);
     if (e->coop) launch_cover_coop<3>(e, e->side_stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);
@@ -3434,6 +3501,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   // which queues nothing on a non-nested PRG: there it runs at the end of side 2, beside that kernel.
   hipStream_t last = general_on_side ? e->side2_stream : stream;
   if (!general_on_side) {
+    launch_one(stream);
     if (e->coop) launch_cover_coop<3>(e, stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, stream, b, o, acc);

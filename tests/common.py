@@ -66,6 +66,9 @@ def _load_emu():
     lib.hostemu_create.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint32, C.c_int, C.c_char_p, C.c_uint64]
     lib.hostemu_destroy.argtypes = [C.c_void_p]
     lib.hostemu_set_single_loci.argtypes = [C.c_void_p, C.c_uint32]
+    lib.hostemu_set_wide.argtypes = [C.c_void_p, C.c_int]
+    lib.hostemu_n_wide.restype = C.c_uint64
+    lib.hostemu_n_wide.argtypes = [C.c_void_p]
     lib.hostemu_map.restype = C.c_int
     lib.hostemu_map.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -77,7 +80,7 @@ def _load_emu():
 
 
 def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048,
-                return_raw=False, single_loci=None):
+                return_raw=False, single_loci=None, wide=False, stats=None):
     """Runs the device headers on the host. Returns (canonical coverage, n_overflow_tasks, rc)."""
     lib = _load_emu()
     arr = np.ascontiguousarray(prg, dtype=np.uint32)
@@ -92,9 +95,13 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
         if single_loci is not None:  # loci capacity of the nested single-instance routine (gmx_cover.h)
             lib.hostemu_set_single_loci(h, single_loci)
+        if wide:  # single-instance tasks through gmx_cover_single_nested_wide (the routine of gmx_cover_one_kernel)
+            lib.hostemu_set_wide(h, 1)
         rc = lib.hostemu_map(h, flat.ctypes.data_as(C.POINTER(C.c_uint8)), offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                              s.ctypes.data_as(C.POINTER(C.c_uint32)), offs.size - 1, fast_states, fast_arena, big_states,
                              big_arena)
+        if stats is not None:
+            stats["n_wide"] = int(lib.hostemu_n_wide(h))
         sizes = np.zeros(7, dtype=np.uint64)
         lib.hostemu_sizes(h, sizes.ctypes.data_as(C.POINTER(C.c_uint64)))
         a = np.zeros(max(int(sizes[0]), 1), dtype=np.uint32)

@@ -107,6 +107,8 @@ struct Emu {
   uint32_t first_error = 0, error_task = 0;
   uint64_t n_overflow_tasks = 0, n_cover_overflow = 0, n_cover_huge = 0;
   uint32_t single_loci = GMX_SINGLE_LOCI;  // hostemu_set_single_loci: force the nested single-instance routine to give up
+  int wide = 0;  // hostemu_set_wide: single-instance tasks take gmx_cover_single_nested_wide first (gmx_cover_one_kernel's routine)
+  uint64_t n_wide = 0;
   std::string err;
 };
 
@@ -346,6 +348,8 @@ void *hostemu_create(const uint32_t *prg, uint64_t n, uint32_t k, int rng_mode, 
 void hostemu_destroy(void *p) { delete (Emu *)p; }
 
 // Same two-tier flow as launch_batch(): fast pass (4 states / 24 arena nodes), large-capacity pass, cover, stats.
+void hostemu_set_wide(void *p, int on) { static_cast<Emu *>(p)->wide = on; }
+uint64_t hostemu_n_wide(void *p) { return static_cast<Emu *>(p)->n_wide; }
 void hostemu_set_single_loci(void *p, uint32_t n) { static_cast<Emu *>(p)->single_loci = n < GMX_SINGLE_LOCI ? n : GMX_SINGLE_LOCI; }
 
 int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads,
@@ -396,7 +400,12 @@ int hostemu_map(void *p, const uint8_t *reads, const uint64_t *offsets, const ui
       EmuEnv env;
       env.arena = use.arena;
       env.e = e;
-      gmx_cover_task(ix, env, use.st, use.n, len, seeds[read], e->rng_mode);
+      bool taken = false;
+      if (e->wide && use.n == 1 && (gmx_text_form(use.st[0].hi) || use.st[0].lo == use.st[0].hi)) {
+        taken = gmx_cover_single_nested_wide(ix, env, use.st[0], len);  // false: nothing recorded, the general routine next
+        if (taken) e->n_wide++;
+      }
+      if (!taken) gmx_cover_task(ix, env, use.st, use.n, len, seeds[read], e->rng_mode);
       uint32_t cstatus = env.status;
       if (cstatus == GMX_TASK_MAPPED && env.reserved != env.appended) cstatus = GMX_TASK_ERROR;  // log reservation mismatch
       if (cstatus == GMX_TASK_OVERFLOW) {  // nothing recorded yet: redo with the large scratch

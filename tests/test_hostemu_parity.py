@@ -73,3 +73,15 @@ def test_inline_sites_dense_snps_short_reads(seed, monkeypatch):
     assert Index(prg, k).info.n_inline_sites == 0
     got2, _, rc = hostemu_map(prg, k, reads, seeds)
     assert rc == 0 and got2 == want
+
+
+@pytest.mark.parametrize("seed", range(0, 90, 3))
+def test_wide_single_instance_routine_matches_oracle(seed):
+    """gmx_cover_single_nested_wide (the routine of gmx_cover_one_kernel: one final state of width one, loci in scratch,
+    no keys / classes / draw) in front of the general routine: same coverage as the oracle on nested and repetitive PRGs."""
+    prg, k, reads, seeds = _case(seed)
+    want = oracle_map(prg, k, reads, seeds, rng_mode=seed % 2)
+    st = {}
+    got, _, rc = hostemu_map(prg, k, reads, seeds, rng_mode=seed % 2, wide=True, stats=st)
+    assert rc == 0 and got == want
+    assert st["n_wide"] > 0 or seed % 3 == 0   # (the low-complexity PRGs may have multi-mapping reads only)
