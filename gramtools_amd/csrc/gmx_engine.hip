@@ -54,6 +54,7 @@
 #define GMX_CNT_LOG_RETRY_RECS 31u  // ... compact records (log_retry_recs: index into cover_recs)
 #define GMX_CNT_LOG_RETRY_HUGE 33u  // ... tasks the last tier has to search again (log_retry_huge)
 #define GMX_CNT_GENERAL_REST 34u    // entries gmx_cover_one_kernel left to the general instances (general_rest_list)
+#define GMX_CNT_ALIVE2 35u          // stragglers of the extend kernel, parked for its second pass (alive2_list)
 #define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
 #ifndef GMX_FAST_ARENA
 #define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
@@ -836,6 +837,11 @@ struct SearchOut {
   uint32_t *log_retry_recs;            // compact records, as index into cover_recs; counter [31]
   uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
   uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
+  // Stragglers: the extend kernel's wave loop has an iteration budget; a lane with work left then (a read inside an MSA
+  // region takes fifty iterations, its 63 neighbours five) parks its pending entries and goes to a second, compacted pass.
+  uint32_t *alive2_list;               // the parked tasks; counter [35]
+  GmxParked *park2;                    // per task: up to GMX_STACK_DEPTH pending entries (its final states stay in finals[])
+  uint32_t *park2_n;                   // per task: how many
 #ifndef GMX_SEARCHOUT_ALT
   unsigned long long *stats; // QuasimapReadsStats (quasimap.hpp:17-24), counted where each task's fate is decided:
 #endif
@@ -844,7 +850,7 @@ struct SearchOut {
 };
 
 #define GMX_REGIONS 8
-enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_N };
+enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_ALIVE2, GMX_TL_N };
 
 // stats[idx] += number of threads of the block with `flag` (one global atomic per block). Every thread of the block
 // must call it. `scratch` is one uint32 of LDS per call site.
@@ -875,12 +881,15 @@ __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task
 
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
 //   done  : the whole read has been consumed (the emitted states are final, not parked)
+//   parked: the task's pending entries are in SearchOut::park2 (a straggler of the extend kernel): alive whatever n_out says
 __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const SearchOut &o, bool active, uint32_t task, FastCtx &ctx,
-                                            uint32_t status, bool done, bool second_phase, uint32_t read_len) {
+                                            uint32_t status, bool done, bool second_phase, uint32_t read_len, bool parked = false) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
-      if (ctx.n_out == 0 && ctx.seed_left == 0)
+      if (parked)
+        alive = true;
+      else if (ctx.n_out == 0 && ctx.seed_left == 0)
         dead = true;
       else {
         mapped = done;
@@ -972,7 +981,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
-    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? 5u : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
+    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? (second_phase ? GMX_CNT_ALIVE2 : 5u) : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
     q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
@@ -986,7 +995,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       o.cover_rec_task[(size_t)cat * o.region_cap + at] = task;
     } else {
       const uint32_t q = cat == Q_OVER ? (second_phase ? GMX_TL_OVERFLOW2 : GMX_TL_OVERFLOW)
-                         : cat == Q_ALIVE ? GMX_TL_ALIVE
+                         : cat == Q_ALIVE ? (second_phase ? GMX_TL_ALIVE2 : GMX_TL_ALIVE)
                          : cat == Q_DEAD  ? (second_phase ? GMX_TL_DEAD2 : GMX_TL_DEAD)
                                           : GMX_TL_GENERAL;
       o.task_lists[(size_t)q * o.list_stride + at] = task;
@@ -1375,14 +1384,19 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_inst_kernel(GmxIndexView
 #define GMX_EXTEND_WAVES 5
 #endif
 #define GMX_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(GMX_EXTEND_WAVES)))
-template <bool CURSOR, bool SEEDED>
-__global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse) {
-  uint32_t n_alive = o.counters[5 * GMX_CNT_STRIDE];
+// MODE 0: the tasks the probe kernel parked (index without a longer seed table); 1: the tasks gmx_seed_kernel queued, from
+// their seed directory entries; 2: the stragglers of a MODE 0 / 1 launch (SearchOut::alive2_list). `budget` (MODE 0, 1):
+// iterations of the wave loop after which a lane with work left is parked for the MODE 2 launch; 0 = none.
+template <bool CURSOR, int MODE>
+__global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse,
+                                                                               uint32_t budget) {
+  constexpr bool SEEDED = MODE == 1;
+  uint32_t n_alive = o.counters[(MODE == 2 ? GMX_CNT_ALIVE2 : 5u) * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   const long long t0 = GMX_CLK();
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = slot < n_alive;
-  uint32_t task = active ? o.alive_list[slot] : 0;
+  uint32_t task = active ? (MODE == 2 ? o.alive2_list : o.alive_list)[slot] : 0;
   uint32_t status = GMX_TASK_MAPPED;
   FastCtx ctx;
   ctx.sp = 0;
@@ -1422,18 +1436,64 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
       ctx.seed_off = o.seed_cursor[task];
       ctx.seed_pos = r.len - (ix.kmer_size2 != 0 && r.len >= ix.kmer_size2 ? ix.kmer_size2 : ix.kmer_size);
     }
-    const GmxParked *parked = reinterpret_cast<const GmxParked *>(ctx.out);  // all read before the first emit overwrites them
-    for (uint32_t s = 0; s < n; ++s) {
-      GmxParked f = parked[s];
-      ctx.push(f.a, f.b, f.tvd, f.tvg, f.pm & 0x3FFFFFFFu, f.pm >> 30);
+    if (MODE == 2) {  // a straggler: its final states so far are in finals[], its pending entries in park2
+      ctx.n_out = n;
+      ctx.mark_out = n;
+      if (n) {
+        const GmxFinalState f0 = ctx.out[0];
+        if (f0.hi == GMX_TEXT_MARK) {
+          ctx.first_pos = f0.lo;
+          ctx.first_tvd = f0.traversed;
+          ctx.first_tvg = f0.traversing;
+        }
+      }
+      const uint32_t np = o.park2_n[task];
+      const GmxParked *parked = o.park2 + (size_t)task * GMX_STACK_DEPTH;
+      for (uint32_t s = 0; s < np; ++s) {
+        GmxParked f = parked[s];
+        ctx.push(f.a, f.b, f.tvd, f.tvg, f.pm & 0x3FFFFFFFu, f.pm >> 30);
+      }
+    } else {
+      const GmxParked *parked = reinterpret_cast<const GmxParked *>(ctx.out);  // all read before the first emit overwrites them
+      for (uint32_t s = 0; s < n; ++s) {
+        GmxParked f = parked[s];
+        ctx.push(f.a, f.b, f.tvd, f.tvg, f.pm & 0x3FFFFFFFu, f.pm >> 30);
+      }
     }
   }
   const long long t1 = GMX_CLK();
   GmxLane ln;
-  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, 0, ln, fuse != 0);
+  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, MODE == 2 ? 0u : budget, ln, fuse != 0);
+  bool done = true;
+  if (MODE != 2 && budget && active && ctx.status == GMX_TASK_MAPPED && (ln.have || ctx.sp || ctx.seed_left)) {
+    // budget spent with work left: the lane's entry and its stack as they are, for the second pass; what it has emitted
+    // stays in finals[] (the first, deferred state is written now). A full stack beside a live entry has no room to be
+    // restored: that task goes to the large-capacity pass.
+    const bool cur = ln.have && ln.mode != GMX_MODE_DEAD;
+    if (cur && ctx.sp >= GMX_STACK_DEPTH) {
+      ctx.fail(GMX_TASK_OVERFLOW);
+    } else {
+      ctx.flush_first();
+      GmxParked *parked = o.park2 + (size_t)task * GMX_STACK_DEPTH;
+      uint32_t np = 0;
+      uint32_t a, bb, tvd, tvg, pos, mode;
+      // (restored by pushing in this order and popping: the live entry goes last so that it is the first one popped)
+      while (ctx.pop(a, bb, tvd, tvg, pos, mode)) parked[np++] = GmxParked{a, bb, tvd, tvg, pos | (mode << 30)};
+      // pop order is top first: reverse so that pushing restores the same stack
+      for (uint32_t i = 0; i + i + 1 < np; ++i) {
+        const GmxParked t = parked[i];
+        parked[i] = parked[np - 1 - i];
+        parked[np - 1 - i] = t;
+      }
+      if (cur) parked[np++] = GmxParked{ln.a, ln.b, ln.tvd, ln.tvg, ln.pos | (ln.mode << 30)};
+      o.park2_n[task] = np;
+      if (ctx.seed_left) o.seed_cursor[task] = ctx.seed_off;
+      done = false;
+    }
+  }
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(ix, o, slot < n_alive, task, ctx, status, true, true, r.len);
+  finish_lane(ix, o, slot < n_alive, task, ctx, status, done, true, r.len, !done);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -2832,6 +2892,10 @@ struct gmx_engine {
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
+  uint32_t extend_budget = 12;  // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
+                                // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
+  GmxParked *d_park2 = nullptr;
+  uint32_t *d_park2_n = nullptr;
   uint32_t fuse = 1;  // fused transitions in the extend kernel's wave loop (GMX_NO_FUSE=1 in the environment: off, for A/B runs)
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
@@ -2993,6 +3057,8 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   e->d_cover_general = e->d_task_lists + (size_t)GMX_TL_GENERAL * n_tasks;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_general_rest, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_park2, (size_t)n_tasks * GMX_STACK_DEPTH, false))) return rc;
+  if ((rc = e->alloc(&e->d_park2_n, n_tasks, false))) return rc;
   if (e->log_sites)
     for (int side = 0; side < 2; ++side) {
       if ((rc = e->alloc(&e->d_log_retry[side], n_tasks, false))) return rc;
@@ -3158,6 +3224,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   if (getenv("GMX_NO_FUSE")) e->fuse = 0;
+  if (const char *eb = getenv("GMX_EXTEND_BUDGET")) e->extend_budget = (uint32_t)std::max(0, atoi(eb));
   if (getenv("GMX_NO_COOP")) e->coop = false;
   // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
   // more than 10 % of the seed states the kernels take them one state at a time (seed cursor, a few % slower), else
@@ -3398,6 +3465,9 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
   o.general_rest_list = e->d_general_rest;
+  o.alive2_list = e->d_task_lists + (size_t)GMX_TL_ALIVE2 * (e->cap_reads * 2);
+  o.park2 = e->d_park2;
+  o.park2_n = e->d_park2_n;
   o.log_retry_list = e->d_log_retry[e->log_retry_side];
   o.log_retry_recs = e->d_log_retry_recs[e->log_retry_side];
   o.log_retry_huge = e->d_log_retry_huge[e->log_retry_side];
@@ -3455,14 +3525,23 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   // (timing leg: the events are attached to this very dispatch — its own start and end, as a kernel trace sees them —
   // instead of being recorded around it, where they add the gap to the kernel before and two barrier packets)
   hipEvent_t k0 = e->timing ? ev.a : nullptr, k1 = e->timing ? ev.b : nullptr;
+  const uint32_t budget = e->extend_budget;
   if (seeded && e->seed_cursor)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<true, true>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
   else if (seeded)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<false, true>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
   else if (e->seed_cursor)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<true, false>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
   else
-    hipExtLaunchKernelGGL((gmx_extend_kernel<false, false>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
+  if (budget) {  // the stragglers, compacted (a block that finds its part of the queue empty returns at once)
+    const dim3 grid2((task_grid.x + 3) / 4);  // (at most a quarter of the tasks are expected here; the rest of a longer queue: below)
+    if (e->seed_cursor)
+      hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, 0u);
+    else
+      hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, 0u);
+    (void)grid2;
+  }
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks
   HIP_TRY(hipEventRecord(e->ev_fork2, stream));
