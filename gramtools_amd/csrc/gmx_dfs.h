@@ -330,12 +330,14 @@ template <class Ctx>
 GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, uint32_t stop, const GmxHitSub &hs) {
   const uint32_t kind = hs.head & 3u;
   if (kind == GMX_HIT_EXIT) {  // update_variant_site_path + exiting_site_search_state, vBWT_jump.cpp:51-92
+    uint32_t rest = GMX_NIL;  // the traversing path without its innermost site (a nested path: one node load)
     if (ln.tvg != GMX_NIL) {
-      if (!gmx_h_inline(ln.tvg) || 5u + 2u * (ln.tvg & ~GMX_INLINE_FLAG) != hs.site) return false;  // general path (or error there)
+      if (ctx.arena_site(ln.tvg) != hs.site) return false;  // the general path reports the inconsistency
+      rest = ctx.arena_next(ln.tvg);
     }
     uint32_t nn = ctx.arena_new(hs.site, (int32_t)hs.y, ln.tvd);
     if (nn == GMX_NIL) return false;
-    ln.tvg = GMX_NIL;
+    ln.tvg = rest;
     ln.tvd = nn;
     ln.a = hs.x;
     ln.b = GMX_TEXT_MARK;
@@ -346,8 +348,9 @@ GMX_HD bool gmx_dfs_fast_hit(Ctx &ctx, GmxLane &ln, uint32_t stop, const GmxHitS
     ln.a = hs.x - (hs.head >> 4);
     ln.b = GMX_TEXT_MARK;
   } else if (kind == GMX_HIT_ENTER || kind == GMX_HIT_FUSED) {  // entering_site_search_state, vBWT_jump.cpp:29-44
-    if (ln.tvg != GMX_NIL) return false;  // nested entry: the general path materialises the list
-    ln.tvg = GMX_INLINE_FLAG | ((hs.site - 5u) >> 1);
+    const uint32_t nn = ctx.arena_new(hs.site, -1, ln.tvg);  // (inline handle for a first site, a node for a nested one)
+    if (nn == GMX_NIL) return false;
+    ln.tvg = nn;
     ln.a = hs.x;
     ln.b = (hs.head & GMX_HITF_TEXT) ? GMX_TEXT_MARK : hs.y;
   } else

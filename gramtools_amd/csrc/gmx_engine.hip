@@ -57,7 +57,8 @@
 #define GMX_CNT_ALIVE2 35u          // stragglers of the extend kernel, parked for its second pass (alive2_list)
 #define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
 #ifndef GMX_FAST_ARENA
-#define GMX_FAST_ARENA 24     // path arena nodes per task (fast pass)
+#define GMX_FAST_ARENA 48     // path arena nodes per task (fast pass): a read through an MSA region of configs[2] needs 25-40
+                              // (24 sent 14 k of a million such reads to the large-capacity pass: 5.1 -> 3.1 ms per batch)
 #endif
 #define GMX_STATUS_MISSING_KMER 5u  // refinement of GMX_TASK_UNMAPPED by the k-mer filter
 #define GMX_STATUS_IGNORED 7u       // reverse-complement task of a forward_only engine: not mapped, not counted
@@ -2892,7 +2893,7 @@ struct gmx_engine {
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
-  uint32_t extend_budget = 12;  // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
+  uint32_t extend_budget = 8;   // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
                                 // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
   GmxParked *d_park2 = nullptr;
   uint32_t *d_park2_n = nullptr;
