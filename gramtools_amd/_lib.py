@@ -104,6 +104,7 @@ SYMBOLS = {
     "gmx_coverage_fetch": (C.c_int, [_vp, _u32p, _u32p, _u32p, C.POINTER(Stats)]),
     "gmx_coverage_fetch_grouped_log": (_i64, [_vp, _u32p, _u64]),
     "gmx_coverage_import_grouped_log": (C.c_int, [_vp, _u32p, _u64, C.c_int]),
+    "gmx_grouped_log_merge_gathered": (_i64, [_vp, _vp, C.c_int, _u64, _vp, _u64]),
     "gmx_finalize_u16": (None, [_u32p, _u64, C.c_int]),
     "gmx_infer_run": (C.c_int, [_vp, _u32p, _u32p, _u32p, _u64, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(_vp)]),
     "gmx_infer_destroy": (None, [_vp]),

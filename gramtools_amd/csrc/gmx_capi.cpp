@@ -540,6 +540,61 @@ int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t unifo
   return GMX_OK;
 }
 
+// ---- grouped logs as values: what every rank does with the all-gathered logs of an exchange (gmx_multi.hip) -----------
+// `gathered` holds `world` slices of `pad` words, slice r carrying sizes[r] words of rank r's log (either record form,
+// GMX_LOG_PAD words skipped); the result is one counted record per distinct (site, ids), in key order.
+int64_t gmx_grouped_log_merge_gathered(const uint32_t *gathered, const uint64_t *sizes, int world, uint64_t pad, uint32_t *out,
+                                       uint64_t cap_words) {
+  if ((!gathered && pad) || !sizes || world < 0) {
+    gmx_set_error("gmx_grouped_log_merge_gathered: null argument");
+    return GMX_EINVAL;
+  }
+  std::map<std::vector<uint32_t>, uint64_t> counts;
+  std::vector<uint32_t> key;
+  for (int r = 0; r < world; ++r) {
+    if (sizes[r] > pad) {
+      gmx_set_error("gmx_grouped_log_merge_gathered: a rank's log is longer than the padded slice");
+      return GMX_EINVAL;
+    }
+    const uint32_t *w = gathered + (size_t)r * pad;
+    const uint64_t n = sizes[r];
+    for (uint64_t i = 0; i < n;) {
+      if (w[i] == 0xFFFFFFFFu) {  // GMX_LOG_PAD
+        ++i;
+        continue;
+      }
+      if (i + 2 > n) {
+        gmx_set_error("corrupt grouped log");
+        return GMX_EINVAL;
+      }
+      const uint32_t n_ids = w[i + 1] & ~GMX_LOG_COUNTED;
+      const uint64_t head = (w[i + 1] & GMX_LOG_COUNTED) ? 4 : 2;
+      if (i + head + n_ids > n) {
+        gmx_set_error("corrupt grouped log");
+        return GMX_EINVAL;
+      }
+      const uint64_t count = head == 4 ? ((uint64_t)w[i + 2] | ((uint64_t)w[i + 3] << 32)) : 1;
+      key.assign(1, w[i]);
+      key.insert(key.end(), w + i + head, w + i + head + n_ids);
+      counts[key] += count;
+      i += head + n_ids;
+    }
+  }
+  uint64_t at = 0;
+  for (auto const &kv : counts) {
+    const uint64_t words = 4 + (kv.first.size() - 1);
+    if (out && at + words <= cap_words) {
+      out[at] = kv.first[0];
+      out[at + 1] = (uint32_t)(kv.first.size() - 1) | GMX_LOG_COUNTED;
+      out[at + 2] = (uint32_t)kv.second;
+      out[at + 3] = (uint32_t)(kv.second >> 32);
+      for (size_t j = 1; j < kv.first.size(); ++j) out[at + 3 + j] = kv.first[j];
+    }
+    at += words;
+  }
+  return (int64_t)at;
+}
+
 void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate) {
   for (uint64_t i = 0; i < n; ++i) values[i] = saturate ? (values[i] > 65535u ? 65535u : values[i]) : (values[i] & 0xFFFFu);
 }

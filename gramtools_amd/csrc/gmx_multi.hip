@@ -98,54 +98,73 @@ struct Member {
   GmxEngineRaw raw{};
 };
 
-// The grouped log, member by member: [n_words, words...] all-gathered in two steps (sizes, then the padded
-// payloads), every member ends with the sum of all logs in its engine (gmx_engine_log_import(replace)).
+// a device allocation that goes away with its scope (the exchange's temporaries, on every error path too)
+struct DevBuf {
+  void *p = nullptr;
+  int device = 0;
+  ~DevBuf() {
+    if (!p) return;
+    (void)hipSetDevice(device);
+    (void)hipFree(p);
+  }
+  template <class T>
+  T *as() const { return static_cast<T *>(p); }
+};
+
+// The grouped log, member by member: all-gathered in two steps (sizes, then the payloads padded to the largest), and
+// every member ends with the sum of all logs in its engine (gmx_grouped_log_merge_gathered, shared with the tests).
+// Everything that can fail on this rank alone (export, allocation) happens BEFORE the first collective, so a failing rank
+// returns without leaving its peers inside an all-gather.
 int exchange_logs_rccl(std::vector<Member> &ms, int world) {
   Rccl &r = rccl();
   const size_t n = ms.size();
   std::vector<std::vector<uint32_t>> mine(n);
-  std::vector<uint64_t *> d_sizes(n, nullptr);
+  std::vector<DevBuf> d_sizes(n);
   for (size_t i = 0; i < n; ++i) {
     int rc = gmx_engine_log_export(ms[i].e, mine[i]);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(ms[i].raw.device));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sizes[i]), (size_t)(world + 1) * 8));
+    d_sizes[i].device = ms[i].raw.device;
+    HIP_TRY(hipMalloc(&d_sizes[i].p, (size_t)(world + 1) * 8));
     const uint64_t sz = mine[i].size();
-    HIP_TRY(hipMemcpy(d_sizes[i] + world, &sz, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_sizes[i].as<uint64_t>() + world, &sz, 8, hipMemcpyHostToDevice));
   }
   NCCL_TRY(r.GroupStart());
-  for (size_t i = 0; i < n; ++i) NCCL_TRY(r.AllGather(d_sizes[i] + world, d_sizes[i], 1, ncclUint64, ms[i].comm, ms[i].stream));
+  for (size_t i = 0; i < n; ++i)
+    NCCL_TRY(r.AllGather(d_sizes[i].as<uint64_t>() + world, d_sizes[i].as<uint64_t>(), 1, ncclUint64, ms[i].comm, ms[i].stream));
   NCCL_TRY(r.GroupEnd());
   std::vector<uint64_t> sizes(world);
   uint64_t pad = 0;
   for (size_t i = 0; i < n; ++i) {
     HIP_TRY(hipSetDevice(ms[i].raw.device));
     HIP_TRY(hipStreamSynchronize(ms[i].stream));
-    HIP_TRY(hipMemcpy(sizes.data(), d_sizes[i], (size_t)world * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_sizes[i]));
+    HIP_TRY(hipMemcpy(sizes.data(), d_sizes[i].as<uint64_t>(), (size_t)world * 8, hipMemcpyDeviceToHost));
   }
   for (uint64_t s : sizes) pad = std::max(pad, s);
-  if (pad == 0) return GMX_OK;
-  std::vector<uint32_t *> d_buf(n, nullptr);
+  if (pad == 0) return GMX_OK;  // (every rank sees the same sizes: all of them return here or none)
+  std::vector<DevBuf> d_buf(n);
   for (size_t i = 0; i < n; ++i) {
     HIP_TRY(hipSetDevice(ms[i].raw.device));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_buf[i]), (size_t)(world + 1) * pad * 4));
-    if (!mine[i].empty()) HIP_TRY(hipMemcpy(d_buf[i] + (size_t)world * pad, mine[i].data(), mine[i].size() * 4, hipMemcpyHostToDevice));
+    d_buf[i].device = ms[i].raw.device;
+    HIP_TRY(hipMalloc(&d_buf[i].p, (size_t)(world + 1) * pad * 4));
+    if (!mine[i].empty())
+      HIP_TRY(hipMemcpy(d_buf[i].as<uint32_t>() + (size_t)world * pad, mine[i].data(), mine[i].size() * 4, hipMemcpyHostToDevice));
   }
   NCCL_TRY(r.GroupStart());
   for (size_t i = 0; i < n; ++i)
-    NCCL_TRY(r.AllGather(d_buf[i] + (size_t)world * pad, d_buf[i], pad, ncclUint32, ms[i].comm, ms[i].stream));
+    NCCL_TRY(r.AllGather(d_buf[i].as<uint32_t>() + (size_t)world * pad, d_buf[i].as<uint32_t>(), pad, ncclUint32, ms[i].comm, ms[i].stream));
   NCCL_TRY(r.GroupEnd());
-  std::vector<uint32_t> all((size_t)world * pad);
+  std::vector<uint32_t> all((size_t)world * pad), merged;
   for (size_t i = 0; i < n; ++i) {
     HIP_TRY(hipSetDevice(ms[i].raw.device));
     HIP_TRY(hipStreamSynchronize(ms[i].stream));
-    HIP_TRY(hipMemcpy(all.data(), d_buf[i], all.size() * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d_buf[i]));
-    for (int rk = 0; rk < world; ++rk) {
-      int rc = gmx_engine_log_import(ms[i].e, all.data() + (size_t)rk * pad, sizes[rk], rk == 0);
-      if (rc) return rc;
-    }
+    HIP_TRY(hipMemcpy(all.data(), d_buf[i].as<uint32_t>(), all.size() * 4, hipMemcpyDeviceToHost));
+    const int64_t words = gmx_grouped_log_merge_gathered(all.data(), sizes.data(), world, pad, nullptr, 0);
+    if (words < 0) return (int)words;
+    merged.assign((size_t)words, 0);
+    if (words && gmx_grouped_log_merge_gathered(all.data(), sizes.data(), world, pad, merged.data(), (uint64_t)words) < 0) return GMX_EINVAL;
+    int rc = gmx_engine_log_import(ms[i].e, merged.data(), merged.size(), true);
+    if (rc) return rc;
   }
   return GMX_OK;
 }
@@ -180,14 +199,15 @@ int gmx_exchange_peer(std::vector<Member> &ms) {
   }
   const int root = ms[0].raw.device;
   HIP_TRY(hipSetDevice(root));
-  uint32_t *tmp = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), ms[0].raw.n_fused * 4));
+  DevBuf tmp_buf;
+  tmp_buf.device = root;
+  HIP_TRY(hipMalloc(&tmp_buf.p, ms[0].raw.n_fused * 4));
+  uint32_t *tmp = tmp_buf.as<uint32_t>();
   for (size_t i = 1; i < n; ++i) {
     HIP_TRY(hipMemcpyPeer(tmp, root, ms[i].raw.d_fused, ms[i].raw.device, ms[0].raw.n_fused * 4));
     hipLaunchKernelGGL(gmx_add_u32_kernel, dim3(1024), dim3(256), 0, ms[0].stream, ms[0].raw.d_fused, tmp, ms[0].raw.n_fused);
     HIP_TRY(hipStreamSynchronize(ms[0].stream));
   }
-  HIP_TRY(hipFree(tmp));
   for (size_t i = 1; i < n; ++i) HIP_TRY(hipMemcpyPeer(ms[i].raw.d_fused, ms[i].raw.device, ms[0].raw.d_fused, root, ms[0].raw.n_fused * 4));
   for (auto &m : ms) {
     int rc = gmx_coverage_reduce_end(m.e, m.stream);

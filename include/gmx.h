@@ -267,6 +267,12 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
 /* Adds the records of a grouped log (either form) to the engine's totals, after emptying them when `replace`: the
  * receiving end of a log exchange done outside the library (gramtools_amd/distributed.py under torch.distributed). */
 int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace);
+/* The receiving end of the log exchange as a pure function (used by gmx_group_allreduce / gmx_comm_allreduce_coverage after
+ * their payload all-gather; exported for the tests): `gathered` = world slices of `pad` words, slice r holding sizes[r] words
+ * of rank r's log (an empty rank: 0). Returns the length of the merged log (counted records, one per distinct (site, ids))
+ * and copies it when it fits cap_words. */
+int64_t gmx_grouped_log_merge_gathered(const uint32_t *gathered, const uint64_t *sizes, int world, uint64_t pad, uint32_t *out,
+                                       uint64_t cap_words);
 void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate);
 
 /* ---- infer stage: genotyping from the recorded coverage, on the host ------------------------------
