@@ -16,6 +16,7 @@ from .quasimap import (  # noqa: F401
     quasimap_reads,
     Genotyped,
     genotyping_model,
+    genotyping_model_debug,
     master_seeds,
     encode_dna_bases,
     dump_allele_sum,

@@ -111,9 +111,14 @@ SYMBOLS = {
     "gmx_infer_write_json": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p]),
     "gmx_infer_write_vcf": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p]),
     "gmx_infer_write_fasta": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "gmx_infer_debug_text": (_i64, [_vp, C.c_char_p, _u64]),
     "gmx_infer_site_json": (_i64, [_vp, _u32, C.c_char_p, _u64]),
     "gmx_infer_model": (_i64, [_u32, C.POINTER(C.c_char_p), _u32p, _u32p, _i32p, _u8p, _u32, _u32p, _i32p, _u32p, C.c_int,
                                C.c_double, C.c_double, C.c_double, C.c_char_p, _u64]),
+    "gmx_infer_debug": (_i64, [C.c_int, _u32, C.POINTER(C.c_char_p), _u32p, _u32p, _i32p, _u8p, _u32, _u32p, _i32p, _u32p, C.c_int,
+                               C.c_double, C.c_double, C.c_double, _i32p, _u32, C.POINTER(C.c_double), _u32p, _i32p, _u32, C.c_char_p, _u64]),
+    "gmx_infer_segments_debug": (_i64, [C.c_char_p, C.c_char_p, C.c_char_p, _u64]),
+    "gmx_infer_extract_debug": (_i64, [_vp, C.c_int, _u32, _u32p, C.c_char_p, C.c_char_p, C.c_char_p, _u64]),
     "gmx_group_create": (C.c_int, [_vp, C.POINTER(EngineOpts), C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "gmx_group_destroy": (None, [_vp]),
     "gmx_group_size": (C.c_int, [_vp]),

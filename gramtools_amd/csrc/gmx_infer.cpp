@@ -77,6 +77,7 @@ struct Site {  // GenotypedSite + LevelGenotypedSite (interfaces.hpp:49-132, lev
   size_t num_haplogroups = 0;
   std::optional<Alleles> extra;
   double gt_conf = 0., gt_conf_percentile = 0.;
+  std::string debug_info;  // --debug: next best genotype's sequences and coverages (model.cpp:452-465)
   bool is_null() const { return !genotype.empty() && genotype[0] == -1; }
   void make_null() {
     genotype = Gt{-1};
@@ -240,6 +241,28 @@ struct Model {
     return r;
   }
 
+  // get_permutations, :247-260: the `size`-subsets of `idx` in the order std::prev_permutation of a selector gives them
+  static std::vector<Gt> permutations(const Gt &idx, size_t size) {
+    std::vector<Gt> r;
+    const size_t n = idx.size();
+    if (n < size) return r;
+    std::vector<bool> v(n);
+    std::fill(v.begin(), v.begin() + (long)size, true);
+    do {
+      Gt combo;
+      for (size_t i = 0; i < n; ++i)
+        if (v[i]) combo.push_back(idx.at(i));
+      std::sort(combo.begin(), combo.end());
+      r.push_back(combo);
+    } while (std::prev_permutation(v.begin(), v.end()));
+    return r;
+  }
+  // the pieces alone (test hook gmx_infer_debug: the reference's unit tests call them one by one)
+  struct Bare {};
+  Model(const Alleles &in, const GroupedCounts &g, int pl, const LStats &l, Bare) : input(in), gp(g), ploidy(pl), ls(l) {
+    for (auto const &e : gp) total_cov += e.second;
+  }
+
   Model(const Alleles &in, const GroupedCounts &g, int pl, const LStats &l) : input(in), gp(g), ploidy(pl), ls(l) {  // :18-60
     const Allele &ref = input.at(0);
     auto mults = multiplicities(input);
@@ -285,21 +308,13 @@ struct Model {
         if (idx == 0 && ignore_ref()) continue;
         if (singleton.at(a.hapg) != 0) selected.push_back(idx);
       }
-      if (selected.size() >= 2) {
-        const size_t n = selected.size();
-        std::vector<bool> v(n);
-        std::fill(v.begin(), v.begin() + 2, true);
-        do {  // get_permutations, :247-260
-          Gt combo;
-          for (size_t i = 0; i < n; ++i)
-            if (v[i]) combo.push_back(selected.at(i));
-          std::sort(combo.begin(), combo.end());
+      if (selected.size() >= 2)
+        for (auto const &combo : permutations(selected, 2)) {
           Allele a1 = used.at(combo.at(0)), a2 = used.at(combo.at(1));
           auto c = diploid_cov(AlleleIds{a1.hapg, a2.hapg}, mults);
           double incompatible = total_cov - c.first - c.second;
           add_likelihood(Alleles{a1, a2}, incompatible, combo);
-        } while (std::prev_permutation(v.begin(), v.end()));
-      }
+        }
     }
     call(mults);
   }
@@ -374,6 +389,13 @@ struct Model {
     site.haplogroups.clear();
     for (int32_t g : rescaled) site.haplogroups.push_back(chosen_alleles.at(g).hapg);
     site.gt_conf = conf;
+    {  // the --debug line of this site (model.cpp:452-465)
+      std::string d = "\tnext_best_seq: ";
+      for (int32_t g : next_best) d += input.at(g).seq + ",";
+      d += "\tnext_best_cov: ";
+      for (int32_t hg : haplogroups_of(input, next_best)) d += std::to_string(haploid.at(hg)) + ",";
+      site.debug_info = d;
+    }
   }
 };
 
@@ -384,6 +406,7 @@ struct Genotyper {
   std::map<uint32_t, std::map<int32_t, std::vector<uint32_t>>> child_m;  // build_child_map, make_data_structures.cpp:53-68
   LStats ls;
   int ploidy = 1;
+  std::string debug_text;  // site_gtyping_debug_info.txt (runner.cpp:66-75): one line per site, in genotyping order
   std::vector<uint32_t> per_base;  // final uint16 values, logical layout
 
   explicit Genotyper(const gmx::HostIndex &hi) : h(hi) {}
@@ -518,6 +541,7 @@ struct Genotyper {
       Alleles extracted = extract(si);
       Model m(extracted, gped.at(si), ploidy, ls);
       auto site = std::make_shared<Site>(m.site);
+      debug_text += "site index: \t" + std::to_string(si) + (site->is_null() ? std::string("\tnull gt \n") : site->debug_info + "\n");
       site->pos = h.site_ref_pos[si];
       site->end_node = h.sites[si].exit_node;
       recs.at(si) = site;
@@ -657,6 +681,8 @@ struct Tracker {  // SegmentTracker, output_specs/segment_tracker.hpp
     max = segs[0].size - 1;
   }
   const std::string &id_of(size_t pos) {
+    // (the reference asserts: positions are queried in ascending order within the segments' total size)
+    if (pos < min || pos >= global_max) throw std::runtime_error("segment tracker: position queried backwards or beyond the last segment");
     while (pos > max) {
       cur++;
       min = max + 1;
@@ -664,7 +690,10 @@ struct Tracker {  // SegmentTracker, output_specs/segment_tracker.hpp
     }
     return segs.at(cur).id;
   }
-  size_t relative(size_t pos) const { return pos - min; }
+  size_t relative(size_t pos) const {
+    if (pos < min || pos >= global_max) throw std::runtime_error("segment tracker: position outside the current segment's reach");
+    return pos - min;
+  }
   size_t edge() const { return max; }
   size_t global_edge() const { return global_max - 1; }
   void reset() {
@@ -844,6 +873,14 @@ int gmx_infer_run(const gmx_index *ix, const uint32_t *per_base_raw, const uint3
 void gmx_infer_destroy(gmx_infer *inf) { delete inf; }
 
 // One site as the jVCF site object (tests, and the unit the JSON writer is made of). Returns the length needed.
+// site_gtyping_debug_info.txt (`--debug`; genotype/parameters.cpp:98, runner.cpp:66-75): returns the length, copies when it fits.
+int64_t gmx_infer_debug_text(const gmx_infer *inf, char *out, uint64_t cap) {
+  if (!inf || !inf->g) return fail("null genotyper");
+  const std::string &t = inf->g->debug_text;
+  if (out && cap > t.size()) memcpy(out, t.c_str(), t.size() + 1);
+  return (int64_t)t.size();
+}
+
 int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out, uint64_t cap) {
   if (!inf || site_index >= inf->g->recs.size()) return fail("gmx_infer_site_json: bad argument");
   const Site &s = *inf->g->recs[site_index];
@@ -885,6 +922,270 @@ int64_t gmx_infer_model(uint32_t n_alleles, const char *const *seqs, const uint3
     return (int64_t)js.size();
   } catch (std::exception const &ex) {
     return fail(std::string("genotyping model: ") + ex.what(), GMX_EREF);
+  }
+}
+
+// Test hook: the model's pieces one by one, as the reference's unit tests call them (tests/genotype/infer/level_genotyping/
+// test_model.cpp). Inputs as gmx_infer_model, plus `ids` (meaning per op) and, for GMX_DBG_CALL, a likelihood map.
+//   0 INTERNALS   set_haploid_coverages + count_total_coverage + get_haplogroup_multiplicities + assign_coverage_to_empty_alleles
+//                 (+ the number of likelihoods of the full model when it can be run)
+//   1 DIPLOID     compute_diploid_coverage of haplogroups ids[0], ids[1] after set_haploid_coverages(gp, ids[2]); multiplicities = ids[3..]
+//   2 NONCREDIBLE fraction_noncredible_positions of allele ids[0] with credible_cov_t = ids[1]
+//   3 PERMUTATIONS get_permutations(ids[1..], ids[0])
+//   4 RESCALE     rescale_genotypes(ids)
+//   5 CALL        the testing constructor (haploid = singleton = group_counts as per-haplogroup coverages) + CallGenotype with
+//                 the likelihood map (lik[i], genotype lik_gt[lik_off[i] .. lik_off[i + 1])) and multiplicities ids
+int64_t gmx_infer_debug(int op, uint32_t n_alleles, const char *const *seqs, const uint32_t *pb_off, const uint32_t *pb_cov,
+                        const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
+                        const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
+                        double mean_pb_error, const int32_t *ids, uint32_t n_ids, const double *lik, const uint32_t *lik_off,
+                        const int32_t *lik_gt, uint32_t n_lik, char *out, uint64_t cap) {
+  try {
+    Alleles als(n_alleles);
+    for (uint32_t i = 0; i < n_alleles; ++i) {
+      als[i].seq = seqs[i];
+      for (uint32_t j = pb_off[i]; j < pb_off[i + 1]; ++j) als[i].pb.push_back((CovCount)pb_cov[j]);
+      als[i].hapg = haplogroups[i];
+      als[i].callable = callable ? callable[i] != 0 : true;
+    }
+    GroupedCounts gp;
+    if (op != 5)
+      for (uint32_t g = 0; g < n_groups; ++g) gp[AlleleIds(group_ids + group_off[g], group_ids + group_off[g + 1])] = (CovCount)group_counts[g];
+    LStats ls = make_l_stats(mean_cov, var_cov, mean_pb_error);
+    std::string js = "{";
+    auto list = [&](const char *name, auto const &v, auto fmt) {
+      js += std::string("\"") + name + "\":[";
+      bool first = true;
+      for (auto const &x : v) {
+        js += (first ? "" : ",") + fmt(x);
+        first = false;
+      }
+      js += "]";
+    };
+    auto num = [](auto x) { return std::to_string((long long)x); };
+    if (op == 0) {
+      Model m(als, gp, ploidy, ls, Model::Bare{});
+      const size_t n_h = n_ids ? (size_t)ids[0] : Model::multiplicities(als).size();
+      m.set_haploid(n_h);
+      list("HAPLOID", m.haploid, num);
+      js += ",";
+      list("SINGLETON", m.singleton, num);
+      js += ",\"TOTAL_COV\":" + std::to_string(m.total_cov) + ",";
+      std::vector<int> mu;
+      for (bool b : Model::multiplicities(als)) mu.push_back(b ? 1 : 0);
+      list("MULT", mu, num);
+      js += ",\"EMPTY_PB\":[";
+      for (uint32_t i = 0; i < n_alleles; ++i) {
+        std::vector<CovCount> pb = als[i].pb;
+        if (als[i].seq.empty() && (size_t)als[i].hapg < m.haploid.size()) pb = {m.haploid.at(als[i].hapg)};
+        js += i ? ",[" : "[";
+        for (size_t j = 0; j < pb.size(); ++j) js += (j ? "," : "") + std::to_string(pb[j]);
+        js += "]";
+      }
+      js += "],\"N_LIKELIHOODS\":";
+      long long n_l = -1;
+      try {
+        Model full(als, gp, ploidy, ls);
+        n_l = (long long)full.likelihoods.size();
+      } catch (std::exception const &) {
+      }
+      js += std::to_string(n_l);
+    } else if (op == 1) {
+      Model m(als, gp, ploidy, ls, Model::Bare{});
+      std::vector<bool> mults;
+      for (uint32_t i = 3; i < n_ids; ++i) mults.push_back(ids[i] != 0);
+      m.set_haploid((size_t)ids[2]);
+      auto c = m.diploid_cov(AlleleIds{ids[0], ids[1]}, mults);
+      js += "\"C\":[" + jdouble(c.first) + "," + jdouble(c.second) + "]";
+    } else if (op == 2) {
+      LStats l2 = ls;
+      l2.credible_cov_t = (CovCount)ids[1];
+      Model m(als, gp, ploidy, l2, Model::Bare{});
+      js += "\"F\":" + jdouble(m.fraction_noncredible(als.at(ids[0])));
+    } else if (op == 3) {
+      Gt idx(ids + 1, ids + n_ids);
+      js += "\"P\":[";
+      bool first = true;
+      for (auto const &c : Model::permutations(idx, (size_t)ids[0])) {
+        js += first ? "[" : ",[";
+        first = false;
+        for (size_t j = 0; j < c.size(); ++j) js += (j ? "," : "") + std::to_string(c[j]);
+        js += "]";
+      }
+      js += "]";
+    } else if (op == 4) {
+      list("G", Model::rescale(Gt(ids, ids + n_ids)), num);
+    } else if (op == 5) {
+      Model m(als, gp, ploidy, ls, Model::Bare{});
+      m.haploid.assign(group_counts, group_counts + n_groups);
+      m.singleton = m.haploid;
+      m.total_cov = 0;
+      for (auto c : m.haploid) m.total_cov += c;
+      for (uint32_t i = 0; i < n_lik; ++i) m.likelihoods.insert({lik[i], Gt(lik_gt + lik_off[i], lik_gt + lik_off[i + 1])});
+      std::vector<bool> mults;
+      for (uint32_t i = 0; i < n_ids; ++i) mults.push_back(ids[i] != 0);
+      m.site.num_haplogroups = mults.size();
+      m.call(mults);
+      js = site_json(m.site, nullptr, 0);
+      js.pop_back();
+      js += ",\"EXTRA\":[";
+      if (m.site.extra)
+        for (size_t i = 0; i < m.site.extra->size(); ++i) js += (i ? "," : "") + jstr((*m.site.extra)[i].seq);
+      js += "],\"EXTRA_CALLABLE\":[";
+      if (m.site.extra)
+        for (size_t i = 0; i < m.site.extra->size(); ++i) js += std::string(i ? "," : "") + ((*m.site.extra)[i].callable ? "true" : "false");
+      js += "],\"HAS_EXTRA\":" + std::string(m.site.extra ? "true" : "false");
+    } else {
+      return fail("gmx_infer_debug: unknown op");
+    }
+    js += "}";
+    if (out && cap > js.size()) memcpy(out, js.c_str(), js.size() + 1);
+    return (int64_t)js.size();
+  } catch (std::exception const &ex) {
+    return fail(std::string("genotyping model: ") + ex.what(), GMX_EREF);
+  }
+}
+
+// Test hook for the segment tracker (output_specs/segment_tracker.hpp; tests/genotype/infer/test_segment_tracker.cpp): `coords` =
+// the text of prg_coords.tsv, `script` = commands separated by ';': "id N", "rel N", "edge", "global_edge", "reset". JSON list
+// of the answers; a command on which the reference asserts ends the script with GMX_EREF.
+int64_t gmx_infer_segments_debug(const char *coords, const char *script, char *out, uint64_t cap) {
+  try {
+    std::istringstream in(coords ? coords : "");
+    Tracker tr(&in);
+    std::string js = "[", cmds = script ? script : "";
+    bool first = true;
+    for (size_t at = 0; at < cmds.size();) {
+      size_t end = cmds.find(';', at);
+      if (end == std::string::npos) end = cmds.size();
+      const std::string c = cmds.substr(at, end - at);
+      at = end + 1;
+      if (c.empty()) continue;
+      std::string ans;
+      if (c.rfind("id ", 0) == 0)
+        ans = jstr(tr.id_of(std::stoull(c.substr(3))));
+      else if (c.rfind("rel ", 0) == 0)
+        ans = std::to_string(tr.relative(std::stoull(c.substr(4))));
+      else if (c == "edge")
+        ans = std::to_string(tr.edge());
+      else if (c == "global_edge")
+        ans = std::to_string(tr.global_edge());
+      else if (c == "reset") {
+        tr.reset();
+        ans = "null";
+      } else
+        return fail("gmx_infer_segments_debug: unknown command");
+      js += (first ? "" : ",") + ans;
+      first = false;
+    }
+    js += "]";
+    if (out && cap > js.size()) memcpy(out, js.c_str(), js.size() + 1);
+    return (int64_t)js.size();
+  } catch (std::exception const &ex) {
+    return fail(std::string("segment tracker: ") + ex.what(), GMX_EREF);
+  }
+}
+
+// Test hook for the allele extracter (infer/allele_extracter.cpp; known answers of tests/genotype/infer/test_allele_extracter.cpp).
+// Alleles travel as text "SEQ/c,c,c/haplogroup/callable;...": `existing` for op 2; `mocks` = one line per already-genotyped
+// child site: "site_index|g,g (-1 = null)|alleles|extra alleles ('-' = none)". per_base NULL = zero coverage everywhere.
+//   0  AlleleExtracter(site).get_alleles()        1  extract_ref_allele(site)        2  allele_combine(existing, site)
+int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index, const uint32_t *per_base_raw, const char *existing,
+                                const char *mocks, char *out, uint64_t cap) {
+  try {
+    const gmx::HostIndex &h = gmx_index_host(ix);
+    if (site_index >= h.sites.size()) return fail("gmx_infer_extract_debug: no such site");
+    auto parse_alleles = [](const std::string &t) {
+      Alleles r;
+      if (t.empty() || t == "-") return r;
+      size_t at = 0;
+      while (at <= t.size()) {
+        size_t end = t.find(';', at);
+        if (end == std::string::npos) end = t.size();
+        const std::string one = t.substr(at, end - at);
+        std::vector<std::string> f;
+        size_t p = 0;
+        for (;;) {
+          size_t q = one.find('/', p);
+          f.push_back(one.substr(p, q == std::string::npos ? std::string::npos : q - p));
+          if (q == std::string::npos) break;
+          p = q + 1;
+        }
+        if (f.size() != 4) throw std::runtime_error("allele text: SEQ/cov,cov/haplogroup/callable");
+        Allele a;
+        a.seq = f[0];
+        for (size_t i = 0; i < f[1].size();) {
+          size_t j = f[1].find(',', i);
+          if (j == std::string::npos) j = f[1].size();
+          if (j > i) a.pb.push_back((CovCount)std::stoul(f[1].substr(i, j - i)));
+          i = j + 1;
+        }
+        a.hapg = std::stoi(f[2]);
+        a.callable = f[3] != "0";
+        r.push_back(a);
+        at = end + 1;
+      }
+      return r;
+    };
+    Genotyper g(h);
+    g.per_base.assign(std::max<size_t>(h.n_pb_slots, 1), 0);
+    if (per_base_raw)
+      for (size_t i = 0; i < h.n_pb_slots; ++i) g.per_base[i] = std::min<uint32_t>(per_base_raw[i], 65535u);
+    g.recs.assign(h.sites.size(), nullptr);
+    for (size_t si = 0; si < h.sites.size(); ++si) {  // (as the runner leaves a site before it is genotyped)
+      g.recs[si] = std::make_shared<Site>();
+      g.recs[si]->end_node = h.sites[si].exit_node;
+    }
+    const std::string all_mocks = mocks ? mocks : "";
+    for (size_t at = 0; at < all_mocks.size();) {
+      size_t end = all_mocks.find('\n', at);
+      if (end == std::string::npos) end = all_mocks.size();
+      const std::string line = all_mocks.substr(at, end - at);
+      at = end + 1;
+      if (line.empty()) continue;
+      std::vector<std::string> f;
+      size_t p = 0;
+      for (;;) {
+        size_t q = line.find('|', p);
+        f.push_back(line.substr(p, q == std::string::npos ? std::string::npos : q - p));
+        if (q == std::string::npos) break;
+        p = q + 1;
+      }
+      if (f.size() != 4) throw std::runtime_error("mock site text: site|genotype|alleles|extra");
+      const size_t si = std::stoul(f[0]);
+      Site &st = *g.recs.at(si);
+      st.genotype.clear();
+      for (size_t i = 0; i < f[1].size();) {
+        size_t j = f[1].find(',', i);
+        if (j == std::string::npos) j = f[1].size();
+        if (j > i) st.genotype.push_back(std::stoi(f[1].substr(i, j - i)));
+        i = j + 1;
+      }
+      st.alleles = parse_alleles(f[2]);
+      if (f[3] != "-") st.extra = parse_alleles(f[3]);
+    }
+    Alleles result;
+    if (op == 0)
+      result = g.extract(site_index);
+    else if (op == 1)
+      result = Alleles{g.ref_allele(h.sites[site_index].entry_node == 0xFFFFFFFFu ? 0u : h.nodes[h.sites[site_index].entry_node].edge0,
+                                    h.sites[site_index].exit_node)};
+    else if (op == 2)
+      result = g.combine(parse_alleles(existing ? existing : ""), site_index);
+    else
+      return fail("gmx_infer_extract_debug: unknown op");
+    std::string js = "[";
+    for (size_t i = 0; i < result.size(); ++i) {
+      js += i ? ",[" : "[";
+      js += jstr(result[i].seq) + ",[";
+      for (size_t j = 0; j < result[i].pb.size(); ++j) js += (j ? "," : "") + std::to_string(result[i].pb[j]);
+      js += "]," + std::to_string(result[i].hapg) + "," + (result[i].callable ? "true" : "false") + "]";
+    }
+    js += "]";
+    if (out && cap > js.size()) memcpy(out, js.c_str(), js.size() + 1);
+    return (int64_t)js.size();
+  } catch (std::exception const &ex) {
+    return fail(std::string("allele extraction: ") + ex.what(), GMX_EREF);
   }
 }
 

@@ -919,6 +919,8 @@ struct Args {
 
 Args parse_sub(int argc, const char *const *argv, int from) {
   Args a;
+  for (int i = 1; i < from && i < argc; ++i)  // `--debug` is a global switch (main.cpp:58): also accepted ahead of the command
+    if (std::string(argv[i]) == "--debug") a.opt["debug"];
   std::string cur;
   for (int i = from; i < argc; ++i) {
     std::string t = argv[i];
@@ -1398,6 +1400,16 @@ int run_genotype(const Args &a) {
   GMX_CHECK(gmx_infer_run(ix, per_base.data(), grouped.data(), glog.data(), (uint64_t)n_log, rs.mean_cov_depth, rs.variance_cov_depth,
                           rs.mean_pb_error, ploidy == "haploid" ? 1 : 2, &inf));
   const std::string coords = join(gram_dir, "prg_coords.tsv");
+  if (a.has("debug")) {  // site_gtyping_debug_info.txt (parameters.cpp:98; genotype.cpp:76-82)
+    const std::string dbg_path = join(run_dir, "site_gtyping_debug_info.txt");
+    std::cout << "Logging debug genotyping stats to " << dbg_path << std::endl;
+    const int64_t n = gmx_infer_debug_text(inf, nullptr, 0);
+    std::string text((size_t)std::max<int64_t>(n, 0) + 1, '\0');
+    if (n > 0) gmx_infer_debug_text(inf, &text[0], (uint64_t)n + 1);
+    std::ofstream o(dbg_path);
+    o.write(text.data(), std::max<int64_t>(n, 0));
+    close_checked(o, dbg_path);
+  }
   std::cout << "Producing json vcf" << std::endl;
   GMX_CHECK(gmx_infer_write_json(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.json").c_str()));
   std::cout << "Producing personalised reference" << std::endl;

@@ -649,6 +649,44 @@ def genotyping_model(alleles, grouped_counts, ploidy, mean_cov, var_cov, mean_pb
     return _json.loads(buf.value.decode())
 
 
+DBG_INTERNALS, DBG_DIPLOID, DBG_NONCREDIBLE, DBG_PERMUTATIONS, DBG_RESCALE, DBG_CALL = range(6)
+
+
+def genotyping_model_debug(op, alleles=(), grouped_counts=None, ploidy=1, mean_cov=10, var_cov=0, mean_pb_error=0.01, ids=(),
+                           likelihoods=()) -> dict:
+    """The likelihood model's pieces one by one (gmx_infer_debug; ops DBG_*): alleles as in :func:`genotyping_model`;
+    ``grouped_counts`` {(ids...): count} — for DBG_CALL a list of per-haplogroup coverages; ``likelihoods`` [(value, (gt...))]."""
+    import json as _json
+    lib = _lib.load()
+    n = len(alleles)
+    seqs = (C.c_char_p * max(n, 1))(*[a[0].encode() for a in alleles])
+    pb_off = np.concatenate([[0], np.cumsum([len(a[1]) for a in alleles])]).astype(np.uint32)
+    pb = np.asarray([c for a in alleles for c in a[1]] or [0], dtype=np.uint32)
+    hap = np.asarray([a[2] for a in alleles] or [0], dtype=np.int32)
+    call = np.asarray([1 if (len(a) < 4 or a[3]) else 0 for a in alleles] or [1], dtype=np.uint8)
+    if op == DBG_CALL:
+        covs = list(grouped_counts or [])
+        n_groups, g_off, g_ids = len(covs), np.zeros(1, np.uint32), np.zeros(1, np.int32)
+        g_cnt = np.asarray(covs or [0], dtype=np.uint32)
+    else:
+        keys = list(grouped_counts or {})
+        n_groups = len(keys)
+        g_off = np.concatenate([[0], np.cumsum([len(k) for k in keys])]).astype(np.uint32)
+        g_ids = np.asarray([i for k in keys for i in k] or [0], dtype=np.int32)
+        g_cnt = np.asarray([grouped_counts[k] for k in keys] or [0], dtype=np.uint32)
+    idv = np.asarray(list(ids) or [0], dtype=np.int32)
+    lv = np.asarray([l[0] for l in likelihoods] or [0.0], dtype=np.float64)
+    l_off = np.concatenate([[0], np.cumsum([len(l[1]) for l in likelihoods])]).astype(np.uint32)
+    l_gt = np.asarray([g for l in likelihoods for g in l[1]] or [0], dtype=np.int32)
+    args = (op, n, seqs, _p(pb_off, C.c_uint32), _p(pb, C.c_uint32), _p(hap, C.c_int32), _p(call, C.c_uint8), n_groups,
+            _p(g_off, C.c_uint32), _p(g_ids, C.c_int32), _p(g_cnt, C.c_uint32), ploidy, mean_cov, var_cov, mean_pb_error,
+            _p(idv, C.c_int32), len(ids), _p(lv, C.c_double), _p(l_off, C.c_uint32), _p(l_gt, C.c_int32), len(likelihoods))
+    size = check(lib.gmx_infer_debug(*args, None, 0))
+    buf = C.create_string_buffer(size + 1)
+    check(lib.gmx_infer_debug(*args, buf, size + 1))
+    return _json.loads(buf.value.decode())
+
+
 def quasimap_reads(index: Index, read_files, seed: int, device: int = 0, rng_mode: int = RNG_LEMIRE) -> Coverage:
     """quasimap_reads (quasimap.cpp:16-57) over already-parsed reads.
 

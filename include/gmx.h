@@ -291,6 +291,9 @@ void gmx_infer_destroy(gmx_infer *inf);
 int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path);
 int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path);
 int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const char *description, const char *out_path);
+/* The text of site_gtyping_debug_info.txt (`gram genotype --debug`; genotype/parameters.cpp:98, level_genotyping/runner.cpp:66-75):
+ * one line per site in genotyping order. Returns the length, copies when it fits cap. */
+int64_t gmx_infer_debug_text(const gmx_infer *inf, char *out, uint64_t cap);
 /* One site as its jVCF object (POS 1-based in PRG coordinates); returns the length, copies when it fits cap. */
 int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out, uint64_t cap);
 /* The likelihood model on explicit alleles and grouped counts (the known answers of tests/genotype/infer/
@@ -299,6 +302,22 @@ int64_t gmx_infer_model(uint32_t n_alleles, const char *const *seqs, const uint3
                         const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
                         const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
                         double mean_pb_error, char *out, uint64_t cap);
+
+/* Test hook: the pieces of the likelihood model one by one (ops documented at the definition, gmx_infer.cpp), as the
+ * reference's unit tests call them (tests/genotype/infer/level_genotyping/test_model.cpp). JSON out. */
+int64_t gmx_infer_debug(int op, uint32_t n_alleles, const char *const *seqs, const uint32_t *pb_off, const uint32_t *pb_cov,
+                        const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
+                        const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
+                        double mean_pb_error, const int32_t *ids, uint32_t n_ids, const double *lik, const uint32_t *lik_off,
+                        const int32_t *lik_gt, uint32_t n_lik, char *out, uint64_t cap);
+
+/* Test hook: the segment tracker of the writers (contig names and offsets from prg_coords.tsv), driven by a small script (see the
+ * definition), as tests/genotype/infer/test_segment_tracker.cpp drives it. JSON list out. */
+int64_t gmx_infer_segments_debug(const char *coords, const char *script, char *out, uint64_t cap);
+/* Test hook: the allele extracter on a PRG with mock genotyped child sites (text formats at the definition, gmx_infer.cpp), as
+ * tests/genotype/infer/test_allele_extracter.cpp drives it. JSON out: [[sequence, [per-base], haplogroup, callable], ...]. */
+int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index, const uint32_t *per_base_raw, const char *existing,
+                                const char *mocks, char *out, uint64_t cap);
 
 /* ---- several GPUs: reads shard, the index is replicated, one exchange at the end ----------------------
  * Replaces the OpenMP loop over reads with shared coverage structures (quasimap.cpp:90-118; omp atomic / omp critical

@@ -85,6 +85,25 @@ def test_integration_cases_through_the_cli(tmp_path, case, gz):
     assert vcf[0] == "##fileformat=VCFv4.2" and vcf[-1].split("\t")[0] == "gramtools_prg"
     fa = (geno / "personalised_reference.fasta").read_text().splitlines()
     assert fa[0].startswith(">gramtools_prg test personalised reference made by gramtools genotype") and set("".join(fa[1:])) <= set("ACGT")
+    # the CALLS: every site of genotyped.json against the pinned infer routines (tests/test_infer*.py) run on the coverage
+    # of the host emulation of the device logic (== the oracle's, tests/test_hostemu_parity.py) with the same statistics
+    import numpy as np
+    from common import hostemu_map
+    from golden_runner import seq
+    from gramtools_amd import Index, Coverage, QuasimapReadsStats, Genotyped, master_seeds
+    prg = np.asarray(case["prg"]["ints"], dtype=np.uint32)
+    rd = [seq(r) for r in reads]
+    raw, _, rc = hostemu_map(prg, 5, rd, master_seeds(42, [len(rd)]), return_raw=True)
+    assert rc == 0
+    ix = Index(prg, 5, threads=1)
+    cov = Coverage(ix, raw["allele_sum"], raw["per_base"], raw["grouped"], raw["grouped_log"], QuasimapReadsStats(*(int(x) for x in raw["stats"])))
+    want = Genotyped(cov, rs["Quality"]["Error_rate_mean"], "haploid",
+                     depth=dict(mean=rs["Read_depth"]["Mean"], variance=rs["Read_depth"]["Variance"]))
+    for i, site in enumerate(j["Sites"]):
+        w = want.site(i)
+        assert site["GT"] == w["GT"] and site["DP"] == w["DP"] and site["ALS"] == w["ALS"] and site["HAPG"] == w["HAPG"], (i, site, w)
+        assert np.allclose(site["COV"][0], w["COV"][0], rtol=0, atol=1e-9)
+        assert abs(site["GT_CONF"][0] - w["GT_CONF"][0]) <= 1e-9 and site["FT"] == w["FT"]
 
 
 @pytest.mark.gpu
@@ -222,3 +241,23 @@ def test_plain_fastq_read_and_parsed_in_one_pass_with_tiny_blocks(tmp_path, monk
         monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
         lines = _parse_check(tmp_path, "".join(recs), threads)
         assert lines[0].startswith("fast 1200 ") and lines[0][5:] == lines[1][5:], (block, lines)
+
+
+@pytest.mark.gpu
+def test_debug_switch_writes_the_genotyping_debug_file(tmp_path):
+    """`--debug` (a global switch, main.cpp:58; after the command as the front-end passes it, genotype.py:71-93):
+    site_gtyping_debug_info.txt (parameters.cpp:98) with one line per site in genotyping order (runner.cpp:66-75)."""
+    case = _it_cases()[1]
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes(case["prg"]["ints"]))
+    reads = [op for op in case["ops"] if op["op"] == "map_reads"][0]["reads"]
+    _write_fastq(tmp_path / "r.fastq", reads)
+    for where in ("after", "before"):
+        out = tmp_path / f"run_{where}"
+        args = ["genotype", "--gram_dir", str(tmp_path), "--reads", str(tmp_path / "r.fastq"), "--sample_id", "t", "--ploidy", "haploid",
+                "--kmer_size", "5", "--genotype_dir", str(out), "--max_threads", "1", "--seed", "42"]
+        r = run(*(args + ["--debug"] if where == "after" else ["--debug"] + args))
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = (out / "site_gtyping_debug_info.txt").read_text().splitlines()
+        n_sites = len(json.loads((out / "genotype" / "genotyped.json").read_text())["Sites"])
+        assert len(lines) == n_sites and all(l.startswith("site index: \t") for l in lines)
+        assert all(("null gt" in l) or ("next_best_seq: " in l and "next_best_cov: " in l) for l in lines)
