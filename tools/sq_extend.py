@@ -15,12 +15,12 @@ name = None
 for line in open(f"{d}/sq_counters.txt"):
     if not line.startswith(" "):
         name = line.strip()
-    elif name and "gmx_extend_kernel" in name:
+    elif name and "gmx_extend_kernel" in name and ", 2>" not in name:  # (the first pass; ", 2>" is the stragglers' pass)
         k, v = line.split()[:2]
         sq[k] = float(v)
 dur_ns = None
 for row in csv.DictReader(open(f"{d}/bench_kernel_stats.csv")):
-    if "gmx_extend_kernel" in row["Name"]:
+    if "gmx_extend_kernel" in row["Name"] and ", 2>" not in row["Name"]:
         dur_ns = float(row["AverageNs"])
 loop = {}
 sect = None

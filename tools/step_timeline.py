@@ -5,8 +5,9 @@ import glob
 import sys
 
 path = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob("gpurun_out/prof_r1/**/*kernel_trace.csv", recursive=True))[0]
+first = sys.argv[2] if len(sys.argv) > 2 else "pack"   # the batch's first kernel: gmx_pack_kernel (bytes) or gmx_batch_begin_kernel (bit planes)
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-packs = [i for i, r in enumerate(rows) if "pack" in r["Kernel_Name"]]
+packs = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 i0, i1 = packs[-3], packs[-2]
 t0 = int(rows[i0]["Start_Timestamp"])
 print("start_us   end_us   dur_us  queue kernel")
