@@ -387,7 +387,7 @@ int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32
   uint32_t code = 0;
   for (uint32_t j = 0; j < len; ++j) {
     if (kmer[j] < 1 || kmer[j] > 4) return GMX_EINVAL;
-    code = (code << 2) | (uint32_t)(kmer[j] - 1);
+    code |= (uint32_t)(kmer[j] - 1) << (2 * j);  // table index: rightmost base most significant (gmx_types.h)
   }
   auto v = gmx::seed_states_of(h, code, len != h.kmer_size);
   if (v.size() > cap) return -(int64_t)v.size();

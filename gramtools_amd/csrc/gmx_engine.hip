@@ -210,7 +210,8 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   // whenever the stack runs empty, instead of being pushed all at once — a k-mer of a large or dense PRG has tens of
   // states, far more than the stack holds. Path nodes of a seed state whose descendants all died are released.
   uint32_t seed_left;               // states of the k-mer index entry not started yet
-  uint32_t seed_off, seed_pos;      // word offset of the next one in seed_words; read position of the seed states
+  uint64_t seed_off;                // word offset of the next one in seed_words (above 2^32 in a whole-genome index)
+  uint32_t seed_pos;                // read position of the seed states
   uint32_t mark_arena, mark_out;    // arena / emitted-state counts when the current seed state started
   __device__ __forceinline__ bool more_seeds() const { return seed_left != 0 && status == GMX_TASK_MAPPED; }
   __device__ __forceinline__ bool next_seed(const GmxIndexView &ix, bool release, uint32_t &a, uint32_t &b, uint32_t &tvd,
@@ -237,7 +238,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
       seed_left = 0;
       return false;
     }
-    seed_off = (uint32_t)(p - ix.seed_words);
+    seed_off = (uint64_t)(p - ix.seed_words);
     --seed_left;
     a = lo;
     b = hi;
@@ -424,17 +425,17 @@ struct BigCtx {  // the same DFS queue with everything in global memory and runt
   }
 };
 
-// k-mer code of oriented positions [start, start + k): leftmost base most significant
+// seed-table index (gmx_types.h GmxSeed) of oriented positions [start, start + k): RIGHTMOST base most significant
 template <class Reader>
 __device__ __forceinline__ uint32_t kmer_code(Reader &r, uint32_t start, uint32_t k) {
   uint32_t code = 0;
-  for (uint32_t j = 0; j < k; ++j) code = (code << 2) | (r.at(start + j) - 1u);
+  for (uint32_t j = 0; j < k; ++j) code |= (r.at(start + j) - 1u) << (2u * j);
   return code;
 }
 
 // k-mer code of the read's LAST k oriented bases (the seed, quasimap.cpp:235-241) from one 32-base window of the
-// bit planes instead of k single-base extractions: forward reads reverse the bit order (leftmost base most
-// significant), reverse-complement reads take the first k raw bases complemented (their order is already reversed).
+// bit planes instead of k single-base extractions: forward reads take the last k raw bases as they lie (leftmost base
+// least significant), reverse-complement reads the first k raw bases complemented and in reverse bit order.
 __device__ __forceinline__ uint32_t spread_even(uint32_t x) {  // bit i -> bit 2i (i < 16)
   x = (x | (x << 8)) & 0x00FF00FFu;
   x = (x | (x << 4)) & 0x0F0F0F0Fu;
@@ -448,19 +449,18 @@ __device__ __forceinline__ uint32_t last_kmer_code(Reader &r, uint32_t k) {
   const uint32_t mask = (1u << k) - 1u;  // k <= 15
   if (r.rc) {
     r.planes(0, lo, hi);
-    lo = ~lo & mask;
-    hi = ~hi & mask;
+    lo = __builtin_bitreverse32(~lo & mask) >> (32u - k);
+    hi = __builtin_bitreverse32(~hi & mask) >> (32u - k);
   } else {
     r.planes(r.len - k, lo, hi);
-    lo = __builtin_bitreverse32(lo) >> (32u - k);
-    hi = __builtin_bitreverse32(hi) >> (32u - k);
+    lo &= mask;
+    hi &= mask;
   }
   return spread_even(lo) | (spread_even(hi) << 1);
 }
 
 // all_read_kmers_occur_in_index (quasimap.cpp:212-225); `bitmap` is the presence bitmap in global memory or LDS
 __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r) {
-  const uint32_t mask = k >= 16 ? 0xFFFFFFFFu : ((1u << (2 * k)) - 1u);
   uint32_t code = kmer_code(r, 0, k);
   for (uint32_t o = 0;;) {  // four independent bitmap probes in flight per round
     uint32_t present = 1;
@@ -468,7 +468,7 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
     for (int j = 0; j < 4; ++j) {
       present &= bitmap[code >> 5] >> (code & 31);
       if (o + k >= r.len) return present & 1u;
-      code = ((code << 2) | (r.at(o + k) - 1u)) & mask;
+      code = (code >> 2) | ((r.at(o + k) - 1u) << (2u * (k - 1u)));
       ++o;
     }
     if (!(present & 1u)) return false;
@@ -484,18 +484,21 @@ __device__ bool all_kmers_present(const uint32_t *bitmap, uint32_t k, ReadRef &r
 #define GMX_SEEDF_BIG 0x80000000u
 #define GMX_SEEDF_EMPTY 0x40000000u
 #define GMX_SEED_OFF(b) ((b) & 0x3FFFFFFFu)
+__device__ __forceinline__ const uint32_t *gmx_seed_entry(const GmxIndexView &ix, uint32_t b) {
+  return ix.seed_words + ((size_t)GMX_SEED_OFF(b) << ix.seed_shift);
+}
 #define GMX_SEED_SPLIT_MAX ((uint32_t)GMX_STACK_DEPTH - 1u)  // a path-less seed state over 2 .. 4 positions is taken apart in the fast pass (stack of 5)
 // A single path-less state over ONE suffix-array position is stored in text form — a = its PRG position, b =
 // GMX_TEXT_MARK — in the device copies: the search needs no suffix-array look-up to start (one dependent, always-missing
 // fetch per task less: 64 MB of the extend kernel's 390 MB of fabric-side fetch at config[1]).
-__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words, const uint32_t *sa) {
+__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words, uint32_t seed_shift, const uint32_t *sa) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const GmxSeed s = seeds[i];
     if (s.a != GMX_SEED_COMPLEX) {
       if (s.a == s.b) seeds[i] = GmxSeed{sa[s.a], GMX_TEXT_MARK};
       continue;
     }
-    const uint32_t *w = seed_words + s.b;
+    const uint32_t *w = seed_words + ((size_t)s.b << seed_shift);
     const uint32_t ns = *w++;
     bool big = ns > 0xFFFFu;
     for (uint32_t j = 0; j < ns && !big; ++j) {
@@ -514,7 +517,7 @@ __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t
     if (s.a <= s.b) push(s.a, s.b, GMX_NIL, GMX_NIL);
     return;
   }
-  const uint32_t *p = ix.seed_words + GMX_SEED_OFF(s.b);
+  const uint32_t *p = gmx_seed_entry(ix, s.b);
   uint32_t ns = *p++;
   for (uint32_t i = 0; i < ns; ++i) {
     uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
@@ -554,12 +557,12 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
     }
     return;
   }
-  const uint32_t ns = ix.seed_words[GMX_SEED_OFF(s.b)];
+  const uint32_t ns = *gmx_seed_entry(ix, s.b);
   if (ns > 0xFFFFu) {
     ctx.fail(GMX_TASK_OVERFLOW);
     return;
   }
-  ctx.seed_off = GMX_SEED_OFF(s.b) + 1;
+  ctx.seed_off = (uint64_t)(gmx_seed_entry(ix, s.b) - ix.seed_words) + 1;
   ctx.seed_pos = from;
   ctx.seed_left = ns;
   ctx.mark_arena = ctx.arena_n;
@@ -801,7 +804,7 @@ struct SearchOut {
   uint32_t *alive_list;      // tasks that survived the probe phase (states parked in `finals`)
   uint32_t *dead_list;       // tasks without final state, to be classified by the k-mer filter: the probe kernel's (counter [6])
   uint32_t *dead2_list;      // ... and the extend kernel's (counter [12]); one filter pass each
-  uint32_t *seed_cursor;     // per task: word offset into seed_words of the next seed state (when n_final's bits 16.. > 0)
+  uint64_t *seed_cursor;     // per task: word offset into seed_words of the next seed state (when n_final's bits 16.. > 0)
   uint32_t *error;           // [0] = first error status, [1] = its task (persist until gmx_engine_sync reads them)
   uint32_t *counters;        // [0] = n mapped_list, [1] = n overflow_list, [2] = first error status, [3] = error task,
                              // [4] = n cover_overflow_list, [5] = n alive_list, [6] = n dead_list
@@ -1215,7 +1218,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
     if (over && sd.a != GMX_SEED_COMPLEX) {
       width = sd.b - sd.a + 1u;
     } else if (over) {  // multi-state entry: one instance per occurrence of its path-less states, one per path-bearing state
-      const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+      const uint32_t *w = gmx_seed_entry(ix, sd.b);
       const uint32_t ns = *w++;
       bool fits = ns <= GMX_INST_MAX;
       for (uint32_t q = 0; q < ns && fits; ++q) {
@@ -1261,7 +1264,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
           o.inst_sa[first + i] = sd.a + i;
         }
       } else {
-        const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+        const uint32_t *w = gmx_seed_entry(ix, sd.b);
         const uint32_t ns = *w++;
         uint32_t i = 0;
         for (uint32_t q = 0; q < ns; ++q) {
@@ -1333,7 +1336,7 @@ __device__ void gmx_inst_rounds(const GmxIndexView &ix, const BatchView &b, cons
         ctx.push(ix.sa[what], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
       } else {  // state (what >> 8) of a multi-state seed entry; occurrence (what & 255) of it when it is path-less
         const GmxSeed sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
-        const uint32_t *p = ix.seed_words + GMX_SEED_OFF(sd.b) + 1;
+        const uint32_t *p = gmx_seed_entry(ix, sd.b) + 1;
         for (uint32_t st = (what >> 8) & 0x7FFFFFu; st > 0; --st) p += 4 + 2 * p[2] + p[3];
         const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
         p += 4;
@@ -1761,7 +1764,7 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
       if (sd.a != GMX_SEED_COMPLEX) {
         if (sd.a <= sd.b) state(sd.a, sd.b, nullptr, 0, 0);
       } else {
-        const uint32_t *w = ix.seed_words + GMX_SEED_OFF(sd.b);
+        const uint32_t *w = gmx_seed_entry(ix, sd.b);
         const uint32_t ns = *w++;
         for (uint32_t i = 0; i < ns && ok; ++i) {
           state(w[0], w[1], w + 4, w[2], w[3]);
@@ -2842,7 +2845,8 @@ struct gmx_engine {
   uint32_t *d_general_rest = nullptr;
   uint32_t *d_task_lists = nullptr;  // SearchOut::task_lists: d_overflow, d_overflow2, d_alive, d_dead, d_dead2, d_cover_general are its slices
   GmxSeed *d_alive_seed = nullptr;
-  uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr, *d_seed_cursor = nullptr;
+  uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr;
+  uint64_t *d_seed_cursor = nullptr;
   bool seed_cursor = false;  // the index has many multi-state k-mer entries: kernels instantiated with the seed cursor
   GmxFinalState *d_finals = nullptr;
   GmxPathNode *d_arena = nullptr;
@@ -2954,8 +2958,8 @@ struct gmx_engine {
     *p = (T *)q;
     return GMX_OK;
   }
-  template <class T>
-  int upload(const T **dst, const std::vector<T> &src) {
+  template <class T, class A>
+  int upload(const T **dst, const std::vector<T, A> &src) {
     T *q = nullptr;
     int rc = alloc(&q, src.size(), false);
     if (rc) return rc;
@@ -3151,13 +3155,13 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   else v.seeds2 = nullptr;
   rc |= e->upload(&v.seed_words, h.seed_words);
   if (!rc) {  // flags in the multi-state entries of the device copies (GMX_SEEDF_*)
-    if (h.seed_words.size() >= (1u << 30)) {
-      gmx_set_error("the seed tables hold more than 2^30 words of multi-state entries");
+    if (((uint64_t)h.seed_words.size() >> h.seed_shift) >= (1u << 30)) {
+      gmx_set_error("the seed tables hold more than 2^30 units of multi-state entries");
       rc = GMX_ECAP;
     } else {
-      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words, v.sa);
+      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words, v.seed_shift, v.sa);
       if (h.kmer_size2)
-        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words, v.sa);
+        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words, v.seed_shift, v.sa);
       rc |= hipDeviceSynchronize() != hipSuccess;
     }
   }
@@ -3206,14 +3210,14 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
                             (int)(words * 4)) == hipSuccess)
       e->filter_lds_words = (uint32_t)words;
     (void)hipGetLastError();
-    if (e->filter_lds_words) {  // re-index the presence bitmap: interleaved code (first base most significant) -> planar
+    if (e->filter_lds_words) {  // re-index the presence bitmap: table index (base j from the left in bit pair j) -> planar
       const uint32_t k = h.kmer_size;
       std::vector<uint32_t> planar(words, 0);
       for (uint64_t code = 0; code < (1ull << (2 * k)); ++code) {
         if (!((h.kmer_bitmap[code >> 5] >> (code & 31)) & 1u)) continue;
         uint32_t lo = 0, hi = 0;
         for (uint32_t j = 0; j < k; ++j) {
-          const uint32_t base = (uint32_t)(code >> (2 * (k - 1 - j))) & 3u;
+          const uint32_t base = (uint32_t)(code >> (2 * j)) & 3u;
           lo |= (base & 1u) << j;
           hi |= (base >> 1) << j;
         }

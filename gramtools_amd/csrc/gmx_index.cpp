@@ -2,6 +2,7 @@
 #include "gmx_index.h"
 
 #include <algorithm>
+#include <array>
 #include <limits>
 #include <atomic>
 #include <chrono>
@@ -458,123 +459,238 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
 }
 
 // ---------------------------------------------------------------------------
-// Host context for gmx_extend (seed-table enumeration)
+// Seed-table enumeration (the k-mer index, build/kmer_index/build.cpp:18-131)
 // ---------------------------------------------------------------------------
-struct HostCtx {
-  struct St {
-    uint32_t lo, hi, tvd, tvg;
-  };
-  std::vector<St> st;
-  uint32_t n = 0;
-  std::vector<GmxPathNode> arena;
-  uint32_t status = GMX_TASK_MAPPED;
+struct WalkState {
+  uint32_t lo, hi, tvd, tvg;
+};
 
-  uint32_t n_states() const { return n; }
-  void set_n_states(uint32_t v) { n = v; }
-  void get(uint32_t s, uint32_t &lo, uint32_t &hi, uint32_t &tvd, uint32_t &tvg) const {
-    lo = st[s].lo;
-    hi = st[s].hi;
-    tvd = st[s].tvd;
-    tvg = st[s].tvg;
-  }
-  void put(uint32_t s, uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) { st[s] = St{lo, hi, tvd, tvg}; }
+// The context gmx_marker_pass / gmx_run_program (gmx_core.h) append to: a list of states and the path nodes they point at.
+// `base` > 0: a piece of a marker pass run beside others — nodes below `base` are the shared ones (read only), this
+// piece's own are numbered from `base` on and renumbered when the pieces are joined in order.
+struct WalkCtx {
+  std::vector<WalkState> *list;
+  std::vector<GmxPathNode> *arena;
+  const std::vector<GmxPathNode> *shared = nullptr;
+  uint32_t base = 0;
+  uint32_t status = GMX_TASK_MAPPED;
   bool push(uint32_t lo, uint32_t hi, uint32_t tvd, uint32_t tvg) {
-    if (n == st.size()) st.resize(st.size() ? st.size() * 2 : 16);
-    st[n++] = St{lo, hi, tvd, tvg};
+    list->push_back(WalkState{lo, hi, tvd, tvg});
     return true;
   }
   uint32_t arena_new(uint32_t site, int32_t allele, uint32_t next) {
-    arena.push_back(GmxPathNode{site, allele, next});
-    return (uint32_t)arena.size() - 1;
+    arena->push_back(GmxPathNode{site, allele, next});
+    return base + (uint32_t)arena->size() - 1;
   }
-  uint32_t arena_site(uint32_t node) const { return arena[node].site; }
-  uint32_t arena_next(uint32_t node) const { return arena[node].next; }
+  const GmxPathNode &node(uint32_t n) const { return n < base ? (*shared)[n] : (*arena)[n - base]; }
+  uint32_t arena_site(uint32_t n) const { return node(n).site; }
+  uint32_t arena_next(uint32_t n) const { return node(n).next; }
   void fail(uint32_t s) { status = s; }
 };
 
-// What one task of the seed-table enumeration produces beside the simple entries it writes straight into the tables:
-// the words of its multi-state entries (both tables, in enumeration order) and where each such entry's words start.
+// What one task of the enumeration produces beside the entries it writes straight into the tables: the words of its
+// multi-state entries (both tables, in enumeration order) and where each such entry's words start.
 struct SeedTask {
   std::vector<uint32_t> words;
   struct Complex {
-    uint32_t code, table, off;  // table 0: k, 1: k2; off: into `words`
+    uint32_t code, table;  // table 0: k, 1: k2
+    uint64_t off;          // into `words`
   };
   std::vector<Complex> complex;
   uint64_t n_present[2] = {0, 0}, n_states_all[2] = {0, 0}, n_states_large[2] = {0, 0};
   std::vector<std::pair<uint32_t, int32_t>> tmp;
-  std::vector<std::vector<HostCtx::St>> saved;  // per depth: the states before the four extensions (no allocation per node)
+  std::vector<std::array<std::vector<WalkState>, 4>> kids;  // per depth: the four children's states (no allocation per node)
 };
 
-// The tasks of the enumeration differ in the RIGHTMOST bases of their k-mers, the low bits of the table index: written
-// in place, neighbouring entries would belong to different threads (every store a contended cache line). Each task
-// therefore fills a dense table of its own, indexed by the remaining high bits; a parallel pass interleaves them.
 struct SeedTables {
   uint32_t k, k2;  // k2 = 0: no longer table
-  uint32_t shift;  // 2 x bases fixed per task
-  GmxSeed *sub, *sub2;  // this task's tables: 4^(k - split) and 4^(k2 - split) entries
+  GmxSeed *table, *table2;
+  uint32_t *bitmap;  // presence bits of the k table
 };
 
-// the entry of `code` in table `t` from the states of `ctx`
-void seed_emit(const HostCtx &ctx, uint32_t code, uint32_t t, const SeedTables &tb, SeedTask &task) {
-  GmxSeed *table = t ? tb.sub2 : tb.sub;
+// Table index of a k-mer (gmx_types.h GmxSeed): the base at distance d from the k-mer's RIGHT end sits in bit pair
+// K - 1 - d — the rightmost base is the most significant. The enumeration shares suffixes (the reference shares them
+// through a cache of prefix diffs, build.cpp:55-86), so a task — the k-mers with given rightmost bases — owns one
+// contiguous range of each table: it fills and writes its range alone, no line is shared between threads, nothing is
+// copied afterwards. The walk carries `rev`, the index for K = 16; the index for K is rev >> 2 (16 - K).
+inline uint32_t seed_index(uint32_t rev, uint32_t K) { return K >= 16 ? rev : rev >> (2 * (16 - K)); }
+
+// the entry of index `code` in table `t` from the states of `list`
+void seed_emit(const std::vector<WalkState> &list, const std::vector<GmxPathNode> &arena, uint32_t code, uint32_t t,
+               const SeedTables &tb, SeedTask &task) {
+  GmxSeed *table = t ? tb.table2 : tb.table;
   task.n_present[t]++;
-  const bool simple = ctx.n == 1 && ctx.st[0].tvd == GMX_NIL && ctx.st[0].tvg == GMX_NIL;
+  if (t == 0) tb.bitmap[code >> 5] |= 1u << (code & 31);  // (whole words belong to the task)
+  const uint32_t n = (uint32_t)list.size();
+  const bool simple = n == 1 && list[0].tvd == GMX_NIL && list[0].tvg == GMX_NIL;
   if (simple) {
-    table[code >> tb.shift] = GmxSeed{ctx.st[0].lo, ctx.st[0].hi};
+    table[code] = GmxSeed{list[0].lo, list[0].hi};
     task.n_states_all[t] += 1;
     return;
   }
-  table[code >> tb.shift] = GmxSeed{GMX_SEED_COMPLEX, 0};  // (the word offset follows when the tasks' words are joined)
-  task.complex.push_back(SeedTask::Complex{code, t, (uint32_t)task.words.size()});
-  task.n_states_all[t] += ctx.n;
-  if (ctx.n > 4) task.n_states_large[t] += ctx.n;
+  table[code] = GmxSeed{GMX_SEED_COMPLEX, 0};  // (the word offset follows when the tasks' words are joined)
+  task.complex.push_back(SeedTask::Complex{code, t, (uint64_t)task.words.size()});
+  task.n_states_all[t] += n;
+  if (n > 4) task.n_states_large[t] += n;
   std::vector<uint32_t> &w = task.words;
-  w.push_back(ctx.n);
-  for (uint32_t s = 0; s < ctx.n; ++s) {
-    auto const &st = ctx.st[s];
+  w.push_back(n);
+  for (uint32_t s = 0; s < n; ++s) {
+    auto const &st = list[s];
     w.push_back(st.lo);
     w.push_back(st.hi);
     size_t at = w.size();
     w.push_back(0);
     w.push_back(0);
     task.tmp.clear();
-    for (uint32_t x = st.tvd; x != GMX_NIL; x = ctx.arena[x].next) task.tmp.push_back({ctx.arena[x].site, ctx.arena[x].allele});
+    for (uint32_t x = st.tvd; x != GMX_NIL; x = arena[x].next) task.tmp.push_back({arena[x].site, arena[x].allele});
     w[at] = (uint32_t)task.tmp.size();
     for (size_t i = task.tmp.size(); i-- > 0;) {
       w.push_back(task.tmp[i].first);
       w.push_back((uint32_t)task.tmp[i].second);
     }
     task.tmp.clear();
-    for (uint32_t x = st.tvg; x != GMX_NIL; x = ctx.arena[x].next) task.tmp.push_back({ctx.arena[x].site, -1});
+    for (uint32_t x = st.tvg; x != GMX_NIL; x = arena[x].next) task.tmp.push_back({arena[x].site, -1});
     w[at + 1] = (uint32_t)task.tmp.size();
     for (size_t i = task.tmp.size(); i-- > 0;) w.push_back(task.tmp[i].first);
   }
 }
 
-// Depth-first enumeration of all k-mers sharing suffixes (the reference shares them through a cache of
-// prefix diffs, build.cpp:55-86). `depth` bases (the rightmost ones) have been processed in `ctx`. One walk serves
-// both tables: the states after k bases are the k table's entry, the walk goes on to k2.
-void seed_dfs(const GmxIndexView &ix, const SeedTables &tb, uint32_t depth, uint32_t code, HostCtx &ctx, SeedTask &task) {
-  if (ctx.n == 0) return;  // every longer k-mer with this suffix is absent too
-  if (depth == tb.k) seed_emit(ctx, code, 0, tb, task);
-  if (depth == tb.k2 && tb.k2 > tb.k) seed_emit(ctx, code, 1, tb, task);
+// Depth-first enumeration of all k-mers sharing suffixes. `list`: the states after `depth` bases (the rightmost ones).
+// One extension step (process_read_char_search_states, quasimap.cpp:258-268; gmx_extend in gmx_core.h) is the marker
+// pass over the states — which does not depend on the base — followed by the LF step of every state, old and new: the
+// marker pass runs ONCE per node and each state's rank block is read once for the four bases (round 3; four calls of
+// gmx_extend per node before: 2230 CPU seconds at chr20 scale). One walk serves both tables: the states after k bases
+// are the k table's entry, the walk goes on to k2. The children's lists have gmx_extend's order: the survivors among
+// the node's states, then those among the states the marker pass added.
+void seed_walk(const GmxIndexView &ix, const SeedTables &tb, uint32_t depth, uint32_t rev, std::vector<WalkState> &list,
+               std::vector<GmxPathNode> &arena, SeedTask &task) {
+  if (list.empty()) return;  // every longer k-mer with this suffix is absent too
+  if (depth == tb.k) seed_emit(list, arena, seed_index(rev, tb.k), 0, tb, task);
+  if (depth == tb.k2 && tb.k2 > tb.k) seed_emit(list, arena, seed_index(rev, tb.k2), 1, tb, task);
   if (depth >= (tb.k2 > tb.k ? tb.k2 : tb.k)) return;
-  // snapshot
-  std::vector<HostCtx::St> &saved = task.saved[depth];
-  saved.assign(ctx.st.begin(), ctx.st.begin() + ctx.n);
-  const uint32_t saved_n = ctx.n;
-  const size_t saved_arena = ctx.arena.size();
-  for (uint32_t b = 1; b <= 4; ++b) {
-    if (b > 1) {
-      if (ctx.st.size() < saved_n) ctx.st.resize(saved_n);
-      std::copy(saved.begin(), saved.end(), ctx.st.begin());
-      ctx.n = saved_n;
-      ctx.arena.resize(saved_arena);
+  const size_t n0 = list.size(), arena0 = arena.size();
+  if (depth > 0) {  // (the first base of a k-mer: no marker pass, build.cpp:23-27)
+    WalkCtx ctx{&list, &arena};
+    for (size_t s = 0; s < n0; ++s) {
+      const WalkState st = list[s];
+      const GmxRankBlock b = ix.blocks[st.lo >> GMX_BLK_SHIFT];
+      gmx_marker_pass(ix, st.lo, st.hi, st.tvd, st.tvg, b, ctx);
     }
-    gmx_extend(ix, b, ctx, depth == 0);
     if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
-    seed_dfs(ix, tb, depth + 1, code | ((b - 1) << (2 * depth)), ctx, task);
   }
+  auto &kids = task.kids[depth];
+  for (auto &kd : kids) kd.clear();
+  for (size_t s = 0; s < list.size(); ++s) {
+    const WalkState st = list[s];
+    const GmxRankBlock b = ix.blocks[st.lo >> GMX_BLK_SHIFT];
+    for (uint32_t c = 1; c <= 4; ++c) {
+      uint32_t lo = st.lo, hi = st.hi;
+      if (gmx_lf(ix, c, lo, hi, b)) kids[c - 1].push_back(WalkState{lo, hi, st.tvd, st.tvg});
+    }
+  }
+  list.resize(n0);
+  for (uint32_t c = 1; c <= 4; ++c) seed_walk(ix, tb, depth + 1, rev | ((c - 1) << (2 * (15 - depth))), kids[c - 1], arena, task);
+  arena.resize(arena0);
+}
+
+// One step of the walk for a node near the root, on all threads: the states after a few bases are millions (every marker
+// of a quarter of the BWT after the second base), one thread per node leaves most of the host idle for seconds. The
+// states are cut into units — runs of states, pieces of a wide interval — whose outputs are joined in order.
+struct WalkNode {
+  std::vector<WalkState> list;
+  std::vector<GmxPathNode> arena;
+};
+
+void seed_step_parallel(const GmxIndexView &ix, const WalkNode &parent, bool marker_pass, WalkNode kids[4], unsigned threads) {
+  std::vector<WalkState> list = parent.list;
+  std::vector<GmxPathNode> arena = parent.arena;
+  if (marker_pass) {
+    struct Unit {
+      size_t s0, s1;    // states [s0, s1) ...
+      uint32_t lo, hi;  // ... or (part) this part of state s0's interval
+      bool part;
+    };
+    std::vector<Unit> units;
+    const uint32_t wide = 1u << 16;
+    for (size_t s = 0; s < list.size();) {
+      if (list[s].hi - list[s].lo >= wide) {
+        for (uint64_t a = list[s].lo; a <= list[s].hi; a += wide)
+          units.push_back(Unit{s, s + 1, (uint32_t)a, (uint32_t)std::min<uint64_t>(list[s].hi, a + wide - 1), true});
+        ++s;
+        continue;
+      }
+      size_t e = s;
+      while (e < list.size() && e - s < 2048 && list[e].hi - list[e].lo < wide) ++e;
+      units.push_back(Unit{s, e, 0, 0, false});
+      s = e;
+    }
+    struct Out {
+      std::vector<WalkState> list;
+      std::vector<GmxPathNode> arena;
+      bool failed = false;
+    };
+    std::vector<Out> outs(units.size());
+    const uint32_t base = (uint32_t)arena.size();
+    par_for(units.size(), threads, [&](size_t u) {
+      WalkCtx ctx{&outs[u].list, &outs[u].arena, &arena, base};
+      for (size_t s = units[u].s0; s < units[u].s1; ++s) {
+        const WalkState st = list[s];
+        const bool part = units[u].part;
+        const uint32_t lo = part ? units[u].lo : st.lo, hi = part ? units[u].hi : st.hi;
+        const GmxRankBlock b = ix.blocks[lo >> GMX_BLK_SHIFT];
+        gmx_marker_pass(ix, lo, hi, st.tvd, st.tvg, b, ctx);
+      }
+      outs[u].failed = ctx.status != GMX_TASK_MAPPED;
+    });
+    for (auto &o : outs) {
+      if (o.failed) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
+      const uint32_t shift = (uint32_t)arena.size() - base;  // this unit's node `base + i` becomes `arena.size() + i`
+      auto fix = [&](uint32_t x) { return x != GMX_NIL && x >= base ? x + shift : x; };
+      for (auto nd : o.arena) {
+        nd.next = fix(nd.next);
+        arena.push_back(nd);
+      }
+      for (auto st : o.list) list.push_back(WalkState{st.lo, st.hi, fix(st.tvd), fix(st.tvg)});
+    }
+  }
+  // LF step of every state for the four bases, in chunks joined in order
+  const size_t chunk = 4096, n_chunks = (list.size() + chunk - 1) / chunk;
+  std::vector<std::array<std::vector<WalkState>, 4>> parts(n_chunks);
+  par_for(n_chunks, threads, [&](size_t ci) {
+    for (size_t s = ci * chunk; s < std::min(list.size(), (ci + 1) * chunk); ++s) {
+      const WalkState st = list[s];
+      const GmxRankBlock b = ix.blocks[st.lo >> GMX_BLK_SHIFT];
+      for (uint32_t c = 1; c <= 4; ++c) {
+        uint32_t lo = st.lo, hi = st.hi;
+        if (gmx_lf(ix, c, lo, hi, b)) parts[ci][c - 1].push_back(WalkState{lo, hi, st.tvd, st.tvg});
+      }
+    }
+  });
+  // each child keeps the path nodes its states reach, renumbered (most nodes belong to states another base continued)
+  par_for(4, threads, [&](size_t c) {
+    WalkNode &kid = kids[c];
+    kid.list.clear();
+    kid.arena.clear();
+    for (auto &pt : parts) kid.list.insert(kid.list.end(), pt[c].begin(), pt[c].end());
+    std::vector<uint32_t> renamed(arena.size(), GMX_NIL);
+    std::vector<uint32_t> chain;
+    auto keep = [&](uint32_t x) -> uint32_t {
+      if (x == GMX_NIL) return x;
+      chain.clear();
+      uint32_t y = x;
+      for (; y != GMX_NIL && renamed[y] == GMX_NIL; y = arena[y].next) chain.push_back(y);
+      uint32_t below = y == GMX_NIL ? GMX_NIL : renamed[y];
+      for (size_t i = chain.size(); i-- > 0;) {
+        kid.arena.push_back(GmxPathNode{arena[chain[i]].site, arena[chain[i]].allele, below});
+        below = renamed[chain[i]] = (uint32_t)kid.arena.size() - 1;
+      }
+      return renamed[x];
+    };
+    for (auto &st : kid.list) {
+      st.tvd = keep(st.tvd);
+      st.tvg = keep(st.tvg);
+    }
+  });
 }
 
 }  // namespace
@@ -611,6 +727,7 @@ GmxIndexView HostIndex::view() const {
   v.seeds2 = seeds2.data();
   v.kmer_size2 = kmer_size2;
   v.seed_words = seed_words.data();
+  v.seed_shift = seed_shift;
   v.kmer_bitmap = kmer_bitmap.data();
   return v;
 }
@@ -1191,89 +1308,58 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     if (!(k2 > kmer_size && k2 <= 15)) k2 = 0;
     const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
     const uint64_t n_k = 1ull << (2 * kmer_size), n_k2 = k2 ? 1ull << (2 * k2) : 0;
-    // the enumeration is split by the rightmost `split` bases: 64 tasks, 256 on a host with more threads than that
-    const uint32_t split = std::min<uint32_t>(kmer_size, hw > 64 ? 4u : 3u);
+    // the enumeration is split by the rightmost `split` bases — the HIGH bits of the table index (seed_index): 256 tasks,
+    // 1024 on a host with more than 64 threads (finer than the threads: the tasks' sizes differ by a quarter), and a
+    // task's range of the presence bitmap is whole words (>= 64 entries)
+    uint32_t split = hw > 64 ? 5u : 4u;
+    while (split > 0 && split + 3 > kmer_size) --split;
     const uint32_t n_tasks = 1u << (2 * split);
     const uint64_t per_task = n_k >> (2 * split), per_task2 = n_k2 >> (2 * split);
-    // the final tables are sized (value-initialised: one thread, 8.6 GB for k2 = 15) beside the enumeration
-    std::thread sizing([&]() {
-      out.seeds.resize(n_k);
-      out.seeds2.resize(n_k2);
-      out.kmer_bitmap.assign((n_k + 31) / 32, 0);
-    });
-    std::unique_ptr<GmxSeed[]> sub(new GmxSeed[n_k]), sub2(new GmxSeed[std::max<uint64_t>(n_k2, 1)]);  // not initialised: every task fills its part
+    out.seeds.resize(n_k);  // (not touched here: every task fills its range, on its own thread and memory node)
+    out.seeds2.resize(n_k2);
+    out.kmer_bitmap.assign((n_k + 31) / 32, 0);
     GmxIndexView ix = out.view();
     std::vector<SeedTask> tasks(n_tasks);
     std::vector<std::string> errors(n_tasks);
-    std::vector<std::vector<HostCtx>> level;
-    auto parallel = [&](uint32_t n_items, std::function<void(uint32_t)> fn) {
-      std::vector<std::thread> pool;
-      std::atomic<uint32_t> next{0};
-      for (unsigned w = 0; w < std::min<unsigned>(hw, n_items); ++w)
-        pool.emplace_back([&]() {
-          for (;;) {
-            uint32_t t = next.fetch_add(1);
-            if (t >= n_items) break;
-            fn(t);
-          }
-        });
-      for (auto &th : pool) th.join();
-    };
-    std::vector<double> t_fill(n_tasks, 0), t_prefix(n_tasks, 0), t_dfs(n_tasks, 0);
+    auto parallel = [&](uint32_t n_items, std::function<void(uint32_t)> fn) { par_for(n_items, hw, [&](size_t i) { fn((uint32_t)i); }); };
+    std::vector<double> t_fill(n_tasks, 0), t_dfs(n_tasks, 0);
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // The first `split` bases, level by level, every node on all threads (seed_step_parallel): node i of level d has
+    // the bases b_0 .. b_(d-1) from the right end, b_0 in the two highest bits of i.
+    std::vector<WalkNode> level(1);
+    level[0].list.push_back(WalkState{0, (uint32_t)n - 1, GMX_NIL, GMX_NIL});  // get_initial_cache_element, build.cpp:35-46
+    const double t_first0 = now();
+    for (uint32_t d = 0; d < split; ++d) {
+      std::vector<WalkNode> next((size_t)1 << (2 * (d + 1)));
+      for (size_t i = 0; i < level.size(); ++i) {
+        if (level[i].list.empty()) continue;
+        seed_step_parallel(ix, level[i], d > 0, &next[4 * i], hw);
+        level[i] = WalkNode();
+      }
+      level.swap(next);
+    }
+    const double t_first = now() - t_first0;
     auto run_task = [&](uint32_t task) {
       try {
         const double ta = now();
         SeedTask &tk = tasks[task];
-        tk.saved.resize((k2 ? k2 : kmer_size) + 1);
-        const SeedTables tb{kmer_size, k2, 2 * split, sub.get() + task * per_task, sub2.get() + task * per_task2};
-        std::fill(tb.sub, tb.sub + per_task, GmxSeed{1, 0});
-        std::fill(tb.sub2, tb.sub2 + per_task2, GmxSeed{1, 0});
+        tk.kids.resize((k2 ? k2 : kmer_size) + 1);
+        const SeedTables tb{kmer_size, k2, out.seeds.data(), out.seeds2.data(), out.kmer_bitmap.data()};
+        std::fill(tb.table + task * per_task, tb.table + (task + 1) * per_task, GmxSeed{1, 0});
+        if (k2) std::fill(tb.table2 + task * per_task2, tb.table2 + (task + 1) * per_task2, GmxSeed{1, 0});
         const double tc = now();
         t_fill[task] = tc - ta;
-        HostCtx ctx;  // the states after the task's `split` rightmost bases (computed below, level by level), in memory of this thread's own
-        {
-          const HostCtx &src = level[split][task];
-          ctx.st.assign(src.st.begin(), src.st.begin() + src.n);
-          ctx.n = src.n;
-          ctx.arena = src.arena;
-        }
-        if (ctx.n != 0) seed_dfs(ix, tb, split, task, ctx, tk);
+        WalkNode node;
+        node.list.swap(level[task].list);
+        node.arena.swap(level[task].arena);
+        seed_walk(ix, tb, split, split ? task << (2 * (16 - split)) : 0u, node.list, node.arena, tk);
         t_dfs[task] = now() - tc;
       } catch (std::exception const &e) {
         errors[task] = e.what();
       }
     };
-    // The first `split` bases, level by level: the states after the rightmost base (LF only over the whole suffix array,
-    // then a marker pass over a quarter of all markers) are shared by every task with that base — computed per task they
-    // cost more than the rest of the walk (chr20 scale: 1350 of 3770 CPU seconds).
-    level.assign(split + 1, std::vector<HostCtx>());
-    level[0].resize(1);
-    level[0][0].push(0, (uint32_t)n - 1, GMX_NIL, GMX_NIL);  // get_initial_cache_element, build.cpp:35-46
-    {
-      const double t0 = now();
-      for (uint32_t d = 0; d < split; ++d) {
-        level[d + 1].resize((size_t)1 << (2 * (d + 1)));
-        parallel(1u << (2 * (d + 1)), [&](uint32_t child) {
-          try {
-            const uint32_t parent = child & ((1u << (2 * d)) - 1u), b = (child >> (2 * d)) + 1;
-            HostCtx ctx = level[d][parent];
-            if (ctx.n != 0) {
-              gmx_extend(ix, b, ctx, d == 0);
-              if (ctx.status != GMX_TASK_MAPPED) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
-            }
-            level[d + 1][child] = std::move(ctx);
-          } catch (std::exception const &e) {
-            errors[child % n_tasks] = e.what();
-          }
-        });
-        level[d].clear();
-      }
-      t_prefix[0] = now() - t0;
-    }
     parallel(n_tasks, run_task);
     level.clear();
-    sizing.join();
     for (auto &e : errors)
       if (!e.empty()) throw std::runtime_error(e);
     build_trace("  k-mers enumerated");
@@ -1286,42 +1372,49 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         }
         fprintf(stderr, "    %s: sum %.2f s over %u tasks, max %.2f s\n", name, sum, n_tasks, mx);
       };
+      fprintf(stderr, "    first %u bases (every node on all threads): %.2f s\n", split, t_first);
       stat("fill", t_fill);
-      stat("first bases", t_prefix);
       stat("walk", t_dfs);
     }
-    {  // the tasks' tables interleaved into the final ones: entry c comes from task c mod 4^split, place c / 4^split
-      const uint32_t mask = n_tasks - 1, shift = 2 * split;
-      const uint32_t chunks = 1024;
-      parallel(chunks, [&](uint32_t ch) {
-        for (int t = 0; t < 2; ++t) {
-          const uint64_t total = t ? n_k2 : n_k, per = t ? per_task2 : per_task;
-          const GmxSeed *src = t ? sub2.get() : sub.get();
-          GmxSeed *dst = t ? out.seeds2.data() : out.seeds.data();
-          uint64_t c0 = total * ch / chunks / 32 * 32, c1 = ch + 1 == chunks ? total : total * (ch + 1) / chunks / 32 * 32;
-          for (uint64_t c = c0; c < c1; ++c) {
-            const GmxSeed sd = src[(c & mask) * per + (c >> shift)];
-            dst[c] = sd;
-            if (t == 0 && !(sd.a == 1 && sd.b == 0)) out.kmer_bitmap[c >> 5] |= 1u << (c & 31);  // whole words per chunk
-          }
-        }
+    // multi-state entries: the tasks' words one after the other, the entries pointed at theirs. An entry's offset has
+    // 30 bits (the device copies keep two flags beside it): from 2^30 words on — whole-genome PRGs — the entries start on
+    // units of 2^seed_shift words, the smallest shift that fits (GMX_SEED_SHIFT in the environment: this shift, for tests).
+    auto entry_len = [](const SeedTask &tk, size_t i) {
+      return (uint64_t)(i + 1 < tk.complex.size() ? tk.complex[i + 1].off : tk.words.size()) - tk.complex[i].off;
+    };
+    std::vector<uint64_t> task_base(n_tasks + 1, 0);
+    uint32_t shift = 0;
+    if (const char *env = getenv("GMX_SEED_SHIFT")) shift = (uint32_t)std::min(8, std::max(0, atoi(env)));
+    for (;; ++shift) {
+      const uint64_t unit = 1ull << shift;
+      parallel(n_tasks, [&](uint32_t t) {
+        uint64_t sum = 0;
+        const SeedTask &tk = tasks[t];
+        if (shift == 0) sum = tk.words.size();
+        else
+          for (size_t i = 0; i < tk.complex.size(); ++i) sum += (entry_len(tk, i) + unit - 1) >> shift << shift;
+        task_base[t + 1] = sum;
       });
-      sub.reset();
-      sub2.reset();
+      for (uint32_t t = 0; t < n_tasks; ++t) task_base[t + 1] += task_base[t];
+      if ((task_base[n_tasks] >> shift) < (1ull << 30)) break;
+      if (shift >= 8) throw std::runtime_error("seed tables: the multi-state entries do not fit 2^30 units of 256 words");
     }
-    build_trace("  tables interleaved");
-    // NB on the code convention: bit pair d (from the least significant end) holds the base at distance d
-    // from the right end of the k-mer, i.e. the leftmost base is most significant.
-    // multi-state entries: the tasks' words one after the other, the entries pointed at theirs
-    uint64_t total_words = 0;
-    for (auto &tk : tasks) total_words += tk.words.size();
-    out.seed_words.reserve(total_words + 1);
+    out.seed_shift = shift;
+    out.seed_words.assign(task_base[n_tasks] + 1, 0);
+    parallel(n_tasks, [&](uint32_t t) {
+      const SeedTask &tk = tasks[t];
+      uint64_t at = task_base[t];
+      for (size_t i = 0; i < tk.complex.size(); ++i) {
+        auto const &c = tk.complex[i];
+        const uint64_t len = entry_len(tk, i);
+        memcpy(out.seed_words.data() + at, tk.words.data() + c.off, len * sizeof(uint32_t));
+        (c.table ? out.seeds2 : out.seeds)[c.code] = GmxSeed{GMX_SEED_COMPLEX, (uint32_t)(at >> shift)};
+        at += shift ? (len + (1ull << shift) - 1) >> shift << shift : len;
+      }
+    });
     out.n_seed_kmers_present = 0;
     uint64_t all[2] = {0, 0}, large[2] = {0, 0};
     for (auto &tk : tasks) {
-      const uint32_t base = (uint32_t)out.seed_words.size();
-      out.seed_words.insert(out.seed_words.end(), tk.words.begin(), tk.words.end());
-      for (auto const &c : tk.complex) (c.table ? out.seeds2 : out.seeds)[c.code] = GmxSeed{GMX_SEED_COMPLEX, base + c.off};
       out.n_seed_kmers_present += tk.n_present[0];
       for (int t = 0; t < 2; ++t) {
         all[t] += tk.n_states_all[t];
@@ -1331,7 +1424,6 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     out.kmer_size2 = k2;
     out.n_seed_states = all[k2 ? 1 : 0];  // of the table the kernels mostly use
     out.n_seed_states_large = large[k2 ? 1 : 0];
-    if (out.seed_words.empty()) out.seed_words.push_back(0);
     build_trace("seed tables");
   }
 }
@@ -1341,7 +1433,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
   GmxSeed s = (longer_table ? ix.seeds2 : ix.seeds).at(code);
   if (s.a == 1 && s.b == 0) return {-1};
   if (s.a != GMX_SEED_COMPLEX) return {1, s.a, s.b, 0, 0};
-  const uint32_t *p = ix.seed_words.data() + s.b;
+  const uint32_t *p = ix.seed_words.data() + ((size_t)s.b << ix.seed_shift);
   uint32_t ns = *p++;
   v.push_back(ns);
   for (uint32_t i = 0; i < ns; ++i) {
@@ -1370,7 +1462,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 8;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 9;                   // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1411,8 +1503,8 @@ struct Writer {
   void pod(const T &v) {
     raw(&v, sizeof(T));
   }
-  template <class T>
-  void vec(const std::vector<T> &v) {
+  template <class T, class A>
+  void vec(const std::vector<T, A> &v) {
     pod<uint64_t>(v.size());
     raw(v.data(), v.size() * sizeof(T));
   }
@@ -1428,8 +1520,8 @@ struct Reader {
   void pod(T &v) {
     raw(&v, sizeof(T));
   }
-  template <class T>
-  void vec(std::vector<T> &v, uint64_t max_elems = (1ull << 36)) {
+  template <class T, class A>
+  void vec(std::vector<T, A> &v, uint64_t max_elems = (1ull << 36)) {
     uint64_t n = 0;
     pod(n);
     if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
@@ -1480,6 +1572,7 @@ void save_index(const HostIndex &h, const std::string &path) {
     w.pod<uint64_t>(fnv1a_u32(h.prg));
     w.pod(h.kmer_size);
     w.pod(h.kmer_size2);
+    w.pod(h.seed_shift);
     w.pod(h.sentinel_pos);
     w.raw(h.C, sizeof(h.C));
     w.pod<uint32_t>(h.is_nested ? 1u : 0u);
@@ -1524,6 +1617,8 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     r.pod(hash);
     r.pod(out.kmer_size);
     r.pod(out.kmer_size2);
+    r.pod(out.seed_shift);
+    if (out.seed_shift > 8) throw std::runtime_error("index cache: corrupt header");
     if (n_prg != prg.size() || hash != fnv1a_u32(prg)) throw std::runtime_error("index cache: built from a different PRG");
     if (out.kmer_size != kmer_size) throw std::runtime_error("index cache: built for a different kmer_size");
     r.pod(out.sentinel_pos);

@@ -7,12 +7,41 @@
 // integer PRG and k, so this engine derives it from `prg` directly.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gmx_types.h"
 
 namespace gmx {
+
+// Allocator of the direct-addressed seed tables (2 GB for k = 14, 8.6 GB for k2 = 15): a resize default-initialises —
+// touches nothing — so that every builder task fills its own range on its own thread and memory node (the first touch
+// of fresh memory is the expensive part on the virtualised hosts this runs on: 279 CPU seconds of the chr20-scale build
+// in round 2, when a second copy of the tables was value-initialised besides). No MADV_HUGEPAGE: with the hosts'
+// `defrag=madvise` setting the faults then compact memory synchronously (measured: 16 s per GB instead of 0.6).
+template <class T>
+struct BigAlloc {
+  typedef T value_type;
+  BigAlloc() = default;
+  template <class U>
+  BigAlloc(const BigAlloc<U> &) {}
+  T *allocate(size_t n) {
+    void *p = malloc(n ? n * sizeof(T) : 1);
+    if (!p) throw std::bad_alloc();
+    return static_cast<T *>(p);
+  }
+  void deallocate(T *p, size_t) { free(p); }
+  template <class U>
+  void construct(U *p) { ::new ((void *)p) U; }
+  template <class U, class A0, class... A>
+  void construct(U *p, A0 &&a0, A &&...a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+  bool operator==(const BigAlloc &) const { return true; }
+  bool operator!=(const BigAlloc &) const { return false; }
+};
+typedef std::vector<GmxSeed, BigAlloc<GmxSeed>> SeedTable;
 
 struct TargetedMarker {
   uint32_t id;
@@ -36,10 +65,11 @@ struct HostIndex {
   std::vector<GmxNode> nodes;  // + 1 closing record
   std::vector<uint32_t> edges;
   std::vector<GmxSite> sites;
-  std::vector<GmxSeed> seeds;
+  SeedTable seeds;              // direct-addressed by the k-mer's table index (gmx_types.h GmxSeed)
   uint32_t kmer_size2 = 0;      // longer seed table (0 = none): the same construction continued to k2 > kmer_size
-  std::vector<GmxSeed> seeds2;  // its 4^k2 entries; multi-state records share seed_words
+  SeedTable seeds2;             // its 4^k2 entries; multi-state records share seed_words
   std::vector<uint32_t> seed_words;
+  uint32_t seed_shift = 0;      // multi-state entries start at (GmxSeed::b << seed_shift); > 0 from 2^30 words on
   std::vector<uint32_t> kmer_bitmap;
   uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
   uint32_t n_acc_slots = 0;                                            // length of the accumulator block

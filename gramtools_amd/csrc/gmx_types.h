@@ -91,11 +91,15 @@ GMX_HD uint32_t gmx_slot_grouped(const GmxSite &s, uint32_t mask) {
   return s.grouped_off + (mask - 1u) - bits;
 }
 
-// Seed directory entry (k-mer index, build/kmer_index/build.cpp:101-131), direct-addressed by k-mer code.
+// Seed directory entry (k-mer index, build/kmer_index/build.cpp:101-131), direct-addressed by the k-mer's table index:
+// base j from the LEFT in bit pair j, i.e. the rightmost base is the most significant — the builder's tasks share the
+// rightmost bases (suffixes) and so own contiguous ranges of the table (gmx_index.cpp, seed_walk).
 //   a <= b               : exactly one path-less state [a, b]
 //   a == 1, b == 0       : k-mer absent
-//   a == 0xFFFFFFFF      : b = word offset into seed_words: [n_states, {lo, hi, n_traversed, n_traversing,
+//   a == 0xFFFFFFFF      : b << seed_shift = word offset into seed_words: [n_states, {lo, hi, n_traversed, n_traversing,
 //                          (site, allele) x n_traversed (push order), site x n_traversing (push order)}*]
+//                          (seed_shift = 0 unless the entries hold 2^30 words or more: whole-genome PRGs; entries then
+//                          start on units of 2^seed_shift words)
 struct GmxSeed {
   uint32_t a, b;
 };
@@ -168,6 +172,7 @@ struct GmxIndexView {
   uint32_t sentinel_pos;  // BWT index holding the sentinel
   uint32_t kmer_size;
   uint32_t kmer_size2;    // longer seed table (0 = none), used for reads of at least that length
+  uint32_t seed_shift;    // multi-state seed entries start at (offset << seed_shift) in seed_words
   uint32_t C[8];          // C[1..4]: first SA index of each base
   uint32_t n_blocks;
   uint32_t n_hits;

@@ -228,7 +228,7 @@ struct Read {
 
 uint32_t kmer_code(const Read &r, uint32_t start, uint32_t k) {
   uint32_t c = 0;
-  for (uint32_t j = 0; j < k; ++j) c = (c << 2) | (r.at(start + j) - 1u);
+  for (uint32_t j = 0; j < k; ++j) c |= (r.at(start + j) - 1u) << (2 * j);  // table index: rightmost base most significant (gmx_types.h)
   return c;
 }
 
@@ -247,7 +247,7 @@ void load_seed(const GmxIndexView &ix, uint32_t code, EmuCtx &ctx) {
     if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL);
     return;
   }
-  const uint32_t *p = ix.seed_words + s.b;
+  const uint32_t *p = ix.seed_words + ((size_t)s.b << ix.seed_shift);
   uint32_t ns = *p++;
   for (uint32_t i = 0; i < ns; ++i) {
     uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
@@ -280,7 +280,7 @@ void dfs_task(const GmxIndexView &ix, const Read &r, EmuDfsCtx &ctx, uint32_t pr
   if (s.a != GMX_SEED_COMPLEX) {
     if (s.a <= s.b) ctx.push(s.a, s.b, GMX_NIL, GMX_NIL, from, GMX_MODE_STATE);
   } else {
-    const uint32_t *p = ix.seed_words + s.b;
+    const uint32_t *p = ix.seed_words + ((size_t)s.b << ix.seed_shift);
     uint32_t ns = *p++;
     for (uint32_t i = 0; i < ns; ++i) {
       uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];

@@ -1,0 +1,76 @@
+"""Multi-state k-mer index entries addressed in units of 2^seed_shift words (gmx_types.h GmxSeed; the builder picks the
+shift from 2^30 words on — whole-genome PRGs, BASELINE configs[4] — and GMX_SEED_SHIFT forces it here). The entries
+themselves (build/kmer_index/build.cpp:101-131) and everything mapped from them must not depend on the shift."""
+import numpy as np
+import pytest
+
+from common import oracle_map, canonical_cov, flatten_reads, hostemu_map
+from gramtools_amd import Index, Quasimapper, master_seeds
+from gramtools_amd.synth import nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, mixed_variant_prg, simulate_haplotype_reads
+
+
+def _nested_case(seed):
+    prg = bracket_to_ints(nested_prg(seed + 40, n_top=10, max_depth=3).replace("t", "a"))  # repeats: many multi-state entries
+    reads = simulate_graph_reads(prg, 300, 16, seed)
+    return prg, reads, master_seeds(seed, [len(reads)])
+
+
+@pytest.mark.parametrize("shift", [1, 4])
+def test_entries_are_the_same_states_under_any_unit(monkeypatch, shift):
+    prg, _, _ = _nested_case(1)
+    plain = Index(prg, 4, threads=1)
+    monkeypatch.setenv("GMX_SEED_SHIFT", str(shift))
+    units = Index(prg, 4, threads=1)
+    n_multi = 0
+    import itertools
+    for kmer in itertools.product((1, 2, 3, 4), repeat=4):
+        a, b = plain.seed_states(kmer), units.seed_states(kmer)
+        assert a == b
+        n_multi += a is not None and len(a) > 1
+    assert n_multi > 20
+    assert units.info.index_bytes > plain.info.index_bytes  # the padding
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_host_emulation_maps_the_same_with_units(monkeypatch, seed):
+    prg, reads, seeds = _nested_case(seed)
+    want = oracle_map(prg, 4, reads, seeds)
+    monkeypatch.setenv("GMX_SEED_SHIFT", "3")
+    got, _, rc = hostemu_map(prg, 4, reads, seeds)
+    assert rc == 0 and got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cursor", ["0", "1"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_engine_maps_the_same_with_units(monkeypatch, seed, cursor):
+    prg, reads, seeds = _nested_case(seed)
+    want = oracle_map(prg, 4, reads, seeds)
+    monkeypatch.setenv("GMX_SEED_SHIFT", "4")
+    monkeypatch.setenv("GMX_SEED_CURSOR", cursor)  # entries taken state by state through the 64-bit cursor, or pushed whole
+    qm = Quasimapper(Index(prg, 4))
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+
+
+@pytest.mark.gpu
+def test_engine_flat_prg_with_units_and_a_cached_index(monkeypatch, tmp_path):
+    ref = random_ref(5000, 3)
+    prg, sites = mixed_variant_prg(ref, 120, 4, max_alleles=4)
+    reads = simulate_haplotype_reads(ref, sites, 2000, 60, 150, 5)
+    seeds = master_seeds(42, [len(reads)])
+    want = oracle_map(prg, 7, reads, seeds, threads=8)
+    monkeypatch.setenv("GMX_SEED_SHIFT", "2")
+    built = Index(prg, 7)
+    prg_path, cache = str(tmp_path / "prg"), str(tmp_path / "ix.gmx")
+    np.asarray(prg, dtype="<u4").tofile(prg_path)
+    built.save(cache)
+    monkeypatch.delenv("GMX_SEED_SHIFT")
+    loaded = Index(prg_path, 7, cache=cache)
+    assert loaded.from_cache
+    flat, offs = flatten_reads(reads)
+    for ix in (built, loaded):
+        qm = Quasimapper(ix)
+        qm.map_reads(flat, offs, seeds)
+        assert canonical_cov(qm.coverage()) == want
