@@ -12,6 +12,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include <unordered_map>
@@ -490,7 +491,8 @@ struct WalkCtx {
 
 // What one task of the enumeration produces beside the entries it writes straight into the tables: the words of its
 // multi-state entries (both tables, in enumeration order) and where each such entry's words start.
-struct SeedTask {
+struct alignas(128) SeedTask {  // (own cache lines: neighbouring tasks run at the same time, their counters and vector
+                                //  headers change at every node — shared lines capped the walk at ~32 threads' worth)
   std::vector<uint32_t> words;
   struct Complex {
     uint32_t code, table;  // table 0: k, 1: k2
@@ -520,6 +522,8 @@ void seed_emit(const std::vector<WalkState> &list, const std::vector<GmxPathNode
                const SeedTables &tb, SeedTask &task) {
   GmxSeed *table = t ? tb.table2 : tb.table;
   task.n_present[t]++;
+  static const bool no_emit = getenv("GMX_WALK_NO_EMIT") != nullptr;  // (experiment: the walk without its stores)
+  if (no_emit) return;
   if (t == 0) tb.bitmap[code >> 5] |= 1u << (code & 31);  // (whole words belong to the task)
   const uint32_t n = (uint32_t)list.size();
   const bool simple = n == 1 && list[0].tvd == GMX_NIL && list[0].tvg == GMX_NIL;
@@ -1331,10 +1335,26 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     const double t_first0 = now();
     for (uint32_t d = 0; d < split; ++d) {
       std::vector<WalkNode> next((size_t)1 << (2 * (d + 1)));
-      for (size_t i = 0; i < level.size(); ++i) {
-        if (level[i].list.empty()) continue;
-        seed_step_parallel(ix, level[i], d > 0, &next[4 * i], hw);
-        level[i] = WalkNode();
+      if (level.size() < 64) {  // few nodes, millions of states each: one after the other, each on all threads
+        for (size_t i = 0; i < level.size(); ++i) {
+          if (level[i].list.empty()) continue;
+          seed_step_parallel(ix, level[i], d > 0, &next[4 * i], hw);
+          level[i] = WalkNode();
+        }
+      } else {  // (a thread per node from here on: starting 256 threads three times per node costs more than the node)
+        std::string first_error;
+        std::mutex mu;
+        par_for(level.size(), hw, [&](size_t i) {
+          if (level[i].list.empty()) return;
+          try {
+            seed_step_parallel(ix, level[i], d > 0, &next[4 * i], 1);
+          } catch (std::exception const &e) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (first_error.empty()) first_error = e.what();
+          }
+          level[i] = WalkNode();
+        });
+        if (!first_error.empty()) throw std::runtime_error(first_error);
       }
       level.swap(next);
     }

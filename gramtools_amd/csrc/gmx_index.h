@@ -6,6 +6,8 @@
 // src/build/kmer_index/load.cpp:161-173). All of it is a pure function of the
 // integer PRG and k, so this engine derives it from `prg` directly.
 #pragma once
+#include <sys/mman.h>
+
 #include <cstdint>
 #include <cstdlib>
 #include <new>
@@ -29,7 +31,16 @@ struct BigAlloc {
   template <class U>
   BigAlloc(const BigAlloc<U> &) {}
   T *allocate(size_t n) {
-    void *p = malloc(n ? n * sizeof(T) : 1);
+    size_t bytes = n ? n * sizeof(T) : 1;
+    void *p;
+    const size_t huge = (size_t)2 << 20;
+    if (bytes >= ((size_t)64 << 20) && getenv("GMX_HUGEPAGES")) {
+      bytes = (bytes + huge - 1) / huge * huge;
+      p = aligned_alloc(huge, bytes);
+      if (p) madvise(p, bytes, MADV_HUGEPAGE);
+    } else {
+      p = malloc(bytes);
+    }
     if (!p) throw std::bad_alloc();
     return static_cast<T *>(p);
   }
