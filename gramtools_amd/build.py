@@ -14,7 +14,7 @@ BIN_DIR = os.path.join(HERE, "bin")
 LIB = os.path.join(LIB_DIR, "libgmx.so")
 GRAM = os.path.join(BIN_DIR, "gram")
 
-LIB_SOURCES = ["gmx_engine.hip", "gmx_multi.hip", "gmx_capi.cpp", "gmx_index.cpp", "gmx_infer.cpp"]
+LIB_SOURCES = ["gmx_engine.hip", "gmx_multi.hip", "gmx_seedwalk.hip", "gmx_capi.cpp", "gmx_index.cpp", "gmx_infer.cpp"]
 HEADERS = ["gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_index.h", "gmx_internal.h", "../../include/gmx.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
@@ -27,16 +27,34 @@ def _stale(target, sources):
     return any(os.path.exists(s) and os.path.getmtime(s) > t for s in sources)
 
 
-def build_library(force=False, verbose=False):
-    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB, deps):
-        os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = [HIPCC] + FLAGS + ["-shared", "-o", LIB] + srcs + ["-lpthread", "-ldl", "-lz"]
+def _link(target, extra_flags, tag, force, verbose):
+    """One object per source under lib/obj (rebuilt when the source or a header is newer), then the shared object."""
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    obj_dir = os.path.join(LIB_DIR, "obj" + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    objs, jobs = [], []
+    for name in LIB_SOURCES:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(obj_dir, name + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            cmd = [HIPCC] + FLAGS + extra_flags + ["-c", "-o", obj, src]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            jobs.append((subprocess.Popen(cmd), cmd))
+    for proc, cmd in jobs:  # (the sources compile side by side)
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    if jobs or force or _stale(target, objs):
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", target] + objs + ["-lpthread", "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
-    return LIB
+    return target
+
+
+def build_library(force=False, verbose=False):
+    return _link(LIB, [], "", force, verbose)
 
 
 LIB_ALT = os.path.join(LIB_DIR, "libgmx_alt.so")
@@ -45,15 +63,7 @@ LIB_ALT = os.path.join(LIB_DIR, "libgmx_alt.so")
 def build_library_alt(force=False, verbose=False):
     """Test build with -DGMX_SEARCHOUT_ALT: SearchOut in the member order that made the round-2 compiler emit a wrong
     gmx_probe_kernel. tests/test_searchout_layout.py runs the probe pipeline with both builds."""
-    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    if force or _stale(LIB_ALT, deps):
-        os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = [HIPCC] + FLAGS + ["-DGMX_SEARCHOUT_ALT", "-shared", "-o", LIB_ALT] + srcs + ["-lpthread", "-ldl", "-lz"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-    return LIB_ALT
+    return _link(LIB_ALT, ["-DGMX_SEARCHOUT_ALT"], "_alt", force, verbose)
 
 
 def build_gram(force=False, verbose=False):

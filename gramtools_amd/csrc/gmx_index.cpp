@@ -462,10 +462,6 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
 // ---------------------------------------------------------------------------
 // Seed-table enumeration (the k-mer index, build/kmer_index/build.cpp:18-131)
 // ---------------------------------------------------------------------------
-struct WalkState {
-  uint32_t lo, hi, tvd, tvg;
-};
-
 // The context gmx_marker_pass / gmx_run_program (gmx_core.h) append to: a list of states and the path nodes they point at.
 // `base` > 0: a piece of a marker pass run beside others — nodes below `base` are the shared ones (read only), this
 // piece's own are numbered from `base` on and renumbered when the pieces are joined in order.
@@ -491,15 +487,7 @@ struct WalkCtx {
 
 // What one task of the enumeration produces beside the entries it writes straight into the tables: the words of its
 // multi-state entries (both tables, in enumeration order) and where each such entry's words start.
-struct alignas(128) SeedTask {  // (own cache lines: neighbouring tasks run at the same time, their counters and vector
-                                //  headers change at every node — shared lines capped the walk at ~32 threads' worth)
-  std::vector<uint32_t> words;
-  struct Complex {
-    uint32_t code, table;  // table 0: k, 1: k2
-    uint64_t off;          // into `words`
-  };
-  std::vector<Complex> complex;
-  uint64_t n_present[2] = {0, 0}, n_states_all[2] = {0, 0}, n_states_large[2] = {0, 0};
+struct alignas(128) SeedTask : SeedPart {  // (own cache lines: neighbouring tasks run at the same time)
   std::vector<std::pair<uint32_t, int32_t>> tmp;
   std::vector<std::array<std::vector<WalkState>, 4>> kids;  // per depth: the four children's states (no allocation per node)
 };
@@ -533,7 +521,7 @@ void seed_emit(const std::vector<WalkState> &list, const std::vector<GmxPathNode
     return;
   }
   table[code] = GmxSeed{GMX_SEED_COMPLEX, 0};  // (the word offset follows when the tasks' words are joined)
-  task.complex.push_back(SeedTask::Complex{code, t, (uint64_t)task.words.size()});
+  task.complex.push_back(SeedEntryRef{code, t, (uint64_t)task.words.size()});
   task.n_states_all[t] += n;
   if (n > 4) task.n_states_large[t] += n;
   std::vector<uint32_t> &w = task.words;
@@ -600,11 +588,6 @@ void seed_walk(const GmxIndexView &ix, const SeedTables &tb, uint32_t depth, uin
 // One step of the walk for a node near the root, on all threads: the states after a few bases are millions (every marker
 // of a quarter of the BWT after the second base), one thread per node leaves most of the host idle for seconds. The
 // states are cut into units — runs of states, pieces of a wide interval — whose outputs are joined in order.
-struct WalkNode {
-  std::vector<WalkState> list;
-  std::vector<GmxPathNode> arena;
-};
-
 void seed_step_parallel(const GmxIndexView &ix, const WalkNode &parent, bool marker_pass, WalkNode kids[4], unsigned threads) {
   std::vector<WalkState> list = parent.list;
   std::vector<GmxPathNode> arena = parent.arena;
@@ -698,6 +681,8 @@ void seed_step_parallel(const GmxIndexView &ix, const WalkNode &parent, bool mar
 }
 
 }  // namespace
+
+DeviceSeedWalk g_device_seed_walk = nullptr;
 
 GmxIndexView HostIndex::view() const {
   GmxIndexView v;
@@ -1315,8 +1300,17 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     // the enumeration is split by the rightmost `split` bases — the HIGH bits of the table index (seed_index): 256 tasks,
     // 1024 on a host with more than 64 threads (finer than the threads: the tasks' sizes differ by a quarter), and a
     // task's range of the presence bitmap is whole words (>= 64 entries)
-    uint32_t split = hw > 64 ? 5u : 4u;
+    // GMX_DEVICE_BUILD: 1 = the walk below the first levels runs on the GPU (gmx_seedwalk.hip; an error if there is none),
+    // 0 = never; unset = on the GPU when one is present and the PRG is large enough for that to pay
+    bool on_device = false;
+    {
+      const char *db = getenv("GMX_DEVICE_BUILD");
+      if (db ? atoi(db) != 0 : N >= (1u << 22)) on_device = g_device_seed_walk != nullptr;
+      if (db && atoi(db) != 0 && !on_device) throw std::runtime_error("GMX_DEVICE_BUILD=1: this build has no device walk");
+    }
+    uint32_t split = on_device ? 4u : (hw > 64 ? 5u : 4u);
     while (split > 0 && split + 3 > kmer_size) --split;
+    if (split == 0) on_device = false;
     const uint32_t n_tasks = 1u << (2 * split);
     const uint64_t per_task = n_k >> (2 * split), per_task2 = n_k2 >> (2 * split);
     out.seeds.resize(n_k);  // (not touched here: every task fills its range, on its own thread and memory node)
@@ -1359,6 +1353,27 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       level.swap(next);
     }
     const double t_first = now() - t_first0;
+    std::vector<const SeedPart *> parts;
+    std::vector<SeedPart> device_parts;
+    if (on_device) {
+      const bool forced = getenv("GMX_DEVICE_BUILD") != nullptr;
+      try {
+        on_device = g_device_seed_walk(out, kmer_size, k2, split, level, out.seeds.data(), out.seeds2.data(), out.kmer_bitmap.data(), device_parts);
+      } catch (std::exception const &e) {
+        if (forced) throw;
+        fprintf(stderr, "gmx: the device walk of the index build failed (%s): walking on the host\n", e.what());
+        on_device = false;
+      }
+      if (!on_device && forced) throw std::runtime_error("GMX_DEVICE_BUILD=1: no usable device");
+      if (on_device) {
+        for (auto &pt : device_parts) parts.push_back(&pt);
+        level.clear();
+        build_trace("  k-mers enumerated (device walk)");
+        if (getenv("GMX_BUILD_TRACE")) fprintf(stderr, "    first %u bases on the host (every node on all threads): %.2f s\n", split, t_first);
+      } else {
+        std::fill(out.kmer_bitmap.begin(), out.kmer_bitmap.end(), 0u);
+      }
+    }
     auto run_task = [&](uint32_t task) {
       try {
         const double ta = now();
@@ -1378,12 +1393,15 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         errors[task] = e.what();
       }
     };
-    parallel(n_tasks, run_task);
-    level.clear();
-    for (auto &e : errors)
-      if (!e.empty()) throw std::runtime_error(e);
-    build_trace("  k-mers enumerated");
-    if (getenv("GMX_BUILD_TRACE")) {
+    if (!on_device) {
+      parallel(n_tasks, run_task);
+      level.clear();
+      for (auto &e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+      for (auto &tk : tasks) parts.push_back(&tk);
+      build_trace("  k-mers enumerated");
+    }
+    if (!on_device && getenv("GMX_BUILD_TRACE")) {
       auto stat = [&](const char *name, const std::vector<double> &v) {
         double sum = 0, mx = 0;
         for (double x : v) {
@@ -1399,32 +1417,44 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     // multi-state entries: the tasks' words one after the other, the entries pointed at theirs. An entry's offset has
     // 30 bits (the device copies keep two flags beside it): from 2^30 words on — whole-genome PRGs — the entries start on
     // units of 2^seed_shift words, the smallest shift that fits (GMX_SEED_SHIFT in the environment: this shift, for tests).
-    auto entry_len = [](const SeedTask &tk, size_t i) {
+    auto entry_len = [](const SeedPart &tk, size_t i) {
       return (uint64_t)(i + 1 < tk.complex.size() ? tk.complex[i + 1].off : tk.words.size()) - tk.complex[i].off;
     };
-    std::vector<uint64_t> task_base(n_tasks + 1, 0);
+    struct Slice {
+      const SeedPart *part;
+      size_t c0, c1;  // its entries [c0, c1)
+    };
+    std::vector<Slice> slices;
+    for (const SeedPart *pt : parts)
+      for (size_t c0 = 0; c0 < pt->complex.size(); c0 += (size_t)1 << 16) slices.push_back(Slice{pt, c0, std::min(pt->complex.size(), c0 + ((size_t)1 << 16))});
+    const uint32_t n_slices = (uint32_t)slices.size();
+    std::vector<uint64_t> slice_base(n_slices + 1, 0);
     uint32_t shift = 0;
     if (const char *env = getenv("GMX_SEED_SHIFT")) shift = (uint32_t)std::min(8, std::max(0, atoi(env)));
     for (;; ++shift) {
       const uint64_t unit = 1ull << shift;
-      parallel(n_tasks, [&](uint32_t t) {
+      parallel(n_slices, [&](uint32_t t) {
         uint64_t sum = 0;
-        const SeedTask &tk = tasks[t];
-        if (shift == 0) sum = tk.words.size();
-        else
-          for (size_t i = 0; i < tk.complex.size(); ++i) sum += (entry_len(tk, i) + unit - 1) >> shift << shift;
-        task_base[t + 1] = sum;
+        const Slice &sl = slices[t];
+        if (sl.c0 < sl.c1) {
+          if (shift == 0)
+            sum = (sl.c1 < sl.part->complex.size() ? sl.part->complex[sl.c1].off : sl.part->words.size()) - sl.part->complex[sl.c0].off;
+          else
+            for (size_t i = sl.c0; i < sl.c1; ++i) sum += (entry_len(*sl.part, i) + unit - 1) >> shift << shift;
+        }
+        slice_base[t + 1] = sum;
       });
-      for (uint32_t t = 0; t < n_tasks; ++t) task_base[t + 1] += task_base[t];
-      if ((task_base[n_tasks] >> shift) < (1ull << 30)) break;
+      for (uint32_t t = 0; t < n_slices; ++t) slice_base[t + 1] += slice_base[t];
+      if ((slice_base[n_slices] >> shift) < (1ull << 30)) break;
       if (shift >= 8) throw std::runtime_error("seed tables: the multi-state entries do not fit 2^30 units of 256 words");
     }
     out.seed_shift = shift;
-    out.seed_words.assign(task_base[n_tasks] + 1, 0);
-    parallel(n_tasks, [&](uint32_t t) {
-      const SeedTask &tk = tasks[t];
-      uint64_t at = task_base[t];
-      for (size_t i = 0; i < tk.complex.size(); ++i) {
+    out.seed_words.assign(slice_base[n_slices] + 1, 0);
+    parallel(n_slices, [&](uint32_t t) {
+      const Slice &sl = slices[t];
+      const SeedPart &tk = *sl.part;
+      uint64_t at = slice_base[t];
+      for (size_t i = sl.c0; i < sl.c1; ++i) {
         auto const &c = tk.complex[i];
         const uint64_t len = entry_len(tk, i);
         memcpy(out.seed_words.data() + at, tk.words.data() + c.off, len * sizeof(uint32_t));
@@ -1434,11 +1464,11 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     });
     out.n_seed_kmers_present = 0;
     uint64_t all[2] = {0, 0}, large[2] = {0, 0};
-    for (auto &tk : tasks) {
-      out.n_seed_kmers_present += tk.n_present[0];
+    for (const SeedPart *pt : parts) {
+      out.n_seed_kmers_present += pt->n_present[0];
       for (int t = 0; t < 2; ++t) {
-        all[t] += tk.n_states_all[t];
-        large[t] += tk.n_states_large[t];
+        all[t] += pt->n_states_all[t];
+        large[t] += pt->n_states_large[t];
       }
     }
     out.kmer_size2 = k2;

@@ -123,6 +123,33 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
 // gram_dir/prg reader: little-endian uint32 per symbol (linearised_prg.cpp:8-45).
 std::vector<uint32_t> read_prg_file(const std::string &path);
 
+// ---- seed-table enumeration: what the host walk and the device walk (gmx_seedwalk.hip) share -----------------------
+struct WalkState {  // one SearchState of the k-mer index walk: SA interval + handles of its traversed / traversing paths
+  uint32_t lo, hi, tvd, tvg;
+};
+struct WalkNode {  // the states after some rightmost bases of a k-mer and the path nodes they point at
+  std::vector<WalkState> list;
+  std::vector<GmxPathNode> arena;
+};
+struct SeedEntryRef {  // a multi-state entry: its table index, its table (0: k, 1: k2), where its words start
+  uint32_t code, table;
+  uint64_t off;
+};
+// What a part of the enumeration hands to the join (gmx_index.cpp): the words of its multi-state entries in enumeration
+// order — by the k-mers' right-to-left base order, a k entry before the k2 entries it is a suffix of — and the entries.
+struct SeedPart {
+  std::vector<uint32_t> words;
+  std::vector<SeedEntryRef> complex;
+  uint64_t n_present[2] = {0, 0}, n_states_all[2] = {0, 0}, n_states_large[2] = {0, 0};
+};
+// The walk below the nodes `roots` (all of depth `depth0`; node i has the bases b_0 .. b_(depth0-1) from the k-mer's right
+// end, b_0 in the two highest bits of i) on the device: fills both tables and the presence bitmap (host memory, every
+// entry written) and returns the parts in order. Registered by gmx_seedwalk.hip when it is linked in (libgmx.so); null in
+// host-only builds (tests/hostemu). Throws std::runtime_error; returns false when no device can be used.
+typedef bool (*DeviceSeedWalk)(const HostIndex &ix, uint32_t k, uint32_t k2, uint32_t depth0, std::vector<WalkNode> &roots,
+                               GmxSeed *table, GmxSeed *table2, uint32_t *bitmap, std::vector<SeedPart> &parts);
+extern DeviceSeedWalk g_device_seed_walk;
+
 // Collects the k-mer index states of one k-mer from the seed table (test / debug helper).
 // Output format: [n_states, {lo, hi, n_traversed, (site, allele)*, n_traversing, (site, -1)*}*] or {-1} if absent.
 std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t kmer_code, bool longer_table = false);

@@ -1,0 +1,77 @@
+"""The seed-table walk of the index build on the GPU (gmx_seedwalk.hip) against the host walk (gmx_index.cpp seed_walk),
+which tests/test_index.py and the parity suites pin to the oracle's k-mer index (build/kmer_index/build.cpp:18-131):
+the two builds must give the SAME index file, byte for byte — tables, multi-state entries in the same order, presence
+bitmap — and reads mapped from the device-built index the oracle's coverage."""
+import numpy as np
+import pytest
+
+from common import oracle_map, canonical_cov, flatten_reads
+from gramtools_amd import Index, Quasimapper, master_seeds
+from gramtools_amd.synth import (nested_prg, bracket_to_ints, simulate_graph_reads, random_ref, snp_prg, mixed_variant_prg,
+                                 simulate_haplotype_reads)
+from golden_runner import load_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def _file_of(prg, k, tmp_path, name, monkeypatch, device, **env):
+    monkeypatch.setenv("GMX_DEVICE_BUILD", "1" if device else "0")
+    for key, val in env.items():
+        monkeypatch.setenv(key, str(val))
+    ix = Index(prg, k)
+    path = str(tmp_path / name)
+    ix.save(path)
+    for key in env:
+        monkeypatch.delenv(key)
+    return ix, open(path, "rb").read()
+
+
+def _same(prg, k, tmp_path, monkeypatch, **env):
+    host, a = _file_of(prg, k, tmp_path, "host", monkeypatch, False, **{k_: v for k_, v in env.items() if k_ == "GMX_SEED_SHIFT"})
+    dev, b = _file_of(prg, k, tmp_path, "dev", monkeypatch, True, **env)
+    assert len(a) == len(b)
+    assert a == b
+    return dev
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_nested_prgs_device_walk_equals_host_walk(tmp_path, monkeypatch, seed):
+    prg = bracket_to_ints(nested_prg(seed + 70, n_top=12, max_depth=3).replace("t", "a" if seed % 2 else "t"))
+    _same(prg, 4 + seed % 3, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("case", [c for c in load_cases("graph_and_kmers.json")][:12], ids=lambda c: c["name"])
+def test_golden_prgs_device_walk_equals_host_walk(tmp_path, monkeypatch, case):
+    prg = np.asarray(case["prg"]["ints"], dtype=np.uint32)
+    for k in (4, 5):
+        if prg.size >= 8:
+            _same(prg, k, tmp_path, monkeypatch)
+
+
+@pytest.mark.parametrize("env", [{}, {"GMX_DEVICE_WALK_GROUP": 5000}, {"GMX_SEED_SHIFT": 3}])
+def test_snp_prg_with_a_longer_table_groups_and_units(tmp_path, monkeypatch, env):
+    ref = random_ref(150_000, 4)
+    prg, pos, alts, n_alts = snp_prg(ref, 4000, 2, multi_allelic_frac=0.1)
+    dev = _same(prg, 7, tmp_path, monkeypatch, **env)
+    assert dev.info.kmer_size2 > 7
+
+
+def test_reads_mapped_from_a_device_built_index(tmp_path, monkeypatch):
+    ref = random_ref(6000, 3)
+    prg, sites = mixed_variant_prg(ref, 150, 4, max_alleles=4)
+    reads = simulate_haplotype_reads(ref, sites, 3000, 60, 150, 5)
+    seeds = master_seeds(42, [len(reads)])
+    want = oracle_map(prg, 7, reads, seeds, threads=8)
+    monkeypatch.setenv("GMX_DEVICE_BUILD", "1")
+    qm = Quasimapper(Index(prg, 7))
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    prg = bracket_to_ints(nested_prg(91, n_top=10, max_depth=3).replace("t", "a"))
+    reads = simulate_graph_reads(prg, 400, 16, 3)
+    seeds = master_seeds(3, [len(reads)])
+    want = oracle_map(prg, 5, reads, seeds)
+    qm = Quasimapper(Index(prg, 5))
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
