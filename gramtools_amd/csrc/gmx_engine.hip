@@ -54,7 +54,8 @@
 #define GMX_CNT_LOG_RETRY_RECS 31u  // ... compact records (log_retry_recs: index into cover_recs)
 #define GMX_CNT_LOG_RETRY_HUGE 33u  // ... tasks the last tier has to search again (log_retry_huge)
 #define GMX_CNT_GENERAL_REST 34u    // entries gmx_cover_one_kernel left to the general instances (general_rest_list)
-#define GMX_CNT_ALIVE2 35u          // stragglers of the extend kernel, parked for its second pass (alive2_list)
+#define GMX_CNT_ALIVE2 35u          // stragglers of the extend kernel, parked for its next pass: [35 + pass], pass 0 .. GMX_EXTRA_PASSES - 1
+#define GMX_EXTRA_PASSES 3          // (counters 35, 36, 37; task lists GMX_TL_ALIVE2 ..)
 #define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
 #ifndef GMX_FAST_ARENA
 #define GMX_FAST_ARENA 48     // path arena nodes per task (fast pass): a read through an MSA region of configs[2] needs 25-40
@@ -843,7 +844,6 @@ struct SearchOut {
   uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
   // Stragglers: the extend kernel's wave loop has an iteration budget; a lane with work left then (a read inside an MSA
   // region takes fifty iterations, its 63 neighbours five) parks its pending entries and goes to a second, compacted pass.
-  uint32_t *alive2_list;               // the parked tasks; counter [35]
   GmxParked *park2;                    // per task: up to GMX_STACK_DEPTH pending entries (its final states stay in finals[])
   uint32_t *park2_n;                   // per task: how many
 #ifndef GMX_SEARCHOUT_ALT
@@ -854,7 +854,7 @@ struct SearchOut {
 };
 
 #define GMX_REGIONS 8
-enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_ALIVE2, GMX_TL_N };
+enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_ALIVE2, GMX_TL_N = GMX_TL_ALIVE2 + GMX_EXTRA_PASSES };
 
 // stats[idx] += number of threads of the block with `flag` (one global atomic per block). Every thread of the block
 // must call it. `scratch` is one uint32 of LDS per call site.
@@ -886,8 +886,10 @@ __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task
 // Common epilogue of the probe and extend kernels: publish the task's emitted states and queue the task.
 //   done  : the whole read has been consumed (the emitted states are final, not parked)
 //   parked: the task's pending entries are in SearchOut::park2 (a straggler of the extend kernel): alive whatever n_out says
+//   alive_pass: which of the extend kernel's straggler lists a parked task goes to (second phase)
 __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const SearchOut &o, bool active, uint32_t task, FastCtx &ctx,
-                                            uint32_t status, bool done, bool second_phase, uint32_t read_len, bool parked = false) {
+                                            uint32_t status, bool done, bool second_phase, uint32_t read_len, bool parked = false,
+                                            uint32_t alive_pass = 0) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
@@ -985,7 +987,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
-    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? (second_phase ? GMX_CNT_ALIVE2 : 5u) : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
+    const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? (second_phase ? GMX_CNT_ALIVE2 + alive_pass : 5u) : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
     q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
   }
   __syncthreads();
@@ -999,7 +1001,7 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       o.cover_rec_task[(size_t)cat * o.region_cap + at] = task;
     } else {
       const uint32_t q = cat == Q_OVER ? (second_phase ? GMX_TL_OVERFLOW2 : GMX_TL_OVERFLOW)
-                         : cat == Q_ALIVE ? (second_phase ? GMX_TL_ALIVE2 : GMX_TL_ALIVE)
+                         : cat == Q_ALIVE ? (second_phase ? GMX_TL_ALIVE2 + alive_pass : GMX_TL_ALIVE)
                          : cat == Q_DEAD  ? (second_phase ? GMX_TL_DEAD2 : GMX_TL_DEAD)
                                           : GMX_TL_GENERAL;
       o.task_lists[(size_t)q * o.list_stride + at] = task;
@@ -1389,18 +1391,20 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_extend_inst_kernel(GmxIndexView
 #endif
 #define GMX_EXTEND_ATTR __attribute__((amdgpu_waves_per_eu(GMX_EXTEND_WAVES)))
 // MODE 0: the tasks the probe kernel parked (index without a longer seed table); 1: the tasks gmx_seed_kernel queued, from
-// their seed directory entries; 2: the stragglers of a MODE 0 / 1 launch (SearchOut::alive2_list). `budget` (MODE 0, 1):
-// iterations of the wave loop after which a lane with work left is parked for the MODE 2 launch; 0 = none.
+// their seed directory entries; 2: the stragglers of the launch before (`pass` 0: of the MODE 0 / 1 launch; 1, 2: of the MODE 2
+// launch with pass - 1), compacted again. `budget`: iterations of the wave loop after which a lane with work left is
+// parked for the next launch; 0 = none (the last pass). A wave takes as long as its slowest lane: on nested PRGs a few
+// tasks need hundreds of iterations, and every launch packs what is left into full waves again.
 template <bool CURSOR, int MODE>
 __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse,
-                                                                               uint32_t budget) {
+                                                                               uint32_t budget, uint32_t pass) {
   constexpr bool SEEDED = MODE == 1;
-  uint32_t n_alive = o.counters[(MODE == 2 ? GMX_CNT_ALIVE2 : 5u) * GMX_CNT_STRIDE];
+  uint32_t n_alive = o.counters[(MODE == 2 ? GMX_CNT_ALIVE2 + pass : 5u) * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   const long long t0 = GMX_CLK();
   uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
   bool active = slot < n_alive;
-  uint32_t task = active ? (MODE == 2 ? o.alive2_list : o.alive_list)[slot] : 0;
+  uint32_t task = active ? (MODE == 2 ? o.task_lists + (size_t)(GMX_TL_ALIVE2 + pass) * o.list_stride : o.alive_list)[slot] : 0;
   uint32_t status = GMX_TASK_MAPPED;
   FastCtx ctx;
   ctx.sp = 0;
@@ -1467,9 +1471,9 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
   }
   const long long t1 = GMX_CLK();
   GmxLane ln;
-  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, MODE == 2 ? 0u : budget, ln, fuse != 0);
+  dfs_run_wave<1, CURSOR>(ix, ctx, r, 0, active, budget, ln, fuse != 0);
   bool done = true;
-  if (MODE != 2 && budget && active && ctx.status == GMX_TASK_MAPPED && (ln.have || ctx.sp || ctx.seed_left)) {
+  if (budget && active && ctx.status == GMX_TASK_MAPPED && (ln.have || ctx.sp || ctx.seed_left)) {
     // budget spent with work left: the lane's entry and its stack as they are, for the second pass; what it has emitted
     // stays in finals[] (the first, deferred state is written now). A full stack beside a live entry has no room to be
     // restored: that task goes to the large-capacity pass.
@@ -1497,7 +1501,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
   }
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(ix, o, slot < n_alive, task, ctx, status, done, true, r.len, !done);
+  finish_lane(ix, o, slot < n_alive, task, ctx, status, done, true, r.len, !done, MODE == 2 ? pass + 1u : 0u);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -2898,6 +2902,8 @@ struct gmx_engine {
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
   uint32_t extend_budget = 8;   // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
+  uint32_t extend_passes = 1;   // launches over the stragglers (<= GMX_EXTRA_PASSES); all but the last with a budget of their own
+  uint32_t extend_budget2[GMX_EXTRA_PASSES] = {24, 96, 0};
                                 // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
   GmxParked *d_park2 = nullptr;
   uint32_t *d_park2_n = nullptr;
@@ -3230,6 +3236,22 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   if (getenv("GMX_NO_FUSE")) e->fuse = 0;
   if (const char *eb = getenv("GMX_EXTEND_BUDGET")) e->extend_budget = (uint32_t)std::max(0, atoi(eb));
+  // passes over the stragglers and the iteration budgets of all but the last. ONE pass by default: at configs[2] (nested
+  // MSA regions) three passes — budgets 24 and 96 — take 230 + 528 + 494 us where the single pass takes 901: what is left
+  // after the first budget is a few tasks with hundreds of general iterations each (~5 us per iteration: dependent fetches
+  // of jump programs and path nodes), and packing them into full waves again does not shorten any of them.
+  // GMX_EXTEND_PASSES = "b0,b1": three passes, budgets b0 and b1 (experiments).
+  e->extend_passes = 1u;
+  e->extend_budget2[0] = 24;
+  e->extend_budget2[1] = 96;
+  if (const char *ep = getenv("GMX_EXTEND_PASSES")) {
+    e->extend_passes = 1;
+    for (const char *q = ep; *q && e->extend_passes < GMX_EXTRA_PASSES;) {
+      e->extend_budget2[e->extend_passes - 1] = (uint32_t)std::max(1l, strtol(q, const_cast<char **>(&q), 10));
+      ++e->extend_passes;
+      if (*q == ',') ++q; else break;
+    }
+  }
   if (getenv("GMX_NO_COOP")) e->coop = false;
   // k-mer entries with many states (small k on a large or dense PRG) do not fit the per-lane stack: when they carry
   // more than 10 % of the seed states the kernels take them one state at a time (seed cursor, a few % slower), else
@@ -3470,7 +3492,6 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
   o.general_rest_list = e->d_general_rest;
-  o.alive2_list = e->d_task_lists + (size_t)GMX_TL_ALIVE2 * (e->cap_reads * 2);
   o.park2 = e->d_park2;
   o.park2_n = e->d_park2_n;
   o.log_retry_list = e->d_log_retry[e->log_retry_side];
@@ -3532,20 +3553,21 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   hipEvent_t k0 = e->timing ? ev.a : nullptr, k1 = e->timing ? ev.b : nullptr;
   const uint32_t budget = e->extend_budget;
   if (seeded && e->seed_cursor)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget, 0u);
   else if (seeded)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 1>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget, 0u);
   else if (e->seed_cursor)
-    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<true, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget, 0u);
   else
-    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget);
+    hipExtLaunchKernelGGL((gmx_extend_kernel<false, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget, 0u);
   if (budget) {  // the stragglers, compacted (a block that finds its part of the queue empty returns at once)
-    const dim3 grid2((task_grid.x + 3) / 4);  // (at most a quarter of the tasks are expected here; the rest of a longer queue: below)
-    if (e->seed_cursor)
-      hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, 0u);
-    else
-      hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, 0u);
-    (void)grid2;
+    for (uint32_t pass = 0; pass < e->extend_passes; ++pass) {
+      const uint32_t budget2 = pass + 1 < e->extend_passes ? e->extend_budget2[pass] : 0u;  // (the last pass runs to the end)
+      if (e->seed_cursor)
+        hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass);
+      else
+        hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass);
+    }
   }
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
   // beside filter + coverage of the regular tasks

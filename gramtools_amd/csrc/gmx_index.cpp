@@ -305,7 +305,7 @@ std::vector<uint32_t> read_prg_file(const std::string &path) {
 // ===========================================================================
 namespace {
 
-enum class MType { sequence, site_entry, allele_end, site_end };
+enum class MType : uint8_t { sequence, site_entry, allele_end, site_end };  // (one byte per PRG position: 3.46 GB at whole-genome scale)
 
 struct BuildNode {
   uint32_t site = 0;
@@ -744,8 +744,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   GraphBuild g;
   build_graph(prg, g);
   out.is_nested = !g.parent.empty();
-  out.pos_node = g.pos_node;
-  out.pos_target = g.pos_target;
+  out.pos_node = std::move(g.pos_node);  // (moved, not copied: 12 + 25 GB at whole-genome scale)
+  out.pos_target = std::move(g.pos_target);
   for (auto &e : g.target_map) out.target_map.push_back({e.first, e.second});
 
   // sites: markers must be 5,7,9,... contiguous (siteID_to_index indexing, data_types.hpp:78-81)
@@ -1097,8 +1097,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
           uint32_t prog_off = 0;
           if (p < N && prg[p] <= 4) {
             // left_markers_search, vBWT_jump.cpp:94-117
-            uint32_t m = g.pos_target[p].first;
-            int32_t a = g.pos_target[p].second;
+            uint32_t m = out.pos_target[p].first;
+            int32_t a = out.pos_target[p].second;
             if ((m & 1) == 0 && g.mtype[p - 1] != MType::site_end) m -= 1;  // allele separator: a site exit going backwards
             prog_off = make_program(ck.prog, memo, m, a);
           }
@@ -1237,41 +1237,51 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     // id = its ordinal among the opening markers — and the closing marker's four sub-records say exactly what the
     // in-register resolution does (FUSED into the allele with that base, dead for every other base).
     if (!getenv("GMX_NO_INLINE_SITES")) {
-      uint32_t ordinal = 0;
-      uint64_t n_inline = 0;
-      for (uint32_t q = 0; q < N; ++q) {
-        const uint32_t sym = prg[q];
-        if (sym <= 4 || !(sym & 1u)) continue;
-        const uint32_t my_ordinal = ordinal++;
-        if (sym != 5u + 2u * my_ordinal) continue;
-        uint32_t A = 0, base_of[4] = {0, 0, 0, 0};  // allele whose base is c (index c - 1), + 1
-        bool ok = true;
-        for (uint32_t p2 = q + 1; p2 + 1 < N && prg[p2] <= 4 && prg[p2 + 1] == sym + 1u; p2 += 2) {  // `base marker` pairs
-          if (A >= 4 || base_of[prg[p2] - 1u]) {
-            ok = false;
-            break;
+      const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+      std::atomic<uint64_t> n_inline_all{0};
+      const size_t n_recs = (N + GMX_TEXT_MASK) >> GMX_TEXT_SHIFT, recs_per_piece = 1u << 14;
+      // (by text record: a site that qualifies lies inside ONE record, so the pieces write disjoint records; the ordinal of
+      // an opening marker = the record's count of opening markers before it + those below it in the record)
+      par_for((n_recs + recs_per_piece - 1) / recs_per_piece, hw, [&](size_t piece) {
+        uint64_t n_inline = 0;
+        const size_t q0 = piece * recs_per_piece << GMX_TEXT_SHIFT, q1 = std::min<size_t>(N, (piece + 1) * recs_per_piece << GMX_TEXT_SHIFT);
+        uint32_t ordinal = out.text[q0 >> GMX_TEXT_SHIFT].srank;
+        for (uint32_t q = (uint32_t)q0; q < q1; ++q) {
+          const uint32_t sym = prg[q];
+          if (sym <= 4 || !(sym & 1u)) continue;
+          const uint32_t my_ordinal = ordinal++;
+          if (sym != 5u + 2u * my_ordinal) continue;
+          uint32_t A = 0, base_of[4] = {0, 0, 0, 0};  // allele whose base is c (index c - 1), + 1
+          bool ok = true;
+          for (uint32_t p2 = q + 1; p2 + 1 < N && prg[p2] <= 4 && prg[p2 + 1] == sym + 1u; p2 += 2) {  // `base marker` pairs
+            if (A >= 4 || base_of[prg[p2] - 1u]) {
+              ok = false;
+              break;
+            }
+            base_of[prg[p2] - 1u] = ++A;
           }
-          base_of[prg[p2] - 1u] = ++A;
-        }
-        // all of the site's alleles are among them (the last pair's marker closes the site), at least two
-        if (!ok || A < 2 || out.sites[(sym - 5u) >> 1].n_alleles != A) continue;
-        const uint32_t q_close = q + 2u * A;
-        if ((q_close >> GMX_TEXT_SHIFT) != (q >> GMX_TEXT_SHIFT)) continue;
-        const GmxHit &hit = out.hits[text_rank(q_close)];
-        for (uint32_t c = 1; c <= 4 && ok; ++c) {
-          const GmxHitSub &sub = hit.sub[c - 1];
-          if (base_of[c - 1]) {
-            const uint32_t j = base_of[c - 1] - 1u, x = q + 1u + 2u * j;
-            ok = (sub.head & 3u) == GMX_HIT_FUSED && (sub.head & GMX_HITF_ALIVE) && (sub.head & GMX_HITF_TEXT) && sub.site == sym &&
-                 sub.y == j && sub.x == x && (sub.head >> 4) == x - q;
-          } else {
-            ok = (sub.head & 3u) == GMX_HIT_ENTER && !(sub.head & GMX_HITF_ALIVE);
+          // all of the site's alleles are among them (the last pair's marker closes the site), at least two
+          if (!ok || A < 2 || out.sites[(sym - 5u) >> 1].n_alleles != A) continue;
+          const uint32_t q_close = q + 2u * A;
+          if ((q_close >> GMX_TEXT_SHIFT) != (q >> GMX_TEXT_SHIFT)) continue;
+          const GmxHit &hit = out.hits[text_rank(q_close)];
+          for (uint32_t c = 1; c <= 4 && ok; ++c) {
+            const GmxHitSub &sub = hit.sub[c - 1];
+            if (base_of[c - 1]) {
+              const uint32_t j = base_of[c - 1] - 1u, x = q + 1u + 2u * j;
+              ok = (sub.head & 3u) == GMX_HIT_FUSED && (sub.head & GMX_HITF_ALIVE) && (sub.head & GMX_HITF_TEXT) && sub.site == sym &&
+                   sub.y == j && sub.x == x && (sub.head >> 4) == x - q;
+            } else {
+              ok = (sub.head & 3u) == GMX_HIT_ENTER && !(sub.head & GMX_HITF_ALIVE);
+            }
           }
+          if (!ok) continue;
+          out.text[q_close >> GMX_TEXT_SHIFT].hi |= 1ull << (q_close & GMX_TEXT_MASK);
+          ++n_inline;
         }
-        if (!ok) continue;
-        out.text[q_close >> GMX_TEXT_SHIFT].hi |= 1ull << (q_close & GMX_TEXT_MASK);
-        ++n_inline;
-      }
+        n_inline_all += n_inline;
+      });
+      const uint64_t n_inline = n_inline_all.load();
       build_trace(("inline sites: " + std::to_string(n_inline)).c_str());
     }
   }
@@ -1449,7 +1459,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       if (shift >= 8) throw std::runtime_error("seed tables: the multi-state entries do not fit 2^30 units of 256 words");
     }
     out.seed_shift = shift;
-    out.seed_words.assign(slice_base[n_slices] + 1, 0);
+    out.seed_words.resize(slice_base[n_slices] + 1);
+    out.seed_words[slice_base[n_slices]] = 0;
     parallel(n_slices, [&](uint32_t t) {
       const Slice &sl = slices[t];
       const SeedPart &tk = *sl.part;
@@ -1459,7 +1470,9 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         const uint64_t len = entry_len(tk, i);
         memcpy(out.seed_words.data() + at, tk.words.data() + c.off, len * sizeof(uint32_t));
         (c.table ? out.seeds2 : out.seeds)[c.code] = GmxSeed{GMX_SEED_COMPLEX, (uint32_t)(at >> shift)};
-        at += shift ? (len + (1ull << shift) - 1) >> shift << shift : len;
+        const uint64_t padded = shift ? (len + (1ull << shift) - 1) >> shift << shift : len;
+        for (uint64_t z = len; z < padded; ++z) out.seed_words[at + z] = 0;
+        at += padded;
       }
     });
     out.n_seed_kmers_present = 0;

@@ -8,6 +8,7 @@
 #pragma once
 #include <sys/mman.h>
 
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <new>
@@ -19,11 +20,38 @@
 
 namespace gmx {
 
-// Allocator of the direct-addressed seed tables (2 GB for k = 14, 8.6 GB for k2 = 15): a resize default-initialises —
-// touches nothing — so that every builder task fills its own range on its own thread and memory node (the first touch
-// of fresh memory is the expensive part on the virtualised hosts this runs on: 279 CPU seconds of the chr20-scale build
-// in round 2, when a second copy of the tables was value-initialised besides). No MADV_HUGEPAGE: with the hosts'
-// `defrag=madvise` setting the faults then compact memory synchronously (measured: 16 s per GB instead of 0.6).
+// Are transparent huge pages worth asking for on this host? With `defrag=madvise` a fault in a MADV_HUGEPAGE region may
+// compact memory synchronously: 16 s per GB on one of the hosts this was developed on, against 0.6 s per GB with 4 KB
+// pages — while on the MI355X boxes 2 GB are touched in 7 ms instead of 120. So it is measured once, on 16 MB each way
+// (GMX_HUGEPAGES=0/1 in the environment overrides).
+inline bool gmx_huge_pages_pay() {
+  static const bool ok = [] {
+    if (const char *e = getenv("GMX_HUGEPAGES")) return atoi(e) != 0;
+    const size_t bytes = (size_t)16 << 20, huge = (size_t)2 << 20;
+    auto touch = [&](bool advise) -> double {
+      void *p = aligned_alloc(huge, bytes);
+      if (!p) return 1e9;
+      if (advise && madvise(p, bytes, MADV_HUGEPAGE) != 0) {
+        free(p);
+        return 1e9;
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      for (size_t i = 0; i < bytes; i += 4096) static_cast<volatile char *>(p)[i] = 1;
+      const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      free(p);
+      return dt;
+    };
+    const double plain = touch(false), advised = touch(true);
+    return advised < plain;
+  }();
+  return ok;
+}
+
+// Allocator of the direct-addressed seed tables (2 GB for k = 14, 8.6 GB for k2 = 15) and of the multi-state entries'
+// words: a resize default-initialises — touches nothing — so that every builder task (or the copy from the device)
+// writes its own range first, on its own thread and memory node; the first touch of fresh memory is the expensive part
+// on the virtualised hosts this runs on (279 CPU seconds of the chr20-scale build in round 2, when a second copy of the
+// tables was value-initialised besides). Large blocks are 2 MB-aligned and advised as huge pages where that pays.
 template <class T>
 struct BigAlloc {
   typedef T value_type;
@@ -34,7 +62,7 @@ struct BigAlloc {
     size_t bytes = n ? n * sizeof(T) : 1;
     void *p;
     const size_t huge = (size_t)2 << 20;
-    if (bytes >= ((size_t)64 << 20) && getenv("GMX_HUGEPAGES")) {
+    if (bytes >= ((size_t)64 << 20) && gmx_huge_pages_pay()) {
       bytes = (bytes + huge - 1) / huge * huge;
       p = aligned_alloc(huge, bytes);
       if (p) madvise(p, bytes, MADV_HUGEPAGE);
@@ -79,7 +107,7 @@ struct HostIndex {
   SeedTable seeds;              // direct-addressed by the k-mer's table index (gmx_types.h GmxSeed)
   uint32_t kmer_size2 = 0;      // longer seed table (0 = none): the same construction continued to k2 > kmer_size
   SeedTable seeds2;             // its 4^k2 entries; multi-state records share seed_words
-  std::vector<uint32_t> seed_words;
+  std::vector<uint32_t, BigAlloc<uint32_t>> seed_words;  // (every word written by the join: not value-initialised)
   uint32_t seed_shift = 0;      // multi-state entries start at (GmxSeed::b << seed_shift); > 0 from 2^30 words on
   std::vector<uint32_t> kmer_bitmap;
   uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
