@@ -1,11 +1,15 @@
-"""BASELINE.json configs[4] as a builder-and-mapping run on one MI355X: a whole-genome-sized PRG (3.1 G random bases,
-85 M SNP sites -> 3.46 G symbols; the recipe of SURVEY §8d at genome scale), index built (GMX_BUILD_TRACE phases),
-cached, reloaded, uploaded, and error-free reads mapped with the size-independent properties of tools/scale_check.py.
-Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=85000000] [K=14] [N_READS=1000000]"""
+"""BASELINE.json configs[4] as a builder-and-mapping run on one MI355X: a whole-genome-sized PRG (3.1 G random bases +
+SNP sites; SURVEY §8d's recipe at genome scale), index built (GMX_BUILD_TRACE phases), uploaded, and error-free reads
+mapped with the size-independent properties of tools/scale_check.py. The GPU boxes give a container 300 GiB of host
+memory and 16 cores of CPU time (cgroup limits), so the number of sites is what the HOST memory of the builder allows,
+not what the device could hold; a guard thread ends the process cleanly before the limit (a box that runs out of memory
+is lost). A scaled-down run (TRIAL bases) comes first and its peak memory is extrapolated.
+Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=8000000] [K=14] [N_READS=1000000] [TRIAL=200000000]"""
+import gc
 import os
 import resource
-import shutil
 import sys
+import threading
 import time
 
 import numpy as np
@@ -19,89 +23,136 @@ from gramtools_amd import Index, Quasimapper, master_seeds  # noqa: E402
 from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads_fast, snp_prg  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 3_100_000_000
-n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 85_000_000
+n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 8_000_000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 n_reads = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
+trial = int(sys.argv[5]) if len(sys.argv) > 5 else 200_000_000
+LIMIT_GB = float(os.environ.get("GMX_RSS_LIMIT_GB", "250"))
+T0 = time.time()
 
 
-def rss_gb():
+def rss_now_gb():
+    with open("/proc/self/statm") as fh:
+        return int(fh.read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 1e9
+
+
+def peak_gb():
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
 
 
 def say(*a):
-    print(f"[{time.time() - T0:8.1f} s, peak RSS {rss_gb():6.1f} GB]", *a, flush=True)
+    print(f"[{time.time() - T0:8.1f} s, RSS {rss_now_gb():6.1f} GB, peak {peak_gb():6.1f} GB]", *a, flush=True)
 
 
-T0 = time.time()
-say(f"host: {os.cpu_count()} hardware threads, {os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES') / 1e9:.0f} GB RAM; "
-    f"device: {torch.cuda.get_device_name(0)}, {torch.cuda.get_device_properties(0).total_memory / 1e9:.0f} GB")
-ref = random_ref(G, 1)
-prg, pos, alts, n_alts = snp_prg(ref, n_sites, 2)
-say(f"PRG: {prg.size} symbols, {n_sites} sites over {G} bases")
-reads = simulate_snp_reads_fast(ref, pos, alts, n_alts, n_reads, 150, 1000)
-say(f"{n_reads} error-free 150 bp reads simulated")
-del ref
-t0 = time.time()
-ix = Index(prg, k)
-info = ix.info
-say(f"index built in {time.time() - t0:.1f} s: {info.index_bytes / 1e9:.1f} GB, k = {k}, k2 = {info.kmer_size2}, "
-    f"{info.n_sites} sites, {info.n_inline_sites} inline")
-tmp = os.environ.get("TMPDIR", "/tmp")
-free = shutil.disk_usage(tmp).free
-cache = os.path.join(tmp, "gmx_config4.idx")
-prg_path = os.path.join(tmp, "gmx_config4.prg")
-if free > 3 * info.index_bytes:
+def guard():
+    while True:
+        if rss_now_gb() > LIMIT_GB:
+            print(f"ABORT: resident memory above {LIMIT_GB} GB (the container's limit is 300 GiB)", flush=True)
+            os._exit(3)
+        time.sleep(0.2)
+
+
+threading.Thread(target=guard, daemon=True).start()
+
+
+def make_prg(G, n_sites, chunk=250_000_000):
+    """snp_prg over chunks of the reference (its temporaries are 8-byte arrays of the chunk's length), sites renumbered."""
+    refs, outs, poss, alt_vals = [], [], [], []
+    done_sites = 0
+    for c0 in range(0, G, chunk):
+        g = min(chunk, G - c0)
+        ns = int(round(n_sites * (c0 + g) / G)) - done_sites
+        ref = random_ref(g, 1 + c0 // chunk)
+        prg, pos, alts, n_alts = snp_prg(ref, ns, 2 + c0 // chunk)
+        marker = prg > 4
+        prg[marker] += np.uint32(2 * done_sites)
+        refs.append(ref)
+        outs.append(prg)
+        poss.append(pos + c0)
+        alt_vals.append(alts[0][1])
+        done_sites += ns
+        del marker
+    ref = np.concatenate(refs)
+    del refs
+    prg = np.concatenate(outs)
+    del outs
+    pos = np.concatenate(poss)
+    alt = np.concatenate(alt_vals)
+    n_alts = np.ones(pos.size, dtype=np.int64)
+    return ref, prg, pos, [(np.ones(pos.size, dtype=bool), alt)], n_alts
+
+
+def run(G, n_sites, n_reads, label):
+    say(f"== {label}: {G} bases, {n_sites} sites, k = {k}")
+    ref, prg, pos, alts, n_alts = make_prg(G, n_sites)
+    say(f"PRG: {prg.size} symbols")
+    reads = simulate_snp_reads_fast(ref, pos, alts, n_alts, n_reads, 150, 1000)
+    del ref, pos, alts, n_alts
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    prg_path = os.path.join(tmp, "gmx_config4.prg")
+    prg.tofile(prg_path)
+    n_symbols = int(prg.size)
+    del prg
+    gc.collect()
+    say(f"{n_reads} error-free 150 bp reads simulated; PRG written ({os.path.getsize(prg_path) / 1e9:.1f} GB); python side freed")
     t0 = time.time()
-    ix.save(cache)
-    np.asarray(prg, dtype="<u4").tofile(prg_path)
-    say(f"cache written in {time.time() - t0:.1f} s: {os.path.getsize(cache) / 1e9:.1f} GB")
-    ix.close()
-    del ix
-    t0 = time.time()
-    ix = Index(prg_path, k, cache=cache)
-    assert ix.from_cache
-    say(f"cache loaded (checksummed) in {time.time() - t0:.1f} s")
-    os.remove(cache)
+    before = peak_gb()
+    ix = Index(prg_path, k)
     os.remove(prg_path)
-else:
-    say(f"cache round trip skipped: {free / 1e9:.0f} GB free under {tmp}")
-del prg
-t0 = time.time()
-qm = Quasimapper(ix)
-say(f"engine created (index in HBM: {torch.cuda.mem_get_info()[1] / 1e9 - torch.cuda.mem_get_info()[0] / 1e9:.1f} GB of the device in use) in {time.time() - t0:.1f} s")
-seeds = master_seeds(42, [n_reads])
-offs = flat_offsets(n_reads, 150)
-flat = reads.reshape(-1)
-t0 = time.time()
-try:
+    info = ix.info
+    say(f"index built in {time.time() - t0:.1f} s: {info.index_bytes / 1e9:.1f} GB, k2 = {info.kmer_size2}, {info.n_sites} sites, "
+        f"{info.n_inline_sites} inline; peak memory of the process so far {peak_gb():.1f} GB (before the build {before:.1f})")
+    t0 = time.time()
+    qm = Quasimapper(ix)
+    free_b, total_b = torch.cuda.mem_get_info()
+    say(f"engine created in {time.time() - t0:.1f} s: {(total_b - free_b) / 1e9:.1f} GB of the device's {total_b / 1e9:.0f} GB in use")
+    seeds = master_seeds(42, [n_reads])
+    offs = flat_offsets(n_reads, 150)
+    flat = reads.reshape(-1)
+    t0 = time.time()
     qm.map_reads(flat, offs, seeds)
     qm.sync()
-except Exception as exc:
-    print("FAILED:", exc, "\nqueues of the last batch:", qm.queue_counts(), flush=True)
-    raise
-dt = time.time() - t0
-fwd = qm.coverage()
-st = fwd.stats.as_dict()
-say(f"mapped {n_reads} reads in {dt:.2f} s ({n_reads / dt / 1e6:.2f} M reads/s, host buffers): {st}")
-print("queues of the last batch:", qm.queue_counts(), flush=True)
-assert st["all"] == 2 * n_reads and st["skipped"] == 0
-assert st["exact_mapped"] >= n_reads, "every error-free read maps in at least one orientation"
-assert st["all"] == st["skipped"] + st["missing_kmer"] + st["no_extension"] + st["exact_mapped"]
-t0 = time.time()
-qm.reset()
-qm.map_reads(flat, offs, seeds)
-qm.sync()
-dt = time.time() - t0
-again = qm.coverage()
-assert (fwd.raw_allele_sum == again.raw_allele_sum).all() and (fwd.raw_per_base == again.raw_per_base).all() and (fwd.raw_grouped == again.raw_grouped).all()
-say(f"second pass of the same reads: {dt:.2f} s ({n_reads / dt / 1e6:.2f} M reads/s), identical coverage")
-rc = np.ascontiguousarray((5 - reads[:, ::-1]).astype(np.uint8)).reshape(-1)
-qm.reset()
-qm.map_reads(rc, offs, seeds)
-back = qm.coverage()
-assert (fwd.raw_allele_sum == back.raw_allele_sum).all() and (fwd.raw_per_base == back.raw_per_base).all()
-assert (fwd.raw_grouped == back.raw_grouped).all()
-a_sum, g_sum, pb_sum = int(fwd.raw_allele_sum.astype(np.int64).sum()), int(fwd.raw_grouped.astype(np.int64).sum()), int(fwd.raw_per_base.astype(np.int64).sum())
-assert a_sum >= g_sum > 0
-say(f"properties hold: counter identity, every read mapped, strand symmetry, repeatability; allele-sum total {a_sum}, "
-    f"grouped total {g_sum}, per-base total {pb_sum}")
+    dt = time.time() - t0
+    fwd = qm.coverage()
+    st = fwd.stats.as_dict()
+    say(f"mapped {n_reads} reads in {dt:.2f} s ({n_reads / dt / 1e6:.2f} M reads/s from host buffers): {st}")
+    print("queues of the last batch:", qm.queue_counts(), flush=True)
+    assert st["all"] == 2 * n_reads and st["skipped"] == 0
+    assert st["exact_mapped"] >= n_reads, "every error-free read maps in at least one orientation"
+    assert st["all"] == st["skipped"] + st["missing_kmer"] + st["no_extension"] + st["exact_mapped"]
+    t0 = time.time()
+    qm.reset()
+    qm.map_reads(flat, offs, seeds)
+    qm.sync()
+    dt = time.time() - t0
+    again = qm.coverage()
+    assert (fwd.raw_allele_sum == again.raw_allele_sum).all() and (fwd.raw_per_base == again.raw_per_base).all() and (fwd.raw_grouped == again.raw_grouped).all()
+    say(f"second pass of the same reads: {dt:.2f} s ({n_reads / dt / 1e6:.2f} M reads/s), identical coverage")
+    rc = np.ascontiguousarray((5 - reads[:, ::-1]).astype(np.uint8)).reshape(-1)
+    qm.reset()
+    qm.map_reads(rc, offs, seeds)
+    back = qm.coverage()
+    assert (fwd.raw_allele_sum == back.raw_allele_sum).all() and (fwd.raw_per_base == back.raw_per_base).all()
+    assert (fwd.raw_grouped == back.raw_grouped).all()
+    a_sum, g_sum = int(fwd.raw_allele_sum.astype(np.int64).sum()), int(fwd.raw_grouped.astype(np.int64).sum())
+    assert a_sum >= g_sum > 0
+    say(f"properties hold: counter identity, every read mapped, strand symmetry, repeatability; allele-sum total {a_sum}, grouped total {g_sum}")
+    qm.close()
+    ix.close()
+    del qm, ix, fwd, again, back
+    gc.collect()
+    return n_symbols
+
+
+say(f"host: {os.cpu_count()} hardware threads; cgroup cpu.max {open('/sys/fs/cgroup/cpu.max').read().strip() if os.path.exists('/sys/fs/cgroup/cpu.max') else '?'}, "
+    f"memory.max {open('/sys/fs/cgroup/memory.max').read().strip() if os.path.exists('/sys/fs/cgroup/memory.max') else '?'}; "
+    f"device: {torch.cuda.get_device_name(0)}, {torch.cuda.get_device_properties(0).total_memory / 1e9:.0f} GB")
+if trial:
+    base = peak_gb()
+    run(trial, int(n_sites * trial / G), min(n_reads, 200_000), "trial")
+    grow = (peak_gb() - base) * G / trial
+    say(f"trial peak {peak_gb():.1f} GB -> extrapolated peak of the full run: {base + grow:.0f} GB (limit {LIMIT_GB:.0f})")
+    if base + grow > LIMIT_GB:
+        say("the full run would not fit: stopping here")
+        sys.exit(4)
+run(G, n_sites, n_reads, "configs[4] scale")
