@@ -51,7 +51,10 @@ HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 # Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (DESIGN.md §8 derives each term):
 # queue entry 4 + seed directory entry 8 + packed read planes 48 + PRG text records 6 x 16 + marker sub-records 3 x 16 +
 # path nodes 2 x 12 + coverage record 32 + task id 4
-B_DESIGN_PER_READ = 4 + 8 + 48 + 6 * 16 + 3 * 16 + 2 * 12 + 32 + 4
+# what gmx_extend_kernel has to move per mapped read since round 3: queue entry 4 + seed directory entry 8 + read
+# planes 48 + PRG text records 3.4 x 32 (64 symbols each; loop_stats.txt: 3.3 heavy steps per lane) + marker sub-records of the
+# sites that are not inline 0.15 x 16 + path nodes 2 x 12 + coverage record 32 + task id 4   (264 B with round 2's 16 B records)
+B_DESIGN_PER_READ = 4 + 8 + 48 + 109 + 2 + 2 * 12 + 32 + 4
 PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
 
 
@@ -75,11 +78,24 @@ def measured_traffic(kernel):
         return None, src
 
 
+def effective_cores():
+    """Cores' worth of CPU time this process can use: the hardware threads, or the container's quota if that is lower (the
+    GPU boxes show 256 hardware threads and grant 16 cores: cgroup cpu.max = 1600000 100000; tools/exp/cpu_probe.cpp)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(prg, reads, seeds, max_seconds=12.0):
     """Oracle (port of the reference algorithm, OpenMP over reads as quasimap.cpp:90) on a bounded sample of the same reads."""
     from oracle import Oracle
     from gramtools_amd.synth import flat_offsets
-    cores = os.cpu_count() or 1
+    cores = effective_cores()
     o = Oracle(prg, KMER)
     n1 = 3000
     t0 = time.time()
@@ -101,7 +117,8 @@ def cpu_baseline(prg, reads, seeds, max_seconds=12.0):
     o.map_reads(reads[:n2].reshape(-1), flat_offsets(n2, READ_LEN), seeds[:n2], threads=cores)
     dt = time.time() - t0
     return {"value": n2 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": f"first {n2} of the rank-0 reads of batch 0, same PRG/k/seeds, OpenMP over reads ({cores} threads), {dt:.1f} s",
+            "sample": f"first {n2} of the rank-0 reads of batch 0, same PRG/k/seeds, OpenMP over reads ({cores} threads = the cores' "
+                      f"worth of CPU time the container grants, of {os.cpu_count()} hardware threads), {dt:.1f} s",
             "single_thread": {"value": n1 / dt1, "unit": "reads/s", "cores": 1, "sample": f"first {n1} reads, {dt1:.1f} s"}}
 
 
@@ -364,12 +381,14 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
                          "alg_bytes_per_read": B_DESIGN_PER_READ,
-                         "alg_bytes_model": "text-form states: 16 B of PRG per 32 bases + one 16 B sub-record per marker (DESIGN.md §8)",
+                         "alg_bytes_model": "text-form states: 32 B of PRG per 64 symbols, SNP sites resolved inside the record; "
+                                            "a 16 B sub-record only for sites that straddle a record end (DESIGN.md §8)",
                          "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
                          "measured": "HIP events attached to the dispatch (hipExtLaunchKernelGGL), reads resident in HBM leg",
                          "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
-                         "what_bounds_it": "the rate of 64-byte transactions behind the XCD L2 (scattered 12-16 byte payloads), not HBM "
-                                           "bandwidth and not instruction issue (DESIGN.md §4)",
+                         "what_bounds_it": "instruction issue of the wave loop (~58 M VALU + 41 M SALU wave-instructions per launch, VALU "
+                                           "busy 0.59) and the slowest lane of each wave, not HBM bandwidth: round 3 halved the "
+                                           "loop's fetches (8.5 -> 3.3 per lane) and gained 10 % (DESIGN.md §4)",
                          "issue": {"valu_busy": sq.get("valu_busy"), "active_lane_share": sq.get("active_lane_share"),
                                    "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
                                    "iterations_per_wave": sq.get("iterations_per_wave"),
