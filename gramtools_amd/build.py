@@ -66,6 +66,15 @@ def build_library_alt(force=False, verbose=False):
     return _link(LIB_ALT, ["-DGMX_SEARCHOUT_ALT"], "_alt", force, verbose)
 
 
+LIB_STATS = os.path.join(LIB_DIR, "libgmx_stats.so")
+
+
+def build_library_stats(force=False, verbose=False):
+    """Debug build with -DGMX_LOOP_STATS (iteration mix and phase clocks of the wave loop and the coverage instances;
+    tools/loop_stats.py, tools/coop_stats_c2.py load it through GMX_LIB). Not built by __graft_entry__.build()."""
+    return _link(LIB_STATS, ["-DGMX_LOOP_STATS"], "_stats", force, verbose)
+
+
 def build_gram(force=False, verbose=False):
     src = os.path.join(CSRC, "gram_main.cpp")
     if not os.path.exists(src):

@@ -65,4 +65,5 @@ echo "pread path (GMX_FASTQ_MMAP=0), 64 threads" >> $OUT/parse_bench.txt; GMX_FA
 rm -f /tmp/r4m.fq
 # ---- index build ----
 GMX_BUILD_TRACE=1 python tools/build_trace.py 64444167 1800000 14 > $OUT/build_trace_chr20_snps.txt 2>&1
+GMX_DEVICE_BUILD=0 GMX_BUILD_TRACE=1 python tools/build_trace.py 64444167 1800000 14 > $OUT/build_trace_chr20_snps_host_walk.txt 2>&1
 tail -3 $OUT/bench.log | cut -c1-600
