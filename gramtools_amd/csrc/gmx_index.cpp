@@ -258,6 +258,48 @@ static bool parallel_suffix_sort(const uint32_t *text, size_t n, uint32_t *sa, u
   return !gave_up.load();
 }
 
+// What the device pre-sort (gmx_suffixsort.hip) leaves: runs of suffixes that agree on their first 24 symbols (bit p of the
+// mask: sa[p] ties with sa[p - 1]) — repeats. Each run is sorted by plain suffix comparison, runs spread over the threads,
+// with parallel_suffix_sort's budget of symbol comparisons (false when it is spent: the caller sorts another way).
+static bool finish_tied_runs(const uint32_t *text, size_t n, uint32_t *sa, const std::vector<uint32_t> &mask, unsigned threads) {
+  std::vector<std::pair<size_t, size_t>> runs;  // [first, last]
+  for (size_t w = 0; w < mask.size(); ++w) {
+    uint32_t bits = mask[w];
+    while (bits) {
+      const size_t p = w * 32 + (size_t)__builtin_ctz(bits);
+      bits &= bits - 1;
+      if (p == 0 || p >= n) continue;
+      if (!runs.empty() && runs.back().second == p - 1) runs.back().second = p;
+      else runs.push_back({p - 1, p});
+    }
+  }
+  if (runs.empty()) return true;
+  std::atomic<uint64_t> budget_left{(uint64_t)n * 400ull + (1ull << 24)};
+  std::atomic<bool> gave_up{false};
+  const size_t chunk = 256;
+  par_for((runs.size() + chunk - 1) / chunk, threads, [&](size_t ci) {
+    if (gave_up.load(std::memory_order_relaxed)) return;
+    uint64_t used = 0;
+    auto less = [&](uint32_t a, uint32_t b) {
+      size_t j = 0;
+      const size_t lim = n - std::max(a, b);
+      while (j < lim && text[a + j] == text[b + j]) ++j;
+      used += j + 1;
+      return j < lim ? text[a + j] < text[b + j] : a > b;
+    };
+    for (size_t r = ci * chunk; r < std::min(runs.size(), (ci + 1) * chunk); ++r) {
+      std::sort(sa + runs[r].first, sa + runs[r].second + 1, less);
+      if (used > (1ull << 22)) {
+        if (budget_left.fetch_sub(used) < used) gave_up.store(true);
+        used = 0;
+        if (gave_up.load(std::memory_order_relaxed)) return;
+      }
+    }
+    if (used && budget_left.fetch_sub(used) < used) gave_up.store(true);
+  });
+  return !gave_up.load();
+}
+
 void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t> &sa, int threads) {
   size_t n = text.size();
   if (n == 0) {
@@ -273,6 +315,33 @@ void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t>
   const unsigned hw = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
   size_t min_n = 1u << 16;  // (below that SA-IS takes milliseconds; GMX_PSORT_MIN: the tests run the parallel sort on small texts)
   if (const char *mn = getenv("GMX_PSORT_MIN")) min_n = (size_t)atoll(mn);
+  // on the GPU when there is one and the text is large (GMX_DEVICE_BUILD=1: whatever the size, an error if it cannot; 0: never)
+  if (g_device_suffix_presort && !getenv("GMX_SAIS")) {
+    const char *db = getenv("GMX_DEVICE_BUILD");
+    const bool forced = db && atoi(db) != 0;
+    if (forced || (!db && n >= ((size_t)1 << 22))) {
+      uint32_t max_sym = 0;
+      {
+        std::vector<uint32_t> part_max(64, 0);
+        par_for(64, hw, [&](size_t c) {
+          uint32_t m = 0;
+          for (size_t i = n * c / 64; i < n * (c + 1) / 64; ++i) m = std::max(m, text[i]);
+          part_max[c] = m;
+        });
+        for (uint32_t m : part_max) max_sym = std::max(max_sym, m);
+      }
+      try {
+        std::vector<uint32_t> mask;
+        if (max_sym < (1u << 28) && g_device_suffix_presort(text.data(), n, sa.data(), mask) && finish_tied_runs(text.data(), n, sa.data(), mask, hw))
+          return;
+        if (forced && max_sym < (1u << 28) && !getenv("GMX_DEVICE_SORT_MAY_FALL_BACK"))
+          throw std::runtime_error("GMX_DEVICE_BUILD=1: the device suffix sort could not be used (no device, or a repetitive text)");
+      } catch (std::exception const &e) {
+        if (forced) throw;
+        fprintf(stderr, "gmx: the device suffix sort failed (%s): sorting on the host\n", e.what());
+      }
+    }
+  }
   if (hw > 1 && n >= min_n && !getenv("GMX_SAIS") && parallel_suffix_sort(text.data(), n, sa.data(), hw)) return;
   // SA-IS on the compacted alphabet: rank of every symbol among the symbols present (no sorted copy of the text: 14 GB at 3.46 G)
   uint32_t max_sym = 0;
@@ -683,6 +752,7 @@ void seed_step_parallel(const GmxIndexView &ix, const WalkNode &parent, bool mar
 }  // namespace
 
 DeviceSeedWalk g_device_seed_walk = nullptr;
+DeviceSuffixPresort g_device_suffix_presort = nullptr;
 
 GmxIndexView HostIndex::view() const {
   GmxIndexView v;

@@ -178,6 +178,12 @@ typedef bool (*DeviceSeedWalk)(const HostIndex &ix, uint32_t k, uint32_t k2, uin
                                GmxSeed *table, GmxSeed *table2, uint32_t *bitmap, std::vector<SeedPart> &parts);
 extern DeviceSeedWalk g_device_seed_walk;
 
+// The suffixes of `text` (n symbols, the last one the unique sentinel 0) ordered by their first 24 symbols on the device
+// (gmx_suffixsort.hip); tie_mask: bit p set = sa[p] still ties with sa[p - 1] — the host finishes those runs by comparison.
+// Null in host-only builds; returns false when no device can be used; throws std::runtime_error.
+typedef bool (*DeviceSuffixPresort)(const uint32_t *text, size_t n, uint32_t *sa, std::vector<uint32_t> &tie_mask);
+extern DeviceSuffixPresort g_device_suffix_presort;
+
 // Collects the k-mer index states of one k-mer from the seed table (test / debug helper).
 // Output format: [n_states, {lo, hi, n_traversed, (site, allele)*, n_traversing, (site, -1)*}*] or {-1} if absent.
 std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t kmer_code, bool longer_table = false);

@@ -80,3 +80,17 @@ def test_reads_mapped_from_a_device_built_index(tmp_path, monkeypatch):
     flat, offs = flatten_reads(reads)
     qm.map_reads(flat, offs, seeds)
     assert canonical_cov(qm.coverage()) == want
+
+
+def test_suffix_array_with_repeats_presorted_on_the_device(tmp_path, monkeypatch):
+    """gmx_suffixsort.hip orders the suffixes by their first 24 symbols; copies of a 2 kb segment tie far beyond that and are
+    finished on the host (finish_tied_runs) — the index file must still equal the host build's (SA-IS / parallel sort)."""
+    ref = random_ref(120_000, 9)
+    rng = np.random.default_rng(3)
+    piece = ref[5000:7000].copy()
+    for dst in (20_000, 55_000, 90_000, 110_000):
+        ref[dst:dst + 2000] = piece
+    ref[30_000:30_400] = 1  # a homopolymer run: one long tie group of the first round
+    prg, pos, alts, n_alts = snp_prg(ref, 3000, 5, multi_allelic_frac=0.1)
+    _same(prg, 7, tmp_path, monkeypatch)
+    del rng
