@@ -316,7 +316,7 @@ void build_suffix_array(const std::vector<uint32_t> &text, std::vector<uint32_t>
   size_t min_n = 1u << 16;  // (below that SA-IS takes milliseconds; GMX_PSORT_MIN: the tests run the parallel sort on small texts)
   if (const char *mn = getenv("GMX_PSORT_MIN")) min_n = (size_t)atoll(mn);
   // on the GPU when there is one and the text is large (GMX_DEVICE_BUILD=1: whatever the size, an error if it cannot; 0: never)
-  if (g_device_suffix_presort && !getenv("GMX_SAIS")) {
+  if (g_device_suffix_presort && !getenv("GMX_SAIS") && !getenv("GMX_NO_DEVICE_SORT")) {
     const char *db = getenv("GMX_DEVICE_BUILD");
     const bool forced = db && atoi(db) != 0;
     if (forced || (!db && n >= ((size_t)1 << 22))) {

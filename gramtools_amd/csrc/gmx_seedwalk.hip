@@ -404,6 +404,7 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
     return false;
   }
   const bool trace = getenv("GMX_BUILD_TRACE") != nullptr;
+  const bool trace2 = trace && atoi(getenv("GMX_BUILD_TRACE")) >= 2;  // every level
   const double t_start = now_s();
   const uint32_t max_depth = k2 > k ? k2 : k;
   if (depth0 >= k || roots.size() != ((size_t)1 << (2 * depth0))) throw std::runtime_error("device walk: roots of the wrong depth");
@@ -589,6 +590,7 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
       if (d == k && k2 > k) em[0].lvl.swap(cur);  // this level's lists are entries still to be written: kept beside the walk
       cur.swap(next);
       t_levels += now_s() - t0;
+      if (trace2) fprintf(stderr, "      level %u: %zu nodes, %zu states (+%zu) -> %zu nodes, %zu states: %.3f s\n", d, nn, n, n_add, cur.n_nodes, cur.n_states, now_s() - t0);
     }
     if (fetch_u32(d_failed.p)) throw std::runtime_error("seed table: inconsistent variant path while indexing k-mers");
     // ---- the group's part: both levels' entries merged in the host walk's order ----------------

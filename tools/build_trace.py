@@ -3,7 +3,7 @@ import os
 import sys
 import time
 
-os.environ["GMX_BUILD_TRACE"] = "1"
+os.environ.setdefault("GMX_BUILD_TRACE", "1")
 sys.path.insert(0, ".")
 from gramtools_amd import Index  # noqa: E402
 from gramtools_amd.synth import random_ref, snp_prg  # noqa: E402
