@@ -202,6 +202,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip kernel_pipeline / sustained / cli_end_to_end / roofline leg")
     ap.add_argument("--cli-reads", type=int, default=4_000_000, help="reads in the FASTQ of the cli_end_to_end leg")
     ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce through torch.distributed instead of the library")
+    ap.add_argument("--upload-seeds", action="store_true",
+                    help="upload the per-read seeds with every batch (default: left in page-locked host memory, read in place)")
     args = ap.parse_args()
 
     import torch
@@ -245,6 +247,10 @@ def main():
     reads = raw[0]
     seeds = batches[0][1].array
     qm = Quasimapper(ix, device=local_rank)
+    if not args.upload_seeds:
+        # the per-read seeds stay in page-locked host memory: only a read with several equally good mapping classes draws, and
+        # the kernels read those few seeds in place (gmx_engine_seeds_in_place) — 40 instead of 44 bytes per read over PCIe
+        qm.seeds_in_place(True)
     stream = torch.cuda.current_stream().cuda_stream   # the default stream: the one the host feed launches on
     from gramtools_amd.distributed import allreduce_device_coverage, fused_coverage_tensor, CoverageComm
     exchange = "none"
@@ -356,7 +362,7 @@ def main():
         sq, sq_src = profile_json("sq_extend.json")
         sq = sq or {}
         traffic, traffic_src = measured_traffic("gmx_extend_kernel")
-        h2d_per_read = 8 * ((READ_LEN + 31) // 32) + 4
+        h2d_per_read = 8 * ((READ_LEN + 31) // 32) + (4 if args.upload_seeds else 0)
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -369,7 +375,8 @@ def main():
                             "end of the job, not one per step: values of different rounds are not comparable",
             "config": {"workload": "configs[1]: M. tuberculosis scale, 4411532 bp random ref + 60000 SNP PRG, k=10, "
                                    f"{n} x 150 bp reads per GPU per step, fwd+rc, {NB} distinct batches cycled, reads handed over as "
-                                   "2-bit planes in page-locked host memory",
+                                   "2-bit planes in page-locked host memory"
+                                   + ("" if args.upload_seeds else ", per-read seeds read in place from page-locked host memory"),
                        "reads_per_gpu": n, "read_len": READ_LEN, "kmer_size": KMER, "distinct_batches": NB,
                        "h2d_bytes_per_read": h2d_per_read,
                        "parallelism": f"reads sharded x{world} by global read index, index replicated, one RCCL all-reduce of the "

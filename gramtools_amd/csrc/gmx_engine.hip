@@ -2902,6 +2902,7 @@ struct gmx_engine {
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
   uint32_t extend_budget = 8;   // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
+  bool seeds_in_place = false;  // gmx_engine_seeds_in_place
   uint32_t extend_passes = 1;   // launches over the stragglers (<= GMX_EXTRA_PASSES); all but the last with a budget of their own
   uint32_t extend_budget2[GMX_EXTRA_PASSES] = {24, 96, 0};
                                 // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
@@ -3832,6 +3833,14 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     (void)hipGetLastError();
     all_pinned = false;
   }
+  // seeds in place (gmx_engine_seeds_in_place): the kernels read the few seeds they need — a read draws only when it has
+  // several equally good mapping classes — from the caller's page-locked buffer over PCIe; nothing is uploaded
+  const uint32_t *d_seeds_host = nullptr;
+  if (e->seeds_in_place && gmx_is_pinned(seeds)) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<uint32_t *>(seeds), 0) == hipSuccess && dp) d_seeds_host = static_cast<const uint32_t *>(dp);
+    else (void)hipGetLastError();
+  }
   const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
   int rc = GMX_OK;
   auto hip_ok = [&](hipError_t err, const char *what) {
@@ -3878,14 +3887,16 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     if (!uniform_len &&
         !hip_ok(hipMemcpyAsync(sl.d_offsets, offsets + done, (n + 1) * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(offsets)"))
       break;
-    if (!hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(seeds)")) break;
+    if (!d_seeds_host &&
+        !hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(seeds)"))
+      break;
     if (skip && !hip_ok(hipMemcpyAsync(sl.d_skip, skip + done, n, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(skip)")) break;
     if (!hip_ok(hipEventRecord(sl.copied, e->copy_stream), "hipEventRecord") ||
         !hip_ok(hipStreamWaitEvent(nullptr, sl.copied, 0), "hipStreamWaitEvent"))
       break;
     BatchInput in;
     in.d_offsets = uniform_len ? nullptr : sl.d_offsets;
-    in.d_seeds = sl.d_seeds;
+    in.d_seeds = d_seeds_host ? d_seeds_host + done : sl.d_seeds;
     in.d_planes = sl.d_planes;
     in.d_skip = skip ? sl.d_skip : nullptr;
     in.uniform_len = uniform_len;
@@ -3908,6 +3919,15 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     if (regs[i].on) (void)hipHostUnregister(const_cast<void *>(regs[i].p));
   (void)hipGetLastError();
   return rc;
+}
+
+int gmx_engine_seeds_in_place(gmx_engine *e, int on) {
+  if (!e) {
+    gmx_set_error("null engine");
+    return GMX_EINVAL;
+  }
+  e->seeds_in_place = on != 0;
+  return GMX_OK;
 }
 
 int gmx_engine_sync_uploads(gmx_engine *e) {

@@ -637,8 +637,17 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
     t_down += now_s() - t1;
   }
   const double t1 = now_s();
-  WCK(hipMemcpy(table, d_table.p, n_k * sizeof(GmxSeed), hipMemcpyDeviceToHost));
-  if (n_k2) WCK(hipMemcpy(table2, d_table2.p, n_k2 * sizeof(GmxSeed), hipMemcpyDeviceToHost));
+  // (10.7 GB at chr20 scale into fresh host memory: page-locked for the copy when the host allows — GMX_WALK_PIN=0: as it is)
+  auto download = [&](void *dst, const void *src, size_t bytes) {
+    static const bool pin = !getenv("GMX_WALK_PIN") || atoi(getenv("GMX_WALK_PIN")) != 0;
+    const bool pinned = pin && bytes >= ((size_t)64 << 20) && hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    if (pinned) (void)hipHostUnregister(dst);
+    if (e != hipSuccess) throw std::runtime_error(std::string("device walk: copy of a seed table to the host: ") + hipGetErrorString(e));
+  };
+  download(table, d_table.p, n_k * sizeof(GmxSeed));
+  if (n_k2) download(table2, d_table2.p, n_k2 * sizeof(GmxSeed));
   WCK(hipMemcpy(bitmap, d_bitmap.p, ((n_k + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost));
   t_down += now_s() - t1;
   if (trace)

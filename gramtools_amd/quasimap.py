@@ -453,6 +453,11 @@ class Quasimapper:
     def sync_uploads(self):
         check(self.lib.gmx_engine_sync_uploads(self.h))
 
+    def seeds_in_place(self, on: bool = True):
+        """map_reads_packed uploads no seeds when they lie in page-locked memory: the kernels read the few they need from
+        there (gmx_engine_seeds_in_place). The seeds must then stay untouched until sync() / coverage()."""
+        check(self.lib.gmx_engine_seeds_in_place(self.h, 1 if on else 0))
+
     def map_reads_device(self, d_reads, d_offsets, d_seeds, n_reads, stream=None):
         """Device-resident buffers (torch CUDA tensors: uint8 / int64-or-uint64 / int32-or-uint32). Asynchronous."""
         sp = C.c_void_p(stream) if stream else None

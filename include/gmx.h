@@ -168,6 +168,12 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
 int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
                               const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads);
 int gmx_engine_sync_uploads(gmx_engine *e);
+/* Seeds in place (off by default): gmx_map_reads_packed_host then uploads NO seeds when `seeds` lies in gmx_host_alloc memory —
+ * a read's seed is consulted only when the read has several equally good mapping classes (coverage_common.cpp:166-177), and
+ * the kernels read those few from the caller's buffer over PCIe (4 of the 44 bytes per 150 bp read stay on the host). The
+ * price is a longer hold: the seeds must stay untouched until gmx_engine_sync / gmx_coverage_fetch, not just until
+ * gmx_engine_sync_uploads. Results are the same either way. */
+int gmx_engine_seeds_in_place(gmx_engine *e, int on);
 uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads);
 /* Encoded reads (one byte per base, 1..4; the input of gmx_map_reads_host) -> bit planes in the layout above, on `threads`
  * host threads (0 = all). skip[r] (may be NULL) = read r holds a byte outside 1..4. With uniform_len every read must be

@@ -175,3 +175,34 @@ def test_packed_feed_through_a_group_of_engines():
         assert canonical_cov(g.coverage(2)) == want
         g.close()
         pk.close()
+
+
+@pytest.mark.gpu
+def test_seeds_read_in_place_give_the_same_draws():
+    """gmx_engine_seeds_in_place: no seeds are uploaded, the kernels read the ones they need from the caller's page-locked
+    buffer. A nested PRG with repeats, so that many reads have several equally good classes and DRAW
+    (coverage_common.cpp:166-177): the coverage must be the oracle's, and differ from a run with other seeds."""
+    from gramtools_amd import PinnedArray
+    prg = bracket_to_ints(nested_prg(23, n_top=10, max_depth=2, seq_max=6).replace("t", "a"))
+    k = 4
+    reads = [np.asarray(r, dtype=np.uint8) for r in simulate_graph_reads(prg, 3000, 18, 5)]
+    seeds = master_seeds(11, [len(reads)])
+    want = oracle_map(prg, k, reads, seeds)
+    assert want != oracle_map(prg, k, reads, master_seeds(12, [len(reads)])), "the case must depend on its seeds"
+    flat, offs = flatten_reads(reads)
+    ix = Index(prg, k)
+    pk = pack_reads(flat, offs, pinned=True)
+    sd = PinnedArray(len(reads), np.uint32)
+    sd.array[:] = seeds
+    for batch in (None, 700):
+        qm = Quasimapper(ix) if batch is None else Quasimapper(ix, max_batch_reads=batch)
+        qm.seeds_in_place(True)
+        qm.map_reads_packed(pk, sd.array)
+        assert canonical_cov(qm.coverage()) == want
+    # seeds in pageable memory with the switch on: uploaded as before
+    qm = Quasimapper(ix)
+    qm.seeds_in_place(True)
+    qm.map_reads_packed(pk, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    pk.close()
+    sd.close()
