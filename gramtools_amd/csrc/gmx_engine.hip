@@ -3984,7 +3984,8 @@ void *gmx_host_alloc(uint64_t bytes) {
     }
   }
   void *p = nullptr;
-  bool pinned = hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p;
+  static const unsigned alloc_flags = getenv("GMX_HOST_ALLOC_FLAGS") ? (unsigned)strtoul(getenv("GMX_HOST_ALLOC_FLAGS"), nullptr, 0) : hipHostMallocDefault;
+  bool pinned = hipHostMalloc(&p, bytes, alloc_flags) == hipSuccess && p;
   if (!pinned) {
     (void)hipGetLastError();
     p = malloc(bytes);
