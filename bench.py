@@ -202,13 +202,15 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip kernel_pipeline / sustained / cli_end_to_end / roofline leg")
     ap.add_argument("--cli-reads", type=int, default=4_000_000, help="reads in the FASTQ of the cli_end_to_end leg")
     ap.add_argument("--torch-exchange", action="store_true", help="N > 1: all-reduce through torch.distributed instead of the library")
+    ap.add_argument("--planes", action="store_true",
+                    help="hand the reads over as bit planes (40 B per 150 bp read) instead of the 2-bit stream (37.5 B)")
     ap.add_argument("--upload-seeds", action="store_true",
                     help="upload the per-read seeds with every batch (default: left in page-locked host memory, read in place)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from gramtools_amd import Index, Quasimapper, master_seeds, pack_reads, PinnedArray
+    from gramtools_amd import Index, Quasimapper, master_seeds, pack_reads, pack_reads_2bit, PinnedArray
     from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads_fast, flat_offsets
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +241,8 @@ def main():
     all_seeds = master_seeds(42, [n * world * NB])      # one master stream for the whole job ...
     batches = []
     for j in range(NB):                                 # ... read i of batch j of rank r is global read (j * world + r) * n + i
-        pk = pack_reads(raw[j].reshape(-1), offs, uniform_len=READ_LEN, threads=max(1, threads // max(world, 1)), pinned=True)
+        pk = (pack_reads if args.planes else pack_reads_2bit)(raw[j].reshape(-1), offs, uniform_len=READ_LEN,
+                                                              threads=max(1, threads // max(world, 1)), pinned=True)
         sd = PinnedArray(n, np.uint32)
         sd.array[:] = all_seeds[(j * world + rank) * n:(j * world + rank + 1) * n]
         batches.append((pk, sd))
@@ -362,7 +365,7 @@ def main():
         sq, sq_src = profile_json("sq_extend.json")
         sq = sq or {}
         traffic, traffic_src = measured_traffic("gmx_extend_kernel")
-        h2d_per_read = 8 * ((READ_LEN + 31) // 32) + (4 if args.upload_seeds else 0)
+        h2d_per_read = (8 * ((READ_LEN + 31) // 32) if args.planes else READ_LEN / 4) + (4 if args.upload_seeds else 0)
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,7 +378,7 @@ def main():
                             "end of the job, not one per step: values of different rounds are not comparable",
             "config": {"workload": "configs[1]: M. tuberculosis scale, 4411532 bp random ref + 60000 SNP PRG, k=10, "
                                    f"{n} x 150 bp reads per GPU per step, fwd+rc, {NB} distinct batches cycled, reads handed over as "
-                                   "2-bit planes in page-locked host memory"
+                                   + ("2-bit planes" if args.planes else "a 2-bit stream (37.5 B per read)") + " in page-locked host memory"
                                    + ("" if args.upload_seeds else ", per-read seeds read in place from page-locked host memory"),
                        "reads_per_gpu": n, "read_len": READ_LEN, "kmer_size": KMER, "distinct_batches": NB,
                        "h2d_bytes_per_read": h2d_per_read,

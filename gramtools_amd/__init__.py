@@ -9,7 +9,7 @@ from .quasimap import (  # noqa: F401
     Quasimapper,
     PackedReads,
     PinnedArray,
-    pack_reads,
+    pack_reads, pack_reads_2bit,
     QuasimapperGroup,
     Coverage,
     QuasimapReadsStats,

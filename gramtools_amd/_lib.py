@@ -89,6 +89,9 @@ SYMBOLS = {
     "gmx_engine_sync_uploads": (C.c_int, [_vp]),
     "gmx_engine_seeds_in_place": (C.c_int, [_vp, C.c_int]),
     "gmx_packed_pairs": (_u64, [_u64p, _u32, _u64]),
+    "gmx_twobit_units": (_u64, [_u64p, _u32, _u64]),
+    "gmx_pack_reads_2bit": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
+    "gmx_map_reads_2bit_host": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u64]),
     "gmx_pack_reads": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
     "gmx_engine_reserve": (C.c_int, [_vp, _u64, _u64]),
     "gmx_engine_reserve_packed": (C.c_int, [_vp, _u64, _u64]),

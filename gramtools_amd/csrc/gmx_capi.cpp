@@ -540,6 +540,52 @@ int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t unifo
   return GMX_OK;
 }
 
+// ---- reads as a 2-bit stream (gmx_map_reads_2bit_host): base j of the batch in bits 2j, 2j + 1 of the stream -------------
+uint64_t gmx_twobit_units(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) {
+  const uint64_t bases = uniform_len ? n_reads * (uint64_t)uniform_len : (offsets ? offsets[n_reads] - offsets[0] : 0);
+  return (bases + 31) / 32 + 1;  // (+ 1: the unit the device reads ahead of a chunk's last base)
+}
+
+int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *stream,
+                        uint8_t *skip, int threads) {
+  if ((!reads && n_reads) || !offsets || !stream) {
+    gmx_set_error("gmx_pack_reads_2bit: null argument");
+    return GMX_EINVAL;
+  }
+  if (uniform_len)
+    for (uint64_t r = 0; r < n_reads; ++r)
+      if (offsets[r + 1] - offsets[r] != uniform_len) {
+        gmx_set_error("gmx_pack_reads_2bit: uniform_len given but read " + std::to_string(r) + " has another length");
+        return GMX_EINVAL;
+      }
+  const uint64_t bases = offsets[n_reads] - offsets[0], units = (bases + 31) / 32 + 1;
+  const uint8_t *src = reads + offsets[0];  // the batch's bases lie back to back: base j of the stream is src[j]
+  const unsigned T = (unsigned)std::max(1, std::min(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), 256));
+  auto work = [&](unsigned t) {
+    for (uint64_t u = units * t / T; u < units * (t + 1) / T; ++u) {  // 32 bases -> one 8-byte unit
+      uint64_t w = 0;
+      const uint64_t j0 = u * 32, j1 = std::min(bases, j0 + 32);
+      for (uint64_t j = j0; j < j1; ++j) w |= (uint64_t)((src[j] - 1u) & 3u) << (2 * (j - j0));
+      stream[u] = w;
+    }
+    if (skip)
+      for (uint64_t r = n_reads * t / T; r < n_reads * (t + 1) / T; ++r) {  // encode_dna_bases: any byte outside 1..4
+        uint8_t bad = 0;
+        for (uint64_t j = offsets[r]; j < offsets[r + 1]; ++j) bad |= (uint8_t)(reads[j] - 1u) > 3u;
+        skip[r] = bad;
+      }
+  };
+  if (T == 1 || n_reads < 4096) {
+    for (unsigned t = 0; t < T; ++t) work(t);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  return GMX_OK;
+}
+
 // ---- grouped logs as values: what every rank does with the all-gathered logs of an exchange (gmx_multi.hip) -----------
 // `gathered` holds `world` slices of `pad` words, slice r carrying sizes[r] words of rank r's log (either record form,
 // GMX_LOG_PAD words skipped); the result is one counted record per distinct (site, ids), in key order.

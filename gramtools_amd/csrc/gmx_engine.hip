@@ -3416,6 +3416,8 @@ struct BatchInput {
   const uint32_t *d_seeds = nullptr;
   const uint2 *d_planes = nullptr;      // non-null: packed input, no pack kernel
   const uint8_t *d_skip = nullptr;      // packed input: per-read skip flags, or null
+  const uint32_t *d_twobit = nullptr;   // non-null: the reads as a 2-bit stream (gmx_map_reads_2bit_host); unpacked into d_packed
+  uint32_t twobit_base0 = 0;            // ... whose first base sits at this base index of d_twobit (< 32)
   uint32_t uniform_len = 0;
   uint64_t n_reads = 0, total_bases = 0;
 };
@@ -3425,6 +3427,51 @@ __global__ void gmx_batch_begin_kernel(uint32_t *counters, uint32_t *zero, uint3
   if (blockIdx.x == 0)
     for (uint32_t i = threadIdx.x; i < GMX_N_COUNTERS * GMX_CNT_STRIDE; i += blockDim.x) counters[i] = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < zero_words; i += gridDim.x * blockDim.x) zero[i] = 0;
+}
+
+// Reads that arrive as a 2-bit stream (include/gmx.h, gmx_pack_reads_2bit: base j of the batch in bits 2j, 2j + 1) -> the bit
+// planes the kernels read, in gmx_pack_kernel's layout. One thread per pair of planes (32 bases): three words of the
+// stream, funnel-shifted to the pair's first base, even bits -> low plane, odd bits -> high plane.
+__device__ __forceinline__ uint32_t gmx_even_bits(unsigned long long x) {  // bits 0, 2, 4, .. 62 of x, compacted
+  x &= 0x5555555555555555ull;
+  x = (x | (x >> 1)) & 0x3333333333333333ull;
+  x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (uint32_t)x;
+}
+__global__ void __launch_bounds__(256) gmx_unpack2_kernel(BatchView b, const uint32_t *stream, uint32_t base0, uint2 *packed) {
+  const uint32_t ppr_uniform = b.pairs_per_read;
+  for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;; t += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t read, pair;
+    uint64_t first_base;  // of the read, in the batch's stream
+    uint32_t len;
+    if (b.uniform_len) {
+      read = (uint32_t)(t / ppr_uniform);
+      if (read >= b.n_reads) break;
+      pair = (uint32_t)(t - (uint64_t)read * ppr_uniform);
+      first_base = (uint64_t)read * b.uniform_len;
+      len = b.uniform_len;
+    } else {  // ragged: one thread per read walks its pairs (the plane layout needs the offsets anyway)
+      read = (uint32_t)t;
+      if (read >= b.n_reads) break;
+      pair = 0;
+      first_base = b.offsets[read] - b.offsets[0];
+      len = (uint32_t)(b.offsets[read + 1] - b.offsets[read]);
+    }
+    uint2 *out = packed + pack_off(b, read);
+    const uint32_t n_pairs = b.uniform_len ? pair + 1 : (len + 31u) / 32u;
+    for (uint32_t p = pair; p < n_pairs; ++p) {
+      const uint64_t j = base0 + first_base + 32ull * p;  // base index in the stream of the pair's first base
+      const uint64_t w = j >> 4;                         // 16 bases per word
+      const uint32_t sh = (uint32_t)(j & 15u) * 2u;
+      const uint32_t w0 = stream[w], w1 = stream[w + 1], w2 = stream[w + 2];
+      const unsigned long long bits = (unsigned long long)__builtin_amdgcn_alignbit(w1, w0, sh) |
+                                      ((unsigned long long)__builtin_amdgcn_alignbit(w2, w1, sh) << 32);
+      out[p] = make_uint2(gmx_even_bits(bits), gmx_even_bits(bits >> 1));
+    }
+  }
 }
 
 static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream) {
@@ -3448,7 +3495,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
       e->cap_packed = need;
     }
   }
-  BatchView b{in.d_reads, in.d_offsets, in.d_seeds, in.d_planes ? in.d_skip : e->d_skip, in.d_planes ? in.d_planes : e->d_packed,
+  BatchView b{in.d_reads, in.d_offsets, in.d_seeds, (in.d_planes || in.d_twobit) ? in.d_skip : e->d_skip, in.d_planes ? in.d_planes : e->d_packed,
               (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0), in.uniform_len, (in.uniform_len + 31u) / 32u};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{};  // (member by member: the struct's order is not part of any contract)
@@ -3504,10 +3551,15 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.log_retry_huge = e->d_log_retry_huge[e->log_retry_side];
   o.stats = e->d_stats;
   uint32_t n_tasks = (uint32_t)n_reads * 2;
-  if (in.d_planes)
+  if (in.d_planes || in.d_twobit) {
     hipLaunchKernelGGL(gmx_batch_begin_kernel, dim3(fold_reset ? 256 : 1), dim3(1024), 0, stream, e->d_counters,
                        fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
-  else
+    if (in.d_twobit) {
+      const uint64_t threads = in.uniform_len ? n_reads * ((in.uniform_len + 31u) / 32u) : n_reads;
+      hipLaunchKernelGGL(gmx_unpack2_kernel, dim3((unsigned)std::min<uint64_t>((threads + 255) / 256, 1u << 20)), dim3(256), 0, stream, b, in.d_twobit,
+                         in.twobit_base0, e->d_packed);
+    }
+  } else
     hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
                        e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
@@ -3813,17 +3865,20 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
   return gmx_engine_sync(e);
 }
 
-int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
-                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+// planes: the bit planes (twobit = false) or the 2-bit stream as 32-bit words (twobit = true; gmx_map_reads_2bit_host)
+static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool twobit, const uint64_t *offsets, uint32_t uniform_len,
+                                 const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
   if (!e || !planes || !seeds || (!offsets && !uniform_len)) {
-    gmx_set_error("gmx_map_reads_packed_host: null argument (offsets may be null only with uniform_len)");
+    gmx_set_error("gmx_map_reads_packed_host / gmx_map_reads_2bit_host: null argument (offsets may be null only with uniform_len)");
     return GMX_EINVAL;
   }
   if (n_reads == 0) return GMX_OK;
   HIP_TRY(hipSetDevice(e->opts.device));
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   const uint32_t ppr = (uniform_len + 31u) / 32u;
-  auto pair_at = [&](uint64_t r) -> uint64_t {  // pairs from the call's first read to read r (gmx.h: layout of `planes`)
+  auto base_at = [&](uint64_t r) -> uint64_t { return uniform_len ? r * uniform_len : offsets[r] - offsets[0]; };
+  auto pair_at = [&](uint64_t r) -> uint64_t {  // 8-byte units from the call's first read to read r (gmx.h: layout of `planes`;
+    if (twobit) return (base_at(r) + 31) >> 5;  //  a 2-bit stream: 32 bases per unit, rounded up)
     return uniform_len ? r * ppr : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r;
   };
   // buffers the runtime cannot DMA from are registered for the duration of the call, which then waits for its uploads
@@ -3857,7 +3912,14 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     gmx_engine::PackSlot &sl = e->pslot[e->pslot_next];
     e->pslot_next = (e->pslot_next + 1) % 3;
     const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
-    const uint64_t p0 = pair_at(done), pairs = pair_at(done + n) - p0;
+    uint64_t p0 = pair_at(done), pairs = pair_at(done + n) - p0;
+    uint32_t twobit_base0 = 0;
+    if (twobit) {  // the chunk's bases from the 8-byte unit holding its first one
+      const uint64_t b0 = base_at(done), b1 = base_at(done + n);
+      p0 = b0 >> 5;
+      pairs = ((b1 + 31) >> 5) - p0;
+      twobit_base0 = (uint32_t)(b0 & 31u);
+    }
     if (sl.busy) {  // the batch that used this slot three chunks ago
       if (!hip_ok(hipEventSynchronize(sl.done), "hipEventSynchronize")) break;
       sl.busy = false;
@@ -3914,7 +3976,9 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     BatchInput in;
     in.d_offsets = uniform_len ? nullptr : sl.d_offsets;
     in.d_seeds = d_seeds_host ? d_seeds_host + done : sl.d_seeds;
-    in.d_planes = sl.d_planes;
+    in.d_planes = twobit ? nullptr : sl.d_planes;
+    in.d_twobit = twobit ? reinterpret_cast<const uint32_t *>(sl.d_planes) : nullptr;
+    in.twobit_base0 = twobit_base0;
     in.d_skip = skip ? sl.d_skip : nullptr;
     in.uniform_len = uniform_len;
     in.n_reads = n;
@@ -3936,6 +4000,16 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
     if (regs[i].on) (void)hipHostUnregister(const_cast<void *>(regs[i].p));
   (void)hipGetLastError();
   return rc;
+}
+
+int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
+                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+  return map_reads_packed_impl(e, planes, false, offsets, uniform_len, seeds, skip, n_reads);
+}
+
+int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_t *offsets, uint32_t uniform_len, const uint32_t *seeds,
+                            const uint8_t *skip, uint64_t n_reads) {
+  return map_reads_packed_impl(e, stream, true, offsets, uniform_len, seeds, skip, n_reads);
 }
 
 int gmx_engine_seeds_in_place(gmx_engine *e, int on) {

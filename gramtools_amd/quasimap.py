@@ -115,6 +115,37 @@ def pack_reads(reads_flat, offsets, uniform_len: int = 0, threads: int = 0, pinn
     return PackedReads(planes, off_out, uniform_len, skip, n, tuple(keep))
 
 
+def pack_reads_2bit(reads_flat, offsets, uniform_len: int = 0, threads: int = 0, pinned: bool = False) -> PackedReads:
+    """Encoded reads -> the 2-bit stream of gmx_map_reads_2bit_host (gmx_pack_reads_2bit): the reads back to back, two bits
+    per base, 32 bases per uint64. Returned as a PackedReads whose ``planes`` is the stream and ``twobit`` is True."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(reads_flat, dtype=np.uint8)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = o.size - 1
+    if r.size == 0:
+        r = np.zeros(1, dtype=np.uint8)
+    units = int(lib.gmx_twobit_units(_p(o, C.c_uint64), uniform_len, n))
+    keep = []
+    if pinned:
+        pa, sk = PinnedArray(units + 8, np.uint64), PinnedArray(max(n, 1), np.uint8)
+        keep = [pa, sk]
+        stream, skip = pa.array, sk.array
+        stream[units:] = 0
+        off_out = None
+        if not uniform_len:
+            po = PinnedArray(n + 1, np.uint64)
+            keep.append(po)
+            po.array[:] = o
+            off_out = po.array
+    else:
+        stream, skip = np.zeros(units + 8, dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint8)
+        off_out = None if uniform_len else o
+    check(lib.gmx_pack_reads_2bit(r.ctypes.data, o.ctypes.data, uniform_len, n, stream.ctypes.data, skip.ctypes.data, threads))
+    pk = PackedReads(stream, off_out, uniform_len, skip, n, tuple(keep))
+    pk.twobit = True
+    return pk
+
+
 class Index:
     """Everything the mapping path needs, derived from the integer PRG and the k-mer size."""
 
@@ -445,9 +476,9 @@ class Quasimapper:
         s = seeds if isinstance(seeds, np.ndarray) and seeds.dtype == np.uint32 and seeds.flags.c_contiguous else \
             np.ascontiguousarray(seeds, dtype=np.uint32)
         skip = packed.skip if use_skip else None
-        check(self.lib.gmx_map_reads_packed_host(
-            self.h, packed.planes.ctypes.data, None if packed.offsets is None else packed.offsets.ctypes.data,
-            packed.uniform_len, s.ctypes.data, None if skip is None else skip.ctypes.data, packed.n_reads))
+        fn = self.lib.gmx_map_reads_2bit_host if getattr(packed, "twobit", False) else self.lib.gmx_map_reads_packed_host
+        check(fn(self.h, packed.planes.ctypes.data, None if packed.offsets is None else packed.offsets.ctypes.data,
+                 packed.uniform_len, s.ctypes.data, None if skip is None else skip.ctypes.data, packed.n_reads))
         self._last_seeds = s  # (kept alive while the upload may be in flight)
 
     def sync_uploads(self):

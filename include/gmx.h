@@ -180,6 +180,17 @@ uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_
  * that long (GMX_EINVAL otherwise). */
 int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *planes,
                    uint8_t *skip, int threads);
+/* The same feed with the reads as a 2-bit STREAM: base j of the call (the reads back to back, in order) in bits 2j, 2j + 1 of
+ * `stream` (little-endian: 32 bases per uint64, base 0 in the lowest bits; A,C,G,T = 0,1,2,3). A read starts wherever the
+ * one before it ends — 37.5 bytes per 150 bp read over PCIe instead of the planes' 40, 25 instead of 32 per 100 bp read — and
+ * the first kernel of the batch turns the stream into the bit planes (gmx_unpack2_kernel, HBM to HBM). offsets / uniform_len /
+ * seeds / skip, asynchrony and gmx_engine_sync_uploads as for gmx_map_reads_packed_host; gmx_twobit_units() gives the
+ * length of `stream` in uint64 (one unit of slack included), gmx_pack_reads_2bit() makes it from encoded bytes. */
+int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_t *offsets, uint32_t uniform_len,
+                            const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads);
+uint64_t gmx_twobit_units(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads);
+int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *stream,
+                        uint8_t *skip, int threads);
 /* Page-locked host memory for the buffers handed to gmx_map_reads_host: the upload is then one DMA at the PCIe rate
  * instead of being staged through small pinned chunks by the runtime. Falls back to plain memory without a device (the
  * parsers also run in tests without one). gmx_host_free takes only pointers gmx_host_alloc returned. */

@@ -206,3 +206,64 @@ def test_seeds_read_in_place_give_the_same_draws():
     assert canonical_cov(qm.coverage()) == want
     pk.close()
     sd.close()
+
+
+def test_two_bit_stream_layout():
+    """gmx_pack_reads_2bit: base j of the batch in bits 2j, 2j + 1 — the reads back to back, whatever their lengths."""
+    from gramtools_amd import pack_reads_2bit
+    rng = np.random.default_rng(9)
+    reads = [rng.integers(1, 5, size=int(L)).astype(np.uint8) for L in rng.integers(0, 200, size=300)]
+    reads[5] = reads[5].copy()
+    if len(reads[5]) == 0:
+        reads[5] = np.array([1, 2, 3], dtype=np.uint8)
+    reads[5][0] = 0
+    flat, offs = flatten_reads(reads)
+    for threads in (1, 4):
+        pk = pack_reads_2bit(flat, offs, threads=threads)
+        bits = np.unpackbits(pk.planes.view(np.uint8), bitorder="little")
+        codes = bits[0:2 * flat.size:2] | (bits[1:2 * flat.size:2] << 1)
+        ok = np.ones(flat.size, dtype=bool)
+        ok[int(offs[5]):int(offs[6])] = False  # a skipped read's bits are not defined
+        assert (codes[ok] == (flat[ok] - 1)).all()
+        assert pk.skip[5] == 1 and pk.skip[:5].sum() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [False, True])
+def test_two_bit_stream_feed_equals_oracle(pinned):
+    from gramtools_amd import pack_reads_2bit
+    # uniform reads on a SNP PRG, several chunks per call
+    prg, reads = _snp_case(6000, 41)
+    k = 7
+    seeds = master_seeds(13, [len(reads)])
+    want = oracle_map(prg, k, list(reads), seeds, threads=8)
+    flat, offs = flatten_reads(list(reads))
+    ix = Index(prg, k)
+    for batch in (None, 1100):
+        pk = pack_reads_2bit(flat, offs, uniform_len=reads.shape[1], pinned=pinned)
+        qm = Quasimapper(ix) if batch is None else Quasimapper(ix, max_batch_reads=batch)
+        qm.map_reads_packed(pk, seeds)
+        assert canonical_cov(qm.coverage()) == want
+        pk.close()
+    # ragged reads with Ns and an empty read on a nested PRG
+    rng = np.random.default_rng(3)
+    prg = bracket_to_ints(nested_prg(17, n_top=12, max_depth=2, seq_max=8))
+    k = 4
+    rr = []
+    for i, r in enumerate(simulate_graph_reads(prg, 1500, 40, 21)):
+        r = np.asarray(r, dtype=np.uint8)
+        if i % 5 == 0:
+            r = r[:int(rng.integers(k, len(r) + 1))]
+        if i % 11 == 0 and len(r):
+            r = r.copy()
+            r[int(rng.integers(0, len(r)))] = 0
+        rr.append(r)
+    rr.append(np.zeros(0, dtype=np.uint8))
+    seeds = master_seeds(7, [len(rr)])
+    want = oracle_map(prg, k, rr, seeds)
+    flat, offs = flatten_reads(rr)
+    pk = pack_reads_2bit(flat, offs, pinned=pinned)
+    qm = Quasimapper(Index(prg, k), max_batch_reads=400)
+    qm.map_reads_packed(pk, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    pk.close()
