@@ -2924,8 +2924,6 @@ struct gmx_engine {
     bool busy = false;
   } stage[2];
   hipStream_t copy_stream = nullptr;
-  hipStream_t copy_stream2 = nullptr;  // the second half of a batch's planes (GMX_COPY_SPLIT=1: two DMA engines side by side)
-  hipEvent_t ev_copy2 = nullptr;
   hipStream_t last_stream = nullptr;
   // gmx_map_reads_packed_host: three slots of device buffers for bit planes, offsets, seeds and skip flags; the upload of
   // a chunk (copy stream, straight from the caller's page-locked buffers) runs beside the kernels of the chunks before
@@ -3290,8 +3288,6 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-  if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
-  if (e->ev_copy2) (void)hipEventDestroy(e->ev_copy2);
   if (e->h_log_state) (void)hipHostFree(e->h_log_state);
   if (e->ev_log_state) (void)hipEventDestroy(e->ev_log_state);
   for (auto &sl : e->pslot) {
@@ -3949,20 +3945,9 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
       if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false)) || (rc = e->alloc(&sl.d_skip, cr, false))) break;
       sl.cap_reads = cr;
     }
-    static const bool copy_split = getenv("GMX_COPY_SPLIT") && atoi(getenv("GMX_COPY_SPLIT")) != 0;
-    uint64_t first_part = pairs;
-    if (copy_split && pairs >= (1u << 16)) {
-      if (!e->copy_stream2 && (!hip_ok(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking), "hipStreamCreate") ||
-                               !hip_ok(hipEventCreateWithFlags(&e->ev_copy2, hipEventDisableTiming), "hipEventCreate")))
-        break;
-      first_part = pairs / 2;
-      if (!hip_ok(hipMemcpyAsync(sl.d_planes + first_part, planes + p0 + first_part, (pairs - first_part) * 8, hipMemcpyHostToDevice, e->copy_stream2),
-                  "hipMemcpyAsync(planes, second half)") ||
-          !hip_ok(hipEventRecord(e->ev_copy2, e->copy_stream2), "hipEventRecord"))
-        break;
-    }
-    if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, first_part * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(planes)")) break;
-    if (first_part != pairs && !hip_ok(hipStreamWaitEvent(e->copy_stream, e->ev_copy2, 0), "hipStreamWaitEvent")) break;
+    // (one copy stream: the planes split over two streams reach 31-37 GB/s instead of 51, and a kernel pulling the stream
+    //  out of the caller's page-locked memory itself 34 GB/s — both measured in round 3 and removed)
+    if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, pairs * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(planes)")) break;
     if (!uniform_len &&
         !hip_ok(hipMemcpyAsync(sl.d_offsets, offsets + done, (n + 1) * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(offsets)"))
       break;
