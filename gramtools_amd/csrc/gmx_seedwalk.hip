@@ -47,6 +47,56 @@ namespace {
     if (e_ != hipSuccess) throw std::runtime_error(std::string("device walk: ") + #x + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Device buffers of the walk come from a pool: a level needs a dozen arrays of the level's size and the next level a dozen
+// of much the same size, and hipMalloc of memory another process used before is not free (the driver clears it: with
+// hipMalloc / hipFree per level the eleven levels of the chr20-scale walk took 1.8 s on a box that had run other GPU work,
+// 0.12 s on a fresh one). A released block is handed out again to a request of up to its size that fills at least half of it.
+struct DevPool {
+  struct Block {
+    void *p;
+    size_t bytes;
+  };
+  std::vector<Block> spare;
+  void *get(size_t bytes) {
+    size_t best = spare.size();
+    for (size_t i = 0; i < spare.size(); ++i)
+      if (spare[i].bytes >= bytes && spare[i].bytes <= 2 * bytes + (1u << 20) && (best == spare.size() || spare[i].bytes < spare[best].bytes)) best = i;
+    if (best != spare.size()) {
+      void *p = spare[best].p;
+      taken.push_back(spare[best]);
+      spare.erase(spare.begin() + (long)best);
+      return p;
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {  // out of device memory with blocks set aside: give them back and try once more
+      (void)hipGetLastError();
+      trim();
+      WCK(hipMalloc(&p, bytes));
+    }
+    taken.push_back(Block{p, bytes});
+    return p;
+  }
+  void put(void *p) {
+    for (size_t i = 0; i < taken.size(); ++i)
+      if (taken[i].p == p) {
+        spare.push_back(taken[i]);
+        taken.erase(taken.begin() + (long)i);
+        return;
+      }
+    (void)hipFree(p);
+  }
+  void trim() {
+    for (auto &b : spare) (void)hipFree(b.p);
+    spare.clear();
+  }
+  ~DevPool() {
+    trim();
+    for (auto &b : taken) (void)hipFree(b.p);
+  }
+  std::vector<Block> taken;
+};
+static thread_local DevPool *g_pool = nullptr;
+
 template <class T>
 struct DBuf {
   T *p = nullptr;
@@ -56,13 +106,18 @@ struct DBuf {
   DBuf &operator=(const DBuf &) = delete;
   ~DBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      if (g_pool) g_pool->put(p);
+      else (void)hipFree(p);
+    }
     p = nullptr;
     n = 0;
   }
   void alloc(size_t count) {
     release();
-    WCK(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)));
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (g_pool) p = static_cast<T *>(g_pool->get(bytes));
+    else WCK(hipMalloc(reinterpret_cast<void **>(&p), bytes));
     n = count;
   }
   void swap(DBuf &o) {
@@ -403,6 +458,11 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
     (void)hipGetLastError();
     return false;
   }
+  DevPool pool;  // (declared first: every buffer below goes back to it before it is destroyed)
+  struct PoolScope {
+    explicit PoolScope(DevPool *p) { g_pool = p; }
+    ~PoolScope() { g_pool = nullptr; }
+  } pool_scope(&pool);
   const bool trace = getenv("GMX_BUILD_TRACE") != nullptr;
   const bool trace2 = trace && atoi(getenv("GMX_BUILD_TRACE")) >= 2;  // every level
   const double t_start = now_s();
