@@ -30,6 +30,8 @@ def _stale(target, sources):
 def _link(target, extra_flags, tag, force, verbose):
     """One object per source under lib/obj (rebuilt when the source or a header is newer), then the shared object."""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    if not force and not _stale(target, [os.path.join(CSRC, name) for name in LIB_SOURCES] + hdrs):
+        return target  # (the shared object travels to the GPU box without its objects: nothing to do there)
     obj_dir = os.path.join(LIB_DIR, "obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
     objs, jobs = [], []
