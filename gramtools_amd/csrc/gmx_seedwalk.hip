@@ -698,7 +698,8 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
   }
   const double t1 = now_s();
   // (10.7 GB at chr20 scale into fresh pageable host memory: 1.4 s. Page-locking the destination for the copy —
-  // GMX_WALK_PIN=1 — was measured at 1.76 s: registering the pages costs more than the staged copy saves.)
+  // GMX_WALK_PIN=1 — was measured at 1.76 s: registering the pages costs more than the staged copy saves; DMA into two
+  // page-locked staging blocks with sixteen host threads copying on: 1.4 s again — the host side of the copy is the limit.)
   auto download = [&](void *dst, const void *src, size_t bytes) {
     static const bool pin = getenv("GMX_WALK_PIN") && atoi(getenv("GMX_WALK_PIN")) != 0;
     const bool pinned = pin && bytes >= ((size_t)64 << 20) && hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess;
