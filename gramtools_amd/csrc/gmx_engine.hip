@@ -39,7 +39,9 @@
 #include "gmx_index.h"
 #include "gmx_internal.h"
 
+#ifndef GMX_BLOCK
 #define GMX_BLOCK 256
+#endif
 #ifndef GMX_FAST_STATES
 #define GMX_FAST_STATES 8     // final / parked states kept per task by the fast pass
 #endif
@@ -853,7 +855,9 @@ struct SearchOut {
                              // (filter kernels, large-capacity passes) [4] exact_mapped (whoever finished the search)
 };
 
+#ifndef GMX_REGIONS
 #define GMX_REGIONS 8
+#endif
 enum : uint32_t { GMX_TL_OVERFLOW = 0, GMX_TL_OVERFLOW2, GMX_TL_ALIVE, GMX_TL_DEAD, GMX_TL_DEAD2, GMX_TL_GENERAL, GMX_TL_ALIVE2, GMX_TL_N = GMX_TL_ALIVE2 + GMX_EXTRA_PASSES };
 
 // stats[idx] += number of threads of the block with `flag` (one global atomic per block). Every thread of the block
