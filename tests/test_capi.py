@@ -78,3 +78,23 @@ def test_reserve_sizes_the_workspace_ahead_of_the_first_call():
     assert b.lib.gmx_engine_reserve(b.h, 100, 100) == 0  # smaller: nothing to do
     b.map_reads(reads.reshape(-1), flat_offsets(3000, 150), seeds)
     assert canonical_cov(a.coverage()) == canonical_cov(b.coverage())
+
+
+def test_two_bit_stream_packer_argument_checks():
+    """gmx_pack_reads_2bit / gmx_twobit_units (host side of gmx_map_reads_2bit_host): sizes and GMX_EINVAL, no device needed."""
+    import ctypes as C
+    import numpy as np
+    from gramtools_amd import _lib
+    lib = _lib.load()
+    offs = np.array([0, 150, 300, 450], dtype=np.uint64)
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint64))
+    assert lib.gmx_twobit_units(p64(offs), 0, 3) == (450 + 31) // 32 + 1
+    assert lib.gmx_twobit_units(None, 150, 3) == (450 + 31) // 32 + 1
+    reads = np.ones(450, dtype=np.uint8)
+    out = np.zeros(20, dtype=np.uint64)
+    assert lib.gmx_pack_reads_2bit(reads.ctypes.data, offs.ctypes.data, 150, 3, out.ctypes.data, None, 1) == 0
+    assert lib.gmx_pack_reads_2bit(reads.ctypes.data, offs.ctypes.data, 151, 3, out.ctypes.data, None, 1) == -1   # GMX_EINVAL: another length
+    assert b"another length" in lib.gmx_last_error()
+    assert lib.gmx_pack_reads_2bit(None, offs.ctypes.data, 150, 3, out.ctypes.data, None, 1) == -1
+    assert lib.gmx_map_reads_2bit_host(None, out.ctypes.data, None, 150, out.ctypes.data, None, 3) == -1
+    assert lib.gmx_engine_seeds_in_place(None, 1) == -1

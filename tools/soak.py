@@ -48,3 +48,35 @@ while time.perf_counter() - t0 < secs:
     assert st["all"] == 2 * n * 2000 and st["exact_mapped"] == n * 2000, st
 dt = time.perf_counter() - t0
 print(f"{batches} batches of {n} reads in {dt:.1f} s = {batches * n / dt / 1e9:.2f} G reads/s; counters exact after every 2 000 batches")
+
+# ---- the host feeds of round 3: planes and the 2-bit stream from page-locked memory, seeds uploaded / read in place, engines
+# created and destroyed around them (upload slots, copy stream and page-locked blocks must come back too) ----
+from gramtools_amd import pack_reads, pack_reads_2bit, PinnedArray  # noqa: E402
+
+want = None
+free_before = torch.cuda.mem_get_info()[0]
+for rnd in range(6):
+    for packer in (pack_reads, pack_reads_2bit):
+        pk = packer(reads.reshape(-1), offs, uniform_len=150, pinned=True)
+        sd = PinnedArray(n, np.uint32)
+        sd.array[:] = seeds
+        q = Quasimapper(ix)
+        q.seeds_in_place(rnd % 2 == 1)
+        t1 = time.perf_counter()
+        for _ in range(50):
+            q.map_reads_packed(pk, sd.array, use_skip=False)
+        cov = q.coverage()
+        dt1 = time.perf_counter() - t1
+        st = cov.stats.as_dict()
+        assert st["all"] == 2 * n * 50 and st["exact_mapped"] == n * 50, st
+        sums = (int(cov.raw_allele_sum.astype(np.int64).sum()), int(cov.raw_per_base.astype(np.int64).sum()), int(cov.raw_grouped.astype(np.int64).sum()))
+        assert want is None or sums == want, (sums, want)  # every feed, every round: the same coverage totals
+        want = sums
+        q.close()
+        pk.close()
+        sd.close()
+        print(f"round {rnd} {packer.__name__:16s} seeds {'in place' if rnd % 2 else 'uploaded'}: {50 * n / dt1 / 1e9:.2f} G reads/s host-inclusive, totals {sums}", flush=True)
+torch.cuda.synchronize()
+leak = free_before - torch.cuda.mem_get_info()[0]
+print(f"device memory not returned after 12 engines with host feeds: {leak / 1e6:.1f} MB")
+assert leak < 64 << 20
