@@ -991,65 +991,108 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     out.sentinel_pos = sentinel.load();
   }
   // symbol -> first SA index (FM-index C array over the compacted alphabet)
-  std::map<uint32_t, uint32_t> sym_first;
-  std::vector<uint32_t> sym_count;  // a flat array: one map look-up per symbol costs minutes at 10^9 symbols
+  // symbol -> first SA index (FM-index C array over the compacted alphabet) and count: flat arrays (a map look-up per symbol
+  // costs minutes at 10^9 symbols, and a map of 170 M marker symbols takes a minute to build); counted on all threads — the
+  // four bases in thread-local counters, the markers (under 1 % of the symbols, each a few times) with relaxed atomics.
+  const unsigned hw_sym = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+  std::vector<uint32_t> sym_count, sym_first;
   {
     uint32_t max_sym = 0;
-    for (auto s : text) max_sym = std::max(max_sym, s);
-    sym_count.assign((size_t)max_sym + 1, 0);
-    for (auto s : text) sym_count[s]++;
-    uint32_t acc = 0;
-    for (size_t c = 0; c < sym_count.size(); ++c)
-      if (sym_count[c]) {
-        sym_first[(uint32_t)c] = acc;
-        acc += sym_count[c];
+    {
+      std::vector<uint32_t> part_max(64, 0);
+      par_for(64, hw_sym, [&](size_t c) {
+        uint32_t m = 0;
+        for (size_t i = n * c / 64; i < n * (c + 1) / 64; ++i) m = std::max(m, text[i]);
+        part_max[c] = m;
+      });
+      for (uint32_t m : part_max) max_sym = std::max(max_sym, m);
+    }
+    std::unique_ptr<std::atomic<uint32_t>[]> cnt(new std::atomic<uint32_t>[(size_t)max_sym + 1]);
+    par_for(64, hw_sym, [&](size_t c) {
+      for (size_t s = ((size_t)max_sym + 1) * c / 64; s < ((size_t)max_sym + 1) * (c + 1) / 64; ++s) cnt[s].store(0, std::memory_order_relaxed);
+    });
+    std::vector<std::array<uint64_t, 8>> base_cnt(64);
+    par_for(64, hw_sym, [&](size_t c) {
+      std::array<uint64_t, 8> local{};
+      for (size_t i = n * c / 64; i < n * (c + 1) / 64; ++i) {
+        const uint32_t s = text[i];
+        if (s <= 4) local[s]++;
+        else cnt[s].fetch_add(1, std::memory_order_relaxed);
       }
+      base_cnt[c] = local;
+    });
+    sym_count.assign((size_t)max_sym + 1, 0);
+    par_for(64, hw_sym, [&](size_t c) {
+      for (size_t s = ((size_t)max_sym + 1) * c / 64; s < ((size_t)max_sym + 1) * (c + 1) / 64; ++s) sym_count[s] = cnt[s].load(std::memory_order_relaxed);
+    });
+    for (uint32_t s = 0; s <= 4 && s <= max_sym; ++s) {
+      uint64_t t = 0;
+      for (auto const &bc : base_cnt) t += bc[s];
+      sym_count[s] = (uint32_t)t;
+    }
+    sym_first.assign((size_t)max_sym + 2, 0);  // exclusive sums of the counts (one pass: a dependent chain, 4 B per symbol value)
+    uint32_t acc = 0;
+    for (size_t c = 0; c < sym_count.size(); ++c) {
+      sym_first[c] = acc;
+      acc += sym_count[c];
+    }
   }
   for (uint32_t c = 1; c <= 4; ++c) {
     // char2comp of an absent symbol is 0 in SDSL, C[0] = 0; an absent base never yields a valid interval
-    out.C[c] = sym_first.count(c) ? sym_first[c] : 0;
+    out.C[c] = c < sym_count.size() && sym_count[c] ? sym_first[c] : 0;
   }
   size_t n_blocks = (n >> GMX_BLK_SHIFT) + 1;
   out.blocks.assign(n_blocks, GmxRankBlock{});
-  {
-    uint32_t cA = 0, cC = 0, cG = 0, cM = 0;
-    for (size_t b = 0; b < n_blocks; ++b) {
-      GmxRankBlock &blk = out.blocks[b];
-      blk.cnt[0] = cA;
-      blk.cnt[1] = cC;
-      blk.cnt[2] = cG;
-      blk.cnt[3] = cM;
-      for (size_t j = 0; j < 128; ++j) {
-        size_t i = (b << GMX_BLK_SHIFT) + j;
-        if (i >= n) break;
-        uint32_t c = out.bwt[i];
-        size_t w = j >> 6, bit = j & 63;
-        if (c > 4) {
-          blk.mk[w] |= 1ull << bit;
-          cM++;
-        } else if (c == 0 || c == 1) {
-          cA++;  // sentinel counted with A (raw count), corrected at query time
-        } else if (c == 2) {
-          blk.lo[w] |= 1ull << bit;
-          cC++;
-        } else if (c == 3) {
-          blk.hi[w] |= 1ull << bit;
-          cG++;
-        } else {
-          blk.lo[w] |= 1ull << bit;
-          blk.hi[w] |= 1ull << bit;
+  {  // in pieces of blocks on all threads: bit planes and the piece's own counts, then the running counts added
+    const size_t piece = 1u << 15, n_pieces = (n_blocks + piece - 1) / piece;
+    std::vector<std::array<uint32_t, 4>> piece_cnt(n_pieces + 1, std::array<uint32_t, 4>{0, 0, 0, 0});
+    par_for(n_pieces, hw_sym, [&](size_t pc) {
+      uint32_t cA = 0, cC = 0, cG = 0, cM = 0;
+      for (size_t b = pc * piece; b < std::min(n_blocks, (pc + 1) * piece); ++b) {
+        GmxRankBlock &blk = out.blocks[b];
+        blk.cnt[0] = cA;  // (within the piece: the pieces before are added below)
+        blk.cnt[1] = cC;
+        blk.cnt[2] = cG;
+        blk.cnt[3] = cM;
+        for (size_t j = 0; j < 128; ++j) {
+          size_t i = (b << GMX_BLK_SHIFT) + j;
+          if (i >= n) break;
+          uint32_t c = out.bwt[i];
+          size_t w = j >> 6, bit = j & 63;
+          if (c > 4) {
+            blk.mk[w] |= 1ull << bit;
+            cM++;
+          } else if (c == 0 || c == 1) {
+            cA++;  // sentinel counted with A (raw count), corrected at query time
+          } else if (c == 2) {
+            blk.lo[w] |= 1ull << bit;
+            cC++;
+          } else if (c == 3) {
+            blk.hi[w] |= 1ull << bit;
+            cG++;
+          } else {
+            blk.lo[w] |= 1ull << bit;
+            blk.hi[w] |= 1ull << bit;
+          }
         }
       }
-    }
+      piece_cnt[pc + 1] = {cA, cC, cG, cM};
+    });
+    for (size_t pc = 0; pc < n_pieces; ++pc)
+      for (int q = 0; q < 4; ++q) piece_cnt[pc + 1][q] += piece_cnt[pc][q];
+    par_for(n_pieces, hw_sym, [&](size_t pc) {
+      if (pc == 0) return;
+      for (size_t b = pc * piece; b < std::min(n_blocks, (pc + 1) * piece); ++b)
+        for (int q = 0; q < 4; ++q) out.blocks[b].cnt[q] += piece_cnt[pc][q];
+    });
   }
 
   build_trace("suffix array, BWT, rank blocks");
   // --- jump programs --------------------------------------------------------------
   // marker SA intervals: site marker -> single index; allele marker -> [C[m], C[next symbol] - 1]
   auto marker_first = [&](uint32_t m) -> uint32_t {
-    auto it = sym_first.find(m);
-    if (it == sym_first.end()) throw std::runtime_error("marker " + std::to_string(m) + " absent from the PRG");
-    return it->second;
+    if (m >= sym_count.size() || sym_count[m] == 0) throw std::runtime_error("marker " + std::to_string(m) + " absent from the PRG");
+    return sym_first[m];
   };
   auto marker_last = [&](uint32_t m) -> uint32_t { return marker_first(m) + sym_count[m] - 1; };
   struct Work {
