@@ -398,26 +398,34 @@ struct GraphBuild {
   std::unordered_map<uint32_t, std::pair<uint32_t, int32_t>> parent;  // par_map
   std::map<uint32_t, std::vector<TargetedMarker>> target_map;
   std::vector<std::pair<uint32_t, int32_t>> pos_target;
-  std::map<uint32_t, std::pair<uint32_t, uint32_t>> bubbles;  // site -> (entry, exit)
-  std::map<uint32_t, uint64_t> site_ref_pos;                   // site -> pos of its bubble start
+  struct Bubble {
+    uint32_t site, entry, exit;  // site marker; its entry and exit nodes
+    uint64_t ref_pos;            // pos of its bubble start
+  };
+  std::vector<Bubble> bubbles;  // ascending site marker (sorted at the end of build_graph: a map insert per site costs seconds at 10^7 sites)
 };
 
 void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
   const size_t N = prg.size();
   // linearised_prg.cpp:52-80: last position of each allele marker; duplicate site markers are an error
-  std::unordered_map<uint32_t, size_t> end_pos;
+  // (flat tables over the marker values: two hash maps with an entry per marker took a third of this function)
+  uint32_t max_marker = 0;
+  for (size_t p = 0; p < N; ++p) max_marker = std::max(max_marker, prg[p]);
+  if ((uint64_t)max_marker > 2ull * N + 16)  // (N symbols cannot hold that many sites: numbered with a gap; no 16 GB table for it)
+    throw std::runtime_error("site markers must be numbered 5,7,9,... without gaps (found " + std::to_string(max_marker - (max_marker & 1 ? 0u : 1u)) + ")");
+  std::vector<uint32_t> end_pos((size_t)max_marker + 1, 0);  // position + 1 of the marker's last occurrence (0: none)
   {
-    std::unordered_map<uint32_t, bool> seen;
+    std::vector<uint8_t> seen((size_t)max_marker + 1, 0);
     for (size_t p = 0; p < N; ++p) {
       uint32_t m = prg[p];
       if (m == 0) throw std::runtime_error("PRG symbols must be >= 1");
       if (m <= 4) continue;
       if (m & 1) {
-        if (seen.count(m))
+        if (seen[m])
           throw std::runtime_error("PRG consistency error: site marker " + std::to_string(m) + " used for two different sites");
-        seen[m] = true;
+        seen[m] = 1;
       } else
-        end_pos[m] = p;
+        end_pos[m] = (uint32_t)p + 1u;
     }
   }
   g.pos_node.assign(N, 0);
@@ -473,15 +481,14 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
         if (!g.target_map.count(m)) g.target_map[m] = {TargetedMarker{target, -1}};
       }
       stack.push_back(OpenSite{m, entry, exit, 0, cur_pos, cur_pos});
-      g.bubbles[m] = {entry, exit};
-      g.site_ref_pos[m] = cur_pos;
+      g.bubbles.push_back(GraphBuild::Bubble{m, entry, exit, cur_pos});
       back = entry;
       g.pos_node[p] = entry;
     } else {
       if (stack.empty() || stack.back().site + 1 != m)
         throw std::runtime_error("PRG consistency error: allele marker " + std::to_string(m) + " does not close the open site");
       OpenSite &top = stack.back();
-      bool last = end_pos.at(m) == p;
+      bool last = end_pos[m] == (uint32_t)p + 1u;
       t = last ? MType::site_end : MType::allele_end;
       int32_t ending_allele = top.allele;
       if (prev_t != MType::sequence) {
@@ -526,6 +533,8 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
   if (!stack.empty()) throw std::runtime_error("PRG consistency error: site " + std::to_string(stack.back().site) + " is never closed");
   uint32_t sink = new_node(0, -1, (uint32_t)N);
   wire(sink);
+  auto by_site = [](const GraphBuild::Bubble &a, const GraphBuild::Bubble &b) { return a.site < b.site; };
+  if (!std::is_sorted(g.bubbles.begin(), g.bubbles.end(), by_site)) std::sort(g.bubbles.begin(), g.bubbles.end(), by_site);
 }
 
 // ---------------------------------------------------------------------------
@@ -824,8 +833,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   {
     uint32_t expect = 5;
     for (auto &b : g.bubbles) {
-      if (b.first != expect)
-        throw std::runtime_error("site markers must be numbered 5,7,9,... without gaps (found " + std::to_string(b.first) + ")");
+      if (b.site != expect)
+        throw std::runtime_error("site markers must be numbered 5,7,9,... without gaps (found " + std::to_string(b.site) + ")");
       expect += 2;
     }
   }
@@ -866,12 +875,12 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   if (const char *dm = getenv("GMX_DENSE_MAX_ALLELES")) dense_max = (uint32_t)std::min(10, std::max(1, atoi(dm)));
   out.site_ref_pos.assign(out.sites.size(), 0);
   for (auto &b : g.bubbles) {
-    uint32_t idx = (b.first - 5) / 2;
+    uint32_t idx = (b.site - 5) / 2;
     GmxSite &s = out.sites[idx];
-    auto pit = g.parent.find(b.first);
+    auto pit = g.parent.find(b.site);
     s.parent_site = pit == g.parent.end() ? 0 : pit->second.first;
     s.parent_allele = pit == g.parent.end() ? -1 : pit->second.second;
-    s.n_alleles = (uint32_t)g.nodes[b.second.first].next.size();
+    s.n_alleles = (uint32_t)g.nodes[b.entry].next.size();
     s.allele_sum_off = as;
     as += s.n_alleles;
     if (s.n_alleles <= dense_max) {
@@ -879,10 +888,10 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       gs += (1u << s.n_alleles) - 1u;
     } else
       s.grouped_off = GMX_GROUPED_LOG;
-    s.entry_node = b.second.first;
-    s.exit_node = b.second.second;
+    s.entry_node = b.entry;
+    s.exit_node = b.exit;
     s.snp_kinds = 0;
-    out.site_ref_pos[idx] = (uint32_t)g.site_ref_pos[b.first];
+    out.site_ref_pos[idx] = (uint32_t)b.ref_pos;
   }
   out.n_allele_slots = as;
   out.n_grouped_slots = gs;
