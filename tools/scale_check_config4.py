@@ -4,7 +4,7 @@ mapped with the size-independent properties of tools/scale_check.py. The GPU box
 memory and 16 cores of CPU time (cgroup limits), so the number of sites is what the HOST memory of the builder allows,
 not what the device could hold; a guard thread ends the process cleanly before the limit (a box that runs out of memory
 is lost). A scaled-down run (TRIAL bases) comes first and its peak memory is extrapolated.
-Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=8000000] [K=14] [N_READS=1000000] [TRIAL=200000000]"""
+Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=20000000] [K=14] [N_READS=1000000] [TRIAL=200000000]"""
 import gc
 import os
 import resource
@@ -23,7 +23,7 @@ from gramtools_amd import Index, Quasimapper, master_seeds  # noqa: E402
 from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads_fast, snp_prg  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 3_100_000_000
-n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 8_000_000
+n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 n_reads = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
 trial = int(sys.argv[5]) if len(sys.argv) > 5 else 200_000_000
