@@ -9,9 +9,11 @@ TIMED REGION (since round 3) = SURVEY.md §8(d)'s: host buffers in -> coverage a
   zeroed accumulators -> K steps -> (N > 1) ONE exchange of the coverage (RCCL all-reduce of the fused block, driven from
   inside the library: gmx_comm_allreduce_coverage, the routine `gram genotype --devices` uses) -> D2H of the accumulator
   block + gather into the three coverage arrays (gmx_coverage_fetch).
-A step = one batch of DISTINCT reads (8 batches are cycled: 320 MB of packed reads, more than the 256 MiB Infinity Cache)
-handed over as 2-bit bit planes in page-locked host memory (gmx_map_reads_packed_host, the form the FASTQ parser threads of
-`gram` emit; SURVEY.md §7 "pre-encoded (2-bit packed ...) pinned-host" input): H2D of 44 B per read on a copy stream beside
+A step = one batch of DISTINCT reads (8 batches are cycled: 300 MB of packed reads, more than the 256 MiB Infinity Cache)
+handed over as a 2-bit stream in page-locked host memory (gmx_map_reads_2bit_host: 37.5 B per 150 bp read, unpacked to bit
+planes by the batch's first kernel; --planes: bit planes, gmx_map_reads_packed_host, 40 B per read, the form the FASTQ parser
+threads of `gram` emit; SURVEY.md §7 "pre-encoded (2-bit packed ...) pinned-host" input), the per-read seeds left in page-locked
+host memory where the few reads that draw read theirs in place (--upload-seeds: + 4 B per read): H2D on a copy stream beside
 the kernels of the batches before, then the whole kernel pipeline (seed look-up, search, k-mer filter, selection, coverage
 atomics; forward and reverse complement). FASTQ parsing and the index build are outside (reported separately).
 Rounds 1 and 2 timed a narrower region as `value` (reads resident in HBM, one batch replayed, coverage left in HBM): that
@@ -23,7 +25,7 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
   exchange_ms      (N > 1) the coverage exchange alone, timed between fences after the job
   per_rank_s       (N > 1) every rank's own time for the timed job
   cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + the three coverage files
-  cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): all host threads and one thread
+  cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): the cores the container grants, and one thread
   roofline         gmx_extend_kernel, the dominant kernel: see DESIGN.md §8 for the byte model
 """
 import argparse
