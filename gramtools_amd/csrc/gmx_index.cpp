@@ -393,7 +393,8 @@ struct BuildNode {
   int32_t allele = -1;
   uint32_t seq_len = 0;
   uint32_t first_pos = 0;
-  std::vector<uint32_t> next;
+  uint32_t n_next = 0;             // outgoing edges (kept in GraphBuild::links: a vector per node is a heap block per node)
+  uint32_t next0 = 0xFFFFFFFFu;    // the first one
 };
 
 struct OpenSite {
@@ -405,6 +406,7 @@ struct OpenSite {
 
 struct GraphBuild {
   std::vector<BuildNode> nodes;
+  std::vector<std::pair<uint32_t, uint32_t>> links;  // edges (from, to) in creation order: a node's edges keep that order
   std::vector<uint32_t> pos_node;
   std::vector<MType> mtype;
   std::unordered_map<uint32_t, std::pair<uint32_t, int32_t>> parent;  // par_map
@@ -454,13 +456,17 @@ void build_graph(const std::vector<uint32_t> &prg, GraphBuild &g) {
   };
   uint32_t back = new_node(0, -1, 0);  // root
   int64_t cur = -1;                    // open sequence node
+  auto link = [&](uint32_t from, uint32_t to) {
+    g.links.push_back({from, to});
+    if (g.nodes[from].n_next++ == 0) g.nodes[from].next0 = to;
+  };
   auto wire = [&](uint32_t target) {   // coverage_graph.cpp:260-266
     if (cur >= 0) {
-      g.nodes[back].next.push_back((uint32_t)cur);
-      g.nodes[cur].next.push_back(target);
+      link(back, (uint32_t)cur);
+      link((uint32_t)cur, target);
       cur = -1;
     } else
-      g.nodes[back].next.push_back(target);
+      link(back, target);
   };
   MType prev_t = MType::sequence;
   uint32_t prev_m = 0;
@@ -853,6 +859,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   // nodes + edges
   out.nodes.resize(g.nodes.size() + 1);
   uint32_t pb = 0;
+  uint32_t edge_at = 0;
   for (size_t i = 0; i < g.nodes.size(); ++i) {
     auto const &bn = g.nodes[i];
     GmxNode &n = out.nodes[i];
@@ -860,16 +867,22 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     n.allele = bn.allele;
     n.seq_len = bn.seq_len;
     n.first_pos = bn.first_pos;
-    n.edge_begin = (uint32_t)out.edges.size();
+    n.edge_begin = edge_at;
+    edge_at += bn.n_next;
     bool in_bubble = bn.allele != -1 && bn.site != 0;  // is_in_bubble, coverage_graph.hpp:60-62
     if (in_bubble && bn.seq_len > 0) {
       n.cov_off = pb;
       pb += bn.seq_len;
     } else
       n.cov_off = GMX_NO_COV;
-    for (auto e : bn.next) out.edges.push_back(e);
-    n.n_edges = (uint32_t)bn.next.size();
-    n.edge0 = bn.next.empty() ? 0xFFFFFFFFu : bn.next[0];
+    n.n_edges = bn.n_next;
+    n.edge0 = bn.next0;
+  }
+  {  // every node's edges side by side, in the order they were made
+    out.edges.assign(edge_at, 0);
+    std::vector<uint32_t> fill(g.nodes.size(), 0);
+    for (auto const &lk : g.links) out.edges[out.nodes[lk.first].edge_begin + fill[lk.first]++] = lk.second;
+    g.links = std::vector<std::pair<uint32_t, uint32_t>>();
   }
   {
     GmxNode &closing = out.nodes[g.nodes.size()];
@@ -892,7 +905,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     auto pit = g.parent.find(b.site);
     s.parent_site = pit == g.parent.end() ? 0 : pit->second.first;
     s.parent_allele = pit == g.parent.end() ? -1 : pit->second.second;
-    s.n_alleles = (uint32_t)g.nodes[b.entry].next.size();
+    s.n_alleles = g.nodes[b.entry].n_next;
     s.allele_sum_off = as;
     as += s.n_alleles;
     if (s.n_alleles <= dense_max) {
