@@ -1891,15 +1891,21 @@ struct CoverLogPart {
   uint32_t log_sites;  // the index has sites that use the log
   __device__ __forceinline__ bool has_log_sites() const { return log_sites != 0; }
   __device__ __forceinline__ bool log_reserve(uint32_t words) {
-    log_at = atomicAdd(log_cursor, words);
-    if (log_at > log_cap || words > log_cap - log_at) {
-      // (given back: the cursor is above the capacity until then, so every reservation in between fails as well and the
-      // successful ones stay contiguous; a task that fails only because of such a moment is redone like the others)
-      atomicSub(log_cursor, words);
-      log_at = log_end = 0;
-      status = GMX_TASK_LOGFULL;
-      return false;
+    // compare-and-swap: the cursor moves only for a reservation that fits, so it never exceeds the capacity, the words
+    // below it are exactly the successful reservations back to back, and a failing task leaves no trace (an add that is
+    // taken back later opens a window in which another task's words end up beyond the cursor).
+    uint32_t cur = __hip_atomic_load(log_cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+      if (cur > log_cap || words > log_cap - cur) {
+        log_at = log_end = 0;
+        status = GMX_TASK_LOGFULL;
+        return false;
+      }
+      const uint32_t seen = atomicCAS(log_cursor, cur, cur + words);
+      if (seen == cur) break;
+      cur = seen;
     }
+    log_at = cur;
     log_end = log_at + words;
     return true;
   }
@@ -3010,7 +3016,10 @@ static int gmx_log_drain(gmx_engine *e, uint64_t keep_below) {
       ++i;
       continue;
     }
-    if (i + 2 > w.size() || i + 2 + w[i + 1] > w.size()) break;
+    if (i + 2 > w.size() || i + 2 + (size_t)w[i + 1] > w.size()) {  // reservations are exact (log_reserve): never expected
+      gmx_set_error("grouped-allele-count log: malformed record at word " + std::to_string(i) + " of " + std::to_string(w.size()));
+      return GMX_EREF;
+    }
     key.assign(1, w[i]);
     key.insert(key.end(), w.begin() + i + 2, w.begin() + i + 2 + w[i + 1]);
     e->log_counts[key] += 1;
@@ -3481,9 +3490,11 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     gmx_set_error("batch too large: at most 44 M reads per launch (lower gmx_engine_opts.max_batch_reads)");
     return GMX_EINVAL;
   }
-  int rc = ensure_batch_capacity(e, n_reads);
+  // the batch before: redo what found the log full, drain when half full. FIRST: a replay reads that batch's queues and
+  // retry lists, which a growing workspace (ensure_batch_capacity) replaces with fresh, uninitialised buffers.
+  int rc = e->log_sites ? log_settle(e) : GMX_OK;
   if (rc) return rc;
-  if (e->log_sites && (rc = log_settle(e))) return rc;  // the batch before: redo what found the log full, drain when half full
+  if ((rc = ensure_batch_capacity(e, n_reads))) return rc;
   const bool fold_reset = e->reset_pending && e->reset_stream == stream;
   if (e->reset_pending && !fold_reset && (rc = flush_reset(e))) return rc;
   e->reset_pending = false;
@@ -3716,6 +3727,10 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
     if (rc) return rc;
     done += n;
   }
+  // An index with log sites: a batch that found the grouped log full is replayed from ITS inputs (read lengths, seeds), and
+  // the caller may reuse its device buffers in stream order after this call: settle now (waits for the batch; engines
+  // without log sites — every dense-count index — stay asynchronous).
+  if (e->log_sites) return log_settle(e);
   return GMX_OK;
 }
 
@@ -3860,6 +3875,7 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
     int rc = launch_batch(e, in, nullptr);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));  // staging buffers are reused by the next batch
+    if (e->log_sites && (rc = log_settle(e))) return rc;  // ... and a replay of this batch reads them: before they are overwritten
     done += n;
   }
   return gmx_engine_sync(e);

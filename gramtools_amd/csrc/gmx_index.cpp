@@ -895,9 +895,9 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   out.n_pb_slots = pb;
   uint32_t as = 0, gs = 0;
   // sites of up to `dense_max` alleles get 2^A - 1 dense group counters; wider ones use the engine's append log, which costs
-  // a drain to the host now and then. GMX_DENSE_MAX_ALLELES (1 .. 10) overrides: the tests force the log with 5.
+  // a drain to the host now and then. GMX_DENSE_MAX_ALLELES (1 .. the default) lowers it: the tests force the log with 5.
   uint32_t dense_max = GMX_GROUPED_DENSE_MAX_ALLELES;
-  if (const char *dm = getenv("GMX_DENSE_MAX_ALLELES")) dense_max = (uint32_t)std::min(10, std::max(1, atoi(dm)));
+  if (const char *dm = getenv("GMX_DENSE_MAX_ALLELES")) dense_max = (uint32_t)std::min(GMX_GROUPED_DENSE_MAX_ALLELES, std::max(1, atoi(dm)));
   out.site_ref_pos.assign(out.sites.size(), 0);
   for (auto &b : g.bubbles) {
     uint32_t idx = (b.site - 5) / 2;

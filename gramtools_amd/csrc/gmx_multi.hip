@@ -337,10 +337,27 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
   std::vector<std::string> errs(n);
   std::vector<std::thread> th;
   const uint64_t ppr = (uniform_len + 31u) / 32u;
+  auto pair_at = [&](uint64_t r) { return uniform_len ? r * ppr : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r; };
+  // Pageable buffers are registered with the runtime HERE, once and whole: the members' sub-ranges share pages, so a
+  // registration per member can fail ("already registered") or make a neighbour's range look page-locked to a member that
+  // then returns with its uploads in flight while the neighbour unregisters. Registered here, every member sees page-locked
+  // memory and only queues its copies; the group waits for all of them before it unregisters.
+  struct Reg { const void *p; uint64_t bytes; bool on; };
+  Reg regs[4] = {{planes, pair_at(n_reads) * 8, false}, {offsets, (n_reads + 1) * 8, false}, {seeds, n_reads * 4, false}, {skip, n_reads, false}};
+  bool registered = false;
+  for (auto &r : regs) {
+    if (!r.p || !r.bytes) continue;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, r.p) == hipSuccess && at.type == hipMemoryTypeHost) continue;
+    (void)hipGetLastError();
+    r.on = hipHostRegister(const_cast<void *>(r.p), r.bytes, hipHostRegisterPortable) == hipSuccess;
+    (void)hipGetLastError();
+    registered = registered || r.on;
+  }
   for (size_t i = 0; i < n; ++i) {
     const uint64_t base = n_reads / n, rem = n_reads % n;
     const uint64_t lo = i * base + std::min<uint64_t>(i, rem), cnt = base + (i < rem ? 1 : 0);
-    const uint64_t p0 = uniform_len ? lo * ppr : ((offsets[lo] >> 5) - (offsets[0] >> 5)) + lo;
+    const uint64_t p0 = pair_at(lo);
     th.emplace_back([=, &rcs, &errs]() {
       if (cnt == 0) return;
       rcs[i] = gmx_map_reads_packed_host(g->ms[i].e, planes + p0, offsets ? offsets + lo : nullptr, uniform_len, seeds + lo,
@@ -349,6 +366,12 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
     });
   }
   for (auto &t : th) t.join();
+  if (registered) {
+    for (auto &m : g->ms) (void)gmx_engine_sync_uploads(m.e);
+    for (auto &r : regs)
+      if (r.on) (void)hipHostUnregister(const_cast<void *>(r.p));
+    (void)hipGetLastError();
+  }
   for (size_t i = 0; i < n; ++i)
     if (rcs[i]) {
       gmx_set_error("device " + std::to_string(g->ms[i].raw.device) + ": " + errs[i]);

@@ -68,7 +68,7 @@ struct GmxSite {
 // atomics). Such a node is recognised by an ODD cov_off (all others are even); its hit counter is at
 // cov_off + 1 and is added to the three logical counters when coverage is fetched (HostIndex::hit_fix).
 // The logical arrays of the C ABI (allele_sum, per_base, grouped_dense) are gathered from it (HostIndex::phys_*).
-#define GMX_GROUPED_DENSE_MAX_ALLELES 8  // default; the index builder reads GMX_DENSE_MAX_ALLELES (gmx_index.cpp)
+#define GMX_GROUPED_DENSE_MAX_ALLELES 8  // default; the upper limit; GMX_DENSE_MAX_ALLELES lowers it at index build (tests)
 
 GMX_HD bool gmx_node_has_hit_counter(const GmxNode &n) { return n.cov_off != GMX_NO_COV && (n.cov_off & 1u); }
 // A dense site whose alleles are all one base long (hit counter) or empty needs no walk to be recorded: the hit

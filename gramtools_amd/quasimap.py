@@ -73,10 +73,12 @@ class PinnedArray:
 
 class PackedReads:
     """Reads as bit planes in host memory (include/gmx.h, gmx_map_reads_packed_host): ``planes`` (uint64 per 32 bases),
-    ``offsets`` (None when ``uniform_len``), ``skip`` (uint8 per read or None), ``n_reads``."""
+    ``offsets`` (None when ``uniform_len``), ``skip`` (uint8 per read or None), ``n_reads``. ``twobit``: ``planes`` holds
+    the reads as a 2-bit stream instead (gmx_map_reads_2bit_host; pack_reads_2bit)."""
 
-    def __init__(self, planes, offsets, uniform_len, skip, n_reads, keep=()):
+    def __init__(self, planes, offsets, uniform_len, skip, n_reads, keep=(), twobit=False):
         self.planes, self.offsets, self.uniform_len, self.skip, self.n_reads = planes, offsets, uniform_len, skip, n_reads
+        self.twobit = bool(twobit)
         self._keep = keep  # the PinnedArray objects behind the arrays
 
     def close(self):
@@ -141,9 +143,7 @@ def pack_reads_2bit(reads_flat, offsets, uniform_len: int = 0, threads: int = 0,
         stream, skip = np.zeros(units + 8, dtype=np.uint64), np.zeros(max(n, 1), dtype=np.uint8)
         off_out = None if uniform_len else o
     check(lib.gmx_pack_reads_2bit(r.ctypes.data, o.ctypes.data, uniform_len, n, stream.ctypes.data, skip.ctypes.data, threads))
-    pk = PackedReads(stream, off_out, uniform_len, skip, n, tuple(keep))
-    pk.twobit = True
-    return pk
+    return PackedReads(stream, off_out, uniform_len, skip, n, tuple(keep), twobit=True)
 
 
 class Index:
@@ -476,7 +476,7 @@ class Quasimapper:
         s = seeds if isinstance(seeds, np.ndarray) and seeds.dtype == np.uint32 and seeds.flags.c_contiguous else \
             np.ascontiguousarray(seeds, dtype=np.uint32)
         skip = packed.skip if use_skip else None
-        fn = self.lib.gmx_map_reads_2bit_host if getattr(packed, "twobit", False) else self.lib.gmx_map_reads_packed_host
+        fn = self.lib.gmx_map_reads_2bit_host if packed.twobit else self.lib.gmx_map_reads_packed_host
         check(fn(self.h, packed.planes.ctypes.data, None if packed.offsets is None else packed.offsets.ctypes.data,
                  packed.uniform_len, s.ctypes.data, None if skip is None else skip.ctypes.data, packed.n_reads))
         self._last_seeds = s  # (kept alive while the upload may be in flight)
@@ -593,6 +593,8 @@ class QuasimapperGroup:
         check(self.lib.gmx_group_map_reads_host(self.h, _p(r, C.c_uint8), _p(o, C.c_uint64), _p(s, C.c_uint32), o.size - 1))
 
     def map_reads_packed(self, packed: "PackedReads", seeds, use_skip=True):
+        if packed.twobit:  # a member's share of a 2-bit stream does not start on a unit boundary: the group takes planes
+            raise ValueError("QuasimapperGroup.map_reads_packed takes bit planes (pack_reads), not a 2-bit stream (pack_reads_2bit)")
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
         skip = packed.skip if use_skip else None
         check(self.lib.gmx_group_map_reads_packed_host(

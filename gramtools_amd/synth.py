@@ -466,6 +466,37 @@ def reads_from_haplotypes(haps, n_reads: int, read_len: int, seed: int, rc_prob:
     return reads
 
 
+def realistic_reads(reads2d: np.ndarray, seed: int, sub_rate: float = 0.005, n_read_frac: float = 0.01,
+                    len_lo: int = 100, len_hi: int = 0):
+    """Error-free simulated reads -> reads as a sequencer delivers them: every base substituted with
+    probability `sub_rate` (by one of the three other bases), `n_read_frac` of the reads with one to three `N`s (byte 0:
+    the whole read is skipped, common/utils.cpp:73-92), and ragged lengths — every read cut at its 3' end to a length drawn
+    from [len_lo, len_hi] (len_hi = 0: the input length). Returns (flat uint8, offsets uint64). Vectorised."""
+    rng = np.random.default_rng(seed)
+    r = np.array(reads2d, dtype=np.uint8, copy=True)
+    n, L = r.shape
+    hi = len_hi or L
+    assert 1 <= len_lo <= hi <= L
+    sub = rng.random(r.shape) < sub_rate
+    shift = rng.integers(1, 4, size=int(sub.sum()), dtype=np.uint8)
+    r[sub] = (r[sub] - 1 + shift) % 4 + 1
+    lens = rng.integers(len_lo, hi + 1, size=n).astype(np.int64)
+    with_n = np.flatnonzero(rng.random(n) < n_read_frac)
+    for _ in range(3):  # one to three Ns inside the kept part of the read
+        take = with_n[rng.random(with_n.size) < (1.0 if _ == 0 else 0.5)]
+        r[take, (rng.random(take.size) * lens[take]).astype(np.int64)] = 0
+    keep = np.arange(L)[None, :] < lens[:, None]
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    return np.ascontiguousarray(r[keep]), offs
+
+
+def split_reads(flat: np.ndarray, offs: np.ndarray):
+    """(flat, offsets) -> list of per-read arrays (views)."""
+    o = offs.astype(np.int64)
+    return [flat[o[i]:o[i + 1]] for i in range(o.size - 1)]
+
+
 def chr20_recipe(G: int, n_sites: int, n_reads: int, seed: int, n_haps: int = 4, read_len: int = 150):
     """BASELINE.json configs[3] at any size: random reference of G bases, n_sites sites (90 % SNPs, 10 % 1-10 bp indels
     incl. pure deletions, 5 % with 3-4 alleles; full size: G = 64 444 167, 1.8 M sites, k = 14), error-free reads

@@ -223,7 +223,13 @@ class Oracle:
             for j in range(k):  # base j of the k-mer has weight 4^j: sorting the codes = the reversed-k-mer order
                 c |= (arr[:, j:j + L - k + 1].astype(np.uint64) - 1) << np.uint64(2 * j)
             codes.append(np.unique(c))
-        u = np.unique(np.concatenate(codes))
+        self._index_kmer_codes(np.unique(np.concatenate(codes)))
+
+    def _index_kmer_codes(self, u):
+        """Sorted unique k-mer codes (base j has weight 4^j) -> prefix diffs -> gmo_index_kmer_diffs."""
+        k = self.k
+        if u.size == 0:
+            return
         km = np.empty((u.size, k), dtype=np.uint8)
         for j in range(k):
             km[:, j] = ((u >> np.uint64(2 * j)) & np.uint64(3)).astype(np.uint8) + 1
@@ -238,6 +244,30 @@ class Oracle:
         ln = lens.astype(np.uint64)
         if self.lib.gmo_index_kmer_diffs(self.h, _p(flat, C.c_uint8), _p(ln, C.c_uint64), int(u.size)) != 0:
             raise self._err()
+
+    def index_kmers_of_read_list(self, flat, offs):
+        """index_kmers_of_reads for ragged reads with errors and Ns (flat uint8, offsets): exactly the k-mers of the clean
+        windows of these reads and of their reverse complements — the only k-mers quasimap ever looks up for them
+        (quasimap.cpp:206-225). Test infrastructure."""
+        k = self.k
+        f = np.ascontiguousarray(flat, dtype=np.uint8)
+        o = np.asarray(offs, dtype=np.int64)
+        n_win = f.size - k + 1
+        if n_win <= 0:
+            return
+        read_of = np.repeat(np.arange(o.size - 1), np.diff(o))
+        ok = (f >= 1) & (f <= 4)
+        bad_before = np.concatenate([[0], np.cumsum(~ok)])
+        valid = (read_of[:n_win] == read_of[k - 1:]) & (bad_before[k:] == bad_before[:n_win])
+        codes = []
+        for arr in (f, np.ascontiguousarray((5 - f.astype(np.int16))[::-1]).astype(np.uint8)):
+            v = valid if arr is f else valid[::-1]
+            c = np.zeros(n_win, dtype=np.uint64)
+            for j in range(k):
+                c |= ((arr[j:j + n_win].astype(np.uint64) - np.uint64(1)) & np.uint64(3)) << np.uint64(2 * j)
+            codes.append(np.unique(c[v]))
+        u = np.unique(np.concatenate(codes))
+        self._index_kmer_codes(u)
 
     @staticmethod
     def all_kmers(k):

@@ -36,9 +36,14 @@ def canonical_cov(cov: Coverage):
 def oracle_map(prg, k, reads, seeds, rng_mode=0, threads=1, kmers_of_reads=False):
     """kmers_of_reads: index only the k-mers of these (equal-length, clean) reads instead of all 4^k (k = 14)."""
     o = Oracle(prg, k, all_kmers=not kmers_of_reads, rng_mode=rng_mode)
-    if kmers_of_reads:
-        o.index_kmers_of_reads(np.asarray(reads, dtype=np.uint8))
-    flat, offs = flatten_reads(reads)
+    if isinstance(reads, tuple):  # (flat, offsets): ragged reads, possibly with errors and Ns
+        flat, offs = reads
+        if kmers_of_reads:
+            o.index_kmers_of_read_list(flat, offs)
+    else:
+        if kmers_of_reads:
+            o.index_kmers_of_reads(np.asarray(reads, dtype=np.uint8))
+        flat, offs = flatten_reads(reads)
     o.map_reads(flat, offs, seeds, threads=threads)
     return canonical_oracle(o)
 

@@ -60,3 +60,58 @@ def test_a_task_that_needs_more_than_the_whole_log_is_reported():
         qm.map_reads(flat, offs, seeds)
         qm.coverage()
     assert e.value.code == -4
+
+
+def _wide_site_case(n_reads, seed):
+    ref = random_ref(6000, seed)
+    prg, sites = mixed_variant_prg(ref, 150, seed + 1, max_alleles=7)
+    reads = simulate_haplotype_reads(ref, sites, n_reads, 60, 150, seed + 2)
+    seeds = master_seeds(42, [len(reads)])
+    return prg, reads, seeds
+
+
+def test_a_larger_batch_after_a_full_log_replays_the_earlier_batchs_own_lists():
+    """batch N + 1 grows the workspace; the replay of batch N must still read batch N's retry lists and inputs
+    (log_settle runs before ensure_batch_capacity)."""
+    prg, reads, seeds = _wide_site_case(3000, 11)
+    want = oracle_map(prg, 7, reads, seeds, threads=8)
+    qm = Quasimapper(Index(prg, 7), log_cap_words=64)
+    cuts = [0, 300, 1100, 3000]  # every call larger than the one before: the workspace is reallocated twice
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        flat, offs = flatten_reads(reads[a:b])
+        qm.map_reads(flat, offs, seeds[a:b])
+    assert canonical_cov(qm.coverage()) == want
+    assert qm.queue_counts()["log_replays"] > 0
+
+
+def test_serial_host_loop_settles_before_its_staging_buffers_are_reused(monkeypatch):
+    """GMX_HOST_SERIAL reuses one staging buffer per batch; a batch that found the log full is replayed from
+    its own reads and seeds, not the next batch's."""
+    monkeypatch.setenv("GMX_HOST_SERIAL", "1")
+    prg, reads, seeds = _wide_site_case(2500, 21)
+    want = oracle_map(prg, 7, reads, seeds, threads=8)
+    qm = Quasimapper(Index(prg, 7), log_cap_words=48, max_batch_reads=400)
+    flat, offs = flatten_reads(reads)
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    assert qm.queue_counts()["log_replays"] > 0
+
+
+def test_device_entry_point_settles_before_it_returns():
+    """gmx_map_reads_device with a log-using index: the caller may overwrite its device buffers in stream order
+    after the call."""
+    import torch
+    prg, reads, seeds = _wide_site_case(2000, 31)
+    want = oracle_map(prg, 7, reads, seeds, threads=8)
+    qm = Quasimapper(Index(prg, 7), log_cap_words=48)
+    for a, b in ((0, 900), (900, 2000)):
+        flat, offs = flatten_reads(reads[a:b])
+        d_r = torch.from_numpy(flat.copy()).cuda()
+        d_o = torch.from_numpy(offs.astype(np.int64)).cuda()
+        d_s = torch.from_numpy(np.ascontiguousarray(seeds[a:b]).view(np.int32).copy()).cuda()
+        qm.map_reads_device(d_r, d_o, d_s, b - a)
+        d_r.zero_()   # stream-ordered reuse of the caller's buffers
+        d_s.zero_()
+        d_o.zero_()
+    assert canonical_cov(qm.coverage()) == want
+    assert qm.queue_counts()["log_replays"] > 0

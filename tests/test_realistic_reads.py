@@ -1,0 +1,63 @@
+"""Reads as a sequencer delivers them: substitution errors, Ns, ragged lengths — the inputs that make
+the `missing_kmer` / `no_extension` split, skipped reads and mid-read deaths happen (quasimap.cpp:159-194,212-225,
+common/utils.cpp:73-92). CPU part: the generator, the oracle's k-mer-list index against its all-k-mers index, and the
+device headers on the host emulation against the oracle. The config-scale GPU cases are in tests/test_configs.py."""
+import numpy as np
+import pytest
+
+from common import oracle_map, hostemu_map
+from gramtools_amd import master_seeds
+from gramtools_amd.synth import (random_ref, snp_prg, simulate_snp_reads, realistic_reads, split_reads, chr20_recipe,
+                                 pf3d7_recipe)
+
+
+def test_generator_makes_what_it_says():
+    ref = random_ref(20_000, 1)
+    prg, pos, alts, n_alts = snp_prg(ref, 200, 2)
+    clean = simulate_snp_reads(ref, pos, alts, n_alts, 4000, 150, 3)
+    flat, offs = realistic_reads(clean, 7, sub_rate=0.01, n_read_frac=0.05, len_lo=100)
+    lens = np.diff(offs.astype(np.int64))
+    assert lens.min() >= 100 and lens.max() <= 150 and len(set(lens.tolist())) > 30
+    reads = split_reads(flat, offs)
+    with_n = sum(1 for r in reads if (r == 0).any())
+    assert 100 < with_n < 320
+    diff = sum(int((r != c[:r.size]).sum()) for r, c in zip(reads, clean))
+    assert 0.007 < diff / flat.size < 0.014
+    assert set(np.unique(flat).tolist()) <= {0, 1, 2, 3, 4}
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_kmer_list_index_equals_full_index_on_realistic_reads(seed):
+    ref = random_ref(30_000, seed)
+    prg, pos, alts, n_alts = snp_prg(ref, 400, seed + 1)
+    clean = simulate_snp_reads(ref, pos, alts, n_alts, 1500, 150, seed + 2)
+    rr = realistic_reads(clean, seed + 3, sub_rate=0.01, n_read_frac=0.03, len_lo=60)
+    seeds = master_seeds(42, [1500])
+    full = oracle_map(prg, 7, rr, seeds)
+    listed = oracle_map(prg, 7, rr, seeds, kmers_of_reads=True)
+    assert listed == full
+    st = full["stats"]
+    assert st["skipped"] > 0 and st["missing_kmer"] > 0 and st["no_extension"] > 0 and st["exact_mapped"] > 0
+
+
+@pytest.mark.parametrize("recipe", ["snp", "chr20", "pf3d7"])
+def test_device_headers_on_realistic_reads(recipe):
+    if recipe == "snp":
+        ref = random_ref(40_000, 5)
+        prg, pos, alts, n_alts = snp_prg(ref, 550, 6)
+        clean = simulate_snp_reads(ref, pos, alts, n_alts, 2500, 150, 7)
+        k = 7
+    elif recipe == "chr20":
+        prg, clean = chr20_recipe(60_000, 1700, 2500, 8)
+        k = 8
+    else:
+        prg, clean = pf3d7_recipe(80_000, 7, 350, 2500, 9)
+        k = 7
+    flat, offs = realistic_reads(clean, 10, sub_rate=0.008, n_read_frac=0.02, len_lo=100)
+    seeds = master_seeds(42, [clean.shape[0]])
+    want = oracle_map(prg, k, (flat, offs), seeds, threads=8)
+    got, _, rc = hostemu_map(prg, k, split_reads(flat, offs), seeds)
+    assert rc == 0
+    assert got == want
+    st = want["stats"]
+    assert st["skipped"] > 0 and st["no_extension"] > 0 and st["exact_mapped"] > 500
