@@ -55,18 +55,14 @@ extern "C" {
 
 const char *gmx_last_error(void) { return g_error.c_str(); }
 
-int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int threads, gmx_index **out) {
-  if (!prg || !out) {
-    gmx_set_error("gmx_index_build: null argument");
-    return GMX_EINVAL;
-  }
+// the symbols are handed over, not copied (12.4 GB at whole-genome scale; round 3 held them three times)
+static int index_build_owned(std::vector<uint32_t> &&v, uint32_t kmer_size, int threads, gmx_index **out) {
   try {
     gmx_index *ix = new gmx_index();
-    std::vector<uint32_t> v(prg, prg + n);
     try {
       int k2 = -1;  // GMX_SEED_K2 in the environment: 0 disables the longer seed table, n forces its length
       if (const char *e = getenv("GMX_SEED_K2")) k2 = atoi(e);
-      gmx::build_index(v, kmer_size, ix->h, threads, k2);
+      gmx::build_index(std::move(v), kmer_size, ix->h, threads, k2);
     } catch (...) {
       delete ix;
       throw;
@@ -82,10 +78,29 @@ int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int thr
   }
 }
 
-int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads, gmx_index **out) {
+int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int threads, gmx_index **out) {
+  if (!prg || !out) {
+    gmx_set_error("gmx_index_build: null argument");
+    return GMX_EINVAL;
+  }
   try {
-    auto prg = gmx::read_prg_file(path);
-    return gmx_index_build(prg.data(), prg.size(), kmer_size, threads, out);
+    return index_build_owned(std::vector<uint32_t>(prg, prg + n), kmer_size, threads, out);
+  } catch (std::bad_alloc const &) {
+    gmx_set_error("out of memory while building the index");
+    return GMX_ENOMEM;
+  }
+}
+
+int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads, gmx_index **out) {
+  if (!path || !out) {
+    gmx_set_error("gmx_index_build_from_file: null argument");
+    return GMX_EINVAL;
+  }
+  try {
+    return index_build_owned(gmx::read_prg_file(path), kmer_size, threads, out);
+  } catch (std::bad_alloc const &) {
+    gmx_set_error("out of memory while reading the PRG");
+    return GMX_ENOMEM;
   } catch (std::exception const &e) {
     gmx_set_error(e.what());
     return GMX_EINVAL;
@@ -146,6 +161,8 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_nodes = h.nodes.empty() ? 0 : (uint32_t)h.nodes.size() - 1;
   o->n_kmers_present = h.n_seed_kmers_present;
   o->kmer_size2 = h.kmer_size2;
+  o->seed_shift = h.seed_shift;
+  o->n_seed_words = h.seed_words.size();
   {
     uint64_t n_inline = 0;
     for (const GmxTextRec &r : h.text) n_inline += (uint64_t)__builtin_popcountll(r.mk & r.hi);
@@ -344,6 +361,10 @@ int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out) {
   return GMX_OK;
 }
 int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out) {
+  if (ix->h.bwt.empty()) {  // (dropped by the builder on PRGs of 2^28 symbols and more: GMX_INDEX_INTROSPECTION=1 keeps it)
+    gmx_set_error("this index was built without its introspection tables (GMX_INDEX_INTROSPECTION=1 keeps them)");
+    return GMX_EINVAL;
+  }
   memcpy(out, ix->h.bwt.data(), ix->h.bwt.size() * 4);
   return GMX_OK;
 }
@@ -354,6 +375,10 @@ uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base) {
 }
 int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out) {
   const auto &h = ix->h;
+  if (h.pos_target.size() != h.prg.size()) {
+    gmx_set_error("this index was built without its introspection tables (GMX_INDEX_INTROSPECTION=1 keeps them)");
+    return GMX_EINVAL;
+  }
   for (size_t p = 0; p < h.prg.size(); ++p) {
     const GmxNode &nd = h.nodes[h.pos_node[p]];
     out[5 * p + 0] = nd.site;

@@ -2985,6 +2985,17 @@ struct gmx_engine {
     *dst = q;
     return GMX_OK;
   }
+  int upload(const uint32_t **dst, const gmx::WordBuf &src) {
+    uint32_t *q = nullptr;
+    int rc = alloc(&q, src.size(), false);
+    if (rc) return rc;
+    const size_t piece = (size_t)1 << 28;  // (pageable memory, tens of GB at whole-genome scale: 1 GB per staged copy)
+    for (size_t at = 0; at < src.size(); at += piece)
+      HIP_TRY(hipMemcpy(q + at, src.data() + at, std::min(piece, src.size() - at) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    index_bytes += src.size() * sizeof(uint32_t);
+    *dst = q;
+    return GMX_OK;
+  }
 };
 
 static int flush_reset(gmx_engine *e) {

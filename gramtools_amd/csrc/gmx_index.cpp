@@ -824,14 +824,34 @@ static void build_trace(const char *what) {
   static auto t_last = std::chrono::steady_clock::now();
   if (!on) return;
   const auto now = std::chrono::steady_clock::now();
-  fprintf(stderr, "[build %8.2f s] %s\n", std::chrono::duration<double>(now - t_last).count(), what);
+  double rss_gb = 0, peak_gb = 0;  // resident memory now and its high-water mark (the container's limit is what bounds a whole-genome build)
+  if (FILE *f = fopen("/proc/self/status", "r")) {
+    char line[256];
+    while (fgets(line, sizeof(line), f)) {
+      unsigned long long kb = 0;
+      if (sscanf(line, "VmRSS: %llu", &kb) == 1) rss_gb = kb / 1048576.0;
+      if (sscanf(line, "VmHWM: %llu", &kb) == 1) peak_gb = kb / 1048576.0;
+    }
+    fclose(f);
+  }
+  fprintf(stderr, "[build %8.2f s, RSS %6.1f GiB, peak %6.1f GiB] %s\n", std::chrono::duration<double>(now - t_last).count(), rss_gb, peak_gb, what);
   t_last = now;
 }
 
+static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, int seed_k2);
 void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads, int seed_k2) {
-  build_trace("start");
   out = HostIndex();
   out.prg = prg;
+  build_index_impl(out, kmer_size, threads, seed_k2);
+}
+void build_index(std::vector<uint32_t> &&prg, uint32_t kmer_size, HostIndex &out, int threads, int seed_k2) {  // (12.4 GB at whole-genome scale: no copy)
+  out = HostIndex();
+  out.prg = std::move(prg);
+  build_index_impl(out, kmer_size, threads, seed_k2);
+}
+static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, int seed_k2) {
+  build_trace("start");
+  const std::vector<uint32_t> &prg = out.prg;
   out.kmer_size = kmer_size;
   const size_t N = prg.size();
   if (N == 0) throw std::runtime_error("empty PRG");
@@ -1434,6 +1454,17 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
   }
 
   build_trace("text records");
+  // The BWT and the per-position target table have served the builder (jump programs, hit records); past this point only
+  // the tests' introspection calls read them (gmx_index_copy_bwt / _copy_pos_info). On a whole-genome PRG they are 12 + 25 GB
+  // that the seed tables need: dropped from 2^28 symbols on (GMX_INDEX_INTROSPECTION=1 keeps, =0 drops them at any size).
+  {
+    const char *keep = getenv("GMX_INDEX_INTROSPECTION");
+    if (keep ? atoi(keep) == 0 : N >= ((size_t)1 << 28)) {
+      std::vector<uint32_t>().swap(out.bwt);
+      std::vector<std::pair<uint32_t, int32_t>>().swap(out.pos_target);
+      build_trace("introspection tables dropped (BWT, per-position targets)");
+    }
+  }
   // --- seed tables -------------------------------------------------------------------
   // The k-mer index of the reference (k = kmer_size) and, when it pays, the same construction continued to a longer
   // k-mer (kmer_size2): the states after k2 matched bases are the states after k bases extended by k2 - k ordinary
@@ -1515,7 +1546,7 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
     if (on_device) {
       const bool forced = getenv("GMX_DEVICE_BUILD") != nullptr;
       try {
-        on_device = g_device_seed_walk(out, kmer_size, k2, split, level, out.seeds.data(), out.seeds2.data(), out.kmer_bitmap.data(), device_parts);
+        on_device = g_device_seed_walk(out, kmer_size, k2, split, level, out.seeds.data(), out.seeds2.data(), out.kmer_bitmap.data(), device_parts, out.seed_words);
       } catch (std::exception const &e) {
         if (forced) throw;
         fprintf(stderr, "gmx: the device walk of the index build failed (%s): walking on the host\n", e.what());
@@ -1529,6 +1560,8 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
         if (getenv("GMX_BUILD_TRACE")) fprintf(stderr, "    first %u bases on the host (every node on all threads): %.2f s\n", split, t_first);
       } else {
         std::fill(out.kmer_bitmap.begin(), out.kmer_bitmap.end(), 0u);
+        device_parts.clear();
+        out.seed_words.clear();
       }
     }
     auto run_task = [&](uint32_t task) {
@@ -1555,7 +1588,23 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       level.clear();
       for (auto &e : errors)
         if (!e.empty()) throw std::runtime_error(e);
-      for (auto &tk : tasks) parts.push_back(&tk);
+      {  // the tasks' words one after the other in the index's buffer; a task's own copy goes as soon as it is appended
+        uint64_t total = 0;
+        for (auto &tk : tasks) total += tk.words.size();
+        out.seed_words.reserve(total + 1);
+        for (auto &tk : tasks) {
+          tk.word_base = out.seed_words.size();
+          tk.n_words = tk.words.size();
+          uint32_t *dst = out.seed_words.grow(tk.n_words);
+          const size_t piece = (size_t)1 << 22;
+          const std::vector<uint32_t> &src = tk.words;
+          par_for((tk.n_words + piece - 1) / piece, hw, [&](size_t c) {
+            memcpy(dst + c * piece, src.data() + c * piece, std::min(piece, (size_t)tk.n_words - c * piece) * sizeof(uint32_t));
+          });
+          std::vector<uint32_t>().swap(tk.words);
+          parts.push_back(&tk);
+        }
+      }
       build_trace("  k-mers enumerated");
     }
     if (!on_device && getenv("GMX_BUILD_TRACE")) {
@@ -1571,57 +1620,104 @@ void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex
       stat("fill", t_fill);
       stat("walk", t_dfs);
     }
-    // multi-state entries: the tasks' words one after the other, the entries pointed at theirs. An entry's offset has
-    // 30 bits (the device copies keep two flags beside it): from 2^30 words on — whole-genome PRGs — the entries start on
-    // units of 2^seed_shift words, the smallest shift that fits (GMX_SEED_SHIFT in the environment: this shift, for tests).
-    auto entry_len = [](const SeedPart &tk, size_t i) {
-      return (uint64_t)(i + 1 < tk.complex.size() ? tk.complex[i + 1].off : tk.words.size()) - tk.complex[i].off;
-    };
+    // multi-state entries: the parts' words lie back to back in out.seed_words (compact); the entries are pointed at theirs.
+    // An entry's offset has 30 bits (the device copies keep two flags beside it): from 2^30 words on — whole-genome PRGs —
+    // the entries start on units of 2^seed_shift words, the smallest shift that fits (GMX_SEED_SHIFT in the environment:
+    // at least this shift, for tests). The padding is made IN PLACE, from the last entry backwards: a padded entry never
+    // starts below its compact position, so moving the last slice first never overwrites words still to be moved; slices
+    // whose destination lies wholly above the sources of their whole run move side by side on all threads.
     struct Slice {
       const SeedPart *part;
-      size_t c0, c1;  // its entries [c0, c1)
+      size_t c0, c1;      // its entries [c0, c1)
+      uint64_t src, len;  // compact words of the slice: [src, src + len) of out.seed_words
+      uint64_t dst;       // where the slice's first entry goes
     };
+    auto entry_at = [](const SeedPart &pt, size_t i) { return pt.word_base + (i < pt.complex.size() ? pt.complex[i].off : pt.n_words); };
+    size_t slice_entries = (size_t)1 << 16;
+    if (const char *env = getenv("GMX_SEED_SLICE")) slice_entries = (size_t)std::max(1, atoi(env));  // (tests: many small slices)
     std::vector<Slice> slices;
-    for (const SeedPart *pt : parts)
-      for (size_t c0 = 0; c0 < pt->complex.size(); c0 += (size_t)1 << 16) slices.push_back(Slice{pt, c0, std::min(pt->complex.size(), c0 + ((size_t)1 << 16))});
+    uint64_t compact_total = 0;
+    for (const SeedPart *pt : parts) {
+      if (pt->word_base != compact_total) throw std::runtime_error("seed tables: the parts' words are not back to back");
+      if (!pt->complex.empty() && pt->complex[0].off != 0) throw std::runtime_error("seed tables: a part's first entry does not start its words");
+      if (pt->complex.empty() && pt->n_words) throw std::runtime_error("seed tables: words without an entry");
+      for (size_t c0 = 0; c0 < pt->complex.size(); c0 += slice_entries) {
+        const size_t c1 = std::min(pt->complex.size(), c0 + slice_entries);
+        slices.push_back(Slice{pt, c0, c1, entry_at(*pt, c0), entry_at(*pt, c1) - entry_at(*pt, c0), 0});
+      }
+      compact_total += pt->n_words;
+    }
+    if (compact_total != out.seed_words.size()) throw std::runtime_error("seed tables: the parts do not add up to the words");
     const uint32_t n_slices = (uint32_t)slices.size();
-    std::vector<uint64_t> slice_base(n_slices + 1, 0);
+    std::vector<uint64_t> padded_len(n_slices, 0);
     uint32_t shift = 0;
     if (const char *env = getenv("GMX_SEED_SHIFT")) shift = (uint32_t)std::min(8, std::max(0, atoi(env)));
+    uint64_t padded_total = 0;
     for (;; ++shift) {
       const uint64_t unit = 1ull << shift;
       parallel(n_slices, [&](uint32_t t) {
-        uint64_t sum = 0;
         const Slice &sl = slices[t];
-        if (sl.c0 < sl.c1) {
-          if (shift == 0)
-            sum = (sl.c1 < sl.part->complex.size() ? sl.part->complex[sl.c1].off : sl.part->words.size()) - sl.part->complex[sl.c0].off;
-          else
-            for (size_t i = sl.c0; i < sl.c1; ++i) sum += (entry_len(*sl.part, i) + unit - 1) >> shift << shift;
+        uint64_t sum = sl.len;
+        if (shift) {
+          sum = 0;
+          for (size_t i = sl.c0; i < sl.c1; ++i) sum += (entry_at(*sl.part, i + 1) - entry_at(*sl.part, i) + unit - 1) >> shift << shift;
         }
-        slice_base[t + 1] = sum;
+        padded_len[t] = sum;
       });
-      for (uint32_t t = 0; t < n_slices; ++t) slice_base[t + 1] += slice_base[t];
-      if ((slice_base[n_slices] >> shift) < (1ull << 30)) break;
+      padded_total = 0;
+      for (uint32_t t = 0; t < n_slices; ++t) {
+        slices[t].dst = padded_total;
+        padded_total += padded_len[t];
+      }
+      if ((padded_total >> shift) < (1ull << 30)) break;
       if (shift >= 8) throw std::runtime_error("seed tables: the multi-state entries do not fit 2^30 units of 256 words");
     }
     out.seed_shift = shift;
-    out.seed_words.resize(slice_base[n_slices] + 1);
-    out.seed_words[slice_base[n_slices]] = 0;
-    parallel(n_slices, [&](uint32_t t) {
-      const Slice &sl = slices[t];
-      const SeedPart &tk = *sl.part;
-      uint64_t at = slice_base[t];
-      for (size_t i = sl.c0; i < sl.c1; ++i) {
-        auto const &c = tk.complex[i];
-        const uint64_t len = entry_len(tk, i);
-        memcpy(out.seed_words.data() + at, tk.words.data() + c.off, len * sizeof(uint32_t));
+    out.seed_words.resize(padded_total + 1);
+    uint32_t *const words = out.seed_words.data();
+    words[padded_total] = 0;
+    // one slice: its entries to their padded places (last first when source and destination overlap), the table entries
+    auto place_slice = [&](const Slice &sl, bool backwards) {
+      const SeedPart &pt = *sl.part;
+      const uint64_t unit = 1ull << shift;
+      auto put = [&](size_t i, uint64_t at) {
+        const uint64_t src = entry_at(pt, i), len = entry_at(pt, i + 1) - src;
+        if (at != src) memmove(words + at, words + src, len * sizeof(uint32_t));
+        const uint64_t padded = (len + unit - 1) >> shift << shift;
+        for (uint64_t z = len; z < padded; ++z) words[at + z] = 0;
+        auto const &c = pt.complex[i];
         (c.table ? out.seeds2 : out.seeds)[c.code] = GmxSeed{GMX_SEED_COMPLEX, (uint32_t)(at >> shift)};
-        const uint64_t padded = shift ? (len + (1ull << shift) - 1) >> shift << shift : len;
-        for (uint64_t z = len; z < padded; ++z) out.seed_words[at + z] = 0;
-        at += padded;
+        return padded;
+      };
+      if (!backwards) {
+        uint64_t at = sl.dst;
+        for (size_t i = sl.c0; i < sl.c1; ++i) at += put(i, at);
+      } else {  // (an entry's padded place is at or above its compact one and below the next entry's padded place)
+        uint64_t end = sl.dst;
+        for (size_t i = sl.c0; i < sl.c1; ++i) end += (entry_at(pt, i + 1) - entry_at(pt, i) + unit - 1) >> shift << shift;
+        for (size_t i = sl.c1; i-- > sl.c0;) {
+          const uint64_t len = entry_at(pt, i + 1) - entry_at(pt, i);
+          end -= (len + unit - 1) >> shift << shift;
+          put(i, end);
+        }
       }
-    });
+    };
+    if (shift == 0) {
+      parallel(n_slices, [&](uint32_t t) { place_slice(slices[t], false); });
+    } else {
+      for (uint32_t hi = n_slices; hi > 0;) {  // runs of slices [lo, hi), from the end of the words
+        const uint64_t src_end = slices[hi - 1].src + slices[hi - 1].len;
+        uint32_t lo = hi;
+        while (lo > 0 && slices[lo - 1].dst >= src_end) --lo;
+        if (lo == hi) {  // the last slice's own destination overlaps its source: alone, last entry first
+          place_slice(slices[hi - 1], true);
+          --hi;
+          continue;
+        }
+        parallel(hi - lo, [&](uint32_t t) { place_slice(slices[lo + t], false); });
+        hi = lo;
+      }
+    }
     out.n_seed_kmers_present = 0;
     uint64_t all[2] = {0, 0}, large[2] = {0, 0};
     for (const SeedPart *pt : parts) {
@@ -1718,6 +1814,11 @@ struct Writer {
     pod<uint64_t>(v.size());
     raw(v.data(), v.size() * sizeof(T));
   }
+  void vec(const WordBuf &v) {  // (the same bytes as a vector of words)
+    pod<uint64_t>(v.size());
+    const size_t piece = (size_t)1 << 28;  // 1 GB writes: a single fwrite of 90 GB is one system call's worth of trouble
+    for (size_t at = 0; at < v.size(); at += piece) raw(v.data() + at, std::min(piece, v.size() - at) * sizeof(uint32_t));
+  }
 };
 struct Reader {
   FILE *f;
@@ -1737,6 +1838,14 @@ struct Reader {
     if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
     v.resize(n);
     raw(v.data(), n * sizeof(T));
+  }
+  void vec(WordBuf &v, uint64_t max_elems = (1ull << 36)) {
+    uint64_t n = 0;
+    pod(n);
+    if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
+    v.resize(n);
+    const size_t piece = (size_t)1 << 28;
+    for (size_t at = 0; at < n; at += piece) raw(v.data() + at, std::min<size_t>(piece, n - at) * sizeof(uint32_t));
   }
 };
 

@@ -8,6 +8,7 @@
 #pragma once
 #include <sys/mman.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
@@ -82,6 +83,65 @@ struct BigAlloc {
 };
 typedef std::vector<GmxSeed, BigAlloc<GmxSeed>> SeedTable;
 
+// The words of the multi-state seed entries: tens of GB for a whole-genome PRG (configs[4]: ~2.7 G path-bearing states),
+// produced group by group. An anonymous mapping grown with mremap — which moves page-table entries, not pages — so that
+// appending never holds a second copy (a std::vector's reallocation does, and round 3's builder kept the parts AND their
+// joined copy: its host peak was what kept the 85 M-site PRG from being built inside the container's 300 GiB). Words are
+// not initialised (the writer writes every one); mapped but untouched capacity costs nothing.
+class WordBuf {
+ public:
+  WordBuf() = default;
+  WordBuf(const WordBuf &) = delete;
+  WordBuf &operator=(const WordBuf &) = delete;
+  WordBuf(WordBuf &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr, o.n_ = o.cap_ = 0; }
+  WordBuf &operator=(WordBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p_ = o.p_, n_ = o.n_, cap_ = o.cap_;
+      o.p_ = nullptr, o.n_ = o.cap_ = 0;
+    }
+    return *this;
+  }
+  ~WordBuf() { release(); }
+  uint32_t *data() { return p_; }
+  const uint32_t *data() const { return p_; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  uint32_t &operator[](size_t i) { return p_[i]; }
+  const uint32_t &operator[](size_t i) const { return p_[i]; }
+  void reserve(size_t words) {
+    if (words <= cap_) return;
+    const size_t page = (size_t)2 << 20;
+    const size_t bytes = (words * sizeof(uint32_t) + page - 1) / page * page;
+    void *q = p_ ? mremap(p_, cap_ * sizeof(uint32_t), bytes, MREMAP_MAYMOVE)
+                 : mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (q == MAP_FAILED) throw std::bad_alloc();
+    if (bytes >= ((size_t)64 << 20) && gmx_huge_pages_pay()) madvise(q, bytes, MADV_HUGEPAGE);
+    p_ = static_cast<uint32_t *>(q);
+    cap_ = bytes / sizeof(uint32_t);
+  }
+  void resize(size_t words) {  // (new words are whatever the mapping holds: zero pages the first time)
+    if (words > cap_) reserve(std::max(words, cap_ + cap_ / 4));
+    n_ = words;
+  }
+  void clear() { n_ = 0; }
+  void release() {
+    if (p_) munmap(p_, cap_ * sizeof(uint32_t));
+    p_ = nullptr;
+    n_ = cap_ = 0;
+  }
+  // room for `words` more at the end; returns where they go (the caller writes all of them)
+  uint32_t *grow(size_t words) {
+    const size_t at = n_;
+    resize(n_ + words);
+    return p_ + at;
+  }
+
+ private:
+  uint32_t *p_ = nullptr;
+  size_t n_ = 0, cap_ = 0;
+};
+
 struct TargetedMarker {
   uint32_t id;
   int32_t deletion_allele;
@@ -107,7 +167,7 @@ struct HostIndex {
   SeedTable seeds;              // direct-addressed by the k-mer's table index (gmx_types.h GmxSeed)
   uint32_t kmer_size2 = 0;      // longer seed table (0 = none): the same construction continued to k2 > kmer_size
   SeedTable seeds2;             // its 4^k2 entries; multi-state records share seed_words
-  std::vector<uint32_t, BigAlloc<uint32_t>> seed_words;  // (every word written by the join: not value-initialised)
+  WordBuf seed_words;           // multi-state entries (every word written by the walks / the join: not value-initialised)
   uint32_t seed_shift = 0;      // multi-state entries start at (GmxSeed::b << seed_shift); > 0 from 2^30 words on
   std::vector<uint32_t> kmer_bitmap;
   uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
@@ -141,6 +201,7 @@ void debug_suffix_array_u16(const uint16_t *text, size_t n, uint16_t *sa);
 // kmer_size == 0 skips the seed table. threads <= 0 uses all hardware threads for the seed table.
 // seed_k2: length of the longer seed table; -1 = choose from the PRG size, 0 (or <= kmer_size) = none.
 void build_index(const std::vector<uint32_t> &prg, uint32_t kmer_size, HostIndex &out, int threads = 0, int seed_k2 = -1);
+void build_index(std::vector<uint32_t> &&prg, uint32_t kmer_size, HostIndex &out, int threads = 0, int seed_k2 = -1);  // takes the symbols over
 
 // Index cache: everything build_index derives, as one flat file, so that `gram genotype` starts with
 // a read + H2D instead of SA construction and the seed-table enumeration. The file is tied to the PRG it was built
@@ -165,8 +226,11 @@ struct SeedEntryRef {  // a multi-state entry: its table index, its table (0: k,
 };
 // What a part of the enumeration hands to the join (gmx_index.cpp): the words of its multi-state entries in enumeration
 // order — by the k-mers' right-to-left base order, a k entry before the k2 entries it is a suffix of — and the entries.
+// The words live in the index's seed_words (HostIndex::seed_words) from word_base on, back to back (the device walk copies
+// every group's words straight there; a host task's `words` are appended and freed when the task is done): no second copy.
 struct SeedPart {
-  std::vector<uint32_t> words;
+  std::vector<uint32_t> words;        // host walk only, until appended
+  uint64_t word_base = 0, n_words = 0;  // this part's words in HostIndex::seed_words; SeedEntryRef::off is relative to word_base
   std::vector<SeedEntryRef> complex;
   uint64_t n_present[2] = {0, 0}, n_states_all[2] = {0, 0}, n_states_large[2] = {0, 0};
 };
@@ -175,7 +239,7 @@ struct SeedPart {
 // entry written) and returns the parts in order. Registered by gmx_seedwalk.hip when it is linked in (libgmx.so); null in
 // host-only builds (tests/hostemu). Throws std::runtime_error; returns false when no device can be used.
 typedef bool (*DeviceSeedWalk)(const HostIndex &ix, uint32_t k, uint32_t k2, uint32_t depth0, std::vector<WalkNode> &roots,
-                               GmxSeed *table, GmxSeed *table2, uint32_t *bitmap, std::vector<SeedPart> &parts);
+                               GmxSeed *table, GmxSeed *table2, uint32_t *bitmap, std::vector<SeedPart> &parts, WordBuf &words);
 extern DeviceSeedWalk g_device_seed_walk;
 
 // The suffixes of `text` (n symbols, the last one the unique sentinel 0) ordered by their first 24 symbols on the device

@@ -452,7 +452,7 @@ struct Emitted {  // one level's entries, until the group's parts are written
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t depth0, std::vector<WalkNode> &roots, GmxSeed *table, GmxSeed *table2,
-                      uint32_t *bitmap, std::vector<SeedPart> &parts) {
+                      uint32_t *bitmap, std::vector<SeedPart> &parts, WordBuf &words) {
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
     (void)hipGetLastError();
@@ -539,6 +539,7 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
     r0 = r1;
     parts.emplace_back();
     SeedPart &part = parts.back();
+    part.word_base = words.size();
     if (st.empty()) continue;
     node_first.push_back((uint32_t)st.size());
     Level cur;
@@ -682,10 +683,14 @@ bool device_seed_walk(const HostIndex &h, uint32_t k, uint32_t k2, uint32_t dept
     }
     t_emit += now_s() - t0;
     const double t1 = now_s();
-    part.words.resize(total_words);
+    // the group's words go straight behind the earlier groups' in the index's buffer (grown without a copy): the builder
+    // never holds them twice (round 3 kept every part and the joined copy — 85 M sites did not fit the container)
+    part.word_base = words.size();
+    part.n_words = total_words;
+    uint32_t *const words_at = words.grow(total_words);
     part.complex.resize(total_entries);
     static_assert(sizeof(DEntryRef) == sizeof(SeedEntryRef), "entry references");
-    if (total_words) WCK(hipMemcpy(part.words.data(), d_words.p, total_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (total_words) WCK(hipMemcpy(words_at, d_words.p, total_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     if (total_entries) WCK(hipMemcpy(part.complex.data(), d_refs.p, total_entries * sizeof(DEntryRef), hipMemcpyDeviceToHost));
     unsigned long long stats[6];
     WCK(hipMemcpy(stats, d_stats.p, sizeof(stats), hipMemcpyDeviceToHost));

@@ -9,6 +9,8 @@ No real genomes are available offline, so every workload is generated here with 
   * :func:`simulate_snp_reads` / :func:`simulate_graph_reads` / :func:`simulate_haplotype_reads`
                            error-free reads from random haplotypes
 """
+import os
+
 import numpy as np
 
 
@@ -506,6 +508,56 @@ def chr20_recipe(G: int, n_sites: int, n_reads: int, seed: int, n_haps: int = 4,
     prg, _ = variant_prg(ref, sites)
     haps = [variant_haplotype(ref, sites, seed + 10 + h)[0] for h in range(n_haps)]
     return prg, reads_from_haplotypes(haps, n_reads, read_len, seed + 2)
+
+
+def _genome_chunk(job):
+    """One chunk of genome_recipe_file (a worker process): its piece of the PRG with the site markers renumbered, and its
+    share of the reads."""
+    g, ns, nr, site0, seed, n_haps, read_len = job
+    ref = random_ref(g, seed)
+    sites = variant_sites(ref, ns, seed + 1)
+    prg, _ = variant_prg(ref, sites)
+    marker = prg > 4
+    prg[marker] += np.uint32(2 * site0)
+    haps = [variant_haplotype(ref, sites, seed + 10 + h)[0] for h in range(n_haps)]
+    reads = reads_from_haplotypes(haps, nr, read_len, seed + 2) if nr else np.zeros((0, read_len), dtype=np.uint8)
+    return prg, reads
+
+
+def genome_recipe_file(path: str, G: int, n_sites: int, n_reads: int, seed: int, chunk: int = 50_000_000, n_haps: int = 2,
+                       read_len: int = 150, workers: int = 0):
+    """BASELINE.json configs[4] (3.1 G bases, 85 M sites "same mix" as configs[3]): chr20_recipe's site mix —
+    90 % SNPs, 10 % 1-10 bp indels incl. pure deletions, 5 % of the sites with 3-4 alleles — over G bases, generated chunk by
+    chunk in worker processes and written to `path` as gram_dir/prg (little-endian uint32). Reads are error-free draws from
+    `n_haps` haplotypes per chunk (none crosses a chunk boundary), shuffled. Returns (n_symbols, reads uint8 [n_reads, L])."""
+    import multiprocessing as mp
+    n_chunks = (G + chunk - 1) // chunk
+    jobs, site0, read0 = [], 0, 0
+    for c in range(n_chunks):
+        g = min(chunk, G - c * chunk)
+        ns = int(round(n_sites * (c * chunk + g) / G)) - site0
+        nr = int(round(n_reads * (c * chunk + g) / G)) - read0
+        jobs.append((g, ns, nr, site0, seed + 100 * c, n_haps, read_len))
+        site0 += ns
+        read0 += nr
+    workers = workers or max(1, min(n_chunks, (os.cpu_count() or 8), 16))
+    n_symbols, reads = 0, []
+    with open(path, "wb") as f:
+        if workers == 1 or n_chunks == 1:
+            results = map(_genome_chunk, jobs)
+            for prg, r in results:
+                prg.astype("<u4", copy=False).tofile(f)
+                n_symbols += int(prg.size)
+                reads.append(r)
+        else:
+            with mp.get_context("fork").Pool(workers) as pool:
+                for prg, r in pool.imap(_genome_chunk, jobs):
+                    prg.astype("<u4", copy=False).tofile(f)
+                    n_symbols += int(prg.size)
+                    reads.append(r)
+    reads = np.concatenate(reads) if reads else np.zeros((0, read_len), dtype=np.uint8)
+    np.random.default_rng(seed + 7).shuffle(reads, axis=0)
+    return n_symbols, reads
 
 
 def msa_region(rng, target_len: int, max_depth: int = 3) -> str:

@@ -61,6 +61,10 @@ typedef struct gmx_index_info {
   uint32_t kmer_size2;       /* length of the longer seed table the search is seeded from (0 = none); see DESIGN.md */
   uint32_t n_inline_sites;   /* sites the text-form search resolves without their marker record (one-base alleles inside one
                                 text record; gmx_types.h) */
+  uint32_t seed_shift;       /* multi-state k-mer index entries start on units of 2^seed_shift words (0 below 2^30 words;
+                                whole-genome PRGs need more: build/kmer_index/build.cpp:101-131 has no such limit) */
+  uint32_t reserved0;
+  uint64_t n_seed_words;     /* words of the multi-state entries (SearchStates with variant paths, several per k-mer) */
 } gmx_index_info;
 int gmx_index_get_info(const gmx_index *ix, gmx_index_info *out);
 

@@ -31,6 +31,34 @@ def test_entries_are_the_same_states_under_any_unit(monkeypatch, shift):
     assert units.info.index_bytes > plain.info.index_bytes  # the padding
 
 
+@pytest.mark.parametrize("slice_entries", [1, 3, 7, 1 << 16])
+@pytest.mark.parametrize("shift", [2, 5])
+def test_padding_in_place_does_not_depend_on_how_the_entries_are_sliced(monkeypatch, tmp_path, shift, slice_entries):
+    """The entries are padded to their units inside the one buffer that holds them (no second copy: what lets the 85 M-site
+    whole-genome PRG build inside the container's memory): slices from the end, overlapping ones entry by entry backwards,
+    the others side by side. Whatever the slicing and the thread count, the index file has the same bytes."""
+    ref = random_ref(3000, 9)
+    prg, _ = mixed_variant_prg(ref, 130, 10, max_alleles=4)
+    np.asarray(prg, dtype="<u4").tofile(str(tmp_path / "prg"))
+    monkeypatch.setenv("GMX_SEED_SHIFT", str(shift))
+    monkeypatch.setenv("GMX_SEED_SLICE", str(1 << 16))
+    want = Index(prg, 6, threads=1)
+    want.save(str(tmp_path / "want.gmx"))
+    monkeypatch.setenv("GMX_SEED_SLICE", str(slice_entries))
+    got = Index(prg, 6, threads=4)
+    got.save(str(tmp_path / "got.gmx"))
+    assert open(tmp_path / "got.gmx", "rb").read() == open(tmp_path / "want.gmx", "rb").read()
+    import itertools
+    monkeypatch.delenv("GMX_SEED_SHIFT")
+    plain = Index(prg, 6, threads=2)
+    n_multi = 0
+    for kmer in itertools.product((1, 2, 3, 4), repeat=6):
+        a = plain.seed_states(kmer)
+        assert got.seed_states(kmer) == a
+        n_multi += a is not None and len(a) > 1
+    assert n_multi > 200
+
+
 @pytest.mark.parametrize("seed", [1, 2])
 def test_host_emulation_maps_the_same_with_units(monkeypatch, seed):
     prg, reads, seeds = _nested_case(seed)

@@ -1,10 +1,11 @@
-"""BASELINE.json configs[4] as a builder-and-mapping run on one MI355X: a whole-genome-sized PRG (3.1 G random bases +
-SNP sites; SURVEY §8d's recipe at genome scale), index built (GMX_BUILD_TRACE phases), uploaded, and error-free reads
-mapped with the size-independent properties of tools/scale_check.py. The GPU boxes give a container 300 GiB of host
+"""BASELINE.json configs[4] as a builder-and-mapping run on one MI355X: SURVEY §8(d)'s recipe — 3.1 G random bases, 85 M
+sites in the configs[3] mix (gramtools_amd.synth.genome_recipe_file) —, index built (GMX_BUILD_TRACE phases with resident
+memory), uploaded, and error-free reads mapped with the size-independent properties of tools/scale_check.py, then the
+packed host feed and the kernel pipeline timed. The GPU boxes give a container 300 GiB of host
 memory and 16 cores of CPU time (cgroup limits), so the number of sites is what the HOST memory of the builder allows,
 not what the device could hold; a guard thread ends the process cleanly before the limit (a box that runs out of memory
 is lost). A scaled-down run (TRIAL bases) comes first and its peak memory is extrapolated.
-Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=20000000] [K=14] [N_READS=1000000] [TRIAL=200000000]"""
+Usage: python tools/scale_check_config4.py [GENOME=3100000000] [N_SITES=85000000] [K=14] [N_READS=1000000] [TRIAL=200000000]"""
 import gc
 import os
 import resource
@@ -20,14 +21,15 @@ import torch  # noqa: E402
 
 torch.cuda.init()
 from gramtools_amd import Index, Quasimapper, master_seeds  # noqa: E402
-from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads_fast, snp_prg  # noqa: E402
+from gramtools_amd.synth import flat_offsets, genome_recipe_file  # noqa: E402
+from gramtools_amd import pack_reads_2bit  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 3_100_000_000
-n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 20_000_000
+n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 85_000_000
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 n_reads = int(sys.argv[4]) if len(sys.argv) > 4 else 1_000_000
 trial = int(sys.argv[5]) if len(sys.argv) > 5 else 200_000_000
-LIMIT_GB = float(os.environ.get("GMX_RSS_LIMIT_GB", "250"))
+LIMIT_GB = float(os.environ.get("GMX_RSS_LIMIT_GB", "285"))
 T0 = time.time()
 
 
@@ -55,53 +57,21 @@ def guard():
 threading.Thread(target=guard, daemon=True).start()
 
 
-def make_prg(G, n_sites, chunk=250_000_000):
-    """snp_prg over chunks of the reference (its temporaries are 8-byte arrays of the chunk's length), sites renumbered."""
-    refs, outs, poss, alt_vals = [], [], [], []
-    done_sites = 0
-    for c0 in range(0, G, chunk):
-        g = min(chunk, G - c0)
-        ns = int(round(n_sites * (c0 + g) / G)) - done_sites
-        ref = random_ref(g, 1 + c0 // chunk)
-        prg, pos, alts, n_alts = snp_prg(ref, ns, 2 + c0 // chunk)
-        marker = prg > 4
-        prg[marker] += np.uint32(2 * done_sites)
-        refs.append(ref)
-        outs.append(prg)
-        poss.append(pos + c0)
-        alt_vals.append(alts[0][1])
-        done_sites += ns
-        del marker
-    ref = np.concatenate(refs)
-    del refs
-    prg = np.concatenate(outs)
-    del outs
-    pos = np.concatenate(poss)
-    alt = np.concatenate(alt_vals)
-    n_alts = np.ones(pos.size, dtype=np.int64)
-    return ref, prg, pos, [(np.ones(pos.size, dtype=bool), alt)], n_alts
-
-
 def run(G, n_sites, n_reads, label):
-    say(f"== {label}: {G} bases, {n_sites} sites, k = {k}")
-    ref, prg, pos, alts, n_alts = make_prg(G, n_sites)
-    say(f"PRG: {prg.size} symbols")
-    reads = simulate_snp_reads_fast(ref, pos, alts, n_alts, n_reads, 150, 1000)
-    del ref, pos, alts, n_alts
+    say(f"== {label}: {G} bases, {n_sites} sites (90 % SNP / 10 % 1-10 bp indels, 5 % with 3-4 alleles), k = {k}")
     tmp = os.environ.get("TMPDIR", "/tmp")
     prg_path = os.path.join(tmp, "gmx_config4.prg")
-    prg.tofile(prg_path)
-    n_symbols = int(prg.size)
-    del prg
+    n_symbols, reads = genome_recipe_file(prg_path, G, n_sites, n_reads, 61 if G > 10 ** 9 else 51)
     gc.collect()
-    say(f"{n_reads} error-free 150 bp reads simulated; PRG written ({os.path.getsize(prg_path) / 1e9:.1f} GB); python side freed")
+    say(f"PRG written: {n_symbols} symbols ({os.path.getsize(prg_path) / 1e9:.1f} GB); {n_reads} error-free 150 bp reads simulated")
     t0 = time.time()
     before = peak_gb()
     ix = Index(prg_path, k)
     os.remove(prg_path)
     info = ix.info
     say(f"index built in {time.time() - t0:.1f} s: {info.index_bytes / 1e9:.1f} GB, k2 = {info.kmer_size2}, {info.n_sites} sites, "
-        f"{info.n_inline_sites} inline; peak memory of the process so far {peak_gb():.1f} GB (before the build {before:.1f})")
+        f"{info.n_inline_sites} inline, {info.n_seed_words / 1e9:.2f} G words of multi-state entries on units of 2^{info.seed_shift}; "
+        f"peak memory of the process so far {peak_gb():.1f} GB (before the build {before:.1f})")
     t0 = time.time()
     qm = Quasimapper(ix)
     free_b, total_b = torch.cuda.mem_get_info()
@@ -137,9 +107,35 @@ def run(G, n_sites, n_reads, label):
     a_sum, g_sum = int(fwd.raw_allele_sum.astype(np.int64).sum()), int(fwd.raw_grouped.astype(np.int64).sum())
     assert a_sum >= g_sum > 0
     say(f"properties hold: counter identity, every read mapped, strand symmetry, repeatability; allele-sum total {a_sum}, grouped total {g_sum}")
+    # the production feed (2-bit stream from page-locked memory) and the kernel pipeline (reads resident in HBM as bytes)
+    pk = pack_reads_2bit(flat, offs, uniform_len=150, pinned=True)
+    qm.reset()
+    qm.map_reads_packed(pk, seeds)
+    packed = qm.coverage()
+    assert (fwd.raw_allele_sum == packed.raw_allele_sum).all() and (fwd.raw_per_base == packed.raw_per_base).all() and (fwd.raw_grouped == packed.raw_grouped).all()
+    for rep in range(2):
+        qm.reset()
+        qm.sync()
+        t0 = time.time()
+        for _ in range(5):
+            qm.map_reads_packed(pk, seeds)
+        qm.sync()
+        dt = (time.time() - t0) / 5
+    say(f"packed host feed (2-bit stream, page-locked): {dt * 1e3:.2f} ms per {n_reads} reads = {n_reads / dt / 1e6:.1f} M reads/s; identical coverage")
+    d_r, d_o, d_s = torch.from_numpy(flat).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda(), torch.from_numpy(seeds.view(np.int32)).cuda()
+    for rep in range(2):
+        qm.reset()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(5):
+            qm.map_reads_device(d_r, d_o, d_s, n_reads)
+        qm.sync()
+        dt = (time.time() - t0) / 5
+    say(f"kernel pipeline (bytes resident in HBM): {dt * 1e3:.2f} ms per {n_reads} reads = {n_reads / dt / 1e6:.1f} M reads/s")
+    pk.close()
     qm.close()
     ix.close()
-    del qm, ix, fwd, again, back
+    del qm, ix, fwd, again, back, packed
     gc.collect()
     return n_symbols
 
