@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "../../include/gmx.h"
+#include "gmx_gzsource.h"
 
 namespace {
 
@@ -709,21 +710,23 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   } buf{nullptr};
   size_t have = 0, consumed = 0;
   bool first = true;
-  gzFile g = nullptr;
+  std::unique_ptr<gmx::GzSource> g;  // gzip input: BGZF members inflated side by side, other members through one zlib stream
   size_t file_at = 0;
   const size_t file_size = stat_ok ? (size_t)sb.st_size : 0;
   if (gz) {
     close(fd);
     fd = -1;
-    g = gzopen(path.c_str(), "rb");
-    if (!g) return false;
-    gzbuffer(g, 1 << 20);
+    try {
+      g.reset(new gmx::GzSource(path, T));
+    } catch (std::exception const &) {
+      return false;
+    }
   } else if (!stat_ok || file_size == 0) {
     close(fd);
     return false;
   }
   auto shut = [&]() {
-    if (g) gzclose(g);
+    g.reset();
     if (fd >= 0) close(fd);
   };
   // Plain files are memory-mapped and parsed in place: one pass over the page cache's own pages (measured on the GPU
@@ -756,17 +759,12 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
     bool final;
     const double t_read = now_s();
     if (g) {
-      while (have < kBlock) {
-        int got = gzread(g, buf.data() + have, (unsigned)std::min<size_t>(kBlock - have, 1u << 30));
-        if (got < 0) {  // a damaged or truncated gzip stream must not pass for the end of the reads
-          int err = 0;
-          const char *msg = gzerror(g, &err);
-          die("gram: " + path + ": " + (msg ? msg : "zlib error"));
-        }
-        if (got == 0) break;
-        have += (size_t)got;
+      try {  // a damaged or truncated gzip stream must not pass for the end of the reads: GzSource throws
+        have += g->read(buf.data() + have, kBlock - std::min(kBlock, have));
+      } catch (std::exception const &e) {
+        die(std::string("gram: ") + e.what());
       }
-      final = gzeof(g) != 0 || have < kBlock;
+      final = g->at_end() || have < kBlock;
     } else if (map) {
       have = std::min(kBlock, file_size - map_pos);
       final = map_pos + have >= file_size;

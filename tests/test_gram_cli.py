@@ -266,3 +266,87 @@ def test_debug_switch_writes_the_genotyping_debug_file(tmp_path):
         n_sites = len(json.loads((out / "genotype" / "genotyped.json").read_text())["Sites"])
         assert len(lines) == n_sites and all(l.startswith("site index: \t") for l in lines)
         assert all(("null gt" in l) or ("next_best_seq: " in l and "next_best_cov: " in l) for l in lines)
+
+
+# ---- gzip containers (gmx_gzsource.h; the reference's reader takes gzip transparently, seqread.hpp:94-180) ----------------
+def _bgzf(data: bytes, block=65280, level=6, eof=True) -> bytes:
+    """BGZF as bgzip writes it (SAM spec §4.1): gzip members of <= 64 KB with a BC extra field holding the member size."""
+    import struct
+    import zlib
+    out = bytearray()
+    pieces = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof else [])
+    for piece in pieces:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(piece) + c.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    return bytes(out)
+
+
+def _fastq_text(n, seed, crlf=False):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        ln = int(rng.integers(1, 260))
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5 if i % 9 == 0 else 4, size=ln))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 75, size=ln))
+        recs.append(f"@r{i}\n{seq}\n+\n{'@' + qual[1:] if i % 4 == 0 else qual}\n")
+    text = "".join(recs)
+    return text.replace("\n", "\r\n") if crlf else text
+
+
+def _same_as_plain(tmp_path, text, binary, threads=6, name="r.fastq.gz"):
+    want = _parse_check(tmp_path, text, threads, name="plain.fastq")
+    got = _parse_check(tmp_path, None, threads, name=name, binary=binary)
+    assert want[0].startswith("fast ") and got[0].startswith("fast ") and got[0] == want[0] and got[1][5:] == got[0][5:], (want, got)
+
+
+@pytest.mark.parametrize("block", ["700", "70000", "100000000"])
+def test_bgzf_members_are_inflated_side_by_side(tmp_path, monkeypatch, block):
+    """BGZF: the member table is walked without inflating, members inflate in parallel into place. Tiny feed blocks force
+    members through the carry buffer (a member larger than the request), large ones the batch path."""
+    monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
+    text = _fastq_text(4000, 21)
+    _same_as_plain(tmp_path, text, _bgzf(text.encode(), block=3000))
+    _same_as_plain(tmp_path, text, _bgzf(text.encode()), threads=64)          # full-size members, more threads than members
+    _same_as_plain(tmp_path, text, _bgzf(text.encode(), eof=False))           # no EOF marker member
+
+
+def test_gzip_members_in_any_mix(tmp_path, monkeypatch):
+    """cat a.gz b.gz, a BGZF run behind a plain member and the other way round, CRLF text, trailing zero bytes."""
+    import gzip
+    a, b, c = _fastq_text(700, 1), _fastq_text(900, 2), _fastq_text(500, 3, crlf=True)
+    for block in ("900", "100000000"):
+        monkeypatch.setenv("GMX_FASTQ_BLOCK", block)
+        _same_as_plain(tmp_path, a + b, gzip.compress(a.encode()) + gzip.compress(b.encode()))
+        _same_as_plain(tmp_path, a + b + c, gzip.compress(a.encode()) + _bgzf(b.encode(), block=5000, eof=False) + gzip.compress(c.encode()))
+        _same_as_plain(tmp_path, b + a, _bgzf(b.encode(), block=4000) + gzip.compress(a.encode(), 1))
+        _same_as_plain(tmp_path, c, gzip.compress(c.encode()) + b"\0" * 512)
+
+
+@pytest.mark.parametrize("kind", ["plain", "bgzf", "bgzf-crc", "garbage-mid"])
+def test_damaged_gzip_is_fatal(tmp_path, kind):
+    """A truncated or damaged gzip file must not pass for the end of the reads (quasimap would silently report coverage of a
+    part of the sample)."""
+    import gzip
+    import subprocess
+    from gramtools_amd.build import build_gram
+    text = _fastq_text(3000, 4).encode()
+    if kind == "plain":
+        data = gzip.compress(text)[:-2000]
+    elif kind == "bgzf":
+        data = _bgzf(text, block=20000)[:-3000]
+    elif kind == "bgzf-crc":
+        d = bytearray(_bgzf(text, block=20000))
+        d[len(d) // 2] ^= 0x55
+        data = bytes(d)
+    else:
+        d = bytearray(gzip.compress(text))
+        d[len(d) // 2:len(d) // 2 + 64] = b"\xff" * 64
+        data = bytes(d)
+    path = tmp_path / "bad.fastq.gz"
+    path.write_bytes(data)
+    out = subprocess.run([build_gram(), "_parse_check", str(path), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode != 0, out.stdout
