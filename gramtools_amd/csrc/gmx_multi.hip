@@ -242,6 +242,15 @@ struct gmx_comm {
 
 extern "C" {
 
+int gmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const int *devices, int n_devices, gmx_group **out) {
   if (!ix || !devices || n_devices <= 0 || !out) {
     gmx_set_error("gmx_group_create: bad argument");
@@ -254,18 +263,34 @@ int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const 
   else
     gmx_engine_default_opts(&opts);
   bool distinct = true;
-  for (int i = 0; i < n_devices; ++i) {
+  for (int i = 0; i < n_devices; ++i)
     for (int j = 0; j < i; ++j) distinct = distinct && devices[i] != devices[j];
-    opts.device = devices[i];
-    Member m;
-    int rc = gmx_engine_create(ix, &opts, &m.e);
-    if (rc) {
+  // one host thread per device: every engine uploads the whole index (replicated), and at whole-genome scale that is
+  // minutes per device when done one after the other. (Engines sharing a device are created in turn.)
+  g->ms.resize(n_devices);
+  std::vector<int> rcs(n_devices, GMX_OK);
+  std::vector<std::string> errs(n_devices);
+  auto create = [&](int i) {
+    gmx_engine_opts o = opts;
+    o.device = devices[i];
+    rcs[i] = gmx_engine_create(ix, &o, &g->ms[i].e);
+    if (rcs[i]) errs[i] = gmx_last_error();
+    else gmx_engine_raw(g->ms[i].e, &g->ms[i].raw);
+  };
+  if (distinct && n_devices > 1) {
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_devices; ++i) th.emplace_back(create, i);
+    for (auto &t : th) t.join();
+  } else {
+    for (int i = 0; i < n_devices; ++i) create(i);
+  }
+  for (int i = 0; i < n_devices; ++i)
+    if (rcs[i]) {
+      gmx_set_error("device " + std::to_string(devices[i]) + ": " + errs[i]);
+      const int rc = rcs[i];
       gmx_group_destroy(g);
       return rc;
     }
-    gmx_engine_raw(m.e, &m.raw);
-    g->ms.push_back(m);
-  }
   if (n_devices > 1 && distinct && !getenv("GMX_NO_RCCL") && rccl().ok) {
     std::vector<ncclComm_t> comms(n_devices);
     if (rccl().CommInitAll(comms.data(), n_devices, devices) == ncclSuccess) {

@@ -62,7 +62,8 @@ const char *kGenotypeHelp =
     "  --max_threads arg (=1)      maximum number of threads used\n"
     "  --seed arg                  seed for pseudo-random selection of multi-mapping reads. a random seed is\n"
     "                              generated if this option is not used.\n"
-    "  --device arg (=0)           HIP device ordinal (engine extension)\n"
+    "  --device arg                HIP device ordinal (engine extension; neither --device nor --devices: every visible GPU\n"
+    "                              when the reads files are large, else device 0)\n"
     "  --devices arg               several GPUs, e.g. 0-7 or 0,2,5: reads sharded, coverage summed (engine extension)\n"
     "  --rng_compat arg (=gcc11)   uniform_int_distribution flavour of the reference build to reproduce:\n"
     "                              gcc11 (libstdc++ >= 11) or gcc10 (libstdc++ <= 10) (engine extension)\n";
@@ -1118,8 +1119,29 @@ int run_genotype(const Args &a) {
       i = j + 1;
     }
     if (devices.empty()) die("--devices takes a list like 0-7 or 0,2,5");
+  } else if (a.has("device")) {
+    devices.push_back(std::stoi(a.one("device")));
   } else {
-    devices.push_back(a.has("device") ? std::stoi(a.one("device")) : 0);
+    // Neither given — what the unmodified front-end does (genotype.py:71-93 passes a fixed argument list): every visible
+    // GPU when the reads are worth sharding, else device 0. "Worth it": the files hold more than GMX_AUTO_DEVICES_MIN_MB of
+    // reads (default 2048 MB of FASTQ, a quarter of that gzipped: ~6 M reads of 150 bp; below it a second index upload costs
+    // more than it saves). GMX_AUTO_DEVICES=0 keeps device 0, =N takes at most N.
+    devices.push_back(0);
+    int n_vis = gmx_device_count();
+    if (const char *ad = getenv("GMX_AUTO_DEVICES")) n_vis = std::min(n_vis, std::max(1, atoi(ad)));
+    if (n_vis > 1) {
+      uint64_t mb = 0;
+      for (auto const &p : reads_paths) {
+        struct stat st;
+        if (stat(p.c_str(), &st) != 0) continue;
+        const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+        mb += ((uint64_t)st.st_size >> 20) * (gz ? 4 : 1);
+      }
+      uint64_t min_mb = 2048;
+      if (const char *mm = getenv("GMX_AUTO_DEVICES_MIN_MB")) min_mb = (uint64_t)atoll(mm);
+      if (mb >= min_mb)
+        for (int d = 1; d < n_vis; ++d) devices.push_back(d);
+    }
   }
   int rng_mode = 0;
   if (a.has("rng_compat")) {

@@ -347,6 +347,11 @@ int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index
  * in it as 16-bit limbs) plus the exchange of the grouped log (counted records) when the PRG has sites with more than
  * 5 alleles. Afterwards every engine holds the totals of the whole job: gmx_coverage_fetch on any of them. */
 typedef struct gmx_group gmx_group; /* N engines in ONE process, one per listed device (the `gram` executable) */
+/* GPUs visible to this process (0 without one). `gram genotype` without --device / --devices takes all of them when the
+ * reads files are large enough for sharding to pay (the front-end passes a fixed argument list, common.py:33-49, so the
+ * unmodified Python command scales with the node). */
+int gmx_device_count(void);
+/* The engines are created side by side, one host thread per device (the index upload of a whole-genome PRG is minutes). */
 int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts, const int *devices, int n_devices, gmx_group **out);
 void gmx_group_destroy(gmx_group *g);
 int gmx_group_size(const gmx_group *g);
