@@ -29,6 +29,8 @@
 #include <thread>
 #include <vector>
 
+#include "gmx_pargz.h"
+
 namespace gmx {
 
 class GzSource {
@@ -45,6 +47,9 @@ class GzSource {
       in_ = static_cast<const unsigned char *>(m);
       madvise(m, size_, MADV_SEQUENTIAL);
     }
+    if (const char *e = getenv("GMX_PARGZ_MIN")) par_min_ = (size_t)atoll(e);      // compressed bytes left for the parallel decoder to engage
+    if (const char *e = getenv("GMX_PARGZ_CHUNK")) par_chunk_ = std::max<size_t>(1024, (size_t)atoll(e));  // compressed bytes per piece
+    if (const char *e = getenv("GMX_PARGZ")) par_on_ = atoi(e) != 0;
   }
   GzSource(const GzSource &) = delete;
   GzSource &operator=(const GzSource &) = delete;
@@ -65,6 +70,10 @@ class GzSource {
         got += n;
         continue;
       }
+      if (par_active_) {  // a plain member being decoded on all threads: its next round of pieces into the carry buffer
+        par_round();
+        continue;
+      }
       if (!streaming_ && pos_ >= size_) break;
       if (!streaming_ && bgzf_at(pos_)) {
         got += read_bgzf(dst + got, want - got);
@@ -76,7 +85,8 @@ class GzSource {
     }
     return got;
   }
-  bool at_end() const { return !streaming_ && pos_ >= size_ && carry_at_ >= carry_.size(); }
+  bool at_end() const { return !streaming_ && !par_active_ && pos_ >= size_ && carry_at_ >= carry_.size(); }
+  uint64_t parallel_pieces() const { return n_par_pieces_; }
   // what the file was, for the feed trace: members inflated side by side / bytes through the single zlib stream
   uint64_t bgzf_members() const { return n_bgzf_; }
   uint64_t stream_bytes() const { return n_stream_bytes_; }
@@ -202,9 +212,11 @@ class GzSource {
         pos_ = size_;  // trailing bytes that are no gzip member: ignored, as zlib's gzread does
         return 0;
       }
+      if (par_on_ && threads_ >= 2 && size_ - pos_ >= par_min_ && par_begin()) return 0;
       memset(&zs_, 0, sizeof(zs_));
       if (inflateInit2(&zs_, 15 + 16) != Z_OK) fail("zlib: inflateInit2 failed");
       streaming_ = true;
+      raw_mode_ = false;
     }
     size_t got = 0;
     while (got < want) {
@@ -218,6 +230,16 @@ class GzSource {
       const size_t n = out_chunk - zs_.avail_out;
       got += n;
       n_stream_bytes_ += n;
+      if (raw_mode_ && n) {
+        par_crc_ = (uint32_t)crc32(par_crc_, reinterpret_cast<const unsigned char *>(dst + got - n), (uInt)n);
+        par_len_ += n;
+      }
+      if (rc == Z_STREAM_END && raw_mode_) {  // the deflate data zlib took over from the parallel decoder ends: the trailer is ours
+        end_stream();
+        raw_mode_ = false;
+        check_trailer();
+        break;
+      }
       if (rc == Z_STREAM_END) {  // end of a member: another one, a BGZF run, trailing bytes, or the end of the file
         if (pos_ + 2 <= size_ && in_[pos_] == 0x1f && in_[pos_ + 1] == 0x8b && !bgzf_at(pos_)) {
           if (inflateReset(&zs_) != Z_OK) fail("zlib: inflateReset failed");
@@ -243,7 +265,187 @@ class GzSource {
   z_stream zs_;
   std::vector<char> carry_;
   size_t carry_at_ = 0;
-  uint64_t n_bgzf_ = 0, n_stream_bytes_ = 0;
+  uint64_t n_bgzf_ = 0, n_stream_bytes_ = 0, n_par_pieces_ = 0;
+  // ---- a plain member on all threads (gmx_pargz.h) ----
+  bool par_on_ = true, par_active_ = false, raw_mode_ = false;
+  size_t par_min_ = (size_t)8 << 20, par_chunk_ = (size_t)2 << 20;
+  uint64_t par_bit_ = 0;              // verified position in the deflate data (bit offset in the file)
+  std::vector<uint8_t> par_window_;   // the last <= 32 KB of the member's output so far
+  uint32_t par_crc_ = 0;
+  uint64_t par_len_ = 0;
+  int par_lone_rounds_ = 0;           // rounds in a row in which only the first piece counted
+
+  // the member at pos_: gzip header (RFC 1952) -> where its deflate data starts. False: not a header this decoder takes.
+  bool par_begin() {
+    const unsigned char *p = in_ + pos_;
+    const size_t left = size_ - pos_;
+    if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return false;
+    const unsigned flg = p[3];
+    size_t at = 10;
+    if (flg & 4) {
+      if (at + 2 > left) return false;
+      at += 2 + le16(p + at);
+    }
+    for (int f = 0; f < 2; ++f)
+      if (flg & (f ? 16 : 8)) {
+        while (at < left && p[at]) ++at;
+        ++at;
+      }
+    if (flg & 2) at += 2;
+    if (at + 8 >= left) return false;
+    par_bit_ = (uint64_t)(pos_ + at) * 8;
+    par_window_.clear();
+    par_crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
+    par_len_ = 0;
+    par_lone_rounds_ = 0;
+    par_active_ = true;
+    return true;
+  }
+
+  void check_trailer() {  // pos_ at the member's 8-byte trailer: CRC-32 and length (mod 2^32) of what was decoded
+    if (pos_ + 8 > size_) fail("truncated gzip stream (no trailer)");
+    if (le32(in_ + pos_) != par_crc_) fail("gzip CRC mismatch");
+    if (le32(in_ + pos_ + 4) != (uint32_t)par_len_) fail("gzip length mismatch");
+    pos_ += 8;
+    if (!(pos_ + 2 <= size_ && in_[pos_] == 0x1f && in_[pos_ + 1] == 0x8b)) pos_ = size_;  // trailing bytes: ignored, as gzread does
+  }
+
+  // hands the rest of the member to zlib: a raw deflate stream from bit par_bit_ with the known window
+  void par_to_zlib() {
+    par_active_ = false;
+    memset(&zs_, 0, sizeof(zs_));
+    if (inflateInit2(&zs_, -15) != Z_OK) fail("zlib: inflateInit2 failed");
+    streaming_ = true;
+    raw_mode_ = true;
+    pos_ = (size_t)(par_bit_ >> 3);
+    const unsigned k = (unsigned)(par_bit_ & 7);
+    if (k) {
+      if (inflatePrime(&zs_, 8 - (int)k, in_[pos_] >> k) != Z_OK) fail("zlib: inflatePrime failed");
+      ++pos_;
+    }
+    if (!par_window_.empty() && inflateSetDictionary(&zs_, par_window_.data(), (uInt)par_window_.size()) != Z_OK)
+      fail("zlib: inflateSetDictionary failed");
+  }
+
+  template <class F>
+  void on_threads(size_t n_items, F fn) {
+    std::atomic<size_t> next{0};
+    std::string error;
+    std::mutex mu;
+    auto work = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= n_items) break;
+        try {
+          fn(i);
+        } catch (std::exception const &e) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (error.empty()) error = e.what();
+        }
+      }
+    };
+    const unsigned T = (unsigned)std::min<size_t>(threads_, n_items);
+    if (T <= 1) {
+      work();
+    } else {
+      std::vector<std::thread> pool;
+      for (unsigned t = 0; t < T; ++t) pool.emplace_back(work);
+      for (auto &t : pool) t.join();
+    }
+    if (!error.empty()) throw std::runtime_error(error);
+  }
+
+  // One round: up to `threads_` pieces of par_chunk_ compressed bytes from par_bit_ on, decoded side by side, verified in
+  // stream order, written to the carry buffer as bytes.
+  void par_round() {
+    using namespace pargz;
+    const uint8_t *base = in_, *end = in_ + size_;
+    const uint64_t byte0 = par_bit_ >> 3;
+    const size_t T = std::max<size_t>(2, threads_);
+    // piece starts: the verified position, then a block found in each following chunk
+    std::vector<uint64_t> starts(T, ~0ull);
+    starts[0] = par_bit_;
+    on_threads(T - 1, [&](size_t i) {
+      const uint64_t from = (byte0 + (i + 1) * par_chunk_) * 8;
+      if (from + 64 >= (uint64_t)size_ * 8) return;
+      starts[i + 1] = find_block(base, end, from, std::min<uint64_t>(from + par_chunk_ * 8, (uint64_t)size_ * 8));
+    });
+    std::vector<Piece> pcs;
+    for (size_t i = 0; i < T; ++i) {
+      if (starts[i] == ~0ull) continue;
+      pcs.emplace_back();
+      pcs.back().start_bit = starts[i];
+      pcs.back().stop_bit = ~0ull;
+      if (pcs.size() > 1) pcs[pcs.size() - 2].stop_bit = starts[i];
+    }
+    pcs[0].known_window = true;
+    const uint64_t soft = (byte0 + T * par_chunk_) * 8;
+    on_threads(pcs.size(), [&](size_t j) {
+      Piece &pc = pcs[j];
+      if (pc.known_window) pc.sym.init_known(par_window_.data(), par_window_.size());
+      else pc.sym.init_unknown();
+      decode_piece(base, end, pc, soft);
+    });
+    if (!pcs[0].ok) fail("damaged gzip stream (deflate data at byte " + std::to_string(byte0) + ")");
+    size_t n_valid = 1;
+    while (n_valid < pcs.size() && !pcs[n_valid - 1].final && pcs[n_valid].ok && pcs[n_valid - 1].end_bit == pcs[n_valid].start_bit) ++n_valid;
+    // windows in stream order: the resolved tail of every piece is the window of the next (32 K symbols each: the serial part)
+    std::vector<std::vector<uint8_t>> win(n_valid + 1);
+    win[0].assign(kWindow, 0);
+    std::copy(par_window_.begin(), par_window_.end(), win[0].end() - par_window_.size());
+    size_t total = 0;
+    for (size_t j = 0; j < n_valid; ++j) {
+      Piece &pc = pcs[j];
+      pc.out_at = total;
+      const size_t n = pc.sym.out_size();
+      total += n;
+      win[j + 1].resize(kWindow);
+      const size_t take = std::min<size_t>(n, kWindow);
+      if (take < kWindow) std::copy(win[j].begin() + take, win[j].end(), win[j + 1].begin());
+      const uint16_t *tail = pc.sym.v.data() + pc.sym.n - take;
+      for (size_t i = 0; i < take; ++i) {
+        const uint16_t s = tail[i];
+        win[j + 1][kWindow - take + i] = s < kUnknown ? (uint8_t)s : win[j][s - kUnknown];
+      }
+    }
+    carry_.resize(total);
+    carry_at_ = 0;
+    on_threads(n_valid, [&](size_t j) {
+      Piece &pc = pcs[j];
+      const uint16_t *src = pc.sym.v.data() + kWindow;
+      const size_t n = pc.sym.out_size();
+      uint8_t *dst = reinterpret_cast<uint8_t *>(carry_.data()) + pc.out_at;
+      const uint8_t *w = win[j].data();
+      for (size_t i = 0; i < n; ++i) {
+        const uint16_t s = src[i];
+        dst[i] = s < kUnknown ? (uint8_t)s : w[s - kUnknown];
+      }
+      uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
+      for (size_t at = 0; at < n; at += (size_t)1 << 30) c = (uint32_t)crc32(c, dst + at, (uInt)std::min<size_t>(n - at, (size_t)1 << 30));
+      pc.crc = c;
+      std::vector<uint16_t>().swap(pc.sym.v);
+    });
+    for (size_t j = 0; j < n_valid; ++j) {
+      const size_t n = (j + 1 < n_valid ? pcs[j + 1].out_at : total) - pcs[j].out_at;
+      par_crc_ = (uint32_t)crc32_combine(par_crc_, pcs[j].crc, (z_off_t)n);
+      par_len_ += n;
+    }
+    n_par_pieces_ += n_valid;
+    const Piece &last = pcs[n_valid - 1];
+    par_bit_ = last.end_bit;
+    // the window as the known bytes before par_bit_: at most 32 KB, fewer near the member's start
+    const uint64_t known = std::min<uint64_t>(par_len_, kWindow);
+    par_window_.assign(win[n_valid].end() - known, win[n_valid].end());
+    if (last.final) {
+      par_active_ = false;
+      pos_ = (size_t)((par_bit_ + 7) >> 3);
+      check_trailer();
+      return;
+    }
+    // speculation that keeps failing (no dynamic block to find, binary data): zlib takes the rest of the member
+    par_lone_rounds_ = n_valid == 1 ? par_lone_rounds_ + 1 : 0;
+    if (par_lone_rounds_ >= 2 || (uint64_t)size_ - (par_bit_ >> 3) < par_min_ / 2) par_to_zlib();
+  }
 };
 
 }  // namespace gmx

@@ -1468,6 +1468,30 @@ int main(int argc, const char *const *argv) {
     if (argc < cmd_at + 3) die("usage: gram _parse_bench FILE THREADS [REPEATS]");
     return run_parse_bench(argv[cmd_at + 1], atoi(argv[cmd_at + 2]), argc > cmd_at + 3 ? atoi(argv[cmd_at + 3]) : 3);
   }
+  if (command == "_gz_info") {  // test / bench hook: a gzip file through GzSource alone: bytes, CRC-32, how it was decompressed, rate
+    if (cmd_at + 2 >= argc) return 1;
+    try {
+      const double t0 = now_s();
+      gmx::GzSource src(argv[cmd_at + 1], (unsigned)std::max(1, atoi(argv[cmd_at + 2])));
+      std::vector<char> buf((size_t)96 << 20);
+      uint64_t total = 0;
+      uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+      const bool with_crc = !getenv("GMX_GZ_INFO_NO_CRC");
+      for (;;) {
+        const size_t got = src.read(buf.data(), buf.size());
+        if (got == 0) break;
+        if (with_crc) crc = (uint32_t)crc32(crc, reinterpret_cast<const unsigned char *>(buf.data()), (uInt)got);
+        total += got;
+      }
+      const double dt = now_s() - t0;
+      std::cout << "bytes=" << total << " crc=" << crc << " pieces=" << src.parallel_pieces() << " bgzf_members=" << src.bgzf_members()
+                << " stream_bytes=" << src.stream_bytes() << " seconds=" << dt << " MBps=" << (dt > 0 ? total / dt / 1e6 : 0) << std::endl;
+      return 0;
+    } catch (std::exception const &e) {
+      std::cout << "gram: " << e.what() << std::endl;
+      return 1;
+    }
+  }
   if (command == "_parse_check") {  // test hook: both read parsers on one file, no GPU (tests/test_gram_cli.py)
     if (cmd_at + 2 >= argc) return 1;
     return run_parse_check(argv[cmd_at + 1], atoi(argv[cmd_at + 2]));

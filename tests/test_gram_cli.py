@@ -350,3 +350,74 @@ def test_damaged_gzip_is_fatal(tmp_path, kind):
     path.write_bytes(data)
     out = subprocess.run([build_gram(), "_parse_check", str(path), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode != 0, out.stdout
+
+
+# ---- a plain gzip stream on all threads (gmx_pargz.h: block starts found by speculation, unknown windows as placeholders) ---
+def _gz(data: bytes, level=6, strategy=None) -> bytes:
+    import zlib
+    c = zlib.compressobj(level, zlib.DEFLATED, 31, 8, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    return c.compress(data) + c.flush()
+
+
+@pytest.mark.parametrize("chunk,threads", [("20000", 4), ("60000", 8), ("7000", 3), ("300000", 16)])
+def test_plain_gzip_decoded_on_all_threads(tmp_path, monkeypatch, chunk, threads):
+    """Pieces of the compressed stream decoded side by side: every piece must start exactly where the one before it ends,
+    placeholders of the unknown 32 KB are resolved in stream order, CRC-32 and length checked against the trailer. The
+    parsed reads equal those of the plain file, whatever the piece size and the thread count."""
+    monkeypatch.setenv("GMX_PARGZ_MIN", "1000")
+    monkeypatch.setenv("GMX_PARGZ_CHUNK", chunk)
+    text = _fastq_text(9000, 31)
+    for level in (1, 6, 9):
+        _same_as_plain(tmp_path, text, _gz(text.encode(), level), threads=threads)
+
+
+def test_parallel_gzip_really_ran_and_falls_back_where_it_cannot(tmp_path, monkeypatch):
+    """`gram _gz_info` reports how a file was decompressed. Dynamic-Huffman streams are taken apart into pieces; streams with
+    no dynamic block to find (fixed codes, stored blocks) go to zlib from the last verified bit, primed with the known
+    window; concatenated members each get their own treatment."""
+    import subprocess
+    from gramtools_amd.build import build_gram
+    monkeypatch.setenv("GMX_PARGZ_MIN", "1000")
+    monkeypatch.setenv("GMX_PARGZ_CHUNK", "30000")
+    import zlib
+    text = _fastq_text(9000, 33)
+
+    def info(binary, name="r.fastq.gz"):
+        (tmp_path / name).write_bytes(binary)
+        out = subprocess.run([build_gram(), "_gz_info", str(tmp_path / name), "6"], stdout=subprocess.PIPE, text=True)
+        assert out.returncode == 0, out.stdout
+        return dict(kv.split("=") for kv in out.stdout.split())
+
+    a = info(_gz(text.encode()))
+    assert int(a["bytes"]) == len(text.encode()) and int(a["pieces"]) > 8 and int(a["crc"]) == zlib.crc32(text.encode())
+    for strategy, level in ((zlib.Z_FIXED, 6), (None, 0)):
+        b = info(_gz(text.encode(), level, strategy))
+        assert int(b["bytes"]) == len(text.encode()) and int(b["crc"]) == zlib.crc32(text.encode())
+        assert int(b["stream_bytes"]) > len(text) // 2   # most of it through zlib
+        _same_as_plain(tmp_path, text, _gz(text.encode(), level, strategy))
+    more = _fastq_text(2500, 34)
+    two = _gz(text.encode()) + _gz(more.encode(), 9)
+    c = info(two)
+    assert int(c["bytes"]) == len(text.encode()) + len(more.encode()) and int(c["pieces"]) > int(a["pieces"])
+    _same_as_plain(tmp_path, text + more, two)
+
+
+@pytest.mark.parametrize("kind", ["truncated", "flipped-bit", "bad-crc", "bad-length"])
+def test_damaged_plain_gzip_is_fatal_with_the_parallel_decoder(tmp_path, monkeypatch, kind):
+    import subprocess
+    from gramtools_amd.build import build_gram
+    monkeypatch.setenv("GMX_PARGZ_MIN", "1000")
+    monkeypatch.setenv("GMX_PARGZ_CHUNK", "25000")
+    d = bytearray(_gz(_fastq_text(8000, 35).encode()))
+    if kind == "truncated":
+        d = d[:len(d) * 2 // 3]
+    elif kind == "flipped-bit":
+        d[len(d) // 2] ^= 0x10
+    elif kind == "bad-crc":
+        d[-6] ^= 0xFF
+    else:
+        d[-2] ^= 0x01
+    path = tmp_path / "bad.fastq.gz"
+    path.write_bytes(bytes(d))
+    out = subprocess.run([build_gram(), "_parse_check", str(path), "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode != 0, out.stdout

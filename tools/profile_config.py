@@ -1,0 +1,63 @@
+"""One configuration's index built and its reads mapped through the kernel-pipeline loop (bytes resident in HBM) and the
+packed host feed (2-bit stream from page-locked memory), for use under rocprofv3 (tools/profile_round4.sh):
+  python tools/profile_config.py 3|4|4s [N_READS=1000000] [STEPS=6]
+    3   BASELINE configs[3]: 64.4 Mb + 1.8 M sites, k = 14 (index 15.5 GB)
+    4   BASELINE configs[4]: 3.1 Gb + 85 M sites, k = 14 (index 160 GB; 4-5 minutes of build)
+    4s  configs[4] at an eighth of its length (400 Mb + 11 M sites)"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+torch.cuda.init()
+sys.path.insert(0, ".")
+from gramtools_amd import Index, Quasimapper, master_seeds, pack_reads_2bit  # noqa: E402
+from gramtools_amd.synth import chr20_recipe, flat_offsets, genome_recipe_file  # noqa: E402
+
+which = sys.argv[1]
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+t0 = time.time()
+if which == "3":
+    prg, reads = chr20_recipe(64_444_167, 1_800_000, n, 32)
+    ix = Index(prg, 14)
+else:
+    G, S, seed = (3_100_000_000, 85_000_000, 61) if which == "4" else (400_000_000, 11_000_000, 51)
+    path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gmx_profile.prg")
+    _, reads = genome_recipe_file(path, G, S, n, seed)
+    ix = Index(path, 14)
+    os.remove(path)
+info = ix.info
+print(f"configs[{which}]: {info.n_text - 1} symbols, {info.n_sites} sites, index {info.index_bytes / 1e9:.1f} GB, k2 = {info.kmer_size2}, "
+      f"seed_shift {info.seed_shift} ({time.time() - t0:.0f} s)", flush=True)
+seeds = master_seeds(42, [n])
+offs = flat_offsets(n, reads.shape[1])
+flat = np.ascontiguousarray(reads).reshape(-1)
+qm = Quasimapper(ix)
+d_r, d_o = torch.from_numpy(flat).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda()
+d_s = torch.from_numpy(np.ascontiguousarray(seeds).view(np.int32).copy()).cuda()
+stream = torch.cuda.current_stream().cuda_stream
+for rep in range(2):  # (the first round sizes the workspace)
+    qm.reset(stream=stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        qm.map_reads_device(d_r, d_o, d_s, n, stream=stream)
+    qm.sync()
+    dt = (time.perf_counter() - t0) / steps
+print(f"kernel pipeline: {dt * 1e3:.3f} ms per {n} reads = {n / dt / 1e6:.1f} M reads/s", flush=True)
+print("queues of the last batch:", qm.queue_counts(), flush=True)
+pk = pack_reads_2bit(flat, offs, uniform_len=reads.shape[1], pinned=True)
+for rep in range(2):
+    qm.reset()
+    qm.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        qm.map_reads_packed(pk, seeds)
+    qm.sync()
+    dt = (time.perf_counter() - t0) / steps
+print(f"packed host feed: {dt * 1e3:.3f} ms per {n} reads = {n / dt / 1e6:.1f} M reads/s", flush=True)
+print("stats:", qm.coverage().stats.as_dict(), flush=True)
+pk.close()
