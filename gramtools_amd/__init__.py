@@ -21,6 +21,11 @@ from .quasimap import (  # noqa: F401
     encode_dna_bases,
     dump_allele_sum,
     dump_allele_base,
+    allele_base_json,
+    hash_allele_groups,
+    group_id_counts,
+    group_id_alleles,
+    grouped_json,
     dump_grouped_allele_counts,
     RNG_LEMIRE,
     RNG_DIVISION,

@@ -249,6 +249,77 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     mode = GMX_MODE_STATE;
     return true;
   }
+  // Would a text-form state at PRG position `tp`, read position `pos`, survive its first text step? Exactly the decision
+  // gmx_dfs_text_apply takes on the record of tp - 1: dead iff the nearest event of the compared range is a mismatch (not a
+  // marker). One 32-byte fetch and ~40 instructions instead of three iterations of the wave loop.
+  template <class Reader>
+  __device__ __forceinline__ bool seed_text_alive(const GmxIndexView &ix, Reader &rd, uint32_t tp, uint32_t pos, uint32_t stop) const {
+    if (pos <= stop) return true;  // already final
+    if (tp == 0) return false;     // PRG start: nothing extends the match (gmx_dfs_text_apply)
+    GmxLane t;
+    t.a = tp, t.b = GMX_TEXT_MARK, t.tvd = t.tvg = GMX_NIL, t.pos = pos, t.mode = GMX_MODE_STATE, t.have = true;
+    const GmxTextRec rec = ix.text[gmx_dfs_text_rec(t)];
+    uint64_t rlo, rhi;
+    gmx_dfs_text_read_planes(t, rd, rlo, rhi);
+    const uint32_t slot = (tp - 1u) & GMX_TEXT_MASK, avail = pos - stop, n = avail < slot + 1u ? avail : slot + 1u;
+    const uint64_t range = gmx_below64(n) << (slot + 1u - n);
+    const uint64_t events = (((rec.lo ^ rlo) | (rec.hi ^ rhi)) | rec.mk) & range;
+    if (events == 0) return true;
+    return ((rec.mk >> (63u - (uint32_t)__builtin_clzll(events))) & 1ull) != 0;
+  }
+  // The seed cursor with a screen in front (indexes whose k-mers have many states: a whole-genome PRG has ~12 occurrences
+  // per 14-mer, a third of them across a site — and all but one of a read's seed states die at their first text step, after
+  // three iterations of the wave loop each: next state, suffix-array look-up, compare). States over ONE suffix-array position
+  // are tested here, in a tight per-lane loop, and only the survivors enter the wave loop — already in text form; a
+  // path-less state over a few positions (the k-mer's occurrences outside sites) is taken apart into its occurrences, which
+  // is the same search (load_seed_cursor, gmx_search_big_kernel), and screened likewise. Nothing changes for the states
+  // that survive: they are searched by the same code from the same position.
+  template <class Reader>
+  __device__ __forceinline__ bool next_seed_screened(const GmxIndexView &ix, Reader &rd, uint32_t stop, uint32_t &a, uint32_t &b,
+                                                     uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    while (seed_left != 0 && status == GMX_TASK_MAPPED) {
+      const uint32_t *p = ix.seed_words + seed_off;
+      const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+      if (hi == GMX_TEXT_MARK || lo == hi) {  // (one position: in text form in the device copy of the entries)
+        const uint32_t tp = hi == GMX_TEXT_MARK ? lo : ix.sa[lo];
+        if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) {
+          seed_off += 4u + 2u * nt + ng;
+          --seed_left;
+          continue;
+        }
+        const bool ok = next_seed(ix, true, a, b, tvd, tvg, pos, mode);
+        if (ok) {
+          a = tp;
+          b = GMX_TEXT_MARK;
+        }
+        return ok;
+      }
+      if (nt == 0 && ng == 0 && hi - lo < 32u && seed_pos > stop) {
+        if (n_out == mark_out) arena_n = mark_arena;  // (as next_seed: the state before left nothing behind)
+        mark_arena = arena_n;
+        mark_out = n_out;
+        seed_off += 4u;
+        --seed_left;
+        uint32_t first = 0, n_alive = 0;
+        for (uint32_t i = lo; i <= hi; ++i) {
+          const uint32_t tp = ix.sa[i];
+          if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) continue;
+          if (n_alive == 0) first = tp;
+          else if (!push(tp, GMX_TEXT_MARK, GMX_NIL, GMX_NIL, seed_pos, GMX_MODE_STATE)) fail(GMX_TASK_OVERFLOW);
+          ++n_alive;
+        }
+        if (n_alive == 0) continue;
+        a = first;
+        b = GMX_TEXT_MARK;
+        tvd = tvg = GMX_NIL;
+        pos = seed_pos;
+        mode = GMX_MODE_STATE;
+        return status == GMX_TASK_MAPPED;
+      }
+      return next_seed(ix, true, a, b, tvd, tvg, pos, mode);
+    }
+    return false;
+  }
   __device__ __forceinline__ bool park(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
     if (n_out >= out_cap) return false;
     reinterpret_cast<GmxParked *>(out)[n_out++] = GmxParked{a, b, tvd, tvg, pos | (mode << 30)};
@@ -359,6 +430,11 @@ struct BigCtx {  // the same DFS queue with everything in global memory and runt
   __device__ __forceinline__ bool more_seeds() const { return false; }
   __device__ __forceinline__ bool next_seed(const GmxIndexView &, bool, uint32_t &, uint32_t &, uint32_t &, uint32_t &, uint32_t &,
                                             uint32_t &) {
+    return false;
+  }
+  template <class Reader>
+  __device__ __forceinline__ bool next_seed_screened(const GmxIndexView &, Reader &, uint32_t, uint32_t &, uint32_t &, uint32_t &, uint32_t &,
+                                                     uint32_t &, uint32_t &) {
     return false;
   }
   uint32_t sp, cap;
@@ -494,18 +570,27 @@ __device__ __forceinline__ const uint32_t *gmx_seed_entry(const GmxIndexView &ix
 // A single path-less state over ONE suffix-array position is stored in text form — a = its PRG position, b =
 // GMX_TEXT_MARK — in the device copies: the search needs no suffix-array look-up to start (one dependent, always-missing
 // fetch per task less: 64 MB of the extend kernel's 390 MB of fabric-side fetch at config[1]).
-__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, const uint32_t *seed_words, uint32_t seed_shift, const uint32_t *sa) {
+// The same inside the multi-state entries (round 4): a state over one suffix-array position — with or without paths — is
+// rewritten in the device copy of the words as (PRG position, GMX_TEXT_MARK). A whole-genome index has ~16 states per k-mer
+// and all but one of a read's seed states die at their first compare: the look-up was a third of their memory requests,
+// each a TLB miss in a 14 GB table. Every device reader of the entries takes both forms (gmx_seed_state_width).
+__device__ __forceinline__ uint32_t gmx_seed_state_width(uint32_t lo, uint32_t hi) { return hi == GMX_TEXT_MARK ? 1u : hi - lo + 1u; }
+__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, uint32_t *seed_words, uint32_t seed_shift, const uint32_t *sa) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const GmxSeed s = seeds[i];
     if (s.a != GMX_SEED_COMPLEX) {
       if (s.a == s.b) seeds[i] = GmxSeed{sa[s.a], GMX_TEXT_MARK};
       continue;
     }
-    const uint32_t *w = seed_words + ((size_t)s.b << seed_shift);
+    uint32_t *w = seed_words + ((size_t)s.b << seed_shift);
     const uint32_t ns = *w++;
     bool big = ns > 0xFFFFu;
-    for (uint32_t j = 0; j < ns && !big; ++j) {
-      big = w[1] >= w[0] + GMX_SEED_SPLIT_MAX && w[2] == 0 && w[3] == 0;
+    for (uint32_t j = 0; j < ns; ++j) {
+      big = big || (w[1] >= w[0] + GMX_SEED_SPLIT_MAX && w[2] == 0 && w[3] == 0);
+      if (w[0] == w[1]) {
+        w[0] = sa[w[0]];
+        w[1] = GMX_TEXT_MARK;
+      }
       w += 4 + 2 * w[2] + w[3];
     }
     seeds[i].b = s.b | (big ? GMX_SEEDF_BIG : 0u) | (ns == 0 ? GMX_SEEDF_EMPTY : 0u);
@@ -696,7 +781,7 @@ __device__ void dfs_run_wave(const GmxIndexView &ix, Ctx &ctx, Reader &rd, uint3
         } else if (kind == GMX_FAST_POP) {
           gmx_dfs_pop(ctx, ln);
         } else if (CURSOR && kind == GMX_WAVE_SEED) {
-          ln.have = ctx.next_seed(ix, true, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
+          ln.have = ctx.next_seed_screened(ix, rd, stop, ln.a, ln.b, ln.tvd, ln.tvg, ln.pos, ln.mode);
         }
       }
       auto text_rec = [&]() {
@@ -1228,7 +1313,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       const uint32_t ns = *w++;
       bool fits = ns <= GMX_INST_MAX;
       for (uint32_t q = 0; q < ns && fits; ++q) {
-        const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
+        const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? gmx_seed_state_width(w[0], w[1]) : 1u;
         fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * w[2] + w[3] + 2 <= GMX_FAST_ARENA;
         width += n_q;
         w += 4 + 2 * w[2] + w[3];
@@ -1274,7 +1359,7 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         const uint32_t ns = *w++;
         uint32_t i = 0;
         for (uint32_t q = 0; q < ns; ++q) {
-          const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? w[1] - w[0] + 1u : 1u;
+          const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? gmx_seed_state_width(w[0], w[1]) : 1u;
           for (uint32_t x = 0; x < n_q; ++x, ++i) {
             o.inst_list[first + i] = (over_at[j] << 6) | i;
             o.inst_sa[first + i] = GMX_INST_COMPLEX | (q << 8) | x;
@@ -1346,8 +1431,8 @@ __device__ void gmx_inst_rounds(const GmxIndexView &ix, const BatchView &b, cons
         for (uint32_t st = (what >> 8) & 0x7FFFFFu; st > 0; --st) p += 4 + 2 * p[2] + p[3];
         const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
         p += 4;
-        if (nt == 0 && ng == 0) {
-          ctx.push(ix.sa[lo + (what & 255u)], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
+        if (nt == 0 && ng == 0) {  // (one position: already in text form in the device copy, gmx_seed_mark_kernel)
+          ctx.push(hi == GMX_TEXT_MARK ? lo : ix.sa[lo + (what & 255u)], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
         } else {
           uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
           bool ok = true;
@@ -3190,9 +3275,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       gmx_set_error("the seed tables hold more than 2^30 units of multi-state entries");
       rc = GMX_ECAP;
     } else {
-      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), v.seed_words, v.seed_shift, v.sa);
+      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa);
       if (h.kmer_size2)
-        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), v.seed_words, v.seed_shift, v.sa);
+        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa);
       rc |= hipDeviceSynchronize() != hipSuccess;
     }
   }

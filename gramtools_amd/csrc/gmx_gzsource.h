@@ -21,7 +21,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -70,8 +72,8 @@ class GzSource {
         got += n;
         continue;
       }
-      if (par_active_) {  // a plain member being decoded on all threads: its next round of pieces into the carry buffer
-        par_round();
+      if (par_active_) {  // a plain member being decoded on all threads: its next round of pieces, straight to the caller
+        got += par_round(dst + got, want - got);  // (what the caller did not ask for waits in the carry buffer)
         continue;
       }
       if (!streaming_ && pos_ >= size_) break;
@@ -357,8 +359,11 @@ class GzSource {
 
   // One round: up to `threads_` pieces of par_chunk_ compressed bytes from par_bit_ on, decoded side by side, verified in
   // stream order, written to the carry buffer as bytes.
-  void par_round() {
+  size_t par_round(char *dst, size_t want) {
     using namespace pargz;
+    static const bool trace = getenv("GMX_PARGZ_TRACE") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     const uint8_t *base = in_, *end = in_ + size_;
     const uint64_t byte0 = par_bit_ >> 3;
     const size_t T = std::max<size_t>(2, threads_);
@@ -370,6 +375,7 @@ class GzSource {
       if (from + 64 >= (uint64_t)size_ * 8) return;
       starts[i + 1] = find_block(base, end, from, std::min<uint64_t>(from + par_chunk_ * 8, (uint64_t)size_ * 8));
     });
+    const double t1 = now();
     std::vector<Piece> pcs;
     for (size_t i = 0; i < T; ++i) {
       if (starts[i] == ~0ull) continue;
@@ -382,10 +388,12 @@ class GzSource {
     const uint64_t soft = (byte0 + T * par_chunk_) * 8;
     on_threads(pcs.size(), [&](size_t j) {
       Piece &pc = pcs[j];
-      if (pc.known_window) pc.sym.init_known(par_window_.data(), par_window_.size());
-      else pc.sym.init_unknown();
+      const size_t expect = par_chunk_ * 6;  // (FASTQ inflates 3-5x; the buffer grows if that is not enough)
+      if (pc.known_window) pc.sym.init_known(par_window_.data(), par_window_.size(), expect);
+      else pc.sym.init_unknown(expect);
       decode_piece(base, end, pc, soft);
     });
+    const double t2 = now();
     if (!pcs[0].ok) fail("damaged gzip stream (deflate data at byte " + std::to_string(byte0) + ")");
     size_t n_valid = 1;
     while (n_valid < pcs.size() && !pcs[n_valid - 1].final && pcs[n_valid].ok && pcs[n_valid - 1].end_bit == pcs[n_valid].start_bit) ++n_valid;
@@ -408,22 +416,35 @@ class GzSource {
         win[j + 1][kWindow - take + i] = s < kUnknown ? (uint8_t)s : win[j][s - kUnknown];
       }
     }
-    carry_.resize(total);
+    const double t3 = now();
+    // bytes: the first `direct` of them to the caller's buffer, the rest to the carry buffer
+    const size_t direct = std::min(total, want);
+    if (carry_.size() < total - direct) carry_ = std::vector<char>();  // (no copy of stale bytes when it grows)
+    carry_.resize(total - direct);
     carry_at_ = 0;
+    const double t4 = now();
     on_threads(n_valid, [&](size_t j) {
       Piece &pc = pcs[j];
       const uint16_t *src = pc.sym.v.data() + kWindow;
       const size_t n = pc.sym.out_size();
-      uint8_t *dst = reinterpret_cast<uint8_t *>(carry_.data()) + pc.out_at;
       const uint8_t *w = win[j].data();
-      for (size_t i = 0; i < n; ++i) {
-        const uint16_t s = src[i];
-        dst[i] = s < kUnknown ? (uint8_t)s : w[s - kUnknown];
-      }
       uint32_t c = (uint32_t)crc32(0L, Z_NULL, 0);
-      for (size_t at = 0; at < n; at += (size_t)1 << 30) c = (uint32_t)crc32(c, dst + at, (uInt)std::min<size_t>(n - at, (size_t)1 << 30));
+      // the piece's bytes [out_at, out_at + n) of the round: below `direct` to dst, from there on to the carry buffer
+      for (int part = 0; part < 2; ++part) {
+        const size_t lo = part == 0 ? pc.out_at : std::max(pc.out_at, direct);
+        const size_t hi = part == 0 ? std::min(pc.out_at + n, direct) : pc.out_at + n;
+        if (lo >= hi) continue;
+        uint8_t *out = reinterpret_cast<uint8_t *>(part == 0 ? dst + lo : carry_.data() + (lo - direct));
+        const uint16_t *from = src + (lo - pc.out_at);
+        const size_t m = hi - lo;
+        for (size_t i = 0; i < m; ++i) {
+          const uint16_t sy = from[i];
+          out[i] = sy < kUnknown ? (uint8_t)sy : w[sy - kUnknown];
+        }
+        for (size_t at = 0; at < m; at += (size_t)1 << 30) c = (uint32_t)crc32(c, out + at, (uInt)std::min<size_t>(m - at, (size_t)1 << 30));
+      }
       pc.crc = c;
-      std::vector<uint16_t>().swap(pc.sym.v);
+      pc.sym.v.release();
     });
     for (size_t j = 0; j < n_valid; ++j) {
       const size_t n = (j + 1 < n_valid ? pcs[j + 1].out_at : total) - pcs[j].out_at;
@@ -431,6 +452,9 @@ class GzSource {
       par_len_ += n;
     }
     n_par_pieces_ += n_valid;
+    if (trace)
+      fprintf(stderr, "[pargz] round: %zu of %zu pieces, %zu bytes: find %.1f ms, decode %.1f ms, windows %.1f ms, resize %.1f ms, bytes+crc %.1f ms\n",
+              n_valid, pcs.size(), total, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (now() - t4) * 1e3);
     const Piece &last = pcs[n_valid - 1];
     par_bit_ = last.end_bit;
     // the window as the known bytes before par_bit_: at most 32 KB, fewer near the member's start
@@ -440,11 +464,12 @@ class GzSource {
       par_active_ = false;
       pos_ = (size_t)((par_bit_ + 7) >> 3);
       check_trailer();
-      return;
+      return direct;
     }
     // speculation that keeps failing (no dynamic block to find, binary data): zlib takes the rest of the member
-    par_lone_rounds_ = n_valid == 1 ? par_lone_rounds_ + 1 : 0;
-    if (par_lone_rounds_ >= 2 || (uint64_t)size_ - (par_bit_ >> 3) < par_min_ / 2) par_to_zlib();
+    par_lone_rounds_ = n_valid == 1 && pcs.size() == 1 && (uint64_t)size_ - (par_bit_ >> 3) > 2 * par_chunk_ ? par_lone_rounds_ + 1 : 0;
+    if (par_lone_rounds_ >= 2) par_to_zlib();
+    return direct;
   }
 };
 

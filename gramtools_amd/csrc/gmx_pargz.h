@@ -22,7 +22,9 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -228,21 +230,48 @@ inline const BlockCodes &fixed_codes() {
 
 // Output of a piece: symbols behind a window of kWindow entries (placeholders, or the real bytes when they are known).
 struct Symbols {
-  std::vector<uint16_t> v;  // [0, kWindow): the window; the piece's output follows
+  // [0, kWindow): the window; the piece's output follows. A raw array: growing it must not zero-fill (a vector's resize
+  // does, and that was a quarter of a round's time), only the used part is copied.
+  struct Buf {
+    uint16_t *p = nullptr;
+    size_t cap = 0;
+    ~Buf() { free(p); }
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    Buf(Buf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr, o.cap = 0; }
+    uint16_t *data() { return p; }
+    const uint16_t *data() const { return p; }
+    uint16_t &operator[](size_t i) { return p[i]; }
+    size_t size() const { return cap; }
+    void grow(size_t want, size_t used) {
+      uint16_t *q = static_cast<uint16_t *>(malloc(want * sizeof(uint16_t)));
+      if (!q) throw std::bad_alloc();
+      if (used) memcpy(q, p, used * sizeof(uint16_t));
+      free(p);
+      p = q;
+      cap = want;
+    }
+    void release() {
+      free(p);
+      p = nullptr;
+      cap = 0;
+    }
+  } v;
   size_t n = kWindow;
-  void init_unknown() {
-    v.resize(kWindow + (1u << 20));
+  void init_unknown(size_t expect = (size_t)1 << 20) {
+    if (v.size() < kWindow + expect) v.grow(kWindow + expect, 0);
     for (uint32_t j = 0; j < kWindow; ++j) v[j] = (uint16_t)(kUnknown + j);
     n = kWindow;
   }
-  void init_known(const uint8_t *win, size_t have) {  // the last `have` (<= kWindow) bytes before the piece
-    v.resize(kWindow + (1u << 20));
+  void init_known(const uint8_t *win, size_t have, size_t expect = (size_t)1 << 20) {  // the last `have` (<= kWindow) bytes before the piece
+    if (v.size() < kWindow + expect) v.grow(kWindow + expect, 0);
     for (uint32_t j = 0; j < kWindow; ++j) v[j] = 0;
     for (size_t j = 0; j < have; ++j) v[kWindow - have + j] = win[j];
     n = kWindow;
   }
   inline void room(size_t more) {
-    if (n + more > v.size()) v.resize(std::max(v.size() * 2, n + more + (1u << 16)));
+    if (n + more > v.size()) v.grow(std::max(v.size() + v.size() / 2, n + more + (1u << 16)), n);
   }
   size_t out_size() const { return n - kWindow; }
 };

@@ -1468,6 +1468,15 @@ int main(int argc, const char *const *argv) {
     if (argc < cmd_at + 3) die("usage: gram _parse_bench FILE THREADS [REPEATS]");
     return run_parse_bench(argv[cmd_at + 1], atoi(argv[cmd_at + 2]), argc > cmd_at + 3 ? atoi(argv[cmd_at + 3]) : 3);
   }
+  if (command == "_read_stats") {  // test hook: ReadStats::compute_base_error_rate on a reads file (test_read_stats.cpp:14-48)
+    if (cmd_at + 1 >= argc) return 1;
+    ReadStats rs;
+    compute_base_error_rate(argv[cmd_at + 1], rs);
+    std::cout.precision(9);
+    std::cout << "num_bases=" << rs.num_bases_processed << " max_read_len=" << rs.max_read_length << " no_qual_reads=" << rs.no_qual_reads
+              << " mean_pb_error=" << rs.mean_pb_error << std::endl;
+    return 0;
+  }
   if (command == "_gz_info") {  // test / bench hook: a gzip file through GzSource alone: bytes, CRC-32, how it was decompressed, rate
     if (cmd_at + 2 >= argc) return 1;
     try {

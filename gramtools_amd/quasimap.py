@@ -378,26 +378,54 @@ def dump_allele_sum(cov: Coverage) -> str:
     return "".join(" ".join(str(c) for c in site) + "\n" for site in cov.allele_sum_coverage)
 
 
+def allele_base_json(sites) -> str:
+    """dump_allele_base_coverage (allele_base.cpp:49-107): {"allele_base_counts":[[[per-base of allele 0],...],...]}, compact."""
+    body = ",".join("[" + ",".join("[" + ",".join(str(int(c)) for c in al) + "]" for al in site) + "]" for site in sites)
+    return '{"allele_base_counts":[' + body + "]}"
+
+
 def dump_allele_base(cov: Coverage) -> str:
     """coverage/allele_base_coverage.json (allele_base.cpp:49-107)."""
-    sites = ",".join("[" + ",".join("[" + ",".join(str(c) for c in al) + "]" for al in site) + "]"
-                     for site in cov.allele_base_coverage)
-    return '{"allele_base_counts":[' + sites + "]}\n"
+    return allele_base_json(cov.allele_base_coverage) + "\n"
+
+
+def hash_allele_groups(sites) -> dict:
+    """hash_allele_groups (grouped_allele_counts.cpp:51-67): every distinct allele-id group of any site gets a group id,
+    ids are 0, 1, 2, ... without gaps. The reference hands them out in unordered_map order (labels); here: first
+    appearance, sites in order, a site's groups sorted."""
+    group_id = {}
+    for site in sites:
+        for ids in sorted(site):
+            group_id.setdefault(tuple(ids), len(group_id))
+    return group_id
+
+
+def group_id_counts(sites, group_hash):
+    """get_group_id_counts (grouped_allele_counts.cpp:69-84): per site {group id (as a string): count}, ordered by the numeric id."""
+    out = []
+    for site in sites:
+        d = {group_hash[tuple(ids)]: int(c) for ids, c in site.items()}
+        out.append({str(g): d[g] for g in sorted(d)})
+    return out
+
+
+def group_id_alleles(group_hash):
+    """get_group_id_alleles (grouped_allele_counts.cpp:86-93): {group id (string): allele ids}, ordered by the NUMERIC id."""
+    return {str(g): list(ids) for ids, g in sorted(group_hash.items(), key=lambda kv: kv[1])}
+
+
+def grouped_json(sites, group_hash) -> str:
+    """get_json(...).dump() (grouped_allele_counts.cpp:95-110): compact, keys in the order above."""
+    groups = ",".join(f'"{g}":[' + ",".join(str(a) for a in ids) + "]" for g, ids in group_id_alleles(group_hash).items())
+    counts = ",".join("{" + ",".join(f'"{g}":{c}' for g, c in d.items()) + "}" for d in group_id_counts(sites, group_hash))
+    return '{"grouped_allele_counts":{"allele_groups":{' + groups + '},"site_counts":[' + counts + "]}}"
 
 
 def dump_grouped_allele_counts(cov: Coverage) -> str:
     """coverage/grouped_allele_counts_coverage.json (grouped_allele_counts.cpp:51-110). Group ids are labels
     (the reference assigns them in unordered_map order); here: first appearance in site order."""
-    group_id, site_counts = {}, []
-    for site in cov.grouped_allele_counts:
-        d = {}
-        for ids in sorted(site):
-            gid = group_id.setdefault(ids, len(group_id))
-            d[gid] = site[ids]
-        site_counts.append(d)
-    groups = ",".join(f'"{g}":[' + ",".join(str(a) for a in ids) + "]" for ids, g in sorted(group_id.items(), key=lambda kv: kv[1]))
-    counts = ",".join("{" + ",".join(f'"{g}":{c}' for g, c in sorted(d.items())) + "}" for d in site_counts)
-    return '{"grouped_allele_counts":{"allele_groups":{' + groups + '},"site_counts":[' + counts + "]}}\n"
+    sites = cov.grouped_allele_counts
+    return grouped_json(sites, hash_allele_groups(sites)) + "\n"
 
 
 LOG_COUNTED = 0x80000000

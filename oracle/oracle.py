@@ -46,6 +46,11 @@ def _load():
         "gmo_reverse_complement": (None, [u8p, u64, u8p]),
         "gmo_all_kmers_in_index": (C.c_int, [vp, u8p, u64]),
         "gmo_max_cov_haplogroup": (None, [vp, u64, i64p, i64p]),
+        "gmo_extract_max_cov_allele": (C.c_long, [vp, u64, C.c_char_p, C.c_long, i64p]),
+        "gmo_set_par_map": (C.c_int, [vp, i64p, u64]),
+        "gmo_check_site_uniqueness": (C.c_int, [vp, i64p]),
+        "gmo_assign_loci": (C.c_long, [vp, i64p, u64, i64p, i64p, C.c_long]),
+        "gmo_unique_site_paths": (C.c_long, [vp, i64p, i64p, C.c_long]),
         "gmo_set_grouped": (None, [vp, u64, i64p, u64, u32]),
         "gmo_text_size": (u64, [vp]),
         "gmo_sa": (None, [vp, u32p]),
@@ -351,6 +356,50 @@ class Oracle:
         nl = out[1 + nb]
         loci = [(out[2 + nb + 2 * j], out[3 + nb + 2 * j]) for j in range(nl)]
         return base, loci
+
+    def extract_max_cov_allele(self, site_marker):
+        """(sequence letters, coverage) of the site's most covered allele (read_stats.cpp:94-117)."""
+        buf = C.create_string_buffer(1 << 16)
+        cov = C.c_int64(0)
+        n = self.lib.gmo_extract_max_cov_allele(self.h, site_marker, buf, len(buf), C.byref(cov))
+        if n < 0:
+            raise self._err()
+        return buf.value.decode(), int(cov.value)
+
+    def set_par_map(self, par_map):
+        """Mock parental map {site: (parent site, parent allele)} (test_coverage_common.cpp:100-112)."""
+        flat = np.asarray([x for k, (ps, pa) in par_map.items() for x in (int(k), ps, pa)] or [0], dtype=np.int64)
+        if self.lib.gmo_set_par_map(self.h, _p(flat, C.c_int64), len(par_map)) != 0:
+            raise self._err()
+
+    def check_site_uniqueness_throws(self, state):
+        r = self.lib.gmo_check_site_uniqueness(self.h, _p(pack_states([state]), C.c_int64))
+        if r < 0:
+            raise self._err()
+        return bool(r)
+
+    def assign_loci(self, loci, traversed_of_states=()):
+        """LocusFinder: assign_nested_locus per locus, then assign_traversed_loci per state -> (base, used, loci)."""
+        fl = np.asarray([x for l in loci for x in l] or [0], dtype=np.int64)
+        st = pack_states(list(traversed_of_states)) if traversed_of_states else None
+        out = [int(x) for x in self._call_out(self.lib.gmo_assign_loci, _p(fl, C.c_int64), len(loci),
+                                              _p(st, C.c_int64) if st is not None else None)]
+        i = 0
+        nb = out[i]; base = out[i + 1:i + 1 + nb]; i += 1 + nb
+        nu = out[i]; used = out[i + 1:i + 1 + nu]; i += 1 + nu
+        nl = out[i]; lo = [(out[i + 1 + 2 * j], out[i + 2 + 2 * j]) for j in range(nl)]
+        return base, used, lo
+
+    def unique_site_paths(self, states):
+        """MappingInstanceSelector::process_searchstates -> (nonvariant count, [(sites, [(lo, hi)...], loci)...] in map order)."""
+        out = [int(x) for x in self._call_out(self.lib.gmo_unique_site_paths, _p(pack_states(states), C.c_int64))]
+        nonvar, n, i, entries = out[0], out[1], 2, []
+        for _ in range(n):
+            ns = out[i]; sites = out[i + 1:i + 1 + ns]; i += 1 + ns
+            nst = out[i]; sts = [(out[i + 1 + 2 * j], out[i + 2 + 2 * j]) for j in range(nst)]; i += 1 + 2 * nst
+            nl = out[i]; loci = [(out[i + 1 + 2 * j], out[i + 2 + 2 * j]) for j in range(nl)]; i += 1 + 2 * nl
+            entries.append((sites, sts, loci))
+        return nonvar, entries
 
     def select_forced(self, states, forced):
         s = pack_states(states)

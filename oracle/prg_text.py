@@ -64,3 +64,22 @@ def ints_to_prg_bytes(ints) -> bytes:
     """The ``gram_dir/prg`` on-disk form: little-endian uint32 per symbol
     (libgramtools/src/prg/linearised_prg.cpp:8-45,82-115)."""
     return np.asarray(ints, dtype="<u4").tobytes()
+
+
+def ints_to_prg_string(ints) -> str:
+    """Integer PRG -> bracketed text (libgramtools/src/prg/linearised_prg.cpp:133-164): odd markers open a site, even ones
+    separate alleles, the last even marker of a site closes it."""
+    out, last = [], {}
+    for pos, s in enumerate(ints):
+        s = int(s)
+        if s > 4:
+            if s % 2 == 1:
+                out.append("[")
+            else:
+                out.append(",")
+                last[s] = pos
+        else:
+            out.append("ACGT"[s - 1])
+    for pos in last.values():
+        out[pos] = "]"
+    return "".join(out)

@@ -1687,6 +1687,82 @@ long gmo_select_forced(void *h, const int64_t *states_in, uint32_t forced, int64
   GMO_CATCH(o, -1)
 }
 
+// Mock parental map (test_coverage_common.cpp:100-112, 300-322 inject one into an otherwise empty coverage_Graph):
+// pairs = (site, parent_site, parent_allele) x n replaces coverage_graph.par_map.
+int gmo_set_par_map(void *h, const int64_t *pairs, uint64_t n) {
+  auto *o = (Oracle *)h;
+  GMO_TRY(o)
+  o->prg_info.coverage_graph.par_map.clear();
+  for (uint64_t i = 0; i < n; ++i)
+    o->prg_info.coverage_graph.par_map.insert({(Marker)pairs[3 * i], VariantLocus{(Marker)pairs[3 * i + 1], (AlleleId)pairs[3 * i + 2]}});
+  return 0;
+  GMO_CATCH(o, -1)
+}
+// LocusFinder::check_site_uniqueness (coverage_common.cpp:17-32): 1 if it throws std::logic_error, 0 if not.
+int gmo_check_site_uniqueness(void *h, const int64_t *state_in) {
+  auto *o = (Oracle *)h;
+  GMO_TRY(o)
+  auto ss = unpack_states(state_in);
+  try {
+    LocusFinder::check_site_uniqueness(ss.front());
+  } catch (std::logic_error const &) {
+    return 1;
+  }
+  return 0;
+  GMO_CATCH(o, -1)
+}
+// LocusFinder::assign_nested_locus for every given locus in turn, then (traversed_of >= 0) assign_traversed_loci of state
+// `traversed_of` (coverage_common.cpp:34-51,78-83): out = [n_base, base..., n_used, used..., n_loci, (site, allele)...]
+long gmo_assign_loci(void *h, const int64_t *loci, uint64_t n_loci, const int64_t *states_in, int64_t *out, long cap) {
+  auto *o = (Oracle *)h;
+  GMO_TRY(o)
+  LocusFinder l;
+  for (uint64_t i = 0; i < n_loci; ++i) l.assign_nested_locus(VariantLocus{(Marker)loci[2 * i], (AlleleId)loci[2 * i + 1]}, &o->prg_info);
+  if (states_in)
+    for (auto const &ss : unpack_states(states_in)) l.assign_traversed_loci(ss, &o->prg_info);
+  std::vector<int64_t> v;
+  v.push_back((int64_t)l.base_sites.size());
+  for (auto s : l.base_sites) v.push_back(s);
+  v.push_back((int64_t)l.used_sites.size());
+  for (auto s : l.used_sites) v.push_back(s);
+  v.push_back((int64_t)l.unique_loci.size());
+  for (auto &x : l.unique_loci) {
+    v.push_back(x.first);
+    v.push_back(x.second);
+  }
+  return emit(v, out, cap);
+  GMO_CATCH(o, -1)
+}
+// MappingInstanceSelector::process_searchstates + count_nonvar_search_states (coverage_common.cpp:110-141):
+// out = [nonvariant_count, n_entries, {n_sites, sites..., n_states, (lo, hi)..., n_loci, (site, allele)...}*] in map order
+long gmo_unique_site_paths(void *h, const int64_t *states_in, int64_t *out, long cap) {
+  auto *o = (Oracle *)h;
+  GMO_TRY(o)
+  auto ss = unpack_states(states_in);
+  uniqueSitePaths usps;
+  select_mapping(ss, &o->prg_info, [](uint32_t a, uint32_t) { return a; }, &usps);
+  int64_t nonvar = 0;
+  for (auto const &s : ss)
+    if (!s.has_path()) nonvar += (int64_t)s.sa_interval.second - (int64_t)s.sa_interval.first + 1;
+  std::vector<int64_t> v{nonvar, (int64_t)usps.size()};
+  for (auto const &e : usps) {
+    v.push_back((int64_t)e.first.size());
+    for (auto m : e.first) v.push_back(m);
+    v.push_back((int64_t)e.second.first.size());
+    for (auto const &st : e.second.first) {
+      v.push_back(st.sa_interval.first);
+      v.push_back(st.sa_interval.second);
+    }
+    v.push_back((int64_t)e.second.second.size());
+    for (auto const &x : e.second.second) {
+      v.push_back(x.first);
+      v.push_back(x.second);
+    }
+  }
+  return emit(v, out, cap);
+  GMO_CATCH(o, -1)
+}
+
 // RNG known answers (test_coverage_common.cpp:257-298)
 void gmo_rng_raw(uint32_t seed, uint32_t n, uint32_t *out) {
   MT19937 g(seed);
@@ -1837,6 +1913,36 @@ int gmo_record_loci(void *h, const int64_t *pairs, uint64_t n_pairs) {  // allel
   record_grouped_allele_counts(o->coverage, l);
   return 0;
   GMO_CATCH(o, -1)
+}
+
+// AbstractReadStats::extract_max_coverage_allele (read_stats.cpp:94-117) for the site with marker `site_marker`: the allele
+// with the most coverage (nested sites resolved the same way) as letters, and that haplogroup's coverage.
+long gmo_extract_max_cov_allele(void *h, uint64_t site_marker, char *seq_out, long cap, int64_t *cov) {
+  auto *o = (Oracle *)h;
+  GMO_TRY(o)
+  auto const &g = o->prg_info.coverage_graph;
+  for (auto const &np : g.bubble_map) {
+    if (g.nodes[np.first].site_ID != (Marker)site_marker) continue;
+    std::string seq;
+    int cur = np.first;
+    auto mx = get_max_cov_haplogroup(o->coverage.grouped_allele_counts.at(siteID_to_index((Marker)site_marker)));
+    *cov = (int64_t)mx.second;
+    while (cur != np.second) {
+      auto const &n = g.nodes[cur];
+      if (n.is_bubble_start()) {
+        mx = get_max_cov_haplogroup(o->coverage.grouped_allele_counts.at(siteID_to_index(n.site_ID)));
+        cur = n.next.at(mx.first);
+        continue;
+      }
+      if (n.has_sequence()) seq += n.sequence;
+      cur = n.next.at(0);
+    }
+    if ((long)seq.size() + 1 > cap) return -(long)seq.size() - 1;
+    memcpy(seq_out, seq.c_str(), seq.size() + 1);
+    return (long)seq.size();
+  }
+  throw std::runtime_error("no such site");
+  GMO_CATCH(o, -1000000)
 }
 
 // Coverage read-back ---------------------------------------------------

@@ -27,8 +27,13 @@ def all_cases():
     for f in sorted(os.listdir(GOLDEN_DIR)):
         if f.endswith(".json"):
             for c in load_cases(f):
-                out.append((f, c))
+                if "kind" not in c:  # (dumps_and_stats.json: host-side formats, driven by tests/test_golden_dumps.py)
+                    out.append((f, c))
     return out
+
+
+def host_cases():
+    return [c for c in load_cases("dumps_and_stats.json")]
 
 
 def prg_ints(spec):
@@ -183,6 +188,26 @@ def run_op(o, op, ints):
         s = st(op["state"])
         base, loci = o.locus_finder((s[0], s[1], [], s[3]))
         assert base == op["expect_base"] and loci == [tuple(x) for x in op["expect_loci"]], (base, loci)
+    elif kind == "set_par_map":
+        o.set_par_map({int(k): tuple(v) for k, v in op["value"].items()})
+    elif kind == "check_site_uniqueness":
+        assert o.check_site_uniqueness_throws(st(op["state"])) == op["expect_throws"]
+    elif kind == "assign_loci":
+        base, used, loci = o.assign_loci([tuple(x) for x in op["loci"]], [st(s) for s in op.get("traversed_of", [])])
+        assert base == op["expect_base"], base
+        if "expect_used" in op:
+            assert used == op["expect_used"], used
+        assert loci == [tuple(x) for x in op["expect_loci"]], loci
+    elif kind == "unique_site_paths":
+        nonvar, entries = o.unique_site_paths([st(s) for s in op["states"]])
+        if "expect_nonvariant" in op:
+            assert nonvar == op["expect_nonvariant"], nonvar
+        if "expect_sites" in op:
+            assert [e[0] for e in entries] == op["expect_sites"], entries
+        if "expect_states" in op:
+            assert [[list(x) for x in e[1]] for e in entries] == op["expect_states"], entries
+        if "expect_loci" in op:
+            assert [[list(x) for x in e[2]] for e in entries] == op["expect_loci"], entries
     elif kind == "select_forced":
         res = o.select_forced([st(s) for s in op["states"]], op["forced"])
         exp = dict(op["expect"])
@@ -219,7 +244,11 @@ def run_op(o, op, ints):
             got.append(list(d[node]) if node in d else None)
         assert got == op["expect"], got
     elif kind == "record_loci":
-        o.record_loci([tuple(x) for x in op["loci"]])
+        for _ in range(op.get("times", 1)):
+            o.record_loci([tuple(x) for x in op["loci"]])
+    elif kind == "extract_max_cov_allele":
+        seq_, cov = o.extract_max_cov_allele(op["site"])
+        assert seq_ == op["expect_sequence"] and cov == op["expect_cov"], (seq_, cov)
     elif kind == "expect_max_haplogroup":
         assert list(o.max_cov_haplogroup(op["site_index"])) == op["expect"]
     elif kind == "expect_depth":

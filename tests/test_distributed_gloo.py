@@ -96,3 +96,21 @@ def test_two_ranks_exchange_the_grouped_log_of_many_allele_sites(monkeypatch):
     got = _run(prg, 6, reads, 42)
     assert got[0] == want and got[1] == want
     assert any(len(ids) >= 1 and max(ids) >= 5 for site in want["grouped"] for ids in site)
+
+
+@pytest.mark.parametrize("n_reads", [5, 203])
+def test_eight_ranks_ragged_shards_empty_ranks_and_a_grouped_log(monkeypatch, n_reads):
+    """World size 8 as on a full MI355X node: 203 reads give shards of 26 and 25 reads; 5 reads leave three ranks with
+    nothing to map — their all-reduce contribution is zeros and their log is empty — and the PRG's 6-7-allele sites keep
+    their grouped counts in the append log every rank gathers from every other. Every rank ends with the single-process
+    oracle's coverage."""
+    monkeypatch.setenv("GMX_DENSE_MAX_ALLELES", "5")
+    ref = random_ref(3000, 21)
+    prg, sites = mixed_variant_prg(ref, 60, 22, max_alleles=7)
+    assert any(len(al) >= 6 for _, _, al in sites)
+    reads = simulate_haplotype_reads(ref, sites, n_reads, 60, 150, 23)
+    want = oracle_map(prg, 6, reads, global_seeds(42, [len(reads)]))
+    sizes = [shard_range(n_reads, 8, r)[1] - shard_range(n_reads, 8, r)[0] for r in range(8)]
+    assert (0 in sizes) == (n_reads < 8) and len(set(sizes)) >= 2
+    got = _run(prg, 6, reads, 42, world=8)
+    assert all(got[r] == want for r in range(8))

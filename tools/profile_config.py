@@ -3,7 +3,8 @@ packed host feed (2-bit stream from page-locked memory), for use under rocprofv3
   python tools/profile_config.py 3|4|4s [N_READS=1000000] [STEPS=6]
     3   BASELINE configs[3]: 64.4 Mb + 1.8 M sites, k = 14 (index 15.5 GB)
     4   BASELINE configs[4]: 3.1 Gb + 85 M sites, k = 14 (index 160 GB; 4-5 minutes of build)
-    4s  configs[4] at an eighth of its length (400 Mb + 11 M sites)"""
+    4s  configs[4] at an eighth of its length (400 Mb + 11 M sites)
+    4k12  the same 400 Mb PRG with k = 12: 26 occurrences per k-mer, the seed cursor route of configs[4] in small"""
 import os
 import sys
 import time
@@ -27,7 +28,7 @@ else:
     G, S, seed = (3_100_000_000, 85_000_000, 61) if which == "4" else (400_000_000, 11_000_000, 51)
     path = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gmx_profile.prg")
     _, reads = genome_recipe_file(path, G, S, n, seed)
-    ix = Index(path, 14)
+    ix = Index(path, 12 if which == "4k12" else 14)
     os.remove(path)
 info = ix.info
 print(f"configs[{which}]: {info.n_text - 1} symbols, {info.n_sites} sites, index {info.index_bytes / 1e9:.1f} GB, k2 = {info.kmer_size2}, "
