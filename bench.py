@@ -26,7 +26,7 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
   per_rank_s       (N > 1) every rank's own time for the timed job
   cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + the three coverage files
   cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): the cores the container grants, and one thread
-  roofline         gmx_extend_kernel, the dominant kernel: see DESIGN.md §8 for the byte model
+  roofline         gmx_extend_kernel, the dominant kernel: see HISTORY.md §8 for the byte model
 """
 import argparse
 import json
@@ -50,14 +50,14 @@ READS_PER_GPU = 1_000_000
 N_BATCHES = 8                                              # distinct batches cycled by the timed loop
 B_NOMINAL_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070 B/read at k = 10
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
-# Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (DESIGN.md §8 derives each term):
+# Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (HISTORY.md §8 derives each term):
 # queue entry 4 + seed directory entry 8 + packed read planes 48 + PRG text records 6 x 16 + marker sub-records 3 x 16 +
 # path nodes 2 x 12 + coverage record 32 + task id 4
-# what gmx_extend_kernel has to move per mapped read since round 3: queue entry 4 + seed directory entry 8 + read
+# what gmx_extend_kernel has to move per mapped read since round 3 (HISTORY.md §8): queue entry 4 + seed directory entry 8 + read
 # planes 48 + PRG text records 3.4 x 32 (64 symbols each; loop_stats.txt: 3.3 heavy steps per lane) + marker sub-records of the
 # sites that are not inline 0.15 x 16 + path nodes 2 x 12 + coverage record 32 + task id 4   (264 B with round 2's 16 B records)
 B_DESIGN_PER_READ = 4 + 8 + 48 + 109 + 2 + 2 * 12 + 32 + 4
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round4"), os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
 
 
 def profile_json(name):
@@ -381,7 +381,8 @@ def main():
             "config": {"workload": "configs[1]: M. tuberculosis scale, 4411532 bp random ref + 60000 SNP PRG, k=10, "
                                    f"{n} x 150 bp reads per GPU per step, fwd+rc, {NB} distinct batches cycled, reads handed over as "
                                    + ("2-bit planes" if args.planes else "a 2-bit stream (37.5 B per read)") + " in page-locked host memory"
-                                   + ("" if args.upload_seeds else ", per-read seeds read in place from page-locked host memory"),
+                                   + ("" if args.upload_seeds else ", per-read seeds read in place from page-locked host memory")
+                                   + "; no skip plane (the synthetic reads hold no N: gmx.h takes a null skip pointer as 'none skipped')",
                        "reads_per_gpu": n, "read_len": READ_LEN, "kmer_size": KMER, "distinct_batches": NB,
                        "h2d_bytes_per_read": h2d_per_read,
                        "parallelism": f"reads sharded x{world} by global read index, index replicated, one RCCL all-reduce of the "
@@ -394,13 +395,13 @@ def main():
                          "traffic_source": f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
                          "alg_bytes_per_read": B_DESIGN_PER_READ,
                          "alg_bytes_model": "text-form states: 32 B of PRG per 64 symbols, SNP sites resolved inside the record; "
-                                            "a 16 B sub-record only for sites that straddle a record end (DESIGN.md §8)",
+                                            "a 16 B sub-record only for sites that straddle a record end (HISTORY.md §8)",
                          "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
                          "measured": "HIP events attached to the dispatch (hipExtLaunchKernelGGL), reads resident in HBM leg",
                          "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
                          "what_bounds_it": "instruction issue of the wave loop (~58 M VALU + 41 M SALU wave-instructions per launch, VALU "
                                            "busy 0.59) and the slowest lane of each wave, not HBM bandwidth: round 3 halved the "
-                                           "loop's fetches (8.5 -> 3.3 per lane) and gained 10 % (DESIGN.md §4)",
+                                           "loop's fetches (8.5 -> 3.3 per lane) and gained 10 % (HISTORY.md §4)",
                          "issue": {"valu_busy": sq.get("valu_busy"), "active_lane_share": sq.get("active_lane_share"),
                                    "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
                                    "iterations_per_wave": sq.get("iterations_per_wave"),

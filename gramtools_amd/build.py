@@ -64,7 +64,7 @@ LIB_ALT = os.path.join(LIB_DIR, "libgmx_alt.so")
 
 def build_library_alt(force=False, verbose=False):
     """Test build with -DGMX_SEARCHOUT_ALT: SearchOut in the member order that made the round-2 compiler emit a wrong
-    gmx_probe_kernel. tests/test_searchout_layout.py runs the probe pipeline with both builds."""
+    gmx_probe_kernel (HISTORY.md §4.5). tests/test_searchout_layout.py runs the probe pipeline with both builds."""
     return _link(LIB_ALT, ["-DGMX_SEARCHOUT_ALT"], "_alt", force, verbose)
 
 

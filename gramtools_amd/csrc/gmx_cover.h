@@ -16,7 +16,7 @@
 //   uint32_t sget(uint32_t word) / void sset(uint32_t word, uint32_t v)   per-task scratch words
 //   uint32_t i_max(), b_max(), loc_max(), h_max()                          capacities (compile-time constants for the fixed
 //                                                                          tiers, runtime values for the last, heap-backed tier)
-//   bool has_log_sites() / bool log_reserve(uint32_t words)                  grouped log of sites with more than 5 alleles: ALL
+//   bool has_log_sites() / bool log_reserve(uint32_t words)                  grouped log of sites with more than 8 alleles: ALL
 //                                                                          words a task will append are reserved at once, before
 //                                                                          anything is recorded (a full log fails the task whole)
 //   void add_allele_sum(uint32_t slot), add_per_base(uint32_t slot), add_grouped_dense(uint32_t slot): +1 on a slot of the

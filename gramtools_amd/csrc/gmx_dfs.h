@@ -10,7 +10,7 @@
 // No second dependent load inside an iteration, no per-wave serialisation of the rare marker path: a marker
 // hit only pushes {hit rank, path handles, position}; it is resolved when popped — by then as the lane's
 // one fetch of that iteration. Final coverage does not depend on the order in which states are explored
-// (DESIGN.md §4), and every state is explored exactly as the reference would.
+// (HISTORY.md §4), and every state is explored exactly as the reference would.
 //
 // Ctx interface (FastCtx in gmx_engine.hip on the device, EmuDfsCtx in tests/hostemu on the host):
 //   bool pop(a, b, tvd, tvg, pos, mode)          next pending entry
@@ -268,9 +268,11 @@ GMX_HD bool gmx_dfs_text_apply(Ctx &ctx, GmxLane &ln, uint32_t stop, Reader &rd,
     ln.mode = GMX_MODE_DEAD;
     return true;
   }
+  // the read's planes aligned with the record, extracted ONCE: behind an inline site the same planes serve, shifted down by
+  // the PRG symbols the site took beyond the one read base it consumed (slot s then holds what slot s + shift held)
+  uint64_t rlo, rhi;
+  gmx_dfs_text_read_planes(ln, rd, rlo, rhi);
   for (;;) {
-    uint64_t rlo, rhi;
-    gmx_dfs_text_read_planes(ln, rd, rlo, rhi);
     const uint32_t t = (ln.a - 1u) & GMX_TEXT_MASK;
     const uint32_t avail = ln.pos - stop;
     const uint32_t n = avail < t + 1u ? avail : t + 1u;
@@ -312,6 +314,8 @@ GMX_HD bool gmx_dfs_text_apply(Ctx &ctx, GmxLane &ln, uint32_t stop, Reader &rd,
       ln.a -= e - o + 1u;  // left of the opening marker
       --ln.pos;
       if (o == 0 || ln.pos <= stop) return true;  // the record is used up (or the read: cannot be, two bases were left)
+      rlo >>= e - o;  // (2 <= e - o <= 63: the site's symbols between its markers, plus one)
+      rhi >>= e - o;
       continue;
     }
     ln.a = rec.mrank + (uint32_t)__builtin_popcountll(rec.mk & gmx_below64(e));

@@ -1,13 +1,13 @@
 // gmx_engine.hip — HIP kernels (gfx950) and the device half of the C ABI.
 //
-// Execution model: one LANE per (read, orientation) task — 64 independent vBWT backward
+// Execution model (HISTORY.md §2): one LANE per (read, orientation) task — 64 independent vBWT backward
 // searches per wavefront. A lane carries one search state in registers and keeps the others on a small LIFO
 // stack in LDS (gmx_dfs.h). A state that has narrowed to ONE suffix-array position is kept in text form and
 // compares 32 read bases per step against a 16-byte record of the PRG itself; wide intervals use 64-byte rank
 // blocks; a variant marker costs one 16-byte sub-record of its pre-resolved hit record. Final states go to
 // the coverage kernels (gmx_cover.h): class selection with the seeded draw, then the coverage atomics.
 //
-// Kernels (launch order):
+// Kernels (launch order, HISTORY.md §2.4):
 //   gmx_pack_kernel          flags reads with a non-ACGT byte (encode_dna_bases, utils.cpp:73-92), packs bases to bit planes
 //   gmx_probe_kernel         seed look-up + the first steps of search_read_backwards (quasimap.cpp:227-256); survivors are parked
 //   gmx_extend_kernel        the rest of the read for the compacted survivors
@@ -191,6 +191,25 @@ struct GmxParked {
 };
 static_assert(GMX_STACK_DEPTH * sizeof(GmxParked) <= GMX_FAST_STATES * sizeof(GmxFinalState), "parked entries overlay finals[]");
 
+// A state of a multi-state k-mer index entry as the DEVICE copy of the words holds it (gmx_seed_mark_kernel rewrites the
+// host form [lo, hi, n_traversed, n_traversing, paths...] in place): a state over ONE suffix-array position is
+// [PRG position, left context, n_traversed | GMX_SEEDST_TEXT, n_traversing, paths...]. Left context: the up to 14 base
+// symbols left of the position (2 bits each, nearest first) up to the first marker or the PRG's start, and in bits 28..31
+// how many there are: a seed state is rejected on it without any fetch (FastCtx::next_seed_screened).
+#define GMX_SEEDST_TEXT 0x80000000u
+#define GMX_SEEDST_CTX 14u
+struct GmxSeedState {
+  uint32_t lo, hi, nt, ng, ctx;
+  __device__ __forceinline__ bool text() const { return hi == GMX_TEXT_MARK; }
+  __device__ __forceinline__ uint32_t words() const { return 4u + 2u * nt + ng; }
+  __device__ __forceinline__ uint32_t width() const { return text() ? 1u : hi - lo + 1u; }
+};
+__device__ __forceinline__ GmxSeedState gmx_seed_state(const uint32_t *p) {
+  const uint32_t w2 = p[2];
+  const bool text = (w2 & GMX_SEEDST_TEXT) != 0;
+  return GmxSeedState{p[0], text ? GMX_TEXT_MARK : p[1], w2 & ~GMX_SEEDST_TEXT, p[3], text ? p[1] : 0u};
+}
+
 struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path arena and emitted states in global memory
   uint32_t sp;
   GmxPathNode *arena;
@@ -216,6 +235,7 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint64_t seed_off;                // word offset of the next one in seed_words (above 2^32 in a whole-genome index)
   uint32_t seed_pos;                // read position of the seed states
   uint32_t mark_arena, mark_out;    // arena / emitted-state counts when the current seed state started
+  uint32_t seed_rctx, seed_rn = 0xFFFFFFFFu;  // the read's bases left of seed_pos as a left-context word, and how many (lazily)
   __device__ __forceinline__ bool more_seeds() const { return seed_left != 0 && status == GMX_TASK_MAPPED; }
   __device__ __forceinline__ bool next_seed(const GmxIndexView &ix, bool release, uint32_t &a, uint32_t &b, uint32_t &tvd,
                                             uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
@@ -224,7 +244,8 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     mark_arena = arena_n;
     mark_out = n_out;
     const uint32_t *p = ix.seed_words + seed_off;
-    const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+    const GmxSeedState ss = gmx_seed_state(p);
+    const uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
     p += 4;
     tvd = tvg = GMX_NIL;
     for (uint32_t j = 0; j < nt; ++j, p += 2) {
@@ -277,13 +298,24 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   template <class Reader>
   __device__ __forceinline__ bool next_seed_screened(const GmxIndexView &ix, Reader &rd, uint32_t stop, uint32_t &a, uint32_t &b,
                                                      uint32_t &tvd, uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
+    if (seed_rn == 0xFFFFFFFFu) {  // the read's bases left of the seed, once per task, in the entries' left-context form
+      seed_rn = seed_pos > stop ? min(seed_pos - stop, GMX_SEEDST_CTX) : 0u;
+      seed_rctx = 0;
+      for (uint32_t j = 0; j < seed_rn; ++j) seed_rctx |= (rd.at(seed_pos - 1u - j) - 1u) << (2u * j);
+    }
     while (seed_left != 0 && status == GMX_TASK_MAPPED) {
       const uint32_t *p = ix.seed_words + seed_off;
-      const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
-      if (hi == GMX_TEXT_MARK || lo == hi) {  // (one position: in text form in the device copy of the entries)
-        const uint32_t tp = hi == GMX_TEXT_MARK ? lo : ix.sa[lo];
-        if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) {
-          seed_off += 4u + 2u * nt + ng;
+      const GmxSeedState ss = gmx_seed_state(p);
+      const uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
+      if (ss.text() || lo == hi) {  // (one position: in text form in the device copy of the entries)
+        bool dead = false;
+        if (ss.text()) {  // a mismatch among the bases before the first marker: dead, without fetching anything
+          const uint32_t n = min(ss.ctx >> 28, seed_rn);
+          dead = n != 0 && (((ss.ctx ^ seed_rctx) << (32u - 2u * n)) != 0u);
+        }
+        const uint32_t tp = ss.text() ? lo : ix.sa[lo];
+        if (dead || !seed_text_alive(ix, rd, tp, seed_pos, stop)) {
+          seed_off += ss.words();
           --seed_left;
           continue;
         }
@@ -571,11 +603,13 @@ __device__ __forceinline__ const uint32_t *gmx_seed_entry(const GmxIndexView &ix
 // GMX_TEXT_MARK — in the device copies: the search needs no suffix-array look-up to start (one dependent, always-missing
 // fetch per task less: 64 MB of the extend kernel's 390 MB of fabric-side fetch at config[1]).
 // The same inside the multi-state entries (round 4): a state over one suffix-array position — with or without paths — is
-// rewritten in the device copy of the words as (PRG position, GMX_TEXT_MARK). A whole-genome index has ~16 states per k-mer
-// and all but one of a read's seed states die at their first compare: the look-up was a third of their memory requests,
-// each a TLB miss in a 14 GB table. Every device reader of the entries takes both forms (gmx_seed_state_width).
-__device__ __forceinline__ uint32_t gmx_seed_state_width(uint32_t lo, uint32_t hi) { return hi == GMX_TEXT_MARK ? 1u : hi - lo + 1u; }
-__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, uint32_t *seed_words, uint32_t seed_shift, const uint32_t *sa) {
+// rewritten in the device copy of the words as (PRG position, left context, flag; GmxSeedState). A whole-genome index has
+// ~16 states per k-mer and all but one of a read's seed states die at their first compare: the suffix-array look-up and
+// the text record were two scattered fetches per state — at 160 GB of index the kernels ran at the memory system's rate of
+// scattered lines — and the left context rejects almost all of them from the entry's own, consecutive, words. Every device
+// reader of the entries goes through gmx_seed_state().
+__global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, uint32_t *seed_words, uint32_t seed_shift, const uint32_t *sa,
+                                     const GmxTextRec *text) {
   for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const GmxSeed s = seeds[i];
     if (s.a != GMX_SEED_COMPLEX) {
@@ -586,12 +620,23 @@ __global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, uint32_t *seed_
     const uint32_t ns = *w++;
     bool big = ns > 0xFFFFu;
     for (uint32_t j = 0; j < ns; ++j) {
-      big = big || (w[1] >= w[0] + GMX_SEED_SPLIT_MAX && w[2] == 0 && w[3] == 0);
-      if (w[0] == w[1]) {
-        w[0] = sa[w[0]];
-        w[1] = GMX_TEXT_MARK;
+      const uint32_t nt = w[2], ng = w[3];
+      big = big || (w[1] >= w[0] + GMX_SEED_SPLIT_MAX && nt == 0 && ng == 0);
+      if (w[0] == w[1]) {  // one position: PRG position + left context (GmxSeedState)
+        const uint32_t tp = sa[w[0]];
+        uint32_t ctx = 0, nv = 0;
+        for (; nv < GMX_SEEDST_CTX && nv < tp; ++nv) {
+          const uint32_t q = tp - 1u - nv;
+          const GmxTextRec rec = text[q >> GMX_TEXT_SHIFT];
+          const uint32_t bit = q & GMX_TEXT_MASK;
+          if ((rec.mk >> bit) & 1ull) break;
+          ctx |= ((uint32_t)((rec.lo >> bit) & 1ull) | ((uint32_t)((rec.hi >> bit) & 1ull) << 1)) << (2u * nv);
+        }
+        w[0] = tp;
+        w[1] = ctx | (nv << 28);
+        w[2] = nt | GMX_SEEDST_TEXT;
       }
-      w += 4 + 2 * w[2] + w[3];
+      w += 4 + 2 * nt + ng;
     }
     seeds[i].b = s.b | (big ? GMX_SEEDF_BIG : 0u) | (ns == 0 ? GMX_SEEDF_EMPTY : 0u);
   }
@@ -608,7 +653,8 @@ __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t
   const uint32_t *p = gmx_seed_entry(ix, s.b);
   uint32_t ns = *p++;
   for (uint32_t i = 0; i < ns; ++i) {
-    uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+    const GmxSeedState ss = gmx_seed_state(p);
+    uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
     p += 4;
     uint32_t tvd = GMX_NIL, tvg = GMX_NIL;
     bool ok = true;
@@ -875,7 +921,7 @@ struct SearchOut {
   uint32_t region_inv;       // ceil(2^32 * GMX_REGIONS / n_prg): region = umulhi(position, region_inv)
   // The six task-id queues finish_lane appends to are slices of ONE allocation, `task_lists` (slice q at q * list_stride,
   // GMX_TL_*), and finish_lane addresses them as base + integer index: a lane-divergent chain of selects between six
-  // queue POINTERS held in spilled SGPRs is what the compiler got wrong in round 2 (the VGPR copy of the
+  // queue POINTERS held in spilled SGPRs is what the compiler got wrong in round 2 (HISTORY.md §4.5: the VGPR copy of the
   // cover_general_list pointer was emitted in a sibling block, under another exec mask). The named members below point
   // into the same allocation for the kernels that read one queue.
   uint32_t *task_lists;
@@ -923,7 +969,7 @@ struct SearchOut {
   uint32_t *big_serial_list;           // ... and for the second part of big_mapped_list (coverage instance 2); counter [28]
   uint32_t *overflow3_list;            // tasks one lane has to search with a whole large-capacity slot (a group's parts did not suffice); counter [29]
   uint32_t split_twice;                // the extend kernel's overflow queue goes through the split search as well
-  // A task that finds the grouped log full (sites with more than 5 alleles) has recorded nothing: its queue entry goes
+  // A task that finds the grouped log full (sites with more than 8 alleles) has recorded nothing: its queue entry goes
   // to one of these lists, the host drains the log after the batch and has the entries redone (launch_log_replay).
   uint32_t *log_retry_list;            // coverage queue entries (task / large-capacity slot / instance slot); counter [30]
   uint32_t *log_retry_recs;            // compact records, as index into cover_recs; counter [31]
@@ -996,11 +1042,8 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       o.error[1] = task;
     }
   }
-  {  // read counters: a skipped read (probe pipeline: the seed kernel counts its own) and every task mapped here
-    __shared__ uint32_t n_skip, n_map;
-    gmx_block_count(o.stats, 1, active && status == GMX_TASK_SKIPPED, &n_skip);
-    gmx_block_count(o.stats, 4, mapped, &n_map);
-  }
+  // (the read counters — skipped reads, tasks mapped here — are tallied in the queue append below: one pair of barriers
+  //  for everything the block publishes, four barriers less than counting them separately)
   // a mapped task with ONE text-form final state and a short path leaves as a compact record (GmxCoverRec)
   GmxCoverRec rec{0, 0, GMX_NIL, {0, 0, 0}, 0, 0};
   bool compact = mapped && ctx.n_out == 1 && ctx.first_pos != GMX_NIL && read_len < 0x10000u &&
@@ -1058,9 +1101,9 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
   // graph tables and of the accumulators (they do not fit one 4 MiB L2 as a whole). The probe
   // kernel's overflow queue is separate from the extend kernel's: it is served while the extend kernel still runs.
   const uint32_t region = min(__umulhi(ctx.first_pos, o.region_inv), (uint32_t)(GMX_REGIONS - 1));
-  enum : uint32_t { Q_OVER = GMX_REGIONS, Q_ALIVE, Q_DEAD, Q_GENERAL, Q_N };
+  enum : uint32_t { Q_OVER = GMX_REGIONS, Q_ALIVE, Q_DEAD, Q_GENERAL, Q_N, Q_SKIPPED = Q_N, Q_COLS };  // Q_SKIPPED: a count only
   const uint32_t cat = mapped ? (compact ? region : Q_GENERAL) : over ? Q_OVER : alive ? Q_ALIVE : dead ? Q_DEAD : 0xFFu;
-  __shared__ uint32_t q_cnt[GMX_BLOCK / 64][Q_N];
+  __shared__ uint32_t q_cnt[GMX_BLOCK / 64][Q_COLS];
   __shared__ uint32_t q_base[Q_N];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long mine = 0;
@@ -1070,6 +1113,10 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     if (lane == 0) q_cnt[wave][c] = (uint32_t)__popcll(m);
     if (cat == c) mine = m;
   }
+  {
+    const unsigned long long m = __ballot(active && status == GMX_TASK_SKIPPED);
+    if (lane == 0) q_cnt[wave][Q_SKIPPED] = (uint32_t)__popcll(m);
+  }
   __syncthreads();
   if (threadIdx.x < Q_N) {
     const uint32_t c = threadIdx.x;
@@ -1078,6 +1125,20 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
     for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) total += q_cnt[w][c];
     const uint32_t counter = c < GMX_REGIONS ? 16 + c : c == Q_OVER ? (second_phase ? 9u : 1u) : c == Q_ALIVE ? (second_phase ? GMX_CNT_ALIVE2 + alive_pass : 5u) : c == Q_DEAD ? (second_phase ? 12u : 6u) : 8u;
     q_base[c] = total ? atomicAdd(&o.counters[counter * GMX_CNT_STRIDE], total) : 0;
+  } else if (threadIdx.x == Q_N) {  // read counters: every task mapped here (the regional queues + the general one) ...
+    uint32_t n_map = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) {
+      n_map += q_cnt[w][Q_GENERAL];
+#pragma unroll
+      for (uint32_t c = 0; c < GMX_REGIONS; ++c) n_map += q_cnt[w][c];
+    }
+    if (n_map) atomicAdd(&o.stats[4], (unsigned long long)n_map);
+  } else if (threadIdx.x == Q_N + 1) {  // ... and the skipped reads (probe pipeline: the seed kernel counts its own)
+    uint32_t n_skip = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < GMX_BLOCK / 64; ++w) n_skip += q_cnt[w][Q_SKIPPED];
+    if (n_skip) atomicAdd(&o.stats[1], (unsigned long long)n_skip);
   }
   __syncthreads();
   if (cat != 0xFFu) {
@@ -1313,10 +1374,11 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
       const uint32_t ns = *w++;
       bool fits = ns <= GMX_INST_MAX;
       for (uint32_t q = 0; q < ns && fits; ++q) {
-        const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? gmx_seed_state_width(w[0], w[1]) : 1u;
-        fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * w[2] + w[3] + 2 <= GMX_FAST_ARENA;
+        const GmxSeedState ss = gmx_seed_state(w);
+        const uint32_t n_q = (ss.nt == 0 && ss.ng == 0) ? ss.width() : 1u;
+        fits = n_q <= GMX_INST_MAX && width + n_q <= GMX_INST_MAX && 2 * ss.nt + ss.ng + 2 <= GMX_FAST_ARENA;
         width += n_q;
-        w += 4 + 2 * w[2] + w[3];
+        w += ss.words();
       }
       if (!fits) width = 0;
     }
@@ -1359,12 +1421,13 @@ __global__ void __launch_bounds__(GMX_SEED_THREADS) gmx_seed_kernel(GmxIndexView
         const uint32_t ns = *w++;
         uint32_t i = 0;
         for (uint32_t q = 0; q < ns; ++q) {
-          const uint32_t n_q = (w[2] == 0 && w[3] == 0) ? gmx_seed_state_width(w[0], w[1]) : 1u;
+          const GmxSeedState ss = gmx_seed_state(w);
+          const uint32_t n_q = (ss.nt == 0 && ss.ng == 0) ? ss.width() : 1u;
           for (uint32_t x = 0; x < n_q; ++x, ++i) {
             o.inst_list[first + i] = (over_at[j] << 6) | i;
             o.inst_sa[first + i] = GMX_INST_COMPLEX | (q << 8) | x;
           }
-          w += 4 + 2 * w[2] + w[3];
+          w += ss.words();
         }
       }
       o.inst_remaining[over_at[j]] = width;
@@ -1428,8 +1491,9 @@ __device__ void gmx_inst_rounds(const GmxIndexView &ix, const BatchView &b, cons
       } else {  // state (what >> 8) of a multi-state seed entry; occurrence (what & 255) of it when it is path-less
         const GmxSeed sd = (longer ? ix.seeds2 : ix.seeds)[last_kmer_code(r, k)];
         const uint32_t *p = gmx_seed_entry(ix, sd.b) + 1;
-        for (uint32_t st = (what >> 8) & 0x7FFFFFu; st > 0; --st) p += 4 + 2 * p[2] + p[3];
-        const uint32_t lo = p[0], hi = p[1], nt = p[2], ng = p[3];
+        for (uint32_t st = (what >> 8) & 0x7FFFFFu; st > 0; --st) p += gmx_seed_state(p).words();
+        const GmxSeedState ss = gmx_seed_state(p);
+        const uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
         p += 4;
         if (nt == 0 && ng == 0) {  // (one position: already in text form in the device copy, gmx_seed_mark_kernel)
           ctx.push(hi == GMX_TEXT_MARK ? lo : ix.sa[lo + (what & 255u)], GMX_TEXT_MARK, GMX_NIL, GMX_NIL, r.len - k, GMX_MODE_STATE);
@@ -1488,6 +1552,11 @@ template <bool CURSOR, int MODE>
 __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(GmxIndexView ix, BatchView b, SearchOut o, uint32_t fuse,
                                                                                uint32_t budget, uint32_t pass) {
   constexpr bool SEEDED = MODE == 1;
+  // bit 31 of `pass`: the last pass runs under a cap — a lane with work left after `budget` iterations is not parked again
+  // but handed to the large-capacity route as an overflow (nested PRGs: a few tasks with hundreds of general iterations held
+  // the main stream for 0.9 ms; the 16-lane split search spreads their states over lanes, on a side stream)
+  const bool capped = (pass & 0x80000000u) != 0;
+  pass &= 0x7FFFFFFFu;
   uint32_t n_alive = o.counters[(MODE == 2 ? GMX_CNT_ALIVE2 + pass : 5u) * GMX_CNT_STRIDE];
   if (blockIdx.x * GMX_BLOCK >= n_alive) return;
   const long long t0 = GMX_CLK();
@@ -1567,7 +1636,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
     // stays in finals[] (the first, deferred state is written now). A full stack beside a live entry has no room to be
     // restored: that task goes to the large-capacity pass.
     const bool cur = ln.have && ln.mode != GMX_MODE_DEAD;
-    if (cur && ctx.sp >= GMX_STACK_DEPTH) {
+    if (capped || (cur && ctx.sp >= GMX_STACK_DEPTH)) {
       ctx.fail(GMX_TASK_OVERFLOW);
     } else {
       ctx.flush_first();
@@ -1860,8 +1929,9 @@ __global__ void __launch_bounds__(64) gmx_search_split_kernel(GmxIndexView ix, B
         const uint32_t *w = gmx_seed_entry(ix, sd.b);
         const uint32_t ns = *w++;
         for (uint32_t i = 0; i < ns && ok; ++i) {
-          state(w[0], w[1], w + 4, w[2], w[3]);
-          w += 4 + 2 * w[2] + w[3];
+          const GmxSeedState ss = gmx_seed_state(w);
+          state(ss.lo, ss.hi, w + 4, ss.nt, ss.ng);
+          w += ss.words();
         }
       }
       if (!ok) ctx.fail(GMX_TASK_OVERFLOW);
@@ -1913,7 +1983,7 @@ struct CoverAcc {
   uint32_t *scratch_big;
   uint32_t n_lanes_big;
   int rng_mode;
-  uint32_t log_sites;   // the index has sites with more than 5 alleles (users of the log)
+  uint32_t log_sites;   // the index has sites with more than 8 alleles (users of the log)
   uint32_t *heap;       // the last tier's memory (gmx_tail_stage)
   uint64_t heap_words;
   const uint32_t *status;      // per task, for the read counters tallied by the batch's last launch
@@ -2964,7 +3034,7 @@ struct gmx_engine {
   bool coop = true;  // GMX_NO_COOP=1 in the environment: serial coverage instances only (A/B runs)
   uint32_t *d_heap = nullptr;      // ... and its memory
   uint64_t heap_words = 0;
-  bool log_sites = false;          // the index has sites with more than 5 alleles
+  bool log_sites = false;          // the index has sites with more than 8 alleles
   // grouped log: drained into `log_counts` (records with counts) whenever the device log may run full, and at fetch time
   std::map<std::vector<uint32_t>, uint64_t> log_counts;  // key = [site_index, ids...]
   // Exact accounting (round 3): after every batch of an engine whose index uses the log, the log cursor and the lengths
@@ -2996,6 +3066,7 @@ struct gmx_engine {
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
+  uint32_t extend_cap = 0;      // iterations of the LAST pass after which a task goes to the large-capacity route (0: runs to the end)
   uint32_t extend_budget = 8;   // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
   bool seeds_in_place = false;  // gmx_engine_seeds_in_place
   uint32_t extend_passes = 1;   // launches over the stragglers (<= GMX_EXTRA_PASSES); all but the last with a budget of their own
@@ -3275,9 +3346,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       gmx_set_error("the seed tables hold more than 2^30 units of multi-state entries");
       rc = GMX_ECAP;
     } else {
-      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa);
+      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
       if (h.kmer_size2)
-        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa);
+        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
       rc |= hipDeviceSynchronize() != hipSuccess;
     }
   }
@@ -3346,6 +3417,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
   if (getenv("GMX_NO_FUSE")) e->fuse = 0;
   if (const char *eb = getenv("GMX_EXTEND_BUDGET")) e->extend_budget = (uint32_t)std::max(0, atoi(eb));
+  e->extend_cap = 0u;  // (GMX_EXTEND_CAP: off by default — at configs[2] a cap of 40 iterations sent 45 k tasks per batch to the
+                       //  large-capacity route and the step took 6.4 ms instead of 2.5; see profiles/round4/config2_cap_sweep.txt)
+  if (const char *ec = getenv("GMX_EXTEND_CAP")) e->extend_cap = (uint32_t)std::max(0, atoi(ec));
   // passes over the stragglers and the iteration budgets of all but the last. ONE pass by default: at configs[2] (nested
   // MSA regions) three passes — budgets 24 and 96 — take 230 + 528 + 494 us where the single pass takes 901: what is left
   // after the first budget is a few tasks with hundreds of general iterations each (~5 us per iteration: dependent fetches
@@ -3447,7 +3521,7 @@ static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const B
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
 }
 
-// ---- grouped log: exact accounting between batches (engines whose index has sites with more than 5 alleles) ----------
+// ---- grouped log: exact accounting between batches (engines whose index has sites with more than 8 alleles) ----------
 static int log_state_enqueue(gmx_engine *e, hipStream_t stream) {
   if (!e->h_log_state) {
     HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&e->h_log_state), 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -3726,11 +3800,14 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     hipExtLaunchKernelGGL((gmx_extend_kernel<false, 0>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, k0, k1, 0u, e->dview, b, o, e->fuse, budget, 0u);
   if (budget) {  // the stragglers, compacted (a block that finds its part of the queue empty returns at once)
     for (uint32_t pass = 0; pass < e->extend_passes; ++pass) {
-      const uint32_t budget2 = pass + 1 < e->extend_passes ? e->extend_budget2[pass] : 0u;  // (the last pass runs to the end)
+      const bool last = pass + 1 >= e->extend_passes;
+      // (the last pass runs to the end, or — nested PRGs — to its cap, beyond which a task goes to the split search)
+      const uint32_t budget2 = last ? e->extend_cap : e->extend_budget2[pass];
+      const uint32_t pass_arg = pass | (last && e->extend_cap ? 0x80000000u : 0u);
       if (e->seed_cursor)
-        hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass);
+        hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass_arg);
       else
-        hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass);
+        hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass_arg);
     }
   }
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
@@ -3765,6 +3842,9 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);
   }
   HIP_TRY(hipEventRecord(e->ev_filter, e->side_stream));
+  // (Round 4 measured the records in PRG order — a radix sort of (position, record) pairs in front of this kernel, for the
+  //  locality of the accumulator and table lines: at configs[3] the kernel took 508 us instead of 436 plus 120 us of sorting, at
+  //  configs[4] 646 instead of 611: neighbouring lanes then hit the SAME accumulator words and their atomics serialise. Dropped.)
   hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   // The batch's last coverage instance (1: what exceeded the regular scratch; its last block also serves the last tier,
   // whose search keeps its first pending entries in LDS) needs every other instance done except gmx_cover_single_kernel,

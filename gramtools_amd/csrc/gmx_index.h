@@ -173,7 +173,7 @@ struct HostIndex {
   uint32_t n_allele_slots = 0, n_pb_slots = 0, n_grouped_slots = 0;  // lengths of the logical arrays
   uint32_t n_acc_slots = 0;                                            // length of the accumulator block
   // logical layout (what the C ABI and the dumps use) and where each logical slot lives in the accumulator block
-  std::vector<uint32_t> l_allele_off, l_grouped_off;  // per site (l_grouped_off = GMX_GROUPED_LOG for > 5 alleles)
+  std::vector<uint32_t> l_allele_off, l_grouped_off;  // per site (l_grouped_off = GMX_GROUPED_LOG for > 8 alleles)
   std::vector<uint32_t> l_cov_off;                    // per node (GMX_NO_COV if none)
   std::vector<uint32_t> phys_allele, phys_pb, phys_grouped;
   // hit counters (gmx_types.h): {slot, logical allele-sum index, logical grouped index, logical per-base index} each

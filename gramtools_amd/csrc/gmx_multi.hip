@@ -5,7 +5,7 @@
 // out by global read index (the per-read seeds are the master stream's, so the result does not depend on the
 // number of GPUs), and at the end the uint32 accumulator blocks are summed: one RCCL all-reduce over xGMI of the
 // fused block (coverage + the five read counters as 16-bit limbs), plus the exchange of the grouped log of sites
-// with more than 5 alleles (counted records: small). uint16 wrap / saturation are functions of the totals, so the
+// with more than 8 alleles (counted records: small). uint16 wrap / saturation are functions of the totals, so the
 // result equals the single-thread reference.
 //
 // One exchange routine (gmx_exchange) serves both users:

@@ -14,7 +14,7 @@
 //   round 2: tied elements by (group, K(i + len(i)))           -> sort by the second key, then stable by the group's start
 //   host:    runs still tied (equal group and second key)      -> comparisons
 //
-// HBM streaming and radix passes; no LDS code of its own, no MFMA. 3.13 G symbols: see DESIGN.md §5.
+// HBM streaming and radix passes; no LDS code of its own, no MFMA. 3.13 G symbols: see HISTORY.md §5.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 

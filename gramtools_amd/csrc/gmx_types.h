@@ -206,7 +206,7 @@ struct GmxIndexView {
 #define GMX_TASK_OVERFLOW 2u      // capacity exceeded: must be re-run by the large-capacity kernel
 #define GMX_TASK_SKIPPED 3u       // read holds a non-ACGT symbol (encode_dna_bases, utils.cpp:73-92)
 #define GMX_TASK_ERROR 4u         // reference would have thrown / asserted (e.g. site traversed twice)
-#define GMX_TASK_LOGFULL 6u       // the grouped-allele-count log is full (sites with more than 5 alleles)
+#define GMX_TASK_LOGFULL 6u       // the grouped-allele-count log is full (sites with more than 8 alleles)
 
 #define GMX_NIL 0xFFFFFFFFu
 

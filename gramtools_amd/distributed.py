@@ -100,7 +100,7 @@ def fused_coverage_tensor(qm):
 def allreduce_device_coverage(qm, dist, tensor=None, stream=None):
     """The exchange through torch.distributed (RCCL): one all-reduce(sum), in place on the engine's coverage block
     (uint32 totals wrap exactly like int32 sums; the uint64 read counters travel as 16-bit limbs), and — when the PRG
-    has sites with more than 5 alleles — an all-gather of the grouped logs (counted records: one per distinct
+    has sites with more than 8 alleles — an all-gather of the grouped logs (counted records: one per distinct
     (site, allele set), small), after which every rank's engine holds the sum of all logs.
     :class:`CoverageComm` does the same inside the library (the implementation `gram --devices` uses)."""
     t = fused_coverage_tensor(qm) if tensor is None else tensor

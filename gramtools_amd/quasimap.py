@@ -186,7 +186,7 @@ class Index:
 
     @property
     def uses_grouped_log(self):
-        """Some site has more than 5 alleles: its grouped counts live in the log, not in dense slots."""
+        """Some site has more than 8 alleles: its grouped counts live in the log, not in dense slots."""
         return bool((self.grouped_off == GROUPED_LOG).any())
 
     def save(self, path: str):

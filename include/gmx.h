@@ -277,7 +277,7 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream);
  * saturates at 65535 (allele_base.cpp:239). gmx_finalize_u16 applies them. */
 int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped_dense,
                        gmx_stats *stats);
-/* Grouped counts of sites with more than 5 alleles (grouped_allele_counts.cpp:17-49 for sites without dense slots).
+/* Grouped counts of sites with more than 8 alleles (grouped_allele_counts.cpp:17-49 for sites without dense slots).
  * Returns the number of uint32 words of the log (and copies it when it fits cap_words). The log is a sequence of records
  *   [site_index, n_ids, ids...]                                     worth +1, or
  *   [site_index, n_ids | GMX_LOG_COUNTED, count_lo, count_hi, ids...] worth +count,
@@ -345,7 +345,7 @@ int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index
  * in coverage/allele_sum.cpp:31-43 and grouped_allele_counts.cpp:17-49). Every GPU has an engine of its own; after the
  * last read the uint32 totals are summed: ONE RCCL all-reduce of each engine's fused block (the five read counters ride
  * in it as 16-bit limbs) plus the exchange of the grouped log (counted records) when the PRG has sites with more than
- * 5 alleles. Afterwards every engine holds the totals of the whole job: gmx_coverage_fetch on any of them. */
+ * 8 alleles (the dense limit, GMX_GROUPED_DENSE_MAX_ALLELES). Afterwards every engine holds the totals of the whole job: gmx_coverage_fetch on any of them. */
 typedef struct gmx_group gmx_group; /* N engines in ONE process, one per listed device (the `gram` executable) */
 /* GPUs visible to this process (0 without one). `gram genotype` without --device / --devices takes all of them when the
  * reads files are large enough for sharding to pay (the front-end passes a fixed argument list, common.py:33-49, so the

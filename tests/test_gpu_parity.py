@@ -281,7 +281,7 @@ def test_device_accumulators_alias_as_torch_tensors_and_allreduce_in_place():
 
 @pytest.mark.parametrize("k2", ["0", "12"])
 def test_results_do_not_depend_on_the_seed_table_length(monkeypatch, k2):
-    """The search is seeded from a longer k-mer table when the PRG is large enough; without it
+    """The search is seeded from a longer k-mer table when the PRG is large enough (HISTORY.md §2); without it
     (GMX_SEED_K2=0) or with another length the coverage is the same, and equal to the oracle's."""
     prg, reads = _snp_workload(200000, 2700, 8000, 15, multi=0.05)
     seeds = master_seeds(11, [8000])

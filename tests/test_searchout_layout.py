@@ -2,7 +2,7 @@
 orders of SearchOut compiled: the regular library and lib/libgmx_alt.so (-DGMX_SEARCHOUT_ALT), each in a process of its own.
 
 Round 2 found gmx_probe_kernel appending mapped tasks to dead_list with one member order. Round 3's reading of the ISA
-(profiles/round3/searchout_layout_bug/): a compiler defect, not undefined behaviour — the exec-masked
+(profiles/round3/searchout_layout_bug/, HISTORY.md §4.5): a compiler defect, not undefined behaviour — the exec-masked
 VGPR copy of the cover_general_list pointer (a spilled SGPR pair) was emitted in a sibling block. finish_lane now
 addresses its queues as one base pointer + an integer index, which leaves no divergent pointer select to get wrong;
 these tests keep both layouts honest against the oracle (IT2 / IT3 are the cases that caught it)."""
