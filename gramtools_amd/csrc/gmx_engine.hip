@@ -1685,6 +1685,55 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_kernel(GmxIndexView ix, 
   gmx_block_count(o.stats, 3, present, &n_noext);
 }
 
+// The same decision where almost every k-mer occurs in the PRG (a whole-genome PRG: 12 occurrences per 14-mer, a few hundred
+// of the 4^14 k-mers absent): the ABSENT k-mers as a hash table in LDS instead of the presence bitmap in memory. With the
+// bitmap (32 MB at k = 14: no LDS, no early exit because nothing is missing) the filter sent 137 scattered requests per dead
+// task to the L2 — 137 M per pass, twice per batch, beside the search kernels that live on the same request path.
+#define GMX_ABSENT_MAX 2048u
+#define GMX_ABSENT_SLOTS 4096u
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_filter_absent_kernel(GmxIndexView ix, BatchView b, SearchOut o, const uint32_t *absent,
+                                                                      uint32_t n_absent, int pass) {
+  const uint32_t n_dead = o.counters[(pass ? 12 : 6) * GMX_CNT_STRIDE];
+  if (blockIdx.x * GMX_BLOCK >= n_dead) return;
+  __shared__ uint32_t table[GMX_ABSENT_SLOTS];
+  for (uint32_t i = threadIdx.x; i < GMX_ABSENT_SLOTS; i += GMX_BLOCK) table[i] = 0xFFFFFFFFu;  // (k-mer codes are < 4^15)
+  __syncthreads();
+  auto slot_of = [](uint32_t code) { return (code * 2654435761u) >> 20; };  // 12 bits
+  for (uint32_t i = threadIdx.x; i < n_absent; i += GMX_BLOCK) {
+    const uint32_t code = absent[i];
+    uint32_t h = slot_of(code);
+    while (atomicCAS(&table[h], 0xFFFFFFFFu, code) != 0xFFFFFFFFu) h = (h + 1u) & (GMX_ABSENT_SLOTS - 1u);
+  }
+  __syncthreads();
+  const uint32_t slot = blockIdx.x * GMX_BLOCK + threadIdx.x;
+  bool present = false, missing = false;
+  if (slot < n_dead) {
+    const uint32_t task = (pass ? o.dead2_list : o.dead_list)[slot];
+    ReadRef r = task_read(b, task);
+    present = true;
+    if (n_absent) {
+      const uint32_t k = ix.kmer_size;
+      uint32_t code = kmer_code(r, 0, k);
+      for (uint32_t at = 0;; ++at) {
+        uint32_t h = slot_of(code), v;
+        while ((v = table[h]) != 0xFFFFFFFFu) {
+          if (v == code) {
+            present = false;
+            break;
+          }
+          h = (h + 1u) & (GMX_ABSENT_SLOTS - 1u);
+        }
+        if (!present || at + k >= r.len) break;
+        code = (code >> 2) | ((r.at(at + k) - 1u) << (2u * (k - 1u)));
+      }
+    }
+    missing = !present;
+  }
+  __shared__ uint32_t n_miss, n_noext;
+  gmx_block_count(o.stats, 2, missing, &n_miss);
+  gmx_block_count(o.stats, 3, present, &n_noext);
+}
+
 // The same with the presence bitmap staged in LDS (k <= 10: 4^k bits <= 128 KB of the CU's 160 KB). The probes
 // of a wave go to 64 unrelated words: from LDS that costs a few bank-conflict cycles, from L1/L2 one tag
 // look-up per lane. One 1024-thread block per CU, persistent over the dead-task queue.
@@ -3064,6 +3113,9 @@ struct gmx_engine {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
+  const uint32_t *d_absent = nullptr;       // the k-mers that do NOT occur, when they are few (gmx_filter_absent_kernel)
+  uint32_t n_absent = 0;
+  bool use_absent = false;
   uint32_t n_cus = 256;
   uint32_t probe_iters = GMX_PROBE_ITERS;  // wave-loop iterations before the probe kernel parks what is left
   uint32_t extend_cap = 0;      // iterations of the LAST pass after which a task goes to the large-capacity route (0: runs to the end)
@@ -3392,7 +3444,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     if (hipGetDeviceProperties(&prop, opts.device) == hipSuccess && prop.multiProcessorCount > 0)
       e->n_cus = (uint32_t)prop.multiProcessorCount;
     const size_t words = h.kmer_bitmap.size();
-    if (words >= 4 && words % 4 == 0 && words * 4 <= 128 * 1024 &&
+    if (!getenv("GMX_FORCE_ABSENT_FILTER") && words >= 4 && words % 4 == 0 && words * 4 <= 128 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(gmx_filter_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(words * 4)) == hipSuccess)
       e->filter_lds_words = (uint32_t)words;
@@ -3412,6 +3464,25 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
         planar[p >> 5] |= 1u << (p & 31);
       }
       rc |= e->upload(&e->d_kmer_planar, planar);
+    } else if (!getenv("GMX_NO_ABSENT_FILTER")) {  // a bitmap too large for LDS: few absent k-mers? (whole-genome PRGs)
+      const uint64_t n_k = 1ull << (2 * h.kmer_size);
+      if (n_k - std::min<uint64_t>(n_k, h.n_seed_kmers_present) <= GMX_ABSENT_MAX) {
+        std::vector<uint32_t> absent;
+        for (size_t w = 0; w < words && absent.size() <= GMX_ABSENT_MAX; ++w) {
+          uint32_t zeros = ~h.kmer_bitmap[w];
+          while (zeros) {
+            const uint64_t code = (uint64_t)w * 32 + (uint32_t)__builtin_ctz(zeros);
+            zeros &= zeros - 1;
+            if (code < n_k) absent.push_back((uint32_t)code);
+          }
+        }
+        if (absent.size() <= GMX_ABSENT_MAX) {
+          e->n_absent = (uint32_t)absent.size();
+          e->use_absent = true;
+          if (absent.empty()) absent.push_back(0);
+          rc |= e->upload(&e->d_absent, absent);
+        }
+      }
     }
   }
   if (const char *pi = getenv("GMX_PROBE_ITERS")) e->probe_iters = (uint32_t)std::max(0, atoi(pi));
@@ -3517,6 +3588,8 @@ static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const B
   if (e->filter_lds_words)
     hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
                        st, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
+  else if (e->use_absent)
+    hipLaunchKernelGGL(gmx_filter_absent_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, e->d_absent, e->n_absent, pass);
   else
     hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
 }

@@ -61,3 +61,25 @@ def test_device_headers_on_realistic_reads(recipe):
     assert got == want
     st = want["stats"]
     assert st["skipped"] > 0 and st["no_extension"] > 0 and st["exact_mapped"] > 500
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_bases", [(5, 6000), (4, 400), (6, 30000)])
+def test_absent_kmer_filter_gives_the_oracles_split(monkeypatch, k, n_bases):
+    """Where almost every k-mer occurs in the PRG (whole-genome PRGs at k = 14) the missing_kmer / no_extension decision
+    (quasimap.cpp:168-186, 212-225) is taken against the few ABSENT k-mers in an LDS hash table
+    (gmx_filter_absent_kernel) instead of the presence bitmap: forced here on small PRGs, with zero, a few and hundreds of
+    absent k-mers, on reads with errors so that both counters move."""
+    from common import canonical_cov
+    from gramtools_amd import Index, Quasimapper
+    monkeypatch.setenv("GMX_FORCE_ABSENT_FILTER", "1")
+    ref = random_ref(n_bases, 40 + k)
+    prg, pos, alts, n_alts = snp_prg(ref, max(4, n_bases // 80), 41 + k)
+    clean = simulate_snp_reads(ref, pos, alts, n_alts, 3000, min(150, n_bases // 3), 42)
+    flat, offs = realistic_reads(clean, 43, sub_rate=0.02, n_read_frac=0.02, len_lo=max(k + 3, clean.shape[1] // 2))
+    seeds = master_seeds(42, [clean.shape[0]])
+    want = oracle_map(prg, k, (flat, offs), seeds, threads=8)
+    qm = Quasimapper(Index(prg, k))
+    qm.map_reads(flat, offs, seeds)
+    assert canonical_cov(qm.coverage()) == want
+    assert want["stats"]["no_extension"] > 0 and (k != 4 or want["stats"]["missing_kmer"] > 0)  # (k = 4 on 400 bases: ~60 of the 256 absent)
