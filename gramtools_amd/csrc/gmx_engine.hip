@@ -204,6 +204,18 @@ struct GmxSeedState {
   __device__ __forceinline__ uint32_t words() const { return 4u + 2u * nt + ng; }
   __device__ __forceinline__ uint32_t width() const { return text() ? 1u : hi - lo + 1u; }
 };
+// the left-context word of PRG position tp (GmxSeedState)
+__device__ __forceinline__ uint32_t gmx_left_context(const GmxTextRec *text, uint32_t tp) {
+  uint32_t ctx = 0, nv = 0;
+  for (; nv < GMX_SEEDST_CTX && nv < tp; ++nv) {
+    const uint32_t q = tp - 1u - nv;
+    const GmxTextRec rec = text[q >> GMX_TEXT_SHIFT];
+    const uint32_t bit = q & GMX_TEXT_MASK;
+    if ((rec.mk >> bit) & 1ull) break;
+    ctx |= ((uint32_t)((rec.lo >> bit) & 1ull) | ((uint32_t)((rec.hi >> bit) & 1ull) << 1)) << (2u * nv);
+  }
+  return ctx | (nv << 28);
+}
 __device__ __forceinline__ GmxSeedState gmx_seed_state(const uint32_t *p) {
   const uint32_t w2 = p[2];
   const bool text = (w2 & GMX_SEEDST_TEXT) != 0;
@@ -270,23 +282,23 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
     mode = GMX_MODE_STATE;
     return true;
   }
-  // Would a text-form state at PRG position `tp`, read position `pos`, survive its first text step? Exactly the decision
-  // gmx_dfs_text_apply takes on the record of tp - 1: dead iff the nearest event of the compared range is a mismatch (not a
-  // marker). One 32-byte fetch and ~40 instructions instead of three iterations of the wave loop.
+  // Would a text-form state at PRG position `tp`, read position `pos`, survive its first text step? A DRY RUN of that very
+  // step — gmx_dfs_text_apply on the record of tp - 1 with a context that allocates nothing — so inline sites are walked
+  // through as the real step walks them: a state next to a SNP site (a site every 36 bases in a whole-genome PRG) is
+  // compared beyond it instead of passing for "alive at a marker" and costing three iterations of the wave loop to die.
+  // One 32-byte fetch; dead here = dead there (the real step takes the same decisions; it can only add an arena overflow).
+  struct DryCtx {
+    __device__ __forceinline__ uint32_t arena_new(uint32_t, int32_t, uint32_t) { return 0u; }
+  };
   template <class Reader>
   __device__ __forceinline__ bool seed_text_alive(const GmxIndexView &ix, Reader &rd, uint32_t tp, uint32_t pos, uint32_t stop) const {
     if (pos <= stop) return true;  // already final
-    if (tp == 0) return false;     // PRG start: nothing extends the match (gmx_dfs_text_apply)
     GmxLane t;
     t.a = tp, t.b = GMX_TEXT_MARK, t.tvd = t.tvg = GMX_NIL, t.pos = pos, t.mode = GMX_MODE_STATE, t.have = true;
     const GmxTextRec rec = ix.text[gmx_dfs_text_rec(t)];
-    uint64_t rlo, rhi;
-    gmx_dfs_text_read_planes(t, rd, rlo, rhi);
-    const uint32_t slot = (tp - 1u) & GMX_TEXT_MASK, avail = pos - stop, n = avail < slot + 1u ? avail : slot + 1u;
-    const uint64_t range = gmx_below64(n) << (slot + 1u - n);
-    const uint64_t events = (((rec.lo ^ rlo) | (rec.hi ^ rhi)) | rec.mk) & range;
-    if (events == 0) return true;
-    return ((rec.mk >> (63u - (uint32_t)__builtin_clzll(events))) & 1ull) != 0;
+    DryCtx dry;
+    (void)gmx_dfs_text_apply(dry, t, stop, rd, rec);
+    return t.mode != GMX_MODE_DEAD;
   }
   // The seed cursor with a screen in front (indexes whose k-mers have many states: a whole-genome PRG has ~12 occurrences
   // per 14-mer, a third of them across a site — and all but one of a read's seed states die at their first text step, after
@@ -303,18 +315,32 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
       seed_rctx = 0;
       for (uint32_t j = 0; j < seed_rn; ++j) seed_rctx |= (rd.at(seed_pos - 1u - j) - 1u) << (2u * j);
     }
-    while (seed_left != 0 && status == GMX_TASK_MAPPED) {
-      const uint32_t *p = ix.seed_words + seed_off;
-      const GmxSeedState ss = gmx_seed_state(p);
+    // a mismatch among the bases before the first marker: dead, without fetching anything
+    auto ctx_dead = [&](uint32_t c) {
+      const uint32_t n = min(c >> 28, seed_rn);
+      return n != 0 && (((c ^ seed_rctx) << (32u - 2u * n)) != 0u);
+    };
+    while (status == GMX_TASK_MAPPED) {
+      // Phase A, a loop of its own: skip the states the left context rejects (a header load and a dozen instructions each).
+      // The lanes of a wave run it together and meet again behind it, so the heavy code below — text record, read planes,
+      // path nodes — runs once per CANDIDATE of the slowest lane, not once per state: in one loop with the test, every
+      // iteration found some lane with a candidate and the wave paid the heavy path ~30 times per entry.
+      GmxSeedState ss;
+      bool have = false;
+      while (seed_left != 0) {
+        ss = gmx_seed_state(ix.seed_words + seed_off);
+        if (!(ss.text() && ctx_dead(ss.ctx))) {
+          have = true;
+          break;
+        }
+        seed_off += ss.words();
+        --seed_left;
+      }
+      if (!have) return false;
       const uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
       if (ss.text() || lo == hi) {  // (one position: in text form in the device copy of the entries)
-        bool dead = false;
-        if (ss.text()) {  // a mismatch among the bases before the first marker: dead, without fetching anything
-          const uint32_t n = min(ss.ctx >> 28, seed_rn);
-          dead = n != 0 && (((ss.ctx ^ seed_rctx) << (32u - 2u * n)) != 0u);
-        }
         const uint32_t tp = ss.text() ? lo : ix.sa[lo];
-        if (dead || !seed_text_alive(ix, rd, tp, seed_pos, stop)) {
+        if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) {
           seed_off += ss.words();
           --seed_left;
           continue;
@@ -333,8 +359,12 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
         seed_off += 4u;
         --seed_left;
         uint32_t first = 0, n_alive = 0;
-        for (uint32_t i = lo; i <= hi; ++i) {
-          const uint32_t tp = ix.sa[i];
+        for (uint32_t i = lo; i <= hi;) {
+          if (ix.sa_ctx) {  // the same two phases over the occurrences: consecutive context words first
+            while (i <= hi && ctx_dead(ix.sa_ctx[i])) ++i;
+            if (i > hi) break;
+          }
+          const uint32_t tp = ix.sa[i++];
           if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) continue;
           if (n_alive == 0) first = tp;
           else if (!push(tp, GMX_TEXT_MARK, GMX_NIL, GMX_NIL, seed_pos, GMX_MODE_STATE)) fail(GMX_TASK_OVERFLOW);
@@ -624,22 +654,21 @@ __global__ void gmx_seed_mark_kernel(GmxSeed *seeds, uint64_t n, uint32_t *seed_
       big = big || (w[1] >= w[0] + GMX_SEED_SPLIT_MAX && nt == 0 && ng == 0);
       if (w[0] == w[1]) {  // one position: PRG position + left context (GmxSeedState)
         const uint32_t tp = sa[w[0]];
-        uint32_t ctx = 0, nv = 0;
-        for (; nv < GMX_SEEDST_CTX && nv < tp; ++nv) {
-          const uint32_t q = tp - 1u - nv;
-          const GmxTextRec rec = text[q >> GMX_TEXT_SHIFT];
-          const uint32_t bit = q & GMX_TEXT_MASK;
-          if ((rec.mk >> bit) & 1ull) break;
-          ctx |= ((uint32_t)((rec.lo >> bit) & 1ull) | ((uint32_t)((rec.hi >> bit) & 1ull) << 1)) << (2u * nv);
-        }
         w[0] = tp;
-        w[1] = ctx | (nv << 28);
+        w[1] = gmx_left_context(text, tp);
         w[2] = nt | GMX_SEEDST_TEXT;
       }
       w += 4 + 2 * nt + ng;
     }
     seeds[i].b = s.b | (big ? GMX_SEEDF_BIG : 0u) | (ns == 0 ? GMX_SEEDF_EMPTY : 0u);
   }
+}
+
+// sa_ctx[i] = left context of text position sa[i] (GmxIndexView::sa_ctx): the occurrences [lo, hi] of a path-less seed state
+// are screened from hi - lo + 1 CONSECUTIVE words instead of a suffix-array look-up and a text record each.
+__global__ void gmx_sa_ctx_kernel(const uint32_t *sa, const GmxTextRec *text, uint64_t n, uint32_t *out) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    out[i] = gmx_left_context(text, sa[i]);
 }
 
 // push(lo, hi, tvd, tvg) receives every seed state
@@ -3513,6 +3542,18 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // the rare large entry goes to the large-capacity pass
   e->seed_cursor = h.n_seed_states_large * 10 > h.n_seed_states;
   if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
+  if (e->seed_cursor && !rc && !getenv("GMX_NO_SA_CTX")) {  // left-context word per suffix-array position (GmxIndexView::sa_ctx): + 4 B per symbol
+    uint32_t *sc = nullptr;
+    if (e->alloc(&sc, h.sa.size(), false) == GMX_OK) {
+      hipLaunchKernelGGL(gmx_sa_ctx_kernel, dim3(8192), dim3(256), 0, nullptr, e->dview.sa, e->dview.text, (uint64_t)h.sa.size(), sc);
+      if (hipDeviceSynchronize() == hipSuccess) {
+        e->dview.sa_ctx = sc;
+        e->index_bytes += h.sa.size() * sizeof(uint32_t);
+      }
+    } else {
+      (void)hipGetLastError();  // (no room: the occurrences are screened through the suffix array and the text, as before)
+    }
+  }
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;

@@ -198,6 +198,8 @@ struct GmxIndexView {
   const GmxSeed *seeds2;      // [4^k2] or null
   const uint32_t *seed_words;
   const uint32_t *kmer_bitmap;  // [4^k / 32] presence bits (all_read_kmers_occur_in_index, quasimap.cpp:212-225)
+  const uint32_t *sa_ctx;       // [n] or null: left-context word of text position sa[i] (device only, engines with a seed cursor:
+                                //   the occurrences of a path-less seed interval are screened from consecutive words; gmx_engine.hip)
 };
 
 // Status of one (read, orientation) task after the search kernel.

@@ -62,3 +62,23 @@ for rep in range(2):
 print(f"packed host feed: {dt * 1e3:.3f} ms per {n} reads = {n / dt / 1e6:.1f} M reads/s", flush=True)
 print("stats:", qm.coverage().stats.as_dict(), flush=True)
 pk.close()
+if os.environ.get("GMX_LIB", "").endswith("libgmx_stats.so"):  # debug build (-DGMX_LOOP_STATS): iteration mix of ONE batch
+    import ctypes as C
+    from gramtools_amd import _lib
+    lib = _lib.load()
+    lib.gmx_debug_loop_stats.restype = C.c_int
+    lib.gmx_debug_loop_stats.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+    buf = (C.c_ulonglong * 48)()
+    lib.gmx_debug_loop_stats(buf, 1)
+    qm.reset()
+    qm.map_reads_device(d_r, d_o, d_s, n, stream=stream)
+    qm.sync()
+    lib.gmx_debug_loop_stats(buf, 1)
+    names = ["fast iterations", "heavy TEXT", "heavy HIT", "heavy WIDE", "light only", "slow iterations", "lanes in heavy kinds",
+             "lanes in slow iterations", "waves", "lanes in light kinds", "clk prologue", "clk loop", "clk epilogue", "live lanes (sum over iterations)"]
+    for kk, kern in enumerate(["probe", "extend", "large-capacity"]):
+        v = np.array(buf[kk * 16:kk * 16 + 14], dtype=np.float64)
+        waves = max(v[8], 1)
+        print(kern, f"waves={int(v[8])}")
+        for nm, x in zip(names, v):
+            print(f"    {nm:34s} {int(x):14d}   {x / waves:10.2f} per wave")
