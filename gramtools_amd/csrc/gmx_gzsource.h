@@ -24,8 +24,10 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -265,7 +267,22 @@ class GzSource {
   size_t size_ = 0, pos_ = 0;
   bool streaming_ = false;
   z_stream zs_;
-  std::vector<char> carry_;
+  struct RawBuf {  // bytes that are always written before they are read: no zero-fill, no copy when it grows
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    char *data() { return p; }
+    size_t size() const { return n; }
+    void resize(size_t want) {
+      if (want > cap) {
+        free(p);
+        p = static_cast<char *>(malloc(want + want / 8 + 64));
+        if (!p) throw std::bad_alloc();
+        cap = want + want / 8 + 64;
+      }
+      n = want;
+    }
+  } carry_;
   size_t carry_at_ = 0;
   uint64_t n_bgzf_ = 0, n_stream_bytes_ = 0, n_par_pieces_ = 0;
   // ---- a plain member on all threads (gmx_pargz.h) ----
@@ -419,7 +436,6 @@ class GzSource {
     const double t3 = now();
     // bytes: the first `direct` of them to the caller's buffer, the rest to the carry buffer
     const size_t direct = std::min(total, want);
-    if (carry_.size() < total - direct) carry_ = std::vector<char>();  // (no copy of stale bytes when it grows)
     carry_.resize(total - direct);
     carry_at_ = 0;
     const double t4 = now();

@@ -54,7 +54,7 @@ struct Bits {
     buf >>= skip;
     cnt -= skip;
   }
-  inline void refill() {
+  __attribute__((always_inline)) inline void refill() {
     if (end - p >= 8) {
       uint64_t w;
       memcpy(&w, p, 8);
@@ -74,12 +74,12 @@ struct Bits {
       }
     }
   }
-  inline uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
-  inline void skip(uint32_t n) {
+  __attribute__((always_inline)) inline uint32_t peek(uint32_t n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+  __attribute__((always_inline)) inline void skip(uint32_t n) {
     buf >>= n;
     cnt -= n;
   }
-  inline uint32_t get(uint32_t n) {  // n <= 32; the caller has refilled
+  __attribute__((always_inline)) inline uint32_t get(uint32_t n) {  // n <= 32; the caller has refilled
     const uint32_t v = peek(n);
     skip(n);
     return v;
@@ -135,7 +135,7 @@ struct Huff {
     return true;
   }
   // decode one symbol; the caller has >= 15 bits in the buffer. Returns 0xFFFF on an invalid code.
-  inline uint32_t decode(Bits &in) const {
+  __attribute__((always_inline)) inline uint32_t decode(Bits &in) const {
     const uint16_t e = fast[in.peek(kFast)];
     if (e) {
       in.skip(e & 15u);
@@ -280,7 +280,9 @@ enum class BlockEnd { Ok, Final, Bad };
 
 // One block at the reader's position into `out`. `text_only`: literals must be text (the block finder's test).
 // `max_out`: give up (Bad) beyond this many output symbols (finder: a wrong start may "decode" forever).
-inline BlockEnd decode_block(Bits &in, Symbols &out, bool text_only, size_t max_out) {
+template <bool TEXT>
+inline BlockEnd decode_block_t(Bits &in, Symbols &out, size_t max_out) {
+  auto is_text = [](uint32_t c) { return (c >= 0x20 && c < 0x7F) || c == '\n' || c == '\r' || c == '\t'; };
   in.refill();
   if (in.overrun || in.past_end()) return BlockEnd::Bad;
   const uint32_t final = in.get(1), type = in.get(2);
@@ -295,7 +297,7 @@ inline BlockEnd decode_block(Bits &in, Symbols &out, bool text_only, size_t max_
       if (in.cnt < 8) in.refill();
       if (in.overrun) return BlockEnd::Bad;
       const uint32_t c = in.get(8);
-      if (text_only && !((c >= 0x20 && c < 0x7F) || c == '\n' || c == '\r' || c == '\t')) return BlockEnd::Bad;
+      if (TEXT && !is_text(c)) return BlockEnd::Bad;
       out.v[out.n++] = (uint16_t)c;
     }
     if (in.past_end()) return BlockEnd::Bad;
@@ -308,44 +310,67 @@ inline BlockEnd decode_block(Bits &in, Symbols &out, bool text_only, size_t max_
     bc = &dyn;
   }
   const size_t limit = max_out ? kWindow + max_out : ~(size_t)0;
+  const uint16_t *const lit_fast = bc->lit.fast;
+  // (the bit reader as a local whose address never leaves this function: its words stay in registers; through the
+  //  reference every step was a store and a reload)
+  Bits lb = in;
+  const BlockEnd result = [&]() __attribute__((always_inline)) -> BlockEnd {
+#define in lb
   for (;;) {
     in.refill();
     if (in.overrun) return BlockEnd::Bad;
-    out.room(600);  // two symbols per refill at most: 2 x 258 matched + slack
-    uint32_t s = bc->lit.decode(in);
-    if (s < 256) {
-      if (text_only && !((s >= 0x20 && s < 0x7F) || s == '\n' || s == '\r' || s == '\t')) return BlockEnd::Bad;
-      out.v[out.n++] = (uint16_t)s;
-      // a second literal from the same refill (the common case in FASTQ quality strings): >= 15 bits are still there
-      if (in.cnt >= 30) {
-        const uint16_t e = bc->lit.fast[in.peek(kFast)];
-        if (e && (e >> 4) < 256) {
-          const uint32_t s2 = e >> 4;
-          if (text_only && !((s2 >= 0x20 && s2 < 0x7F) || s2 == '\n' || s2 == '\r' || s2 == '\t')) return BlockEnd::Bad;
-          in.skip(e & 15u);
-          out.v[out.n++] = (uint16_t)s2;
-        }
+    if (out.n + 600 > out.v.size()) out.room(600);  // per refill: at most seven literals, or a match of 258 (+ 3 of the wide copy)
+    uint16_t *const base = out.v.data();
+    size_t n = out.n;
+    // literals for as long as the bit buffer holds a whole code (FASTQ quality strings are runs of literals: one refill
+    // serves four to seven of them)
+    uint32_t s;
+    for (;;) {
+      const uint16_t e = lit_fast[in.peek(kFast)];
+      if (e) {
+        in.skip(e & 15u);
+        s = e >> 4;
+      } else {
+        s = bc->lit.decode(in);
       }
-      if (out.n > limit) return BlockEnd::Bad;
+      if (s >= 256) break;
+      if (TEXT && !is_text(s)) return BlockEnd::Bad;
+      base[n++] = (uint16_t)s;
+      if (in.cnt < 15) break;
+    }
+    out.n = n;
+    if (s < 256) {
+      if (n > limit) return BlockEnd::Bad;
       continue;
     }
     if (s == 256) break;
     if (s > 285) return BlockEnd::Bad;  // (286, 287 and the invalid-code mark)
     s -= 257;
+    if (in.cnt < 48) in.refill();  // length extra <= 5, distance code <= 15, distance extra <= 13
     const uint32_t len = kLenBase[s] + in.get(kLenExtra[s]);
-    if (in.cnt < 32) in.refill();
     const uint32_t ds = bc->dist.decode(in);
     if (ds > 29) return BlockEnd::Bad;
     const uint32_t dist = kDistBase[ds] + in.get(kDistExtra[ds]);
-    if (dist > out.n) return BlockEnd::Bad;  // (cannot happen with the window in front; kept for safety)
-    uint16_t *dst = out.v.data() + out.n;
+    if (dist > n) return BlockEnd::Bad;  // (cannot happen with the window in front; kept for safety)
+    uint16_t *dst = base + n;
     const uint16_t *src = dst - dist;
-    for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];  // (overlapping on purpose: a run repeats its period)
-    out.n += len;
+    if (dist >= 4) {  // four symbols per copy (the source chunk ends before the destination chunk starts); up to 3 symbols
+      for (uint32_t i = 0; i < len; i += 4) memcpy(dst + i, src + i, 8);  // of overshoot land in the buffer's slack
+    } else {
+      for (uint32_t i = 0; i < len; ++i) dst[i] = src[i];  // (overlapping on purpose: a run repeats its period)
+    }
+    out.n = n + len;
     if (out.n > limit) return BlockEnd::Bad;
   }
   if (in.past_end()) return BlockEnd::Bad;
   return final ? BlockEnd::Final : BlockEnd::Ok;
+#undef in
+  }();
+  in = lb;
+  return result;
+}
+inline BlockEnd decode_block(Bits &in, Symbols &out, bool text_only, size_t max_out) {
+  return text_only ? decode_block_t<true>(in, out, max_out) : decode_block_t<false>(in, out, max_out);
 }
 
 // A deflate block start at or after bit `from` (below bit `upto`): a non-final dynamic block whose header is valid, that
