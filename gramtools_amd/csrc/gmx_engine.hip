@@ -320,6 +320,18 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
       const uint32_t n = min(c >> 28, seed_rn);
       return n != 0 && (((c ^ seed_rctx) << (32u - 2u * n)) != 0u);
     };
+    // The WHOLE rest of the entry is screened in this one call: the first survivor becomes the lane's state, further ones
+    // (rare) go on its stack. A lane that came back to the cursor after every survivor put the screening loop into most
+    // iterations of its wave (lanes finish at different times), at the price of the loop's instructions for all 64.
+    bool got = false;
+    auto take = [&](uint32_t sa_, uint32_t sb_, uint32_t st_, uint32_t sg_) {
+      if (!got) {
+        a = sa_, b = sb_, tvd = st_, tvg = sg_, pos = seed_pos, mode = GMX_MODE_STATE;
+        got = true;
+      } else if (!push(sa_, sb_, st_, sg_, seed_pos, GMX_MODE_STATE)) {
+        fail(GMX_TASK_OVERFLOW);
+      }
+    };
     while (status == GMX_TASK_MAPPED) {
       // Phase A, a loop of its own: skip the states the left context rejects (a header load and a dozen instructions each).
       // The lanes of a wave run it together and meet again behind it, so the heavy code below — text record, read planes,
@@ -336,7 +348,8 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
         seed_off += ss.words();
         --seed_left;
       }
-      if (!have) return false;
+      if (!have) break;
+      if (got && sp + 2u > GMX_STACK_DEPTH) break;  // (no room for another survivor: the rest of the entry on a later visit)
       const uint32_t lo = ss.lo, hi = ss.hi, nt = ss.nt, ng = ss.ng;
       if (ss.text() || lo == hi) {  // (one position: in text form in the device copy of the entries)
         const uint32_t tp = ss.text() ? lo : ix.sa[lo];
@@ -345,42 +358,34 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
           --seed_left;
           continue;
         }
-        const bool ok = next_seed(ix, true, a, b, tvd, tvg, pos, mode);
-        if (ok) {
-          a = tp;
-          b = GMX_TEXT_MARK;
-        }
-        return ok;
+        uint32_t xa, xb, xt, xg, xp, xm;
+        if (!next_seed(ix, !got, xa, xb, xt, xg, xp, xm)) break;  // (path nodes: arena full -> the task overflows)
+        take(tp, GMX_TEXT_MARK, xt, xg);
+        continue;
       }
       if (nt == 0 && ng == 0 && hi - lo < 32u && seed_pos > stop) {
-        if (n_out == mark_out) arena_n = mark_arena;  // (as next_seed: the state before left nothing behind)
-        mark_arena = arena_n;
-        mark_out = n_out;
+        if (!got) {
+          if (n_out == mark_out) arena_n = mark_arena;  // (as next_seed: the state before left nothing behind)
+          mark_arena = arena_n;
+          mark_out = n_out;
+        }
         seed_off += 4u;
         --seed_left;
-        uint32_t first = 0, n_alive = 0;
         for (uint32_t i = lo; i <= hi;) {
           if (ix.sa_ctx) {  // the same two phases over the occurrences: consecutive context words first
             while (i <= hi && ctx_dead(ix.sa_ctx[i])) ++i;
             if (i > hi) break;
           }
           const uint32_t tp = ix.sa[i++];
-          if (!seed_text_alive(ix, rd, tp, seed_pos, stop)) continue;
-          if (n_alive == 0) first = tp;
-          else if (!push(tp, GMX_TEXT_MARK, GMX_NIL, GMX_NIL, seed_pos, GMX_MODE_STATE)) fail(GMX_TASK_OVERFLOW);
-          ++n_alive;
+          if (seed_text_alive(ix, rd, tp, seed_pos, stop)) take(tp, GMX_TEXT_MARK, GMX_NIL, GMX_NIL);
         }
-        if (n_alive == 0) continue;
-        a = first;
-        b = GMX_TEXT_MARK;
-        tvd = tvg = GMX_NIL;
-        pos = seed_pos;
-        mode = GMX_MODE_STATE;
-        return status == GMX_TASK_MAPPED;
+        continue;
       }
-      return next_seed(ix, true, a, b, tvd, tvg, pos, mode);
+      uint32_t xa, xb, xt, xg, xp, xm;  // anything else (an interval state with paths): as it is
+      if (!next_seed(ix, !got, xa, xb, xt, xg, xp, xm)) break;
+      take(xa, xb, xt, xg);
     }
-    return false;
+    return got && status == GMX_TASK_MAPPED;
   }
   __device__ __forceinline__ bool park(uint32_t a, uint32_t b, uint32_t tvd, uint32_t tvg, uint32_t pos, uint32_t mode) {
     if (n_out >= out_cap) return false;
