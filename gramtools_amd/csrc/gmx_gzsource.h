@@ -33,6 +33,7 @@
 #include <thread>
 #include <vector>
 
+#include "gmx_crc32.h"
 #include "gmx_pargz.h"
 
 namespace gmx {
@@ -147,7 +148,7 @@ class GzSource {
     const bool ok = rc == Z_STREAM_END && zs.avail_out == 0 && zs.avail_in == 0;
     inflateEnd(&zs);
     if (!ok) fail("damaged BGZF member at byte " + std::to_string(m.data));
-    if (m.isize && (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(dst), m.isize) != m.crc)
+    if (m.isize && crc32_fast((uint32_t)crc32(0L, Z_NULL, 0), reinterpret_cast<const unsigned char *>(dst), m.isize) != m.crc)
       fail("CRC mismatch in the BGZF member at byte " + std::to_string(m.data));
   }
 
@@ -457,7 +458,7 @@ class GzSource {
           const uint16_t sy = from[i];
           out[i] = sy < kUnknown ? (uint8_t)sy : w[sy - kUnknown];
         }
-        for (size_t at = 0; at < m; at += (size_t)1 << 30) c = (uint32_t)crc32(c, out + at, (uInt)std::min<size_t>(m - at, (size_t)1 << 30));
+        c = crc32_fast(c, out, m);
       }
       pc.crc = c;
       pc.sym.v.release();
