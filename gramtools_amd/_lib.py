@@ -16,7 +16,7 @@ class IndexInfo(C.Structure):
                 ("n_allele_slots", C.c_uint32), ("n_per_base_slots", C.c_uint32), ("n_grouped_slots", C.c_uint32),
                 ("n_nodes", C.c_uint32), ("n_kmers_present", C.c_uint64), ("index_bytes", C.c_uint64),
                 ("kmer_size2", C.c_uint32), ("n_inline_sites", C.c_uint32), ("seed_shift", C.c_uint32),
-                ("reserved0", C.c_uint32), ("n_seed_words", C.c_uint64)]
+                ("n_jump_sites", C.c_uint32), ("n_seed_words", C.c_uint64)]
 
 
 class EngineOpts(C.Structure):

@@ -162,6 +162,8 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   o->n_kmers_present = h.n_seed_kmers_present;
   o->kmer_size2 = h.kmer_size2;
   o->seed_shift = h.seed_shift;
+  o->n_jump_sites = 0;
+  for (const GmxSiteGeo &g : h.site_geo) o->n_jump_sites += (g.flags & GMX_SITE_JUMP) ? 1u : 0u;
   o->n_seed_words = h.seed_words.size();
   {
     uint64_t n_inline = 0;
@@ -170,7 +172,7 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
   }
   o->index_bytes = h.blocks.size() * sizeof(GmxRankBlock) + h.hits.size() * sizeof(GmxHit) + h.text.size() * sizeof(GmxTextRec) + (h.hit_perm.size() + h.hit_prog.size() + h.prog.size() + h.sa.size() + h.pos_node.size() +
                    h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.seeds2.size() * sizeof(GmxSeed) + h.nodes.size() * sizeof(GmxNode) +
-                   h.sites.size() * sizeof(GmxSite) + h.seeds.size() * sizeof(GmxSeed);
+                   h.sites.size() * (sizeof(GmxSite) + sizeof(GmxSiteGeo)) + h.seeds.size() * sizeof(GmxSeed);
   return GMX_OK;
 }
 

@@ -103,6 +103,9 @@ GMX_HD bool gmx_uniform_1_to_n(uint32_t seed, uint32_t n, int mode, uint32_t &re
 // ---------------------------------------------------------------------------
 // scratch layout (words)
 // ---------------------------------------------------------------------------
+#ifndef GMX_COVER_ROUTE  // test build: which routine recorded a single-instance task (tests/hostemu)
+#define GMX_COVER_ROUTE(k) do { } while (0)
+#endif
 #ifndef GMX_COVER_PROF
 #define GMX_COVER_PROF(env, k) do { } while (0)
 #endif
@@ -567,6 +570,71 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       if (ix.sites[(env.h_site(x) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
     if (words && !env.log_reserve(words)) return;
   }
+  // Without the walk, from the sites' geometry (GmxSiteGeo, gmx_types.h): every site of the path is a flat site whose
+  // 32-byte geometry record says where it lies in the PRG, how long its alleles are and where their counters are, so the
+  // walk's bookkeeping — bases left, first and last base covered in each allele — is position arithmetic on ONE sector per
+  // site instead of ~5 dependent node / edge records per site crossed, and GmxSite is not looked at. First a dry pass:
+  // whatever the arithmetic cannot vouch for (a site without geometry, a gap that is not the stretch between two
+  // neighbouring sites, a read that ends early or runs on into another site) leaves the task to the code below, which
+  // decides as the reference does.
+  if (enc_site == 0 && ix.site_geo) {
+    auto jump = [&](const bool record) -> bool {
+      uint32_t remaining = read_len, cur = p, tail = 0xFFFFFFFFu;
+      if (remaining == 0) return false;
+      if (tvg != GMX_NIL) {  // the read starts inside an allele of the traversing site
+        const uint32_t site0 = env.h_site(tvg);
+        const GmxSiteGeo g0 = ix.site_geo[(site0 - 5) >> 1];
+        if (!(g0.flags & GMX_SITE_JUMP) || !gmx_in_bubble(rec0) || rec0.site != site0 || rec0.seq_len == 0 ||
+            (uint32_t)rec0.allele >= gmx_geo_alleles(g0) || rec0.cov_off == GMX_NO_COV || p < rec0.first_pos || p - rec0.first_pos >= rec0.seq_len)
+          return false;
+        const uint32_t start = p - rec0.first_pos;
+        const uint32_t end = start + remaining - 1u < rec0.seq_len - 1u ? start + remaining - 1u : rec0.seq_len - 1u;
+        remaining -= end - start + 1u;
+        if (record) {
+          if (gmx_node_has_hit_counter(rec0)) {
+            env.add_hit(rec0.cov_off + 1);
+          } else {
+            for (uint32_t i = start; i <= end; ++i) env.add_per_base(rec0.cov_off + i);
+            env.add_allele_and_group(g0.allele_sum_off + 2u * (uint32_t)rec0.allele);
+          }
+        }
+        cur = gmx_geo_exit_pos(g0) + 1u;
+        tail = g0.tail_len;
+      }
+      for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
+        const GmxSiteGeo g = ix.site_geo[(env.h_site(x) - 5) >> 1];
+        const uint32_t allele = (uint32_t)env.h_allele(x);
+        if (!(g.flags & GMX_SITE_JUMP) || allele >= gmx_geo_alleles(g) || g.entry_pos < cur) return false;
+        const uint32_t gap = g.entry_pos - cur;  // base symbols in front of the site
+        if (remaining <= gap || (tail != 0xFFFFFFFFu && gap != tail)) return false;
+        remaining -= gap;
+        const uint32_t kind = (g.flags >> (2u * allele)) & 3u;
+        if (kind == GMX_ALLELE_HIT) {
+          remaining -= 1u;
+          if (record) env.add_hit(gmx_geo_cov_off(g, allele) + 1);
+        } else {
+          if (kind == GMX_ALLELE_LONG) {
+            const uint32_t len = gmx_geo_allele_len(g, allele);
+            const uint32_t n = remaining < len ? remaining : len;
+            remaining -= n;
+            if (record) {
+              const uint32_t cov = gmx_geo_cov_off(g, allele);
+              for (uint32_t i = 0; i < n; ++i) env.add_per_base(cov + i);
+            }
+          }
+          if (record) env.add_allele_and_group(g.allele_sum_off + 2u * allele);
+        }
+        cur = gmx_geo_exit_pos(g) + 1u;
+        tail = g.tail_len;
+      }
+      return tail != 0xFFFFFFFFu && remaining <= tail;  // (the rest of the read lies in the stretch behind the last site)
+    };
+    if (jump(false)) {
+      GMX_COVER_ROUTE(1);
+      jump(true);
+      return;
+    }
+  }
   // Without the walk: every traversed site is walk-free (gmx_types.h: a one-base allele is its hit counter, an empty
   // one its allele-sum/group pair) and the first node, if in play, has a hit counter. The site records are
   // independent loads; the walk below is a chain of dependent ones.
@@ -576,6 +644,7 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     for (uint32_t x = tvd; x != GMX_NIL && walk_free; x = env.h_next(x))
       walk_free = (ix.sites[(env.h_site(x) - 5) >> 1].snp_kinds & GMX_SITE_WALK_FREE) != 0;
     if (walk_free) {
+      GMX_COVER_ROUTE(0);
       if (first_in_play) env.add_hit(rec0.cov_off + 1);
       for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
         const GmxSite &s = ix.sites[(env.h_site(x) - 5) >> 1];
@@ -589,6 +658,7 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       return;
     }
   }
+  GMX_COVER_ROUTE(2);
   if (!first_in_play) {
     node0 = ix.pos_node[p];
     rec0 = ix.nodes[node0];

@@ -2866,6 +2866,7 @@ struct CompactEnv : CoverLogPart {
 
 // The common case, one lane per compact record and no scratch (gmx_cover_single, gmx_cover.h): a task with ONE
 // final state of width one. Few registers, a coalesced queue, region-local tables.
+template <bool NESTED>  // (two kernels: the nested routine's locus arrays would cost the flat one registers and scratch)
 __device__ __forceinline__ void gmx_cover_single_rec(const GmxIndexView &ix, const SearchOut &o, const CoverAcc &acc, size_t rec_idx,
                                                      uint32_t *handoff_list, uint32_t handoff_counter) {
   CompactEnv env;
@@ -2878,7 +2879,7 @@ __device__ __forceinline__ void gmx_cover_single_rec(const GmxIndexView &ix, con
   env.status = GMX_TASK_MAPPED;
   env.log_at = 0;
   const GmxFinalState st{env.rec.p, GMX_TEXT_MARK, env.n_trav() ? 0u : GMX_NIL, env.rec.tvg};
-  if (!ix.is_nested) {
+  if constexpr (!NESTED) {
     gmx_cover_single(ix, env, st, env.rec.len_n & 0xFFFFu);
   } else if (!gmx_cover_single_nested(ix, env, st, env.rec.len_n & 0xFFFFu)) {  // many loci: the general instance next
     handoff_list[atomicAdd(&o.counters[handoff_counter * GMX_CNT_STRIDE], 1u)] = o.cover_rec_task[rec_idx];
@@ -2891,12 +2892,13 @@ __device__ __forceinline__ void gmx_cover_single_rec(const GmxIndexView &ix, con
   env.log_abandon();
 }
 
+template <bool NESTED>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
   const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);  // = the XCD this workgroup runs on (round-robin dispatch)
   const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
   const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
   if (m >= n_mapped) return;
-  gmx_cover_single_rec(ix, o, acc, (size_t)region * o.region_cap + m, o.cover_general_list, 8u);
+  gmx_cover_single_rec<NESTED>(ix, o, acc, (size_t)region * o.region_cap + m, o.cover_general_list, 8u);
 }
 
 // ---- grouped log full: the batch's failed entries again, after the host has drained the log (launch_log_replay) ----
@@ -2918,11 +2920,12 @@ __global__ void gmx_log_replay_setup_kernel(SearchOut o, const uint32_t *retry_h
     c[GMX_CNT_LOG_RETRY_HUGE * GMX_CNT_STRIDE] = 0;
   }
 }
+template <bool NESTED>
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_replay_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc,
                                                                             const uint32_t *recs_in) {
   const uint32_t n = o.counters[GMX_CNT_REPLAY_RECS * GMX_CNT_STRIDE];
   for (uint32_t i = blockIdx.x * GMX_BLOCK + threadIdx.x; i < n; i += gridDim.x * GMX_BLOCK)
-    gmx_cover_single_rec(ix, o, acc, recs_in[i], o.cover_overflow_list, 4u);  // (nested, many loci: the large scratch, which runs next)
+    gmx_cover_single_rec<NESTED>(ix, o, acc, recs_in[i], o.cover_overflow_list, 4u);  // (nested, many loci: the large scratch, which runs next)
 }
 
 // The five uint64 read counters <-> 16-bit limbs in uint32 words, so that they travel inside the one uint32
@@ -3423,6 +3426,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= e->upload(&v.nodes, h.nodes);
   rc |= e->upload(&v.edges, h.edges);
   rc |= e->upload(&v.sites, h.sites);
+  rc |= e->upload(&v.site_geo, h.site_geo);
   rc |= e->upload(&v.seeds, h.seeds);
   if (h.kmer_size2) rc |= e->upload(&v.seeds2, h.seeds2);
   else v.seeds2 = nullptr;
@@ -3665,7 +3669,11 @@ static int launch_log_replay(gmx_engine *e, hipStream_t stream) {
   o.log_retry_huge = e->d_log_retry_huge[out];
   o.cover_overflow_list = e->d_log_retry[in];  // the queue of gmx_cover_kernel<CoverEnvBig, 1>: this round's entries
   hipLaunchKernelGGL(gmx_log_replay_setup_kernel, dim3(1), dim3(1024), 0, stream, o, e->d_log_retry_huge[in]);
-  hipLaunchKernelGGL(gmx_cover_single_replay_kernel, dim3(e->n_cus * 4), dim3(GMX_BLOCK), 0, stream, e->dview, e->last_b, o, e->last_acc,
+  if (e->dview.is_nested)
+    hipLaunchKernelGGL(gmx_cover_single_replay_kernel<true>, dim3(e->n_cus * 4), dim3(GMX_BLOCK), 0, stream, e->dview, e->last_b, o, e->last_acc,
+                     e->d_log_retry_recs[in]);
+  else
+    hipLaunchKernelGGL(gmx_cover_single_replay_kernel<false>, dim3(e->n_cus * 4), dim3(GMX_BLOCK), 0, stream, e->dview, e->last_b, o, e->last_acc,
                      e->d_log_retry_recs[in]);
   hipLaunchKernelGGL((gmx_cover_kernel<CoverEnvBig, 1>), dim3(e->cover_big_lanes / 64), dim3(64), e->last_big_lds, stream, e->dview,
                      e->last_b, o, e->big, e->last_acc, 64u, 0u);
@@ -3964,7 +3972,10 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   // (Round 4 measured the records in PRG order — a radix sort of (position, record) pairs in front of this kernel, for the
   //  locality of the accumulator and table lines: at configs[3] the kernel took 508 us instead of 436 plus 120 us of sorting, at
   //  configs[4] 646 instead of 611: neighbouring lanes then hit the SAME accumulator words and their atomics serialise. Dropped.)
-  hipLaunchKernelGGL(gmx_cover_single_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  if (e->dview.is_nested)
+    hipLaunchKernelGGL(gmx_cover_single_kernel<true>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  else
+    hipLaunchKernelGGL(gmx_cover_single_kernel<false>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   // The batch's last coverage instance (1: what exceeded the regular scratch; its last block also serves the last tier,
   // whose search keeps its first pending entries in LDS) needs every other instance done except gmx_cover_single_kernel,
   // which queues nothing on a non-nested PRG: there it runs at the end of side 2, beside that kernel.

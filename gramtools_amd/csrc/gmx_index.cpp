@@ -809,6 +809,7 @@ GmxIndexView HostIndex::view() const {
   v.nodes = nodes.data();
   v.edges = edges.data();
   v.sites = sites.data();
+  v.site_geo = site_geo.data();
   v.seeds = seeds.data();
   v.seeds2 = seeds2.data();
   v.kmer_size2 = kmer_size2;
@@ -1023,7 +1024,58 @@ static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, in
     }
     out.n_acc_slots = at;
   }
-
+  // --- site geometry (GmxSiteGeo, gmx_types.h): flat PRGs, dense sites whose alleles are one node each ------------------
+  out.site_geo.assign(out.sites.size(), GmxSiteGeo{});
+  if (!out.is_nested && !getenv("GMX_NO_SITE_JUMP")) {
+    const unsigned hw_geo = threads > 0 ? (unsigned)threads : std::max(1u, std::thread::hardware_concurrency());
+    const size_t n_sites_geo = out.sites.size(), piece = 1u << 16;
+    par_for((n_sites_geo + piece - 1) / piece, hw_geo, [&](size_t c) {
+      for (size_t i = c * piece; i < std::min(n_sites_geo, (c + 1) * piece); ++i) {
+        const GmxSite &s = out.sites[i];
+        const uint32_t A = s.n_alleles;
+        const GmxNode &entry = out.nodes[s.entry_node], &exitn = out.nodes[s.exit_node];
+        if (A < 2 || A > 8 || s.grouped_off == GMX_GROUPED_LOG || entry.n_edges != A) continue;
+        GmxSiteGeo geo{};
+        geo.allele_sum_off = s.allele_sum_off;
+        geo.entry_pos = entry.first_pos;
+        geo.flags = A << 16;
+        bool ok = entry.first_pos < N && prg[entry.first_pos] == 5 + 2 * i;
+        uint32_t at_pos = entry.first_pos + 1;
+        for (uint32_t a = 0; a < A && ok; ++a) {  // lengths first: the layout rule reads them
+          const uint32_t tgt = out.edges[entry.edge_begin + a];
+          if (tgt != s.exit_node) {
+            const GmxNode &n = out.nodes[tgt];
+            ok = n.site == 5 + 2 * i && n.allele == (int32_t)a && n.n_edges == 1 && n.edge0 == s.exit_node && n.seq_len >= 1 &&
+                 n.seq_len <= 254 && n.first_pos == at_pos && n.cov_off != GMX_NO_COV;
+            if (!ok) break;
+            geo.allele_lens |= (uint64_t)n.seq_len << (8 * a);
+            at_pos += n.seq_len;
+          }
+          at_pos += 1;  // the separator behind the allele, or the end marker
+        }
+        for (uint32_t a = 0; a < A && ok; ++a) {  // the counters where the rule puts them; kinds as the recording takes them
+          const uint32_t tgt = out.edges[entry.edge_begin + a];
+          if (tgt == s.exit_node) {
+            geo.flags |= GMX_ALLELE_EMPTY << (2 * a);
+            continue;
+          }
+          const GmxNode &n = out.nodes[tgt];
+          ok = gmx_geo_cov_off(geo, a) == n.cov_off && (n.seq_len == 1) == gmx_node_has_hit_counter(n);
+          geo.flags |= (n.seq_len == 1 ? GMX_ALLELE_HIT : GMX_ALLELE_LONG) << (2 * a);
+        }
+        // the end marker where the lengths put it, and base symbols only up to the next marker
+        ok = ok && exitn.first_pos == at_pos - 1 && gmx_geo_exit_pos(geo) == exitn.first_pos && exitn.first_pos < N &&
+             prg[exitn.first_pos] == 6 + 2 * i;
+        if (ok && (s.snp_kinds & GMX_SITE_WALK_FREE)) ok = (s.snp_kinds & 0xFFFFu) == (geo.flags & 0xFFFFu);
+        if (!ok) continue;
+        size_t j = (size_t)exitn.first_pos + 1;
+        while (j < N && prg[j] <= 4) ++j;
+        geo.tail_len = (uint32_t)(j - exitn.first_pos - 1);
+        geo.flags |= GMX_SITE_JUMP | (s.snp_kinds & GMX_SITE_WALK_FREE);
+        out.site_geo[i] = geo;
+      }
+    });
+  }
   build_trace("accumulator layout");
   // --- suffix array, BWT, rank blocks -----------------------------------------
   std::vector<uint32_t> text(prg);
@@ -1768,7 +1820,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 9;                   // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 10;                  // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;
@@ -1862,6 +1914,7 @@ void index_tables(IO &io, H &h) {  // one list of tables for both directions
   io.vec(h.nodes);
   io.vec(h.edges);
   io.vec(h.sites);
+  io.vec(h.site_geo);
   io.vec(h.seeds);
   io.vec(h.seeds2);
   io.vec(h.seed_words);

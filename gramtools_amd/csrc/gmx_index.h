@@ -164,6 +164,7 @@ struct HostIndex {
   std::vector<GmxNode> nodes;  // + 1 closing record
   std::vector<uint32_t> edges;
   std::vector<GmxSite> sites;
+  std::vector<GmxSiteGeo> site_geo;  // per site; flags = 0 where the site has no geometry (gmx_types.h)
   SeedTable seeds;              // direct-addressed by the k-mer's table index (gmx_types.h GmxSeed)
   uint32_t kmer_size2 = 0;      // longer seed table (0 = none): the same construction continued to k2 > kmer_size
   SeedTable seeds2;             // its 4^k2 entries; multi-state records share seed_words

@@ -57,6 +57,7 @@ struct GmxSite {
   uint32_t exit_node;       // bubble end node
   uint32_t snp_kinds;       // bit 31: every allele is one base long or empty (below); bits 2a, 2a+1: GMX_ALLELE_* of allele a
 };
+
 #define GMX_GROUPED_LOG 0xFFFFFFFFu
 // ONE accumulator block holds all three coverage structures, laid out per site so that what a read touches at a
 // site sits in one cache line and the two counters every single-allele locus increments together are one 64-bit word:
@@ -77,6 +78,48 @@ GMX_HD bool gmx_node_has_hit_counter(const GmxNode &n) { return n.cov_off != GMX
 #define GMX_ALLELE_HIT 1u    // one base, hit counter
 #define GMX_ALLELE_EMPTY 2u  // no base: allele-sum and group {allele} only
 #define GMX_SITE_WALK_FREE 0x80000000u
+// Geometry of a flat site of up to 8 single-node alleles of up to 254 bases (GMX_SITE_JUMP): all that recording a read
+// through the site needs, in ONE 32-byte sector of a table of its own — no walk of the coverage graph node by node, no
+// look at GmxSite (gmx_cover_single). Sites without it (nested PRGs, more than 8 alleles, longer alleles) have flags = 0.
+struct alignas(32) GmxSiteGeo {
+  uint32_t flags;           // bits 0..15: GMX_ALLELE_* of allele a in bits 2a, 2a+1 (LONG: per-base counters); 16..19: alleles;
+                            // 30: GMX_SITE_JUMP; 31: GMX_SITE_WALK_FREE (as GmxSite::snp_kinds)
+  uint32_t allele_sum_off;  // GmxSite::allele_sum_off
+  uint32_t entry_pos;       // PRG position of the site's entry marker; allele a starts at entry_pos + 1 + sum (len_b + 1), b < a
+  uint32_t tail_len;        // base symbols between the site's end marker and the next marker (or the PRG's end)
+  uint64_t allele_lens;     // bases of allele a in bits 8a .. 8a+7
+  uint32_t reserved[2];
+};
+static_assert(sizeof(GmxSiteGeo) == 32, "one sector per site");
+#define GMX_SITE_JUMP 0x40000000u
+GMX_HD uint32_t gmx_geo_alleles(const GmxSiteGeo &g) { return (g.flags >> 16) & 15u; }
+GMX_HD uint32_t gmx_geo_allele_len(const GmxSiteGeo &g, uint32_t allele) { return (uint32_t)(g.allele_lens >> (8u * allele)) & 0xFFu; }
+GMX_HD uint32_t gmx_geo_exit_pos(const GmxSiteGeo &g) {  // PRG position of the end marker: lengths + separators
+  const uint64_t m = 0x00FF00FF00FF00FFull;
+  const uint64_t pairs = (g.allele_lens & m) + ((g.allele_lens >> 8) & m);
+  return g.entry_pos + gmx_geo_alleles(g) + (uint32_t)((pairs * 0x0001000100010001ull) >> 48);
+}
+// cov_off of allele a's node by the accumulator block's layout rule (above; HostIndex verifies it against the nodes when it
+// sets GMX_SITE_JUMP): the pairs, the groups of 2+ alleles, then the alleles' per-base counters in allele order — a one-base
+// allele on an odd slot with its hit counter behind it, a longer one on an even slot. 0 bases: no counters.
+GMX_HD uint32_t gmx_geo_cov_off(const GmxSiteGeo &g, uint32_t allele) {
+  const uint32_t A = gmx_geo_alleles(g);
+  uint32_t at = g.allele_sum_off + 2u * A + ((1u << A) - 1u - A), cov = 0;
+  uint64_t lens = g.allele_lens;
+  for (uint32_t b = 0; b <= allele; ++b, lens >>= 8) {
+    const uint32_t len = (uint32_t)lens & 0xFFu;
+    if (len == 1u) {
+      at |= 1u;
+      cov = at;
+      at += 2u;
+    } else if (len != 0u) {
+      at += at & 1u;
+      cov = at;
+      at += len;
+    }
+  }
+  return cov;
+}
 GMX_HD uint32_t gmx_slot_hit(const GmxSite &s, uint32_t allele) {  // walk-free sites, GMX_ALLELE_HIT alleles
   const uint32_t A = s.n_alleles;
   const uint32_t first = (s.allele_sum_off + 2u * A + ((1u << A) - 1u - A)) | 1u;
@@ -194,6 +237,7 @@ struct GmxIndexView {
   const GmxNode *nodes;       // [n_nodes + 1] (sentinel record closes the last edge range)
   const uint32_t *edges;
   const GmxSite *sites;       // [n_sites]
+  const GmxSiteGeo *site_geo;  // [n_sites] (flags = 0: no geometry)
   const GmxSeed *seeds;       // [4^k]
   const GmxSeed *seeds2;      // [4^k2] or null
   const uint32_t *seed_words;

@@ -63,7 +63,8 @@ typedef struct gmx_index_info {
                                 text record; gmx_types.h) */
   uint32_t seed_shift;       /* multi-state k-mer index entries start on units of 2^seed_shift words (0 below 2^30 words;
                                 whole-genome PRGs need more: build/kmer_index/build.cpp:101-131 has no such limit) */
-  uint32_t reserved0;
+  uint32_t n_jump_sites;     /* sites whose coverage is recorded from the site record alone (flat sites of up to 8 single-node
+                                alleles of up to 254 bases; gmx_types.h GMX_SITE_JUMP) */
   uint64_t n_seed_words;     /* words of the multi-state entries (SearchStates with variant paths, several per k-mer) */
 } gmx_index_info;
 int gmx_index_get_info(const gmx_index *ix, gmx_index_info *out);

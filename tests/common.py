@@ -77,6 +77,7 @@ def _load_emu():
     lib.hostemu_map.restype = C.c_int
     lib.hostemu_map.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.hostemu_routes.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     lib.hostemu_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hostemu_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                   C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -107,6 +108,9 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
                              big_arena)
         if stats is not None:
             stats["n_wide"] = int(lib.hostemu_n_wide(h))
+            routes = np.zeros(3, dtype=np.uint64)  # single-instance tasks by routine: walk-free, jump, walk (process-wide: reset here)
+            lib.hostemu_routes(routes.ctypes.data_as(C.POINTER(C.c_uint64)), 1)
+            stats["routes"] = [int(x) for x in routes]
         sizes = np.zeros(7, dtype=np.uint64)
         lib.hostemu_sizes(h, sizes.ctypes.data_as(C.POINTER(C.c_uint64)))
         a = np.zeros(max(int(sizes[0]), 1), dtype=np.uint32)

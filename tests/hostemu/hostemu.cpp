@@ -10,6 +10,9 @@
 #include <string>
 #include <vector>
 
+// which routine recorded a single-instance task on a flat PRG (gmx_cover_single): 0 walk-free, 1 jump, 2 the walk
+static uint64_t g_cover_routes[3];
+#define GMX_COVER_ROUTE(k) (++g_cover_routes[k])
 #include "../../gramtools_amd/csrc/gmx_core.h"
 #include "../../gramtools_amd/csrc/gmx_cover.h"
 #include "../../gramtools_amd/csrc/gmx_dfs.h"
@@ -349,6 +352,12 @@ void hostemu_destroy(void *p) { delete (Emu *)p; }
 
 // Same two-tier flow as launch_batch(): fast pass (4 states / 24 arena nodes), large-capacity pass, cover, stats.
 void hostemu_set_wide(void *p, int on) { static_cast<Emu *>(p)->wide = on; }
+void hostemu_routes(uint64_t *out, int reset) {
+  for (int i = 0; i < 3; ++i) {
+    out[i] = g_cover_routes[i];
+    if (reset) g_cover_routes[i] = 0;
+  }
+}
 uint64_t hostemu_n_wide(void *p) { return static_cast<Emu *>(p)->n_wide; }
 void hostemu_set_single_loci(void *p, uint32_t n) { static_cast<Emu *>(p)->single_loci = n < GMX_SINGLE_LOCI ? n : GMX_SINGLE_LOCI; }
 
