@@ -530,6 +530,143 @@ GMX_HD bool gmx_record_locus(const GmxIndexView &ix, Env &env, uint32_t site, in
   }
   return true;
 }
+// ---------------------------------------------------------------------------
+// Recording a single-instance read on a flat PRG WITHOUT the walk, from the sites' geometry (GmxSiteGeo, gmx_types.h):
+// every site of the path has a 32-byte record that says where it lies in the PRG, how long its alleles are and where
+// their counters are, so the walk's bookkeeping — bases left, first and last base covered in each allele — is position
+// arithmetic on ONE sector per site instead of ~5 dependent node / edge records per site crossed, and GmxSite is not
+// looked at. The records of up to four loci are fetched side by side (the walk is one chain of dependent loads: a wave
+// of these tasks waits for memory four fifths of its time).
+// Nothing is recorded before the whole path has been checked. What the arithmetic cannot vouch for (a site without
+// geometry, a gap that is not the stretch between two neighbouring sites, a read that ends early or runs on into another
+// site) returns false with nothing recorded, and the caller takes the routine that decides as the reference does. The
+// check pass leaves the increments it found as a short list of operations in `stage` (the kernel: LDS); a path with more
+// of them than the stage holds is gone through a second time.
+// ---------------------------------------------------------------------------
+struct GmxStageNone {
+  GMX_HD uint32_t cap() const { return 0u; }
+  GMX_HD void put(uint32_t, uint32_t) {}
+  GMX_HD uint32_t get(uint32_t) const { return 0u; }
+};
+struct GmxStageTest {
+  uint32_t w[16], n;
+  GMX_HD uint32_t cap() const { return n; }
+  GMX_HD void put(uint32_t i, uint32_t v) { w[i] = v; }
+  GMX_HD uint32_t get(uint32_t i) const { return w[i]; }
+};
+#define GMX_STAGE_MAX 16u  // operations a stage may hold (two bits of kind each in one register)
+template <class Env, class Stage>
+GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, const GmxNode &rec0,
+                           uint32_t read_len) {
+  const uint32_t cap = stage.cap() < GMX_STAGE_MAX ? stage.cap() : GMX_STAGE_MAX;
+  uint32_t n_ops = 0, kinds = 0;  // staged operations: 0 hit counter, 1 allele-sum + group pair, 2 per-base range (slot), 3 its length
+  auto pass = [&](const bool direct) -> bool {
+    auto op = [&](uint32_t kind, uint32_t word) {
+      if (n_ops < cap) {
+        stage.put(n_ops, word);
+        kinds |= kind << (2u * n_ops);
+      }
+      ++n_ops;
+    };
+    auto hit = [&](uint32_t slot) {
+      if (direct) env.add_hit(slot);
+      else op(0u, slot);
+    };
+    auto pair = [&](uint32_t slot) {
+      if (direct) env.add_allele_and_group(slot);
+      else op(1u, slot);
+    };
+    auto range = [&](uint32_t slot, uint32_t n) {
+      if (direct) {
+        for (uint32_t i = 0; i < n; ++i) env.add_per_base(slot + i);
+      } else {
+        op(2u, slot);
+        op(3u, n);
+      }
+    };
+    uint32_t remaining = read_len, cur = p, tail = 0xFFFFFFFFu;
+    if (remaining == 0) return false;
+    if (tvg != GMX_NIL || tvd == GMX_NIL) {  // the read starts inside an allele: of the traversing site, or of the one it never leaves
+      if (!gmx_in_bubble(rec0) || rec0.seq_len == 0 || rec0.cov_off == GMX_NO_COV || p < rec0.first_pos || p - rec0.first_pos >= rec0.seq_len)
+        return false;
+      if (tvg != GMX_NIL && rec0.site != env.h_site(tvg)) return false;
+      const GmxSiteGeo g0 = ix.site_geo[(rec0.site - 5) >> 1];
+      if (!(g0.flags & GMX_SITE_JUMP) || (uint32_t)rec0.allele >= gmx_geo_alleles(g0)) return false;
+      const uint32_t start = p - rec0.first_pos;
+      const uint32_t n = remaining < rec0.seq_len - start ? remaining : rec0.seq_len - start;
+      remaining -= n;
+      if (gmx_node_has_hit_counter(rec0)) {
+        hit(rec0.cov_off + 1);
+      } else {
+        range(rec0.cov_off + start, n);
+        pair(g0.allele_sum_off + 2u * (uint32_t)rec0.allele);
+      }
+      if (tvg == GMX_NIL) return remaining == 0;  // (no path at all: the whole read inside the allele)
+      cur = gmx_geo_exit_pos(g0) + 1u;
+      tail = g0.tail_len;
+    }
+    auto locus = [&](const GmxSiteGeo &g, const uint32_t allele) -> bool {
+      if (!(g.flags & GMX_SITE_JUMP) || allele >= gmx_geo_alleles(g) || g.entry_pos < cur) return false;
+      const uint32_t gap = g.entry_pos - cur;  // base symbols in front of the site
+      if (remaining <= gap || (tail != 0xFFFFFFFFu && gap != tail)) return false;
+      remaining -= gap;
+      const uint32_t kind = (g.flags >> (2u * allele)) & 3u;
+      if (kind == GMX_ALLELE_HIT) {
+        remaining -= 1u;
+        hit(gmx_geo_cov_off(g, allele) + 1);
+      } else {
+        if (kind == GMX_ALLELE_LONG) {
+          const uint32_t len = gmx_geo_allele_len(g, allele);
+          const uint32_t n = remaining < len ? remaining : len;
+          remaining -= n;
+          range(gmx_geo_cov_off(g, allele), n);
+        }
+        pair(g.allele_sum_off + 2u * allele);
+      }
+      cur = gmx_geo_exit_pos(g) + 1u;
+      tail = g.tail_len;
+      return true;
+    };
+    for (uint32_t x = tvd; x != GMX_NIL;) {  // four loci at a time: their records are independent loads
+      uint32_t hx[4];
+      uint32_t m = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j) {
+        hx[j] = x;
+        if (x != GMX_NIL) {
+          ++m;
+          x = env.h_next(x);
+        }
+      }
+      GmxSiteGeo g[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (j < m) g[j] = ix.site_geo[(env.h_site(hx[j]) - 5) >> 1];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; ++j)
+        if (j < m && !locus(g[j], (uint32_t)env.h_allele(hx[j]))) return false;
+    }
+    return tail != 0xFFFFFFFFu && remaining <= tail;  // (the rest of the read lies in the stretch behind the last site)
+  };
+  if (!pass(false)) return false;
+  if (n_ops > cap) {  // more than the stage holds: once more, recording
+    pass(true);
+    return true;
+  }
+  for (uint32_t i = 0; i < n_ops; ++i) {
+    const uint32_t kind = (kinds >> (2u * i)) & 3u, w = stage.get(i);
+    if (kind == 0u) {
+      env.add_hit(w);
+    } else if (kind == 1u) {
+      env.add_allele_and_group(w);
+    } else {
+      const uint32_t n = stage.get(++i);
+      for (uint32_t k = 0; k < n; ++k) env.add_per_base(w + k);
+    }
+  }
+  return true;
+}
+
 template <class Env>
 GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalState &st, uint32_t read_len) {
   const uint32_t tvd = st.traversed, tvg = st.traversing;
@@ -570,68 +707,15 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       if (ix.sites[(env.h_site(x) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
     if (words && !env.log_reserve(words)) return;
   }
-  // Without the walk, from the sites' geometry (GmxSiteGeo, gmx_types.h): every site of the path is a flat site whose
-  // 32-byte geometry record says where it lies in the PRG, how long its alleles are and where their counters are, so the
-  // walk's bookkeeping — bases left, first and last base covered in each allele — is position arithmetic on ONE sector per
-  // site instead of ~5 dependent node / edge records per site crossed, and GmxSite is not looked at. First a dry pass:
-  // whatever the arithmetic cannot vouch for (a site without geometry, a gap that is not the stretch between two
-  // neighbouring sites, a read that ends early or runs on into another site) leaves the task to the code below, which
-  // decides as the reference does.
-  if (enc_site == 0 && ix.site_geo) {
-    auto jump = [&](const bool record) -> bool {
-      uint32_t remaining = read_len, cur = p, tail = 0xFFFFFFFFu;
-      if (remaining == 0) return false;
-      if (tvg != GMX_NIL) {  // the read starts inside an allele of the traversing site
-        const uint32_t site0 = env.h_site(tvg);
-        const GmxSiteGeo g0 = ix.site_geo[(site0 - 5) >> 1];
-        if (!(g0.flags & GMX_SITE_JUMP) || !gmx_in_bubble(rec0) || rec0.site != site0 || rec0.seq_len == 0 ||
-            (uint32_t)rec0.allele >= gmx_geo_alleles(g0) || rec0.cov_off == GMX_NO_COV || p < rec0.first_pos || p - rec0.first_pos >= rec0.seq_len)
-          return false;
-        const uint32_t start = p - rec0.first_pos;
-        const uint32_t end = start + remaining - 1u < rec0.seq_len - 1u ? start + remaining - 1u : rec0.seq_len - 1u;
-        remaining -= end - start + 1u;
-        if (record) {
-          if (gmx_node_has_hit_counter(rec0)) {
-            env.add_hit(rec0.cov_off + 1);
-          } else {
-            for (uint32_t i = start; i <= end; ++i) env.add_per_base(rec0.cov_off + i);
-            env.add_allele_and_group(g0.allele_sum_off + 2u * (uint32_t)rec0.allele);
-          }
-        }
-        cur = gmx_geo_exit_pos(g0) + 1u;
-        tail = g0.tail_len;
-      }
-      for (uint32_t x = tvd; x != GMX_NIL; x = env.h_next(x)) {
-        const GmxSiteGeo g = ix.site_geo[(env.h_site(x) - 5) >> 1];
-        const uint32_t allele = (uint32_t)env.h_allele(x);
-        if (!(g.flags & GMX_SITE_JUMP) || allele >= gmx_geo_alleles(g) || g.entry_pos < cur) return false;
-        const uint32_t gap = g.entry_pos - cur;  // base symbols in front of the site
-        if (remaining <= gap || (tail != 0xFFFFFFFFu && gap != tail)) return false;
-        remaining -= gap;
-        const uint32_t kind = (g.flags >> (2u * allele)) & 3u;
-        if (kind == GMX_ALLELE_HIT) {
-          remaining -= 1u;
-          if (record) env.add_hit(gmx_geo_cov_off(g, allele) + 1);
-        } else {
-          if (kind == GMX_ALLELE_LONG) {
-            const uint32_t len = gmx_geo_allele_len(g, allele);
-            const uint32_t n = remaining < len ? remaining : len;
-            remaining -= n;
-            if (record) {
-              const uint32_t cov = gmx_geo_cov_off(g, allele);
-              for (uint32_t i = 0; i < n; ++i) env.add_per_base(cov + i);
-            }
-          }
-          if (record) env.add_allele_and_group(g.allele_sum_off + 2u * allele);
-        }
-        cur = gmx_geo_exit_pos(g) + 1u;
-        tail = g.tail_len;
-      }
-      return tail != 0xFFFFFFFFu && remaining <= tail;  // (the rest of the read lies in the stretch behind the last site)
-    };
-    if (jump(false)) {
+  {
+#ifdef GMX_COVER_TEST_STAGE  // test build (tests/hostemu): the staged form, with the capacity the test asks for
+    GmxStageTest none;
+    none.n = GMX_COVER_TEST_STAGE;
+#else
+    GmxStageNone none;
+#endif
+    if (ix.site_geo && gmx_cover_jump(ix, env, none, p, tvd, tvg, rec0, read_len)) {
       GMX_COVER_ROUTE(1);
-      jump(true);
       return;
     }
   }

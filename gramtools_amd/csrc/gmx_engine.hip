@@ -58,6 +58,7 @@
 #define GMX_CNT_GENERAL_REST 34u    // entries gmx_cover_one_kernel left to the general instances (general_rest_list)
 #define GMX_CNT_ALIVE2 35u          // stragglers of the extend kernel, parked for its next pass: [35 + pass], pass 0 .. GMX_EXTRA_PASSES - 1
 #define GMX_EXTRA_PASSES 3          // (counters 35, 36, 37; task lists GMX_TL_ALIVE2 ..)
+#define GMX_CNT_SINGLE_REST 38u     // compact records gmx_cover_jump_kernel left to gmx_cover_single_rest_kernel (single_rest_list)
 #define GMX_CNT_REPLAY_RECS 32u     // replay: number of compact records to redo (gmx_cover_single_replay_kernel)
 #ifndef GMX_FAST_ARENA
 #define GMX_FAST_ARENA 48     // path arena nodes per task (fast pass): a read through an MSA region of configs[2] needs 25-40
@@ -1009,6 +1010,7 @@ struct SearchOut {
   uint32_t *log_retry_recs;            // compact records, as index into cover_recs; counter [31]
   uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
   uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
+  uint32_t *single_rest_list;          // compact records (index into cover_recs) gmx_cover_jump_kernel declined; counter [38]
   // Stragglers: the extend kernel's wave loop has an iteration budget; a lane with work left then (a read inside an MSA
   // region takes fifty iterations, its 63 neighbours five) parks its pending entries and goes to a second, compacted pass.
   GmxParked *park2;                    // per task: up to GMX_STACK_DEPTH pending entries (its final states stay in finals[])
@@ -2550,7 +2552,10 @@ struct OneEnv : CoverLogPart {
 __global__ void __launch_bounds__(GMX_ONE_THREADS) gmx_cover_one_kernel(GmxIndexView ix, BatchView b, SearchOut o, BigOut g, CoverAcc acc,
                                                                         uint32_t enabled) {
   const uint32_t n = o.counters[8 * GMX_CNT_STRIDE];
-  for (uint32_t m = blockIdx.x * GMX_ONE_THREADS + threadIdx.x; m < n; m += gridDim.x * GMX_ONE_THREADS) {
+  // (entry m = lane * blocks + block: a short queue — a few thousand entries among a million reads on a flat PRG — is spread
+  //  over all workgroups, a handful of lanes each, instead of filling the first few waves with 64 divergent dependent-load
+  //  chains apiece: the kernel's duration is that of its slowest wave)
+  for (uint32_t m = threadIdx.x * gridDim.x + blockIdx.x; m < n; m += gridDim.x * GMX_ONE_THREADS) {
     const uint32_t entry = o.cover_general_list[m];
     const GmxTaskStates ts = gmx_entry_states(entry, o, g);
     bool taken = false;
@@ -2567,7 +2572,18 @@ __global__ void __launch_bounds__(GMX_ONE_THREADS) gmx_cover_one_kernel(GmxIndex
         env.log_sites = acc.log_sites;
         env.status = GMX_TASK_MAPPED;
         env.log_at = 0;
-        taken = gmx_cover_single_nested_wide(ix, env, st, read_len(b, ts.task >> 1));
+        const uint32_t len = read_len(b, ts.task >> 1);
+        if (!ix.is_nested && ix.site_geo) {  // flat PRG: from the sites' geometry records where they vouch for the path (gmx_cover_jump)
+          const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
+          GmxNode rec0{};
+          if (st.traversing != GMX_NIL || st.traversed == GMX_NIL) {
+            rec0 = ix.nodes[ix.pos_node[p]];
+            taken = st.traversing == GMX_NIL && rec0.site == 0;  // a non-variant instance only: nothing to record
+          }
+          GmxStageNone none;
+          if (!taken) taken = gmx_cover_jump(ix, env, none, p, st.traversed, st.traversing, rec0, len);
+        }
+        if (!taken) taken = gmx_cover_single_nested_wide(ix, env, st, len);
         if (env.status == GMX_TASK_LOGFULL) {
           o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = entry;
         } else if (env.status != GMX_TASK_MAPPED && atomicCAS(&o.error[0], 0u, env.status) == 0u) {
@@ -2841,19 +2857,26 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
 
 // Path handles of a GmxCoverRec: traversed loci are addressed by their index in the record (newest first), the
 // traversing path is an inline handle (gmx_types.h) or nil.
+struct CompactRec {  // a GmxCoverRec in scalars (with the array member the compiler kept the record in scratch memory and indexed it)
+  uint32_t p, len_n, tvg, s0, s1, s2, a01, a2;
+  __device__ __forceinline__ CompactRec &operator=(const GmxCoverRec &r) {
+    p = r.p, len_n = r.len_n, tvg = r.tvg, s0 = r.site[0], s1 = r.site[1], s2 = r.site[2], a01 = r.a01, a2 = r.a2;
+    return *this;
+  }
+};
 struct CompactEnv : CoverLogPart {
-  GmxCoverRec rec;
+  CompactRec rec;
   __device__ __forceinline__ uint32_t n_trav() const { return (rec.len_n >> 16) & 31u; }
   __device__ __forceinline__ bool run_form() const { return (rec.len_n & GMX_REC_RUN_FLAG) != 0; }
   __device__ __forceinline__ uint32_t h_site(uint32_t h) const {
     if (h & GMX_INLINE_FLAG) return 5u + 2u * (h & ~GMX_INLINE_FLAG);
-    if (run_form()) return rec.site[0] + 2u * h;
-    return h == 0 ? rec.site[0] : (h == 1 ? rec.site[1] : rec.site[2]);
+    if (run_form()) return rec.s0 + 2u * h;
+    return h == 0 ? rec.s0 : (h == 1 ? rec.s1 : rec.s2);
   }
   __device__ __forceinline__ int32_t h_allele(uint32_t h) const {
     if (h & GMX_INLINE_FLAG) return -1;
     if (run_form()) {
-      const uint32_t q = h >> 2, w = q == 0 ? rec.site[1] : q == 1 ? rec.site[2] : q == 2 ? rec.a01 : rec.a2;
+      const uint32_t q = h >> 2, w = q == 0 ? rec.s1 : q == 1 ? rec.s2 : q == 2 ? rec.a01 : rec.a2;
       return (int32_t)((w >> (8u * (h & 3u))) & 0xFFu);
     }
     return (int32_t)(h == 0 ? (rec.a01 & 0xFFFFu) : (h == 1 ? (rec.a01 >> 16) : rec.a2));
@@ -2899,6 +2922,50 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
   const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
   if (m >= n_mapped) return;
   gmx_cover_single_rec<NESTED>(ix, o, acc, (size_t)region * o.region_cap + m, o.cover_general_list, 8u);
+}
+
+// The same queue on a flat PRG whose sites have geometry records (GmxSiteGeo): gmx_cover_jump alone — no walk, no GmxSite, the
+// increments staged in LDS between its check pass and the recording — and what it declines (a site of more than 8 alleles
+// or an allele of 255+ bases on the path) goes to gmx_cover_single_rest_kernel, the routine above over a list. Leaving the
+// walk out of this kernel is what keeps it at 8 waves per SIMD.
+struct StageLds {
+  uint32_t *w;  // this lane's words, GMX_BLOCK apart
+  __device__ __forceinline__ uint32_t cap() const { return GMX_STAGE_MAX; }
+  __device__ __forceinline__ void put(uint32_t i, uint32_t v) { w[i * GMX_BLOCK] = v; }
+  __device__ __forceinline__ uint32_t get(uint32_t i) const { return w[i * GMX_BLOCK]; }
+};
+__global__ void __launch_bounds__(GMX_BLOCK, 2) gmx_cover_jump_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
+  const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);
+  const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
+  const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
+  if (m >= n_mapped) return;
+  const size_t rec_idx = (size_t)region * o.region_cap + m;
+  CompactEnv env;
+  env.rec = o.cover_recs[rec_idx];
+  env.acc = acc.acc;
+  env.log = nullptr;
+  env.log_cursor = nullptr;
+  env.log_cap = 0;
+  env.log_sites = 0;
+  env.status = GMX_TASK_MAPPED;
+  env.log_at = env.log_end = 0;
+  const uint32_t p = env.rec.p, tvd = env.n_trav() ? 0u : GMX_NIL, tvg = env.rec.tvg;
+  GmxNode rec0{};
+  bool done = false;
+  if (tvg != GMX_NIL || tvd == GMX_NIL) {  // the first node matters: the read starts inside an allele
+    rec0 = ix.nodes[ix.pos_node[p]];
+    done = tvg == GMX_NIL && rec0.site == 0;  // a non-variant instance only: nothing to record
+  }
+  if (!done) {
+    StageLds stage{gmx_lds + threadIdx.x};
+    done = gmx_cover_jump(ix, env, stage, p, tvd, tvg, rec0, env.rec.len_n & 0xFFFFu);
+  }
+  if (!done) o.single_rest_list[atomicAdd(&o.counters[GMX_CNT_SINGLE_REST * GMX_CNT_STRIDE], 1u)] = (uint32_t)rec_idx;
+}
+__global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_rest_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
+  const uint32_t n = o.counters[GMX_CNT_SINGLE_REST * GMX_CNT_STRIDE];
+  for (uint32_t i = blockIdx.x * GMX_BLOCK + threadIdx.x; i < n; i += gridDim.x * GMX_BLOCK)
+    gmx_cover_single_rec<false>(ix, o, acc, o.single_rest_list[i], o.cover_general_list, 8u);
 }
 
 // ---- grouped log full: the batch's failed entries again, after the host has drained the log (launch_log_replay) ----
@@ -3098,6 +3165,8 @@ struct gmx_engine {
   uint64_t cap_packed = 0;
   uint32_t *d_status = nullptr, *d_n_final = nullptr, *d_mapped = nullptr, *d_overflow = nullptr, *d_counters = nullptr;
   uint32_t *d_general_rest = nullptr;
+  uint32_t *d_single_rest = nullptr;
+  bool cover_jump = false;  // gmx_cover_jump_kernel + gmx_cover_single_rest_kernel instead of gmx_cover_single_kernel<false>
   uint32_t *d_task_lists = nullptr;  // SearchOut::task_lists: d_overflow, d_overflow2, d_alive, d_dead, d_dead2, d_cover_general are its slices
   GmxSeed *d_alive_seed = nullptr;
   uint32_t *d_alive = nullptr, *d_dead = nullptr, *d_dead2 = nullptr;
@@ -3338,6 +3407,7 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   e->d_cover_general = e->d_task_lists + (size_t)GMX_TL_GENERAL * n_tasks;
   if ((rc = e->alloc(&e->d_cover_overflow, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_general_rest, n_tasks, false))) return rc;
+  if ((rc = e->alloc(&e->d_single_rest, n_tasks, false))) return rc;
   if ((rc = e->alloc(&e->d_park2, (size_t)n_tasks * GMX_STACK_DEPTH, false))) return rc;
   if ((rc = e->alloc(&e->d_park2_n, n_tasks, false))) return rc;
   if (e->log_sites)
@@ -3463,6 +3533,11 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // The grouped log is used only by sites with more alleles than get dense group counters (gmx_index.cpp: 8). Between
   // batches the engine looks at its real fill (log_settle): drained when half full; entries that found it full are redone.
   for (const GmxSite &st : h.sites) e->log_sites = e->log_sites || st.grouped_off == GMX_GROUPED_LOG;
+  {  // the lean single-instance coverage kernel where most sites have geometry records (GMX_NO_COVER_JUMP: A/B runs)
+    uint64_t n_jump = 0;
+    for (const GmxSiteGeo &g : h.site_geo) n_jump += (g.flags & GMX_SITE_JUMP) ? 1u : 0u;
+    e->cover_jump = !h.is_nested && 2 * n_jump > h.site_geo.size() && !getenv("GMX_NO_COVER_JUMP");
+  }
   {
     uint64_t cap = opts.log_cap_words ? opts.log_cap_words
                    : e->log_sites     ? (1ull << 26)  // 256 MB; a batch that fills it is settled by drain + replay (log_settle)
@@ -3852,6 +3927,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
   o.general_rest_list = e->d_general_rest;
+  o.single_rest_list = e->d_single_rest;
   o.park2 = e->d_park2;
   o.park2_n = e->d_park2_n;
   o.log_retry_list = e->d_log_retry[e->log_retry_side];
@@ -3972,10 +4048,18 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   // (Round 4 measured the records in PRG order — a radix sort of (position, record) pairs in front of this kernel, for the
   //  locality of the accumulator and table lines: at configs[3] the kernel took 508 us instead of 436 plus 120 us of sorting, at
   //  configs[4] 646 instead of 611: neighbouring lanes then hit the SAME accumulator words and their atomics serialise. Dropped.)
-  if (e->dview.is_nested)
+  if (e->dview.is_nested) {
     hipLaunchKernelGGL(gmx_cover_single_kernel<true>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
-  else
+  } else if (e->cover_jump) {  // most sites have geometry records: the lean kernel, then the few records it declined
+    // (Measured and dropped: this kernel over the records queued by then BESIDE the extend kernel's passes over the stragglers,
+    //  those moved to side 1 — at configs[3] the passes then took 335 us instead of 165 and the batch 1.13 ms instead of 1.07:
+    //  the two kernels wait for the same thing, the memory system's rate of scattered accesses.)
+    hipLaunchKernelGGL(gmx_cover_jump_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), GMX_STAGE_MAX * GMX_BLOCK * sizeof(uint32_t), stream, e->dview,
+                       b, o, acc);
+    hipLaunchKernelGGL(gmx_cover_single_rest_kernel, dim3(e->n_cus * 2), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  } else {
     hipLaunchKernelGGL(gmx_cover_single_kernel<false>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+  }
   // The batch's last coverage instance (1: what exceeded the regular scratch; its last block also serves the last tier,
   // whose search keeps its first pending entries in LDS) needs every other instance done except gmx_cover_single_kernel,
   // which queues nothing on a non-nested PRG: there it runs at the end of side 2, beside that kernel.

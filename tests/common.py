@@ -77,6 +77,7 @@ def _load_emu():
     lib.hostemu_map.restype = C.c_int
     lib.hostemu_map.argtypes = [C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint64,
                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.hostemu_set_stage.argtypes = [C.c_uint32]
     lib.hostemu_routes.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     lib.hostemu_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     lib.hostemu_fetch.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
@@ -86,7 +87,7 @@ def _load_emu():
 
 
 def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, big_states=1024, big_arena=2048,
-                return_raw=False, single_loci=None, wide=False, stats=None):
+                return_raw=False, single_loci=None, wide=False, stats=None, stage=0):
     """Runs the device headers on the host. Returns (canonical coverage, n_overflow_tasks, rc)."""
     lib = _load_emu()
     arr = np.ascontiguousarray(prg, dtype=np.uint32)
@@ -101,6 +102,7 @@ def hostemu_map(prg, k, reads, seeds, rng_mode=0, fast_states=8, fast_arena=24, 
         s = np.ascontiguousarray(seeds, dtype=np.uint32)
         if single_loci is not None:  # loci capacity of the nested single-instance routine (gmx_cover.h)
             lib.hostemu_set_single_loci(h, single_loci)
+        lib.hostemu_set_stage(stage)  # operations gmx_cover_jump stages between its check pass and the recording (gmx_cover.h)
         if wide:  # single-instance tasks through gmx_cover_single_nested_wide (the routine of gmx_cover_one_kernel)
             lib.hostemu_set_wide(h, 1)
         rc = lib.hostemu_map(h, flat.ctypes.data_as(C.POINTER(C.c_uint8)), offs.ctypes.data_as(C.POINTER(C.c_uint64)),

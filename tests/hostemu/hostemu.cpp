@@ -13,6 +13,8 @@
 // which routine recorded a single-instance task on a flat PRG (gmx_cover_single): 0 walk-free, 1 jump, 2 the walk
 static uint64_t g_cover_routes[3];
 #define GMX_COVER_ROUTE(k) (++g_cover_routes[k])
+static uint32_t g_stage_cap = 0;  // hostemu_set_stage: operations gmx_cover_jump may stage (0: it records in a second pass)
+#define GMX_COVER_TEST_STAGE g_stage_cap
 #include "../../gramtools_amd/csrc/gmx_core.h"
 #include "../../gramtools_amd/csrc/gmx_cover.h"
 #include "../../gramtools_amd/csrc/gmx_dfs.h"
@@ -358,6 +360,7 @@ void hostemu_routes(uint64_t *out, int reset) {
     if (reset) g_cover_routes[i] = 0;
   }
 }
+void hostemu_set_stage(uint32_t cap) { g_stage_cap = cap; }
 uint64_t hostemu_n_wide(void *p) { return static_cast<Emu *>(p)->n_wide; }
 void hostemu_set_single_loci(void *p, uint32_t n) { static_cast<Emu *>(p)->single_loci = n < GMX_SINGLE_LOCI ? n : GMX_SINGLE_LOCI; }
 

@@ -40,6 +40,9 @@ def test_host_emulation_takes_the_jump_and_matches_oracle(seed, monkeypatch):
     assert rc == 0 and got == want
     walk_free, jump, walk = stats["routes"]
     assert walk_free == 0 and jump > 200 and jump > 4 * walk, stats  # the walk is left with the reads through wide sites
+    for stage in (16, 5):  # the increments staged between the check pass and the recording; 5: longer paths go through twice
+        got_s, _, rc = hostemu_map(prg, 7, reads, seeds, stats=stats, stage=stage)
+        assert rc == 0 and got_s == want and stats["routes"][1] == jump
     monkeypatch.setenv("GMX_NO_SITE_JUMP", "1")
     got2, _, rc = hostemu_map(prg, 7, reads, seeds, stats=stats)
     assert rc == 0 and got2 == want and stats["routes"][1] == 0 and stats["routes"][0] + stats["routes"][2] >= jump
@@ -91,9 +94,10 @@ def test_reads_ending_at_site_borders():
     want = oracle_map(prg, 3, reads, seeds, threads=4)
     stats = {}
     hostemu_map(prg, 3, reads[:1], seeds[:1], stats=stats)
-    got, _, rc = hostemu_map(prg, 3, reads, seeds, stats=stats)
-    assert rc == 0 and got == want
-    assert stats["routes"][1] > 1000, stats
+    for stage in (0, 16, 3):
+        got, _, rc = hostemu_map(prg, 3, reads, seeds, stats=stats, stage=stage)
+        assert rc == 0 and got == want
+        assert stats["routes"][1] > 1000, stats
 
 
 @pytest.mark.gpu
