@@ -554,10 +554,19 @@ struct GmxStageTest {
   GMX_HD void put(uint32_t i, uint32_t v) { w[i] = v; }
   GMX_HD uint32_t get(uint32_t i) const { return w[i]; }
 };
+#ifndef GMX_JUMP_BATCH
+#define GMX_JUMP_BATCH 4u  // geometry records fetched side by side
+#endif
 #define GMX_STAGE_MAX 16u  // operations a stage may hold (two bits of kind each in one register)
 template <class Env, class Stage>
-GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, const GmxNode &rec0,
+GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, const GmxNode *rec0_in,
                            uint32_t read_len) {
+  // the node of the read's first base, when it matters (the read starts inside an allele): the caller's copy, or fetched
+  // here BEHIND the first four geometry loads — pos_node -> node -> its site's geometry is a chain of three dependent loads
+  // that nearly every wave of 64 tasks has a lane for, and the loci's records need not wait for it
+  GmxNode rec0{};
+  bool have_rec0 = rec0_in != nullptr;
+  if (have_rec0) rec0 = *rec0_in;
   const uint32_t cap = stage.cap() < GMX_STAGE_MAX ? stage.cap() : GMX_STAGE_MAX;
   uint32_t n_ops = 0, kinds = 0;  // staged operations: 0 hit counter, 1 allele-sum + group pair, 2 per-base range (slot), 3 its length
   auto pass = [&](const bool direct) -> bool {
@@ -586,7 +595,29 @@ GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint3
     };
     uint32_t remaining = read_len, cur = p, tail = 0xFFFFFFFFu;
     if (remaining == 0) return false;
+    uint32_t x = tvd, m = 0, hx[GMX_JUMP_BATCH];
+    GmxSiteGeo g[GMX_JUMP_BATCH];
+    auto fetch = [&]() {  // the next GMX_JUMP_BATCH loci: their records are independent loads
+      m = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < GMX_JUMP_BATCH; ++j) {
+        hx[j] = x;
+        if (x != GMX_NIL) {
+          ++m;
+          x = env.h_next(x);
+        }
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < GMX_JUMP_BATCH; ++j)
+        if (j < m) g[j] = ix.site_geo[(env.h_site(hx[j]) - 5) >> 1];
+    };
+    fetch();
     if (tvg != GMX_NIL || tvd == GMX_NIL) {  // the read starts inside an allele: of the traversing site, or of the one it never leaves
+      if (!have_rec0) {
+        rec0 = ix.nodes[ix.pos_node[p]];
+        have_rec0 = true;
+      }
+      if (tvg == GMX_NIL && rec0.site == 0) return true;  // a non-variant instance only: nothing to record
       if (!gmx_in_bubble(rec0) || rec0.seq_len == 0 || rec0.cov_off == GMX_NO_COV || p < rec0.first_pos || p - rec0.first_pos >= rec0.seq_len)
         return false;
       if (tvg != GMX_NIL && rec0.site != env.h_site(tvg)) return false;
@@ -627,24 +658,11 @@ GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint3
       tail = g.tail_len;
       return true;
     };
-    for (uint32_t x = tvd; x != GMX_NIL;) {  // four loci at a time: their records are independent loads
-      uint32_t hx[4];
-      uint32_t m = 0;
+    while (m != 0) {
 #pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) {
-        hx[j] = x;
-        if (x != GMX_NIL) {
-          ++m;
-          x = env.h_next(x);
-        }
-      }
-      GmxSiteGeo g[4];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j)
-        if (j < m) g[j] = ix.site_geo[(env.h_site(hx[j]) - 5) >> 1];
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j)
+      for (uint32_t j = 0; j < GMX_JUMP_BATCH; ++j)
         if (j < m && !locus(g[j], (uint32_t)env.h_allele(hx[j]))) return false;
+      fetch();
     }
     return tail != 0xFFFFFFFFu && remaining <= tail;  // (the rest of the read lies in the stretch behind the last site)
   };
@@ -714,7 +732,7 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
 #else
     GmxStageNone none;
 #endif
-    if (ix.site_geo && gmx_cover_jump(ix, env, none, p, tvd, tvg, rec0, read_len)) {
+    if (ix.site_geo && gmx_cover_jump(ix, env, none, p, tvd, tvg, first_in_play ? &rec0 : nullptr, read_len)) {
       GMX_COVER_ROUTE(1);
       return;
     }

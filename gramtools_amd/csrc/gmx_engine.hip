@@ -1011,6 +1011,7 @@ struct SearchOut {
   uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
   uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
   uint32_t *single_rest_list;          // compact records (index into cover_recs) gmx_cover_jump_kernel declined; counter [38]
+  uint32_t general_rest_counter;       // counter of general_rest_list: GMX_CNT_GENERAL_REST, or 8 where gmx_cover_one_kernel is left out
   // Stragglers: the extend kernel's wave loop has an iteration budget; a lane with work left then (a read inside an MSA
   // region takes fifty iterations, its 63 neighbours five) parks its pending entries and goes to a second, compacted pass.
   GmxParked *park2;                    // per task: up to GMX_STACK_DEPTH pending entries (its final states stay in finals[])
@@ -2448,7 +2449,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
   // in counter [10], 2 starts there
   // (instances 3, 5 and 2 after the cooperative kernel: only what that one left, reject lists and counters [27], [26], [28])
-  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : GMX_CNT_GENERAL_REST)
+  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : o.general_rest_counter)
                                  : LIST == 0 ? 13
                                  : LIST == 1 ? 4
                                  : LIST == 5 ? (after_coop ? 26 : 25)
@@ -2573,16 +2574,6 @@ __global__ void __launch_bounds__(GMX_ONE_THREADS) gmx_cover_one_kernel(GmxIndex
         env.status = GMX_TASK_MAPPED;
         env.log_at = 0;
         const uint32_t len = read_len(b, ts.task >> 1);
-        if (!ix.is_nested && ix.site_geo) {  // flat PRG: from the sites' geometry records where they vouch for the path (gmx_cover_jump)
-          const uint32_t p = gmx_occ_pos(ix, st.hi, st.lo);
-          GmxNode rec0{};
-          if (st.traversing != GMX_NIL || st.traversed == GMX_NIL) {
-            rec0 = ix.nodes[ix.pos_node[p]];
-            taken = st.traversing == GMX_NIL && rec0.site == 0;  // a non-variant instance only: nothing to record
-          }
-          GmxStageNone none;
-          if (!taken) taken = gmx_cover_jump(ix, env, none, p, st.traversed, st.traversing, rec0, len);
-        }
         if (!taken) taken = gmx_cover_single_nested_wide(ix, env, st, len);
         if (env.status == GMX_TASK_LOGFULL) {
           o.log_retry_list[atomicAdd(&o.counters[GMX_CNT_LOG_RETRY * GMX_CNT_STRIDE], 1u)] = entry;
@@ -2639,7 +2630,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
   typedef typename CoopSizes<LIST>::Class CoopClassEnv;
   typedef GmxScratch<CoopItemEnv> SI;
   typedef GmxScratch<CoopClassEnv> SC;
-  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : GMX_CNT_GENERAL_REST) * GMX_CNT_STRIDE];
+  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : o.general_rest_counter) * GMX_CNT_STRIDE];
   const uint32_t n_first = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;  // instance 2 starts where instance 4 stopped
   const uint32_t *list = LIST == 5 ? o.inst_mapped_list : LIST == 2 ? o.big_mapped_list : o.general_rest_list;
   uint32_t *reject = LIST == 5 ? o.inst_serial_list : LIST == 2 ? o.big_serial_list : o.general_serial_list;
@@ -2934,7 +2925,10 @@ struct StageLds {
   __device__ __forceinline__ void put(uint32_t i, uint32_t v) { w[i * GMX_BLOCK] = v; }
   __device__ __forceinline__ uint32_t get(uint32_t i) const { return w[i * GMX_BLOCK]; }
 };
-__global__ void __launch_bounds__(GMX_BLOCK, 2) gmx_cover_jump_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
+#ifndef GMX_JUMP_MIN_BLOCKS
+#define GMX_JUMP_MIN_BLOCKS 1  // (8 = 64 registers, 8 waves per SIMD with spills: measured slower, and its LDS crowds out the side streams' kernels)
+#endif
+__global__ void __launch_bounds__(GMX_BLOCK, GMX_JUMP_MIN_BLOCKS) gmx_cover_jump_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
   const uint32_t region = blockIdx.x & (GMX_REGIONS - 1);
   const uint32_t n_mapped = o.counters[(16 + region) * GMX_CNT_STRIDE];
   const uint32_t m = (blockIdx.x / GMX_REGIONS) * GMX_BLOCK + threadIdx.x;
@@ -2950,16 +2944,8 @@ __global__ void __launch_bounds__(GMX_BLOCK, 2) gmx_cover_jump_kernel(GmxIndexVi
   env.status = GMX_TASK_MAPPED;
   env.log_at = env.log_end = 0;
   const uint32_t p = env.rec.p, tvd = env.n_trav() ? 0u : GMX_NIL, tvg = env.rec.tvg;
-  GmxNode rec0{};
-  bool done = false;
-  if (tvg != GMX_NIL || tvd == GMX_NIL) {  // the first node matters: the read starts inside an allele
-    rec0 = ix.nodes[ix.pos_node[p]];
-    done = tvg == GMX_NIL && rec0.site == 0;  // a non-variant instance only: nothing to record
-  }
-  if (!done) {
-    StageLds stage{gmx_lds + threadIdx.x};
-    done = gmx_cover_jump(ix, env, stage, p, tvd, tvg, rec0, env.rec.len_n & 0xFFFFu);
-  }
+  StageLds stage{gmx_lds + threadIdx.x};
+  const bool done = gmx_cover_jump(ix, env, stage, p, tvd, tvg, nullptr, env.rec.len_n & 0xFFFFu);
   if (!done) o.single_rest_list[atomicAdd(&o.counters[GMX_CNT_SINGLE_REST * GMX_CNT_STRIDE], 1u)] = (uint32_t)rec_idx;
 }
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_rest_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
@@ -3638,6 +3624,8 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       (void)hipGetLastError();  // (no room: the occurrences are screened through the suffix array and the text, as before)
     }
   }
+  // (stream priorities for the side streams — the few-task kernels first — were measured in round 4: no difference, the
+  //  chains there wait for memory, not for wave slots)
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;
@@ -3926,7 +3914,12 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.big_serial_list = e->d_big_serial;
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
-  o.general_rest_list = e->d_general_rest;
+  // (flat PRG with the lean single-instance kernel: the general instances take the queue as it is, without gmx_cover_one_kernel
+  //  in front — that kernel's ~100 us for a few thousand tasks made the side chain the batch's longest path once the
+  //  single-instance kernel beside it took 280 us instead of 490)
+  const bool skip_one = e->cover_jump && !getenv("GMX_KEEP_COVER_ONE");
+  o.general_rest_list = skip_one ? e->d_cover_general : e->d_general_rest;
+  o.general_rest_counter = skip_one ? 8u : GMX_CNT_GENERAL_REST;
   o.single_rest_list = e->d_single_rest;
   o.park2 = e->d_park2;
   o.park2_n = e->d_park2_n;
@@ -4039,7 +4032,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     hipLaunchKernelGGL(gmx_cover_one_kernel, dim3(e->n_cus * 4), dim3(GMX_ONE_THREADS), one_lds, st, e->dview, b, o, e->big, acc, one ? 1u : 0u);
   };
   if (general_on_side) {
-    launch_one(e->side_stream);
+    if (!skip_one) launch_one(e->side_stream);
     if (e->coop) launch_cover_coop<3>(e, e->side_stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);

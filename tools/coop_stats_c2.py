@@ -1,5 +1,5 @@
 """configs[2] (nested MSA regions): wave-level wall time of the cooperative coverage instances' phases and the serial
-instances' phases, from a -DGMX_LOOP_STATS build (GMX_LIB=.../libgmx_stats.so). Usage: python tools/coop_stats_c2.py [N_READS]"""
+instances' phases, from a -DGMX_LOOP_STATS build (GMX_LIB=.../libgmx_stats.so). Usage: python tools/coop_stats_c2.py [N_READS] [3]"""
 import ctypes as C
 import sys
 
@@ -7,11 +7,15 @@ import numpy as np
 
 sys.path.insert(0, ".")
 from gramtools_amd import Index, Quasimapper, _lib, master_seeds  # noqa: E402
-from gramtools_amd.synth import flat_offsets, pf3d7_recipe  # noqa: E402
+from gramtools_amd.synth import chr20_recipe, flat_offsets, pf3d7_recipe  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-prg, reads = pf3d7_recipe(23_300_000, 2000, 100_000, n, 22)
-ix = Index(prg, 10)
+if len(sys.argv) > 2 and sys.argv[2] == "3":  # configs[3] instead: flat, SNP / indel mix
+    prg, reads = chr20_recipe(64_444_167, 1_800_000, n, 32)
+    ix = Index(prg, 14)
+else:
+    prg, reads = pf3d7_recipe(23_300_000, 2000, 100_000, n, 22)
+    ix = Index(prg, 10)
 seeds = master_seeds(42, [n])
 offs = flat_offsets(n, reads.shape[1])
 qm = Quasimapper(ix)
