@@ -725,6 +725,11 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       if (ix.sites[(env.h_site(x) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
     if (words && !env.log_reserve(words)) return;
   }
+  // gmx_cover_jump first — in HOST builds only (tests/hostemu: that is how the routine is checked against the oracle on the
+  // CPU, staged and unstaged). On the device it runs in gmx_cover_jump_kernel alone: called from here, i.e. from the general
+  // coverage instances (paths of more than 16 loci, arena handles), a GPU run recorded nothing for the reads that start inside
+  // an allele — with printf in the routine it recorded them; not understood (round 4), so those instances keep the walk.
+#ifndef __HIP_DEVICE_COMPILE__
   {
 #ifdef GMX_COVER_TEST_STAGE  // test build (tests/hostemu): the staged form, with the capacity the test asks for
     GmxStageTest none;
@@ -737,6 +742,7 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       return;
     }
   }
+#endif
   // Without the walk: every traversed site is walk-free (gmx_types.h: a one-base allele is its hit counter, an empty
   // one its allele-sum/group pair) and the first node, if in play, has a hit counter. The site records are
   // independent loads; the walk below is a chain of dependent ones.

@@ -1011,7 +1011,6 @@ struct SearchOut {
   uint32_t *log_retry_huge;            // tasks of the last tier's search; counter [33]
   uint32_t *general_rest_list;         // entries of cover_general_list that gmx_cover_one_kernel left to the general instances; counter [34]
   uint32_t *single_rest_list;          // compact records (index into cover_recs) gmx_cover_jump_kernel declined; counter [38]
-  uint32_t general_rest_counter;       // counter of general_rest_list: GMX_CNT_GENERAL_REST, or 8 where gmx_cover_one_kernel is left out
   // Stragglers: the extend kernel's wave loop has an iteration budget; a lane with work left then (a read inside an MSA
   // region takes fifty iterations, its 63 neighbours five) parks its pending entries and goes to a second, compacted pass.
   GmxParked *park2;                    // per task: up to GMX_STACK_DEPTH pending entries (its final states stay in finals[])
@@ -2449,7 +2448,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_kernel(GmxIndexView ix, B
   // LIST 4 and 2 share the large-capacity pass's queue: 4 takes what its first instance mapped and leaves the length
   // in counter [10], 2 starts there
   // (instances 3, 5 and 2 after the cooperative kernel: only what that one left, reject lists and counters [27], [26], [28])
-  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : o.general_rest_counter)
+  uint32_t n_mapped = o.counters[(LIST == 3   ? (after_coop ? 27 : GMX_CNT_GENERAL_REST)
                                  : LIST == 0 ? 13
                                  : LIST == 1 ? 4
                                  : LIST == 5 ? (after_coop ? 26 : 25)
@@ -2630,7 +2629,7 @@ __global__ void __launch_bounds__(64) gmx_cover_coop_kernel(GmxIndexView ix, Bat
   typedef typename CoopSizes<LIST>::Class CoopClassEnv;
   typedef GmxScratch<CoopItemEnv> SI;
   typedef GmxScratch<CoopClassEnv> SC;
-  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : o.general_rest_counter) * GMX_CNT_STRIDE];
+  const uint32_t n = o.counters[(LIST == 5 ? 25 : LIST == 2 ? 7 : GMX_CNT_GENERAL_REST) * GMX_CNT_STRIDE];
   const uint32_t n_first = LIST == 2 ? o.counters[10 * GMX_CNT_STRIDE] : 0u;  // instance 2 starts where instance 4 stopped
   const uint32_t *list = LIST == 5 ? o.inst_mapped_list : LIST == 2 ? o.big_mapped_list : o.general_rest_list;
   uint32_t *reject = LIST == 5 ? o.inst_serial_list : LIST == 2 ? o.big_serial_list : o.general_serial_list;
@@ -3914,12 +3913,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.big_serial_list = e->d_big_serial;
   o.overflow3_list = e->d_overflow3;
   o.split_twice = getenv("GMX_NO_SPLIT2") ? 0u : 1u;
-  // (flat PRG with the lean single-instance kernel: the general instances take the queue as it is, without gmx_cover_one_kernel
-  //  in front — that kernel's ~100 us for a few thousand tasks made the side chain the batch's longest path once the
-  //  single-instance kernel beside it took 280 us instead of 490)
-  const bool skip_one = e->cover_jump && !getenv("GMX_KEEP_COVER_ONE");
-  o.general_rest_list = skip_one ? e->d_cover_general : e->d_general_rest;
-  o.general_rest_counter = skip_one ? 8u : GMX_CNT_GENERAL_REST;
+  o.general_rest_list = e->d_general_rest;
   o.single_rest_list = e->d_single_rest;
   o.park2 = e->d_park2;
   o.park2_n = e->d_park2_n;
@@ -4032,7 +4026,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     hipLaunchKernelGGL(gmx_cover_one_kernel, dim3(e->n_cus * 4), dim3(GMX_ONE_THREADS), one_lds, st, e->dview, b, o, e->big, acc, one ? 1u : 0u);
   };
   if (general_on_side) {
-    if (!skip_one) launch_one(e->side_stream);
+    launch_one(e->side_stream);
     if (e->coop) launch_cover_coop<3>(e, e->side_stream, b, o, acc);
     launch_cover_lds<CoverEnvLds, 3>(e, e->side_stream, b, o, acc, e->coop);
     launch_cover_lds<CoverEnv, 0>(e, e->side_stream, b, o, acc);

@@ -1820,7 +1820,7 @@ std::vector<int64_t> seed_states_of(const HostIndex &ix, uint32_t code, bool lon
 // ---------------------------------------------------------------------------------------
 namespace {
 const uint64_t kCacheMagic = 0x31584449584d47ull;  // "GMXIDX1"
-const uint32_t kCacheVersion = 10;                  // bump on any change of the tables' layout or meaning
+const uint32_t kCacheVersion = 11;                  // bump on any change of the tables' layout or meaning
 
 uint64_t fnv1a_u32(const std::vector<uint32_t> &v) {
   uint64_t h = 1469598103934665603ull;

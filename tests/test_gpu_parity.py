@@ -120,9 +120,9 @@ def test_config1_1kb_10snps_10k_reads():
     assert got["stats"]["exact_mapped"] >= 10000
 
 
-@pytest.mark.parametrize("n_sites", [1500, 3000, 6000])
+@pytest.mark.parametrize("n_sites", [1500, 3000, 6000, 7400])
 def test_dense_sites_matches_oracle(n_sites):
-    """A SNP every 20 / 10 / 5 bp: 7, 15 and 30 loci per read. The search kernels hand single-instance tasks to the
+    """A SNP every 20 / 10 / 5 / 4 bp: 7, 15, 30 and 37 loci per read (beyond the 32 the one-lane routine of the general queue holds). The search kernels hand single-instance tasks to the
     coverage kernel as compact records — three (site, allele) pairs, or a run of up to 16 consecutive sites — and
     longer paths as task ids for the general instance; all three routes must give the oracle's coverage."""
     prg, reads = _snp_workload(30000, n_sites, 3000, 40 + n_sites, multi=0.1)
