@@ -559,14 +559,15 @@ struct GmxStageTest {
 #endif
 #define GMX_STAGE_MAX 16u  // operations a stage may hold (two bits of kind each in one register)
 template <class Env, class Stage>
-GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, const GmxNode *rec0_in,
-                           uint32_t read_len) {
-  // the node of the read's first base, when it matters (the read starts inside an allele): the caller's copy, or fetched
-  // here BEHIND the first four geometry loads — pos_node -> node -> its site's geometry is a chain of three dependent loads
-  // that nearly every wave of 64 tasks has a lane for, and the loci's records need not wait for it
+GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, uint32_t read_len) {
+  // the node of the read's first base, when it matters (the read starts inside an allele), is fetched here BEHIND the first
+  // four geometry loads — pos_node -> node -> its site's geometry is a chain of three dependent loads that nearly every wave
+  // of 64 tasks has a lane for, and the loci's records need not wait for it. (A form of this routine that took the caller's
+  // copy of that node by pointer recorded NOTHING for such reads in a GPU build — 16 914 increments instead of the oracle's
+  // 22 196 on tests' 37-loci workload — while this form, the host build of the other, and the other with printf in it were
+  // right: a code generation problem we could not pin down. The pointer form is gone.)
   GmxNode rec0{};
-  bool have_rec0 = rec0_in != nullptr;
-  if (have_rec0) rec0 = *rec0_in;
+  bool have_rec0 = false;
   const uint32_t cap = stage.cap() < GMX_STAGE_MAX ? stage.cap() : GMX_STAGE_MAX;
   uint32_t n_ops = 0, kinds = 0;  // staged operations: 0 hit counter, 1 allele-sum + group pair, 2 per-base range (slot), 3 its length
   auto pass = [&](const bool direct) -> bool {
@@ -726,9 +727,9 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
     if (words && !env.log_reserve(words)) return;
   }
   // gmx_cover_jump first — in HOST builds only (tests/hostemu: that is how the routine is checked against the oracle on the
-  // CPU, staged and unstaged). On the device it runs in gmx_cover_jump_kernel alone: called from here, i.e. from the general
-  // coverage instances (paths of more than 16 loci, arena handles), a GPU run recorded nothing for the reads that start inside
-  // an allele — with printf in the routine it recorded them; not understood (round 4), so those instances keep the walk.
+  // CPU, staged and unstaged). On the device it runs in gmx_cover_jump_kernel alone; the general coverage instances, which
+  // reach this routine with paths of more than 16 loci, keep the walk: they are a few thousand tasks per million reads, and
+  // the one GPU build that called it from here is the one that hit the code generation problem noted at gmx_cover_jump.
 #ifndef __HIP_DEVICE_COMPILE__
   {
 #ifdef GMX_COVER_TEST_STAGE  // test build (tests/hostemu): the staged form, with the capacity the test asks for
@@ -737,7 +738,7 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
 #else
     GmxStageNone none;
 #endif
-    if (ix.site_geo && gmx_cover_jump(ix, env, none, p, tvd, tvg, first_in_play ? &rec0 : nullptr, read_len)) {
+    if (ix.site_geo && gmx_cover_jump(ix, env, none, p, tvd, tvg, read_len)) {
       GMX_COVER_ROUTE(1);
       return;
     }

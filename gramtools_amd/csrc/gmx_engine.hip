@@ -2944,7 +2944,7 @@ __global__ void __launch_bounds__(GMX_BLOCK, GMX_JUMP_MIN_BLOCKS) gmx_cover_jump
   env.log_at = env.log_end = 0;
   const uint32_t p = env.rec.p, tvd = env.n_trav() ? 0u : GMX_NIL, tvg = env.rec.tvg;
   StageLds stage{gmx_lds + threadIdx.x};
-  const bool done = gmx_cover_jump(ix, env, stage, p, tvd, tvg, nullptr, env.rec.len_n & 0xFFFFu);
+  const bool done = gmx_cover_jump(ix, env, stage, p, tvd, tvg, env.rec.len_n & 0xFFFFu);
   if (!done) o.single_rest_list[atomicAdd(&o.counters[GMX_CNT_SINGLE_REST * GMX_CNT_STRIDE], 1u)] = (uint32_t)rec_idx;
 }
 __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_rest_kernel(GmxIndexView ix, BatchView b, SearchOut o, CoverAcc acc) {
