@@ -2916,8 +2916,8 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_cover_single_kernel(GmxIndexVie
 
 // The same queue on a flat PRG whose sites have geometry records (GmxSiteGeo): gmx_cover_jump alone — no walk, no GmxSite, the
 // increments staged in LDS between its check pass and the recording — and what it declines (a site of more than 8 alleles
-// or an allele of 255+ bases on the path) goes to gmx_cover_single_rest_kernel, the routine above over a list. Leaving the
-// walk out of this kernel is what keeps it at 8 waves per SIMD.
+// or an allele of 255+ bases on the path) goes to gmx_cover_single_rest_kernel, the routine above over a list. (Forced to 64
+// registers for 8 waves per SIMD it spills and is no faster: GMX_JUMP_MIN_BLOCKS; profiles/round4/cover_jump_variants_config3.txt.)
 struct StageLds {
   uint32_t *w;  // this lane's words, GMX_BLOCK apart
   __device__ __forceinline__ uint32_t cap() const { return GMX_STAGE_MAX; }
