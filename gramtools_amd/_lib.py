@@ -102,6 +102,10 @@ SYMBOLS = {
     "gmx_engine_enable_timing": (C.c_int, [_vp, C.c_int]),
     "gmx_engine_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "gmx_engine_queue_counts": (C.c_int, [_vp, C.POINTER(QueueCounts)]),
+    "gmx_engine_debug_keep_states": (C.c_int, [_vp, C.c_int]),
+    "gmx_debug_final_states": (C.c_int, [_vp, _u64, _u32p, _u64, _u64p, C.POINTER(C.c_int)]),
+    "gmx_debug_search": (C.c_int, [_vp, _u8p, _u32, C.c_int, _u32p, _u64, _u32, _u32, C.c_int, _u32p, _u64, _u64p]),
+    "gmx_debug_encapsulate": (C.c_int, [_vp, _u32p, _u64, _u32p, _u64, _u64p, _u32p, _u64, _u64p]),
     "gmx_master_seeds": (C.c_int, [_u32, _u64p, _u64, _u32p]),
     "gmx_coverage_device": (C.c_int, [_vp, C.POINTER(DeviceCoverage)]),
     "gmx_coverage_reduce_begin": (C.c_int, [_vp, _vp]),

@@ -1140,6 +1140,34 @@ GMX_HD void gmx_class_record(const GmxIndexView &ix, Env &env, uint32_t n_loci, 
 }
 
 // ---------------------------------------------------------------------------
+// The items of a task's final states (handle_allele_encapsulated_states, encapsulated_search.cpp:30-107): a path-bearing
+// state as it is; a path-less one position by position — inside an allele it becomes a state of its own with that locus
+// as its path (add_item(lo, hi, traversed, traversing, site, allele)), outside every site it only counts
+// (nonvariant(position index): count_nonvar_search_states, coverage_common.cpp:130-141). The reference merges neighbouring
+// positions of one allele into an interval; position by position is the same set of mapping instances.
+// false: add_item refused (scratch full). Used by gmx_cover_task and by the test hook gmx_debug_encapsulate.
+// ---------------------------------------------------------------------------
+template <class AddItem, class NonVariant>
+GMX_HD bool gmx_final_items(const GmxIndexView &ix, const GmxFinalState *finals, uint32_t n_final, AddItem add_item, NonVariant nonvariant) {
+  for (uint32_t f = 0; f < n_final; ++f) {
+    GmxFinalState st = finals[f];
+    if (st.traversed != GMX_NIL || st.traversing != GMX_NIL) {
+      if (!add_item(st.lo, st.hi, st.traversed, st.traversing, 0, -1)) return false;
+      continue;
+    }
+    for (uint32_t i = st.lo;; ++i) {
+      const GmxNode &nd = ix.nodes[ix.pos_node[gmx_occ_pos(ix, st.hi, i)]];
+      if (nd.site == 0)
+        nonvariant(i);
+      else if (!add_item(i, gmx_text_form(st.hi) ? st.hi : i, GMX_NIL, GMX_NIL, nd.site, nd.allele))
+        return false;
+      if (gmx_text_form(st.hi) || i == st.hi) break;
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
 // The whole recording step for one mapped task.
 // ---------------------------------------------------------------------------
 template <class Env>
@@ -1172,21 +1200,7 @@ GMX_HD void gmx_cover_task(const GmxIndexView &ix, Env &env, const GmxFinalState
     ++n_items;
     return true;
   };
-  for (uint32_t f = 0; f < n_final; ++f) {
-    GmxFinalState st = finals[f];
-    if (st.traversed != GMX_NIL || st.traversing != GMX_NIL) {
-      if (!add_item(st.lo, st.hi, st.traversed, st.traversing, 0, -1)) return;
-      continue;
-    }
-    for (uint32_t i = st.lo;; ++i) {
-      const GmxNode &nd = ix.nodes[ix.pos_node[gmx_occ_pos(ix, st.hi, i)]];
-      if (nd.site == 0)
-        nonvariant += 1;
-      else if (!add_item(i, gmx_text_form(st.hi) ? st.hi : i, GMX_NIL, GMX_NIL, nd.site, nd.allele))
-        return;
-      if (gmx_text_form(st.hi) || i == st.hi) break;
-    }
-  }
+  if (!gmx_final_items(ix, finals, n_final, add_item, [&](uint32_t) { nonvariant += 1; })) return;
   GMX_COVER_PROF(env, 0);
   if (n_items == 0) return;  // usps.size() == 0: nothing recorded, no draw (coverage_common.cpp:96-97)
 

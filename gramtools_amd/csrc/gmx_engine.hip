@@ -932,6 +932,7 @@ struct BatchView {
   uint32_t forward_only;
   uint32_t uniform_len;      // != 0: every read has this many bases and starts at pair r * pairs_per_read (no offsets)
   uint32_t pairs_per_read;   // ceil(uniform_len / 32)
+  uint32_t keep_states;      // test hook (gmx_engine_debug_keep_states): every task's final states stay readable in finals[] / n_final[]
 };
 // Layout of the bit planes (include/gmx.h, gmx_pack_reads): P(r) = (offsets[r] >> 5) + r pairs from P(0) — ceil(len/32)
 // pairs fit between consecutive starts whatever the offsets are, and a sub-range of a packed batch is again a packed
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ void task_read_regs(const BatchView &b, uint32_t task
 //   alive_pass: which of the extend kernel's straggler lists a parked task goes to (second phase)
 __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const SearchOut &o, bool active, uint32_t task, FastCtx &ctx,
                                             uint32_t status, bool done, bool second_phase, uint32_t read_len, bool parked = false,
-                                            uint32_t alive_pass = 0) {
+                                            uint32_t alive_pass = 0, bool b_keep = false) {
   bool mapped = false, alive = false, dead = false, over = false;
   if (active && status != GMX_TASK_SKIPPED && status != GMX_STATUS_IGNORED) {
     if (status == GMX_TASK_MAPPED) {
@@ -1127,10 +1128,10 @@ __device__ __forceinline__ void finish_lane(const GmxIndexView &ix, const Search
       rec.a2 = w3;
     }
   }
-  if (mapped && !compact) ctx.flush_first();  // the general coverage routine reads finals[]
+  if (mapped && (!compact || b_keep)) ctx.flush_first();  // the general coverage routine reads finals[]
   // the state counts of a task are read by the extend kernel (parked tasks) and by the general coverage routine; a
   // compact record needs neither (on a nested PRG the single-instance kernel may still hand the task on)
-  if (alive || (mapped && (!compact || ix.is_nested))) o.n_final[task] = ctx.n_out | (ctx.arena_n << 8) | (ctx.seed_left << 16);
+  if (alive || (mapped && (!compact || ix.is_nested || b_keep))) o.n_final[task] = ctx.n_out | (ctx.arena_n << 8) | (ctx.seed_left << 16);
   // Every lane goes to at most one queue; all of them are appended in one pass (one barrier pair, one atomic per
   // queue and block). Compact mapped tasks are queued by the PRG region they map to: workgroup b of the coverage
   // kernel serves region b % 8, workgroups go round-robin over the 8 XCDs, so every XCD's L2 sees one eighth of the
@@ -1271,7 +1272,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) gmx_probe_kernel(GmxIndexView ix, B
     }
     status = ctx.status;
   }
-  finish_lane(ix, o, active, task, ctx, status, done, false, r.len);
+  finish_lane(ix, o, active, task, ctx, status, done, false, r.len, false, 0, b.keep_states != 0);
 }
 
 // Phase 2 — the compacted survivors: all 64 lanes of a wave carry a live search for the rest of the read.
@@ -1615,7 +1616,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
   ctx.out_cap = GMX_FAST_STATES;
   ctx.parking = false;
   ctx.park_pos = 0;
-  ctx.defer_first = !ix.is_nested;  // (on a nested PRG the single-instance kernel may hand a task on to the general one)
+  ctx.defer_first = !ix.is_nested && !b.keep_states;  // (on a nested PRG the single-instance kernel may hand a task on to the general one)
   ctx.first_deferred = false;
   ctx.first_pos = ctx.first_tvd = ctx.first_tvg = GMX_NIL;
   ctx.seed_left = ctx.seed_off = ctx.seed_pos = ctx.mark_arena = ctx.mark_out = 0;
@@ -1695,7 +1696,7 @@ __global__ void __launch_bounds__(GMX_BLOCK) GMX_EXTEND_ATTR gmx_extend_kernel(G
   }
   status = ctx.status;
   const long long t2 = GMX_CLK();
-  finish_lane(ix, o, slot < n_alive, task, ctx, status, done, true, r.len, !done, MODE == 2 ? pass + 1u : 0u);
+  finish_lane(ix, o, slot < n_alive, task, ctx, status, done, true, r.len, !done, MODE == 2 ? pass + 1u : 0u, b.keep_states != 0);
   const long long t3 = GMX_CLK();
   GMX_TSTAT(1, 10, t1 - t0);
   GMX_TSTAT(1, 11, t2 - t1);
@@ -3217,6 +3218,10 @@ struct gmx_engine {
                                 // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
   GmxParked *d_park2 = nullptr;
   uint32_t *d_park2_n = nullptr;
+  // test hook (gmx_engine_debug_keep_states, gmx_debug_final_states): the last batch's per-task search results stay readable
+  bool keep_states = false;
+  uint64_t keep_reads = 0;            // reads of that batch
+  std::vector<uint32_t> debug_isa;    // inverse suffix array (text position -> SA index), fetched on first use
   uint32_t fuse = 1;  // fused transitions in the extend kernel's wave loop (GMX_NO_FUSE=1 in the environment: off, for A/B runs)
   // host staging for the _host entry point
   uint8_t *d_reads = nullptr;
@@ -3866,7 +3871,8 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     }
   }
   BatchView b{in.d_reads, in.d_offsets, in.d_seeds, (in.d_planes || in.d_twobit) ? in.d_skip : e->d_skip, in.d_planes ? in.d_planes : e->d_packed,
-              (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0), in.uniform_len, (in.uniform_len + 31u) / 32u};
+              (uint32_t)n_reads, (uint32_t)(e->opts.forward_only ? 1 : 0), in.uniform_len, (in.uniform_len + 31u) / 32u,
+              e->keep_states ? 1u : 0u};
   const uint32_t region_inv = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)GMX_REGIONS << 32) + e->dview.n_prg - 1) / std::max<uint32_t>(e->dview.n_prg, 1u));
   SearchOut o{};  // (member by member: the struct's order is not part of any contract)
   o.status = e->d_status;
@@ -3922,6 +3928,10 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   o.log_retry_huge = e->d_log_retry_huge[e->log_retry_side];
   o.stats = e->d_stats;
   uint32_t n_tasks = (uint32_t)n_reads * 2;
+  if (e->keep_states) {  // test hook: a task that never reaches a kernel that writes its state count reads as "no state"
+    HIP_TRY(hipMemsetAsync(e->d_n_final, 0, (size_t)n_tasks * sizeof(uint32_t), stream));
+    e->keep_reads = n_reads;
+  }
   if (in.d_planes || in.d_twobit) {
     hipLaunchKernelGGL(gmx_batch_begin_kernel, dim3(fold_reset ? 256 : 1), dim3(1024), 0, stream, e->d_counters,
                        fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
@@ -4811,3 +4821,5 @@ int gmx_engine_log_import(gmx_engine *e, const uint32_t *w, size_t n_words, bool
   }
   return GMX_OK;
 }
+
+#include "gmx_engine_debug.h"  // test hooks (final SearchStates of a task, the search loop on given states)

@@ -547,6 +547,72 @@ class Quasimapper:
         check(self.lib.gmx_engine_queue_counts(self.h, C.byref(q)))
         return {n: int(getattr(q, n)) for n, _ in q._fields_}
 
+    # ---- test hooks: SearchStates of the HIP path (gmx.h; states as (lo, hi, [(site, allele)...], [(site, -1)...])) ----
+    @staticmethod
+    def _states_to_words(states):
+        w = [len(states)]
+        for lo, hi, tvd, tvg in states:
+            w += [lo, hi, len(tvd), len(tvg)]
+            for site, allele in tvd:
+                w += [site, allele & 0xFFFFFFFF]
+            w += [x[0] if isinstance(x, (tuple, list)) else x for x in tvg]
+        return np.asarray(w, dtype=np.uint32)
+
+    @staticmethod
+    def _words_to_states(w):
+        out, at = [], 1
+        for _ in range(int(w[0])):
+            lo, hi, nt, ng = (int(x) for x in w[at:at + 4])
+            at += 4
+            tvd = [(int(w[at + 2 * j]), int(np.int32(w[at + 2 * j + 1]))) for j in range(nt)]
+            at += 2 * nt
+            tvg = [(int(w[at + j]), -1) for j in range(ng)]
+            at += ng
+            out.append((lo, hi, tvd, tvg))
+        return out
+
+    def debug_keep_states(self, on=True):
+        """From the next batch on every task's final states stay readable (debug_final_states)."""
+        check(self.lib.gmx_engine_debug_keep_states(self.h, 1 if on else 0))
+
+    def debug_final_states(self, read, orientation=0):
+        """Final SearchStates of (read, orientation) of the last launch, as search_read_backwards leaves them. -> (states, tier)"""
+        n, tier = C.c_uint64(0), C.c_int(-1)
+        check(self.lib.gmx_debug_final_states(self.h, 2 * read + orientation, None, 0, C.byref(n), C.byref(tier)))
+        buf = np.zeros(max(n.value, 1), dtype=np.uint32)
+        check(self.lib.gmx_debug_final_states(self.h, 2 * read + orientation, _p(buf, C.c_uint32), buf.size, C.byref(n), C.byref(tier)))
+        return self._words_to_states(buf), tier.value
+
+    def debug_search(self, read, states=None, from_pos=None, stop=0, lf_only=False):
+        """The device's search loop on one read. states=None: seeded from the k-mer index (search_read_backwards); else from
+        the given states at read position from_pos (default: the whole read is still to be matched) down to stop."""
+        r = np.ascontiguousarray(read, dtype=np.uint8)
+        seeded = states is None
+        sw = np.zeros(1, dtype=np.uint32) if seeded else self._states_to_words(states)
+        frm = r.size if from_pos is None else from_pos
+        n = C.c_uint64(0)
+        cap = 1 << 16
+        while True:
+            buf = np.zeros(cap, dtype=np.uint32)
+            rc = self.lib.gmx_debug_search(self.h, _p(r, C.c_uint8), r.size, 1 if seeded else 0, _p(sw, C.c_uint32), sw.size, frm, stop,
+                                           1 if lf_only else 0, _p(buf, C.c_uint32), buf.size, C.byref(n))
+            if rc == -4 and n.value > cap:
+                cap = int(n.value)
+                continue
+            check(rc)
+            return self._words_to_states(buf)
+
+    def debug_encapsulate(self, states):
+        """The device's handle_allele_encapsulated_states on the given states -> (states inside sites, SA indices outside sites)."""
+        sw = self._states_to_words(states)
+        positions = sum(hi - lo + 1 for lo, hi, _, _ in states) + len(states) + 1
+        buf = np.zeros(8 * positions + 64 + sw.size, dtype=np.uint32)
+        nv = np.zeros(positions, dtype=np.uint32)
+        n, n_nv = C.c_uint64(0), C.c_uint64(0)
+        check(self.lib.gmx_debug_encapsulate(self.h, _p(sw, C.c_uint32), sw.size, _p(buf, C.c_uint32), buf.size, C.byref(n),
+                                             _p(nv, C.c_uint32), nv.size, C.byref(n_nv)))
+        return self._words_to_states(buf), [int(x) for x in nv[:n_nv.value]]
+
     def reduce_begin(self, stream=None):
         """Before the all-reduce of the fused block: read counters -> 16-bit limbs inside it."""
         check(self.lib.gmx_coverage_reduce_begin(self.h, C.c_void_p(stream) if stream else None))

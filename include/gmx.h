@@ -222,6 +222,37 @@ typedef struct gmx_timing {
 } gmx_timing;
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
 
+/* ---- test hooks: SearchStates of the HIP path -----------------------------------------
+ * The reference's unit tests pin the search at the level of SearchStates (search/types.hpp:31-57;
+ * tests/genotype/quasimap/search/test_vBWT_jump.cpp:55-405, test_encapsulated_search.cpp:28-254, the
+ * search_read_backwards cases of test_quasimap.cpp). These entry points expose the device's states so that
+ * tests/ can run those vectors on the HIP kernels; none of them is on the mapping path.
+ * States travel as words in the k-mer index's serialisation, SA intervals as the reference has them:
+ *   [n_states, {lo, hi, n_traversed, n_traversing, (site, allele) x n_traversed, site x n_traversing}*]   (push order)
+ * Every call sets *n_words to the words of the answer; GMX_ECAP when `out` (non-null) holds fewer.
+ *
+ * gmx_engine_debug_keep_states(e, 1): from the next batch on, every task's final states stay readable after the
+ *   batch (the kernels then also write the copies a compact coverage record makes redundant).
+ * gmx_debug_final_states: the final states of task 2 * read + orientation of the LAST launch (one call of a
+ *   gmx_map_reads_* entry point with at most max_batch_reads reads), as search_read_backwards leaves them
+ *   (quasimap.cpp:227-256, before handle_allele_encapsulated_states). *tier: 0 fast pass, 1 a large-capacity
+ *   slot, 2 instance lanes. GMX_ECAP for a task the last tier searched (it keeps nothing).
+ * gmx_debug_search: the device's search loop on ONE read (bases 1..4) from caller-given states at read position
+ *   `from` (bases [0, from) are still to be matched) down to `stop`; lf_only: the given states take their first
+ *   step without a marker pass (search_base_backwards, BWT_search.cpp:78-94), else marker pass + LF step
+ *   (process_read_char_search_states, quasimap.cpp:258-268). from_seed_table != 0: seeded from the k-mer index
+ *   entry of the read's last k-mer and run to the read's start instead (search_read_backwards).
+ * gmx_debug_encapsulate: the device's handle_allele_encapsulated_states (encapsulated_search.cpp:30-107) on the
+ *   given states: position by position; out = the states that stay mapping instances of a site, nonvariant_sa =
+ *   the SA indices of the path-less positions outside every site (the reference keeps them as path-less states). */
+int gmx_engine_debug_keep_states(gmx_engine *e, int on);
+int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t cap_words, uint64_t *n_words, int *tier);
+int gmx_debug_search(gmx_engine *e, const uint8_t *read, uint32_t read_len, int from_seed_table, const uint32_t *states,
+                     uint64_t n_state_words, uint32_t from, uint32_t stop, int lf_only, uint32_t *out, uint64_t cap_words,
+                     uint64_t *n_words);
+int gmx_debug_encapsulate(gmx_engine *e, const uint32_t *states, uint64_t n_state_words, uint32_t *out, uint64_t cap_words,
+                          uint64_t *n_words, uint32_t *nonvariant_sa, uint64_t cap_nonvariant, uint64_t *n_nonvariant);
+
 /* Queue lengths of the LAST batch (after gmx_engine_sync): how many (read, orientation) tasks took which route.
  * Diagnostics for capacity planning; tasks_overflow_* are redone by the large-capacity kernel. */
 typedef struct gmx_queue_counts {
