@@ -560,14 +560,16 @@ struct GmxStageTest {
 #define GMX_STAGE_MAX 16u  // operations a stage may hold (two bits of kind each in one register)
 template <class Env, class Stage>
 GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint32_t p, uint32_t tvd, uint32_t tvg, uint32_t read_len) {
-  // the node of the read's first base, when it matters (the read starts inside an allele), is fetched here BEHIND the first
-  // four geometry loads — pos_node -> node -> its site's geometry is a chain of three dependent loads that nearly every wave
-  // of 64 tasks has a lane for, and the loci's records need not wait for it. (A form of this routine that took the caller's
-  // copy of that node by pointer recorded NOTHING for such reads in a GPU build — 16 914 increments instead of the oracle's
-  // 22 196 on tests' 37-loci workload — while this form, the host build of the other, and the other with printf in it were
-  // right: a code generation problem we could not pin down. The pointer form is gone.)
-  GmxNode rec0{};
-  bool have_rec0 = false;
+  // NO multi-word state crosses from the check pass to the recording pass: each pass derives everything from the scalars
+  // (p, tvd, tvg, read_len) and fetches the node of the read's first base itself, when it matters (the read starts inside an
+  // allele) — BEHIND its first four geometry loads: pos_node -> node -> its site's geometry is a chain of three dependent
+  // loads that nearly every wave of 64 tasks has a lane for, and the loci's records need not wait for it.
+  // Why (round 5, DESIGN.md §4, profiles/round5/jump_ptr_form_*): the round-4 form kept that node in a local captured by
+  // reference, copied from the caller through a pointer and re-fetched under `if (!have)` inside the lambda. The compiler
+  // inlines the lambda twice; behind the first body the node's fields meet in a ten-way phi (early returns), and the AMDGPU
+  // back end lowered that join by parking three of the five live fields in temporaries copied under a narrower exec mask than
+  // the one they are copied back under — the lanes in between entered the recording pass with first_pos = 3 and recorded
+  // nothing: 16 914 increments instead of 22 196. The optimized IR is right (every edge defined), the machine code is not.
   const uint32_t cap = stage.cap() < GMX_STAGE_MAX ? stage.cap() : GMX_STAGE_MAX;
   uint32_t n_ops = 0, kinds = 0;  // staged operations: 0 hit counter, 1 allele-sum + group pair, 2 per-base range (slot), 3 its length
   auto pass = [&](const bool direct) -> bool {
@@ -614,10 +616,7 @@ GMX_HD bool gmx_cover_jump(const GmxIndexView &ix, Env &env, Stage &stage, uint3
     };
     fetch();
     if (tvg != GMX_NIL || tvd == GMX_NIL) {  // the read starts inside an allele: of the traversing site, or of the one it never leaves
-      if (!have_rec0) {
-        rec0 = ix.nodes[ix.pos_node[p]];
-        have_rec0 = true;
-      }
+      const GmxNode rec0 = ix.nodes[ix.pos_node[p]];
       if (tvg == GMX_NIL && rec0.site == 0) return true;  // a non-variant instance only: nothing to record
       if (!gmx_in_bubble(rec0) || rec0.seq_len == 0 || rec0.cov_off == GMX_NO_COV || p < rec0.first_pos || p - rec0.first_pos >= rec0.seq_len)
         return false;
@@ -726,11 +725,9 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       if (ix.sites[(env.h_site(x) - 5) >> 1].grouped_off == GMX_GROUPED_LOG) words += 3;
     if (words && !env.log_reserve(words)) return;
   }
-  // gmx_cover_jump first — in HOST builds only (tests/hostemu: that is how the routine is checked against the oracle on the
-  // CPU, staged and unstaged). On the device it runs in gmx_cover_jump_kernel alone; the general coverage instances, which
-  // reach this routine with paths of more than 16 loci, keep the walk: they are a few thousand tasks per million reads, and
-  // the one GPU build that called it from here is the one that hit the code generation problem noted at gmx_cover_jump.
-#ifndef __HIP_DEVICE_COMPILE__
+  // gmx_cover_jump first — host and device alike since round 5 (the general coverage instances reach this routine with
+  // paths of more than 16 loci; in round 4 the device kept the walk here because of the wrong-result build explained at
+  // gmx_cover_jump). What it declines takes the routines below, which decide as the reference does.
   {
 #ifdef GMX_COVER_TEST_STAGE  // test build (tests/hostemu): the staged form, with the capacity the test asks for
     GmxStageTest none;
@@ -743,7 +740,6 @@ GMX_HD void gmx_cover_single(const GmxIndexView &ix, Env &env, const GmxFinalSta
       return;
     }
   }
-#endif
   // Without the walk: every traversed site is walk-free (gmx_types.h: a one-base allele is its hit counter, an empty
   // one its allele-sum/group pair) and the first node, if in play, has a hit counter. The site records are
   // independent loads; the walk below is a chain of dependent ones.

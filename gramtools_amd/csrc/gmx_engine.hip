@@ -3527,6 +3527,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
     uint64_t n_jump = 0;
     for (const GmxSiteGeo &g : h.site_geo) n_jump += (g.flags & GMX_SITE_JUMP) ? 1u : 0u;
     e->cover_jump = !h.is_nested && 2 * n_jump > h.site_geo.size() && !getenv("GMX_NO_COVER_JUMP");
+    // GMX_NO_COVER_JUMP=1 (the escape hatch, and the walk side of tests/test_cover_jump_ab.py): no kernel
+    // sees the geometry records, every single-instance read is recorded by the walk as the reference walks it
+    if (getenv("GMX_NO_COVER_JUMP")) e->dview.site_geo = nullptr;
   }
   {
     uint64_t cap = opts.log_cap_words ? opts.log_cap_words

@@ -484,7 +484,7 @@ void hostemu_fetch(void *p, uint32_t *allele_sum, uint32_t *per_base, uint32_t *
     grouped[e->h.hit_fix[i + 2]] += hits;
     per_base[e->h.hit_fix[i + 3]] += hits;
   }
-  memcpy(log, e->log.data(), e->log.size() * 4);
+  if (!e->log.empty()) memcpy(log, e->log.data(), e->log.size() * 4);
   memcpy(stats, e->stats, sizeof(e->stats));
 }
 
