@@ -26,7 +26,14 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
   per_rank_s       (N > 1) every rank's own time for the timed job
   cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + the three coverage files
   cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): the cores the container grants, and one thread
-  roofline         gmx_extend_kernel, the dominant kernel: see HISTORY.md §8 for the byte model
+  roofline         what bounds the STEP (the host link: bound "pcie", achieved = H2D GB/s of the timed job against the
+                   PCIe Gen5 x16 spec) and, in roofline.kernels, one object per leading kernel — gmx_extend_kernel first (the
+                   dominant one: HBM fraction by the byte model of DESIGN.md §8, by counter traffic, and its issue fraction),
+                   then the single-instance coverage kernel, the k-mer filter and the seed look-up — each with the duration
+                   of its own dispatch measured live (HIP events attached to the dispatch inside the library)
+  configs          (N = 1) BASELINE.json configs[2] and configs[3] built at full size: kernel-pipeline and packed-feed
+                   reads/s and their leading kernels' durations (--configs 2,3,4 adds configs[4] on a box with >= 280 GiB)
+  jobs             the timed job is run --jobs times (default 5), exactly --steps steps each; `value` is the MEDIAN job
 """
 import argparse
 import json
@@ -50,6 +57,7 @@ READS_PER_GPU = 1_000_000
 N_BATCHES = 8                                              # distinct batches cycled by the timed loop
 B_NOMINAL_PER_READ = 128 * (READ_LEN - KMER) + READ_LEN   # 18 070 B/read at k = 10
 HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md: 8.0 TB/s spec
+PCIE_PEAK_GBS = 63.0                                       # MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec), per direction
 # Algorithmic bytes gmx_extend_kernel must move per mapped read with text-form states (HISTORY.md §8 derives each term):
 # queue entry 4 + seed directory entry 8 + packed read planes 48 + PRG text records 6 x 16 + marker sub-records 3 x 16 +
 # path nodes 2 x 12 + coverage record 32 + task id 4
@@ -57,7 +65,7 @@ HBM_PEAK_GBS = 8000.0                                      # MI355X_MICROARCH.md
 # planes 48 + PRG text records 3.4 x 32 (64 symbols each; loop_stats.txt: 3.3 heavy steps per lane) + marker sub-records of the
 # sites that are not inline 0.15 x 16 + path nodes 2 x 12 + coverage record 32 + task id 4   (264 B with round 2's 16 B records)
 B_DESIGN_PER_READ = 4 + 8 + 48 + 109 + 2 + 2 * 12 + 32 + 4
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round4"), os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round5"), os.path.join(ROOT, "profiles", "round4"), os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
 
 
 def profile_json(name):
@@ -191,6 +199,102 @@ def cli_end_to_end(prg, batches, threads):
                 "note": "plain four-line FASTQ -> coverage files, the call made twice and the faster one quoted; parse_and_map = parser threads (2-bit planes) + H2D + kernels"}
 
 
+def _container_memory_gib():
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            return int(v) / 2 ** 30
+    except OSError:
+        pass
+    return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+
+
+def config_leg(which, n_reads, steps, device, stream):
+    """BASELINE.json configs[which] at full size (SURVEY §8(d)'s recipe): index built, `n_reads` reads mapped through the
+    kernel-pipeline loop (bytes resident in HBM) and the packed host feed (2-bit stream from page-locked memory), with the
+    leading kernels' own durations. The reference's loop being replaced: quasimap.cpp:82-141."""
+    import torch
+    from gramtools_amd import Index, Quasimapper, master_seeds, pack_reads_2bit
+    from gramtools_amd.synth import chr20_recipe, flat_offsets, genome_recipe_file, pf3d7_recipe
+    t0 = time.time()
+    if which == 2:
+        k, what = 10, "configs[2]: 23.3 Mb random ref + 2000 nested MSA regions (depth <= 3) + 100 k SNPs, k = 10"
+        prg, reads = pf3d7_recipe(23_300_000, 2000, 100_000, n_reads, 22)
+        ix = Index(prg, k)
+    elif which == 3:
+        k, what = 14, "configs[3]: 64 444 167 bp random ref + 1.8 M sites (90 % SNP / 10 % indel, 5 % multi-allelic), k = 14"
+        prg, reads = chr20_recipe(64_444_167, 1_800_000, n_reads, 32)
+        ix = Index(prg, k)
+    else:
+        k, what = 14, "configs[4]: 3.1 G bases + 85 M sites (the configs[3] mix), k = 14; index replicated per GPU"
+        if _container_memory_gib() < 280:
+            return {"skipped": f"needs >= 280 GiB of host memory for the index build; this box has {_container_memory_gib():.0f} GiB"}
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gmx_bench_{os.getpid()}.prg")
+        _, reads = genome_recipe_file(path, 3_100_000_000, 85_000_000, n_reads, 61)
+        ix = Index(path, k)
+        os.remove(path)
+        prg = None
+    del prg
+    info = ix.info
+    t_build = time.time() - t0
+    n = reads.shape[0]
+    seeds = master_seeds(42, [n])
+    offs = flat_offsets(n, reads.shape[1])
+    flat = np.ascontiguousarray(reads).reshape(-1)
+    qm = Quasimapper(ix, device=device)
+    d_r, d_o = torch.from_numpy(flat).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_s = torch.from_numpy(np.ascontiguousarray(seeds).view(np.int32).copy()).cuda()
+
+    def loop_kernel(count):
+        qm.reset(stream=stream)
+        for _ in range(count):
+            qm.map_reads_device(d_r, d_o, d_s, n, stream=stream)
+        qm.sync()
+
+    loop_kernel(2)                      # (sizes the workspace, warms the clocks)
+    rates = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        loop_kernel(steps)
+        rates.append(n * steps / (time.perf_counter() - t0))
+    qm.enable_timing(True)
+    loop_kernel(3)
+    tm = qm.timing()
+    qm.enable_timing(False)
+    queues = qm.queue_counts()
+    pk = pack_reads_2bit(flat, offs, uniform_len=reads.shape[1], pinned=True)
+    feed = []
+    for rep_ in range(4):
+        qm.reset()
+        qm.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            qm.map_reads_packed(pk, seeds)
+        qm.sync()
+        feed.append(n * steps / (time.perf_counter() - t0))
+    st = qm.coverage().stats.as_dict()
+    pk.close()
+    L = max(tm["search_launches"], 1)
+    kernels = {"gmx_extend_kernel (first pass)": tm["search_ms"] / L}
+    for nm, label in (("extend2", "gmx_extend_kernel (first pass over the stragglers)"), ("single", "single-instance coverage kernel"),
+                      ("seed", "gmx_seed_kernel / gmx_probe_kernel"), ("filter0", "k-mer filter, pass 0"), ("filter1", "k-mer filter, pass 1")):
+        kk = tm["kernels"][nm]
+        if kk["launches"]:
+            kernels[label] = kk["ms"] / kk["launches"]
+    dominant = max(kernels, key=kernels.get)
+    out = {"workload": what, "reads_per_step": n, "steps": steps, "symbols": int(info.n_text - 1), "sites": int(info.n_sites),
+           "index_bytes": int(info.index_bytes), "is_nested": bool(info.is_nested), "build_and_generate_s": round(t_build, 1),
+           "kernel_pipeline": {"value": float(np.median(rates)), "unit": "reads/s", "runs": [float(r) for r in rates]},
+           "packed_host_feed": {"value": float(np.median(feed[1:])), "unit": "reads/s", "runs": [float(r) for r in feed[1:]]},
+           "kernel_ms": {k_: round(v, 4) for k_, v in kernels.items()}, "dominant_kernel": dominant,
+           "batch_ms_kernel_pipeline": n / float(np.median(rates)) * 1e3,
+           "stats": st, "all_reads_mapped": st["exact_mapped"] >= n * steps and st["all"] == 2 * n * steps,
+           "routes": {k_: int(queues[k_]) for k_ in ("mapped", "cover_general", "overflow_probe", "overflow_extend", "inst_mapped", "seed_cursor")}}
+    del qm, ix, d_r, d_o, d_s
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,6 +304,9 @@ def main():
     ap.add_argument("--total-reads", type=int, default=0,
                     help="strong scaling: this many reads per step for the WHOLE job, split over the GPUs")
     ap.add_argument("--batches", type=int, default=N_BATCHES, help="distinct batches of reads cycled by the timed loop")
+    ap.add_argument("--jobs", type=int, default=5, help="the timed job (exactly --steps steps) is run this many times; value = the median job")
+    ap.add_argument("--configs", default="2,3", help="N = 1 side legs: BASELINE configs built at full size (2,3; 4 needs >= 280 GiB of host memory and ~6 minutes)")
+    ap.add_argument("--config-reads", type=int, default=1_000_000, help="reads per step of the --configs legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel_pipeline / sustained / cli_end_to_end / roofline leg")
     ap.add_argument("--cli-reads", type=int, default=4_000_000, help="reads in the FASTQ of the cli_end_to_end leg")
@@ -335,6 +442,7 @@ def main():
     fence()
     tm = qm.timing()
     qm.enable_timing(False)
+    q1 = qm.queue_counts() if rank == 0 else None
     if extras:
         dtk, _, _ = timed(kernel_job, args.steps)
         side["kernel_pipeline"] = {"value": n * args.steps / dtk, "unit": "reads/s", "ms_per_step": dtk / args.steps * 1e3,
@@ -344,7 +452,14 @@ def main():
     # ---- W warm-up steps, then THE timed region: exactly `steps` steps, max over ranks ----
     if args.warmup:
         job(args.warmup)
-    dt, own, cov = timed(job, args.steps, args.warmup)
+    # `--jobs` jobs of EXACTLY `steps` steps each, every one between fences (barrier + device synchronisation on both
+    # sides, max over ranks); the MEDIAN job is the one quoted (a 15 ms job moves by several per cent on one hiccup)
+    runs = []
+    for j in range(max(1, args.jobs)):
+        runs.append(timed(job, args.steps, args.warmup + j * args.steps))
+    order = sorted(range(len(runs)), key=lambda i: runs[i][0])
+    dt, own, cov = runs[order[len(order) // 2]]
+    job_seconds = [r[0] for r in runs]
     st = cov.stats.as_dict() if rank == 0 else None
     per_rank = None
     exchange_ms = None
@@ -368,6 +483,57 @@ def main():
         sq = sq or {}
         traffic, traffic_src = measured_traffic("gmx_extend_kernel")
         h2d_per_read = (8 * ((READ_LEN + 31) // 32) if args.planes else READ_LEN / 4) + (4 if args.upload_seeds else 0)
+        h2d_gbs = h2d_per_read * value / world / 1e9
+        # ---- one roofline object per leading kernel; durations measured live (events attached to each dispatch) ----
+        def k_ms(name):
+            kk = tm["kernels"][name]
+            return kk["ms"] / kk["launches"] if kk["launches"] else None
+        n_tasks_l = 2 * reads_per_launch
+        n_dead0 = q1["dead"] if q1 else None
+        n_mapped = q1["mapped"] if q1 else reads_per_launch
+        ext = {"kernel": "gmx_extend_kernel<false,1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+               "frac_by_counter_traffic": (traffic / search_s / 1e9 / HBM_PEAK_GBS) if traffic and search_s > 0 else None,
+               "traffic_source": f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
+               "alg_bytes_per_read": B_DESIGN_PER_READ,
+               "alg_bytes_model": "text-form states: 32 B of PRG per 64 symbols, SNP sites resolved inside the record; "
+                                  "a 16 B sub-record only for sites that straddle a record end (DESIGN.md §8)",
+               "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
+               "measured": "HIP events attached to the dispatch (hipExtLaunchKernelGGL), reads resident in HBM leg",
+               "what_bounds_it": "instruction issue of the wave loop and the slowest lane of each wave, not HBM bandwidth",
+               "issue": {"valu_busy": sq.get("valu_busy"), "active_lane_share": sq.get("active_lane_share"),
+                         "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
+                         "iterations_per_wave": sq.get("iterations_per_wave"),
+                         "heavy_steps_per_lane": sq.get("heavy_steps_per_lane"),
+                         "source": f"{sq_src} (rocprofv3 --pmc SQ counters + GMX_LOOP_STATS build)"},
+               "nominal": {"bytes_per_read": b_nominal_kernel, "bytes_per_read_whole_path": B_NOMINAL_PER_READ,
+                           "achieved": b_nominal_kernel * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0,
+                           "note": "SURVEY §8(d) prices a 128 B rank block per base (the reference's algorithm); "
+                                   "exceeds the HBM peak because the kernel does not move those bytes"}}
+        kernel_rooflines = [ext]
+
+        def add_kernel(name, ms, bytes_per_launch, model, bounded_by, traffic_name=None):
+            if not ms:
+                return
+            tr, tr_src = measured_traffic(traffic_name) if traffic_name else (None, None)
+            a = bytes_per_launch / (ms / 1e3) / 1e9
+            kernel_rooflines.append({"kernel": name, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": a / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src, "avg_launch_ms": ms,
+                                     "alg_bytes_per_launch": int(bytes_per_launch), "alg_bytes_model": model,
+                                     "what_bounds_it": bounded_by})
+        add_kernel("gmx_cover_jump_kernel", k_ms("single"), n_mapped * (32 + 4 + 2 * 32 + 2 * 8),
+                   "per mapped read: compact record 32 + task id 4 + a 32 B geometry record and one 8 B atomic per site crossed (2 at configs[1])",
+                   "the memory system's rate of scattered accesses (a sector + an atomic per site crossed), not bandwidth",
+                   "gmx_cover_jump_kernel")
+        if n_dead0:
+            add_kernel("k-mer filter, pass 0 (gmx_filter_lds_kernel)", k_ms("filter0"), n_dead0 * (48 + 4) + 256 * 131072,
+                       "per dead task: read planes 48 + queue entry 4; + the 128 KB presence bitmap staged into LDS by each of 256 workgroups (from L2)",
+                       "LDS bitmap probes and VALU (141 k-mers per dead task), one 1024-thread workgroup per CU; decides only which COUNTER "
+                       "(missing_kmer / no_extension, quasimap.cpp:212-225) a task without states lands in; runs on a side stream",
+                       "gmx_filter_lds_kernel")
+        add_kernel("gmx_seed_kernel", k_ms("seed"), n_tasks_l * (16 + 8) + reads_per_launch * 12 + (n_dead0 or 0) * 4,
+                   "per task: the read's last plane pair 16 + seed directory entry 8; per alive task 12 (queue entry + entry copy), per dead task 4",
+                   "2 M scattered 8-byte entries of a 537 MB table per launch", "gmx_seed_kernel")
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -389,28 +555,21 @@ def main():
                                       "coverage block per JOB (after the last step), then D2H",
                        "exchange": exchange, "index_build_s": round(t_index, 2), "reads_generation_s": round(t_reads, 2),
                        "index_bytes": int(ix.info.index_bytes)},
-            "h2d_rate_GBps": h2d_per_read * value / world / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "gmx_extend_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1 M reads per launch)",
-                         "alg_bytes_per_read": B_DESIGN_PER_READ,
-                         "alg_bytes_model": "text-form states: 32 B of PRG per 64 symbols, SNP sites resolved inside the record; "
-                                            "a 16 B sub-record only for sites that straddle a record end (HISTORY.md §8)",
-                         "reads_per_launch": reads_per_launch, "avg_launch_ms": search_s * 1e3,
-                         "measured": "HIP events attached to the dispatch (hipExtLaunchKernelGGL), reads resident in HBM leg",
-                         "other_kernels_ms_per_launch": tm["cover_ms"] / max(tm["cover_launches"], 1),
-                         "what_bounds_it": "instruction issue of the wave loop (~58 M VALU + 41 M SALU wave-instructions per launch, VALU "
-                                           "busy 0.59) and the slowest lane of each wave, not HBM bandwidth: round 3 halved the "
-                                           "loop's fetches (8.5 -> 3.3 per lane) and gained 10 % (HISTORY.md §4)",
-                         "issue": {"valu_busy": sq.get("valu_busy"), "active_lane_share": sq.get("active_lane_share"),
-                                   "frac": (sq.get("valu_busy") or 0) * (sq.get("active_lane_share") or 0) or None,
-                                   "iterations_per_wave": sq.get("iterations_per_wave"),
-                                   "heavy_steps_per_lane": sq.get("heavy_steps_per_lane"),
-                                   "source": f"{sq_src} (rocprofv3 --pmc SQ counters + GMX_LOOP_STATS build)"},
-                         "nominal": {"bytes_per_read": b_nominal_kernel, "bytes_per_read_whole_path": B_NOMINAL_PER_READ,
-                                     "achieved": b_nominal_kernel * reads_per_launch / search_s / 1e9 if search_s > 0 else 0.0,
-                                     "note": "SURVEY §8(d) prices a 128 B rank block per base (the reference's algorithm); "
-                                             "exceeds the HBM peak because the kernel does not move those bytes"}},
+            "h2d_rate_GBps": h2d_gbs,
+            "jobs": {"n": len(job_seconds), "seconds": job_seconds, "value_is": "the median job",
+                     "values": [total_reads / x for x in job_seconds]},
+            "roofline": {
+                # what bounds the STEP: the host link. 37.5 B per read cross PCIe once; the kernels of a batch take less than
+                # half of the step (kernel_pipeline), the rest of the time the GPU waits for the next batch's bytes.
+                "bound": "pcie", "achieved": h2d_gbs, "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": h2d_gbs / PCIE_PEAK_GBS,
+                "traffic": int(h2d_per_read * n),
+                "traffic_is": "bytes uploaded per step and GPU (exact: reads x h2d_bytes_per_read; no PMC counter sees the host link)",
+                "peak_source": "MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec), per direction",
+                "step_ms": dt / args.steps * 1e3,
+                "kernels_ms_per_step": side.get("kernel_pipeline", {}).get("ms_per_step"),
+                "dominant_kernel": "gmx_extend_kernel",
+                "kernels": kernel_rooflines,
+            },
             "stats_job": st,
         }
         out.update(side)
@@ -426,6 +585,19 @@ def main():
         # ---- the executable on a FASTQ file -----------------------------------------------------------------------
         n_cli = max(1, min(NB, -(-args.cli_reads // n)))
         out["cli_end_to_end"] = cli_end_to_end(prg, raw[:n_cli], min(os.cpu_count() or 8, 64))
+        # ---- the other BASELINE configurations at full size (their own index, 1 M reads per step) ---------------------
+        del d_reads, d_offs, d_seeds
+        for pk_, sd_ in batches:
+            pk_.close()
+        batches.clear()
+        del qm
+        torch.cuda.empty_cache()
+        out["configs"] = {}
+        for which in [int(x) for x in args.configs.split(",") if x.strip()]:
+            try:
+                out["configs"][str(which)] = config_leg(which, args.config_reads, 6, local_rank, stream)
+            except Exception as exc:  # a leg must not cost the headline
+                out["configs"][str(which)] = {"error": repr(exc)[:300]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prg, reads, np.asarray(seeds))

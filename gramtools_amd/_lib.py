@@ -39,7 +39,8 @@ class QueueCounts(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("search_ms", C.c_double), ("search_launches", C.c_uint64), ("cover_ms", C.c_double),
-                ("cover_launches", C.c_uint64), ("reads", C.c_uint64)]
+                ("cover_launches", C.c_uint64), ("reads", C.c_uint64), ("kernel_ms", C.c_double * 8),
+                ("kernel_launches", C.c_uint64 * 8)]
 
 
 class DepthStats(C.Structure):

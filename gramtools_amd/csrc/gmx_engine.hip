@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
 #include <string>
@@ -3129,6 +3130,10 @@ __global__ void __launch_bounds__(GMX_PACK_THREADS) gmx_pack_kernel(BatchView b,
     }                                                                                      \
   } while (0)
 
+// kernels timed one by one besides gmx_extend_kernel (gmx_timing::kernel_ms; include/gmx.h lists them)
+enum : int { GMX_TK_SEED = 0, GMX_TK_FILTER0, GMX_TK_FILTER1, GMX_TK_SINGLE, GMX_TK_EXTEND2, GMX_TK_UNPACK, GMX_TK_N };
+static_assert(GMX_TK_N <= GMX_TIMED_KERNELS, "gmx_timing::kernel_ms holds GMX_TIMED_KERNELS entries");
+
 struct gmx_engine {
   gmx_engine_opts opts;
   GmxIndexView dview;  // device pointers
@@ -3203,6 +3208,7 @@ struct gmx_engine {
   hipEvent_t ev_fork2 = nullptr, ev_side1 = nullptr, ev_filter = nullptr;
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_wait = nullptr;  // blocking event of gmx_quiesce
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   const uint32_t *d_absent = nullptr;       // the k-mers that do NOT occur, when they are few (gmx_filter_absent_kernel)
@@ -3264,10 +3270,12 @@ struct gmx_engine {
   }
   // optional HIP-event timing of the kernels (bench.py roofline leg)
   bool timing = false;
-  struct EvTriple { hipEvent_t s, a, b, c; uint64_t reads; };
+  struct EvTriple { hipEvent_t s, a, b, c; uint64_t reads; hipEvent_t k[GMX_TIMED_KERNELS][2]; uint32_t timed; };
   std::vector<EvTriple> pending;
   double search_ms = 0, cover_ms = 0;
   uint64_t search_launches = 0, cover_launches = 0, timed_reads = 0;
+  double kernel_ms[GMX_TIMED_KERNELS] = {0};        // gmx_timing::kernel_ms (GMX_TK_*)
+  uint64_t kernel_launches[GMX_TIMED_KERNELS] = {0};
 
   template <class T>
   int alloc(T **p, size_t count, bool zero) {
@@ -3301,6 +3309,43 @@ struct gmx_engine {
     return GMX_OK;
   }
 };
+
+// Host-side wait for an event that costs no core: query, nap, query. hipEventSynchronize — also on an event created with
+// hipEventBlockingSync — kept the calling thread AND a thread of the runtime at 100 % of a core each on the GPU boxes
+// (tools/exp/host_call_cost.py: 1500 back-to-back calls, 1.03 s of wall time, 1.03 s of CPU in each of the two threads), so a
+// feeder that runs ahead of its GPU cost two cores: eight of them, sixteen — the whole container. The nap (50 us) is far
+// below a batch (0.4-3 ms) and three batches are in flight per engine, so the GPU never waits for the host's wake-up.
+// GMX_WAIT_SPIN=1: hipEventSynchronize as before (A/B runs).
+static hipError_t gmx_event_wait(hipEvent_t ev) {
+  static const bool spin = getenv("GMX_WAIT_SPIN") != nullptr;
+  if (spin) return hipEventSynchronize(ev);
+  for (uint32_t polls = 0;; ++polls) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q != hipErrorNotReady) return q;
+    (void)hipGetLastError();  // (hipErrorNotReady is sticky for hipGetLastError)
+    if (polls < 4) continue;  // (a kernel that is about to end: a few immediate queries first)
+    struct timespec ts = {0, 50 * 1000};
+    nanosleep(&ts, nullptr);
+  }
+}
+
+// Wait for the engine's own streams WITHOUT spinning: a blocking event per stream (the thread sleeps until the interrupt).
+// hipStreamSynchronize / hipDeviceSynchronize poll — one core per waiting thread; a node's eight feeder threads, each ahead
+// of its GPU, cost eight cores that way (profiles/round4/feed_x8.txt: 2.5 ns of host CPU per read, 27 cores' worth at
+// 8 x 1.34 G reads/s). The callers still issue their hipDeviceSynchronize afterwards: it then returns at once.
+static int gmx_quiesce(gmx_engine *e) {
+  if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming | hipEventBlockingSync));
+  hipStream_t streams[4] = {e->last_stream, e->copy_stream, e->side_stream, e->side2_stream};
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0 && !streams[i]) continue;  // ([0]: the null stream counts)
+    bool seen = false;
+    for (int j = 0; j < i; ++j) seen = seen || streams[j] == streams[i];
+    if (seen) continue;
+    HIP_TRY(hipEventRecord(e->ev_wait, streams[i]));
+    HIP_TRY(gmx_event_wait(e->ev_wait));
+  }
+  return GMX_OK;
+}
 
 static int flush_reset(gmx_engine *e) {
   if (!e->reset_pending) return GMX_OK;
@@ -3661,6 +3706,7 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_filter) (void)hipEventDestroy(e->ev_filter);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->ev_wait) (void)hipEventDestroy(e->ev_wait);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
   if (e->h_log_state) (void)hipHostFree(e->h_log_state);
   if (e->ev_log_state) (void)hipEventDestroy(e->ev_log_state);
@@ -3704,14 +3750,15 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   return GMX_OK;
 }
 
-static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass) {
+static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass,
+                          hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   if (e->filter_lds_words)
-    hipLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
-                       st, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
+    hipExtLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
+                          st, t0, t1, 0u, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
   else if (e->use_absent)
-    hipLaunchKernelGGL(gmx_filter_absent_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, e->d_absent, e->n_absent, pass);
+    hipExtLaunchKernelGGL(gmx_filter_absent_kernel, task_grid, dim3(GMX_BLOCK), 0, st, t0, t1, 0u, e->dview, b, o, e->d_absent, e->n_absent, pass);
   else
-    hipLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, e->dview, b, o, pass);
+    hipExtLaunchKernelGGL(gmx_filter_kernel, task_grid, dim3(GMX_BLOCK), 0, st, t0, t1, 0u, e->dview, b, o, pass);
 }
 
 // ---- grouped log: exact accounting between batches (engines whose index has sites with more than 8 alleles) ----------
@@ -3935,37 +3982,49 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     HIP_TRY(hipMemsetAsync(e->d_n_final, 0, (size_t)n_tasks * sizeof(uint32_t), stream));
     e->keep_reads = n_reads;
   }
-  if (in.d_planes || in.d_twobit) {
-    hipLaunchKernelGGL(gmx_batch_begin_kernel, dim3(fold_reset ? 256 : 1), dim3(1024), 0, stream, e->d_counters,
-                       fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
-    if (in.d_twobit) {
-      const uint64_t threads = in.uniform_len ? n_reads * ((in.uniform_len + 31u) / 32u) : n_reads;
-      hipLaunchKernelGGL(gmx_unpack2_kernel, dim3((unsigned)std::min<uint64_t>((threads + 255) / 256, 1u << 20)), dim3(256), 0, stream, b, in.d_twobit,
-                         in.twobit_base0, e->d_packed);
-    }
-  } else
-    hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
-                       e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
-  size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
-  const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   gmx_engine::EvTriple ev{};
   if (e->timing) {
     HIP_TRY(hipEventCreate(&ev.s));
     HIP_TRY(hipEventCreate(&ev.a));
     HIP_TRY(hipEventCreate(&ev.b));
     HIP_TRY(hipEventCreate(&ev.c));
+    for (int k = 0; k < GMX_TK_N; ++k) {
+      HIP_TRY(hipEventCreate(&ev.k[k][0]));
+      HIP_TRY(hipEventCreate(&ev.k[k][1]));
+    }
     ev.reads = n_reads;
     HIP_TRY(hipEventRecord(ev.s, stream));
   }
+  // (timing leg: events attached to the dispatches themselves — their own start and end, as a kernel trace sees them)
+  auto t_ev = [&](int k, int side) -> hipEvent_t {
+    if (!e->timing) return nullptr;
+    ev.timed |= 1u << k;
+    return ev.k[k][side];
+  };
+  if (in.d_planes || in.d_twobit) {
+    hipLaunchKernelGGL(gmx_batch_begin_kernel, dim3(fold_reset ? 256 : 1), dim3(1024), 0, stream, e->d_counters,
+                       fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
+    if (in.d_twobit) {
+      const uint64_t threads = in.uniform_len ? n_reads * ((in.uniform_len + 31u) / 32u) : n_reads;
+      hipExtLaunchKernelGGL(gmx_unpack2_kernel, dim3((unsigned)std::min<uint64_t>((threads + 255) / 256, 1u << 20)), dim3(256), 0, stream,
+                            t_ev(GMX_TK_UNPACK, 0), t_ev(GMX_TK_UNPACK, 1), 0u, b, in.d_twobit, in.twobit_base0, e->d_packed);
+    }
+  } else
+    hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
+                       e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
+  size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
+  const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
   const bool seeded = e->dview.kmer_size2 != 0 && !getenv("GMX_NO_SEEDED");  // longer seed table: no probe phase (gmx_seed_kernel)
   if (seeded)
-    hipLaunchKernelGGL(gmx_seed_kernel, dim3((n_tasks + GMX_SEED_THREADS * GMX_SEED_CHUNKS - 1) / (GMX_SEED_THREADS * GMX_SEED_CHUNKS)), dim3(GMX_SEED_THREADS), 0, stream,
-                       e->dview, b, o);
+    hipExtLaunchKernelGGL(gmx_seed_kernel, dim3((n_tasks + GMX_SEED_THREADS * GMX_SEED_CHUNKS - 1) / (GMX_SEED_THREADS * GMX_SEED_CHUNKS)), dim3(GMX_SEED_THREADS), 0, stream,
+                          t_ev(GMX_TK_SEED, 0), t_ev(GMX_TK_SEED, 1), 0u, e->dview, b, o);
   else if (e->seed_cursor)
-    hipLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
+    hipExtLaunchKernelGGL(gmx_probe_kernel<true>, task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, t_ev(GMX_TK_SEED, 0), t_ev(GMX_TK_SEED, 1), 0u, e->dview, b, o,
+                          e->probe_iters);
   else
-    hipLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), lds, stream, e->dview, b, o, e->probe_iters);
+    hipExtLaunchKernelGGL(gmx_probe_kernel<false>, task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, t_ev(GMX_TK_SEED, 0), t_ev(GMX_TK_SEED, 1), 0u, e->dview, b, o,
+                          e->probe_iters);
   // fork 1: the probe kernel's overflow queue (few, long-running tasks) is served by the large-capacity kernel on a
   // side stream while the extend kernel runs, and so is the k-mer filter of the tasks the probe kernel found dead
   // (most reverse-complement tasks; the extend kernel queues its own dead tasks separately)
@@ -3988,7 +4047,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
   }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
-  launch_filter(e, e->side_stream, task_grid, b, o, 0);
+  launch_filter(e, e->side_stream, task_grid, b, o, 0, t_ev(GMX_TK_FILTER0, 0), t_ev(GMX_TK_FILTER0, 1));
   // (timing leg: the events are attached to this very dispatch — its own start and end, as a kernel trace sees them —
   // instead of being recorded around it, where they add the gap to the kernel before and two barrier packets)
   hipEvent_t k0 = e->timing ? ev.a : nullptr, k1 = e->timing ? ev.b : nullptr;
@@ -4007,10 +4066,11 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
       // (the last pass runs to the end, or — nested PRGs — to its cap, beyond which a task goes to the split search)
       const uint32_t budget2 = last ? e->extend_cap : e->extend_budget2[pass];
       const uint32_t pass_arg = pass | (last && e->extend_cap ? 0x80000000u : 0u);
+      hipEvent_t p0 = pass == 0 ? t_ev(GMX_TK_EXTEND2, 0) : nullptr, p1 = pass == 0 ? t_ev(GMX_TK_EXTEND2, 1) : nullptr;
       if (e->seed_cursor)
-        hipLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass_arg);
+        hipExtLaunchKernelGGL((gmx_extend_kernel<true, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, p0, p1, 0u, e->dview, b, o, e->fuse, budget2, pass_arg);
       else
-        hipLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, e->dview, b, o, e->fuse, budget2, pass_arg);
+        hipExtLaunchKernelGGL((gmx_extend_kernel<false, 2>), task_grid, dim3(GMX_BLOCK), (uint32_t)lds, stream, p0, p1, 0u, e->dview, b, o, e->fuse, budget2, pass_arg);
     }
   }
   // fork 2: the extend kernel's overflow queue, then the coverage of everything the large-capacity kernel mapped,
@@ -4020,7 +4080,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
   // the second filter pass (the tasks the extend kernel found dead) comes first here: side 1 is busy with the first pass
   // for most of the batch, and behind the few-lane kernels below it would end after the main stream's last kernel
-  launch_filter(e, e->side2_stream, task_grid, b, o, 1);
+  launch_filter(e, e->side2_stream, task_grid, b, o, 1, t_ev(GMX_TK_FILTER1, 0), t_ev(GMX_TK_FILTER1, 1));
   // the extend kernel's overflow queue (and the tasks whose instances ran out of their pools): the 16-lane split search
   // first, one lane with a whole slot for what that leaves
   static const bool split2 = getenv("GMX_NO_SPLIT2") == nullptr;
@@ -4049,16 +4109,18 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   //  locality of the accumulator and table lines: at configs[3] the kernel took 508 us instead of 436 plus 120 us of sorting, at
   //  configs[4] 646 instead of 611: neighbouring lanes then hit the SAME accumulator words and their atomics serialise. Dropped.)
   if (e->dview.is_nested) {
-    hipLaunchKernelGGL(gmx_cover_single_kernel<true>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+    hipExtLaunchKernelGGL(gmx_cover_single_kernel<true>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, t_ev(GMX_TK_SINGLE, 0), t_ev(GMX_TK_SINGLE, 1), 0u,
+                          e->dview, b, o, acc);
   } else if (e->cover_jump) {  // most sites have geometry records: the lean kernel, then the few records it declined
     // (Measured and dropped: this kernel over the records queued by then BESIDE the extend kernel's passes over the stragglers,
     //  those moved to side 1 — at configs[3] the passes then took 335 us instead of 165 and the batch 1.13 ms instead of 1.07:
     //  the two kernels wait for the same thing, the memory system's rate of scattered accesses.)
-    hipLaunchKernelGGL(gmx_cover_jump_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), GMX_STAGE_MAX * GMX_BLOCK * sizeof(uint32_t), stream, e->dview,
-                       b, o, acc);
+    hipExtLaunchKernelGGL(gmx_cover_jump_kernel, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), (uint32_t)(GMX_STAGE_MAX * GMX_BLOCK * sizeof(uint32_t)), stream,
+                          t_ev(GMX_TK_SINGLE, 0), t_ev(GMX_TK_SINGLE, 1), 0u, e->dview, b, o, acc);
     hipLaunchKernelGGL(gmx_cover_single_rest_kernel, dim3(e->n_cus * 2), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
   } else {
-    hipLaunchKernelGGL(gmx_cover_single_kernel<false>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, e->dview, b, o, acc);
+    hipExtLaunchKernelGGL(gmx_cover_single_kernel<false>, dim3(task_grid.x * GMX_REGIONS), dim3(GMX_BLOCK), 0, stream, t_ev(GMX_TK_SINGLE, 0), t_ev(GMX_TK_SINGLE, 1), 0u,
+                          e->dview, b, o, acc);
   }
   // The batch's last coverage instance (1: what exceeded the regular scratch; its last block also serves the last tier,
   // whose search keeps its first pending entries in LDS) needs every other instance done except gmx_cover_single_kernel,
@@ -4156,12 +4218,12 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
     const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
     const uint64_t b0 = offsets[done], bases = offsets[done + n] - b0;
     if (sl.busy) {  // the chunk that used this slot two rounds ago
-      if (!hip_ok(hipEventSynchronize(sl.done), "hipEventSynchronize")) break;
+      if (!hip_ok(gmx_event_wait(sl.done), "hipEventSynchronize")) break;
       sl.busy = false;
     }
     if (!sl.copied) {
-      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate") ||
-          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate"))
+      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate") ||
+          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate"))
         break;
     }
     if (bases > sl.cap_bases) {  // (the slot is idle: its superseded buffer can go at once)
@@ -4327,12 +4389,12 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
       twobit_base0 = (uint32_t)(b0 & 31u);
     }
     if (sl.busy) {  // the batch that used this slot three chunks ago
-      if (!hip_ok(hipEventSynchronize(sl.done), "hipEventSynchronize")) break;
+      if (!hip_ok(gmx_event_wait(sl.done), "hipEventSynchronize")) break;
       sl.busy = false;
     }
     if (!sl.copied) {
-      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming), "hipEventCreate") ||
-          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), "hipEventCreate"))
+      if (!hip_ok(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate") ||
+          !hip_ok(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync), "hipEventCreate"))
         break;
     }
     if (pairs + 16 > sl.cap_pairs) {  // (+ slack: the kernels fetch whole 16-byte pieces and one pair ahead)
@@ -4422,7 +4484,11 @@ int gmx_engine_sync_uploads(gmx_engine *e) {
     return GMX_EINVAL;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
-  if (e->copy_stream) HIP_TRY(hipStreamSynchronize(e->copy_stream));
+  if (e->copy_stream) {  // (sleeping, not polling: gmx_quiesce)
+    if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming | hipEventBlockingSync));
+    HIP_TRY(hipEventRecord(e->ev_wait, e->copy_stream));
+    HIP_TRY(gmx_event_wait(e->ev_wait));
+  }
   return GMX_OK;
 }
 
@@ -4527,8 +4593,8 @@ int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs)
   for (auto &sl : e->pslot) {
     if (sl.busy) continue;
     if (!sl.copied) {
-      HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming | hipEventBlockingSync));
+      HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync));
     }
     if (n_pairs + 16 > sl.cap_pairs) {
       e->release(sl.d_planes);
@@ -4560,6 +4626,10 @@ int gmx_engine_sync(gmx_engine *e) {
     int frc = flush_reset(e);
     if (frc) return frc;
     if ((frc = log_settle(e))) return frc;
+  }
+  {
+    int qrc = gmx_quiesce(e);
+    if (qrc) return qrc;
   }
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
@@ -4613,6 +4683,17 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
     e->search_launches++;
     e->cover_launches++;
     e->timed_reads += ev.reads;
+    for (int k = 0; k < GMX_TK_N; ++k) {
+      if (ev.timed & (1u << k)) {  // (events of other streams: complete, ev.c is behind the batch's join)
+        float ms = 0;
+        HIP_TRY(hipEventSynchronize(ev.k[k][1]));
+        HIP_TRY(hipEventElapsedTime(&ms, ev.k[k][0], ev.k[k][1]));
+        e->kernel_ms[k] += ms;
+        e->kernel_launches[k]++;
+      }
+      (void)hipEventDestroy(ev.k[k][0]);
+      (void)hipEventDestroy(ev.k[k][1]);
+    }
     (void)hipEventDestroy(ev.s);
     (void)hipEventDestroy(ev.a);
     (void)hipEventDestroy(ev.b);
@@ -4624,6 +4705,12 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
   out->cover_ms = e->cover_ms;
   out->cover_launches = e->cover_launches;
   out->reads = e->timed_reads;
+  for (int k = 0; k < GMX_TIMED_KERNELS; ++k) {
+    out->kernel_ms[k] = e->kernel_ms[k];
+    out->kernel_launches[k] = e->kernel_launches[k];
+    e->kernel_ms[k] = 0;
+    e->kernel_launches[k] = 0;
+  }
   e->search_ms = e->cover_ms = 0;
   e->search_launches = e->cover_launches = e->timed_reads = 0;
   return GMX_OK;

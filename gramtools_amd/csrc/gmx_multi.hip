@@ -23,8 +23,35 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+
 #include "../../include/gmx.h"
 #include "gmx_internal.h"
+
+// One feeder thread per GPU, each on a core of its own (the i-th CPU the process may run on): a feeder is a short burst of
+// launches per batch and then sleeps on its slot event (gmx_engine.hip: blocking events); kept on one core it does not
+// chase the parser threads around the socket. GMX_PIN_FEEDERS=0 switches the pinning off. The reference's unit of
+// parallelism for context: one OpenMP loop over the reads of a batch (quasimap.cpp:90).
+static void gmx_pin_feeder(size_t i) {
+  static const bool on = !(getenv("GMX_PIN_FEEDERS") && getenv("GMX_PIN_FEEDERS")[0] == '0');
+  if (!on) return;
+  cpu_set_t allowed;
+  CPU_ZERO(&allowed);
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return;
+  const int n_allowed = CPU_COUNT(&allowed);
+  if (n_allowed < 2) return;
+  int want = (int)(i % (size_t)n_allowed), seen = 0;
+  for (int c = 0; c < CPU_SETSIZE; ++c) {
+    if (!CPU_ISSET(c, &allowed)) continue;
+    if (seen++ == want) {
+      cpu_set_t one;
+      CPU_ZERO(&one);
+      CPU_SET(c, &one);
+      (void)sched_setaffinity(0, sizeof(one), &one);
+      return;
+    }
+  }
+}
 
 #define HIP_TRY(expr)                                                       \
   do {                                                                      \
@@ -385,6 +412,7 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
     const uint64_t p0 = pair_at(lo);
     th.emplace_back([=, &rcs, &errs]() {
       if (cnt == 0) return;
+      gmx_pin_feeder(i);
       rcs[i] = gmx_map_reads_packed_host(g->ms[i].e, planes + p0, offsets ? offsets + lo : nullptr, uniform_len, seeds + lo,
                                          skip ? skip + lo : nullptr, cnt);
       if (rcs[i]) errs[i] = gmx_last_error();

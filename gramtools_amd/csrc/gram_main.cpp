@@ -394,6 +394,13 @@ struct FeedTimes {
 };
 static FeedTimes g_feed;
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// GMX_PHASE_TRACE=1 in the environment: where a whole `gram genotype` call spends its wall time, on stderr — milliseconds
+// since main() was entered (the dynamic loader's part of the call comes before that; tools/cli_phases.sh adds it).
+static const double g_phase_t0 = now_s();
+static inline void phase(const char *what) {
+  static const bool on = getenv("GMX_PHASE_TRACE") != nullptr;
+  if (on) fprintf(stderr, "[phase %9.2f ms] %s\n", (now_s() - g_phase_t0) * 1e3, what);
+}
 // Parses the complete four-line records of d[0, size). When `final` is false a record that is not complete within
 // the buffer ends the parse (`consumed` = its start), so that a stream can be parsed block by block.
 // Returns false on anything that is not plain four-line FASTQ.
@@ -1165,8 +1172,10 @@ int run_genotype(const Args &a) {
   mkdirs(geno_dir);
 
   std::cout << "Executing genotype command" << std::endl;
+  phase("arguments parsed, output directories made");
   ReadStats rs;
   compute_base_error_rate(reads_paths[0], rs);  // genotype.cpp:32-34
+  phase("base error rate of the first 10 000 reads");
 
   auto t0 = clk::now();
   // Beside the index load: the page-locked buffers the reads feed will ask for (two parsed blocks in flight: bases,
@@ -1195,6 +1204,7 @@ int run_genotype(const Args &a) {
     else
       GMX_CHECK(gmx_index_build_from_file(join(gram_dir, "prg").c_str(), kmer_size, max_threads, &ix));
   }
+  phase("index loaded (host)");
   gmx_index_info info;
   GMX_CHECK(gmx_index_get_info(ix, &info));
   std::cout << "Loading kmer index data" << std::endl;
@@ -1203,10 +1213,12 @@ int run_genotype(const Args &a) {
   opts.rng_mode = rng_mode;
   gmx_group *grp = nullptr;
   GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
+  phase("engines created (HIP start-up, index upload)");
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
   for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), 1u << 20, (6ull << 20) + 64));
   if (prewarm.joinable()) prewarm.join();
+  phase("workspace reserved, page-locked buffers warmed");
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
   std::cout << "Running quasimap" << std::endl;
@@ -1287,6 +1299,7 @@ int run_genotype(const Args &a) {
   GMX_CHECK(gmx_engine_sync(eng));
   feed_trace("engine synchronised");
   double t_map = std::chrono::duration<double>(clk::now() - t0).count();
+  phase("quasimap done (reads parsed, mapped, coverage exchanged)");
 
   // ---- coverage read-back + uint16 semantics --------------------------------------------------------------
   std::vector<uint32_t> allele_sum(std::max<uint32_t>(info.n_allele_slots, 1)), per_base(std::max<uint32_t>(info.n_per_base_slots, 1)),
@@ -1397,6 +1410,7 @@ int run_genotype(const Args &a) {
     o << "]}}\n";
     close_checked(o, join(cov_dir, "grouped_allele_counts_coverage.json"));
   }
+  phase("coverage files written");
   std::string rs_path = join(run_dir, "read_stats.json");
   std::cout << "Writing read stats to " << rs_path << std::endl;
   write_read_stats(rs_path, rs);
@@ -1432,6 +1446,7 @@ int run_genotype(const Args &a) {
     o.write(text.data(), std::max<int64_t>(n, 0));
     close_checked(o, dbg_path);
   }
+  phase("genotyping model run");
   std::cout << "Producing json vcf" << std::endl;
   GMX_CHECK(gmx_infer_write_json(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.json").c_str()));
   std::cout << "Producing personalised reference" << std::endl;
@@ -1440,9 +1455,11 @@ int run_genotype(const Args &a) {
   std::cout << "Producing vcf" << std::endl;
   GMX_CHECK(gmx_infer_write_vcf(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.vcf.gz").c_str()));
   gmx_infer_destroy(inf);
+  phase("jVCF, personalised reference and VCF written");
   std::cout << "  Genotyping: " << std::chrono::duration<double>(clk::now() - t_inf).count() << std::endl;
   gmx_group_destroy(grp);
   gmx_index_destroy(ix);
+  phase("engines and index destroyed");
   return 0;
 }
 

@@ -533,8 +533,10 @@ class Quasimapper:
         """HIP-event time of the kernels since the last call: dict(search_ms, search_launches, cover_ms, ..., reads)."""
         t = _lib.Timing()
         check(self.lib.gmx_engine_timing(self.h, C.byref(t)))
+        names = ("seed", "filter0", "filter1", "single", "extend2", "unpack")
+        kernels = {nm: dict(ms=t.kernel_ms[i], launches=int(t.kernel_launches[i])) for i, nm in enumerate(names)}
         return dict(search_ms=t.search_ms, search_launches=t.search_launches, cover_ms=t.cover_ms,
-                    cover_launches=t.cover_launches, reads=t.reads)
+                    cover_launches=t.cover_launches, reads=t.reads, kernels=kernels)
 
     def device_coverage(self):
         dc = _lib.DeviceCoverage()

@@ -215,10 +215,17 @@ int gmx_engine_sync(gmx_engine *e);
  * gmx_engine_timing() (call after gmx_engine_sync) returns the accumulated milliseconds and launch counts since
  * the last call and resets them. */
 int gmx_engine_enable_timing(gmx_engine *e, int on);
+#define GMX_TIMED_KERNELS 8
 typedef struct gmx_timing {
   double search_ms;  uint64_t search_launches;   /* gmx_extend_kernel (the dominant kernel) */
   double cover_ms;   uint64_t cover_launches;    /* everything else: validate, probe, big pass, filter, coverage, stats */
   uint64_t reads;                                /* reads covered by those launches */
+  /* further kernels, each with events attached to its own dispatch (start / end of that kernel alone, whichever stream):
+   * [0] gmx_seed_kernel (gmx_probe_kernel without a longer seed table)   [1] k-mer filter, pass 0   [2] k-mer filter, pass 1
+   * [3] the single-instance coverage kernel (gmx_cover_jump_kernel; gmx_cover_single_kernel on nested PRGs or with
+   *     GMX_NO_COVER_JUMP)   [4] gmx_extend_kernel's first pass over the stragglers   [5] gmx_unpack2_kernel (2-bit feed) */
+  double kernel_ms[GMX_TIMED_KERNELS];
+  uint64_t kernel_launches[GMX_TIMED_KERNELS];
 } gmx_timing;
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
 

@@ -15,7 +15,7 @@ import torch
 
 torch.cuda.init()
 sys.path.insert(0, ".")
-from gramtools_amd import Index, QuasimapperGroup, Quasimapper, master_seeds, pack_reads  # noqa: E402
+from gramtools_amd import Index, QuasimapperGroup, Quasimapper, master_seeds, pack_reads, PinnedArray  # noqa: E402
 from gramtools_amd.synth import flat_offsets, random_ref, simulate_snp_reads, snp_prg  # noqa: E402
 from gramtools_amd.build import build_gram  # noqa: E402
 from oracle.prg_text import ints_to_prg_bytes  # noqa: E402  (tool: writes gram_dir/prg)
@@ -30,7 +30,9 @@ ix = Index(prg, k)
 n = N * per
 reads = simulate_snp_reads(ref, pos, alts, n_alts, min(n, 2_000_000), 150, 1000)
 reads = np.concatenate([reads] * (-(-n // reads.shape[0])))[:n]
-seeds = master_seeds(42, [n])
+_sd = PinnedArray(n, np.uint32)  # page-locked like the planes (round 5: pageable seeds were registered and unregistered by every
+_sd.array[:] = master_seeds(42, [n])  # call — 1 ms of host CPU per 1 M reads that round 4's figures included)
+seeds = _sd.array
 offs = flat_offsets(n, 150)
 pk = pack_reads(np.ascontiguousarray(reads).reshape(-1), offs, uniform_len=150, pinned=True)
 
@@ -40,16 +42,38 @@ def cpu_seconds():
     return r.ru_utime + r.ru_stime
 
 
+def thread_times():
+    """CPU seconds per thread of this process (feeder threads come and go per call: summed by name is not possible, so the
+    runtime's long-lived threads are listed and the rest — the feeders — is the difference to the process total)"""
+    out = {}
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            f = open(f"/proc/self/task/{tid}/stat").read()
+            rest = f[f.rindex(")") + 2:].split()
+            out[int(tid)] = (int(rest[11]) + int(rest[12])) / os.sysconf("SC_CLK_TCK")
+        except OSError:
+            pass
+    return out
+
+
 for n_eng in sorted({1, 2, N}):
     grp = QuasimapperGroup(ix, [0] * n_eng)
     m = n_eng * per
     sub = pk if m == n else pack_reads(np.ascontiguousarray(reads[:m]).reshape(-1), flat_offsets(m, 150), uniform_len=150, pinned=True)
     for rep in range(2):
+        th0 = thread_times()
         c0, t0 = cpu_seconds(), time.perf_counter()
         for _ in range(steps):
             grp.map_reads_packed(sub, seeds[:m], use_skip=False)
         grp.allreduce()
         dt, cpu = (time.perf_counter() - t0) / steps, (cpu_seconds() - c0) / steps
+        th1 = thread_times()
+    lived = sorted(((th1[t] - th0[t]) / steps for t in th1 if t in th0 and t != os.getpid()), reverse=True)
+    runtime_thread = lived[0] if lived else 0.0  # the HIP runtime's event thread: busy whenever work is in flight, ONE per process
+    print(f"   of which: the runtime's busiest long-lived thread {runtime_thread * 1e3:.2f} ms per step (a cost per second of wall time and PROCESS, "
+          f"not per read), the calling thread {(th1[os.getpid()] - th0[os.getpid()]) / steps * 1e3:.2f} ms, feeder threads + rest "
+          f"{(cpu - runtime_thread - (th1[os.getpid()] - th0[os.getpid()]) / steps) * 1e3:.2f} ms per step = "
+          f"{(cpu - runtime_thread) / m * 1e9:.2f} ns per read without the runtime thread", flush=True)
     print(f"{n_eng} engine(s) on device 0, {per} reads each per step: {dt * 1e3:.2f} ms per step = {m / dt / 1e6:.0f} M reads/s aggregate, "
           f"H2D {m * 40 / dt / 1e9:.1f} GB/s (40 B per read as planes), host CPU {cpu * 1e3:.1f} ms per step = {cpu / m * 1e9:.1f} ns per read", flush=True)
     grp.close()
@@ -72,7 +96,7 @@ for devs in ("0", ",".join(["0"] * N)):
         c0 = resource.getrusage(resource.RUSAGE_CHILDREN)
         out = subprocess.run([gram, "genotype", "--gram_dir", d, "--reads", fq, "--sample_id", "s", "--ploidy", "haploid", "--kmer_size", str(k),
                               "--genotype_dir", os.path.join(d, "run"), "--max_threads", "64", "--seed", "42", "--devices", devs],
-                             stdout=subprocess.PIPE, text=True, env={"LD_LIBRARY_PATH": "", "GMX_FEED_TRACE": ""})
+                             stdout=subprocess.PIPE, text=True, env={"LD_LIBRARY_PATH": ""})
         c1 = resource.getrusage(resource.RUSAGE_CHILDREN)
         wall = time.perf_counter() - t0
     line = [x for x in out.stdout.splitlines() if "quasimap" in x.lower() or "reads/s" in x.lower()]
