@@ -409,9 +409,13 @@ class GzSource {
       const size_t expect = par_chunk_ * 6;  // (FASTQ inflates 3-5x; the buffer grows if that is not enough)
       if (pc.known_window) pc.sym.init_known(par_window_.data(), par_window_.size(), expect);
       else pc.sym.init_unknown(expect);
-      decode_piece(base, end, pc, soft);
+      decode_piece(base, end, pc, soft, par_chunk_ * 32);  // (FASTQ inflates 3-5x; 32x covers any text worth the name)
     });
     const double t2 = now();
+    if (!pcs[0].ok && pcs[0].capped) {  // not damage: more output per compressed byte than the pieces may hold: zlib from here
+      par_to_zlib();
+      return 0;
+    }
     if (!pcs[0].ok) fail("damaged gzip stream (deflate data at byte " + std::to_string(byte0) + ")");
     size_t n_valid = 1;
     while (n_valid < pcs.size() && !pcs[n_valid - 1].final && pcs[n_valid].ok && pcs[n_valid - 1].end_bit == pcs[n_valid].start_bit) ++n_valid;

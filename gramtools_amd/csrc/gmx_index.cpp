@@ -11,6 +11,7 @@
 #include <memory>
 #include <cstring>
 #include <fstream>
+#include <sys/stat.h>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -1875,8 +1876,11 @@ struct Writer {
 struct Reader {
   FILE *f;
   Checksum sum;
+  uint64_t left = ~0ull;  // bytes of the file not read yet: no table can be larger (a damaged count must not map 256 GB first)
   void raw(void *p, size_t n) {
+    if (n > left) throw std::runtime_error("index cache: truncated file");
     if (n && fread(p, 1, n, f) != n) throw std::runtime_error("index cache: truncated file");
+    left -= n;
     sum.add(p, n);
   }
   template <class T>
@@ -1887,14 +1891,14 @@ struct Reader {
   void vec(std::vector<T, A> &v, uint64_t max_elems = (1ull << 36)) {
     uint64_t n = 0;
     pod(n);
-    if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
+    if (n > max_elems || n > left / sizeof(T)) throw std::runtime_error("index cache: implausible table size");
     v.resize(n);
     raw(v.data(), n * sizeof(T));
   }
   void vec(WordBuf &v, uint64_t max_elems = (1ull << 36)) {
     uint64_t n = 0;
     pod(n);
-    if (n > max_elems) throw std::runtime_error("index cache: implausible table size");
+    if (n > max_elems || n > left / sizeof(uint32_t)) throw std::runtime_error("index cache: implausible table size");
     v.resize(n);
     const size_t piece = (size_t)1 << 28;
     for (size_t at = 0; at < n; at += piece) raw(v.data() + at, std::min<size_t>(piece, n - at) * sizeof(uint32_t));
@@ -1980,6 +1984,10 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
   if (!f) throw std::runtime_error("index cache: cannot open " + path);
   try {
     Reader r{f};
+    {
+      struct stat st;
+      if (fstat(fileno(f), &st) == 0 && st.st_size >= 0) r.left = (uint64_t)st.st_size;
+    }
     uint64_t magic = 0, n_prg = 0, hash = 0;
     uint32_t version = 0, nested = 0;
     r.pod(magic);
@@ -2023,7 +2031,9 @@ void load_index(const std::string &path, const std::vector<uint32_t> &prg, uint3
     if (out.sa.size() != prg.size() + 1 || out.pos_node.size() != prg.size() || out.text.size() != prg.size() / 64 + 1 ||
         out.seeds.size() != (kmer_size ? (1ull << (2 * kmer_size)) : 0) ||
         out.seeds2.size() != (out.kmer_size2 ? (1ull << (2 * out.kmer_size2)) : 0) || out.kmer_size2 > 15 || out.nodes.empty() || out.phys_allele.size() != out.n_allele_slots ||
-        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0 || out.site_ref_pos.size() != out.sites.size())
+        out.phys_pb.size() != out.n_pb_slots || out.phys_grouped.size() != out.n_grouped_slots || out.hit_fix.size() % 4 != 0 || out.site_ref_pos.size() != out.sites.size() ||
+        out.site_geo.size() != out.sites.size() ||  // (the kernels index site_geo by site: a shorter table is an out-of-bounds device read)
+        (out.seed_words.size() >> out.seed_shift) >= (1ull << 30))  // (entry offsets are 30-bit units of 2^seed_shift words)
       throw std::runtime_error("index cache: inconsistent tables");
   } catch (...) {
     fclose(f);

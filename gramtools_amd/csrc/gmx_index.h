@@ -88,6 +88,11 @@ typedef std::vector<GmxSeed, BigAlloc<GmxSeed>> SeedTable;
 // appending never holds a second copy (a std::vector's reallocation does, and round 3's builder kept the parts AND their
 // joined copy: its host peak was what kept the 85 M-site PRG from being built inside the container's 300 GiB). Words are
 // not initialised (the writer writes every one); mapped but untouched capacity costs nothing.
+// Failure mode (documented, not hidden): the mapping is MAP_NORESERVE — capacity is address space, not a promise of memory —
+// so a host that runs out of memory while the words are WRITTEN kills the process (SIGBUS / the OOM killer), it does not
+// raise bad_alloc / GMX_ENOMEM as the vectors around it do. The whole-genome build sizes this buffer at 80+ GB inside a
+// 300 GiB container (212 GiB peak); reserving it up front would double-count against overcommit limits that
+// count reservations. The cache reader bounds a table by the bytes left in the file before it maps anything (gmx_index.cpp).
 class WordBuf {
  public:
   WordBuf() = default;

@@ -259,16 +259,22 @@ struct Symbols {
     }
   } v;
   size_t n = kWindow;
+  // symbols of the window that stand for real history: all of it for a piece inside the stream (placeholders of the bytes
+  // before it), only the bytes the member has produced so far for its first piece. A back-reference beyond them reaches
+  // before the start of the member: zlib rejects that ("invalid distance too far back"), and so does decode_block.
+  size_t hist = kWindow;
   void init_unknown(size_t expect = (size_t)1 << 20) {
     if (v.size() < kWindow + expect) v.grow(kWindow + expect, 0);
     for (uint32_t j = 0; j < kWindow; ++j) v[j] = (uint16_t)(kUnknown + j);
     n = kWindow;
+    hist = kWindow;
   }
   void init_known(const uint8_t *win, size_t have, size_t expect = (size_t)1 << 20) {  // the last `have` (<= kWindow) bytes before the piece
     if (v.size() < kWindow + expect) v.grow(kWindow + expect, 0);
     for (uint32_t j = 0; j < kWindow; ++j) v[j] = 0;
     for (size_t j = 0; j < have; ++j) v[kWindow - have + j] = win[j];
     n = kWindow;
+    hist = have;
   }
   inline void room(size_t more) {
     if (n + more > v.size()) v.grow(std::max(v.size() + v.size() / 2, n + more + (1u << 16)), n);
@@ -310,6 +316,7 @@ inline BlockEnd decode_block_t(Bits &in, Symbols &out, size_t max_out) {
     bc = &dyn;
   }
   const size_t limit = max_out ? kWindow + max_out : ~(size_t)0;
+  const size_t hist = out.hist;
   const uint16_t *const lit_fast = bc->lit.fast;
   // (the bit reader as a local whose address never leaves this function: its words stay in registers; through the
   //  reference every step was a store and a reload)
@@ -351,7 +358,7 @@ inline BlockEnd decode_block_t(Bits &in, Symbols &out, size_t max_out) {
     const uint32_t ds = bc->dist.decode(in);
     if (ds > 29) return BlockEnd::Bad;
     const uint32_t dist = kDistBase[ds] + in.get(kDistExtra[ds]);
-    if (dist > n) return BlockEnd::Bad;  // (cannot happen with the window in front; kept for safety)
+    if (dist > n - (kWindow - hist)) return BlockEnd::Bad;  // too far back: before the member's first byte (Symbols::hist)
     uint16_t *dst = base + n;
     const uint16_t *src = dst - dist;
     if (dist >= 4) {  // four symbols per copy (the source chunk ends before the destination chunk starts); up to 3 symbols
@@ -415,6 +422,7 @@ inline uint64_t find_block(const uint8_t *base, const uint8_t *end, uint64_t fro
 struct Piece {
   uint64_t start_bit = 0, stop_bit = 0, end_bit = 0;  // from, where the next piece starts (~0: open end), where decoding ended
   bool known_window = false, ok = false, final = false;
+  bool capped = false;  // gave up because the output passed the per-piece bound (not damage: zlib takes the member over)
   Symbols sym;
   uint32_t crc = 0;
   size_t out_at = 0;
@@ -422,12 +430,18 @@ struct Piece {
 
 // Decodes from start_bit, block by block, until a block ends at or beyond stop_bit (or the final block ends, or, with an
 // open end, once `soft_limit_bit` is passed).
-inline void decode_piece(const uint8_t *base, const uint8_t *end, Piece &pc, uint64_t soft_limit_bit) {
+// `max_out`: bound on the piece's output symbols (two bytes each in memory) — a crafted stream inflates 1000-fold, and every
+// thread would grow its buffer without limit; a piece that passes the bound is marked `capped`.
+inline void decode_piece(const uint8_t *base, const uint8_t *end, Piece &pc, uint64_t soft_limit_bit, size_t max_out) {
   Bits in(base, end, pc.start_bit);
   pc.ok = false;
+  pc.capped = false;
   for (;;) {
-    const BlockEnd r = decode_block(in, pc.sym, false, 0);
-    if (r == BlockEnd::Bad) return;
+    const BlockEnd r = decode_block(in, pc.sym, false, max_out);
+    if (r == BlockEnd::Bad) {
+      pc.capped = max_out != 0 && pc.sym.out_size() > max_out;
+      return;
+    }
     pc.end_bit = in.bit_pos();
     if (r == BlockEnd::Final) {
       pc.final = true;

@@ -1109,6 +1109,7 @@ int run_genotype(const Args &a) {
   // --device N, or --devices 0-7 / 0,2,5: one engine and one host thread per listed GPU, reads dealt by read index,
   // coverage summed at the end (gmx.h: gmx_group_*). The result does not depend on the number of GPUs.
   std::vector<int> devices;
+  bool devices_auto = false;  // the list below was chosen here, not named by the caller
   if (a.has("devices")) {
     std::string spec = a.one("devices");
     size_t i = 0;
@@ -1136,6 +1137,7 @@ int run_genotype(const Args &a) {
     // reads (default 2048 MB of FASTQ, a quarter of that gzipped: ~6 M reads of 150 bp; below it a second index upload costs
     // more than it saves). GMX_AUTO_DEVICES=0 keeps device 0, =N takes at most N.
     devices.push_back(0);
+    devices_auto = true;
     int n_vis = gmx_device_count();
     if (const char *ad = getenv("GMX_AUTO_DEVICES")) n_vis = std::min(n_vis, std::max(1, atoi(ad)));
     if (n_vis > 1) {
@@ -1212,7 +1214,29 @@ int run_genotype(const Args &a) {
   gmx_engine_default_opts(&opts);
   opts.rng_mode = rng_mode;
   gmx_group *grp = nullptr;
-  GMX_CHECK(gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp));
+  {
+    int grc = gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp);
+    if (grc != GMX_OK && devices_auto && devices.size() > 1) {
+      // The list was OUR choice (neither --device nor --devices: every visible GPU for a large reads file). A busy or full
+      // secondary GPU on a shared node must not fail a run that device 0 alone — the default before the auto-choice
+      // existed — would have completed: the devices that do come up, at least device 0. Named devices stay a hard failure.
+      std::cerr << "warning: not every visible GPU could be used (" << gmx_last_error() << "); ";
+      std::vector<int> usable;
+      for (int d : devices) {
+        gmx_group *one = nullptr;
+        if (d == 0 || gmx_group_create(ix, &opts, &d, 1, &one) == GMX_OK) usable.push_back(d);
+        if (one) gmx_group_destroy(one);
+      }
+      std::cerr << "continuing on " << usable.size() << " of " << devices.size() << " devices" << std::endl;
+      devices = usable;
+      grc = gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp);
+      if (grc != GMX_OK && devices.size() > 1) {
+        devices.assign(1, 0);
+        grc = gmx_group_create(ix, &opts, devices.data(), 1, &grp);
+      }
+    }
+    GMX_CHECK(grc);
+  }
   phase("engines created (HIP start-up, index upload)");
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)

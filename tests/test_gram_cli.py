@@ -421,3 +421,53 @@ def test_damaged_plain_gzip_is_fatal_with_the_parallel_decoder(tmp_path, monkeyp
     path.write_bytes(bytes(d))
     out = subprocess.run([build_gram(), "_parse_check", str(path), "5"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode != 0, out.stdout
+
+
+def test_parallel_gzip_bounds_its_pieces_and_rejects_distances_before_the_member(tmp_path, monkeypatch):
+    """(round 5, ADVICE) (a) A stream that inflates more than 32-fold per piece — one read repeated — is not damage: the
+    parallel decoder stops at its per-piece bound and zlib takes the member over from the last verified bit; the reads are
+    those of the plain file. (b) A back-reference that reaches before the first byte of a member is rejected as zlib
+    rejects it ("invalid distance too far back"), not resolved to zero bytes."""
+    import subprocess
+    import zlib
+    from gramtools_amd.build import build_gram
+    monkeypatch.setenv("GMX_PARGZ_MIN", "1000")
+    monkeypatch.setenv("GMX_PARGZ_CHUNK", "4000")
+    one = _fastq_text(1, 41)
+    text = one * 30000          # ~10 MB that deflate packs ~300-fold: far beyond 32 x 4000 bytes per piece
+    binary = _gz(text.encode(), 9)
+    assert len(text) > 100 * len(binary)
+    (tmp_path / "rep.fastq.gz").write_bytes(binary)
+    out = subprocess.run([build_gram(), "_gz_info", str(tmp_path / "rep.fastq.gz"), "6"], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0, out.stdout
+    info = dict(kv.split("=") for kv in out.stdout.split())
+    assert int(info["bytes"]) == len(text.encode()) and int(info["crc"]) == zlib.crc32(text.encode())
+    assert int(info["stream_bytes"]) > len(text) // 2   # zlib did the work
+    _same_as_plain(tmp_path, text, binary)
+    # (b) a raw deflate stream whose first block copies 10 bytes from distance 5 with nothing in front: fixed-Huffman block,
+    # length code 264 (len 10), distance code 4 (dist 5): built bit by bit
+    bits = []
+
+    def put(value, n, msb_first=False):
+        for i in (range(n - 1, -1, -1) if msb_first else range(n)):
+            bits.append((value >> i) & 1)
+    put(0, 1)            # BFINAL = 0
+    put(1, 2)            # BTYPE = 01 fixed
+    put(0b0001000, 7, True)   # length symbol 264 (7-bit code 0001000): length 10
+    put(0b00100, 5, True)     # distance symbol 4: distance 5, one extra bit
+    put(0, 1)
+    put(0, 7, True)      # end of block (256)
+    put(0, 1)            # an empty stored block: BFINAL = 0, BTYPE = 00, padding to the byte, LEN = 0, NLEN = 0xFFFF
+    put(0, 2)
+    while len(bits) % 8:
+        bits.append(0)
+    raw = bytes(sum(b << i for i, b in enumerate(bits[j:j + 8])) for j in range(0, len(bits), 8)) + b"\x00\x00\xff\xff"
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    raw += c.compress(_fastq_text(6000, 42).encode()) + c.flush()   # the rest of the member: ordinary deflate blocks, > 100 KB
+    with pytest.raises(zlib.error, match="too far back"):
+        zlib.decompress(raw, -15)
+    member = b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + raw + (0).to_bytes(4, "little") + (10).to_bytes(4, "little")
+    assert len(member) > 50_000   # large enough for the parallel decoder (GMX_PARGZ_MIN = 1000): ITS first piece must refuse
+    (tmp_path / "far.fastq.gz").write_bytes(member)
+    out = subprocess.run([build_gram(), "_parse_check", str(tmp_path / "far.fastq.gz"), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode != 0, out.stdout
