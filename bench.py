@@ -189,6 +189,26 @@ def cli_end_to_end(prg, batches, threads):
                 if line.strip().startswith("feed:"):
                     feed = line.strip()
             runs.append(dict(parse_and_map_s=t_map, whole_call_s=t_all, index_load_s=t_load, feed=feed))
+        # many samples on one index upload (`--samples_list`, round 5): the same FASTQ as 8 samples of one call
+        n_smp = 8
+        with open(os.path.join(d, "samples.tsv"), "w") as fh:
+            for i in range(n_smp):
+                fh.write(f"s{i}\t{os.path.join(d, 'multi', f's{i}')}\t{fq}\n")
+        t0 = time.time()
+        m = subprocess.run([gram, "genotype", "--gram_dir", d, "--samples_list", os.path.join(d, "samples.tsv"), "--ploidy", "haploid",
+                            "--kmer_size", str(KMER), "--max_threads", str(threads), "--seed", "42"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True)
+        t_multi = time.time() - t0
+        multi = {"samples": n_smp, "whole_call_s": t_multi, "per_sample_s": t_multi / n_smp, "rc": m.returncode,
+                 "same_files_as_a_call_of_its_own": None}
+        if m.returncode == 0:
+            same = True
+            # (the genotype/ files carry the sample's name; tests/test_gram_cli.py compares all seven files with equal names)
+            for name in ("coverage/allele_sum_coverage", "coverage/allele_base_coverage.json", "coverage/grouped_allele_counts_coverage.json",
+                         "read_stats.json"):
+                a = open(os.path.join(d, "run1", name), "rb").read()
+                same = same and all(open(os.path.join(d, "multi", f"s{i}", name), "rb").read() == a for i in (0, n_smp - 1))
+            multi["same_files_as_a_call_of_its_own"] = same
         n = sum(r.shape[0] for r in batches)
         best = min(runs, key=lambda r: r["parse_and_map_s"] or 1e30)
         t_map, t_all, t_load, feed = best["parse_and_map_s"], best["whole_call_s"], best["index_load_s"], best["feed"]
@@ -196,6 +216,7 @@ def cli_end_to_end(prg, batches, threads):
                 "parse_and_map_s": t_map, "value": n / t_map if t_map else None, "unit": "reads/s",
                 "whole_call_s": t_all, "whole_call_reads_per_s": n / t_all, "index_load_s": t_load, "gram_build_s": t_build,
                 "feed": feed, "parse_and_map_s_of_both_calls": [r["parse_and_map_s"] for r in runs],
+                "whole_call_s_of_both_calls": [r["whole_call_s"] for r in runs], "samples_in_one_call": multi,
                 "note": "plain four-line FASTQ -> coverage files, the call made twice and the faster one quoted; parse_and_map = parser threads (2-bit planes) + H2D + kernels"}
 
 

@@ -130,6 +130,7 @@ SYMBOLS = {
     "gmx_infer_segments_debug": (_i64, [C.c_char_p, C.c_char_p, C.c_char_p, _u64]),
     "gmx_infer_extract_debug": (_i64, [_vp, C.c_int, _u32, _u32p, C.c_char_p, C.c_char_p, C.c_char_p, _u64]),
     "gmx_device_count": (C.c_int, []),
+    "gmx_device_warmup": (C.c_int, [C.c_int]),
     "gmx_group_create": (C.c_int, [_vp, C.POINTER(EngineOpts), C.POINTER(C.c_int), C.c_int, C.POINTER(_vp)]),
     "gmx_group_destroy": (None, [_vp]),
     "gmx_group_size": (C.c_int, [_vp]),

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -29,6 +30,8 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <exception>
 #include <unordered_map>
 #include <vector>
 
@@ -36,6 +39,43 @@
 #include "gmx_internal.h"
 
 namespace {
+// contiguous ranges of [0, n) on up to 16 threads (fn(begin, end, part)); one range when n is small. Used where the
+// reference's loops are independent per site: genotyping the sites of a non-nested PRG, formatting the output records.
+template <class F>
+void par_ranges(size_t n, size_t min_per_part, F fn) {
+  size_t parts = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16), n / std::max<size_t>(min_per_part, 1) + 1);
+  if (const char *e = getenv("GMX_INFER_THREADS")) parts = std::max(1, atoi(e));
+  parts = std::max<size_t>(1, std::min(parts, std::max<size_t>(n, 1)));
+  if (parts == 1) {
+    fn((size_t)0, n, (size_t)0);
+    return;
+  }
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(parts);
+  for (size_t p = 0; p < parts; ++p)
+    th.emplace_back([&, p]() {
+      try {
+        fn(n * p / parts, n * (p + 1) / parts, p);
+      } catch (...) {
+        err[p] = std::current_exception();
+      }
+    });
+  for (auto &t : th) t.join();
+  for (auto &e : err)
+    if (e) std::rethrow_exception(e);
+}
+// GMX_PHASE_TRACE=1: wall time of the stage's parts on stderr (milliseconds since the first call)
+void infer_phase(const char *what) {
+  static const bool on = getenv("GMX_PHASE_TRACE") != nullptr;
+  if (!on) return;
+  static const auto t0 = std::chrono::steady_clock::now();
+  fprintf(stderr, "[infer %8.2f ms] %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+size_t par_parts(size_t n, size_t min_per_part) {  // how many ranges par_ranges will make (callers size their per-part buffers)
+  size_t parts = std::min<size_t>(std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), 16), n / std::max<size_t>(min_per_part, 1) + 1);
+  if (const char *e = getenv("GMX_INFER_THREADS")) parts = std::max(1, atoi(e));
+  return std::max<size_t>(1, std::min(parts, std::max<size_t>(n, 1)));
+}
 
 using CovCount = uint16_t;  // common/data_types.hpp:52
 using AlleleIds = std::vector<int32_t>;
@@ -536,6 +576,30 @@ struct Genotyper {
       if (h.site_ref_pos[a] != h.site_ref_pos[b]) return h.site_ref_pos[a] > h.site_ref_pos[b];
       return a > b;
     });
+    infer_phase("  sites ordered");
+    if (child_m.empty()) {
+      // A non-nested PRG: no site reads another site's result (no invalidation, no filter propagation), so the sites are
+      // genotyped side by side — the same arithmetic per site, in the same order within it; the debug text is put together
+      // in genotyping order afterwards. (60 k sites: 72 ms on one thread of the GPU box.)
+      std::vector<std::string> dbg(n_sites);
+      par_ranges(n_sites, 512, [&](size_t b, size_t e, size_t) {
+        for (size_t k = b; k < e; ++k) {
+          const uint32_t si = order[k];
+          Alleles extracted = extract(si);
+          Model m(extracted, gped.at(si), ploidy, ls);
+          auto site = std::make_shared<Site>(m.site);
+          dbg[k] = "site index: \t" + std::to_string(si) + (site->is_null() ? std::string("\tnull gt \n") : site->debug_info + "\n");
+          site->pos = h.site_ref_pos[si];
+          site->end_node = h.sites[si].exit_node;
+          recs[si] = site;
+        }
+      });
+      infer_phase("  sites genotyped (side by side)");
+      for (auto const &d : dbg) debug_text += d;
+      infer_phase("  debug text joined");
+      add_percentiles();
+      return;
+    }
     for (uint32_t si : order) {
       const uint32_t site_id = 5 + 2 * si;
       Alleles extracted = extract(si);
@@ -780,12 +844,39 @@ struct Bgzf {
     }
     out.write(reinterpret_cast<const char *>(tail), 8);
   }
+  // one BGZF member (header, raw deflate of up to 0xff00 bytes, CRC-32 and length) as bytes
+  static std::string member(const char *data, size_t n) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+    std::vector<unsigned char> comp(n + n / 8 + 1024);
+    zs.next_in = reinterpret_cast<Bytef *>(const_cast<char *>(data));
+    zs.avail_in = (uInt)n;
+    zs.next_out = comp.data();
+    zs.avail_out = (uInt)comp.size();
+    deflate(&zs, Z_FINISH);
+    const size_t clen = zs.total_out;
+    deflateEnd(&zs);
+    const uint16_t bsize = (uint16_t)(clen + 25);
+    const unsigned char head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (unsigned char)(bsize & 0xFF), (unsigned char)(bsize >> 8)};
+    std::string out(reinterpret_cast<const char *>(head), 18);
+    out.append(reinterpret_cast<const char *>(comp.data()), clen);
+    const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), reinterpret_cast<const Bytef *>(data), (uInt)n), isize = (uint32_t)n;
+    for (int i = 0; i < 4; ++i) out.push_back((char)(unsigned char)(crc >> (8 * i)));
+    for (int i = 0; i < 4; ++i) out.push_back((char)(unsigned char)(isize >> (8 * i)));
+    return out;
+  }
   void write(const std::string &s) {
     buf += s;
-    while (buf.size() >= 0xff00) {
-      block(buf.data(), 0xff00);
-      buf.erase(0, 0xff00);
-    }
+    const size_t n_blocks = buf.size() / 0xff00;
+    if (n_blocks == 0) return;
+    // the same members, in the same order, as one block after the other would give: compressed side by side
+    std::vector<std::string> members(n_blocks);
+    par_ranges(n_blocks, 4, [&](size_t b, size_t e, size_t) {
+      for (size_t i = b; i < e; ++i) members[i] = member(buf.data() + i * 0xff00, 0xff00);
+    });
+    for (auto const &m : members) out.write(m.data(), (std::streamsize)m.size());
+    buf.erase(0, n_blocks * 0xff00);
   }
   void close() {
     if (!buf.empty()) block(buf.data(), buf.size());
@@ -854,15 +945,19 @@ int gmx_infer_run(const gmx_index *ix, const uint32_t *per_base_raw, const uint3
   if (!ix || !out || (ploidy != 1 && ploidy != 2)) return fail("gmx_infer_run: bad argument (ploidy is 1 or 2)");
   const gmx::HostIndex &h = gmx_index_host(ix);
   try {
+    infer_phase("start");
     auto inf = std::make_unique<gmx_infer>();
     inf->ix = ix;
     inf->g = std::make_unique<Genotyper>(h);
     inf->g->per_base.assign(h.n_pb_slots, 0);
     for (uint32_t i = 0; i < h.n_pb_slots; ++i) inf->g->per_base[i] = std::min<uint32_t>(per_base_raw ? per_base_raw[i] : 0, 65535u);
     std::vector<GroupedCounts> gped;
+    infer_phase("per-base values copied");
     int rc = grouped_of_sites(h, grouped_dense_raw, grouped_log, n_log_words, gped);
     if (rc) return rc;
+    infer_phase("grouped counts per site");
     inf->g->run(gped, mean_cov_depth, variance_cov_depth, mean_pb_error, ploidy);
+    infer_phase("sites genotyped, percentiles added");
     *out = inf.release();
     return GMX_OK;
   } catch (std::exception const &ex) {
@@ -1239,10 +1334,20 @@ int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const ch
     << jstr(kGtConfDesc) << "},\"GT_CONF_PERCENTILE\":{\"Desc\":" << jstr(kGcpDesc)
     << "},\"HAPG\":{\"Desc\":\"Sample haplogroups of genotyped alleles\"},\"POS\":{\"Desc\":\"Position on reference or pseudo-reference\"},"
        "\"SEG\":{\"Desc\":\"Segment ID\"}},\"Sites\":[";
-  for (size_t i = 0; i < g.recs.size(); ++i) {
-    const Site &s = *g.recs[i];
-    const std::string seg = tr.id_of(s.pos);
-    o << (i ? "," : "") << site_json(s, &seg, tr.relative(s.pos) + 1);
+  {  // the records formatted side by side (each range with a tracker of its own: positions ascend within a range), written in order
+    const size_t n = g.recs.size();
+    std::vector<std::string> part(par_parts(n, 2048));
+    par_ranges(n, 2048, [&](size_t b, size_t e, size_t p) {
+      Tracker t2 = tr;
+      std::string &out = part[p];
+      for (size_t i = b; i < e; ++i) {
+        const Site &s = *g.recs[i];
+        const std::string seg = t2.id_of(s.pos);
+        if (i) out += ',';
+        out += site_json(s, &seg, t2.relative(s.pos) + 1);
+      }
+    });
+    for (auto const &ps : part) o << ps;
   }
   o << "]}" << std::endl;
   o.close();
@@ -1271,12 +1376,17 @@ int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const cha
      << "##FILTER=<ID=AMBIG,Description=\"" << kAmbigDesc << "\",Source=\"gramtools\">\n"
      << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" << (sample_id ? sample_id : "sample") << "\n";
   z.write(hd.str());
-  for (size_t i = 0; i < g.recs.size(); ++i) {
+  const size_t n_recs = g.recs.size();
+  std::vector<std::string> part(par_parts(n_recs, 2048));
+  par_ranges(n_recs, 2048, [&](size_t rb, size_t re, size_t pp) {
+  Tracker t2 = tr;  // (a tracker per range: positions ascend within it)
+  std::string &acc = part[pp];
+  for (size_t i = rb; i < re; ++i) {
     if (g.h.sites[i].parent_site != 0) continue;  // next_valid_idx: sites nested in no other
     const Site &s = *g.recs[i];
     std::ostringstream r;
-    const std::string chrom = tr.id_of(s.pos);
-    r << chrom << "\t" << tr.relative(s.pos) + 1 << "\t.\t";
+    const std::string chrom = t2.id_of(s.pos);
+    r << chrom << "\t" << t2.relative(s.pos) + 1 << "\t.\t";
     // an empty allele would be an invalid VCF field; htslib writes what it is given, so do we
     r << (s.alleles.empty() ? std::string(".") : s.alleles[0].seq) << "\t";
     if (s.alleles.size() < 2)
@@ -1300,8 +1410,10 @@ int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const cha
     else  // the reference hands htslib only the first string of the vector (make_vcf.cpp:124-134)
       r << s.filters[0] << (s.filters.size() > 1 ? "," : "");
     r << ":" << fmt_g(s.gt_conf) << ":" << fmt_g(s.gt_conf_percentile) << "\n";
-    z.write(r.str());
+    acc += r.str();
   }
+  });
+  for (auto const &ps : part) z.write(ps);
   z.close();
   return GMX_OK;
 }
@@ -1354,7 +1466,11 @@ int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const c
         if (gts.size() != ploidy) throw std::runtime_error("The sites do not all have the same GT cardinality (ploidy)");
         for (size_t i = 0; i < ploidy; ++i) refs.at(i + offset).seq += site.alleles.at(gts.at(i)).seq;
         // the site's end node sits at start + length of its first allele
-        ref_pos = site.pos + g.ref_allele(h.edges[h.nodes[cur].edge_begin], site.end_node).seq.size();
+        {  // (the LENGTH of extract_ref_allele's sequence: the first-edge path from the first allele to the site's end)
+          size_t ref_len = 0;
+          for (uint32_t n = h.edges[h.nodes[cur].edge_begin]; n != site.end_node; n = g.first_edge(n)) ref_len += h.nodes[n].seq_len;
+          ref_pos = site.pos + ref_len;
+        }
         cur = site.end_node;
         if (cur_edge == ref_pos - 1) cur_edge = switch_segment();
       }

@@ -278,6 +278,24 @@ int gmx_device_count(void) {
   return n;
 }
 
+// (gmx.h) Brings the HIP runtime, the device's context and this library's code objects up — 150-250 ms that a caller can
+// spend on another thread while it loads its index from disk.
+__global__ void gmx_warmup_kernel(uint32_t *p) {
+  if (p) *p = 1u;
+}
+int gmx_device_warmup(int device) {
+  if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) {
+    gmx_set_error(std::string("gmx_device_warmup: device ") + std::to_string(device) + ": " + hipGetErrorString(hipGetLastError()));
+    return GMX_ENODEV;
+  }
+  hipLaunchKernelGGL(gmx_warmup_kernel, dim3(1), dim3(1), 0, nullptr, (uint32_t *)nullptr);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    gmx_set_error(std::string("gmx_device_warmup: ") + hipGetErrorString(hipGetLastError()));
+    return GMX_EHIP;
+  }
+  return GMX_OK;
+}
+
 int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const int *devices, int n_devices, gmx_group **out) {
   if (!ix || !devices || n_devices <= 0 || !out) {
     gmx_set_error("gmx_group_create: bad argument");

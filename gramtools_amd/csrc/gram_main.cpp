@@ -66,7 +66,11 @@ const char *kGenotypeHelp =
     "                              when the reads files are large, else device 0)\n"
     "  --devices arg               several GPUs, e.g. 0-7 or 0,2,5: reads sharded, coverage summed (engine extension)\n"
     "  --rng_compat arg (=gcc11)   uniform_int_distribution flavour of the reference build to reproduce:\n"
-    "                              gcc11 (libstdc++ >= 11) or gcc10 (libstdc++ <= 10) (engine extension)\n";
+    "                              gcc11 (libstdc++ >= 11) or gcc10 (libstdc++ <= 10) (engine extension)\n"
+    "  --samples_list arg          many samples in one call (engine extension): a file with one line per sample,\n"
+    "                              tab-separated: sample_id, genotype_dir, reads file(s). Replaces --reads / --sample_id /\n"
+    "                              --genotype_dir. The index is loaded and uploaded once; every sample's files are those of\n"
+    "                              a call of its own with the same --seed\n";
 
 [[noreturn]] void die(const std::string &msg, int code = 1) {
   std::cout << msg << std::endl;
@@ -1097,14 +1101,51 @@ class SeedStream {
 
 int run_genotype(const Args &a) {
   using clk = std::chrono::steady_clock;
+  // The HIP runtime, device 0's context and the library's kernels come up on a thread of their own (150-250 ms) while this
+  // one reads the arguments, the first reads and the index cache; joined before the first call that needs a device.
+  std::thread hip_warm([]() { (void)gmx_device_warmup(0); });
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
+    }
+  } hip_warm_join{hip_warm};
   std::string gram_dir = a.one("gram_dir");
-  if (!a.has("reads") || a.opt.at("reads").empty()) die(std::string("the option '--reads' is required but missing\n") + kGenotypeHelp);
-  std::vector<std::string> reads_paths = a.opt.at("reads");
-  std::string sample_id = a.one("sample_id");
+  // One sample (the reference's interface: genotype/parameters.cpp:54-72), or --samples_list: many samples on one index
+  // upload — "(tens of!) thousands of samples" of one species (the reference's README) pay the start-up once.
+  struct Sample {
+    std::string id, run_dir;
+    std::vector<std::string> reads;
+  };
+  std::vector<Sample> samples;
+  if (a.has("samples_list")) {
+    if (a.has("reads") || a.has("sample_id") || a.has("genotype_dir")) die(std::string("--samples_list replaces --reads, --sample_id and --genotype_dir\n") + kGenotypeHelp);
+    std::ifstream in(a.one("samples_list"));
+    if (!in) die("cannot read the samples list " + a.one("samples_list"));
+    std::string line;
+    while (std::getline(in, line)) {
+      if (line.empty() || line[0] == '#') continue;
+      std::vector<std::string> f;
+      size_t i = 0;
+      while (i <= line.size()) {
+        size_t j = line.find('\t', i);
+        if (j == std::string::npos) j = line.size();
+        f.push_back(line.substr(i, j - i));
+        i = j + 1;
+      }
+      if (f.size() < 3 || f[0].empty() || f[1].empty() || f[2].empty()) die("samples list: a line needs sample_id, genotype_dir and at least one reads file, tab-separated: " + line);
+      samples.push_back(Sample{f[0], f[1], std::vector<std::string>(f.begin() + 2, f.end())});
+    }
+    if (samples.empty()) die("samples list: no sample in " + a.one("samples_list"));
+  } else {
+    if (!a.has("reads") || a.opt.at("reads").empty()) die(std::string("the option '--reads' is required but missing\n") + kGenotypeHelp);
+    samples.push_back(Sample{a.one("sample_id"), a.one("genotype_dir"), a.opt.at("reads")});
+  }
+  std::vector<std::string> reads_paths;  // of all samples (the automatic choice of devices looks at their total size)
+  for (auto const &smp : samples) reads_paths.insert(reads_paths.end(), smp.reads.begin(), smp.reads.end());
   std::string ploidy = a.one("ploidy");
   if (ploidy != "haploid" && ploidy != "diploid") die(std::string("Invalid/unsupported ploidy\n") + kGenotypeHelp);
   uint32_t kmer_size = (uint32_t)std::stoul(a.one("kmer_size"));
-  std::string run_dir = a.one("genotype_dir");
   int max_threads = a.has("max_threads") ? std::stoi(a.one("max_threads")) : 1;
   // --device N, or --devices 0-7 / 0,2,5: one engine and one host thread per listed GPU, reads dealt by read index,
   // coverage summed at the end (gmx.h: gmx_group_*). The result does not depend on the number of GPUs.
@@ -1138,20 +1179,19 @@ int run_genotype(const Args &a) {
     // more than it saves). GMX_AUTO_DEVICES=0 keeps device 0, =N takes at most N.
     devices.push_back(0);
     devices_auto = true;
-    int n_vis = gmx_device_count();
-    if (const char *ad = getenv("GMX_AUTO_DEVICES")) n_vis = std::min(n_vis, std::max(1, atoi(ad)));
-    if (n_vis > 1) {
-      uint64_t mb = 0;
-      for (auto const &p : reads_paths) {
-        struct stat st;
-        if (stat(p.c_str(), &st) != 0) continue;
-        const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
-        mb += ((uint64_t)st.st_size >> 20) * (gz ? 4 : 1);
-      }
-      uint64_t min_mb = 2048;
-      if (const char *mm = getenv("GMX_AUTO_DEVICES_MIN_MB")) min_mb = (uint64_t)atoll(mm);
-      if (mb >= min_mb)
-        for (int d = 1; d < n_vis; ++d) devices.push_back(d);
+    uint64_t mb = 0;
+    for (auto const &p : reads_paths) {
+      struct stat st;
+      if (stat(p.c_str(), &st) != 0) continue;
+      const bool gz = p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+      mb += ((uint64_t)st.st_size >> 20) * (gz ? 4 : 1);
+    }
+    uint64_t min_mb = 2048;
+    if (const char *mm = getenv("GMX_AUTO_DEVICES_MIN_MB")) min_mb = (uint64_t)atoll(mm);
+    if (mb >= min_mb) {  // (only then is the device count needed this early: it waits for the runtime to come up)
+      int n_vis = gmx_device_count();
+      if (const char *ad = getenv("GMX_AUTO_DEVICES")) n_vis = std::min(n_vis, std::max(1, atoi(ad)));
+      for (int d = 1; d < n_vis; ++d) devices.push_back(d);
     }
   }
   int rng_mode = 0;
@@ -1162,22 +1202,13 @@ int run_genotype(const Args &a) {
     else if (m != "gcc11")
       die("--rng_compat must be gcc11 or gcc10");
   }
-  uint32_t seed;
-  if (a.has("seed"))
-    seed = (uint32_t)std::stoul(a.one("seed"));
-  else {
-    std::random_device rd;  // random.cpp:8-13
-    seed = rd();
+  for (auto const &smp : samples) {
+    mkdirs(join(smp.run_dir, "coverage"));
+    mkdirs(join(smp.run_dir, "genotype"));
   }
-  std::string cov_dir = join(run_dir, "coverage"), geno_dir = join(run_dir, "genotype");
-  mkdirs(cov_dir);
-  mkdirs(geno_dir);
 
   std::cout << "Executing genotype command" << std::endl;
   phase("arguments parsed, output directories made");
-  ReadStats rs;
-  compute_base_error_rate(reads_paths[0], rs);  // genotype.cpp:32-34
-  phase("base error rate of the first 10 000 reads");
 
   auto t0 = clk::now();
   // Beside the index load: the page-locked buffers the reads feed will ask for (two parsed blocks in flight: bases,
@@ -1213,6 +1244,8 @@ int run_genotype(const Args &a) {
   gmx_engine_opts opts;
   gmx_engine_default_opts(&opts);
   opts.rng_mode = rng_mode;
+  if (hip_warm.joinable()) hip_warm.join();
+  phase("HIP runtime up (warm-up thread joined)");
   gmx_group *grp = nullptr;
   {
     int grc = gmx_group_create(ix, &opts, devices.data(), (int)devices.size(), &grp);
@@ -1245,6 +1278,25 @@ int run_genotype(const Args &a) {
   phase("workspace reserved, page-locked buffers warmed");
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
 
+  for (size_t sample_i = 0; sample_i < samples.size(); ++sample_i) {  // ---- one sample: what a call of its own does from here on ----
+  const std::vector<std::string> &reads_paths = samples[sample_i].reads;
+  const std::string &sample_id = samples[sample_i].id, &run_dir = samples[sample_i].run_dir;
+  const std::string cov_dir = join(run_dir, "coverage"), geno_dir = join(run_dir, "genotype");
+  if (samples.size() > 1) std::cout << "==== sample " << sample_id << " (" << sample_i + 1 << " of " << samples.size() << ")" << std::endl;
+  uint32_t seed;
+  if (a.has("seed"))
+    seed = (uint32_t)std::stoul(a.one("seed"));
+  else {
+    std::random_device rd;  // random.cpp:8-13
+    seed = rd();
+  }
+  ReadStats rs;
+  compute_base_error_rate(reads_paths[0], rs);  // genotype.cpp:32-34
+  phase("base error rate of the first 10 000 reads");
+  if (sample_i > 0) {  // the accumulators and read counters of the sample before
+    for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reset(gmx_group_engine(grp, d)));
+    g_feed = FeedTimes{};
+  }
   std::cout << "Running quasimap" << std::endl;
   std::cout << "Generating allele quasimap data structure" << std::endl;
   std::cout << "Done generating allele quasimap data structure" << std::endl;
@@ -1345,6 +1397,11 @@ int run_genotype(const Args &a) {
   std::vector<uint32_t> n_alleles(info.n_sites), as_off(info.n_sites), g_off(info.n_sites);
   GMX_CHECK(gmx_index_site_layout(ix, n_alleles.data(), as_off.data(), g_off.data(), nullptr, nullptr));
 
+  // The three coverage files and read_stats.json are written on a thread of their own, beside the genotyping model below
+  // (round 5: at configs[1] they were 42 ms of a call whose mapping takes 24; nothing below reads what they write).
+  std::string rs_path = join(run_dir, "read_stats.json");
+  std::cout << "Writing read stats to " << rs_path << std::endl;
+  std::thread cov_writer([&]() {
   {  // coverage::dump::allele_sum (allele_sum.cpp:45-57): uint16 wrap
     std::ofstream o(join(cov_dir, "allele_sum_coverage"));
     for (uint32_t s = 0; s < info.n_sites; ++s) {
@@ -1434,10 +1491,9 @@ int run_genotype(const Args &a) {
     o << "]}}\n";
     close_checked(o, join(cov_dir, "grouped_allele_counts_coverage.json"));
   }
-  phase("coverage files written");
-  std::string rs_path = join(run_dir, "read_stats.json");
-  std::cout << "Writing read stats to " << rs_path << std::endl;
   write_read_stats(rs_path, rs);
+  phase("coverage files written (writer thread)");
+  });
 
   std::cout << std::endl;
   std::cout << "The following counts include generated reverse complement reads." << std::endl;
@@ -1471,20 +1527,47 @@ int run_genotype(const Args &a) {
     close_checked(o, dbg_path);
   }
   phase("genotyping model run");
+  // the three writers read the same results and write three different files: side by side
   std::cout << "Producing json vcf" << std::endl;
-  GMX_CHECK(gmx_infer_write_json(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.json").c_str()));
   std::cout << "Producing personalised reference" << std::endl;
-  const std::string desc = sample_id + " personalised reference made by gramtools genotype";
-  GMX_CHECK(gmx_infer_write_fasta(inf, coords.c_str(), desc.c_str(), join(geno_dir, "personalised_reference.fasta").c_str()));
   std::cout << "Producing vcf" << std::endl;
-  GMX_CHECK(gmx_infer_write_vcf(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.vcf.gz").c_str()));
-  gmx_infer_destroy(inf);
+  const std::string desc = sample_id + " personalised reference made by gramtools genotype";
+  int w_rc[3] = {GMX_OK, GMX_OK, GMX_OK};
+  std::string w_err[3];
+  std::thread w_json([&]() {
+    if ((w_rc[0] = gmx_infer_write_json(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.json").c_str()))) w_err[0] = gmx_last_error();
+    phase("  jVCF written (writer thread)");
+  });
+  std::thread w_fasta([&]() {
+    if ((w_rc[1] = gmx_infer_write_fasta(inf, coords.c_str(), desc.c_str(), join(geno_dir, "personalised_reference.fasta").c_str()))) w_err[1] = gmx_last_error();
+    phase("  personalised reference written (writer thread)");
+  });
+  if ((w_rc[2] = gmx_infer_write_vcf(inf, coords.c_str(), sample_id.c_str(), join(geno_dir, "genotyped.vcf.gz").c_str()))) w_err[2] = gmx_last_error();
+  phase("  VCF written");
+  w_json.join();
+  w_fasta.join();
+  cov_writer.join();
+  for (int i = 0; i < 3; ++i)
+    if (w_rc[i] != GMX_OK) die("gram: " + w_err[i]);
   phase("jVCF, personalised reference and VCF written");
+  // (60 k site records freed one by one: 57 ms — left to the process exit for the last sample)
+  if (getenv("GMX_FULL_TEARDOWN") || sample_i + 1 < samples.size()) gmx_infer_destroy(inf);
   std::cout << "  Genotyping: " << std::chrono::duration<double>(clk::now() - t_inf).count() << std::endl;
-  gmx_group_destroy(grp);
-  gmx_index_destroy(ix);
-  phase("engines and index destroyed");
-  return 0;
+  }  // ---- next sample ----
+  // Every output file is closed. The engines' and the index's memory goes back with the process: freeing 0.7 GB of device
+  // and host tables one by one and unloading the runtime took 65 + ~100 ms of a 1 s call (round 5, tools/cli_phases.sh).
+  // GMX_FULL_TEARDOWN=1 destroys everything in order (leak checks).
+  if (getenv("GMX_FULL_TEARDOWN")) {
+    gmx_group_destroy(grp);
+    gmx_index_destroy(ix);
+    phase("engines and index destroyed");
+    return 0;
+  }
+  phase("done (teardown left to the process exit)");
+  std::cout.flush();
+  std::cerr.flush();
+  fflush(nullptr);
+  _exit(0);
 }
 
 }  // namespace

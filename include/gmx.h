@@ -390,6 +390,9 @@ typedef struct gmx_group gmx_group; /* N engines in ONE process, one per listed 
  * reads files are large enough for sharding to pay (the front-end passes a fixed argument list, common.py:33-49, so the
  * unmodified Python command scales with the node). */
 int gmx_device_count(void);
+/* Brings the HIP runtime, the device's context and the library's kernels up (150-250 ms): `gram genotype` does it on a
+ * thread of its own beside the index load. GMX_ENODEV without a usable device. */
+int gmx_device_warmup(int device);
 /* The engines are created side by side, one host thread per device (the index upload of a whole-genome PRG is minutes). */
 int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts, const int *devices, int n_devices, gmx_group **out);
 void gmx_group_destroy(gmx_group *g);

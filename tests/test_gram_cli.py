@@ -471,3 +471,43 @@ def test_parallel_gzip_bounds_its_pieces_and_rejects_distances_before_the_member
     (tmp_path / "far.fastq.gz").write_bytes(member)
     out = subprocess.run([build_gram(), "_parse_check", str(tmp_path / "far.fastq.gz"), "4"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode != 0, out.stdout
+
+
+@pytest.mark.gpu
+def test_many_samples_in_one_call_equal_one_call_each(tmp_path):
+    """`gram genotype --samples_list` (round 5: one index load and upload for many samples of one species — the reference's
+    stated use, README.md:156): every file of every sample is byte-identical to that of a call of its own with the same
+    --seed (files written: genotype/parameters.cpp:94-110)."""
+    import numpy as np
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads
+    ref = random_ref(60_000, 91)
+    prg, pos, alts, n_alts = snp_prg(ref, 900, 92, multi_allelic_frac=0.1)
+    (tmp_path / "prg").write_bytes(ints_to_prg_bytes([int(x) for x in prg]))
+    assert run("build", "--gram_dir", str(tmp_path), "--kmer_size", "7", "--max_threads", "4").returncode == 0
+    letters = np.frombuffer(b"NACGT", dtype=np.uint8)
+    lines = []
+    for s in range(3):
+        paths = []
+        for f in range(1 + s % 2):  # samples with one and with two reads files (5 000-draw rule per file)
+            rd = simulate_snp_reads(ref, pos, alts, n_alts, 6000 + 701 * s + 13 * f, 120 + 10 * s, 93 + 10 * s + f)
+            fq = tmp_path / f"s{s}_{f}.fastq"
+            _write_fastq(fq, [letters[r].tobytes().decode() for r in rd], False)
+            paths.append(str(fq))
+        lines.append((f"smp{s}", paths))
+    common_args = ["--gram_dir", str(tmp_path), "--ploidy", "haploid", "--kmer_size", "7", "--max_threads", "4", "--seed", "7"]
+    for sid, paths in lines:
+        r = run("genotype", *common_args, "--reads", *paths, "--sample_id", sid, "--genotype_dir", str(tmp_path / f"single_{sid}"))
+        assert r.returncode == 0, r.stdout + r.stderr
+    (tmp_path / "samples.tsv").write_text("".join("\t".join([sid, str(tmp_path / f"multi_{sid}")] + paths) + "\n" for sid, paths in lines))
+    r = run("genotype", *common_args, "--samples_list", str(tmp_path / "samples.tsv"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Count all reads:") == 3
+    names = ["coverage/allele_sum_coverage", "coverage/allele_base_coverage.json", "coverage/grouped_allele_counts_coverage.json",
+             "read_stats.json", "genotype/genotyped.json", "genotype/genotyped.vcf.gz", "genotype/personalised_reference.fasta"]
+    for sid, _ in lines:
+        for n in names:
+            a, b = (tmp_path / f"single_{sid}" / n).read_bytes(), (tmp_path / f"multi_{sid}" / n).read_bytes()
+            assert a == b and len(a) > 0, (sid, n)
+    # and the list replaces the single-sample options
+    bad = run("genotype", *common_args, "--samples_list", str(tmp_path / "samples.tsv"), "--sample_id", "x")
+    assert bad.returncode != 0

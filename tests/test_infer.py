@@ -187,3 +187,34 @@ def test_gt_conf_percentiles_are_reproducible_and_monotone():
     assert a == b
     pairs = sorted((s["GT_CONF"][0], s["GT_CONF_PERCENTILE"][0]) for s in a)
     assert all(0 <= p <= 100 for _, p in pairs) and all(x[1] <= y[1] for x, y in zip(pairs, pairs[1:]))
+
+
+def test_threads_change_nothing_in_the_calls_or_the_files(tmp_path, monkeypatch):
+    """(round 5) On a non-nested PRG the sites are genotyped side by side and the jVCF / VCF records are formatted and the BGZF
+    members compressed on several threads: calls and files are byte-identical to the one-thread run (the reference's loops:
+    level_genotyping/runner.cpp:29-103, make_json.cpp, make_vcf.cpp)."""
+    import numpy as np
+    from gramtools_amd import Index, Coverage, QuasimapReadsStats
+    from gramtools_amd.quasimap import Genotyped
+    from gramtools_amd.synth import random_ref, snp_prg
+    ref = random_ref(300_000, 71)
+    prg, pos, alts, n_alts = snp_prg(ref, 9000, 72, multi_allelic_frac=0.2)
+    ix = Index(prg, 5)
+    info = ix.info
+    rng = np.random.default_rng(73)
+    cov = Coverage(ix, rng.integers(0, 40, info.n_allele_slots, dtype=np.uint32), rng.integers(0, 40, info.n_per_base_slots, dtype=np.uint32),
+                   rng.integers(0, 25, max(info.n_grouped_slots, 1), dtype=np.uint32), np.zeros(0, dtype=np.uint32),
+                   QuasimapReadsStats(0, 0, 0, 0, 0))
+    open(tmp_path / "coords.tsv", "w").write("chr1\t100000\nchr2\t120000\nchr3\t80000\n")
+    outs = []
+    for threads in ("1", "7", "16"):
+        monkeypatch.setenv("GMX_INFER_THREADS", threads)
+        d = tmp_path / f"t{threads}"
+        d.mkdir()
+        g = Genotyped(cov, 0.001, depth=dict(mean=18.0, variance=30.0))
+        g.write(str(d), "s", str(tmp_path / "coords.tsv"))
+        outs.append({n: open(d / n, "rb").read() for n in ("genotyped.json", "genotyped.vcf.gz", "personalised_reference.fasta")} |
+                    {"sites": [g.site(i) for i in (0, 1, 4500, 8999)]})
+        g.close()
+    assert outs[0] == outs[1] == outs[2]
+    assert len(gzip.decompress(outs[0]["genotyped.vcf.gz"]).splitlines()) > 9000 and len(outs[0]["genotyped.vcf.gz"]) > 3 * 0xff00 // 10
