@@ -37,6 +37,11 @@ class QueueCounts(C.Structure):
                                           "inst_mapped", "huge_cover", "log_replays", "log_replayed_entries")]
 
 
+class StockReport(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("kmers", "states", "kmer_mismatches", "kmers_missing_in_files", "duplicate_kmers",
+                                          "mask_bits", "mask_mismatches")]
+
+
 class Timing(C.Structure):
     _fields_ = [("search_ms", C.c_double), ("search_launches", C.c_uint64), ("cover_ms", C.c_double),
                 ("cover_launches", C.c_uint64), ("reads", C.c_uint64), ("kernel_ms", C.c_double * 8),
@@ -103,6 +108,10 @@ SYMBOLS = {
     "gmx_engine_enable_timing": (C.c_int, [_vp, C.c_int]),
     "gmx_engine_timing": (C.c_int, [_vp, C.POINTER(Timing)]),
     "gmx_engine_queue_counts": (C.c_int, [_vp, C.POINTER(QueueCounts)]),
+    "gmx_stock_read_int_vector": (_i64, [C.c_char_p, _u32, _u64p, _u64, C.POINTER(C.c_uint32)]),
+    "gmx_stock_write_int_vector": (C.c_int, [C.c_char_p, _u64p, _u64, _u32, C.c_int]),
+    "gmx_index_write_stock_files": (C.c_int, [_vp, C.c_char_p]),
+    "gmx_index_check_stock_files": (C.c_int, [_vp, C.c_char_p, C.POINTER(StockReport)]),
     "gmx_engine_debug_keep_states": (C.c_int, [_vp, C.c_int]),
     "gmx_debug_final_states": (C.c_int, [_vp, _u64, _u32p, _u64, _u64p, C.POINTER(C.c_int)]),
     "gmx_debug_search": (C.c_int, [_vp, _u8p, _u32, C.c_int, _u32p, _u64, _u32, _u32, C.c_int, _u32p, _u64, _u64p]),

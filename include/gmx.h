@@ -229,6 +229,30 @@ typedef struct gmx_timing {
 } gmx_timing;
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out);
 
+/* ---- files of a stock gramtools gram_dir ------------------------------
+ * Readers of the SDSL-lite 2.1.1 vectors a stock `gramtools build` writes: kmers (int_vector<3>), kmers_stats,
+ * sa_intervals, paths (int_vector<>, bit-compressed) — read as build/kmer_index/load.cpp:71-173 reads them — and the four
+ * {a,c,g,t}_base_bwt_mask bit_vectors (prg/make_data_structures.cpp:140-156). On-disk form: 64-bit length in bits, a
+ * width byte for variable-width vectors, values packed LSB-first in 64-bit words. fm_index (csa_wt) and cov_graph (Boost
+ * archive) are not read: both are functions of gram_dir/prg, from which the native index is built.
+ * PARITY UNPINNED: no reference-written file exists here; checked against the format, hand-assembled bytes and a round
+ * trip through the writers (tests/test_stock_files.py).
+ * fixed_width: 0 = variable-width vector (width byte in the file), else the vector's compile-time width (3 for kmers,
+ * 1 for a bit_vector). Returns the number of elements (also with out == null), or a negative code. */
+int64_t gmx_stock_read_int_vector(const char *path, uint32_t fixed_width, uint64_t *out, uint64_t cap, uint32_t *width_out);
+int gmx_stock_write_int_vector(const char *path, const uint64_t *values, uint64_t n, uint32_t width, int fixed);
+/* the index's k-mer table and BWT masks in those formats (as dump.cpp:27-137 / make_data_structures.cpp:112-138 write them) */
+int gmx_index_write_stock_files(const gmx_index *ix, const char *gram_dir);
+typedef struct gmx_stock_report {
+  uint64_t kmers, states;               /* read from the files */
+  uint64_t kmer_mismatches;             /* k-mers whose states differ from the native index's (as sets of states) */
+  uint64_t kmers_missing_in_files;      /* indexed natively, absent from the files (a stock build may index fewer k-mers) */
+  uint64_t duplicate_kmers;
+  uint64_t mask_bits, mask_mismatches;  /* over the four masks */
+} gmx_stock_report;
+/* reads the files of gram_dir and compares them with the native index of the same PRG and k */
+int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_stock_report *out);
+
 /* ---- test hooks: SearchStates of the HIP path -----------------------------------------
  * The reference's unit tests pin the search at the level of SearchStates (search/types.hpp:31-57;
  * tests/genotype/quasimap/search/test_vBWT_jump.cpp:55-405, test_encapsulated_search.cpp:28-254, the

@@ -11,7 +11,7 @@ src=$work/gramtools_amd/csrc
 for v in P G; do
   flag=$([ $v = P ] && echo -DGMX_JUMP_PTR_FORM || echo -DGMX_JUMP_GENERAL)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $flag -DGMX_JUMP_DBG -shared -o $work/libgmx_jump$v.so \
-    $src/gmx_engine.hip $src/gmx_multi.hip $src/gmx_seedwalk.hip $src/gmx_suffixsort.hip $src/gmx_capi.cpp $src/gmx_index.cpp $src/gmx_infer.cpp -lpthread -ldl -lz
+    $src/gmx_engine.hip $src/gmx_multi.hip $src/gmx_seedwalk.hip $src/gmx_suffixsort.hip $src/gmx_capi.cpp $src/gmx_index.cpp $src/gmx_infer.cpp $src/gmx_stock.cpp -lpthread -ldl -lz
   echo "== build $v ($flag)" >> $out
   GMX_LIB=$work/libgmx_jump$v.so timeout 600 python tools/exp/jump_dbg.py 2>&1 | tail -3 >> $out
   GMX_LIB=$work/libgmx_jump$v.so timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "dense_sites" 2>&1 | tail -3 >> $out
