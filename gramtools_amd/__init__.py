@@ -8,6 +8,8 @@ from .quasimap import (  # noqa: F401
     Index,
     Quasimapper,
     PackedReads,
+    Ingest,
+    bgzf_members,
     PinnedArray,
     pack_reads, pack_reads_2bit,
     QuasimapperGroup,
@@ -28,6 +30,7 @@ from .quasimap import (  # noqa: F401
     grouped_json,
     dump_grouped_allele_counts,
     RNG_LEMIRE,
+    GMX_INGEST_BAD_RECORD, GMX_INGEST_BAD_MEMBER, GMX_INGEST_BAD_CRC, GMX_INGEST_TOO_MANY_LINES,
     RNG_DIVISION,
 )
 from ._lib import GmxError  # noqa: F401

@@ -48,6 +48,17 @@ class Timing(C.Structure):
                 ("kernel_launches", C.c_uint64 * 8)]
 
 
+class BgzfMember(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("size", C.c_uint32), ("isize", C.c_uint32), ("crc32", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class IngestResult(C.Structure):
+    _fields_ = [("status", C.c_uint32), ("bad_member", C.c_uint32), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64),
+                ("n_pairs", C.c_uint64), ("uniform_len", C.c_uint32), ("any_skip", C.c_uint32), ("text_bytes", C.c_uint64),
+                ("consumed_bytes", C.c_uint64), ("tail_bytes", C.c_uint64), ("sub_pairs", C.c_uint64 * 16),
+                ("d_planes", C.c_void_p), ("d_offsets", C.c_void_p), ("d_skip", C.c_void_p)]
+
+
 class DepthStats(C.Structure):
     _fields_ = [("mean_cov_depth", C.c_double), ("variance_cov_depth", C.c_double), ("num_sites_noCov", C.c_uint64),
                 ("num_sites_total", C.c_uint64)]
@@ -99,6 +110,18 @@ SYMBOLS = {
     "gmx_twobit_units": (_u64, [_u64p, _u32, _u64]),
     "gmx_pack_reads_2bit": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
     "gmx_map_reads_2bit_host": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u64]),
+    "gmx_map_reads_packed_device": (C.c_int, [_vp, _vp, _vp, _u32, _vp, _vp, _u64]),
+    "gmx_ingest_create": (C.c_int, [C.c_int, _u64, C.POINTER(_vp)]),
+    "gmx_ingest_destroy": (None, [_vp]),
+    "gmx_ingest_max_text": (_u64, [_vp]),
+    "gmx_ingest_max_compressed": (_u64, [_vp]),
+    "gmx_ingest_reset": (C.c_int, [_vp]),
+    "gmx_ingest_submit_bgzf": (C.c_int, [_vp, C.c_int, _vp, _u64, C.POINTER(BgzfMember), _u64, C.c_int]),
+    "gmx_ingest_submit_text": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int]),
+    "gmx_ingest_wait": (C.c_int, [_vp, C.c_int, C.POINTER(IngestResult)]),
+    "gmx_ingest_release_after": (C.c_int, [_vp, C.c_int, _vp]),
+    "gmx_ingest_fetch_text": (_i64, [_vp, C.c_int, _vp, _u64]),
+    "gmx_ingest_fetch_reads": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "gmx_pack_reads": (C.c_int, [_vp, _vp, _u32, _u64, _vp, _vp, C.c_int]),
     "gmx_engine_reserve": (C.c_int, [_vp, _u64, _u64]),
     "gmx_engine_reserve_packed": (C.c_int, [_vp, _u64, _u64]),

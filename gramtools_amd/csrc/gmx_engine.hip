@@ -4471,6 +4471,48 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
   return map_reads_packed_impl(e, planes, false, offsets, uniform_len, seeds, skip, n_reads);
 }
 
+// bit planes already in HBM (gmx_ingest_*): nothing to upload; seeds in device memory, or page-locked and read in place
+int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const uint64_t *d_offsets, uint32_t uniform_len,
+                                const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads) {
+  if (!e || !d_planes || !seeds || (!d_offsets && !uniform_len)) {
+    gmx_set_error("gmx_map_reads_packed_device: null argument (d_offsets may be null only with uniform_len)");
+    return GMX_EINVAL;
+  }
+  if (n_reads == 0) return GMX_OK;
+  HIP_TRY(hipSetDevice(e->opts.device));
+  const uint32_t *d_seeds = seeds;
+  if (gmx_is_pinned(seeds)) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<uint32_t *>(seeds), 0) != hipSuccess || !dp) {
+      (void)hipGetLastError();
+      gmx_set_error("gmx_map_reads_packed_device: the page-locked seeds have no device address");
+      return GMX_EHIP;
+    }
+    d_seeds = static_cast<const uint32_t *>(dp);
+  }
+  const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+  if (!uniform_len && n_reads > chunk) {
+    gmx_set_error("gmx_map_reads_packed_device: with d_offsets a call takes at most 2^20 reads (and at most max_batch_reads)");
+    return GMX_EINVAL;
+  }
+  const uint64_t ppr = (uniform_len + 31u) / 32u;
+  for (uint64_t done = 0; done < n_reads;) {
+    const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
+    BatchInput in;
+    in.d_planes = reinterpret_cast<const uint2 *>(d_planes + done * ppr);
+    in.d_offsets = uniform_len ? nullptr : d_offsets;
+    in.d_seeds = d_seeds + done;
+    in.d_skip = d_skip ? d_skip + done : nullptr;
+    in.uniform_len = uniform_len;
+    in.n_reads = n;
+    in.total_bases = uniform_len ? n * (uint64_t)uniform_len : 0;  // (sizes the pack buffer of byte input only)
+    int rc = launch_batch(e, in, nullptr);
+    if (rc) return rc;
+    done += n;
+  }
+  return GMX_OK;
+}
+
 int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_t *offsets, uint32_t uniform_len, const uint32_t *seeds,
                             const uint8_t *skip, uint64_t n_reads) {
   return map_reads_packed_impl(e, stream, true, offsets, uniform_len, seeds, skip, n_reads);

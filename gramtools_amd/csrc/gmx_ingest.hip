@@ -1,0 +1,1057 @@
+// gmx_ingest.hip — reads files decoded ON the device (round 5; SURVEY.md §8f-3, VERDICT round 4 "missing" #4).
+//
+// The reference reads `.fastq.gz` through zlib / htslib on one host thread (libgramtools/include/sequence_read/seqread.hpp:94-180,
+// src/genotype/quasimap/quasimap.cpp:65-76). The mapping kernels take 1 M reads in 0.4 ms; sixteen host cores inflate BGZF at
+// 32-48 M reads/s. Here the compressed members go over PCIe as they lie in the file (a quarter of the text) and the GPU does
+// the rest:
+//
+//   gmx_inflate_kernel     one wavefront per BGZF member (<= 64 KB of text, independent deflate streams, SAM spec §4.1): the
+//                          Huffman tables of the member's blocks and a 4 KB window of its output live in LDS; the bit stream
+//                          is decoded by the wave as ONE scalar thread of control (every value wave-uniform: the compiler
+//                          keeps the bit buffer in SGPRs), match copies and line flushes use the 64 lanes; CRC-32 of the
+//                          member's text by the same wave (64 slices, GF(2) combination), compared with the trailer's.
+//   gmx_nl_count/_mark     newline positions of the chunk's text (tile counts -> scan -> positions)
+//   gmx_records_kernel     four-line records: checks '@' / '+' / equal lengths, read lengths, one length for all or not
+//   gmx_fq_pack_kernel     32 letters -> one pair of bit planes, in the layout gmx_pack_reads / the host parser produce
+//                          (include/gmx.h), unencodable reads flagged in skip[] (encode_dna_bases, common/utils.cpp:73-92)
+//
+// A chunk's incomplete last record is carried into the next chunk on the device. Anything irregular (not four-line FASTQ, a
+// damaged member, a CRC mismatch) is reported in gmx_ingest_result::status and decided by the caller (`gram` re-inflates the
+// chunk with zlib and hands the text to gmx_ingest_submit_text, so a defect of this decoder cannot lose or invent reads).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "gmx_internal.h"
+
+#define ING_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gmx_set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+      return GMX_EHIP;                                                                     \
+    }                                                                                      \
+  } while (0)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// device-side state of one chunk (one slot): written by the kernels, read by the next kernel and, at the end, by the host
+// ------------------------------------------------------------------------------------------------------------------
+struct IngestState {
+  uint32_t text_start;     // first byte of the chunk's text in the slot's text buffer (carry of the chunk before included)
+  uint32_t text_len;       // bytes from there
+  uint32_t n_lines;        // complete lines (a last line without '\n' counts when the chunk is the file's last)
+  uint32_t n_reads;
+  uint32_t min_len, max_len;
+  uint32_t flags;          // GMX_INGEST_* status bits
+  uint32_t bad_member;     // first member that failed (index within the chunk)
+  uint32_t consumed;       // bytes of text the records take
+  uint32_t tail_len;       // text_len - consumed: carried into the next chunk
+  uint32_t any_skip;
+  uint32_t uniform_len;
+  unsigned long long n_bases;
+  unsigned long long n_pairs;
+  unsigned long long sub_pairs[16];  // pair index of read i * 2^20 (offsets form): where a launch of <= 2^20 reads starts
+  uint32_t final_chunk;
+  uint32_t pad;
+};
+
+struct IngestMember {
+  uint32_t in_off, in_len;   // deflate data within the chunk's compressed bytes
+  uint32_t out_off, isize;   // its text within the chunk's text (from the first member's first byte)
+  uint32_t crc, pad;
+};
+
+#define ING_CARRY_MAX (1u << 20)  // bytes of an incomplete last record that can be carried (a record longer than this: irregular)
+#define ING_LIT_ROOT 10
+#define ING_DIST_ROOT 8
+#define ING_RING 4096u
+#define ING_RING_MASK (ING_RING - 1u)
+#define ING_NEAR_MAX (ING_RING - 320u)  // distances up to this are served from the LDS window
+
+// table entry: code length (4) | extra bits (4) | type (2) << 8 | value << 16
+#define ING_T_LIT 0u
+#define ING_T_BASE 1u
+#define ING_T_EOB 2u
+#define ING_T_LONG 3u
+
+struct WaveLds {
+  uint32_t lit[1u << ING_LIT_ROOT];    // literal/length codes of up to ING_LIT_ROOT bits, by the next bits of the stream (4 KB); the CRC table afterwards
+  uint32_t dist[1u << ING_DIST_ROOT];  // distance codes (1 KB); the code-length code while a dynamic block's lengths are read
+  uint8_t ring[ING_RING];              // the last 4 KB of the member's text
+  uint16_t lit_sorted[288];            // symbols by (code length, symbol): codes longer than the root are decoded bit by bit
+  uint16_t dist_sorted[32];
+  uint32_t lit_count[16], dist_count[16];
+  uint8_t lens[320];
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+struct Bits {  // every member wave-uniform
+  const uint32_t *w;
+  uint32_t next;
+  uint64_t buf;
+  uint32_t cnt;
+  __device__ __forceinline__ void start(const uint32_t *words, uint32_t byte_off) {
+    w = words;
+    const uint32_t idx = byte_off >> 2, skip = (byte_off & 3u) * 8u;
+    buf = (uint64_t)(uni(words[idx]) >> skip);
+    cnt = 32u - skip;
+    next = idx + 1u;
+  }
+  __device__ __forceinline__ void refill() {  // afterwards at least 33 bits
+    if (cnt <= 32u) {
+      buf |= (uint64_t)uni(w[next]) << cnt;
+      ++next;
+      cnt += 32u;
+    }
+  }
+  __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
+  __device__ __forceinline__ void drop(uint32_t n) {
+    buf >>= n;
+    cnt -= n;
+  }
+  __device__ __forceinline__ uint32_t take(uint32_t n) {
+    const uint32_t v = peek(n);
+    drop(n);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t byte_pos() const { return next * 4u - cnt / 8u; }  // of the next unread bit's byte (cnt a multiple of 8)
+};
+
+// what a symbol of one of the three codes stands for, as a table entry of `len` bits
+__device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len) {
+  if (kind == 0) {  // literal / length (RFC 1951 §3.2.5)
+    if (s < 256u) return len | (ING_T_LIT << 8) | (s << 16);
+    if (s == 256u) return len | (ING_T_EOB << 8);
+    if (s > 285u) return 0u;
+    const uint32_t t = s - 257u;
+    uint32_t base, extra;
+    if (t < 8u) {
+      base = 3u + t;
+      extra = 0;
+    } else if (t == 28u) {
+      base = 258u;
+      extra = 0;
+    } else {
+      extra = (t - 4u) >> 2;
+      base = 3u + ((4u + (t & 3u)) << extra);
+    }
+    return len | (extra << 4) | (ING_T_BASE << 8) | (base << 16);
+  }
+  if (kind == 1) {  // distance
+    if (s > 29u) return 0u;
+    uint32_t base, extra;
+    if (s < 4u) {
+      base = 1u + s;
+      extra = 0;
+    } else {
+      extra = (s - 2u) >> 1;
+      base = 1u + ((2u + (s & 1u)) << extra);
+    }
+    return len | (extra << 4) | (ING_T_BASE << 8) | (base << 16);
+  }
+  return len | (ING_T_LIT << 8) | (s << 16);  // code-length code: the symbol itself
+}
+
+// Canonical Huffman code of lens[0, n) (RFC 1951 §3.2.2) -> look-up table of `root` bits + the sorted symbols and the
+// counts per length for the bit-by-bit path. The wave works on 64 symbols at a time; a symbol's rank among those of its
+// length comes from ballots. Returns false on an over-subscribed set of lengths.
+__device__ bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint32_t *count, int kind) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (uint32_t i = lane; i < (1u << root); i += 64u) tab[i] = 0;
+  uint32_t cnt[16];
+#pragma unroll
+  for (int L = 0; L < 16; ++L) cnt[L] = 0;
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t s = base + lane, l = s < n ? lens[s] : 0u;
+#pragma unroll
+    for (uint32_t L = 1; L <= 15u; ++L) cnt[L] += (uint32_t)__popcll(__ballot(l == L));
+  }
+  int left = 1;
+#pragma unroll
+  for (int L = 1; L <= 15; ++L) {
+    left <<= 1;
+    left -= (int)cnt[L];
+    if (left < 0) return false;
+  }
+  uint32_t first[16], offs[16], run[16];
+  {
+    uint32_t code = 0, o = 0;
+    first[0] = offs[0] = run[0] = 0;
+#pragma unroll
+    for (int L = 1; L <= 15; ++L) {
+      code = (code + cnt[L - 1]) << 1;
+      first[L] = code;
+      offs[L] = run[L] = o;
+      o += cnt[L];
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int L = 0; L < 16; ++L) count[L] = cnt[L];
+    count[0] = 0;
+  }
+  __syncthreads();  // (the zeroed table before the entries)
+  for (uint32_t base = 0; base < n; base += 64u) {
+    const uint32_t s = base + lane, l = s < n ? lens[s] : 0u;
+    uint32_t my_at = 0, my_first = 0, my_offs = 0;
+#pragma unroll
+    for (uint32_t L = 1; L <= 15u; ++L) {
+      const unsigned long long m = __ballot(l == L);
+      if (l == L) {
+        my_at = run[L] + (uint32_t)__popcll(m & lt);
+        my_first = first[L];
+        my_offs = offs[L];
+      }
+      run[L] += (uint32_t)__popcll(m);
+    }
+    if (l) {
+      sorted[my_at] = (uint16_t)s;
+      const uint32_t code = my_first + (my_at - my_offs);
+      const uint32_t rev = __builtin_bitreverse32(code) >> (32u - l);
+      if (l <= root) {
+        const uint32_t e = ing_entry(kind, s, l);
+        for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab[j] = e;
+      } else {
+        tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 8);
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// a code longer than the table's root: bit by bit against the canonical code's first code of every length
+__device__ int ing_decode_slow(Bits &bs, const uint32_t *count, const uint16_t *sorted, uint32_t *len_out) {
+  uint32_t code = 0, first = 0, index = 0;
+  for (uint32_t len = 1; len <= 15u; ++len) {
+    code |= bs.take(1);
+    const uint32_t c = uni(count[len]);
+    if (code - first < c) {
+      *len_out = len;
+      return (int)uni(sorted[index + (code - first)]);
+    }
+    index += c;
+    first += c;
+    first <<= 1;
+    code <<= 1;
+  }
+  return -1;
+}
+
+// CRC-32 (IEEE, reflected) as polynomial arithmetic: a * b mod P, and x^n mod P (zlib's crc32_combine does the same)
+#define ING_CRC_POLY 0xedb88320u
+__device__ __forceinline__ uint32_t ing_mulmod(uint32_t a, uint32_t b) {
+  uint32_t m = 1u << 31, p = 0;
+  for (int i = 0; i < 32; ++i) {
+    if (a & m) p ^= b;
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ ING_CRC_POLY : b >> 1;
+  }
+  return p;
+}
+__device__ __forceinline__ uint32_t ing_xpow8(uint32_t n_bytes) {  // x^(8 n)
+  uint32_t base = 1u << 30;  // x^1
+  base = ing_mulmod(base, base);
+  base = ing_mulmod(base, base);
+  base = ing_mulmod(base, base);  // x^8
+  uint32_t r = 1u << 31;          // x^0
+  while (n_bytes) {
+    if (n_bytes & 1u) r = ing_mulmod(r, base);
+    base = ing_mulmod(base, base);
+    n_bytes >>= 1;
+  }
+  return r;
+}
+
+__device__ __forceinline__ uint8_t ing_load_coherent(const uint8_t *p) {  // text this wave stored earlier: past the vector L1
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wavefront per member: its text goes to text[out_off, out_off + isize).
+__global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
+                                                         uint8_t *text, IngestState *st, int check_crc) {
+  __shared__ WaveLds L;
+  const uint32_t mi = blockIdx.x;
+  if (mi >= n_members) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t in_off = uni(members[mi].in_off), in_len = uni(members[mi].in_len), isize = uni(members[mi].isize);
+  uint8_t *out = text + uni(members[mi].out_off);
+  Bits bs;
+  bs.start(comp, in_off);
+  uint32_t out_pos = 0, flushed = 0;  // bytes decoded; bytes (whole 64-byte lines) already stored from the window
+  uint32_t err = 0;
+  auto flush_lines = [&](uint32_t upto) {  // lines [flushed, upto): upto a multiple of 64, or the member's end
+    for (uint32_t p = flushed; p < upto; p += 64u) {
+      const uint32_t i = p + lane;
+      if (i < upto) out[i] = L.ring[i & ING_RING_MASK];
+    }
+    flushed = upto;
+  };
+  auto put_literal = [&](uint32_t b) {
+    if (lane == 0) L.ring[out_pos & ING_RING_MASK] = (uint8_t)b;
+    ++out_pos;
+    if ((out_pos & 63u) == 0) flush_lines(out_pos);
+  };
+  // bytes [out_pos, out_pos + len) = the len bytes starting dist back (RFC 1951 §3.2.3: may overlap what it writes)
+  auto copy_match = [&](uint32_t len, uint32_t dist) {
+    const bool near = dist <= ING_NEAR_MAX;
+    if (!near) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the lines flushed so far have reached the L2
+    for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+      const uint32_t i = i0 + lane;
+      uint8_t b = 0;
+      if (i < len) {
+        const uint32_t j = dist >= len ? i : i % dist;
+        const uint32_t src = out_pos - dist + j;
+        b = near ? L.ring[src & ING_RING_MASK] : ing_load_coherent(out + src);
+      }
+      if (i < len) L.ring[(out_pos + i) & ING_RING_MASK] = b;
+    }
+    out_pos += len;
+    if ((out_pos & ~63u) > flushed) flush_lines(out_pos & ~63u);
+  };
+  for (bool last = false; !last && !err;) {
+    bs.refill();
+    last = bs.take(1) != 0;
+    const uint32_t btype = bs.take(2);
+    if (btype == 0) {  // stored (RFC 1951 §3.2.4)
+      bs.drop(bs.cnt & 7u);
+      bs.refill();
+      const uint32_t len = bs.take(16), nlen = bs.take(16);
+      if ((len ^ nlen) != 0xFFFFu) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      const uint32_t from = bs.byte_pos();
+      if (from + len > in_off + in_len || out_pos + len > isize) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      const uint8_t *src = reinterpret_cast<const uint8_t *>(comp) + from;
+      for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+        const uint32_t n = min(64u, len - i0);
+        if (lane < n) L.ring[(out_pos + lane) & ING_RING_MASK] = src[i0 + lane];
+        out_pos += n;
+        if ((out_pos & ~63u) > flushed) flush_lines(out_pos & ~63u);
+      }
+      bs.start(comp, from + len);
+      continue;
+    }
+    if (btype == 3) {
+      err = GMX_INGEST_BAD_MEMBER;
+      break;
+    }
+    if (btype == 1) {  // fixed codes (§3.2.6)
+      for (uint32_t s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+      __syncthreads();
+      bool ok = ing_build(L.lens, 288, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0);
+      if (lane < 32) L.lens[lane] = 5;
+      __syncthreads();
+      ok = ing_build(L.lens, 32, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1) && ok;
+      if (!ok) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+    } else {  // dynamic codes (§3.2.7)
+      const uint32_t hlit = bs.take(5) + 257u, hdist = bs.take(5) + 1u, hclen = bs.take(4) + 4u;
+      if (hlit > 286u || hdist > 30u) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      if (lane < 19) L.lens[lane] = 0;
+      __syncthreads();
+      for (uint32_t i = 0; i < hclen; ++i) {
+        bs.refill();
+        const uint32_t v = bs.take(3);
+        // order of the code-length code's lengths: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+        const uint32_t sym = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1) + 0u;
+        if (lane == 0) L.lens[sym] = (uint8_t)v;
+      }
+      __syncthreads();
+      // (the code-length code's table borrows the distance table: root 7, every code at most 7 bits)
+      if (!ing_build(L.lens, 19, L.dist, 7, L.dist_sorted, L.dist_count, 2)) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      const uint32_t total = hlit + hdist;
+      uint32_t at = 0, prev = 0;
+      while (at < total && !err) {
+        bs.refill();
+        const uint32_t e = uni(L.dist[bs.peek(7)]);
+        if ((e & 15u) == 0) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        bs.drop(e & 15u);
+        const uint32_t sym = e >> 16;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16u) {
+          if (at == 0) {
+            err = GMX_INGEST_BAD_MEMBER;
+            break;
+          }
+          rep = 3u + bs.take(2);
+          val = prev;
+        } else if (sym == 17u) {
+          rep = 3u + bs.take(3);
+          val = 0;
+        } else if (sym == 18u) {
+          rep = 11u + bs.take(7);
+          val = 0;
+        }
+        if (at + rep > total) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        for (uint32_t i = lane; i < rep; i += 64u) L.lens[at + i] = (uint8_t)val;  // (lens[0, 19) held the code-length code's lengths: its table is built)
+        at += rep;
+        prev = val;
+      }
+      if (err) break;
+      for (uint32_t i = total + lane; i < 320u; i += 64u) L.lens[i] = 0;
+      __syncthreads();
+      if (uni(L.lens[256]) == 0) {  // no end-of-block code
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      bool ok = ing_build(L.lens, hlit, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0);
+      ok = ing_build(L.lens + hlit, hdist, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1) && ok;
+      if (!ok) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+    }
+    // ---- the block's symbols ----
+    for (;;) {
+      bs.refill();
+      uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
+      if ((e & 15u) == 0) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      if (((e >> 8) & 3u) == ING_T_LONG) {
+        uint32_t l;
+        const int sym = ing_decode_slow(bs, L.lit_count, L.lit_sorted, &l);
+        e = sym < 0 ? 0u : ing_entry(0, (uint32_t)sym, l);
+        if ((e & 15u) == 0) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+      } else {
+        bs.drop(e & 15u);
+      }
+      const uint32_t type = (e >> 8) & 3u;
+      if (type == ING_T_LIT) {
+        if (out_pos >= isize) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        put_literal(e >> 16);
+        continue;
+      }
+      if (type == ING_T_EOB) break;
+      const uint32_t len = (e >> 16) + bs.take((e >> 4) & 15u);
+      bs.refill();
+      uint32_t d = uni(L.dist[bs.peek(ING_DIST_ROOT)]);
+      if ((d & 15u) == 0) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      if (((d >> 8) & 3u) == ING_T_LONG) {
+        uint32_t l;
+        const int sym = ing_decode_slow(bs, L.dist_count, L.dist_sorted, &l);
+        d = sym < 0 ? 0u : ing_entry(1, (uint32_t)sym, l);
+        if ((d & 15u) == 0) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        bs.refill();
+      } else {
+        bs.drop(d & 15u);
+      }
+      const uint32_t dist = (d >> 16) + bs.take((d >> 4) & 15u);
+      if (dist > out_pos || out_pos + len > isize) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      copy_match(len, dist);
+    }
+  }
+  if (!err) {
+    flush_lines(out_pos);
+    // every byte of the member's deflate data used, and as much text as its trailer says
+    const uint32_t used_bits = (bs.next * 32u - bs.cnt) - in_off * 8u;
+    if (out_pos != isize || (used_bits + 7u) / 8u != in_len) err = GMX_INGEST_BAD_MEMBER;
+  }
+  if (!err && check_crc && isize) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    for (uint32_t i = lane; i < 256u; i += 64u) {  // the byte table, where the literal/length table was
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ ING_CRC_POLY : c >> 1;
+      L.lit[i] = c;
+    }
+    __syncthreads();
+    const uint32_t per = (isize + 63u) / 64u;
+    const uint32_t lo = min(isize, lane * per), hi = min(isize, lo + per);
+    uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u, n = hi - lo;
+    for (uint32_t i = lo; i < hi; ++i) c = L.lit[(c ^ ing_load_coherent(out + i)) & 0xFFu] ^ (c >> 8);
+    for (uint32_t dlt = 1; dlt < 64u; dlt <<= 1) {  // register of (left part || right part) = left * x^(8 |right|) + right
+      const uint32_t c_r = __shfl_down(c, dlt), n_r = __shfl_down(n, dlt);
+      if ((lane & (2u * dlt - 1u)) == 0) {
+        c = (n_r ? ing_mulmod(c, ing_xpow8(n_r)) : c) ^ c_r;
+        n += n_r;
+      }
+    }
+    if (uni(~c) != uni(members[mi].crc)) err = GMX_INGEST_BAD_CRC;
+  }
+  if (err && lane == 0) {
+    atomicOr(&st->flags, err);
+    atomicMin(&st->bad_member, mi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the chunk's text -> records -> bit planes
+// ------------------------------------------------------------------------------------------------------------------
+// starts a chunk: the incomplete last record of the chunk before (prev; null: a file's first chunk) in front of this one's text
+__global__ void gmx_carry_kernel(const IngestState *prev, const uint8_t *prev_text, IngestState *cur, uint8_t *cur_text, uint32_t members_text,
+                                 uint32_t final_chunk) {
+  uint32_t tail = 0;
+  if (prev) {
+    tail = prev->tail_len;
+    if (tail > ING_CARRY_MAX) tail = 0;  // (reported below)
+    const uint8_t *src = prev_text + prev->consumed;
+    uint8_t *dst = cur_text + ING_CARRY_MAX - tail;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < tail; i += gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cur->text_start = ING_CARRY_MAX - tail;
+    cur->text_len = tail + members_text;
+    cur->n_lines = cur->n_reads = 0;
+    cur->min_len = 0xFFFFFFFFu;
+    cur->max_len = 0;
+    cur->flags = (prev && prev->tail_len > ING_CARRY_MAX) ? GMX_INGEST_BAD_RECORD : 0u;
+    cur->bad_member = 0xFFFFFFFFu;
+    cur->consumed = ING_CARRY_MAX - tail;
+    cur->tail_len = 0;
+    cur->any_skip = 0;
+    cur->uniform_len = 0;
+    cur->n_bases = 0;
+    cur->n_pairs = 0;
+    for (int i = 0; i < 16; ++i) cur->sub_pairs[i] = 0;
+    cur->final_chunk = final_chunk;
+  }
+}
+
+#define ING_TILE 4096u  // bytes of text per 256-thread block of the newline kernels (16 per thread)
+__device__ __forceinline__ uint32_t ing_nl_mask16(const uint8_t *text, uint32_t at, uint32_t lo, uint32_t hi) {  // bit j: text[at + j] == '\n', within [lo, hi)
+  if (at + 16u <= lo || at >= hi) return 0u;
+  const uint4 v = *reinterpret_cast<const uint4 *>(text + at);  // (at a multiple of 16; the buffer is padded)
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t t = w[q] ^ 0x0A0A0A0Au;
+    const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 in every zero byte, exactly
+    m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
+  }
+  if (at < lo) m &= ~((1u << (lo - at)) - 1u);
+  if (at + 16u > hi) m &= (1u << (hi - at)) - 1u;
+  return m;
+}
+__global__ void __launch_bounds__(256) gmx_nl_count_kernel(const uint8_t *text, const IngestState *st, uint32_t *tile_count) {
+  const uint32_t lo = st->text_start, hi = lo + st->text_len;
+  const uint32_t at = blockIdx.x * ING_TILE + threadIdx.x * 16u;
+  uint32_t c = (uint32_t)__popc(ing_nl_mask16(text, at, lo, hi));
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+  __shared__ uint32_t part[4];
+  if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// exclusive scan of in[0, n) by ONE block of 1024 threads (n up to a few hundred thousand tiles / a few million reads);
+// out may alias in. total -> *total_out (64-bit)
+template <class TIn, class TOut>
+__device__ void ing_block_scan(const TIn *in, TOut *out, uint32_t n, unsigned long long *total_out) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
+  const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
+  unsigned long long s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += in[i];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024u; d <<= 1) {
+    const unsigned long long v = t >= d ? part[t - d] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = part[t] - s;
+  for (uint32_t i = lo; i < hi; ++i) {
+    const unsigned long long v = in[i];
+    out[i] = (TOut)run;
+    run += v;
+  }
+  if (t == 1023u && total_out) *total_out = part[1023];
+}
+__global__ void __launch_bounds__(1024) gmx_tile_scan_kernel(uint32_t *tile_count, uint32_t n_tiles, IngestState *st, uint32_t cap_lines) {
+  __shared__ unsigned long long total;
+  ing_block_scan<uint32_t, uint32_t>(tile_count, tile_count, n_tiles, &total);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->n_lines = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+    if (total > cap_lines) atomicOr(&st->flags, GMX_INGEST_TOO_MANY_LINES);
+  }
+}
+__global__ void __launch_bounds__(256) gmx_nl_mark_kernel(const uint8_t *text, const IngestState *st, const uint32_t *tile_base, uint32_t *line_end,
+                                                          uint32_t cap_lines) {
+  if (st->flags & GMX_INGEST_TOO_MANY_LINES) return;
+  const uint32_t lo = st->text_start, hi = lo + st->text_len;
+  const uint32_t at = blockIdx.x * ING_TILE + threadIdx.x * 16u;
+  uint32_t m = ing_nl_mask16(text, at, lo, hi);
+  const uint32_t c = (uint32_t)__popc(m);
+  uint32_t incl = c;  // inclusive scan over the block: within the wave by shuffles, across the four waves through LDS
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d);
+    if ((int)(threadIdx.x & 63u) >= d) incl += up;
+  }
+  __shared__ uint32_t wsum[4];
+  if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t before = tile_base[blockIdx.x] + incl - c;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
+  while (m) {
+    const uint32_t j = (uint32_t)__builtin_ctz(m);
+    m &= m - 1u;
+    if (before < cap_lines) line_end[before] = at + j;
+    ++before;
+  }
+}
+
+// One thread per record (grid-stride). Line i of the chunk ends at line_end[i]; a last line without '\n' ends at the text's
+// end when the chunk is the file's last.
+__global__ void __launch_bounds__(256) gmx_records_kernel(const uint8_t *text, IngestState *st, const uint32_t *line_end, uint32_t *rec_start,
+                                                          uint32_t *rec_len, uint8_t *skip, uint32_t cap_reads) {
+  if (st->flags & GMX_INGEST_TOO_MANY_LINES) return;
+  const uint32_t lo = st->text_start, hi = lo + st->text_len, n_nl = st->n_lines;
+  const uint32_t last_nl_end = n_nl ? line_end[n_nl - 1] + 1u : lo;
+  const bool virt = st->final_chunk && last_nl_end < hi;  // text behind the last newline of the file's last chunk: a line
+  const uint32_t lines = n_nl + (virt ? 1u : 0u);
+  uint32_t n_reads = lines / 4u;
+  bool too_many = false;
+  if (n_reads > cap_reads) {
+    n_reads = 0;
+    too_many = true;
+  }
+  auto le = [&](uint32_t i) { return i < n_nl ? line_end[i] : hi; };
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  unsigned long long bases = 0;
+  bool bad = false;
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += gridDim.x * blockDim.x) {
+    const uint32_t s1 = r ? line_end[4u * r - 1u] + 1u : lo;
+    const uint32_t e1 = le(4u * r), e2 = le(4u * r + 1u), e3 = le(4u * r + 2u), e4 = le(4u * r + 3u);
+    const uint32_t s2 = e1 + 1u, s3 = e2 + 1u, s4 = e3 + 1u;
+    uint32_t n = e2 - s2, nq = e4 >= s4 ? e4 - s4 : 0u;
+    if (n && text[s2 + n - 1u] == '\r') --n;
+    if (nq && text[s4 + nq - 1u] == '\r') --nq;
+    if (text[s1] != '@' || s3 >= hi || text[s3] != '+' || nq != n || n == 0) bad = true;
+    rec_start[r] = s2;
+    rec_len[r] = n;
+    skip[r] = 0;
+    mn = min(mn, n);
+    mx = max(mx, n);
+    bases += n;
+    if (r == n_reads - 1u) {
+      const uint32_t end = e4 < hi ? e4 + 1u : hi;
+      st->consumed = end;
+      st->tail_len = hi - end;
+      if (st->final_chunk && end != hi) atomicOr(&st->flags, GMX_INGEST_BAD_RECORD);
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->n_reads = n_reads;
+    if (too_many) atomicOr(&st->flags, GMX_INGEST_TOO_MANY_LINES);
+    if (n_reads == 0) {
+      st->consumed = lo;
+      st->tail_len = hi - lo;
+      if (st->final_chunk && hi != lo) atomicOr(&st->flags, GMX_INGEST_BAD_RECORD);  // fewer than four lines at the end of the file
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mn = min(mn, (uint32_t)__shfl_down(mn, off));
+    mx = max(mx, (uint32_t)__shfl_down(mx, off));
+    bases += __shfl_down(bases, off);
+  }
+  const unsigned long long any_bad = __ballot(bad);
+  if ((threadIdx.x & 63u) == 0) {
+    if (mn != 0xFFFFFFFFu) atomicMin(&st->min_len, mn);
+    if (mx) atomicMax(&st->max_len, mx);
+    if (bases) atomicAdd(&st->n_bases, bases);
+    if (any_bad) atomicOr(&st->flags, GMX_INGEST_BAD_RECORD);
+  }
+}
+// one length for all reads? -> layout of the planes; reads of different lengths: their base offsets (one block)
+__global__ void __launch_bounds__(1024) gmx_layout_kernel(IngestState *st, const uint32_t *rec_len, unsigned long long *offsets) {
+  const uint32_t n = st->n_reads;
+  const bool uniform = n != 0 && st->min_len == st->max_len;
+  if (uniform || n == 0) {
+    if (threadIdx.x == 0) {
+      st->uniform_len = uniform ? st->max_len : 0u;
+      const unsigned long long ppr = (st->max_len + 31u) / 32u;
+      st->n_pairs = (unsigned long long)n * ppr;
+      for (uint32_t i = 0; i < 16u; ++i) st->sub_pairs[i] = ((unsigned long long)i << 20) * ppr;
+    }
+    return;
+  }
+  __shared__ unsigned long long total;
+  ing_block_scan<uint32_t, unsigned long long>(rec_len, offsets, n, &total);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    offsets[n] = total;
+    st->uniform_len = 0;
+    st->n_pairs = (total >> 5) + n;
+  }
+  if (threadIdx.x < 16u) {
+    const unsigned long long r = (unsigned long long)threadIdx.x << 20;
+    st->sub_pairs[threadIdx.x] = r < n ? (offsets[r] >> 5) + r : 0ull;
+  }
+}
+// One thread per pair of planes: 32 letters -> (low bits, high bits) of the codes A,C,G,T = 0..3; from the letters' own bits
+// (bit 2 of the ASCII code is the code's high bit, bit 1 XOR bit 2 the low one: 'A' 0x41 'C' 0x43 'G' 0x47 'T' 0x54, either case)
+__global__ void __launch_bounds__(256) gmx_fq_pack_kernel(const uint8_t *text, IngestState *st, const uint32_t *rec_start, const uint32_t *rec_len,
+                                                          const unsigned long long *offsets, unsigned long long *planes, uint8_t *skip) {
+  if (st->flags & (GMX_INGEST_TOO_MANY_LINES | GMX_INGEST_BAD_RECORD)) return;
+  const uint32_t n_reads = st->n_reads, uniform = st->uniform_len;
+  const uint32_t wpr = (st->max_len + 31u) / 32u + (uniform ? 0u : 1u);
+  const unsigned long long items = (unsigned long long)n_reads * wpr;
+  for (unsigned long long it = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (unsigned long long)gridDim.x * blockDim.x) {
+    const uint32_t r = (uint32_t)(it / wpr), w = (uint32_t)(it - (unsigned long long)r * wpr);
+    const uint32_t len = rec_len[r];
+    unsigned long long first, count;
+    if (uniform) {
+      first = (unsigned long long)r * wpr;
+      count = wpr;
+    } else {
+      const unsigned long long off = offsets[r];
+      first = (off >> 5) + r;
+      count = ((off + len) >> 5) - (off >> 5) + 1ull;
+    }
+    if (w >= count) continue;
+    uint32_t lo = 0, hi = 0;
+    bool ok = true;
+    if (w * 32u < len) {
+      const uint8_t *src = text + rec_start[r] + w * 32u;
+      const uint32_t m = min(32u, len - w * 32u);
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t c = src[j], u = c & 0xDFu;
+        ok = ok && (u == 0x41u || u == 0x43u || u == 0x47u || u == 0x54u);
+        const uint32_t h = (c >> 2) & 1u;
+        hi |= h << j;
+        lo |= (((c >> 1) & 1u) ^ h) << j;
+      }
+    }
+    planes[first + w] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    if (!ok) {
+      skip[r] = 1;
+      st->any_skip = 1;
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct gmx_ingest {
+  int device = 0;
+  uint64_t max_text = 0, max_comp = 0;
+  uint32_t cap_reads = 0, cap_lines = 0, cap_members = 0, n_tiles_max = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  struct Slot {
+    uint32_t *d_comp = nullptr;
+    IngestMember *d_members = nullptr;
+    uint8_t *d_text = nullptr;
+    uint32_t *d_line_end = nullptr, *d_rec_start = nullptr, *d_rec_len = nullptr, *d_tiles = nullptr;
+    unsigned long long *d_planes = nullptr, *d_offsets = nullptr;
+    uint8_t *d_skip = nullptr;
+    IngestState *d_state = nullptr, *h_state = nullptr;
+    IngestMember *h_members = nullptr;  // page-locked staging of the member table
+    hipEvent_t copied = nullptr, done = nullptr, released = nullptr;
+    bool in_flight = false, has_release = false;
+  } slot[2];
+  int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
+  std::vector<void *> allocs;
+  int check_crc = 1;
+};
+
+namespace {
+template <class T>
+int ing_alloc(gmx_ingest *g, T **p, size_t count, bool zero) {
+  void *q = nullptr;
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  ING_TRY(hipMalloc(&q, bytes));
+  if (zero) ING_TRY(hipMemset(q, 0, bytes));
+  g->allocs.push_back(q);
+  *p = static_cast<T *>(q);
+  return GMX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
+  if (!out || max_text_bytes < (1u << 16) || max_text_bytes > (3ull << 30)) {
+    gmx_set_error("gmx_ingest_create: max_text_bytes must lie between 64 KB and 3 GB");
+    return GMX_EINVAL;
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) {
+    (void)hipGetLastError();
+    gmx_set_error("gmx_ingest_create: no such HIP device (reads are decoded on the GPU: there is no CPU fallback here)");
+    return GMX_ENODEV;
+  }
+  ING_TRY(hipSetDevice(device));
+  gmx_ingest *g = new gmx_ingest();
+  g->device = device;
+  g->max_text = max_text_bytes;
+  g->max_comp = max_text_bytes / 2 + (1u << 20);
+  g->cap_reads = (uint32_t)(max_text_bytes / 32 + 1024);
+  g->cap_lines = 4u * g->cap_reads + 8u;
+  g->cap_members = (uint32_t)(max_text_bytes / 512 + 1024);  // (members of half a KB of text on average, or larger)
+  g->n_tiles_max = (uint32_t)((ING_CARRY_MAX + max_text_bytes + ING_TILE - 1) / ING_TILE);
+  g->check_crc = getenv("GMX_INGEST_NO_CRC") ? 0 : 1;
+  int rc = GMX_OK;
+  auto fail = [&](int code) {
+    gmx_ingest_destroy(g);
+    return code;
+  };
+  if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    gmx_set_error("gmx_ingest_create: hipStreamCreate failed");
+    return fail(GMX_EHIP);
+  }
+  for (auto &s : g->slot) {
+    if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 16, true)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
+        (rc = ing_alloc(g, &s.d_text, ING_CARRY_MAX + max_text_bytes + 64, true)) || (rc = ing_alloc(g, &s.d_line_end, g->cap_lines, false)) ||
+        (rc = ing_alloc(g, &s.d_rec_start, g->cap_reads, false)) || (rc = ing_alloc(g, &s.d_rec_len, g->cap_reads, false)) ||
+        (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, true)) ||
+        (rc = ing_alloc(g, &s.d_offsets, (size_t)g->cap_reads + 1, false)) || (rc = ing_alloc(g, &s.d_skip, g->cap_reads, true)) ||
+        (rc = ing_alloc(g, &s.d_state, 1, true)))
+      return fail(rc);
+    if (hipHostMalloc(reinterpret_cast<void **>(&s.h_state), sizeof(IngestState), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&s.h_members), (size_t)g->cap_members * sizeof(IngestMember), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
+        hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess) {
+      gmx_set_error("gmx_ingest_create: page-locked memory / events");
+      return fail(GMX_EHIP);
+    }
+  }
+  *out = g;
+  return GMX_OK;
+}
+
+void gmx_ingest_destroy(gmx_ingest *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+  for (auto &s : g->slot) {
+    if (s.h_state) (void)hipHostFree(s.h_state);
+    if (s.h_members) (void)hipHostFree(s.h_members);
+    if (s.copied) (void)hipEventDestroy(s.copied);
+    if (s.done) (void)hipEventDestroy(s.done);
+    if (s.released) (void)hipEventDestroy(s.released);
+  }
+  for (void *p : g->allocs) (void)hipFree(p);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  (void)hipGetLastError();
+  delete g;
+}
+
+uint64_t gmx_ingest_max_text(const gmx_ingest *g) { return g ? g->max_text : 0; }
+uint64_t gmx_ingest_max_compressed(const gmx_ingest *g) { return g ? g->max_comp : 0; }
+
+int gmx_ingest_reset(gmx_ingest *g) {  // the next chunk starts a file: nothing is carried into it
+  if (!g) {
+    gmx_set_error("null ingest");
+    return GMX_EINVAL;
+  }
+  g->last_slot = -1;
+  return GMX_OK;
+}
+
+// the kernels behind a chunk's text, the result's copy to the host, the slot's event
+static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int final_chunk, bool inflate, uint32_t n_members) {
+  gmx_ingest::Slot &s = g->slot[si];
+  const gmx_ingest::Slot *prev = g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
+  hipLaunchKernelGGL(gmx_carry_kernel, dim3(64), dim3(256), 0, g->stream, prev ? prev->d_state : nullptr, prev ? prev->d_text : nullptr, s.d_state, s.d_text,
+                     members_text, (uint32_t)(final_chunk ? 1 : 0));
+  if (inflate && n_members)
+    hipLaunchKernelGGL(gmx_inflate_kernel, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX, s.d_state,
+                       g->check_crc);
+  const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
+  hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);
+  hipLaunchKernelGGL(gmx_tile_scan_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_tiles, n_tiles, s.d_state, g->cap_lines);
+  hipLaunchKernelGGL(gmx_nl_mark_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles, s.d_line_end, g->cap_lines);
+  hipLaunchKernelGGL(gmx_records_kernel, dim3(2048), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_line_end, s.d_rec_start, s.d_rec_len, s.d_skip, g->cap_reads);
+  hipLaunchKernelGGL(gmx_layout_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_state, s.d_rec_len, s.d_offsets);
+  hipLaunchKernelGGL(gmx_fq_pack_kernel, dim3(4096), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_rec_start, s.d_rec_len, s.d_offsets, s.d_planes, s.d_skip);
+  ING_TRY(hipGetLastError());
+  ING_TRY(hipMemcpyAsync(s.h_state, s.d_state, sizeof(IngestState), hipMemcpyDeviceToHost, g->stream));
+  ING_TRY(hipEventRecord(s.done, g->stream));
+  s.in_flight = true;
+  g->last_slot = si;
+  return GMX_OK;
+}
+
+static int ing_begin(gmx_ingest *g, int si, const char *who) {
+  if (!g || si < 0 || si > 1) {
+    gmx_set_error(std::string(who) + ": null ingest or slot not 0 / 1");
+    return GMX_EINVAL;
+  }
+  if (g->slot[si].in_flight) {
+    gmx_set_error(std::string(who) + ": the slot's chunk before has not been waited for (gmx_ingest_wait)");
+    return GMX_EINVAL;
+  }
+  ING_TRY(hipSetDevice(g->device));
+  gmx_ingest::Slot &s = g->slot[si];
+  if (s.has_release) {  // the mapping kernels that read the slot's planes (gmx_ingest_release_after)
+    ING_TRY(hipStreamWaitEvent(g->copy_stream, s.released, 0));
+    ING_TRY(hipStreamWaitEvent(g->stream, s.released, 0));
+    s.has_release = false;
+  }
+  return GMX_OK;
+}
+
+int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members, uint64_t n_members,
+                           int final_chunk) {
+  int rc = ing_begin(g, slot, "gmx_ingest_submit_bgzf");
+  if (rc) return rc;
+  if ((!compressed && n_bytes) || (!members && n_members) || n_bytes > g->max_comp || n_members > g->cap_members) {
+    gmx_set_error("gmx_ingest_submit_bgzf: null argument, or more compressed bytes / members than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  gmx_ingest::Slot &s = g->slot[slot];
+  uint64_t text = 0;
+  for (uint64_t i = 0; i < n_members; ++i) {
+    const gmx_bgzf_member &m = members[i];
+    if (m.offset + m.size > n_bytes || m.isize > (1u << 16)) {
+      gmx_set_error("gmx_ingest_submit_bgzf: member " + std::to_string(i) + " lies outside the bytes given, or holds more than 64 KB of text");
+      return GMX_EINVAL;
+    }
+    s.h_members[i] = IngestMember{(uint32_t)m.offset, (uint32_t)m.size, (uint32_t)text, m.isize, m.crc32, 0u};
+    text += m.isize;
+  }
+  if (text > g->max_text) {
+    gmx_set_error("gmx_ingest_submit_bgzf: the members hold more text than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  // (the last word of the deflate data is fetched whole, and one more: the staging buffer has slack, zeroed here)
+  if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_comp, compressed, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.d_comp) + n_bytes, 0, 16, g->copy_stream));
+  if (n_members) ING_TRY(hipMemcpyAsync(s.d_members, s.h_members, n_members * sizeof(IngestMember), hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipEventRecord(s.copied, g->copy_stream));
+  ING_TRY(hipStreamWaitEvent(g->stream, s.copied, 0));
+  return ing_enqueue_scan(g, slot, (uint32_t)text, final_chunk, true, (uint32_t)n_members);
+}
+
+int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes, int final_chunk) {
+  int rc = ing_begin(g, slot, "gmx_ingest_submit_text");
+  if (rc) return rc;
+  if ((!text && n_bytes) || n_bytes > g->max_text) {
+    gmx_set_error("gmx_ingest_submit_text: null text, or more text than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  gmx_ingest::Slot &s = g->slot[slot];
+  if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX, text, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipEventRecord(s.copied, g->copy_stream));
+  ING_TRY(hipStreamWaitEvent(g->stream, s.copied, 0));
+  return ing_enqueue_scan(g, slot, (uint32_t)n_bytes, final_chunk, false, 0);
+}
+
+int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {
+  if (!g || slot < 0 || slot > 1 || !out) {
+    gmx_set_error("gmx_ingest_wait: null argument or slot not 0 / 1");
+    return GMX_EINVAL;
+  }
+  gmx_ingest::Slot &s = g->slot[slot];
+  if (!s.in_flight) {
+    gmx_set_error("gmx_ingest_wait: nothing was submitted to the slot");
+    return GMX_EINVAL;
+  }
+  ING_TRY(hipSetDevice(g->device));
+  ING_TRY(hipEventSynchronize(s.done));
+  s.in_flight = false;
+  const IngestState &st = *s.h_state;
+  memset(out, 0, sizeof(*out));
+  out->status = st.flags;
+  out->bad_member = st.bad_member;
+  out->n_reads = st.n_reads;
+  out->n_bases = st.n_bases;
+  out->uniform_len = st.uniform_len;
+  out->any_skip = st.any_skip;
+  out->n_pairs = st.n_pairs;
+  out->text_bytes = st.text_len;
+  out->consumed_bytes = st.consumed - st.text_start;
+  out->tail_bytes = st.tail_len;
+  for (int i = 0; i < 16; ++i) out->sub_pairs[i] = st.sub_pairs[i];
+  out->d_planes = reinterpret_cast<const uint64_t *>(s.d_planes);
+  out->d_offsets = st.uniform_len ? nullptr : reinterpret_cast<const uint64_t *>(s.d_offsets);
+  out->d_skip = s.d_skip;
+  return GMX_OK;
+}
+
+int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) {
+  if (!g || slot < 0 || slot > 1) {
+    gmx_set_error("gmx_ingest_release_after: null ingest or slot not 0 / 1");
+    return GMX_EINVAL;
+  }
+  ING_TRY(hipSetDevice(g->device));
+  ING_TRY(hipEventRecord(g->slot[slot].released, (hipStream_t)hip_stream));
+  g->slot[slot].has_release = true;
+  return GMX_OK;
+}
+
+int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
+  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+    gmx_set_error("gmx_ingest_fetch_text: null ingest, bad slot, or the slot's chunk is still in flight");
+    return GMX_EINVAL;
+  }
+  const IngestState &st = *g->slot[slot].h_state;
+  if (!out) return (int64_t)st.text_len;
+  if (cap < st.text_len) {
+    gmx_set_error("gmx_ingest_fetch_text: buffer too small");
+    return GMX_EINVAL;
+  }
+  if (hipSetDevice(g->device) != hipSuccess || hipMemcpy(out, g->slot[slot].d_text + st.text_start, st.text_len, hipMemcpyDeviceToHost) != hipSuccess) {
+    gmx_set_error("gmx_ingest_fetch_text: hipMemcpy failed");
+    return GMX_EHIP;
+  }
+  return (int64_t)st.text_len;
+}
+
+int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *offsets, uint8_t *skip) {
+  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+    gmx_set_error("gmx_ingest_fetch_reads: null ingest, bad slot, or the slot's chunk is still in flight");
+    return GMX_EINVAL;
+  }
+  const gmx_ingest::Slot &s = g->slot[slot];
+  const IngestState &st = *s.h_state;
+  ING_TRY(hipSetDevice(g->device));
+  if (planes && st.n_pairs) ING_TRY(hipMemcpy(planes, s.d_planes, st.n_pairs * 8, hipMemcpyDeviceToHost));
+  if (offsets && !st.uniform_len && st.n_reads) ING_TRY(hipMemcpy(offsets, s.d_offsets, ((size_t)st.n_reads + 1) * 8, hipMemcpyDeviceToHost));
+  if (skip && st.n_reads) ING_TRY(hipMemcpy(skip, s.d_skip, st.n_reads, hipMemcpyDeviceToHost));
+  return GMX_OK;
+}
+
+}  // extern "C"

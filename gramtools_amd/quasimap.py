@@ -19,6 +19,7 @@ from . import _lib
 from ._lib import check
 
 RNG_LEMIRE = 0
+GMX_INGEST_BAD_RECORD, GMX_INGEST_BAD_MEMBER, GMX_INGEST_BAD_CRC, GMX_INGEST_TOO_MANY_LINES = 1, 2, 4, 8  # gmx_ingest_result.status
 RNG_DIVISION = 1
 GROUPED_LOG = 0xFFFFFFFF
 
@@ -517,6 +518,19 @@ class Quasimapper:
         there (gmx_engine_seeds_in_place). The seeds must then stay untouched until sync() / coverage()."""
         check(self.lib.gmx_engine_seeds_in_place(self.h, 1 if on else 0))
 
+    def map_ingested(self, res, seeds: "PinnedArray"):
+        """The reads a slot of an Ingest holds (gmx_ingest_result), mapped where they lie in HBM (gmx_map_reads_packed_device);
+        `seeds`: a PinnedArray of uint32, one per read, read in place by the kernels."""
+        n = int(res.n_reads)
+        if res.uniform_len:
+            check(self.lib.gmx_map_reads_packed_device(self.h, res.d_planes, None, res.uniform_len, seeds.ptr, res.d_skip if res.any_skip else None, n))
+        else:
+            for i, r0 in enumerate(range(0, n, 1 << 20)):
+                m = min(1 << 20, n - r0)
+                check(self.lib.gmx_map_reads_packed_device(self.h, res.d_planes + 8 * int(res.sub_pairs[i]), res.d_offsets + 8 * r0, 0,
+                                                           seeds.ptr + 4 * r0, (res.d_skip + r0) if res.any_skip else None, m))
+        self._last_seeds = seeds
+
     def map_reads_device(self, d_reads, d_offsets, d_seeds, n_reads, stream=None):
         """Device-resident buffers (torch CUDA tensors: uint8 / int64-or-uint64 / int32-or-uint32). Asynchronous."""
         sp = C.c_void_p(stream) if stream else None
@@ -650,6 +664,95 @@ class Quasimapper:
         stats = QuasimapReadsStats(st.all_reads_count, st.skipped_reads_count, st.missing_kmer_reads_count,
                                    st.no_extension_reads_count, st.exact_mapped_reads_count)
         return Coverage(self.index, a[:info.n_allele_slots], p[:info.n_per_base_slots], g[:info.n_grouped_slots], log[:n], stats)
+
+
+def bgzf_members(data) -> list:
+    """The members of a BGZF file (SAM spec 4.1) as (offset of the deflate data, its size, isize, crc32) without inflating
+    anything: the walk `gram` does before it hands a file to the device (gmx_ingest_submit_bgzf). Raises ValueError on
+    anything that is not a BGZF member; the EOF marker (an empty member) is dropped."""
+    import struct
+    mv = memoryview(data)
+    out, at, n = [], 0, len(mv)
+    while at < n:
+        if at + 18 > n or bytes(mv[at:at + 4]) != b"\x1f\x8b\x08\x04":
+            raise ValueError(f"no BGZF member at byte {at}")
+        xlen = struct.unpack_from("<H", mv, at + 10)[0]
+        x, bsize = 0, None
+        while x + 4 <= xlen:
+            si1, si2, slen = struct.unpack_from("<BBH", mv, at + 12 + x)
+            if si1 == 66 and si2 == 67 and slen == 2:
+                bsize = struct.unpack_from("<H", mv, at + 12 + x + 4)[0] + 1
+            x += 4 + slen
+        if bsize is None or bsize < 12 + xlen + 8 or at + bsize > n:
+            raise ValueError(f"damaged BGZF member at byte {at}")
+        crc, isize = struct.unpack_from("<II", mv, at + bsize - 8)
+        if isize:
+            out.append((at + 12 + xlen, bsize - 12 - xlen - 8, isize, crc))
+        at += bsize
+    return out
+
+
+class Ingest:
+    """Reads files decoded on the device (include/gmx.h, gmx_ingest_*): BGZF members inflated, four-line records found and
+    packed into bit planes by HIP kernels; two slots. ``submit_bgzf`` / ``submit_text`` enqueue a chunk, ``wait`` returns
+    its gmx_ingest_result; Quasimapper.map_ingested maps what a slot holds."""
+
+    def __init__(self, device: int = 0, max_text_bytes: int = 64 << 20):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        check(self.lib.gmx_ingest_create(device, max_text_bytes, C.byref(self.h)))
+        self._keep = [None, None]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gmx_ingest_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        check(self.lib.gmx_ingest_reset(self.h))
+
+    def submit_bgzf(self, slot: int, data, members, final: bool):
+        """`data`: bytes-like holding the chunk's members; `members`: (offset, size, isize, crc32) of each, offsets into data."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        arr = (_lib.BgzfMember * max(len(members), 1))()
+        for i, (off, size, isize, crc) in enumerate(members):
+            arr[i] = _lib.BgzfMember(off, size, isize, crc, 0)
+        self._keep[slot] = (buf, arr)
+        check(self.lib.gmx_ingest_submit_bgzf(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, len(members), 1 if final else 0))
+
+    def submit_text(self, slot: int, text, final: bool):
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        self._keep[slot] = (buf,)
+        check(self.lib.gmx_ingest_submit_text(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, 1 if final else 0))
+
+    def wait(self, slot: int) -> "_lib.IngestResult":
+        res = _lib.IngestResult()
+        check(self.lib.gmx_ingest_wait(self.h, slot, C.byref(res)))
+        self._keep[slot] = None
+        return res
+
+    def release_after(self, slot: int, stream=None):
+        check(self.lib.gmx_ingest_release_after(self.h, slot, C.c_void_p(stream) if stream else None))
+
+    def fetch_text(self, slot: int) -> bytes:
+        n = self.lib.gmx_ingest_fetch_text(self.h, slot, None, 0)
+        if n < 0:
+            check(int(n))
+        out = np.zeros(max(int(n), 1), dtype=np.uint8)
+        got = self.lib.gmx_ingest_fetch_text(self.h, slot, out.ctypes.data, out.size)
+        if got < 0:
+            check(int(got))
+        return out[:int(n)].tobytes()
+
+    def fetch_reads(self, slot: int, res) -> "PackedReads":
+        """The slot's reads in the host layout (bit planes, offsets, skip flags): what the host parser produces of the same text."""
+        planes = np.zeros(int(res.n_pairs) + 8, dtype=np.uint64)
+        offsets = None if res.uniform_len else np.zeros(int(res.n_reads) + 1, dtype=np.uint64)
+        skip = np.zeros(max(int(res.n_reads), 1), dtype=np.uint8)
+        check(self.lib.gmx_ingest_fetch_reads(self.h, slot, planes.ctypes.data, None if offsets is None else offsets.ctypes.data, skip.ctypes.data))
+        return PackedReads(planes, offsets, int(res.uniform_len), skip, int(res.n_reads))
 
 
 class QuasimapperGroup:

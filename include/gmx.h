@@ -196,6 +196,68 @@ int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_
 uint64_t gmx_twobit_units(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads);
 int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *stream,
                         uint8_t *skip, int threads);
+/* The same from bit planes that are already IN HBM (what gmx_ingest_* below leaves there): nothing is uploaded but the
+ * seeds — `seeds` is a device pointer, or a gmx_host_alloc pointer, which the kernels then read in place over PCIe as with
+ * gmx_engine_seeds_in_place. Layout of d_planes / d_offsets / d_skip as for gmx_map_reads_packed_host; with d_offsets the
+ * call takes at most 2^20 reads (a longer batch is split by the caller at reads whose pair index it knows:
+ * gmx_ingest_result::sub_pairs). Enqueues on the engine's stream without synchronising; the buffers must stay untouched
+ * until gmx_engine_sync (or an event recorded behind the call on the NULL stream). */
+int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const uint64_t *d_offsets, uint32_t uniform_len,
+                                const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads);
+
+/* ---- reads files decoded on the device -----------------------------------------------------------
+ * Replaces the reference's reads reader for gzipped FASTQ — SeqRead over zlib / htslib on one host thread
+ * (include/sequence_read/seqread.hpp:94-180, quasimap.cpp:65-76) — for BGZF files (bgzip, htslib, BCL Convert: gzip members
+ * of <= 64 KB that carry their size in a `BC` extra field, SAM spec §4.1): the compressed members are uploaded as they lie in
+ * the file and HIP kernels inflate them (one wavefront per member, CRC-32 checked), find the four-line records and pack
+ * their bases into the bit planes of gmx_map_reads_packed_host, all in HBM. A file is handed over in CHUNKS of whole
+ * members, in order; a record cut by a chunk's end is carried into the next chunk on the device. Two slots alternate, so
+ * that a chunk uploads and inflates while the one before is mapped:
+ *     submit(slot 0, chunk 0); submit(slot 1, chunk 1); wait(slot 0) -> map -> release_after(slot 0); submit(slot 0, chunk 2); ...
+ * There is no CPU fallback inside: a chunk the kernels cannot take (status != 0) is the caller's to handle — `gram` inflates
+ * it with zlib and passes the text through gmx_ingest_submit_text (same kernels behind the inflate step), or reports the
+ * file as damaged when zlib agrees. */
+typedef struct gmx_ingest gmx_ingest;
+typedef struct {
+  uint64_t offset;   /* of the member's deflate data within the chunk's bytes (behind the gzip header and its extra field) */
+  uint32_t size;     /* bytes of deflate data */
+  uint32_t isize;    /* bytes of text it inflates to (the member's trailer; <= 65536) */
+  uint32_t crc32;    /* of that text (the trailer) */
+  uint32_t reserved;
+} gmx_bgzf_member;
+#define GMX_INGEST_BAD_RECORD 1u      /* not plain four-line FASTQ (blank / multi-line record, '@' or '+' missing, lengths differ) */
+#define GMX_INGEST_BAD_MEMBER 2u      /* a member's deflate data could not be decoded */
+#define GMX_INGEST_BAD_CRC 4u         /* a member's text does not match its trailer */
+#define GMX_INGEST_TOO_MANY_LINES 8u  /* more lines / records than the ingest has room for (lines of a few bytes) */
+typedef struct {
+  uint32_t status;        /* 0, or GMX_INGEST_* bits: the reads below are then NOT to be used */
+  uint32_t bad_member;    /* first member (index within the chunk) with GMX_INGEST_BAD_MEMBER / _BAD_CRC */
+  uint64_t n_reads, n_bases, n_pairs;
+  uint32_t uniform_len;   /* != 0: every read has this many bases (d_offsets is NULL) */
+  uint32_t any_skip;      /* some read holds a non-ACGT letter (d_skip says which) */
+  uint64_t text_bytes;    /* text of the chunk, the carried start of its first record included */
+  uint64_t consumed_bytes, tail_bytes; /* taken by complete records / carried into the next chunk */
+  uint64_t sub_pairs[16]; /* pair index of read i * 2^20 within d_planes (reads of different lengths: where a sub-batch starts) */
+  const uint64_t *d_planes, *d_offsets; /* device memory of the slot, valid until the slot's next submit */
+  const uint8_t *d_skip;
+} gmx_ingest_result;
+/* max_text_bytes: most text (inflated bytes) a chunk may hold; compressed bytes per chunk: up to gmx_ingest_max_compressed(). */
+int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out);
+void gmx_ingest_destroy(gmx_ingest *g);
+uint64_t gmx_ingest_max_text(const gmx_ingest *g);
+uint64_t gmx_ingest_max_compressed(const gmx_ingest *g);
+int gmx_ingest_reset(gmx_ingest *g); /* the next chunk is a file's first: nothing is carried into it */
+/* `compressed` (host memory; page-locked = asynchronous upload) must stay untouched until the slot's gmx_ingest_wait. */
+int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members,
+                           uint64_t n_members, int final_chunk);
+int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes, int final_chunk);
+int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out);
+/* The slot's planes are read by work enqueued on hip_stream (the mapping call): its next submit waits for that work. */
+int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream);
+/* test hooks: the chunk's text (NULL out: its length), its reads in the host layout of gmx_map_reads_packed_host */
+int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap);
+int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *offsets, uint8_t *skip);
+
 /* Page-locked host memory for the buffers handed to gmx_map_reads_host: the upload is then one DMA at the PCIe rate
  * instead of being staged through small pinned chunks by the runtime. Falls back to plain memory without a device (the
  * parsers also run in tests without one). gmx_host_free takes only pointers gmx_host_alloc returned. */

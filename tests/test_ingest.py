@@ -1,0 +1,243 @@
+"""Reads files decoded on the device (include/gmx.h gmx_ingest_*, gmx_ingest.hip): BGZF members inflated by HIP kernels, records
+found and packed into bit planes there. Checked against zlib (the text), against the host packer (planes, offsets, skip flags)
+and, end to end, against the byte feed (coverage). Replaces the reference's reader for gzipped FASTQ
+(libgramtools/include/sequence_read/seqread.hpp:94-180, src/genotype/quasimap/quasimap.cpp:65-76)."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf(data: bytes, block=65280, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, eof=True) -> bytes:
+    out = bytearray()
+    for i in range(0, len(data), block):
+        piece = data[i:i + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        comp = c.compress(piece) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+        out += comp + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece))
+    if eof:
+        out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    return bytes(out)
+
+
+def fastq(rng, n, lo, hi, bad_every=0, crlf=False, lower=False):
+    """n records with lengths in [lo, hi]; every bad_every-th read holds an N. Returns (text, list of sequences)."""
+    seqs, lines = [], []
+    nl = "\r\n" if crlf else "\n"
+    for i in range(n):
+        ln = int(rng.integers(lo, hi + 1))
+        s = "".join("ACGT"[c] for c in rng.integers(0, 4, ln))
+        if lower and i % 3 == 0:
+            s = s.lower()
+        if bad_every and i % bad_every == bad_every - 1:
+            k = int(rng.integers(0, ln))
+            s = s[:k] + "N" + s[k + 1:]
+        q = "".join(chr(33 + int(c)) for c in rng.integers(2, 41, ln))
+        seqs.append(s)
+        lines.append(f"@read{i} some/description:{i * 7919}{nl}{s}{nl}+{nl}{q}{nl}")
+    return "".join(lines).encode(), seqs
+
+
+def expected_planes(seqs):
+    """Planes / offsets / skip as the host packer makes them (gmx_pack_reads) of the encoded reads."""
+    from gramtools_amd import pack_reads
+    lens = np.array([len(s) for s in seqs], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    tab = np.zeros(256, dtype=np.uint8)
+    for ch, v in zip("ACGTacgt", (1, 2, 3, 4, 1, 2, 3, 4)):
+        tab[ord(ch)] = v
+    flat = tab[np.frombuffer("".join(seqs).encode(), dtype=np.uint8)]
+    uniform = int(lens[0]) if len(seqs) and (lens == lens[0]).all() else 0
+    return pack_reads(flat, offs, uniform_len=uniform), offs, uniform
+
+
+def check_reads(ing, slot, res, seqs):
+    from gramtools_amd import pack_reads  # noqa: F401
+    exp, offs, uniform = expected_planes(seqs)
+    assert res.status == 0, f"status {res.status} (member {res.bad_member})"
+    assert res.n_reads == len(seqs)
+    assert res.uniform_len == uniform
+    assert res.n_bases == int(offs[-1])
+    got = ing.fetch_reads(slot, res)
+    skip_exp = np.array([0 if set(s.upper()) <= set("ACGT") else 1 for s in seqs], dtype=np.uint8)
+    assert (got.skip[:len(seqs)] == skip_exp).all()
+    assert bool(res.any_skip) == bool(skip_exp.any())
+    if not uniform:
+        assert (got.offsets == offs).all()
+    n_pairs = int(res.n_pairs)
+    if skip_exp.any():  # an unencodable read's planes are whatever its letters' bits give: compare the others pair by pair
+        ppr = (uniform + 31) // 32
+        for r, s in enumerate(seqs):
+            if skip_exp[r]:
+                continue
+            p0 = r * ppr if uniform else (int(offs[r]) >> 5) + r
+            k = (len(s) + 31) // 32
+            assert (got.planes[p0:p0 + k] == exp.planes[p0:p0 + k]).all(), f"read {r}"
+    else:
+        assert (got.planes[:n_pairs] == exp.planes[:n_pairs]).all()
+
+
+@pytest.mark.parametrize("level,strategy,block", [(6, zlib.Z_DEFAULT_STRATEGY, 65280), (1, zlib.Z_DEFAULT_STRATEGY, 20000), (9, zlib.Z_DEFAULT_STRATEGY, 65280),
+                                                  (0, zlib.Z_DEFAULT_STRATEGY, 30000), (6, zlib.Z_FIXED, 40000), (6, zlib.Z_HUFFMAN_ONLY, 65280),
+                                                  (6, zlib.Z_RLE, 3000)])
+def test_bgzf_members_inflate_to_the_text_zlib_gives(level, strategy, block):
+    """Every kind of deflate block (stored, fixed codes, dynamic codes; matches near and far) through gmx_inflate_kernel; the
+    text is compared byte for byte, the member CRCs are checked on the device, the reads against the host packer."""
+    from gramtools_amd import Ingest, bgzf_members
+    rng = np.random.default_rng(level * 17 + block)
+    text, seqs = fastq(rng, 3000, 150, 150)
+    data = bgzf(text, block=block, level=level, strategy=strategy)
+    ing = Ingest(max_text_bytes=4 << 20)
+    ing.submit_bgzf(0, data, bgzf_members(data), True)
+    res = ing.wait(0)
+    assert res.status == 0, f"status {res.status} at member {res.bad_member}"
+    assert ing.fetch_text(0) == text
+    check_reads(ing, 0, res, seqs)
+    ing.close()
+
+
+def test_far_matches_and_long_codes():
+    """Text that is not FASTQ-like at all: distances beyond the LDS window (repeats 5-30 KB apart), all 256 byte values (codes
+    longer than the table's root bits). Only the inflate step is looked at (the record scan reports it as irregular)."""
+    from gramtools_amd import Ingest, bgzf_members, GMX_INGEST_BAD_RECORD
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, 20000, dtype=np.uint8).tobytes()
+    skew = bytes(rng.choice(256, 60000, p=np.array([2.0 ** -(i // 8) for i in range(256)]) / sum(2.0 ** -(i // 8) for i in range(256))).astype(np.uint8))
+    text = a[:7000] + skew[:20000] + a[:7000] + skew[20000:] + a + a[3000:9000]
+    data = bgzf(text, block=65000, level=9)
+    ing = Ingest(max_text_bytes=1 << 20)
+    ing.submit_bgzf(0, data, bgzf_members(data), True)
+    res = ing.wait(0)
+    assert res.status & ~(GMX_INGEST_BAD_RECORD | 8) == 0, f"status {res.status} at member {res.bad_member}"
+    assert ing.fetch_text(0) == text
+    ing.close()
+
+
+@pytest.mark.parametrize("lo,hi,bad,crlf", [(150, 150, 0, False), (100, 150, 0, False), (36, 251, 7, False), (150, 150, 50, True), (1, 40, 0, False)])
+def test_records_across_chunks(lo, hi, bad, crlf):
+    """A file handed over in chunks of a few members, alternating slots: records cut by a chunk's end continue in the next
+    (the tail is carried on the device), reads of one length / ragged, non-ACGT letters, CRLF line ends, lower case."""
+    from gramtools_amd import Ingest, bgzf_members
+    rng = np.random.default_rng(lo * 1000 + hi)
+    text, seqs = fastq(rng, 4000, lo, hi, bad_every=bad, crlf=crlf, lower=True)
+    data = bgzf(text, block=7001)
+    mem = bgzf_members(data)
+    ing = Ingest(max_text_bytes=1 << 20)
+    got_reads, at, slot = 0, 0, 0
+    step = 9
+    chunks = [mem[i:i + step] for i in range(0, len(mem), step)]
+    for ci, ch in enumerate(chunks):
+        lo_b, hi_b = ch[0][0], ch[-1][0] + ch[-1][1]
+        piece = data[lo_b:hi_b]
+        ing.submit_bgzf(slot, piece, [(o - lo_b, s, i, c) for o, s, i, c in ch], ci == len(chunks) - 1)
+        res = ing.wait(slot)
+        n = int(res.n_reads)
+        check_reads(ing, slot, res, seqs[got_reads:got_reads + n])
+        got_reads += n
+        slot ^= 1
+    assert got_reads == len(seqs)
+    ing.close()
+
+
+def test_text_chunks_go_through_the_same_kernels():
+    """gmx_ingest_submit_text: plain text from the host (what `gram` falls back to for a chunk the inflate kernel declined)."""
+    from gramtools_amd import Ingest
+    rng = np.random.default_rng(11)
+    text, seqs = fastq(rng, 2500, 90, 160, bad_every=11)
+    ing = Ingest(max_text_bytes=1 << 20)
+    cut = len(text) // 2 + 17
+    ing.submit_text(0, text[:cut], False)
+    r0 = ing.wait(0)
+    ing.submit_text(1, text[cut:], True)
+    r1 = ing.wait(1)
+    n0 = int(r0.n_reads)
+    check_reads(ing, 0, r0, seqs[:n0])
+    check_reads(ing, 1, r1, seqs[n0:])
+    assert n0 + int(r1.n_reads) == len(seqs) and r1.tail_bytes == 0
+    ing.close()
+
+
+def test_damage_is_reported_not_decoded():
+    from gramtools_amd import Ingest, bgzf_members, GMX_INGEST_BAD_RECORD, GMX_INGEST_BAD_MEMBER, GMX_INGEST_BAD_CRC
+    rng = np.random.default_rng(3)
+    text, seqs = fastq(rng, 1500, 150, 150)
+    data = bytearray(bgzf(text, block=30000))
+    mem = bgzf_members(bytes(data))
+    ing = Ingest(max_text_bytes=1 << 20)
+    # a flipped byte in the middle of the third member's deflate data: undecodable, or decodable to other text (CRC)
+    d2 = bytearray(data)
+    d2[mem[2][0] + mem[2][1] // 2] ^= 0x5A
+    ing.submit_bgzf(0, bytes(d2), mem, True)
+    res = ing.wait(0)
+    assert res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC) and res.bad_member == 2
+    # a wrong CRC in a trailer
+    m3 = list(mem)
+    m3[1] = (m3[1][0], m3[1][1], m3[1][2], m3[1][3] ^ 1)
+    ing.reset()
+    ing.submit_bgzf(1, bytes(data), m3, True)
+    res = ing.wait(1)
+    assert res.status & GMX_INGEST_BAD_CRC and res.bad_member == 1
+    # irregular records: a blank line, a multi-line record, a truncated file
+    for broken in (text.replace(b"\n+\n", b"\n\n+\n", 1), text[:len(text) // 2]):
+        ing.reset()
+        ing.submit_text(0, broken, True)
+        assert ing.wait(0).status & GMX_INGEST_BAD_RECORD
+    ing.close()
+
+
+def test_mapping_from_the_device_feed_equals_the_byte_feed():
+    """End to end: BGZF -> gmx_ingest -> gmx_map_reads_packed_device gives the coverage of gmx_map_reads_host on the same reads
+    (one length and ragged with unencodable reads; seeds read in place from page-locked memory)."""
+    from gramtools_amd import Index, Quasimapper, Ingest, PinnedArray, bgzf_members
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads
+    ref = random_ref(20000, 4)
+    prg, pos, alts, n_alts = snp_prg(ref, 300, 2)
+    ix = Index(prg, 7)
+    for ragged in (False, True):
+        n = 6000
+        reads = simulate_snp_reads(ref, pos, alts, n_alts, n, 150, 9)
+        rng = np.random.default_rng(1)
+        lens = rng.integers(60, 151, n) if ragged else np.full(n, 150)
+        letters = np.array(list("NACGT"))
+        recs, seqs = [], []
+        for i in range(n):
+            s = "".join(letters[reads[i, :lens[i]]])
+            if ragged and i % 97 == 5:
+                s = s[:10] + "N" + s[11:]
+            seqs.append(s)
+            recs.append(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n")
+        text = "".join(recs).encode()
+        data = bgzf(text, block=50000)
+        seeds = PinnedArray(n, np.uint32)
+        seeds.array[:] = (np.arange(n, dtype=np.uint64) * 2654435761 % (2 ** 32)).astype(np.uint32)
+        ing = Ingest(max_text_bytes=8 << 20)
+        ing.submit_bgzf(0, data, bgzf_members(data), True)
+        res = ing.wait(0)
+        assert res.status == 0 and res.n_reads == n
+        qm = Quasimapper(ix)
+        qm.map_ingested(res, seeds)
+        cov = qm.coverage()
+        # the byte feed of the same reads
+        tab = np.zeros(256, dtype=np.uint8)
+        for ch, v in zip("ACGT", (1, 2, 3, 4)):
+            tab[ord(ch)] = v
+        flat, offs = [], [0]
+        for s in seqs:
+            enc = tab[np.frombuffer(s.encode(), dtype=np.uint8)]
+            if (enc == 0).any():
+                enc = enc[:0]  # an unencodable read is handed over empty: skipped (quasimap.cpp:109-113)
+            flat.append(enc)
+            offs.append(offs[-1] + len(enc))
+        qm2 = Quasimapper(ix)
+        qm2.map_reads(np.concatenate(flat), np.array(offs, dtype=np.uint64), seeds.array.copy())
+        cov2 = qm2.coverage()
+        assert cov.stats.as_dict() == cov2.stats.as_dict()
+        assert cov.allele_sum_coverage == cov2.allele_sum_coverage
+        assert cov.allele_base_coverage == cov2.allele_base_coverage
+        assert cov.grouped_allele_counts == cov2.grouped_allele_counts
+        ing.close()
+        seeds.close()

@@ -36,7 +36,7 @@ for _ in range(3):
     t0 = time.perf_counter(); loop(30); best = min(best, (time.perf_counter() - t0) / 30)
 st = qm.coverage().stats.as_dict()
 print(json.dumps({"ms_per_step": best * 1e3, "extend_ms": tm["search_ms"] / tm["search_launches"], "inline_sites": int(ix.info.n_inline_sites),
-                  "exact_mapped": st["exact_mapped"], "queues": qm.queue_counts()}))
+                  "exact_mapped": st["exact_mapped"], "stats": st, "queues": qm.queue_counts()}))
 """
 libs = sys.argv[1:] or [""]
 for lib in libs:
@@ -49,4 +49,4 @@ for lib in libs:
             print(lib or "default", "FAILED", out.stderr[-600:])
             break
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        print(f"{lib or 'default':40s} {d['ms_per_step']:.4f} ms/step  extend {d['extend_ms']:.4f} ms  inline {d['inline_sites']}  mapped {d['exact_mapped']}", flush=True)
+        print(f"{lib or 'default':40s} {d['ms_per_step']:.4f} ms/step  extend {d['extend_ms']:.4f} ms  inline {d['inline_sites']}  {d['stats']}", flush=True)
