@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -74,16 +75,21 @@ struct IngestMember {
 #define ING_RING_MASK (ING_RING - 1u)
 #define ING_NEAR_MAX (ING_RING - 320u)  // distances up to this are served from the LDS window
 
-// table entry: code length (4) | extra bits (4) | type (2) << 8 | value << 16
+// table entry: bits 0-3 the bits it takes (0: no code here), bits 4-5 its type, and
+//   literals     bits 6-7 how many more than one (gmx ing_fuse: up to three literals whose codes fit the root bits together
+//                take ONE look-up), bits 8-31 the bytes, first one lowest
+//   length/dist  bits 8-11 extra bits, bits 12-27 base value
+//   code length  bits 8-12 the symbol
 #define ING_T_LIT 0u
 #define ING_T_BASE 1u
 #define ING_T_EOB 2u
 #define ING_T_LONG 3u
+#define ING_TYPE(e) (((e) >> 4) & 3u)
 
 struct WaveLds {
   uint32_t lit[1u << ING_LIT_ROOT];    // literal/length codes of up to ING_LIT_ROOT bits, by the next bits of the stream (4 KB); the CRC table afterwards
   uint32_t dist[1u << ING_DIST_ROOT];  // distance codes (1 KB); the code-length code while a dynamic block's lengths are read
-  uint8_t ring[ING_RING];              // the last 4 KB of the member's text
+  alignas(16) uint8_t ring[ING_RING];  // the last 4 KB of the member's text
   uint16_t lit_sorted[288];            // symbols by (code length, symbol): codes longer than the root are decoded bit by bit
   uint16_t dist_sorted[32];
   uint32_t lit_count[16], dist_count[16];
@@ -92,21 +98,35 @@ struct WaveLds {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-struct Bits {  // every member wave-uniform
+// The bit reader. Everything but `cur` is wave-uniform. The compressed words are fetched 64 at a time, one per lane (a
+// coalesced load; a single word per refill left the wave waiting a memory round trip every 32 bits) and taken, lane by
+// lane, with v_readlane. No load stays in flight between refills: a prefetched next set made every iteration of the
+// symbol loop wait for vector memory (its register copies), i.e. for every line of text flushed so far.
+struct Bits {
   const uint32_t *w;
-  uint32_t next;
+  uint32_t next;   // index of the next word to take
+  uint32_t base;   // index of the word lane 0 holds in `cur`
+  uint32_t cur;
   uint64_t buf;
   uint32_t cnt;
   __device__ __forceinline__ void start(const uint32_t *words, uint32_t byte_off) {
     w = words;
     const uint32_t idx = byte_off >> 2, skip = (byte_off & 3u) * 8u;
-    buf = (uint64_t)(uni(words[idx]) >> skip);
+    base = idx;
+    cur = words[idx + threadIdx.x];
+    buf = (uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)cur, 0) >> skip);
     cnt = 32u - skip;
     next = idx + 1u;
   }
   __device__ __forceinline__ void refill() {  // afterwards at least 33 bits
     if (cnt <= 32u) {
-      buf |= (uint64_t)uni(w[next]) << cnt;
+      uint32_t rel = next - base;
+      if (rel == 64u) {
+        base += 64u;
+        cur = w[base + threadIdx.x];
+        rel = 0;
+      }
+      buf |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cur, (int)rel) << cnt;
       ++next;
       cnt += 32u;
     }
@@ -127,8 +147,8 @@ struct Bits {  // every member wave-uniform
 // what a symbol of one of the three codes stands for, as a table entry of `len` bits
 __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len) {
   if (kind == 0) {  // literal / length (RFC 1951 §3.2.5)
-    if (s < 256u) return len | (ING_T_LIT << 8) | (s << 16);
-    if (s == 256u) return len | (ING_T_EOB << 8);
+    if (s < 256u) return len | (ING_T_LIT << 4) | (s << 8);
+    if (s == 256u) return len | (ING_T_EOB << 4);
     if (s > 285u) return 0u;
     const uint32_t t = s - 257u;
     uint32_t base, extra;
@@ -142,7 +162,7 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
       extra = (t - 4u) >> 2;
       base = 3u + ((4u + (t & 3u)) << extra);
     }
-    return len | (extra << 4) | (ING_T_BASE << 8) | (base << 16);
+    return len | (ING_T_BASE << 4) | (extra << 8) | (base << 12);
   }
   if (kind == 1) {  // distance
     if (s > 29u) return 0u;
@@ -154,9 +174,9 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
       extra = (s - 2u) >> 1;
       base = 1u + ((2u + (s & 1u)) << extra);
     }
-    return len | (extra << 4) | (ING_T_BASE << 8) | (base << 16);
+    return len | (ING_T_BASE << 4) | (extra << 8) | (base << 12);
   }
-  return len | (ING_T_LIT << 8) | (s << 16);  // code-length code: the symbol itself
+  return len | (ING_T_LIT << 4) | (s << 8);  // code-length code: the symbol itself
 }
 
 // Canonical Huffman code of lens[0, n) (RFC 1951 §3.2.2) -> look-up table of `root` bits + the sorted symbols and the
@@ -220,12 +240,38 @@ __device__ bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32
         const uint32_t e = ing_entry(kind, s, l);
         for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab[j] = e;
       } else {
-        tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 8);
+        tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 4);
       }
     }
   }
   __syncthreads();
   return true;
+}
+
+// Literal/length table: an entry whose literal leaves room in the root bits for the next code, when that is a literal too,
+// becomes both (and a third): the bases of a FASTQ take two bits each, a run of one quality value one or two. The entry at j
+// = the bits behind the first code does not depend on bits it does not cover, so T[i >> l1] IS the second look-up. In place,
+// from the top down: an entry only looks at entries below itself, and a wave's LDS accesses keep their order.
+__device__ void ing_fuse(uint32_t *tab, uint32_t root) {
+  const uint32_t lane = threadIdx.x & 63u;
+  for (int c = (int)((1u << root) / 64u) - 1; c >= 0; --c) {
+    const uint32_t i = (uint32_t)c * 64u + lane;
+    uint32_t e = tab[i];
+    uint32_t l = e & 15u;
+    if (l != 0 && ING_TYPE(e) == ING_T_LIT && l < root) {
+      const uint32_t e2 = tab[i >> l], l2 = e2 & 15u;
+      if (l2 != 0 && ING_TYPE(e2) == ING_T_LIT && l + l2 <= root) {
+        e = (l + l2) | (1u << 6) | (e & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+        l += l2;
+        if (l < root) {
+          const uint32_t e3 = tab[i >> l], l3 = e3 & 15u;
+          if (l3 != 0 && ING_TYPE(e3) == ING_T_LIT && l + l3 <= root) e = (l + l3) | (2u << 6) | (e & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
+        }
+      }
+    }
+    tab[i] = e;
+  }
+  __syncthreads();
 }
 
 // a code longer than the table's root: bit by bit against the canonical code's first code of every length
@@ -271,56 +317,74 @@ __device__ __forceinline__ uint32_t ing_xpow8(uint32_t n_bytes) {  // x^(8 n)
   return r;
 }
 
-__device__ __forceinline__ uint8_t ing_load_coherent(const uint8_t *p) {  // text this wave stored earlier: past the vector L1
+// The member's text is addressed as GLOBAL memory explicitly: through a generic pointer the stores were flat_store_byte,
+// which count as LDS operations too — every table look-up behind a flushed line then waited for the line to reach memory.
+typedef __attribute__((address_space(1))) uint8_t ing_g8;
+typedef __attribute__((address_space(1))) uint32_t ing_g32;
+typedef uint32_t ing_v4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) ing_v4 ing_g128;
+__device__ __forceinline__ uint8_t ing_load_coherent(const ing_g8 *p) {  // text this wave stored earlier: past the vector L1
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wavefront per member: its text goes to text[out_off, out_off + isize).
+template <bool STATS>
 __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
-                                                         uint8_t *text, IngestState *st, int check_crc) {
+                                                         uint8_t *text, IngestState *st, int check_crc, unsigned long long *dbg) {
   __shared__ WaveLds L;
+  // dbg (GMX_INGEST_STATS=1): [0] look-ups of the literal/length table [1] literal bytes [2] matches [3] far matches [4] bit-by-bit
+  // decodes [5] blocks [6..9] clocks: whole member, table building, match copies, CRC [10] members [11] match bytes
+  unsigned long long n_look = 0, n_lit_total = 0, n_match = 0, n_far = 0, n_slow = 0, n_blocks = 0, t_build = 0, t_copy = 0, t_crc = 0, n_mbytes = 0;
+  const long long t_begin = STATS ? clock64() : 0;
   const uint32_t mi = blockIdx.x;
   if (mi >= n_members) return;
   const uint32_t lane = threadIdx.x;
   const uint32_t in_off = uni(members[mi].in_off), in_len = uni(members[mi].in_len), isize = uni(members[mi].isize);
-  uint8_t *out = text + uni(members[mi].out_off);
+  // Positions are counted from the 16-byte boundary at or below the member's first byte: byte p of that line-up lives at
+  // al[p] and at ring[p & mask], so that a KB of the window goes to memory as one 16-byte store per lane (64-byte lines
+  // stored byte by byte were 1 024 store instructions per member — and, loads and stores returning in order, every wait
+  // for a load was a wait for the last of them).
+  ing_g8 *const out0 = (ing_g8 *)(text + uni(members[mi].out_off));
+  const uint32_t mis = (uint32_t)((uintptr_t)out0 & 15u);
+  ing_g8 *const al = out0 - mis;
+  const uint32_t end_v = isize + mis;
   Bits bs;
   bs.start(comp, in_off);
-  uint32_t out_pos = 0, flushed = 0;  // bytes decoded; bytes (whole 64-byte lines) already stored from the window
+  uint32_t out_pos = mis, flushed = mis;  // bytes decoded so far end here; bytes already stored from the window end here
   uint32_t err = 0;
-  auto flush_lines = [&](uint32_t upto) {  // lines [flushed, upto): upto a multiple of 64, or the member's end
-    for (uint32_t p = flushed; p < upto; p += 64u) {
-      const uint32_t i = p + lane;
-      if (i < upto) out[i] = L.ring[i & ING_RING_MASK];
+  auto flush_to = [&](uint32_t upto) {  // [flushed, upto): upto a multiple of 1024, or the member's end
+    for (uint32_t blk = flushed & ~1023u; blk < upto; blk += 1024u) {
+      const uint32_t cs = blk + 16u * lane, ce = cs + 16u;
+      if (cs >= flushed && ce <= upto) {
+        *(ing_g128 *)(al + cs) = *reinterpret_cast<const ing_v4 *>(&L.ring[cs & ING_RING_MASK]);
+      } else if (ce > flushed && cs < upto) {  // the member's first and last piece: its neighbours own the rest of the 16 bytes
+        for (uint32_t i = max(cs, flushed); i < min(ce, upto); ++i) al[i] = L.ring[i & ING_RING_MASK];
+      }
     }
     flushed = upto;
   };
-  auto put_literal = [&](uint32_t b) {
-    if (lane == 0) L.ring[out_pos & ING_RING_MASK] = (uint8_t)b;
-    ++out_pos;
-    if ((out_pos & 63u) == 0) flush_lines(out_pos);
-  };
   // bytes [out_pos, out_pos + len) = the len bytes starting dist back (RFC 1951 §3.2.3: may overlap what it writes)
   auto copy_match = [&](uint32_t len, uint32_t dist) {
-    const bool near = dist <= ING_NEAR_MAX;
-    if (!near) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the lines flushed so far have reached the L2
-    for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
-      const uint32_t i = i0 + lane;
-      uint8_t b = 0;
-      if (i < len) {
-        const uint32_t j = dist >= len ? i : i % dist;
-        const uint32_t src = out_pos - dist + j;
-        b = near ? L.ring[src & ING_RING_MASK] : ing_load_coherent(out + src);
+    // Two loops with nothing in common: sharing the byte's register, the window's path (LDS only) inherited the other one's
+    // wait for vector memory — which, stores and loads returning in order, is a wait for every line flushed so far.
+    if (dist <= ING_NEAR_MAX) {
+      if (dist >= len) {
+        for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = L.ring[(out_pos - dist + i) & ING_RING_MASK];
+      } else {  // the copy overlaps what it writes: byte i repeats byte i mod dist
+        for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = L.ring[(out_pos - dist + i % dist) & ING_RING_MASK];
       }
-      if (i < len) L.ring[(out_pos + i) & ING_RING_MASK] = b;
+    } else {  // beyond the window: from the lines already flushed (dist > len: no overlap); the load is ordered behind them
+      for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = ing_load_coherent(al + (out_pos - dist + i));
     }
     out_pos += len;
-    if ((out_pos & ~63u) > flushed) flush_lines(out_pos & ~63u);
+    if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
   };
   for (bool last = false; !last && !err;) {
     bs.refill();
     last = bs.take(1) != 0;
     const uint32_t btype = bs.take(2);
+    if (STATS) ++n_blocks;
+    const long long t_b0 = STATS ? clock64() : 0;
     if (btype == 0) {  // stored (RFC 1951 §3.2.4)
       bs.drop(bs.cnt & 7u);
       bs.refill();
@@ -330,7 +394,7 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
         break;
       }
       const uint32_t from = bs.byte_pos();
-      if (from + len > in_off + in_len || out_pos + len > isize) {
+      if (from + len > in_off + in_len || out_pos + len > end_v) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
@@ -339,7 +403,7 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
         const uint32_t n = min(64u, len - i0);
         if (lane < n) L.ring[(out_pos + lane) & ING_RING_MASK] = src[i0 + lane];
         out_pos += n;
-        if ((out_pos & ~63u) > flushed) flush_lines(out_pos & ~63u);
+        if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
       }
       bs.start(comp, from + len);
       continue;
@@ -390,7 +454,7 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
           break;
         }
         bs.drop(e & 15u);
-        const uint32_t sym = e >> 16;
+        const uint32_t sym = e >> 8;
         uint32_t rep = 1, val = sym;
         if (sym == 16u) {
           if (at == 0) {
@@ -428,15 +492,19 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
         break;
       }
     }
+    ing_fuse(L.lit, ING_LIT_ROOT);
+    if (STATS) t_build += clock64() - t_b0;
     // ---- the block's symbols ----
     for (;;) {
       bs.refill();
       uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
+      if (STATS) ++n_look;
       if ((e & 15u) == 0) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
-      if (((e >> 8) & 3u) == ING_T_LONG) {
+      if (ING_TYPE(e) == ING_T_LONG) {
+        if (STATS) ++n_slow;
         uint32_t l;
         const int sym = ing_decode_slow(bs, L.lit_count, L.lit_sorted, &l);
         e = sym < 0 ? 0u : ing_entry(0, (uint32_t)sym, l);
@@ -447,24 +515,28 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
       } else {
         bs.drop(e & 15u);
       }
-      const uint32_t type = (e >> 8) & 3u;
-      if (type == ING_T_LIT) {
-        if (out_pos >= isize) {
+      const uint32_t type = ING_TYPE(e);
+      if (type == ING_T_LIT) {  // one to three literals
+        const uint32_t n_lit = ((e >> 6) & 3u) + 1u;
+        if (out_pos + n_lit > end_v) {
           err = GMX_INGEST_BAD_MEMBER;
           break;
         }
-        put_literal(e >> 16);
+        if (lane < n_lit) L.ring[(out_pos + lane) & ING_RING_MASK] = (uint8_t)(e >> (8u + 8u * lane));
+        out_pos += n_lit;
+        if (STATS) n_lit_total += n_lit;
+        if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
         continue;
       }
       if (type == ING_T_EOB) break;
-      const uint32_t len = (e >> 16) + bs.take((e >> 4) & 15u);
+      const uint32_t len = ((e >> 12) & 0xFFFFu) + bs.take((e >> 8) & 15u);
       bs.refill();
       uint32_t d = uni(L.dist[bs.peek(ING_DIST_ROOT)]);
       if ((d & 15u) == 0) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
-      if (((d >> 8) & 3u) == ING_T_LONG) {
+      if (ING_TYPE(d) == ING_T_LONG) {
         uint32_t l;
         const int sym = ing_decode_slow(bs, L.dist_count, L.dist_sorted, &l);
         d = sym < 0 ? 0u : ing_entry(1, (uint32_t)sym, l);
@@ -476,41 +548,90 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
       } else {
         bs.drop(d & 15u);
       }
-      const uint32_t dist = (d >> 16) + bs.take((d >> 4) & 15u);
-      if (dist > out_pos || out_pos + len > isize) {
+      const uint32_t dist = ((d >> 12) & 0xFFFFu) + bs.take((d >> 8) & 15u);
+      if (dist > out_pos - mis || out_pos + len > end_v) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
-      copy_match(len, dist);
+      if (STATS) {
+        ++n_match;
+        n_mbytes += len;
+        if (dist > ING_NEAR_MAX) ++n_far;
+      }
+      {
+        const long long t_c0 = STATS ? clock64() : 0;
+        copy_match(len, dist);
+        if (STATS) t_copy += clock64() - t_c0;
+      }
     }
   }
   if (!err) {
-    flush_lines(out_pos);
+    flush_to(out_pos);
     // every byte of the member's deflate data used, and as much text as its trailer says
     const uint32_t used_bits = (bs.next * 32u - bs.cnt) - in_off * 8u;
-    if (out_pos != isize || (used_bits + 7u) / 8u != in_len) err = GMX_INGEST_BAD_MEMBER;
+    if (out_pos != end_v || (used_bits + 7u) / 8u != in_len) err = GMX_INGEST_BAD_MEMBER;
   }
+  const long long t_crc0 = STATS ? clock64() : 0;
   if (!err && check_crc && isize) {
+    // CRC-32 of the member's text: 64 slices side by side, four table look-ups per word (the tables take the place of the
+    // literal/length table), then the slices' registers combined pairwise. (One byte per step from memory — a memory round
+    // trip each — was a third of the kernel's time.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    for (uint32_t i = lane; i < 256u; i += 64u) {  // the byte table, where the literal/length table was
+    for (uint32_t i = lane; i < 256u; i += 64u) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ ING_CRC_POLY : c >> 1;
       L.lit[i] = c;
     }
     __syncthreads();
-    const uint32_t per = (isize + 63u) / 64u;
-    const uint32_t lo = min(isize, lane * per), hi = min(isize, lo + per);
-    uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u, n = hi - lo;
-    for (uint32_t i = lo; i < hi; ++i) c = L.lit[(c ^ ing_load_coherent(out + i)) & 0xFFu] ^ (c >> 8);
+    for (uint32_t t = 1; t < 4u; ++t) {
+      for (uint32_t i = lane; i < 256u; i += 64u) {
+        const uint32_t v = L.lit[(t - 1u) * 256u + i];
+        L.lit[t * 256u + i] = (v >> 8) ^ L.lit[v & 0xFFu];
+      }
+      __syncthreads();
+    }
+    // slices of whole words, counted like everything else from the 16-byte boundary below the member's first byte
+    const uint32_t total = end_v;
+    const uint32_t per = (((total + 63u) / 64u) + 3u) & ~3u;
+    uint32_t lo = min(total, lane * per), hi = min(total, lo + per);
+    if (lane == 0) lo = mis;
+    uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
+    const uint32_t n = hi > lo ? hi - lo : 0u;
+    auto byte_step = [&](uint32_t at) { c = L.lit[(c ^ ing_load_coherent(al + at)) & 0xFFu] ^ (c >> 8); };
+    while (lo < hi && (lo & 3u)) byte_step(lo++);
+    const ing_g32 *words = (const ing_g32 *)al;
+    for (; lo + 16u <= hi; lo += 16u) {  // four words in flight
+      const uint32_t w0 = __hip_atomic_load(words + lo / 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     w1 = __hip_atomic_load(words + lo / 4u + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     w2 = __hip_atomic_load(words + lo / 4u + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                     w3 = __hip_atomic_load(words + lo / 4u + 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t ws[4] = {w0, w1, w2, w3};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c ^= ws[q];
+        c = L.lit[768u + (c & 0xFFu)] ^ L.lit[512u + ((c >> 8) & 0xFFu)] ^ L.lit[256u + ((c >> 16) & 0xFFu)] ^ L.lit[c >> 24];
+      }
+    }
+    for (; lo + 4u <= hi; lo += 4u) {
+      c ^= __hip_atomic_load(words + lo / 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      c = L.lit[768u + (c & 0xFFu)] ^ L.lit[512u + ((c >> 8) & 0xFFu)] ^ L.lit[256u + ((c >> 16) & 0xFFu)] ^ L.lit[c >> 24];
+    }
+    while (lo < hi) byte_step(lo++);
+    uint32_t nn = n;
     for (uint32_t dlt = 1; dlt < 64u; dlt <<= 1) {  // register of (left part || right part) = left * x^(8 |right|) + right
-      const uint32_t c_r = __shfl_down(c, dlt), n_r = __shfl_down(n, dlt);
+      const uint32_t c_r = __shfl_down(c, dlt), n_r = __shfl_down(nn, dlt);
       if ((lane & (2u * dlt - 1u)) == 0) {
         c = (n_r ? ing_mulmod(c, ing_xpow8(n_r)) : c) ^ c_r;
-        n += n_r;
+        nn += n_r;
       }
     }
     if (uni(~c) != uni(members[mi].crc)) err = GMX_INGEST_BAD_CRC;
+  }
+  if (STATS && dbg && lane == 0) {
+    t_crc = clock64() - t_crc0;
+    const unsigned long long v[12] = {n_look, n_lit_total, n_match, n_far, n_slow, n_blocks, (unsigned long long)(clock64() - t_begin), t_build, t_copy, t_crc, 1ull, n_mbytes};
+    for (int i = 0; i < 12; ++i) atomicAdd(&dbg[i], v[i]);
   }
   if (err && lane == 0) {
     atomicOr(&st->flags, err);
@@ -791,6 +912,7 @@ struct gmx_ingest {
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
   std::vector<void *> allocs;
   int check_crc = 1;
+  unsigned long long *d_dbg = nullptr;  // GMX_INGEST_STATS=1: counters of gmx_inflate_kernel, printed by gmx_ingest_destroy
 };
 
 namespace {
@@ -829,6 +951,7 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
   g->cap_members = (uint32_t)(max_text_bytes / 512 + 1024);  // (members of half a KB of text on average, or larger)
   g->n_tiles_max = (uint32_t)((ING_CARRY_MAX + max_text_bytes + ING_TILE - 1) / ING_TILE);
   g->check_crc = getenv("GMX_INGEST_NO_CRC") ? 0 : 1;
+  if (getenv("GMX_INGEST_STATS") && ing_alloc(g, &g->d_dbg, 16, true) != GMX_OK) g->d_dbg = nullptr;
   int rc = GMX_OK;
   auto fail = [&](int code) {
     gmx_ingest_destroy(g);
@@ -839,7 +962,7 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
     return fail(GMX_EHIP);
   }
   for (auto &s : g->slot) {
-    if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 16, true)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
+    if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 256, true)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
         (rc = ing_alloc(g, &s.d_text, ING_CARRY_MAX + max_text_bytes + 64, true)) || (rc = ing_alloc(g, &s.d_line_end, g->cap_lines, false)) ||
         (rc = ing_alloc(g, &s.d_rec_start, g->cap_reads, false)) || (rc = ing_alloc(g, &s.d_rec_len, g->cap_reads, false)) ||
         (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, true)) ||
@@ -864,6 +987,13 @@ void gmx_ingest_destroy(gmx_ingest *g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+  if (g->d_dbg) {
+    unsigned long long v[16] = {0};
+    if (hipMemcpy(v, g->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess && v[10])
+      fprintf(stderr, "[gmx_ingest] per member: %.0f look-ups, %.0f literal bytes, %.0f matches (%.0f bytes, %.1f far), %.1f bit-by-bit, %.2f blocks; kclocks %.0f total, %.0f tables, %.0f copies, %.0f crc (%llu members)\n",
+              (double)v[0] / v[10], (double)v[1] / v[10], (double)v[2] / v[10], (double)v[11] / v[10], (double)v[3] / v[10], (double)v[4] / v[10], (double)v[5] / v[10],
+              v[6] / 1e3 / v[10], v[7] / 1e3 / v[10], v[8] / 1e3 / v[10], v[9] / 1e3 / v[10], v[10]);
+  }
   for (auto &s : g->slot) {
     if (s.h_state) (void)hipHostFree(s.h_state);
     if (s.h_members) (void)hipHostFree(s.h_members);
@@ -896,9 +1026,14 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
   const gmx_ingest::Slot *prev = g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
   hipLaunchKernelGGL(gmx_carry_kernel, dim3(64), dim3(256), 0, g->stream, prev ? prev->d_state : nullptr, prev ? prev->d_text : nullptr, s.d_state, s.d_text,
                      members_text, (uint32_t)(final_chunk ? 1 : 0));
-  if (inflate && n_members)
-    hipLaunchKernelGGL(gmx_inflate_kernel, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX, s.d_state,
-                       g->check_crc);
+  if (inflate && n_members) {
+    if (g->d_dbg)
+      hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                         s.d_state, g->check_crc, g->d_dbg);
+    else
+      hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                         s.d_state, g->check_crc, g->d_dbg);
+  }
   const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
   hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);
   hipLaunchKernelGGL(gmx_tile_scan_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_tiles, n_tiles, s.d_state, g->cap_lines);
@@ -956,7 +1091,7 @@ int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, u
     gmx_set_error("gmx_ingest_submit_bgzf: the members hold more text than the ingest was created for");
     return GMX_EINVAL;
   }
-  // (the last word of the deflate data is fetched whole, and one more: the staging buffer has slack, zeroed here)
+  // (the bit reader fetches up to 128 words ahead: the staging buffer has slack; the words right behind the data are zeroed)
   if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_comp, compressed, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.d_comp) + n_bytes, 0, 16, g->copy_stream));
   if (n_members) ING_TRY(hipMemcpyAsync(s.d_members, s.h_members, n_members * sizeof(IngestMember), hipMemcpyHostToDevice, g->copy_stream));

@@ -860,6 +860,172 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   return true;
 }
 
+#define GMX_CHECK(expr)                                                        \
+  do {                                                                         \
+    int _rc = (expr);                                                          \
+    if (_rc < 0) die(std::string("gram: ") + #expr + " failed: " + gmx_last_error()); \
+  } while (0)
+
+// ---- BGZF files decoded on the GPU (include/gmx.h gmx_ingest_*, gmx_ingest.hip) ------------------------------------------
+// A file that is BGZF members from its first byte to its last (bgzip, htslib, BCL Convert) is handed to the device as it
+// lies in the page cache: the member table is walked here (18 bytes per member), the deflate data of a few thousand members
+// at a time is copied into page-locked memory by all threads and uploaded, and HIP kernels inflate it, check every member's
+// CRC-32, find the records and pack the bases — the host inflates nothing (sixteen cores manage 32-48 M reads/s of BGZF; the
+// mapping kernels take 2 400 M). `on_chunk(result, slot)` is called for every chunk in file order, with the chunk's reads in
+// HBM; it must enqueue what reads them and call gmx_ingest_release_after.
+// Returns  0  the whole file was delivered
+//          1  declined before anything was delivered (not pure BGZF, or not four-line FASTQ: the caller's other readers decide)
+//          2  a chunk could not be decoded after `delivered` reads had been: the caller re-reads the file on the host, which
+//             either reports the damage or — a defect of the device decoder — delivers the rest
+static bool bgzf_member_at(const unsigned char *in, size_t size, size_t at, gmx_bgzf_member *m, size_t *next) {
+  auto le16 = [](const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8; };
+  auto le32 = [](const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; };
+  if (at + 18 > size) return false;
+  const unsigned char *p = in + at;
+  if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || p[3] != 4) return false;
+  const uint32_t xlen = le16(p + 10);
+  if (at + 12 + xlen > size) return false;
+  uint32_t bsize = 0;
+  bool found = false;
+  for (uint32_t x = 0; x + 4 <= xlen;) {
+    const unsigned char *f = p + 12 + x;
+    const uint32_t slen = le16(f + 2);
+    if (f[0] == 'B' && f[1] == 'C' && slen == 2 && x + 6 <= xlen) {
+      bsize = le16(f + 4) + 1;
+      found = true;
+    }
+    x += 4 + slen;
+  }
+  if (!found || bsize < 12 + xlen + 8 || at + bsize > size) return false;
+  m->offset = at + 12 + xlen;
+  m->size = bsize - 12 - xlen - 8;
+  m->crc32 = le32(p + bsize - 8);
+  m->isize = le32(p + bsize - 4);
+  m->reserved = 0;
+  *next = at + bsize;
+  return m->isize <= 65536u;
+}
+
+struct DeviceFeed {  // one per process: the ingest object and its page-locked staging, sized by the largest file seen
+  gmx_ingest *ing = nullptr;
+  uint64_t max_text = 0;
+  int device = 0;
+  HostBuf<uint8_t> stage[2];
+  ~DeviceFeed() {
+    if (ing) gmx_ingest_destroy(ing);
+  }
+};
+static DeviceFeed g_device_feed;
+
+template <class OnChunk>
+int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk on_chunk, uint64_t *delivered) {
+  *delivered = 0;
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return 1;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size < 28) {
+    close(fd);
+    return 1;
+  }
+  const size_t size = (size_t)sb.st_size;
+  void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
+  close(fd);
+  if (mp == MAP_FAILED) return 1;
+  const unsigned char *in = static_cast<const unsigned char *>(mp);
+  struct Unmap {
+    void *p;
+    size_t n;
+    ~Unmap() { munmap(p, n); }
+  } unmap{mp, size};
+  // the member table: every byte of the file must belong to a BGZF member
+  std::vector<gmx_bgzf_member> members;
+  members.reserve(size / 16000 + 16);
+  for (size_t at = 0; at < size;) {
+    gmx_bgzf_member m;
+    size_t next;
+    if (!bgzf_member_at(in, size, at, &m, &next)) return 1;
+    if (m.isize) members.push_back(m);  // (empty members — the EOF marker — hold nothing)
+    at = next;
+  }
+  feed_trace("BGZF member table walked");
+  // chunks of members: at most kMembers (two rounds of the GPU's 3 840 wavefronts), and what the ingest has room for
+  uint64_t kMembers = 7680;
+  if (const char *e = getenv("GMX_INGEST_MEMBERS")) kMembers = std::max<uint64_t>(1, (uint64_t)atoll(e));
+  uint64_t file_text = 0;
+  for (const auto &m : members) file_text += m.isize;
+  const uint64_t want_text = std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(file_text, kMembers * 65536ull), 1u << 16) + (1u << 16), 3ull << 30);
+  DeviceFeed &df = g_device_feed;
+  if (!df.ing || df.max_text < want_text || df.device != device) {
+    if (df.ing) gmx_ingest_destroy(df.ing);
+    df.ing = nullptr;
+    if (gmx_ingest_create(device, want_text, &df.ing) != GMX_OK) return 1;
+    df.max_text = want_text;
+    df.device = device;
+  }
+  gmx_ingest *ing = df.ing;
+  GMX_CHECK(gmx_ingest_reset(ing));
+  const uint64_t max_text = gmx_ingest_max_text(ing), max_comp = gmx_ingest_max_compressed(ing);
+  struct Chunk {
+    size_t first, count;  // members
+    size_t lo, hi;        // file bytes their deflate data spans
+  };
+  std::vector<Chunk> chunks;
+  for (size_t i = 0; i < members.size();) {
+    Chunk c{i, 0, (size_t)members[i].offset, 0};
+    uint64_t text = 0;
+    while (i < members.size() && c.count < kMembers && text + members[i].isize <= max_text &&
+           members[i].offset + members[i].size - c.lo <= max_comp) {
+      text += members[i].isize;
+      c.hi = (size_t)(members[i].offset + members[i].size);
+      ++c.count;
+      ++i;
+    }
+    if (c.count == 0) return 1;  // (a member the ingest has no room for: cannot happen with <= 64 KB members)
+    chunks.push_back(c);
+  }
+  if (chunks.empty()) {  // no reads at all
+    return 0;
+  }
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  std::vector<gmx_bgzf_member> rel;
+  auto submit = [&](size_t ci) {
+    const Chunk &c = chunks[ci];
+    HostBuf<uint8_t> &st = df.stage[ci & 1];
+    const size_t n = c.hi - c.lo;
+    st.resize(n + 64);
+    parallel_for(T, [&](unsigned t) {  // the compressed bytes, from the page cache into page-locked memory
+      const size_t a = n * t / T, b = n * (t + 1) / T;
+      if (b > a) memcpy(st.data() + a, in + c.lo + a, b - a);
+    });
+    rel.assign(members.begin() + (long)c.first, members.begin() + (long)(c.first + c.count));
+    for (auto &m : rel) m.offset -= c.lo;
+    GMX_CHECK(gmx_ingest_submit_bgzf(ing, (int)(ci & 1), st.data(), n, rel.data(), rel.size(), ci + 1 == chunks.size() ? 1 : 0));
+    feed_trace("chunk submitted to the device");
+  };
+  submit(0);
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    if (ci + 1 < chunks.size()) submit(ci + 1);
+    gmx_ingest_result res;
+    GMX_CHECK(gmx_ingest_wait(ing, (int)(ci & 1), &res));
+    feed_trace("chunk decoded");
+    if (res.status) {
+      if (ci + 1 < chunks.size()) {  // (the chunk behind is in flight: let it finish before the slots are reused)
+        gmx_ingest_result drop;
+        GMX_CHECK(gmx_ingest_wait(ing, (int)((ci + 1) & 1), &drop));
+      }
+      if ((res.status & (GMX_INGEST_BAD_RECORD | GMX_INGEST_TOO_MANY_LINES)) && !(res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC))) {
+        if (*delivered == 0) return 1;
+        die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(*delivered) +
+            " reads (multi-line or blank lines); decompress and reformat, or use a four-line FASTQ");
+      }
+      return *delivered == 0 && ci == 0 ? 2 : 2;
+    }
+    on_chunk(res, (int)(ci & 1));
+    *delivered += res.n_reads;
+  }
+  return 0;
+}
+
 struct ReadStats {  // include/genotype/read_stats.hpp
   double mean_cov_depth = -1, variance_cov_depth = -1;
   uint64_t num_sites_noCov = 0;
@@ -913,11 +1079,6 @@ void write_read_stats(const std::string &path, const ReadStats &rs) {  // ReadSt
   close_checked(o, path);
 }
 
-#define GMX_CHECK(expr)                                                        \
-  do {                                                                         \
-    int _rc = (expr);                                                          \
-    if (_rc < 0) die(std::string("gram: ") + #expr + " failed: " + gmx_last_error()); \
-  } while (0)
 
 struct Args {
   std::map<std::string, std::vector<std::string>> opt;
@@ -994,6 +1155,26 @@ int run_parse_check(const std::string &path, int threads) {
     slow.offsets.push_back(slow.bases.size());
   }
   std::cout << "slow " << slow.offsets.size() - 1 << " " << slow.bases.size() << " " << fnv(slow) << std::endl;
+  if (getenv("GMX_PARSE_CHECK_DEVICE")) {  // the same file through the device-side decoder (needs a GPU): a third line
+    fast = Flat{};
+    ParsedReads blk;
+    uint64_t delivered = 0;
+    const int rc = ingest_bgzf_file(path, threads, 0, [&](const gmx_ingest_result &res, int slot) {
+      blk.reset();
+      blk.n_reads = res.n_reads;
+      blk.n_bases = res.n_bases;
+      blk.uniform_len = res.uniform_len;
+      blk.planes.resize(res.n_pairs + 8);
+      blk.offsets.resize(res.n_reads + 1);
+      blk.skip.resize(std::max<uint64_t>(res.n_reads, 1));
+      GMX_CHECK(gmx_ingest_fetch_reads(g_device_feed.ing, slot, blk.planes.data(), blk.offsets.data(), blk.skip.data()));
+      collect(blk);
+    }, &delivered);
+    if (rc == 0)
+      std::cout << "device " << fast.offsets.size() - 1 << " " << fast.bases.size() << " " << fnv(fast) << std::endl;
+    else
+      std::cout << "device " << (rc == 1 ? "declined" : "failed") << " after " << delivered << " reads" << std::endl;
+  }
   return 0;
 }
 
@@ -1316,8 +1497,55 @@ int run_genotype(const Args &a) {
     // of the file takes draw file_base + i of the master stream, and the file uses up ceil(n / 5000) * 5000 draws
     uint64_t in_file = 0;
     const uint64_t file_base = seed_stream.base;
+    // A BGZF file is decoded on the GPU (one engine; GMX_HOST_GZ=1: on the host as before): compressed members up, reads
+    // found and packed in HBM, mapped where they lie. Should the device decoder give up on a chunk, the host reader below
+    // takes the file from its start and drops the reads already mapped.
+    uint64_t skip_reads = 0;
+    if (devices.size() == 1 && !getenv("GMX_HOST_GZ")) {
+      static HostBuf<uint32_t> dev_seeds[2];
+      uint64_t delivered = 0;
+      const int rc = ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) {
+        const uint64_t n = res.n_reads;
+        if (n == 0) return;
+        // (the kernels read the few seeds they need in place: the buffer a slot used two chunks ago must be done with)
+        GMX_CHECK(gmx_engine_sync(eng));
+        dev_seeds[slot].resize(n);
+        seed_stream.copy(file_base + in_file, n, dev_seeds[slot].data());
+        if (res.uniform_len) {
+          GMX_CHECK(gmx_map_reads_packed_device(eng, res.d_planes, nullptr, res.uniform_len, dev_seeds[slot].data(), res.any_skip ? res.d_skip : nullptr, n));
+        } else {
+          for (uint64_t r0 = 0, i = 0; r0 < n; r0 += 1u << 20, ++i) {
+            const uint64_t m = std::min<uint64_t>(1u << 20, n - r0);
+            GMX_CHECK(gmx_map_reads_packed_device(eng, res.d_planes + res.sub_pairs[i], res.d_offsets + r0, 0, dev_seeds[slot].data() + r0,
+                                                  res.any_skip ? res.d_skip + r0 : nullptr, m));
+          }
+        }
+        GMX_CHECK(gmx_ingest_release_after(g_device_feed.ing, slot, nullptr));
+        in_file += n;
+        total_reads += n;
+      }, &delivered);
+      if (rc == 0) {
+        GMX_CHECK(gmx_engine_sync(eng));
+        seed_stream.base = file_base + (in_file + kBatch - 1) / kBatch * kBatch;
+        continue;
+      }
+      if (rc == 2) {
+        GMX_CHECK(gmx_engine_sync(eng));
+        std::cerr << "warning: " << path << ": the device-side BGZF decoder gave up after " << delivered << " reads; the host reader takes over" << std::endl;
+        skip_reads = delivered;
+        in_file = 0;               // (the host reader counts the file's reads from its start again)
+        total_reads -= delivered;
+      }
+    }
     auto sink = [&](ParsedReads &block) {  // runs on the pipe's consumer thread, block after block in file order
-      const uint64_t n = block.n_reads;
+      uint64_t n = block.n_reads, first = 0;
+      if (skip_reads) {  // reads the device feed already mapped (a sub-range of a packed batch is a packed batch, gmx.h)
+        first = std::min<uint64_t>(skip_reads, n);
+        skip_reads -= first;
+        in_file += first;
+        total_reads += first;
+        n -= first;
+      }
       block.seeds.resize(std::max<uint64_t>(n, 1));
       const double t_seeds = now_s();
       seed_stream.copy(file_base + in_file, n, block.seeds.data());
@@ -1326,8 +1554,8 @@ int run_genotype(const Args &a) {
       // the block goes up as it is — bit planes from page-locked memory, chunk by chunk beside the kernels (the call returns
       // once everything is enqueued) — and may be overwritten by the parser as soon as its uploads are done
       if (n) {
-        GMX_CHECK(gmx_group_map_reads_packed_host(grp, block.planes.data(), block.uniform_len ? nullptr : block.offsets.data(),
-                                                  block.uniform_len, block.seeds.data(), block.any_skip ? block.skip.data() : nullptr, n));
+        GMX_CHECK(gmx_group_map_reads_packed_host(grp, block.planes.data() + block.pair_of(first), block.uniform_len ? nullptr : block.offsets.data() + first,
+                                                  block.uniform_len, block.seeds.data(), block.any_skip ? block.skip.data() + first : nullptr, n));
         GMX_CHECK(gmx_group_sync_uploads(grp));
       }
       total_reads += n;
@@ -1336,6 +1564,7 @@ int run_genotype(const Args &a) {
       seed_stream.base = file_base + (in_file + kBatch - 1) / kBatch * kBatch;
       continue;
     }
+    if (skip_reads) die("gram: " + path + ": the device-side decoder delivered reads of a file the host readers cannot parse");
     // (the general reader below draws from `master`: bring it to where the stream stands)
     master.seed(seed);
     master.discard(seed_stream.base);

@@ -241,3 +241,84 @@ def test_mapping_from_the_device_feed_equals_the_byte_feed():
         assert cov.grouped_allele_counts == cov2.grouped_allele_counts
         ing.close()
         seeds.close()
+
+
+# ---- through the `gram` executable ------------------------------------------------------------------------------------
+def _gram(*args, env=None):
+    import os
+    import subprocess
+    from gramtools_amd.build import build_gram
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([build_gram(), *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=e)
+
+
+def _cli_fastq(n, seed, crlf=False):
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        ln = int(rng.integers(1, 260))
+        seq = "".join("ACGTN"[int(x)] for x in rng.integers(0, 5 if i % 9 == 0 else 4, size=ln))
+        qual = "".join(chr(int(x)) for x in rng.integers(33, 75, size=ln))
+        recs.append(f"@r{i}\n{seq}\n+\n{'@' + qual[1:] if i % 4 == 0 else qual}\n")
+    text = "".join(recs)
+    return text.replace("\n", "\r\n") if crlf else text
+
+
+@pytest.mark.parametrize("block,members,crlf", [(3000, "7680", False), (65280, "7680", False), (3000, "5", False), (20000, "2", True)])
+def test_gram_parse_check_device_line(tmp_path, block, members, crlf):
+    """`gram _parse_check` (GMX_PARSE_CHECK_DEVICE=1): the reads the device-side decoder makes of a BGZF file hash to what the
+    host's parallel parser and its sequential reader make of it — whole file in one chunk, and chunks of a few members
+    (GMX_INGEST_MEMBERS) with records cut at every chunk's end."""
+    text = _cli_fastq(4000, 21, crlf=crlf)
+    path = tmp_path / "r.fastq.gz"
+    path.write_bytes(bgzf(text.encode(), block=block))
+    out = _gram("_parse_check", str(path), "6", env={"GMX_PARSE_CHECK_DEVICE": "1", "GMX_INGEST_MEMBERS": members})
+    assert out.returncode == 0, out.stdout
+    lines = [l for l in out.stdout.strip().splitlines() if l.split()[0] in ("fast", "slow", "device")]
+    assert len(lines) == 3 and lines[0].startswith("fast ") and lines[2].startswith("device "), out.stdout
+    assert lines[0][5:] == lines[1][5:] == lines[2][7:], out.stdout
+
+
+def test_gram_genotype_bgzf_on_the_device_equals_plain(tmp_path):
+    """`gram genotype` on a BGZF reads file (decoded on the GPU), on the same file with GMX_HOST_GZ=1 (inflated on the host)
+    and on the plain text: the three coverage files and the counters are byte-identical. Two files, so that the 5000-draw
+    seeding carries across a device-fed file into a host-fed one."""
+    import json
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads
+    ref = random_ref(3000, 4)
+    prg, pos, alts, n_alts = snp_prg(ref, 40, 5, multi_allelic_frac=0.3)
+    (tmp_path / "prg").write_bytes(np.array(prg, dtype="<u4").tobytes())
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, 7300, 60, 6)
+    txt = ["".join("ACGT"[b - 1] for b in r) for r in reads]
+    txt[17] = txt[17][:10] + "N" + txt[17][11:]
+    fq = lambda rs: "".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(rs)).encode()  # noqa: E731
+    a, b = fq(txt[:5100]), fq(txt[5100:])
+    (tmp_path / "a.fq").write_bytes(a)
+    (tmp_path / "b.fq").write_bytes(b)
+    (tmp_path / "a.fq.gz").write_bytes(bgzf(a, block=30000))
+    (tmp_path / "b.fq.gz").write_bytes(bgzf(b, block=9000))
+    outs = {}
+    for name, files, env in (("plain", ("a.fq", "b.fq"), {}), ("device", ("a.fq.gz", "b.fq.gz"), {"GMX_INGEST_MEMBERS": "3"}),
+                             ("host", ("a.fq.gz", "b.fq.gz"), {"GMX_HOST_GZ": "1"}), ("mixed", ("a.fq.gz", "b.fq"), {})):
+        out = tmp_path / name
+        r = _gram("genotype", "--gram_dir", str(tmp_path), "--reads", *[str(tmp_path / f) for f in files], "--sample_id", "s", "--ploidy", "diploid",
+                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", env=env)
+        assert r.returncode == 0, r.stdout
+        counters = [l for l in r.stdout.splitlines() if l.startswith("Count ")]
+        outs[name] = ([(out / "coverage" / f).read_bytes() for f in ("allele_sum_coverage", "allele_base_coverage.json", "grouped_allele_counts_coverage.json")],
+                      counters, json.loads((out / "read_stats.json").read_text())["Read_depth"])
+    for name in ("device", "host", "mixed"):
+        assert outs[name] == outs["plain"], name
+
+
+def test_gram_damaged_bgzf_is_fatal_on_the_device_path_too(tmp_path):
+    """A member whose bytes were damaged: the device decoder reports it, the host reader takes the file over and fails on the
+    same member — the call must not end with the coverage of a part of the sample."""
+    text = _cli_fastq(3000, 4).encode()
+    d = bytearray(bgzf(text, block=20000))
+    d[len(d) // 2] ^= 0x55
+    path = tmp_path / "bad.fastq.gz"
+    path.write_bytes(bytes(d))
+    out = _gram("_parse_check", str(path), "4", env={"GMX_PARSE_CHECK_DEVICE": "1"})
+    assert out.returncode != 0, out.stdout
