@@ -25,6 +25,7 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
   exchange_ms      (N > 1) the coverage exchange alone, timed between fences after the job
   per_rank_s       (N > 1) every rank's own time for the timed job
   cli_end_to_end   the `gram` executable on a FASTQ file: parse + upload + map + the three coverage files
+  bgzf_device_feed the reads as a BGZF FASTQ decoded by HIP kernels (inflate, CRC, record scan, packing) and mapped
   cpu_baseline     the oracle (CPU restatement of the reference algorithm, "port"): the cores the container grants, and one thread
   roofline         what bounds the STEP (the host link: bound "pcie", achieved = H2D GB/s of the timed job against the
                    PCIe Gen5 x16 spec) and, in roofline.kernels, one object per leading kernel — gmx_extend_kernel first (the
@@ -154,6 +155,92 @@ def write_fastq(path, batches):
             row[:, o + 3 + L] = ord("\n")
             row.tofile(fh)
             first += n
+
+
+def _bgzf_piece(args):
+    """(worker) records of `reads` (uint8 1..4) with Illumina-style headers and binned qualities, as BGZF members."""
+    import struct
+    import zlib
+    seed, first, reads = args
+    rng = np.random.default_rng(seed)
+    n, L = reads.shape
+    bases = np.frombuffer(b"NACGT", dtype=np.uint8)[reads]
+    lvl = np.frombuffer(b"F:,#", dtype=np.uint8)
+    q = lvl[np.repeat(rng.choice(4, size=(n, (L + 4) // 5), p=[0.9, 0.06, 0.03, 0.01]), 5, axis=1)[:, :L]]
+    xs, ys = rng.integers(1000, 30000, n), rng.integers(1000, 30000, n)
+    text = b"".join(b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ACGTACGT\n%s\n+\n%s\n" % (1101 + (first + i) // 40000, xs[i], ys[i], bases[i].tobytes(), q[i].tobytes())
+                    for i in range(n))
+    out = bytearray()
+    for i in range(0, len(text), 65280):
+        p = text[i:i + 65280]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        comp = c.compress(p) + c.flush()
+        out += b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+        out += comp + struct.pack("<II", zlib.crc32(p) & 0xFFFFFFFF, len(p))
+    return bytes(out), len(text)
+
+
+def bgzf_device_feed(ix, reads, seeds_np):
+    """SURVEY 8f-3 on the device (gmx_ingest_*): the batch's reads as a BGZF FASTQ (bgzip's members, zlib level 6) in page-locked
+    memory -> upload of the compressed members, inflate + CRC, record scan, 2-bit packing, quasimap — nothing inflated or
+    parsed on the host. Rate of the whole chain, and of the decoding alone."""
+    from concurrent.futures import ProcessPoolExecutor
+    from gramtools_amd import Ingest, PinnedArray, Quasimapper, bgzf_members
+    n = reads.shape[0]
+    per = 25000
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+        parts = list(ex.map(_bgzf_piece, [(11 + i, i * per, reads[i * per:(i + 1) * per]) for i in range((n + per - 1) // per)]))
+    data = b"".join(p for p, _ in parts)
+    text_bytes = sum(t for _, t in parts)
+    mem = bgzf_members(data)
+    pin = PinnedArray(len(data) + 64, np.uint8)
+    pin.array[:len(data)] = np.frombuffer(data, dtype=np.uint8)
+    step = 7168
+    chunks = [mem[i:i + step] for i in range(0, len(mem), step)]
+    ing = Ingest(max_text_bytes=min(len(mem), step) * 65536 + (1 << 20))
+    seeds = PinnedArray(n, np.uint32)
+    seeds.array[:] = seeds_np[:n]
+    qm = Quasimapper(ix)
+
+    def run(mapped):
+        ing.reset()
+        if mapped:
+            qm.reset()
+        total, at = 0, 0
+
+        def submit(ci):
+            ch = chunks[ci]
+            lo, hi = ch[0][0], ch[-1][0] + ch[-1][1]
+            ing.submit_bgzf(ci & 1, pin.array[lo:hi], [(o - lo, s_, i_, c_) for o, s_, i_, c_ in ch], ci == len(chunks) - 1)
+        t0 = time.perf_counter()
+        submit(0)
+        for ci in range(len(chunks)):
+            if ci + 1 < len(chunks):
+                submit(ci + 1)
+            res = ing.wait(ci & 1)
+            if res.status:
+                raise RuntimeError(f"gmx_ingest status {res.status} at member {res.bad_member}")
+            if mapped:
+                qm.map_ingested(res, seeds, first=at)
+                ing.release_after(ci & 1)
+            at += int(res.n_reads)
+            total += int(res.n_reads)
+        if mapped:
+            qm.sync()
+        return total, time.perf_counter() - t0
+    run(True)
+    dec = sorted(run(False)[1] for _ in range(3))[1]
+    both = sorted(run(True)[1] for _ in range(3))[1]
+    st = qm.coverage().stats.as_dict()
+    ing.close()
+    out = {"reads": n, "bgzf_bytes_per_read": len(data) / n, "text_bytes_per_read": text_bytes / n, "members": len(mem),
+           "decode_only": {"value": n / dec, "unit": "reads/s", "text_GBps": text_bytes / dec / 1e9},
+           "decode_and_quasimap": {"value": n / both, "unit": "reads/s"}, "exact_mapped": st["exact_mapped"],
+           "bound": "gmx_inflate_kernel: the CU's scalar unit (one thread of control per wavefront; profiles/round5/ingest_inflate_sq_counters.txt)",
+           "host_feed_for_comparison": "BGZF inflated by 16 host cores: 32-48 M reads/s (profiles/round4/gz_feed.txt)"}
+    pin.close()
+    seeds.close()
+    return out
 
 
 def cli_end_to_end(prg, batches, threads):
@@ -610,6 +697,11 @@ def main():
         # ---- the executable on a FASTQ file -----------------------------------------------------------------------
         n_cli = max(1, min(NB, -(-args.cli_reads // n)))
         out["cli_end_to_end"] = cli_end_to_end(prg, raw[:n_cli], min(os.cpu_count() or 8, 64))
+        # ---- the same reads as a BGZF FASTQ, decoded on the device ---------------------------------------------------
+        try:
+            out["bgzf_device_feed"] = bgzf_device_feed(ix, raw[0], np.asarray(seeds))
+        except Exception as exc:  # a leg must not cost the headline
+            out["bgzf_device_feed"] = {"error": repr(exc)[:300]}
         # ---- the other BASELINE configurations at full size (their own index, 1 M reads per step) ---------------------
         del d_reads, d_offs, d_seeds
         for pk_, sd_ in batches:

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,9 +70,18 @@ struct IngestMember {
 };
 
 #define ING_CARRY_MAX (1u << 20)  // bytes of an incomplete last record that can be carried (a record longer than this: irregular)
-#define ING_LIT_ROOT 10
-#define ING_DIST_ROOT 8
-#define ING_RING 4096u
+#ifndef ING_LIT_ROOT
+#define ING_LIT_ROOT 9
+#endif
+#ifndef ING_DIST_ROOT
+#define ING_DIST_ROOT 7
+#endif
+#ifndef ING_RING
+#define ING_RING 2048u
+#endif
+#ifndef ING_WAVES
+#define ING_WAVES 7
+#endif
 #define ING_RING_MASK (ING_RING - 1u)
 #define ING_NEAR_MAX (ING_RING - 320u)  // distances up to this are served from the LDS window
 
@@ -94,9 +104,11 @@ struct WaveLds {
   uint16_t dist_sorted[32];
   uint32_t lit_count[16], dist_count[16];
   uint8_t lens[320];
+  uint8_t dummy[64];                   // where a lane with nothing to write writes: the symbol loop has no lane-divergent branch
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 
 // The bit reader. Everything but `cur` is wave-uniform. The compressed words are fetched 64 at a time, one per lane (a
 // coalesced load; a single word per refill left the wave waiting a memory round trip every 32 bits) and taken, lane by
@@ -114,9 +126,12 @@ struct Bits {
     const uint32_t idx = byte_off >> 2, skip = (byte_off & 3u) * 8u;
     base = idx;
     cur = words[idx + threadIdx.x];
-    buf = (uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)cur, 0) >> skip);
+    buf = (uint64_t)(word_of(0) >> skip);
     cnt = 32u - skip;
     next = idx + 1u;
+  }
+  __device__ __forceinline__ uint32_t word_of(uint32_t rel) const {  // the word lane `rel` holds
+    return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)rel);
   }
   __device__ __forceinline__ void refill() {  // afterwards at least 33 bits
     if (cnt <= 32u) {
@@ -126,7 +141,7 @@ struct Bits {
         cur = w[base + threadIdx.x];
         rel = 0;
       }
-      buf |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)cur, (int)rel) << cnt;
+      buf |= (uint64_t)word_of(rel) << cnt;
       ++next;
       cnt += 32u;
     }
@@ -182,7 +197,7 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
 // Canonical Huffman code of lens[0, n) (RFC 1951 §3.2.2) -> look-up table of `root` bits + the sorted symbols and the
 // counts per length for the bit-by-bit path. The wave works on 64 symbols at a time; a symbol's rank among those of its
 // length comes from ballots. Returns false on an over-subscribed set of lengths.
-__device__ bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint32_t *count, int kind) {
+__device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint32_t *count, int kind) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lt = (1ull << lane) - 1ull;
   for (uint32_t i = lane; i < (1u << root); i += 64u) tab[i] = 0;
@@ -252,7 +267,7 @@ __device__ bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32
 // becomes both (and a third): the bases of a FASTQ take two bits each, a run of one quality value one or two. The entry at j
 // = the bits behind the first code does not depend on bits it does not cover, so T[i >> l1] IS the second look-up. In place,
 // from the top down: an entry only looks at entries below itself, and a wave's LDS accesses keep their order.
-__device__ void ing_fuse(uint32_t *tab, uint32_t root) {
+__device__ __attribute__((noinline)) void ing_fuse(uint32_t *tab, uint32_t root) {
   const uint32_t lane = threadIdx.x & 63u;
   for (int c = (int)((1u << root) / 64u) - 1; c >= 0; --c) {
     const uint32_t i = (uint32_t)c * 64u + lane;
@@ -274,22 +289,20 @@ __device__ void ing_fuse(uint32_t *tab, uint32_t root) {
   __syncthreads();
 }
 
-// a code longer than the table's root: bit by bit against the canonical code's first code of every length
-__device__ int ing_decode_slow(Bits &bs, const uint32_t *count, const uint16_t *sorted, uint32_t *len_out) {
+// a code longer than the table's root: bit by bit against the canonical code's first code of every length. Out of line and
+// by value (the symbol loop stays small): returns symbol | bits taken << 16, or ~0 when no code matches.
+__device__ __attribute__((noinline)) uint32_t ing_decode_slow(uint64_t buf, const uint32_t *count, const uint16_t *sorted) {
   uint32_t code = 0, first = 0, index = 0;
   for (uint32_t len = 1; len <= 15u; ++len) {
-    code |= bs.take(1);
+    code |= (uint32_t)(buf >> (len - 1u)) & 1u;
     const uint32_t c = uni(count[len]);
-    if (code - first < c) {
-      *len_out = len;
-      return (int)uni(sorted[index + (code - first)]);
-    }
+    if (code - first < c) return uni(sorted[index + (code - first)]) | (len << 16);
     index += c;
     first += c;
     first <<= 1;
     code <<= 1;
   }
-  return -1;
+  return 0xFFFFFFFFu;
 }
 
 // CRC-32 (IEEE, reflected) as polynomial arithmetic: a * b mod P, and x^n mod P (zlib's crc32_combine does the same)
@@ -329,9 +342,9 @@ __device__ __forceinline__ uint8_t ing_load_coherent(const ing_g8 *p) {  // text
 
 // One wavefront per member: its text goes to text[out_off, out_off + isize).
 template <bool STATS>
-__global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
-                                                         uint8_t *text, IngestState *st, int check_crc, unsigned long long *dbg) {
-  __shared__ WaveLds L;
+__device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
+                                                   uint8_t *text, IngestState *st, int check_crc, unsigned long long *dbg, uint32_t exp_mode) {
+  const uint32_t xm = STATS ? uni(exp_mode) : 0u;  // timing experiments (GMX_INGEST_EXP, with GMX_INGEST_STATS): the text is then wrong
   // dbg (GMX_INGEST_STATS=1): [0] look-ups of the literal/length table [1] literal bytes [2] matches [3] far matches [4] bit-by-bit
   // decodes [5] blocks [6..9] clocks: whole member, table building, match copies, CRC [10] members [11] match bytes
   unsigned long long n_look = 0, n_lit_total = 0, n_match = 0, n_far = 0, n_slow = 0, n_blocks = 0, t_build = 0, t_copy = 0, t_crc = 0, n_mbytes = 0;
@@ -352,29 +365,60 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
   bs.start(comp, in_off);
   uint32_t out_pos = mis, flushed = mis;  // bytes decoded so far end here; bytes already stored from the window end here
   uint32_t err = 0;
-  auto flush_to = [&](uint32_t upto) {  // [flushed, upto): upto a multiple of 1024, or the member's end
-    for (uint32_t blk = flushed & ~1023u; blk < upto; blk += 1024u) {
-      const uint32_t cs = blk + 16u * lane, ce = cs + 16u;
-      if (cs >= flushed && ce <= upto) {
-        *(ing_g128 *)(al + cs) = *reinterpret_cast<const ing_v4 *>(&L.ring[cs & ING_RING_MASK]);
-      } else if (ce > flushed && cs < upto) {  // the member's first and last piece: its neighbours own the rest of the 16 bytes
-        for (uint32_t i = max(cs, flushed); i < min(ce, upto); ++i) al[i] = L.ring[i & ING_RING_MASK];
-      }
+  // The symbol loop below has only wave-uniform branches: a lane with nothing to do writes its byte to L.dummy instead of
+  // sitting out a branch. (With lane-divergent branches and loops inside it the compiler restructured the whole loop around
+  // flag registers: some 170 instruction slots per table look-up — and one wave issues an instruction every four clocks.)
+  auto flush_partial = [&](uint32_t lo, uint32_t hi) {  // within one KB; the member's first and last pieces: a neighbour owns the rest of a 16-byte piece
+    const uint32_t cs = (lo & ~1023u) + 16u * lane, ce = cs + 16u;
+    if (cs >= lo && ce <= hi) {
+      *(ing_g128 *)(al + cs) = *reinterpret_cast<const ing_v4 *>(&L.ring[cs & ING_RING_MASK]);
+    } else if (ce > lo && cs < hi) {
+      for (uint32_t i = max(cs, lo); i < min(ce, hi); ++i) al[i] = L.ring[i & ING_RING_MASK];
     }
+  };
+  auto flush_to = [&](uint32_t upto) {  // [flushed, upto), upto a multiple of 1024
+    if (xm & 4u) {
+      flushed = upto;
+      return;
+    }
+    uint32_t blk = flushed;
+    if (blk & 1023u) {  // (once: the member's first KB starts at `mis`)
+      flush_partial(blk, (blk & ~1023u) + 1024u);
+      blk = (blk & ~1023u) + 1024u;
+    }
+    for (; blk < upto; blk += 1024u) *(ing_g128 *)(al + blk + 16u * lane) = *reinterpret_cast<const ing_v4 *>(&L.ring[(blk + 16u * lane) & ING_RING_MASK]);
     flushed = upto;
   };
   // bytes [out_pos, out_pos + len) = the len bytes starting dist back (RFC 1951 §3.2.3: may overlap what it writes)
   auto copy_match = [&](uint32_t len, uint32_t dist) {
-    // Two loops with nothing in common: sharing the byte's register, the window's path (LDS only) inherited the other one's
-    // wait for vector memory — which, stores and loads returning in order, is a wait for every line flushed so far.
-    if (dist <= ING_NEAR_MAX) {
+    if (xm & 1u) {
+      out_pos += len;
+      if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
+      return;
+    }
+    if (dist <= ING_NEAR_MAX || (xm & 2u)) {  // from the window
       if (dist >= len) {
-        for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = L.ring[(out_pos - dist + i) & ING_RING_MASK];
+        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+          const uint32_t i = i0 + lane;
+          const uint8_t v = L.ring[(out_pos - dist + i) & ING_RING_MASK];
+          uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
+          *dst = v;
+        }
       } else {  // the copy overlaps what it writes: byte i repeats byte i mod dist
-        for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = L.ring[(out_pos - dist + i % dist) & ING_RING_MASK];
+        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+          const uint32_t i = i0 + lane;
+          const uint8_t v = L.ring[(out_pos - dist + i % dist) & ING_RING_MASK];
+          uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
+          *dst = v;
+        }
       }
-    } else {  // beyond the window: from the lines already flushed (dist > len: no overlap); the load is ordered behind them
-      for (uint32_t i = lane; i < len; i += 64u) L.ring[(out_pos + i) & ING_RING_MASK] = ing_load_coherent(al + (out_pos - dist + i));
+    } else {  // beyond the window: from the KBs already flushed (dist > 3776: every byte read lies below `flushed`, for the idle lanes too)
+      for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint8_t v = ing_load_coherent(al + (out_pos - dist + i));
+        uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
+        *dst = v;
+      }
     }
     out_pos += len;
     if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
@@ -415,10 +459,10 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
     if (btype == 1) {  // fixed codes (§3.2.6)
       for (uint32_t s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
       __syncthreads();
-      bool ok = ing_build(L.lens, 288, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0);
+      bool ok = uni(ing_build(L.lens, 288, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0)) != 0;
       if (lane < 32) L.lens[lane] = 5;
       __syncthreads();
-      ok = ing_build(L.lens, 32, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1) && ok;
+      ok = uni(ing_build(L.lens, 32, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
       if (!ok) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
@@ -440,7 +484,7 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
       }
       __syncthreads();
       // (the code-length code's table borrows the distance table: root 7, every code at most 7 bits)
-      if (!ing_build(L.lens, 19, L.dist, 7, L.dist_sorted, L.dist_count, 2)) {
+      if (!uni(ing_build(L.lens, 19, L.dist, 7, L.dist_sorted, L.dist_count, 2))) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
@@ -485,8 +529,8 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
-      bool ok = ing_build(L.lens, hlit, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0);
-      ok = ing_build(L.lens + hlit, hdist, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1) && ok;
+      bool ok = uni(ing_build(L.lens, hlit, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0)) != 0;
+      ok = uni(ing_build(L.lens + hlit, hdist, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
       if (!ok) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
@@ -499,51 +543,53 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
       bs.refill();
       uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
       if (STATS) ++n_look;
-      if ((e & 15u) == 0) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
-      if (ING_TYPE(e) == ING_T_LONG) {
-        if (STATS) ++n_slow;
-        uint32_t l;
-        const int sym = ing_decode_slow(bs, L.lit_count, L.lit_sorted, &l);
-        e = sym < 0 ? 0u : ing_entry(0, (uint32_t)sym, l);
+      uint32_t type = ING_TYPE(e);
+      if ((e & 15u) == 0 || type >= ING_T_EOB) {  // rare: no code here, the end of the block, or a code longer than the root
         if ((e & 15u) == 0) {
           err = GMX_INGEST_BAD_MEMBER;
           break;
         }
+        if (type == ING_T_EOB) {
+          bs.drop(e & 15u);
+          break;
+        }
+        if (STATS) ++n_slow;
+        const uint32_t r = uni(ing_decode_slow(bs.buf, L.lit_count, L.lit_sorted));
+        e = r == 0xFFFFFFFFu ? 0u : ing_entry(0, r & 0xFFFFu, 1);
+        if ((e & 15u) == 0) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        bs.drop(r >> 16);
+        type = ING_TYPE(e);
+        if (type == ING_T_EOB) break;
       } else {
         bs.drop(e & 15u);
       }
-      const uint32_t type = ING_TYPE(e);
       if (type == ING_T_LIT) {  // one to three literals
         const uint32_t n_lit = ((e >> 6) & 3u) + 1u;
         if (out_pos + n_lit > end_v) {
           err = GMX_INGEST_BAD_MEMBER;
           break;
         }
-        if (lane < n_lit) L.ring[(out_pos + lane) & ING_RING_MASK] = (uint8_t)(e >> (8u + 8u * lane));
+        uint8_t *dst = lane < n_lit ? &L.ring[(out_pos + lane) & ING_RING_MASK] : &L.dummy[lane];
+        *dst = (uint8_t)(e >> (8u + 8u * (lane & 3u)));
         out_pos += n_lit;
         if (STATS) n_lit_total += n_lit;
         if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
         continue;
       }
-      if (type == ING_T_EOB) break;
       const uint32_t len = ((e >> 12) & 0xFFFFu) + bs.take((e >> 8) & 15u);
       bs.refill();
       uint32_t d = uni(L.dist[bs.peek(ING_DIST_ROOT)]);
-      if ((d & 15u) == 0) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
-      if (ING_TYPE(d) == ING_T_LONG) {
-        uint32_t l;
-        const int sym = ing_decode_slow(bs, L.dist_count, L.dist_sorted, &l);
-        d = sym < 0 ? 0u : ing_entry(1, (uint32_t)sym, l);
+      if ((d & 15u) == 0 || ING_TYPE(d) != ING_T_BASE) {  // rare
+        const uint32_t r = (d & 15u) == 0 ? 0xFFFFFFFFu : uni(ing_decode_slow(bs.buf, L.dist_count, L.dist_sorted));
+        d = r == 0xFFFFFFFFu ? 0u : ing_entry(1, r & 0xFFFFu, 1);
         if ((d & 15u) == 0) {
           err = GMX_INGEST_BAD_MEMBER;
           break;
         }
+        bs.drop(r >> 16);
         bs.refill();
       } else {
         bs.drop(d & 15u);
@@ -566,7 +612,11 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
     }
   }
   if (!err) {
-    flush_to(out_pos);
+    if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
+    if (out_pos > flushed) {  // the member's last piece (and, for a member below one KB, its first)
+      flush_partial(flushed, out_pos);
+      flushed = out_pos;
+    }
     // every byte of the member's deflate data used, and as much text as its trailer says
     const uint32_t used_bits = (bs.next * 32u - bs.cnt) - in_off * 8u;
     if (out_pos != end_v || (used_bits + 7u) / 8u != in_len) err = GMX_INGEST_BAD_MEMBER;
@@ -576,18 +626,20 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
     // CRC-32 of the member's text: 64 slices side by side, four table look-ups per word (the tables take the place of the
     // literal/length table), then the slices' registers combined pairwise. (One byte per step from memory — a memory round
     // trip each — was a third of the kernel's time.)
+    static_assert(offsetof(WaveLds, ring) + ING_RING >= 4096u && offsetof(WaveLds, lit) == 0, "the four CRC tables take the place of the tables and the window");
+    uint32_t *const crc_tab = reinterpret_cast<uint32_t *>(&L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     for (uint32_t i = lane; i < 256u; i += 64u) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ ING_CRC_POLY : c >> 1;
-      L.lit[i] = c;
+      crc_tab[i] = c;
     }
     __syncthreads();
     for (uint32_t t = 1; t < 4u; ++t) {
       for (uint32_t i = lane; i < 256u; i += 64u) {
-        const uint32_t v = L.lit[(t - 1u) * 256u + i];
-        L.lit[t * 256u + i] = (v >> 8) ^ L.lit[v & 0xFFu];
+        const uint32_t v = crc_tab[(t - 1u) * 256u + i];
+        crc_tab[t * 256u + i] = (v >> 8) ^ crc_tab[v & 0xFFu];
       }
       __syncthreads();
     }
@@ -598,7 +650,7 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
     if (lane == 0) lo = mis;
     uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
     const uint32_t n = hi > lo ? hi - lo : 0u;
-    auto byte_step = [&](uint32_t at) { c = L.lit[(c ^ ing_load_coherent(al + at)) & 0xFFu] ^ (c >> 8); };
+    auto byte_step = [&](uint32_t at) { c = crc_tab[(c ^ ing_load_coherent(al + at)) & 0xFFu] ^ (c >> 8); };
     while (lo < hi && (lo & 3u)) byte_step(lo++);
     const ing_g32 *words = (const ing_g32 *)al;
     for (; lo + 16u <= hi; lo += 16u) {  // four words in flight
@@ -610,12 +662,12 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         c ^= ws[q];
-        c = L.lit[768u + (c & 0xFFu)] ^ L.lit[512u + ((c >> 8) & 0xFFu)] ^ L.lit[256u + ((c >> 16) & 0xFFu)] ^ L.lit[c >> 24];
+        c = crc_tab[768u + (c & 0xFFu)] ^ crc_tab[512u + ((c >> 8) & 0xFFu)] ^ crc_tab[256u + ((c >> 16) & 0xFFu)] ^ crc_tab[c >> 24];
       }
     }
     for (; lo + 4u <= hi; lo += 4u) {
       c ^= __hip_atomic_load(words + lo / 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      c = L.lit[768u + (c & 0xFFu)] ^ L.lit[512u + ((c >> 8) & 0xFFu)] ^ L.lit[256u + ((c >> 16) & 0xFFu)] ^ L.lit[c >> 24];
+      c = crc_tab[768u + (c & 0xFFu)] ^ crc_tab[512u + ((c >> 8) & 0xFFu)] ^ crc_tab[256u + ((c >> 16) & 0xFFu)] ^ crc_tab[c >> 24];
     }
     while (lo < hi) byte_step(lo++);
     uint32_t nn = n;
@@ -637,6 +689,19 @@ __global__ void __launch_bounds__(64) gmx_inflate_kernel(const uint32_t *__restr
     atomicOr(&st->flags, err);
     atomicMin(&st->bad_member, mi);
   }
+}
+
+// The decoder is ONE thread of control per wavefront, compiled scalar: it runs on the CU's single scalar unit, which all of
+// the CU's wavefronts share. That unit is what bounds the kernel (profiles/round5/ingest_inflate_sq_counters.txt: 603 k scalar
+// instructions per member, the scalar unit busy 68 % of the kernel's cycles; 4 or 7 waves per SIMD decode the same
+// 30-34 GB/s of text). The same arithmetic compiled for the vector units — every lane redundantly — came out no faster: its
+// branches cost as many scalar instructions (exec masks) as the scalar form's arithmetic. DESIGN.md §11: what comes next.
+template <bool STATS>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ING_WAVES, 8)))
+gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members, uint8_t *text, IngestState *st,
+                   int check_crc, unsigned long long *dbg, uint32_t exp_mode) {
+  __shared__ WaveLds L;
+  ing_inflate_member<STATS>(L, comp, members, n_members, text, st, check_crc, dbg, exp_mode);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -912,6 +977,7 @@ struct gmx_ingest {
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
   std::vector<void *> allocs;
   int check_crc = 1;
+  uint32_t exp_mode = 0;
   unsigned long long *d_dbg = nullptr;  // GMX_INGEST_STATS=1: counters of gmx_inflate_kernel, printed by gmx_ingest_destroy
 };
 
@@ -951,6 +1017,7 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
   g->cap_members = (uint32_t)(max_text_bytes / 512 + 1024);  // (members of half a KB of text on average, or larger)
   g->n_tiles_max = (uint32_t)((ING_CARRY_MAX + max_text_bytes + ING_TILE - 1) / ING_TILE);
   g->check_crc = getenv("GMX_INGEST_NO_CRC") ? 0 : 1;
+  if (getenv("GMX_INGEST_EXP")) g->exp_mode = (uint32_t)atoi(getenv("GMX_INGEST_EXP"));
   if (getenv("GMX_INGEST_STATS") && ing_alloc(g, &g->d_dbg, 16, true) != GMX_OK) g->d_dbg = nullptr;
   int rc = GMX_OK;
   auto fail = [&](int code) {
@@ -1029,10 +1096,10 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
   if (inflate && n_members) {
     if (g->d_dbg)
       hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                         s.d_state, g->check_crc, g->d_dbg);
+                         s.d_state, g->check_crc, g->d_dbg, g->exp_mode);
     else
       hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                         s.d_state, g->check_crc, g->d_dbg);
+                         s.d_state, g->check_crc, g->d_dbg, 0u);
   }
   const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
   hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);

@@ -917,6 +917,31 @@ struct DeviceFeed {  // one per process: the ingest object and its page-locked s
 };
 static DeviceFeed g_device_feed;
 
+// the ingest object and its staging buffers ahead of the first BGZF file (called beside the index load: device memory for a
+// chunk and two page-locked buffers take 30 ms to come by)
+static bool hipSetDeviceForPrewarm(int) { return true; }  // (gmx_ingest_create selects the device itself)
+static void device_feed_prepare(int device, uint64_t want_text, uint64_t stage_bytes) {
+  DeviceFeed &df = g_device_feed;
+  if (!df.ing || df.max_text < want_text || df.device != device) {
+    if (df.ing) gmx_ingest_destroy(df.ing);
+    df.ing = nullptr;
+    df.max_text = 0;
+    if (gmx_ingest_create(device, want_text, &df.ing) != GMX_OK) return;
+    df.max_text = want_text;
+    df.device = device;
+  }
+  for (auto &st : df.stage)
+    if (st.size() < stage_bytes) st.resize(stage_bytes);
+}
+static uint64_t device_feed_members() {
+  uint64_t k = 7168;  // one round of the wavefronts an MI355X holds of gmx_inflate_kernel (28 per CU)
+  if (const char *e = getenv("GMX_INGEST_MEMBERS")) k = std::max<uint64_t>(1, (uint64_t)atoll(e));
+  return k;
+}
+static uint64_t device_feed_text_for(uint64_t file_text) {
+  return std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(file_text, device_feed_members() * 65536ull), 1u << 16) + (1u << 16), 3ull << 30);
+}
+
 template <class OnChunk>
 int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk on_chunk, uint64_t *delivered) {
   *delivered = 0;
@@ -948,20 +973,13 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     at = next;
   }
   feed_trace("BGZF member table walked");
-  // chunks of members: at most kMembers (two rounds of the GPU's 3 840 wavefronts), and what the ingest has room for
-  uint64_t kMembers = 7680;
-  if (const char *e = getenv("GMX_INGEST_MEMBERS")) kMembers = std::max<uint64_t>(1, (uint64_t)atoll(e));
+  // chunks of members: at most kMembers, and what the ingest has room for
+  const uint64_t kMembers = device_feed_members();
   uint64_t file_text = 0;
   for (const auto &m : members) file_text += m.isize;
-  const uint64_t want_text = std::min<uint64_t>(std::max<uint64_t>(std::min<uint64_t>(file_text, kMembers * 65536ull), 1u << 16) + (1u << 16), 3ull << 30);
   DeviceFeed &df = g_device_feed;
-  if (!df.ing || df.max_text < want_text || df.device != device) {
-    if (df.ing) gmx_ingest_destroy(df.ing);
-    df.ing = nullptr;
-    if (gmx_ingest_create(device, want_text, &df.ing) != GMX_OK) return 1;
-    df.max_text = want_text;
-    df.device = device;
-  }
+  device_feed_prepare(device, device_feed_text_for(file_text), 0);
+  if (!df.ing) return 1;
   gmx_ingest *ing = df.ing;
   GMX_CHECK(gmx_ingest_reset(ing));
   const uint64_t max_text = gmx_ingest_max_text(ing), max_comp = gmx_ingest_max_compressed(ing);
@@ -1395,7 +1413,23 @@ int run_genotype(const Args &a) {
   // Beside the index load: the page-locked buffers the reads feed will ask for (two parsed blocks in flight: bases,
   // offsets, seeds, sized for 150 bp reads in blocks of GMX_FASTQ_BLOCK bytes; other sizes are allocated when needed).
   // Freed right away, they wait in the library's cache of page-locked blocks.
-  std::thread prewarm([]() {
+  std::thread prewarm([&]() {
+    if (devices.size() == 1 && !getenv("GMX_HOST_GZ")) {  // a BGZF reads file: the device-side decoder's memory, now
+      for (const auto &smp : samples) {
+        if (smp.reads.empty()) continue;
+        unsigned char h[16] = {0};
+        struct stat sb;
+        const int fd = open(smp.reads[0].c_str(), O_RDONLY);
+        if (fd < 0) break;
+        const bool bg = pread(fd, h, 16, 0) == 16 && fstat(fd, &sb) == 0 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && h[3] == 4 && h[12] == 'B' && h[13] == 'C';
+        close(fd);
+        if (bg && hipSetDeviceForPrewarm(devices[0])) {
+          const uint64_t text = device_feed_text_for((uint64_t)sb.st_size * 6);
+          device_feed_prepare(devices[0], text, std::min<uint64_t>((uint64_t)sb.st_size, text / 2) + 64);
+        }
+        break;
+      }
+    }
     size_t block = 96u << 20;
     if (const char *eb = getenv("GMX_FASTQ_BLOCK")) block = std::max<size_t>(64, (size_t)atoll(eb));
     if (block < (8u << 20)) return;

@@ -518,17 +518,18 @@ class Quasimapper:
         there (gmx_engine_seeds_in_place). The seeds must then stay untouched until sync() / coverage()."""
         check(self.lib.gmx_engine_seeds_in_place(self.h, 1 if on else 0))
 
-    def map_ingested(self, res, seeds: "PinnedArray"):
+    def map_ingested(self, res, seeds: "PinnedArray", first: int = 0):
         """The reads a slot of an Ingest holds (gmx_ingest_result), mapped where they lie in HBM (gmx_map_reads_packed_device);
-        `seeds`: a PinnedArray of uint32, one per read, read in place by the kernels."""
+        `seeds`: a PinnedArray of uint32 read in place by the kernels, the chunk's first read taking seeds[first]."""
         n = int(res.n_reads)
+        sp = seeds.ptr + 4 * first
         if res.uniform_len:
-            check(self.lib.gmx_map_reads_packed_device(self.h, res.d_planes, None, res.uniform_len, seeds.ptr, res.d_skip if res.any_skip else None, n))
+            check(self.lib.gmx_map_reads_packed_device(self.h, res.d_planes, None, res.uniform_len, sp, res.d_skip if res.any_skip else None, n))
         else:
             for i, r0 in enumerate(range(0, n, 1 << 20)):
                 m = min(1 << 20, n - r0)
                 check(self.lib.gmx_map_reads_packed_device(self.h, res.d_planes + 8 * int(res.sub_pairs[i]), res.d_offsets + 8 * r0, 0,
-                                                           seeds.ptr + 4 * r0, (res.d_skip + r0) if res.any_skip else None, m))
+                                                           sp + 4 * r0, (res.d_skip + r0) if res.any_skip else None, m))
         self._last_seeds = seeds
 
     def map_reads_device(self, d_reads, d_offsets, d_seeds, n_reads, stream=None):

@@ -7,7 +7,7 @@ acc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for path in sys.argv[1:]:
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            name = row["Kernel_Name"].split("(")[0]
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             if name.startswith("__amd") or "at::" in name or "nccl" in name.lower():
                 continue
             cell = acc[name][row["Counter_Name"]]
