@@ -184,11 +184,11 @@ def bgzf_device_feed(ix, reads, seeds_np):
     """SURVEY 8f-3 on the device (gmx_ingest_*): the batch's reads as a BGZF FASTQ (bgzip's members, zlib level 6) in page-locked
     memory -> upload of the compressed members, inflate + CRC, record scan, 2-bit packing, quasimap — nothing inflated or
     parsed on the host. Rate of the whole chain, and of the decoding alone."""
-    from concurrent.futures import ProcessPoolExecutor
+    from concurrent.futures import ThreadPoolExecutor  # (threads: zlib releases the GIL; a fork of a process that holds a HIP context is not safe)
     from gramtools_amd import Ingest, PinnedArray, Quasimapper, bgzf_members
     n = reads.shape[0]
     per = 25000
-    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
         parts = list(ex.map(_bgzf_piece, [(11 + i, i * per, reads[i * per:(i + 1) * per]) for i in range((n + per - 1) // per)]))
     data = b"".join(p for p, _ in parts)
     text_bytes = sum(t for _, t in parts)

@@ -63,6 +63,10 @@ struct IngestState {
   uint32_t pad;
 };
 
+struct IngestInflateStatus {  // written by gmx_inflate_kernel (a stream of its own), merged into the chunk's state by gmx_layout_kernel
+  uint32_t flags, bad_member;
+};
+
 struct IngestMember {
   uint32_t in_off, in_len;   // deflate data within the chunk's compressed bytes
   uint32_t out_off, isize;   // its text within the chunk's text (from the first member's first byte)
@@ -343,7 +347,7 @@ __device__ __forceinline__ uint8_t ing_load_coherent(const ing_g8 *p) {  // text
 // One wavefront per member: its text goes to text[out_off, out_off + isize).
 template <bool STATS>
 __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
-                                                   uint8_t *text, IngestState *st, int check_crc, unsigned long long *dbg, uint32_t exp_mode) {
+                                                   uint8_t *text, IngestInflateStatus *st, int check_crc, unsigned long long *dbg, uint32_t exp_mode) {
   const uint32_t xm = STATS ? uni(exp_mode) : 0u;  // timing experiments (GMX_INGEST_EXP, with GMX_INGEST_STATS): the text is then wrong
   // dbg (GMX_INGEST_STATS=1): [0] look-ups of the literal/length table [1] literal bytes [2] matches [3] far matches [4] bit-by-bit
   // decodes [5] blocks [6..9] clocks: whole member, table building, match copies, CRC [10] members [11] match bytes
@@ -698,7 +702,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
 // branches cost as many scalar instructions (exec masks) as the scalar form's arithmetic. DESIGN.md §11: what comes next.
 template <bool STATS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ING_WAVES, 8)))
-gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members, uint8_t *text, IngestState *st,
+gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members, uint8_t *text, IngestInflateStatus *st,
                    int check_crc, unsigned long long *dbg, uint32_t exp_mode) {
   __shared__ WaveLds L;
   ing_inflate_member<STATS>(L, comp, members, n_members, text, st, check_crc, dbg, exp_mode);
@@ -885,7 +889,11 @@ __global__ void __launch_bounds__(256) gmx_records_kernel(const uint8_t *text, I
   }
 }
 // one length for all reads? -> layout of the planes; reads of different lengths: their base offsets (one block)
-__global__ void __launch_bounds__(1024) gmx_layout_kernel(IngestState *st, const uint32_t *rec_len, unsigned long long *offsets) {
+__global__ void __launch_bounds__(1024) gmx_layout_kernel(IngestState *st, const uint32_t *rec_len, unsigned long long *offsets, const IngestInflateStatus *inf) {
+  if (threadIdx.x == 0 && inf && inf->flags) {  // what the inflate kernel reported
+    st->flags |= inf->flags;
+    st->bad_member = inf->bad_member;
+  }
   const uint32_t n = st->n_reads;
   const bool uniform = n != 0 && st->min_len == st->max_len;
   if (uniform || n == 0) {
@@ -971,8 +979,10 @@ struct gmx_ingest {
     uint8_t *d_skip = nullptr;
     IngestState *d_state = nullptr, *h_state = nullptr;
     IngestMember *h_members = nullptr;  // page-locked staging of the member table
-    hipEvent_t copied = nullptr, done = nullptr, released = nullptr;
-    bool in_flight = false, has_release = false;
+    IngestInflateStatus *d_inflate_status = nullptr;
+    hipStream_t inflate_stream = nullptr;  // the slot's inflate kernel: beside the scan of the chunk before and the tail of its inflate kernel
+    hipEvent_t copied = nullptr, done = nullptr, released = nullptr, inflated = nullptr, carried = nullptr;
+    bool in_flight = false, has_release = false, has_carried = false;
   } slot[2];
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
   std::vector<void *> allocs;
@@ -1029,18 +1039,19 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
     return fail(GMX_EHIP);
   }
   for (auto &s : g->slot) {
-    if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 256, true)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
-        (rc = ing_alloc(g, &s.d_text, ING_CARRY_MAX + max_text_bytes + 64, true)) || (rc = ing_alloc(g, &s.d_line_end, g->cap_lines, false)) ||
+    if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 256, false)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
+        (rc = ing_alloc(g, &s.d_text, ING_CARRY_MAX + max_text_bytes + 64, false)) || (rc = ing_alloc(g, &s.d_line_end, g->cap_lines, false)) ||
         (rc = ing_alloc(g, &s.d_rec_start, g->cap_reads, false)) || (rc = ing_alloc(g, &s.d_rec_len, g->cap_reads, false)) ||
-        (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, true)) ||
-        (rc = ing_alloc(g, &s.d_offsets, (size_t)g->cap_reads + 1, false)) || (rc = ing_alloc(g, &s.d_skip, g->cap_reads, true)) ||
-        (rc = ing_alloc(g, &s.d_state, 1, true)))
+        (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, false)) ||
+        (rc = ing_alloc(g, &s.d_offsets, (size_t)g->cap_reads + 1, false)) || (rc = ing_alloc(g, &s.d_skip, g->cap_reads, false)) ||
+        (rc = ing_alloc(g, &s.d_state, 1, true)) || (rc = ing_alloc(g, &s.d_inflate_status, 1, true)))
       return fail(rc);
     if (hipHostMalloc(reinterpret_cast<void **>(&s.h_state), sizeof(IngestState), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&s.h_members), (size_t)g->cap_members * sizeof(IngestMember), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
-        hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.inflated, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.carried, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&s.inflate_stream, hipStreamNonBlocking) != hipSuccess) {
       gmx_set_error("gmx_ingest_create: page-locked memory / events");
       return fail(GMX_EHIP);
     }
@@ -1067,6 +1078,12 @@ void gmx_ingest_destroy(gmx_ingest *g) {
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.released) (void)hipEventDestroy(s.released);
+    if (s.inflated) (void)hipEventDestroy(s.inflated);
+    if (s.carried) (void)hipEventDestroy(s.carried);
+    if (s.inflate_stream) {
+      (void)hipStreamSynchronize(s.inflate_stream);
+      (void)hipStreamDestroy(s.inflate_stream);
+    }
   }
   for (void *p : g->allocs) (void)hipFree(p);
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -1087,26 +1104,39 @@ int gmx_ingest_reset(gmx_ingest *g) {  // the next chunk starts a file: nothing 
   return GMX_OK;
 }
 
-// the kernels behind a chunk's text, the result's copy to the host, the slot's event
+// The kernels behind a chunk's bytes. Three streams: the slot's own for its inflate kernel — so that it runs beside the scan of
+// the chunk before and fills the CUs the tail of that chunk's inflate kernel leaves idle —, one for the scans (in chunk order:
+// a chunk's carry needs the state of the chunk before), the copy stream. Orderings that are not a stream's own:
+//   inflate(i) after the upload of chunk i, and after carry(i - 1): that kernel reads the END of chunk i - 2's text from this slot
+//   scan(i) after inflate(i); the slot's next upload / inflate / pack after whatever read its planes (gmx_ingest_release_after)
 static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int final_chunk, bool inflate, uint32_t n_members) {
   gmx_ingest::Slot &s = g->slot[si];
   const gmx_ingest::Slot *prev = g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
+  if (inflate) {
+    ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.copied, 0));
+    ING_TRY(hipMemsetAsync(&s.d_inflate_status->flags, 0, 4, s.inflate_stream));
+    ING_TRY(hipMemsetAsync(&s.d_inflate_status->bad_member, 0xFF, 4, s.inflate_stream));
+    if (n_members) {
+      if (g->d_dbg)
+        hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                           s.d_inflate_status, g->check_crc, g->d_dbg, g->exp_mode);
+      else
+        hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                           s.d_inflate_status, g->check_crc, g->d_dbg, 0u);
+    }
+    ING_TRY(hipEventRecord(s.inflated, s.inflate_stream));
+  }
   hipLaunchKernelGGL(gmx_carry_kernel, dim3(64), dim3(256), 0, g->stream, prev ? prev->d_state : nullptr, prev ? prev->d_text : nullptr, s.d_state, s.d_text,
                      members_text, (uint32_t)(final_chunk ? 1 : 0));
-  if (inflate && n_members) {
-    if (g->d_dbg)
-      hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                         s.d_state, g->check_crc, g->d_dbg, g->exp_mode);
-    else
-      hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, g->stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                         s.d_state, g->check_crc, g->d_dbg, 0u);
-  }
+  ING_TRY(hipEventRecord(s.carried, g->stream));
+  s.has_carried = true;
+  ING_TRY(hipStreamWaitEvent(g->stream, inflate ? s.inflated : s.copied, 0));
   const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
   hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);
   hipLaunchKernelGGL(gmx_tile_scan_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_tiles, n_tiles, s.d_state, g->cap_lines);
   hipLaunchKernelGGL(gmx_nl_mark_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles, s.d_line_end, g->cap_lines);
   hipLaunchKernelGGL(gmx_records_kernel, dim3(2048), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_line_end, s.d_rec_start, s.d_rec_len, s.d_skip, g->cap_reads);
-  hipLaunchKernelGGL(gmx_layout_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_state, s.d_rec_len, s.d_offsets);
+  hipLaunchKernelGGL(gmx_layout_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_state, s.d_rec_len, s.d_offsets, inflate ? s.d_inflate_status : nullptr);
   hipLaunchKernelGGL(gmx_fq_pack_kernel, dim3(4096), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_rec_start, s.d_rec_len, s.d_offsets, s.d_planes, s.d_skip);
   ING_TRY(hipGetLastError());
   ING_TRY(hipMemcpyAsync(s.h_state, s.d_state, sizeof(IngestState), hipMemcpyDeviceToHost, g->stream));
@@ -1125,12 +1155,24 @@ static int ing_begin(gmx_ingest *g, int si, const char *who) {
     gmx_set_error(std::string(who) + ": the slot's chunk before has not been waited for (gmx_ingest_wait)");
     return GMX_EINVAL;
   }
+  if (g->last_slot == si) {
+    gmx_set_error(std::string(who) + ": the chunk before went to the same slot (the slots alternate: its text holds the start of this chunk's first record; gmx_ingest_reset starts a new file)");
+    return GMX_EINVAL;
+  }
   ING_TRY(hipSetDevice(g->device));
   gmx_ingest::Slot &s = g->slot[si];
   if (s.has_release) {  // the mapping kernels that read the slot's planes (gmx_ingest_release_after)
     ING_TRY(hipStreamWaitEvent(g->copy_stream, s.released, 0));
     ING_TRY(hipStreamWaitEvent(g->stream, s.released, 0));
+    ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.released, 0));
     s.has_release = false;
+  }
+  // this slot's text is about to be overwritten (inflate kernel, or the upload of a text chunk): the carry of the chunk before —
+  // in the other slot — reads the end of this slot's old text
+  gmx_ingest::Slot &other = g->slot[si ^ 1];
+  if (g->last_slot == (si ^ 1) && other.has_carried) {
+    ING_TRY(hipStreamWaitEvent(s.inflate_stream, other.carried, 0));
+    ING_TRY(hipStreamWaitEvent(g->copy_stream, other.carried, 0));
   }
   return GMX_OK;
 }
@@ -1163,7 +1205,6 @@ int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, u
   ING_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.d_comp) + n_bytes, 0, 16, g->copy_stream));
   if (n_members) ING_TRY(hipMemcpyAsync(s.d_members, s.h_members, n_members * sizeof(IngestMember), hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipEventRecord(s.copied, g->copy_stream));
-  ING_TRY(hipStreamWaitEvent(g->stream, s.copied, 0));
   return ing_enqueue_scan(g, slot, (uint32_t)text, final_chunk, true, (uint32_t)n_members);
 }
 
@@ -1177,7 +1218,6 @@ int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_
   gmx_ingest::Slot &s = g->slot[slot];
   if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX, text, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipEventRecord(s.copied, g->copy_stream));
-  ING_TRY(hipStreamWaitEvent(g->stream, s.copied, 0));
   return ing_enqueue_scan(g, slot, (uint32_t)n_bytes, final_chunk, false, 0);
 }
 
