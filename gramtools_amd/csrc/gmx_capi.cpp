@@ -1,4 +1,5 @@
 // gmx_capi.cpp — host half of the C ABI: index construction, introspection, seeds, u16 finalisation.
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -12,13 +13,16 @@
 #include "gmx_core.h"
 #include "gmx_internal.h"
 
+static std::atomic<uint64_t> g_index_serial{1};
 struct gmx_index {
   gmx::HostIndex h;
+  const uint64_t serial = g_index_serial.fetch_add(1);  // identity within the process (gmx_engine.hip shares device copies by it: an address can come back)
 };
 
 static thread_local std::string g_error;
 void gmx_set_error(const std::string &msg) { g_error = msg; }
 const gmx::HostIndex &gmx_index_host(const gmx_index *ix) { return ix->h; }
+uint64_t gmx_index_serial(const gmx_index *ix) { return ix->serial; }
 
 namespace {
 // host context used only by gmx_index_jump_states (introspection of the pre-resolved jump programs)

@@ -3210,6 +3210,7 @@ struct gmx_engine {
   hipStream_t side_stream = nullptr;  // large-capacity search + its coverage run beside filter/cover
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_wait = nullptr;  // blocking event of gmx_quiesce
+  struct GmxDeviceIndex *shared_index = nullptr;  // the device copy of the index tables, shared with the other engines of this index on this device
   uint32_t filter_lds_words = 0;  // > 0: the k-mer presence bitmap fits LDS (gmx_filter_lds_kernel)
   const uint32_t *d_kmer_planar = nullptr;  // that bitmap indexed by planar k-mer code (all_kmers_present_planar)
   const uint32_t *d_absent = nullptr;       // the k-mers that do NOT occur, when they are few (gmx_filter_absent_kernel)
@@ -3492,6 +3493,28 @@ static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   return GMX_OK;
 }
 
+// The device copy of an index is shared by the engines made of it on one device (round 5): several engines per GPU keep batches
+// in flight side by side — a nested PRG's batch is a 0.4 ms burst and then 2 ms of a few straggler tasks on a handful of CUs —
+// and the second one must not cost a second upload and a second copy in HBM. Reference counted; GMX_NO_INDEX_SHARE=1: off.
+struct GmxDeviceIndex {
+  uint64_t serial = 0;  // gmx_index_serial of the index it was uploaded from
+  int device = 0;
+  GmxIndexView view{};
+  std::vector<void *> allocs;
+  uint64_t bytes = 0;
+  int refs = 0;
+};
+static std::mutex g_dev_index_mu;
+static std::vector<GmxDeviceIndex *> g_dev_indexes;
+static void gmx_dev_index_release(GmxDeviceIndex *d) {
+  if (!d) return;
+  std::lock_guard<std::mutex> lk(g_dev_index_mu);
+  if (--d->refs > 0) return;
+  for (void *p : d->allocs) (void)hipFree(p);
+  g_dev_indexes.erase(std::remove(g_dev_indexes.begin(), g_dev_indexes.end(), d), g_dev_indexes.end());
+  delete d;
+}
+
 int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine **out) {
   if (!ixh || !out) {
     gmx_set_error("gmx_engine_create: null argument");
@@ -3527,34 +3550,61 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   e->opts = opts;
   GmxIndexView v = h.view();
   int rc = 0;
-  rc |= e->upload(&v.blocks, h.blocks);
-  rc |= e->upload(&v.hits, h.hits);
-  rc |= e->upload(&v.hit_perm, h.hit_perm);
-  rc |= e->upload(&v.hit_prog, h.hit_prog);
-  rc |= e->upload(&v.text, h.text);
-  rc |= e->upload(&v.prog, h.prog);
-  rc |= e->upload(&v.sa, h.sa);
-  rc |= e->upload(&v.pos_node, h.pos_node);
-  rc |= e->upload(&v.nodes, h.nodes);
-  rc |= e->upload(&v.edges, h.edges);
-  rc |= e->upload(&v.sites, h.sites);
-  rc |= e->upload(&v.site_geo, h.site_geo);
-  rc |= e->upload(&v.seeds, h.seeds);
-  if (h.kmer_size2) rc |= e->upload(&v.seeds2, h.seeds2);
-  else v.seeds2 = nullptr;
-  rc |= e->upload(&v.seed_words, h.seed_words);
-  if (!rc) {  // flags in the multi-state entries of the device copies (GMX_SEEDF_*)
-    if (((uint64_t)h.seed_words.size() >> h.seed_shift) >= (1u << 30)) {
-      gmx_set_error("the seed tables hold more than 2^30 units of multi-state entries");
-      rc = GMX_ECAP;
+  {
+    std::lock_guard<std::mutex> share_lock(g_dev_index_mu);  // (engines of one group are created side by side: the second waits for the first one's upload)
+    GmxDeviceIndex *found = nullptr;
+    if (!getenv("GMX_NO_INDEX_SHARE"))
+      for (GmxDeviceIndex *d : g_dev_indexes)
+        if (d->serial == gmx_index_serial(ixh) && d->device == opts.device) found = d;
+    if (found) {
+      ++found->refs;
+      v = found->view;
+      e->index_bytes = found->bytes;
+      e->shared_index = found;
     } else {
-      hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
-      if (h.kmer_size2)
-        hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
-      rc |= hipDeviceSynchronize() != hipSuccess;
+      rc |= e->upload(&v.blocks, h.blocks);
+      rc |= e->upload(&v.hits, h.hits);
+      rc |= e->upload(&v.hit_perm, h.hit_perm);
+      rc |= e->upload(&v.hit_prog, h.hit_prog);
+      rc |= e->upload(&v.text, h.text);
+      rc |= e->upload(&v.prog, h.prog);
+      rc |= e->upload(&v.sa, h.sa);
+      rc |= e->upload(&v.pos_node, h.pos_node);
+      rc |= e->upload(&v.nodes, h.nodes);
+      rc |= e->upload(&v.edges, h.edges);
+      rc |= e->upload(&v.sites, h.sites);
+      rc |= e->upload(&v.site_geo, h.site_geo);
+      rc |= e->upload(&v.seeds, h.seeds);
+      if (h.kmer_size2) rc |= e->upload(&v.seeds2, h.seeds2);
+      else v.seeds2 = nullptr;
+      rc |= e->upload(&v.seed_words, h.seed_words);
+      if (!rc) {  // flags in the multi-state entries of the device copies (GMX_SEEDF_*)
+        if (((uint64_t)h.seed_words.size() >> h.seed_shift) >= (1u << 30)) {
+          gmx_set_error("the seed tables hold more than 2^30 units of multi-state entries");
+          rc = GMX_ECAP;
+        } else {
+          hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds), (uint64_t)h.seeds.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
+          if (h.kmer_size2)
+            hipLaunchKernelGGL(gmx_seed_mark_kernel, dim3(4096), dim3(256), 0, nullptr, const_cast<GmxSeed *>(v.seeds2), (uint64_t)h.seeds2.size(), const_cast<uint32_t *>(v.seed_words), v.seed_shift, v.sa, v.text);
+          rc |= hipDeviceSynchronize() != hipSuccess;
+        }
+      }
+      rc |= e->upload(&v.kmer_bitmap, h.kmer_bitmap);
+
+      if (!rc) {  // everything allocated so far is the index: it moves to the shared object
+        GmxDeviceIndex *d = new GmxDeviceIndex();
+        d->serial = gmx_index_serial(ixh);
+        d->device = opts.device;
+        d->view = v;
+        d->allocs = std::move(e->allocs);
+        e->allocs.clear();
+        d->bytes = e->index_bytes;
+        d->refs = 1;
+        g_dev_indexes.push_back(d);
+        e->shared_index = d;
+      }
     }
   }
-  rc |= e->upload(&v.kmer_bitmap, h.kmer_bitmap);
   e->dview = v;
   e->n_allele = h.n_allele_slots;
   e->n_pb = h.n_pb_slots;
@@ -3728,6 +3778,7 @@ void gmx_engine_destroy(gmx_engine *e) {
     if (sl.h_seeds) (void)hipHostFree(sl.h_seeds);
   }
   for (void *p : e->allocs) (void)hipFree(p);
+  gmx_dev_index_release(e->shared_index);
   delete e;
 }
 
@@ -4289,6 +4340,7 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
   return rc ? rc : gmx_engine_sync(e);
 }
 
+static uint64_t gmx_feed_chunk(const gmx_engine *e);  // reads per launch of the host feeds (below)
 int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
                        uint64_t n_reads) {
   if (!e) {
@@ -4298,7 +4350,7 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
   if (n_reads == 0) return GMX_OK;
   HIP_TRY(hipSetDevice(e->opts.device));
   {
-    const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+    const uint64_t chunk = gmx_feed_chunk(e);
     if (n_reads > chunk && !getenv("GMX_HOST_SERIAL")) return map_reads_host_pipelined(e, reads, offsets, seeds, n_reads, chunk);
   }
   uint64_t done = 0;
@@ -4375,7 +4427,7 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
     if (hipHostGetDevicePointer(&dp, const_cast<uint32_t *>(seeds), 0) == hipSuccess && dp) d_seeds_host = static_cast<const uint32_t *>(dp);
     else (void)hipGetLastError();
   }
-  const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+  const uint64_t chunk = gmx_feed_chunk(e);
   int rc = GMX_OK;
   auto hip_ok = [&](hipError_t err, const char *what) {
     if (err == hipSuccess) return true;
@@ -4471,6 +4523,16 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
   return map_reads_packed_impl(e, planes, false, offsets, uniform_len, seeds, skip, n_reads);
 }
 
+// Reads per launch of the host / device-plane feeds: 2^20 — uploads of one launch then hide behind the kernels of the one before —
+// except on a NESTED PRG, where a batch ends with ~2 ms of a few straggler tasks (reads inside MSA regions: hundreds of
+// dependent general iterations each) whatever its size: configs[2] maps 138 M reads/s in batches of 250 k, 388 M at 1 M,
+// 640 M at 4 M (round 5, tools/exp/engines_in_flight.py). There the whole call, up to max_batch_reads, is one launch.
+static uint64_t gmx_feed_chunk(const gmx_engine *e) {
+  static const char *env = getenv("GMX_FEED_CHUNK");
+  if (env) return std::max<uint64_t>(1, std::min<uint64_t>(e->opts.max_batch_reads, strtoull(env, nullptr, 10)));
+  return e->dview.is_nested ? e->opts.max_batch_reads : std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+}
+
 // bit planes already in HBM (gmx_ingest_*): nothing to upload; seeds in device memory, or page-locked and read in place
 int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const uint64_t *d_offsets, uint32_t uniform_len,
                                 const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads) {
@@ -4490,7 +4552,7 @@ int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const u
     }
     d_seeds = static_cast<const uint32_t *>(dp);
   }
-  const uint64_t chunk = std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+  const uint64_t chunk = gmx_feed_chunk(e);
   if (!uniform_len && n_reads > chunk) {
     gmx_set_error("gmx_map_reads_packed_device: with d_offsets a call takes at most 2^20 reads (and at most max_batch_reads)");
     return GMX_EINVAL;
@@ -4635,7 +4697,7 @@ int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs)
     return GMX_EINVAL;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
-  n_reads = std::min<uint64_t>(std::min<uint64_t>(n_reads, e->opts.max_batch_reads), 1u << 20);
+  n_reads = std::min<uint64_t>(n_reads, gmx_feed_chunk(e));
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));

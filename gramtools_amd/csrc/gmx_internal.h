@@ -8,6 +8,7 @@
 
 void gmx_set_error(const std::string &msg);
 const gmx::HostIndex &gmx_index_host(const gmx_index *ix);
+uint64_t gmx_index_serial(const gmx_index *ix);  // unique within the process
 
 // What the multi-GPU exchange (gmx_multi.hip) needs of an engine (gmx_engine.hip).
 struct GmxEngineRaw {

@@ -696,6 +696,12 @@ struct BlockPipe {
   ~BlockPipe() { finish(); }
 };
 
+// Reads per engine call. A nested PRG's batch ends with ~2 ms of a few straggler tasks whatever its size (gmx_engine.hip:
+// gmx_feed_chunk), so there the feed hands over blocks of ~4 M reads instead of ~0.3 M: file blocks 12 times as large,
+// three times the BGZF members per device chunk (set by run_genotype once the index is loaded).
+static size_t g_block_scale = 1;
+static uint64_t g_ingest_member_scale = 1;
+
 // the file block being parsed (kept between files; `gram genotype` allocates and touches it beside the index load)
 static std::unique_ptr<char[]> g_block_mem;
 static size_t g_block_cap = 0;
@@ -714,7 +720,7 @@ bool parse_fastq_file(const std::string &path, int threads, Sink sink) {
   const bool stat_ok = fstat(fd, &sb) == 0;
   // (gzip input: larger blocks — the inflated text is parsed from a buffer, block after block, and a block's fixed costs,
   //  64 thread wake-ups and the leftover's move, were two thirds of the BGZF leg's parse time at 96 MB)
-  size_t kBlock = gz ? (size_t)384 << 20 : (size_t)96 << 20;
+  size_t kBlock = (gz ? (size_t)384 << 20 : (size_t)96 << 20) * g_block_scale;
   if (const char *eb = getenv("GMX_FASTQ_BLOCK")) kBlock = std::max<size_t>(64, (size_t)atoll(eb));  // tests: tiny blocks
   const unsigned T = (unsigned)std::max(1, std::min(threads, 128));
   feed_trace("file opened");
@@ -934,7 +940,7 @@ static void device_feed_prepare(int device, uint64_t want_text, uint64_t stage_b
     if (st.size() < stage_bytes) st.resize(stage_bytes);
 }
 static uint64_t device_feed_members() {
-  uint64_t k = 7168;  // one round of the wavefronts an MI355X holds of gmx_inflate_kernel (28 per CU)
+  uint64_t k = 7168 * g_ingest_member_scale;  // one round of the wavefronts an MI355X holds of gmx_inflate_kernel (28 per CU)
   if (const char *e = getenv("GMX_INGEST_MEMBERS")) k = std::max<uint64_t>(1, (uint64_t)atoll(e));
   return k;
 }
@@ -1455,6 +1461,10 @@ int run_genotype(const Args &a) {
   phase("index loaded (host)");
   gmx_index_info info;
   GMX_CHECK(gmx_index_get_info(ix, &info));
+  if (info.is_nested) {  // (a batch's straggler tail: larger batches)
+    g_block_scale = 12;
+    g_ingest_member_scale = 3;
+  }
   std::cout << "Loading kmer index data" << std::endl;
   gmx_engine_opts opts;
   gmx_engine_default_opts(&opts);
@@ -1488,7 +1498,7 @@ int run_genotype(const Args &a) {
   phase("engines created (HIP start-up, index upload)");
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
-  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), 1u << 20, (6ull << 20) + 64));
+  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), info.is_nested ? 4u << 20 : 1u << 20, ((info.is_nested ? 24ull : 6ull) << 20) + 64));
   if (prewarm.joinable()) prewarm.join();
   phase("workspace reserved, page-locked buffers warmed");
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();

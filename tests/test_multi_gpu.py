@@ -101,3 +101,31 @@ def test_gram_devices_option_gives_the_same_files(tmp_path):
     want = oracle_map(prg, 7, reads, master_seeds(42, [len(reads)]), threads=8)
     asum = [[int(x) for x in l.split()] for l in outs[1][1]["allele_sum_coverage"].decode().splitlines()]
     assert asum == want["allele_sum"]
+
+
+def test_engines_of_one_index_share_its_device_copy():
+    """Engines made of one index on one device share the device copy of its tables (reference counted, gmx_engine.hip:
+    GmxDeviceIndex): the second engine maps as the first, keeps working when the first is destroyed, and an engine of ANOTHER
+    index that happens to be built afterwards does not pick the old copy up (the key is a serial, not an address)."""
+    import gc
+    prg, reads, seeds = _workload(seed=5, n_reads=2000)
+    flat, offs = flatten_reads(reads)
+    want = oracle_map(prg, 5, reads, seeds, threads=8)
+    ix = Index(prg, 5)
+    a, b = Quasimapper(ix), Quasimapper(ix)
+    a.map_reads(flat, offs, seeds)
+    b.map_reads(flat, offs, seeds)
+    assert canonical_cov(a.coverage()) == want and canonical_cov(b.coverage()) == want
+    a.close()
+    b.reset()
+    b.map_reads(flat, offs, seeds)
+    assert canonical_cov(b.coverage()) == want
+    b.close()
+    del ix
+    gc.collect()
+    prg2, reads2, seeds2 = _workload(seed=9, n_reads=1500)
+    flat2, offs2 = flatten_reads(reads2)
+    ix2 = Index(prg2, 5)
+    c = Quasimapper(ix2)
+    c.map_reads(flat2, offs2, seeds2)
+    assert canonical_cov(c.coverage()) == oracle_map(prg2, 5, reads2, seeds2, threads=8)
