@@ -4523,14 +4523,16 @@ int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint6
   return map_reads_packed_impl(e, planes, false, offsets, uniform_len, seeds, skip, n_reads);
 }
 
-// Reads per launch of the host / device-plane feeds: 2^20 — uploads of one launch then hide behind the kernels of the one before —
-// except on a NESTED PRG, where a batch ends with ~2 ms of a few straggler tasks (reads inside MSA regions: hundreds of
-// dependent general iterations each) whatever its size: configs[2] maps 138 M reads/s in batches of 250 k, 388 M at 1 M,
-// 640 M at 4 M (round 5, tools/exp/engines_in_flight.py). There the whole call, up to max_batch_reads, is one launch.
+// Reads per launch of the host / device-plane feeds: the whole call, up to max_batch_reads (4 M). Every batch ends with a tail
+// of few-lane kernels — on a NESTED PRG with ~2 ms of a few straggler tasks (reads inside MSA regions: hundreds of dependent
+// general iterations each) whatever its size —, and the tail is paid per launch (round 5, tools/exp/engines_in_flight.py,
+// kernel pipeline): configs[2] maps 138 M reads/s in launches of 250 k reads, 388 M at 1 M, 640 M at 4 M; configs[3] 914 M ->
+// 1 173 M, configs[4] 350 -> 412 M, configs[1] 2.30 -> 2.63 G from 1 M to 4 M. (Until round 5 a launch took at most 2^20 reads;
+// a call's first upload is now up to four times as long, the uploads behind it still hide behind the kernels.)
 static uint64_t gmx_feed_chunk(const gmx_engine *e) {
   static const char *env = getenv("GMX_FEED_CHUNK");
   if (env) return std::max<uint64_t>(1, std::min<uint64_t>(e->opts.max_batch_reads, strtoull(env, nullptr, 10)));
-  return e->dview.is_nested ? e->opts.max_batch_reads : std::min<uint64_t>(e->opts.max_batch_reads, 1u << 20);
+  return e->opts.max_batch_reads;
 }
 
 // bit planes already in HBM (gmx_ingest_*): nothing to upload; seeds in device memory, or page-locked and read in place

@@ -75,7 +75,7 @@ struct IngestMember {
 
 #define ING_CARRY_MAX (1u << 20)  // bytes of an incomplete last record that can be carried (a record longer than this: irregular)
 #ifndef ING_LIT_ROOT
-#define ING_LIT_ROOT 9
+#define ING_LIT_ROOT 10
 #endif
 #ifndef ING_DIST_ROOT
 #define ING_DIST_ROOT 7
@@ -84,7 +84,7 @@ struct IngestMember {
 #define ING_RING 2048u
 #endif
 #ifndef ING_WAVES
-#define ING_WAVES 7
+#define ING_WAVES 5
 #endif
 #define ING_RING_MASK (ING_RING - 1u)
 #define ING_NEAR_MAX (ING_RING - 320u)  // distances up to this are served from the LDS window
@@ -99,6 +99,8 @@ struct IngestMember {
 #define ING_T_EOB 2u
 #define ING_T_LONG 3u
 #define ING_TYPE(e) (((e) >> 4) & 3u)
+#define ING_RARE 0x80000000u  // set in every entry that is not a literal or a length / distance base: no code, end of block, longer code
+                               // (a third fused literal is below 0x80, so that its byte does not reach the bit)
 
 struct WaveLds {
   uint32_t lit[1u << ING_LIT_ROOT];    // literal/length codes of up to ING_LIT_ROOT bits, by the next bits of the stream (4 KB); the CRC table afterwards
@@ -120,8 +122,8 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // symbol loop wait for vector memory (its register copies), i.e. for every line of text flushed so far.
 struct Bits {
   const uint32_t *w;
-  uint32_t next;   // index of the next word to take
   uint32_t base;   // index of the word lane 0 holds in `cur`
+  uint32_t rel;    // lane of `cur` that holds the next word to take (64: the next set is due)
   uint32_t cur;
   uint64_t buf;
   uint32_t cnt;
@@ -132,24 +134,24 @@ struct Bits {
     cur = words[idx + threadIdx.x];
     buf = (uint64_t)(word_of(0) >> skip);
     cnt = 32u - skip;
-    next = idx + 1u;
+    rel = 1u;
   }
-  __device__ __forceinline__ uint32_t word_of(uint32_t rel) const {  // the word lane `rel` holds
-    return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)rel);
+  __device__ __forceinline__ uint32_t word_of(uint32_t lane_of) const {  // the word that lane holds
+    return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)lane_of);
   }
   __device__ __forceinline__ void refill() {  // afterwards at least 33 bits
     if (cnt <= 32u) {
-      uint32_t rel = next - base;
       if (rel == 64u) {
         base += 64u;
         cur = w[base + threadIdx.x];
         rel = 0;
       }
       buf |= (uint64_t)word_of(rel) << cnt;
-      ++next;
+      ++rel;
       cnt += 32u;
     }
   }
+  __device__ __forceinline__ uint32_t next_word() const { return base + rel; }  // index of the next word to take
   __device__ __forceinline__ uint32_t peek(uint32_t n) const { return (uint32_t)buf & ((1u << n) - 1u); }
   __device__ __forceinline__ void drop(uint32_t n) {
     buf >>= n;
@@ -160,15 +162,15 @@ struct Bits {
     drop(n);
     return v;
   }
-  __device__ __forceinline__ uint32_t byte_pos() const { return next * 4u - cnt / 8u; }  // of the next unread bit's byte (cnt a multiple of 8)
+  __device__ __forceinline__ uint32_t byte_pos() const { return next_word() * 4u - cnt / 8u; }  // of the next unread bit's byte (cnt a multiple of 8)
 };
 
 // what a symbol of one of the three codes stands for, as a table entry of `len` bits
 __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len) {
   if (kind == 0) {  // literal / length (RFC 1951 §3.2.5)
     if (s < 256u) return len | (ING_T_LIT << 4) | (s << 8);
-    if (s == 256u) return len | (ING_T_EOB << 4);
-    if (s > 285u) return 0u;
+    if (s == 256u) return len | (ING_T_EOB << 4) | ING_RARE;
+    if (s > 285u) return ING_RARE;
     const uint32_t t = s - 257u;
     uint32_t base, extra;
     if (t < 8u) {
@@ -184,7 +186,7 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
     return len | (ING_T_BASE << 4) | (extra << 8) | (base << 12);
   }
   if (kind == 1) {  // distance
-    if (s > 29u) return 0u;
+    if (s > 29u) return ING_RARE;
     uint32_t base, extra;
     if (s < 4u) {
       base = 1u + s;
@@ -204,7 +206,7 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
 __device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint32_t *count, int kind) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (uint32_t i = lane; i < (1u << root); i += 64u) tab[i] = 0;
+  for (uint32_t i = lane; i < (1u << root); i += 64u) tab[i] = ING_RARE;
   uint32_t cnt[16];
 #pragma unroll
   for (int L = 0; L < 16; ++L) cnt[L] = 0;
@@ -259,7 +261,7 @@ __device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_
         const uint32_t e = ing_entry(kind, s, l);
         for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab[j] = e;
       } else {
-        tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 4);
+        tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 4) | ING_RARE;
       }
     }
   }
@@ -284,7 +286,7 @@ __device__ __attribute__((noinline)) void ing_fuse(uint32_t *tab, uint32_t root)
         l += l2;
         if (l < root) {
           const uint32_t e3 = tab[i >> l], l3 = e3 & 15u;
-          if (l3 != 0 && ING_TYPE(e3) == ING_T_LIT && l + l3 <= root) e = (l + l3) | (2u << 6) | (e & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
+          if (l3 != 0 && ING_TYPE(e3) == ING_T_LIT && l + l3 <= root && (e3 & 0x8000u) == 0) e = (l + l3) | (2u << 6) | (e & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
         }
       }
     }
@@ -543,75 +545,76 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
     ing_fuse(L.lit, ING_LIT_ROOT);
     if (STATS) t_build += clock64() - t_b0;
     // ---- the block's symbols ----
-    for (;;) {
-      bs.refill();
-      uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
-      if (STATS) ++n_look;
-      uint32_t type = ING_TYPE(e);
-      if ((e & 15u) == 0 || type >= ING_T_EOB) {  // rare: no code here, the end of the block, or a code longer than the root
-        if ((e & 15u) == 0) {
-          err = GMX_INGEST_BAD_MEMBER;
-          break;
-        }
-        if (type == ING_T_EOB) {
-          bs.drop(e & 15u);
-          break;
-        }
-        if (STATS) ++n_slow;
-        const uint32_t r = uni(ing_decode_slow(bs.buf, L.lit_count, L.lit_sorted));
-        e = r == 0xFFFFFFFFu ? 0u : ing_entry(0, r & 0xFFFFu, 1);
-        if ((e & 15u) == 0) {
-          err = GMX_INGEST_BAD_MEMBER;
-          break;
-        }
-        bs.drop(r >> 16);
-        type = ING_TYPE(e);
-        if (type == ING_T_EOB) break;
-      } else {
-        bs.drop(e & 15u);
-      }
-      if (type == ING_T_LIT) {  // one to three literals
+    // what an entry that is a literal run or a length stands for (its bits already dropped); false: the member is damaged.
+    // (Inlined at both of its call sites: merged behind the rare path the common path carried that path's flag registers.)
+    auto process = [&](uint32_t e) __attribute__((always_inline)) -> bool {
+      if ((e & 16u) == 0) {  // a literal entry (type bit 0 clear): one to three literals
         const uint32_t n_lit = ((e >> 6) & 3u) + 1u;
-        if (out_pos + n_lit > end_v) {
-          err = GMX_INGEST_BAD_MEMBER;
-          break;
-        }
+        if (out_pos + n_lit > end_v) return false;
         uint8_t *dst = lane < n_lit ? &L.ring[(out_pos + lane) & ING_RING_MASK] : &L.dummy[lane];
         *dst = (uint8_t)(e >> (8u + 8u * (lane & 3u)));
         out_pos += n_lit;
         if (STATS) n_lit_total += n_lit;
         if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
-        continue;
+        return true;
       }
       const uint32_t len = ((e >> 12) & 0xFFFFu) + bs.take((e >> 8) & 15u);
       bs.refill();
       uint32_t d = uni(L.dist[bs.peek(ING_DIST_ROOT)]);
-      if ((d & 15u) == 0 || ING_TYPE(d) != ING_T_BASE) {  // rare
+      if ((int32_t)d < 0) {  // rare (ING_RARE)
         const uint32_t r = (d & 15u) == 0 ? 0xFFFFFFFFu : uni(ing_decode_slow(bs.buf, L.dist_count, L.dist_sorted));
-        d = r == 0xFFFFFFFFu ? 0u : ing_entry(1, r & 0xFFFFu, 1);
-        if ((d & 15u) == 0) {
-          err = GMX_INGEST_BAD_MEMBER;
-          break;
-        }
+        d = r == 0xFFFFFFFFu ? ING_RARE : ing_entry(1, r & 0xFFFFu, 1);
+        if ((d & 15u) == 0) return false;
         bs.drop(r >> 16);
         bs.refill();
       } else {
         bs.drop(d & 15u);
       }
       const uint32_t dist = ((d >> 12) & 0xFFFFu) + bs.take((d >> 8) & 15u);
-      if (dist > out_pos - mis || out_pos + len > end_v) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
+      if (dist > out_pos - mis || out_pos + len > end_v) return false;
       if (STATS) {
         ++n_match;
         n_mbytes += len;
         if (dist > ING_NEAR_MAX) ++n_far;
       }
-      {
-        const long long t_c0 = STATS ? clock64() : 0;
-        copy_match(len, dist);
-        if (STATS) t_copy += clock64() - t_c0;
+      const long long t_c0 = STATS ? clock64() : 0;
+      copy_match(len, dist);
+      if (STATS) t_copy += clock64() - t_c0;
+      return true;
+    };
+    for (;;) {
+      bs.refill();
+      const uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
+      if (STATS) ++n_look;
+      if ((int32_t)e >= 0) {  // a literal run or a length
+        bs.drop(e & 15u);
+        if (!process(e)) {
+          err = GMX_INGEST_BAD_MEMBER;
+          break;
+        }
+        continue;
+      }
+      // rare (ING_RARE): no code here, the end of the block, or a code longer than the table's bits
+      if ((e & 15u) == 0) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      if (ING_TYPE(e) == ING_T_EOB) {
+        bs.drop(e & 15u);
+        break;
+      }
+      if (STATS) ++n_slow;
+      const uint32_t r = uni(ing_decode_slow(bs.buf, L.lit_count, L.lit_sorted));
+      const uint32_t e2 = r == 0xFFFFFFFFu ? ING_RARE : ing_entry(0, r & 0xFFFFu, 1);
+      if ((e2 & 15u) == 0) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
+      }
+      bs.drop(r >> 16);
+      if (ING_TYPE(e2) == ING_T_EOB) break;
+      if (!process(e2)) {
+        err = GMX_INGEST_BAD_MEMBER;
+        break;
       }
     }
   }
@@ -622,7 +625,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
       flushed = out_pos;
     }
     // every byte of the member's deflate data used, and as much text as its trailer says
-    const uint32_t used_bits = (bs.next * 32u - bs.cnt) - in_off * 8u;
+    const uint32_t used_bits = (bs.next_word() * 32u - bs.cnt) - in_off * 8u;
     if (out_pos != end_v || (used_bits + 7u) / 8u != in_len) err = GMX_INGEST_BAD_MEMBER;
   }
   const long long t_crc0 = STATS ? clock64() : 0;
