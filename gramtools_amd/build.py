@@ -15,7 +15,7 @@ LIB = os.path.join(LIB_DIR, "libgmx.so")
 GRAM = os.path.join(BIN_DIR, "gram")
 
 LIB_SOURCES = ["gmx_engine.hip", "gmx_ingest.hip", "gmx_multi.hip", "gmx_seedwalk.hip", "gmx_suffixsort.hip", "gmx_capi.cpp", "gmx_index.cpp", "gmx_infer.cpp", "gmx_stock.cpp"]
-HEADERS = ["gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_index.h", "gmx_internal.h", "gmx_engine_debug.h", "gmx_gzsource.h", "gmx_pargz.h", "gmx_crc32.h", "../../include/gmx.h"]
+HEADERS = ["gmx_engine_search.h", "gmx_engine_cover_kernels.h", "gmx_engine_host.h", "gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_index.h", "gmx_internal.h", "gmx_engine_debug.h", "gmx_gzsource.h", "gmx_pargz.h", "gmx_crc32.h", "../../include/gmx.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 5: the round-4 wrong-result build of gmx_cover_jump, reproduced and explained (profiles/round5/jump_ptr_form_*).
-# Applies tools/exp/jump_ptr_form.patch (made against the sources of the commit that added it; later edits of gmx_cover.h may need it refreshed)
+# Applies tools/exp/jump_ptr_form.patch (made against the sources of commit 0e49958, when gmx_engine.hip was still one file: run it on a
+# checkout of that commit — `git worktree add /tmp/jp 0e49958` —, later sources need the patch refreshed)
 # — (the form that took the caller's first node by pointer, plus counters) to a scratch copy
 # of the sources, builds P (pointer form) and G (the node fetched inside, same call sites) and runs the 37-loci workload and
 # the flat fuzz slice with each. Usage (on a GPU box): tools/exp/jump_ptr_form.sh
