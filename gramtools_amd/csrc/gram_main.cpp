@@ -1032,17 +1032,21 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     gmx_ingest_result res;
     GMX_CHECK(gmx_ingest_wait(ing, (int)(ci & 1), &res));
     feed_trace("chunk decoded");
+    if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))  // test hook: the device decoder "gives up" on this chunk (tests/test_ingest.py)
+      if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_BAD_MEMBER;
     if (res.status) {
       if (ci + 1 < chunks.size()) {  // (the chunk behind is in flight: let it finish before the slots are reused)
         gmx_ingest_result drop;
         GMX_CHECK(gmx_ingest_wait(ing, (int)((ci + 1) & 1), &drop));
       }
-      if ((res.status & (GMX_INGEST_BAD_RECORD | GMX_INGEST_TOO_MANY_LINES)) && !(res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC))) {
+      const bool decoder = (res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC | GMX_INGEST_TOO_MANY_LINES)) != 0;
+      if (!decoder) {  // the text itself is not four-line FASTQ: the host's fast path would say the same
         if (*delivered == 0) return 1;
         die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(*delivered) +
             " reads (multi-line or blank lines); decompress and reformat, or use a four-line FASTQ");
       }
-      return *delivered == 0 && ci == 0 ? 2 : 2;
+      // a member the kernels would not decode, or lines of a few bytes (more records than the ingest has room for): the host reader's
+      return *delivered == 0 && !(res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC)) ? 1 : 2;
     }
     on_chunk(res, (int)(ci & 1));
     *delivered += res.n_reads;

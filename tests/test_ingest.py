@@ -322,3 +322,56 @@ def test_gram_damaged_bgzf_is_fatal_on_the_device_path_too(tmp_path):
     path.write_bytes(bytes(d))
     out = _gram("_parse_check", str(path), "4", env={"GMX_PARSE_CHECK_DEVICE": "1"})
     assert out.returncode != 0, out.stdout
+
+
+@pytest.mark.parametrize("fail_chunk", ["0", "2"])
+def test_gram_host_reader_takes_over_where_the_device_decoder_gives_up(tmp_path, fail_chunk):
+    """GMX_INGEST_TEST_FAIL_CHUNK: `gram genotype` treats that chunk as one the device decoder would not take. The host reader then
+    reads the file from its start and drops the reads already mapped from the device feed — coverage files, counters and the
+    seeds' assignment (a second file follows) must come out as for the plain text."""
+    import json
+    from gramtools_amd.synth import random_ref, snp_prg, simulate_snp_reads
+    ref = random_ref(3000, 4)
+    prg, pos, alts, n_alts = snp_prg(ref, 40, 5, multi_allelic_frac=0.3)
+    (tmp_path / "prg").write_bytes(np.array(prg, dtype="<u4").tobytes())
+    reads = simulate_snp_reads(ref, pos, alts, n_alts, 7300, 60, 6)
+    txt = ["".join("ACGT"[b - 1] for b in r) for r in reads]
+    fq = lambda rs: "".join(f"@r{i}\n{s}\n+\n{'I' * len(s)}\n" for i, s in enumerate(rs)).encode()  # noqa: E731
+    a, b = fq(txt[:5100]), fq(txt[5100:])
+    (tmp_path / "a.fq").write_bytes(a)
+    (tmp_path / "b.fq").write_bytes(b)
+    (tmp_path / "a.fq.gz").write_bytes(bgzf(a, block=9000))
+    outs = {}
+    for name, files, env in (("plain", ("a.fq", "b.fq"), {}), ("takeover", ("a.fq.gz", "b.fq"), {"GMX_INGEST_MEMBERS": "20", "GMX_INGEST_TEST_FAIL_CHUNK": fail_chunk,
+                                                                                                "GMX_FASTQ_BLOCK": "200000"})):
+        out = tmp_path / name
+        r = _gram("genotype", "--gram_dir", str(tmp_path), "--reads", *[str(tmp_path / f) for f in files], "--sample_id", "s", "--ploidy", "diploid",
+                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", env=env)
+        assert r.returncode == 0, r.stdout
+        if name == "takeover":
+            assert "the host reader takes over" in r.stdout
+        counters = [l for l in r.stdout.splitlines() if l.startswith("Count ")]
+        outs[name] = ([(out / "coverage" / f).read_bytes() for f in ("allele_sum_coverage", "allele_base_coverage.json", "grouped_allele_counts_coverage.json")],
+                      counters, json.loads((out / "read_stats.json").read_text())["Read_depth"])
+    assert outs["takeover"] == outs["plain"]
+
+
+def test_tiny_and_long_reads_and_empty_files(tmp_path):
+    """Edges of the device feed through `gram _parse_check`: reads of a few bases (more records than a chunk's tables hold: the
+    host reader's), a read longer than a BGZF member (it spans three), a file that is only the EOF marker."""
+    rng = np.random.default_rng(8)
+    long_read = "".join("ACGT"[c] for c in rng.integers(0, 4, 150000))
+    recs = [f"@r{i}\n{'ACGT'[i % 4] * (1 + i % 3)}\n+\n{'I' * (1 + i % 3)}\n" for i in range(3000)]
+    for name, text in (("tiny", "".join(recs)), ("long", f"@a\nACGT\n+\nIIII\n@long\n{long_read}\n+\n{'I' * len(long_read)}\n@b\nGGCC\n+\nIIII\n")):
+        path = tmp_path / f"{name}.fastq.gz"
+        path.write_bytes(bgzf(text.encode(), block=60000))
+        out = _gram("_parse_check", str(path), "4", env={"GMX_PARSE_CHECK_DEVICE": "1"})
+        assert out.returncode == 0, out.stdout
+        lines = {l.split()[0]: l.split()[1:] for l in out.stdout.strip().splitlines() if l.split()[0] in ("fast", "slow", "device")}
+        assert lines["fast"] == lines["slow"], out.stdout
+        if lines["device"][0] not in ("declined", "failed"):
+            assert lines["device"] == lines["fast"], out.stdout
+    empty = tmp_path / "empty.fastq.gz"
+    empty.write_bytes(bgzf(b"", eof=True))
+    out = _gram("_parse_check", str(empty), "4", env={"GMX_PARSE_CHECK_DEVICE": "1"})
+    assert out.returncode == 0 and "device 0 0 " in out.stdout, out.stdout
