@@ -39,6 +39,10 @@ def test_engine_fails_loudly_without_gpu():
     with pytest.raises(GmxError) as e:
         Quasimapper(ix)
     assert e.value.code in (-2, -3)  # GMX_ENODEV / GMX_EHIP: no CPU fallback exists
+    from gramtools_amd import Ingest
+    with pytest.raises(GmxError) as e:  # the device-side reads decoder likewise: nothing is inflated or parsed on the host behind this API
+        Ingest(max_text_bytes=1 << 20)
+    assert e.value.code in (-2, -3)
 
 
 @pytest.mark.gpu
@@ -98,3 +102,12 @@ def test_two_bit_stream_packer_argument_checks():
     assert lib.gmx_pack_reads_2bit(None, offs.ctypes.data, 150, 3, out.ctypes.data, None, 1) == -1
     assert lib.gmx_map_reads_2bit_host(None, out.ctypes.data, None, 150, out.ctypes.data, None, 3) == -1
     assert lib.gmx_engine_seeds_in_place(None, 1) == -1
+    # the device-plane feed and the device-side reads decoder: argument checks come before any device call
+    assert lib.gmx_map_reads_packed_device(None, out.ctypes.data, None, 150, out.ctypes.data, None, 3) == -1
+    assert lib.gmx_ingest_reset(None) == -1 and lib.gmx_ingest_max_text(None) == 0
+    import ctypes as C
+    from gramtools_amd import _lib as L
+    res = L.IngestResult()
+    assert lib.gmx_ingest_wait(None, 0, C.byref(res)) == -1 and lib.gmx_ingest_submit_text(None, 0, None, 0, 1) == -1
+    h = C.c_void_p()
+    assert lib.gmx_ingest_create(0, 1000, C.byref(h)) == -1 and b"64 KB" in lib.gmx_last_error()   # GMX_EINVAL before the device is looked for
