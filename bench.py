@@ -740,7 +740,7 @@ def main():
         out["cli_end_to_end"] = cli_end_to_end(prg, raw[:n_cli], min(os.cpu_count() or 8, 64))
         # ---- the same reads as a BGZF FASTQ, decoded on the device ---------------------------------------------------
         try:
-            out["bgzf_device_feed"] = bgzf_device_feed(ix, raw[0], np.asarray(seeds))
+            out["bgzf_device_feed"] = bgzf_device_feed(ix, np.concatenate(raw[:3]) if len(raw) >= 3 else raw[0], master_seeds(42, [3 * n if len(raw) >= 3 else n]))  # (3 M reads: two full chunks and a part)
         except Exception as exc:  # a leg must not cost the headline
             out["bgzf_device_feed"] = {"error": repr(exc)[:300]}
         # ---- the other BASELINE configurations at full size (their own index, 1 M reads per step) ---------------------
