@@ -1424,7 +1424,7 @@ int run_genotype(const Args &a) {
   // offsets, seeds, sized for 150 bp reads in blocks of GMX_FASTQ_BLOCK bytes; other sizes are allocated when needed).
   // Freed right away, they wait in the library's cache of page-locked blocks.
   std::thread prewarm([&]() {
-    if (devices.size() == 1 && !getenv("GMX_HOST_GZ")) {  // a BGZF reads file: the device-side decoder's memory, now
+    if (!getenv("GMX_HOST_GZ")) {  // a BGZF reads file: the device-side decoder's memory, now (on the first device)
       for (const auto &smp : samples) {
         if (smp.reads.empty()) continue;
         unsigned char h[16] = {0};
@@ -1545,11 +1545,13 @@ int run_genotype(const Args &a) {
     // of the file takes draw file_base + i of the master stream, and the file uses up ceil(n / 5000) * 5000 draws
     uint64_t in_file = 0;
     const uint64_t file_base = seed_stream.base;
-    // A BGZF file is decoded on the GPU (one engine; GMX_HOST_GZ=1: on the host as before): compressed members up, reads
-    // found and packed in HBM, mapped where they lie. Should the device decoder give up on a chunk, the host reader below
-    // takes the file from its start and drops the reads already mapped.
+    // A BGZF file is decoded on the GPU (GMX_HOST_GZ=1: on the host as before): compressed members up, reads found and packed in
+    // HBM, mapped where they lie. Should the device decoder give up on a chunk, the host reader below takes the file from its
+    // start and drops the reads already mapped. With several engines the first one decodes AND maps such a file (its 100 M reads/s
+    // of decoding are what bounds the file — a twentieth of what the engine maps —, and the host path the other engines would be
+    // fed from inflates 32-48 M): the others add nothing until the exchange. (Decoding on every GPU: DESIGN.md §11, next.)
     uint64_t skip_reads = 0;
-    if (devices.size() == 1 && !getenv("GMX_HOST_GZ")) {
+    if (!getenv("GMX_HOST_GZ")) {
       static HostBuf<uint32_t> dev_seeds[2];
       uint64_t delivered = 0;
       const int rc = ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) {

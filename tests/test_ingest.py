@@ -300,15 +300,17 @@ def test_gram_genotype_bgzf_on_the_device_equals_plain(tmp_path):
     (tmp_path / "b.fq.gz").write_bytes(bgzf(b, block=9000))
     outs = {}
     for name, files, env in (("plain", ("a.fq", "b.fq"), {}), ("device", ("a.fq.gz", "b.fq.gz"), {"GMX_INGEST_MEMBERS": "3"}),
-                             ("host", ("a.fq.gz", "b.fq.gz"), {"GMX_HOST_GZ": "1"}), ("mixed", ("a.fq.gz", "b.fq"), {})):
+                             ("host", ("a.fq.gz", "b.fq.gz"), {"GMX_HOST_GZ": "1"}), ("mixed", ("a.fq.gz", "b.fq"), {}),
+                             ("two-engines", ("a.fq.gz", "b.fq"), {"DEVICES": "0,0"})):  # the first engine decodes and maps the BGZF file, both map the plain one
         out = tmp_path / name
+        extra = ["--devices", env.pop("DEVICES")] if "DEVICES" in env else []
         r = _gram("genotype", "--gram_dir", str(tmp_path), "--reads", *[str(tmp_path / f) for f in files], "--sample_id", "s", "--ploidy", "diploid",
-                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", env=env)
+                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", *extra, env=env)
         assert r.returncode == 0, r.stdout
         counters = [l for l in r.stdout.splitlines() if l.startswith("Count ")]
         outs[name] = ([(out / "coverage" / f).read_bytes() for f in ("allele_sum_coverage", "allele_base_coverage.json", "grouped_allele_counts_coverage.json")],
                       counters, json.loads((out / "read_stats.json").read_text())["Read_depth"])
-    for name in ("device", "host", "mixed"):
+    for name in ("device", "host", "mixed", "two-engines"):
         assert outs[name] == outs["plain"], name
 
 
