@@ -119,6 +119,9 @@ SYMBOLS = {
     "gmx_ingest_submit_bgzf": (C.c_int, [_vp, C.c_int, _vp, _u64, C.POINTER(BgzfMember), _u64, C.c_int]),
     "gmx_ingest_submit_text": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int]),
     "gmx_ingest_wait": (C.c_int, [_vp, C.c_int, C.POINTER(IngestResult)]),
+    "gmx_ingest_submit_bgzf_deferred": (C.c_int, [_vp, C.c_int, _vp, _u64, C.POINTER(BgzfMember), _u64]),
+    "gmx_ingest_scan": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int]),
+    "gmx_ingest_fetch_tail": (_i64, [_vp, C.c_int, _vp, _u64]),
     "gmx_ingest_release_after": (C.c_int, [_vp, C.c_int, _vp]),
     "gmx_ingest_fetch_text": (_i64, [_vp, C.c_int, _vp, _u64]),
     "gmx_ingest_fetch_reads": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),

@@ -716,8 +716,8 @@ gmx_inflate_kernel(const uint32_t *__restrict__ comp, const IngestMember *__rest
 // ------------------------------------------------------------------------------------------------------------------
 // starts a chunk: the incomplete last record of the chunk before (prev; null: a file's first chunk) in front of this one's text
 __global__ void gmx_carry_kernel(const IngestState *prev, const uint8_t *prev_text, IngestState *cur, uint8_t *cur_text, uint32_t members_text,
-                                 uint32_t final_chunk) {
-  uint32_t tail = 0;
+                                 uint32_t final_chunk, uint32_t host_tail) {
+  uint32_t tail = host_tail;  // (gmx_ingest_scan: the caller has put that many bytes in front of the chunk's text already)
   if (prev) {
     tail = prev->tail_len;
     if (tail > ING_CARRY_MAX) tail = 0;  // (reported below)
@@ -986,6 +986,8 @@ struct gmx_ingest {
     hipStream_t inflate_stream = nullptr;  // the slot's inflate kernel: beside the scan of the chunk before and the tail of its inflate kernel
     hipEvent_t copied = nullptr, done = nullptr, released = nullptr, inflated = nullptr, carried = nullptr;
     bool in_flight = false, has_release = false, has_carried = false;
+    bool deferred = false;       // gmx_ingest_submit_bgzf_deferred: inflate kernel enqueued, scan still to come (gmx_ingest_scan)
+    uint32_t deferred_text = 0;  // ... bytes of text of its members
   } slot[2];
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
   std::vector<void *> allocs;
@@ -1112,25 +1114,34 @@ int gmx_ingest_reset(gmx_ingest *g) {  // the next chunk starts a file: nothing 
 // a chunk's carry needs the state of the chunk before), the copy stream. Orderings that are not a stream's own:
 //   inflate(i) after the upload of chunk i, and after carry(i - 1): that kernel reads the END of chunk i - 2's text from this slot
 //   scan(i) after inflate(i); the slot's next upload / inflate / pack after whatever read its planes (gmx_ingest_release_after)
-static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int final_chunk, bool inflate, uint32_t n_members) {
+static int ing_enqueue_inflate(gmx_ingest *g, int si, uint32_t n_members) {
   gmx_ingest::Slot &s = g->slot[si];
-  const gmx_ingest::Slot *prev = g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
-  if (inflate) {
-    ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.copied, 0));
-    ING_TRY(hipMemsetAsync(&s.d_inflate_status->flags, 0, 4, s.inflate_stream));
-    ING_TRY(hipMemsetAsync(&s.d_inflate_status->bad_member, 0xFF, 4, s.inflate_stream));
-    if (n_members) {
-      if (g->d_dbg)
-        hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                           s.d_inflate_status, g->check_crc, g->d_dbg, g->exp_mode);
-      else
-        hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
-                           s.d_inflate_status, g->check_crc, g->d_dbg, 0u);
-    }
-    ING_TRY(hipEventRecord(s.inflated, s.inflate_stream));
+  ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.copied, 0));
+  ING_TRY(hipMemsetAsync(&s.d_inflate_status->flags, 0, 4, s.inflate_stream));
+  ING_TRY(hipMemsetAsync(&s.d_inflate_status->bad_member, 0xFF, 4, s.inflate_stream));
+  if (n_members) {
+    if (g->d_dbg)
+      hipLaunchKernelGGL(gmx_inflate_kernel<true>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                         s.d_inflate_status, g->check_crc, g->d_dbg, g->exp_mode);
+    else
+      hipLaunchKernelGGL(gmx_inflate_kernel<false>, dim3(n_members), dim3(64), 0, s.inflate_stream, s.d_comp, s.d_members, n_members, s.d_text + ING_CARRY_MAX,
+                         s.d_inflate_status, g->check_crc, g->d_dbg, 0u);
+  }
+  ING_TRY(hipGetLastError());
+  ING_TRY(hipEventRecord(s.inflated, s.inflate_stream));
+  return GMX_OK;
+}
+// host_tail = ~0: the cut record comes from the chunk before on this device (g->last_slot); else that many bytes lie in front of the text
+static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int final_chunk, bool inflate, uint32_t n_members, uint32_t host_tail = 0xFFFFFFFFu) {
+  gmx_ingest::Slot &s = g->slot[si];
+  const bool from_device = host_tail == 0xFFFFFFFFu;
+  const gmx_ingest::Slot *prev = from_device && g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
+  if (inflate && from_device) {
+    int rc = ing_enqueue_inflate(g, si, n_members);
+    if (rc) return rc;
   }
   hipLaunchKernelGGL(gmx_carry_kernel, dim3(64), dim3(256), 0, g->stream, prev ? prev->d_state : nullptr, prev ? prev->d_text : nullptr, s.d_state, s.d_text,
-                     members_text, (uint32_t)(final_chunk ? 1 : 0));
+                     members_text, (uint32_t)(final_chunk ? 1 : 0), from_device ? 0u : host_tail);
   ING_TRY(hipEventRecord(s.carried, g->stream));
   s.has_carried = true;
   ING_TRY(hipStreamWaitEvent(g->stream, inflate ? s.inflated : s.copied, 0));
@@ -1145,7 +1156,8 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
   ING_TRY(hipMemcpyAsync(s.h_state, s.d_state, sizeof(IngestState), hipMemcpyDeviceToHost, g->stream));
   ING_TRY(hipEventRecord(s.done, g->stream));
   s.in_flight = true;
-  g->last_slot = si;
+  s.deferred = false;
+  g->last_slot = from_device ? si : -1;  // (a chunk scanned with a host-provided start carries nothing on the device)
   return GMX_OK;
 }
 
@@ -1154,8 +1166,8 @@ static int ing_begin(gmx_ingest *g, int si, const char *who) {
     gmx_set_error(std::string(who) + ": null ingest or slot not 0 / 1");
     return GMX_EINVAL;
   }
-  if (g->slot[si].in_flight) {
-    gmx_set_error(std::string(who) + ": the slot's chunk before has not been waited for (gmx_ingest_wait)");
+  if (g->slot[si].in_flight || g->slot[si].deferred) {
+    gmx_set_error(std::string(who) + ": the slot's chunk before has not been waited for (gmx_ingest_wait), or still awaits its gmx_ingest_scan");
     return GMX_EINVAL;
   }
   if (g->last_slot == si) {
@@ -1222,6 +1234,74 @@ int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_
   if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX, text, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipEventRecord(s.copied, g->copy_stream));
   return ing_enqueue_scan(g, slot, (uint32_t)n_bytes, final_chunk, false, 0);
+}
+
+// Chunks dealt over several devices (one ingest per device): the cut record at a chunk's start lies on ANOTHER device, so a chunk
+// is uploaded and inflated at once (_deferred) and scanned (gmx_ingest_scan) when the caller has the end of the chunk before —
+// gmx_ingest_fetch_tail of that chunk's slot, on its device — which it hands over as host bytes.
+int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members, uint64_t n_members) {
+  if (g) g->last_slot = -1;  // (nothing is carried on the device in this mode: the slots need not alternate)
+  int rc = ing_begin(g, slot, "gmx_ingest_submit_bgzf_deferred");
+  if (rc) return rc;
+  if ((!compressed && n_bytes) || (!members && n_members) || n_bytes > g->max_comp || n_members > g->cap_members) {
+    gmx_set_error("gmx_ingest_submit_bgzf_deferred: null argument, or more compressed bytes / members than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  gmx_ingest::Slot &s = g->slot[slot];
+  uint64_t text = 0;
+  for (uint64_t i = 0; i < n_members; ++i) {
+    const gmx_bgzf_member &m = members[i];
+    if (m.offset + m.size > n_bytes || m.isize > (1u << 16)) {
+      gmx_set_error("gmx_ingest_submit_bgzf_deferred: member " + std::to_string(i) + " lies outside the bytes given, or holds more than 64 KB of text");
+      return GMX_EINVAL;
+    }
+    s.h_members[i] = IngestMember{(uint32_t)m.offset, (uint32_t)m.size, (uint32_t)text, m.isize, m.crc32, 0u};
+    text += m.isize;
+  }
+  if (text > g->max_text) {
+    gmx_set_error("gmx_ingest_submit_bgzf_deferred: the members hold more text than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_comp, compressed, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s.d_comp) + n_bytes, 0, 16, g->copy_stream));
+  if (n_members) ING_TRY(hipMemcpyAsync(s.d_members, s.h_members, n_members * sizeof(IngestMember), hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipEventRecord(s.copied, g->copy_stream));
+  rc = ing_enqueue_inflate(g, slot, (uint32_t)n_members);
+  if (rc) return rc;
+  s.deferred = true;
+  s.deferred_text = (uint32_t)text;
+  return GMX_OK;
+}
+
+int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk) {
+  if (!g || slot < 0 || slot > 1 || !g->slot[slot].deferred || (!carry && n_carry) || n_carry > ING_CARRY_MAX) {
+    gmx_set_error("gmx_ingest_scan: null ingest, slot without a gmx_ingest_submit_bgzf_deferred chunk, or more than 1 MB of carried text (a record that long is not FASTQ)");
+    return GMX_EINVAL;
+  }
+  ING_TRY(hipSetDevice(g->device));
+  gmx_ingest::Slot &s = g->slot[slot];
+  // the carried bytes right in front of the members' text (pageable memory: the copy is over when the call returns)
+  if (n_carry) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX - n_carry, carry, n_carry, hipMemcpyHostToDevice, g->stream));
+  return ing_enqueue_scan(g, slot, s.deferred_text, final_chunk, true, 0, (uint32_t)n_carry);
+}
+
+int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
+  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+    gmx_set_error("gmx_ingest_fetch_tail: null ingest, bad slot, or the slot's chunk is still in flight");
+    return GMX_EINVAL;
+  }
+  const IngestState &st = *g->slot[slot].h_state;
+  if (!out) return (int64_t)st.tail_len;
+  if (cap < st.tail_len) {
+    gmx_set_error("gmx_ingest_fetch_tail: buffer too small");
+    return GMX_EINVAL;
+  }
+  if (st.tail_len && (hipSetDevice(g->device) != hipSuccess ||
+                      hipMemcpy(out, g->slot[slot].d_text + st.consumed, st.tail_len, hipMemcpyDeviceToHost) != hipSuccess)) {
+    gmx_set_error("gmx_ingest_fetch_tail: hipMemcpy failed");
+    return GMX_EHIP;
+  }
+  return (int64_t)st.tail_len;
 }
 
 int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {

@@ -723,6 +723,29 @@ class Ingest:
         self._keep[slot] = (buf, arr)
         check(self.lib.gmx_ingest_submit_bgzf(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, len(members), 1 if final else 0))
 
+    def submit_bgzf_deferred(self, slot: int, data, members):
+        """Upload + inflate only (chunks dealt over several devices): gmx_ingest_scan follows when the end of the chunk before is known."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        arr = (_lib.BgzfMember * max(len(members), 1))()
+        for i, (off, size, isize, crc) in enumerate(members):
+            arr[i] = _lib.BgzfMember(off, size, isize, crc, 0)
+        self._keep[slot] = (buf, arr)
+        check(self.lib.gmx_ingest_submit_bgzf_deferred(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, len(members)))
+
+    def scan(self, slot: int, carry: bytes, final: bool):
+        c = np.frombuffer(carry, dtype=np.uint8) if carry else np.zeros(0, dtype=np.uint8)
+        check(self.lib.gmx_ingest_scan(self.h, slot, c.ctypes.data if c.size else None, c.size, 1 if final else 0))
+
+    def fetch_tail(self, slot: int) -> bytes:
+        n = self.lib.gmx_ingest_fetch_tail(self.h, slot, None, 0)
+        if n < 0:
+            check(int(n))
+        out = np.zeros(max(int(n), 1), dtype=np.uint8)
+        got = self.lib.gmx_ingest_fetch_tail(self.h, slot, out.ctypes.data, out.size)
+        if got < 0:
+            check(int(got))
+        return out[:int(n)].tobytes()
+
     def submit_text(self, slot: int, text, final: bool):
         buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
         self._keep[slot] = (buf,)

@@ -252,6 +252,15 @@ int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, u
                            uint64_t n_members, int final_chunk);
 int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes, int final_chunk);
 int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out);
+/* A file's chunks dealt over SEVERAL devices (one gmx_ingest each; SURVEY.md §8e: the path shards by chunk): the record cut by a
+ * chunk's end continues on another device, so the caller carries it through the host. _deferred uploads a chunk and enqueues its
+ * inflate kernel at once; gmx_ingest_scan enqueues the rest when the caller holds the end of the chunk before
+ * (gmx_ingest_fetch_tail of that chunk's slot after its gmx_ingest_wait; nothing for a file's first chunk), then gmx_ingest_wait as
+ * usual. Chunks are scanned in file order; their inflate kernels run ahead on all devices. */
+int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members,
+                                    uint64_t n_members);
+int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk);
+int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap); /* NULL out: its length */
 /* The slot's planes are read by work enqueued on hip_stream (the mapping call): its next submit waits for that work. */
 int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream);
 /* test hooks: the chunk's text (NULL out: its length), its reads in the host layout of gmx_map_reads_packed_host */

@@ -377,3 +377,40 @@ def test_tiny_and_long_reads_and_empty_files(tmp_path):
     empty.write_bytes(bgzf(b"", eof=True))
     out = _gram("_parse_check", str(empty), "4", env={"GMX_PARSE_CHECK_DEVICE": "1"})
     assert out.returncode == 0 and "device 0 0 " in out.stdout, out.stdout
+
+
+@pytest.mark.parametrize("n_dev,lo,hi", [(2, 150, 150), (3, 40, 200)])
+def test_chunks_dealt_over_several_ingests(n_dev, lo, hi):
+    """The several-GPU form of the device feed, on one GPU: one ingest per "device", the file's chunks dealt round, every chunk
+    inflated ahead (gmx_ingest_submit_bgzf_deferred) and scanned in file order with the cut record of the chunk before handed
+    over by the host (gmx_ingest_fetch_tail -> gmx_ingest_scan). The reads equal the host packer's, chunk by chunk."""
+    from gramtools_amd import Ingest, bgzf_members
+    rng = np.random.default_rng(n_dev * 31 + lo)
+    text, seqs = fastq(rng, 5000, lo, hi, bad_every=13)
+    data = bgzf(text, block=6007)
+    mem = bgzf_members(data)
+    step = 7
+    chunks = [mem[i:i + step] for i in range(0, len(mem), step)]
+    ings = [Ingest(max_text_bytes=1 << 20) for _ in range(n_dev)]
+
+    def submit(c):
+        ch = chunks[c]
+        lo_b, hi_b = ch[0][0], ch[-1][0] + ch[-1][1]
+        ings[c % n_dev].submit_bgzf_deferred((c // n_dev) & 1, data[lo_b:hi_b], [(o - lo_b, s, i, k) for o, s, i, k in ch])
+    for c in range(min(len(chunks), 2 * n_dev)):
+        submit(c)
+    got, tail = 0, b""
+    for c in range(len(chunks)):
+        ing, slot = ings[c % n_dev], (c // n_dev) & 1
+        ing.scan(slot, tail, c == len(chunks) - 1)
+        res = ing.wait(slot)
+        n = int(res.n_reads)
+        check_reads(ing, slot, res, seqs[got:got + n])
+        got += n
+        tail = ing.fetch_tail(slot)
+        assert len(tail) == res.tail_bytes
+        if c + 2 * n_dev < len(chunks):
+            submit(c + 2 * n_dev)
+    assert got == len(seqs) and tail == b""
+    for ing in ings:
+        ing.close()
