@@ -921,13 +921,14 @@ struct DeviceFeed {  // one per process: the ingest object and its page-locked s
     if (ing) gmx_ingest_destroy(ing);
   }
 };
-static DeviceFeed g_device_feed;
+static DeviceFeed g_device_feed;                             // the first (or only) engine's
+static std::vector<std::unique_ptr<DeviceFeed>> g_more_feeds;  // the other engines' (several GPUs: chunks dealt round)
 
 // the ingest object and its staging buffers ahead of the first BGZF file (called beside the index load: device memory for a
 // chunk and two page-locked buffers take 30 ms to come by)
 static bool hipSetDeviceForPrewarm(int) { return true; }  // (gmx_ingest_create selects the device itself)
-static void device_feed_prepare(int device, uint64_t want_text, uint64_t stage_bytes) {
-  DeviceFeed &df = g_device_feed;
+static void device_feed_prepare(int device, uint64_t want_text, uint64_t stage_bytes, DeviceFeed *which = nullptr) {
+  DeviceFeed &df = which ? *which : g_device_feed;
   if (!df.ing || df.max_text < want_text || df.device != device) {
     if (df.ing) gmx_ingest_destroy(df.ing);
     df.ing = nullptr;
@@ -1050,6 +1051,121 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     }
     on_chunk(res, (int)(ci & 1));
     *delivered += res.n_reads;
+  }
+  return 0;
+}
+
+// The same over SEVERAL engines (`--devices`): one ingest per engine, the file's chunks dealt round. Every chunk
+// is uploaded and inflated ahead (two per device in flight); the chunks are scanned in file order, each with the cut record of
+// the chunk before — which lies on another device — handed over through the host (a few hundred bytes). on_chunk(result, k, slot):
+// engine k's ingest holds the chunk's reads. Return values as ingest_bgzf_file.
+template <class OnChunk>
+int ingest_bgzf_file_dealt(const std::string &path, int threads, const std::vector<int> &devs, OnChunk on_chunk, uint64_t *delivered) {
+  *delivered = 0;
+  const size_t N = devs.size();
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return 1;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0 || sb.st_size < 28) {
+    close(fd);
+    return 1;
+  }
+  const size_t size = (size_t)sb.st_size;
+  void *mp = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_NORESERVE, fd, 0);
+  close(fd);
+  if (mp == MAP_FAILED) return 1;
+  const unsigned char *in = static_cast<const unsigned char *>(mp);
+  struct Unmap {
+    void *p;
+    size_t n;
+    ~Unmap() { munmap(p, n); }
+  } unmap{mp, size};
+  std::vector<gmx_bgzf_member> members;
+  members.reserve(size / 16000 + 16);
+  for (size_t at = 0; at < size;) {
+    gmx_bgzf_member m;
+    size_t next;
+    if (!bgzf_member_at(in, size, at, &m, &next)) return 1;
+    if (m.isize) members.push_back(m);
+    at = next;
+  }
+  const uint64_t kMembers = device_feed_members();
+  uint64_t file_text = 0;
+  for (const auto &m : members) file_text += m.isize;
+  while (g_more_feeds.size() + 1 < N) g_more_feeds.emplace_back(new DeviceFeed());
+  auto feed = [&](size_t k) -> DeviceFeed & { return k == 0 ? g_device_feed : *g_more_feeds[k - 1]; };
+  for (size_t k = 0; k < N; ++k) {
+    device_feed_prepare(devs[k], device_feed_text_for(file_text), 0, &feed(k));
+    if (!feed(k).ing) return 1;
+    GMX_CHECK(gmx_ingest_reset(feed(k).ing));
+  }
+  feed_trace("ingests of all engines ready");
+  const uint64_t max_text = gmx_ingest_max_text(feed(0).ing), max_comp = gmx_ingest_max_compressed(feed(0).ing);
+  struct Chunk {
+    size_t first, count, lo, hi;
+  };
+  std::vector<Chunk> chunks;
+  for (size_t i = 0; i < members.size();) {
+    Chunk c{i, 0, (size_t)members[i].offset, 0};
+    uint64_t text = 0;
+    while (i < members.size() && c.count < kMembers && text + members[i].isize <= max_text && members[i].offset + members[i].size - c.lo <= max_comp) {
+      text += members[i].isize;
+      c.hi = (size_t)(members[i].offset + members[i].size);
+      ++c.count;
+      ++i;
+    }
+    if (c.count == 0) return 1;
+    chunks.push_back(c);
+  }
+  if (chunks.empty()) return 0;
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  std::vector<gmx_bgzf_member> rel;
+  auto dev_of = [&](size_t ci) { return ci % N; };
+  auto slot_of = [&](size_t ci) { return (int)((ci / N) & 1); };
+  auto submit = [&](size_t ci) {  // upload + inflate; the scan follows when the chunk before has been scanned
+    const Chunk &c = chunks[ci];
+    HostBuf<uint8_t> &st = feed(dev_of(ci)).stage[slot_of(ci)];
+    const size_t n = c.hi - c.lo;
+    st.resize(n + 64);
+    parallel_for(T, [&](unsigned t) {
+      const size_t a = n * t / T, b = n * (t + 1) / T;
+      if (b > a) memcpy(st.data() + a, in + c.lo + a, b - a);
+    });
+    rel.assign(members.begin() + (long)c.first, members.begin() + (long)(c.first + c.count));
+    for (auto &m : rel) m.offset -= c.lo;
+    GMX_CHECK(gmx_ingest_submit_bgzf_deferred(feed(dev_of(ci)).ing, slot_of(ci), st.data(), n, rel.data(), rel.size()));
+    feed_trace("chunk submitted to its device (inflate)");
+  };
+  size_t submitted = 0;
+  for (; submitted < std::min(chunks.size(), 2 * N); ++submitted) submit(submitted);
+  std::vector<uint8_t> tail;
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    gmx_ingest *ing = feed(dev_of(ci)).ing;
+    GMX_CHECK(gmx_ingest_scan(ing, slot_of(ci), tail.data(), tail.size(), ci + 1 == chunks.size() ? 1 : 0));
+    gmx_ingest_result res;
+    GMX_CHECK(gmx_ingest_wait(ing, slot_of(ci), &res));
+    feed_trace("chunk scanned");
+    if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))
+      if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_BAD_MEMBER;
+    if (res.status) {
+      for (size_t cj = ci + 1; cj < submitted; ++cj) {  // (chunks inflating ahead: scanned with nothing and dropped, so that their slots are free again)
+        gmx_ingest_result drop;
+        GMX_CHECK(gmx_ingest_scan(feed(dev_of(cj)).ing, slot_of(cj), nullptr, 0, 0));
+        GMX_CHECK(gmx_ingest_wait(feed(dev_of(cj)).ing, slot_of(cj), &drop));
+      }
+      const bool decoder = (res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC | GMX_INGEST_TOO_MANY_LINES)) != 0;
+      if (!decoder) {
+        if (*delivered == 0) return 1;
+        die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(*delivered) +
+            " reads (multi-line or blank lines); decompress and reformat, or use a four-line FASTQ");
+      }
+      return *delivered == 0 && !(res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC)) ? 1 : 2;
+    }
+    tail.resize(res.tail_bytes);
+    if (res.tail_bytes && gmx_ingest_fetch_tail(ing, slot_of(ci), tail.data(), tail.size()) < 0) die(std::string("gram: ") + gmx_last_error());
+    on_chunk(res, dev_of(ci), slot_of(ci));
+    *delivered += res.n_reads;
+    if (submitted < chunks.size()) submit(submitted++);  // (its slot: chunk submitted - 2 N, waited for and handed on two rounds ago)
   }
   return 0;
 }
@@ -1547,40 +1663,49 @@ int run_genotype(const Args &a) {
     const uint64_t file_base = seed_stream.base;
     // A BGZF file is decoded on the GPU (GMX_HOST_GZ=1: on the host as before): compressed members up, reads found and packed in
     // HBM, mapped where they lie. Should the device decoder give up on a chunk, the host reader below takes the file from its
-    // start and drops the reads already mapped. With several engines the first one decodes AND maps such a file (its 100 M reads/s
-    // of decoding are what bounds the file — a twentieth of what the engine maps —, and the host path the other engines would be
-    // fed from inflates 32-48 M): the others add nothing until the exchange. (Decoding on every GPU: DESIGN.md §11, next.)
+    // start and drops the reads already mapped. With several engines the file's chunks are dealt round: every GPU decodes and maps
+    // its share (ingest_bgzf_file_dealt), the record a chunk's end cuts travels to the next GPU through the host.
     uint64_t skip_reads = 0;
     if (!getenv("GMX_HOST_GZ")) {
-      static HostBuf<uint32_t> dev_seeds[2];
+      static std::vector<std::unique_ptr<HostBuf<uint32_t>>> dev_seeds;  // per engine and slot
+      while (dev_seeds.size() < 2 * devices.size()) dev_seeds.emplace_back(new HostBuf<uint32_t>());
       uint64_t delivered = 0;
-      const int rc = ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) {
+      auto map_chunk = [&](const gmx_ingest_result &res, size_t k, int slot) {  // engine k's ingest holds the chunk's reads in its HBM
         const uint64_t n = res.n_reads;
         if (n == 0) return;
+        gmx_engine *ek = gmx_group_engine(grp, (int)k);
+        HostBuf<uint32_t> &sd = *dev_seeds[2 * k + (size_t)slot];
         // (the kernels read the few seeds they need in place: the buffer a slot used two chunks ago must be done with)
-        GMX_CHECK(gmx_engine_sync(eng));
-        dev_seeds[slot].resize(n);
-        seed_stream.copy(file_base + in_file, n, dev_seeds[slot].data());
+        GMX_CHECK(gmx_engine_sync(ek));
+        sd.resize(n);
+        seed_stream.copy(file_base + in_file, n, sd.data());
         if (res.uniform_len) {
-          GMX_CHECK(gmx_map_reads_packed_device(eng, res.d_planes, nullptr, res.uniform_len, dev_seeds[slot].data(), res.any_skip ? res.d_skip : nullptr, n));
+          GMX_CHECK(gmx_map_reads_packed_device(ek, res.d_planes, nullptr, res.uniform_len, sd.data(), res.any_skip ? res.d_skip : nullptr, n));
         } else {
           for (uint64_t r0 = 0, i = 0; r0 < n; r0 += 1u << 20, ++i) {
             const uint64_t m = std::min<uint64_t>(1u << 20, n - r0);
-            GMX_CHECK(gmx_map_reads_packed_device(eng, res.d_planes + res.sub_pairs[i], res.d_offsets + r0, 0, dev_seeds[slot].data() + r0,
+            GMX_CHECK(gmx_map_reads_packed_device(ek, res.d_planes + res.sub_pairs[i], res.d_offsets + r0, 0, sd.data() + r0,
                                                   res.any_skip ? res.d_skip + r0 : nullptr, m));
           }
         }
-        GMX_CHECK(gmx_ingest_release_after(g_device_feed.ing, slot, nullptr));
+        GMX_CHECK(gmx_ingest_release_after(k == 0 ? g_device_feed.ing : g_more_feeds[k - 1]->ing, slot, nullptr));
         in_file += n;
         total_reads += n;
-      }, &delivered);
+      };
+      // several engines: every one decodes and maps its share of the file's chunks (GMX_INGEST_ONE_DEVICE=1: the first one all of them)
+      const bool dealt = devices.size() > 1 && !getenv("GMX_INGEST_ONE_DEVICE");
+      const int rc = dealt ? ingest_bgzf_file_dealt(path, max_threads, devices, map_chunk, &delivered)
+                           : ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) { map_chunk(res, 0, slot); }, &delivered);
+      auto sync_all = [&]() {
+        for (int d = 0; d < (dealt ? gmx_group_size(grp) : 1); ++d) GMX_CHECK(gmx_engine_sync(gmx_group_engine(grp, d)));
+      };
       if (rc == 0) {
-        GMX_CHECK(gmx_engine_sync(eng));
+        sync_all();
         seed_stream.base = file_base + (in_file + kBatch - 1) / kBatch * kBatch;
         continue;
       }
       if (rc == 2) {
-        GMX_CHECK(gmx_engine_sync(eng));
+        sync_all();
         std::cerr << "warning: " << path << ": the device-side BGZF decoder gave up after " << delivered << " reads; the host reader takes over" << std::endl;
         skip_reads = delivered;
         in_file = 0;               // (the host reader counts the file's reads from its start again)

@@ -301,7 +301,9 @@ def test_gram_genotype_bgzf_on_the_device_equals_plain(tmp_path):
     outs = {}
     for name, files, env in (("plain", ("a.fq", "b.fq"), {}), ("device", ("a.fq.gz", "b.fq.gz"), {"GMX_INGEST_MEMBERS": "3"}),
                              ("host", ("a.fq.gz", "b.fq.gz"), {"GMX_HOST_GZ": "1"}), ("mixed", ("a.fq.gz", "b.fq"), {}),
-                             ("two-engines", ("a.fq.gz", "b.fq"), {"DEVICES": "0,0"})):  # the first engine decodes and maps the BGZF file, both map the plain one
+                             ("two-engines", ("a.fq.gz", "b.fq"), {"DEVICES": "0,0", "GMX_INGEST_MEMBERS": "2"}),   # chunks dealt over the engines' ingests
+                             ("three-engines", ("a.fq.gz", "b.fq.gz"), {"DEVICES": "0,0,0", "GMX_INGEST_MEMBERS": "1"}),
+                             ("first-engine-only", ("a.fq.gz", "b.fq"), {"DEVICES": "0,0", "GMX_INGEST_ONE_DEVICE": "1", "GMX_INGEST_MEMBERS": "2"})):
         out = tmp_path / name
         extra = ["--devices", env.pop("DEVICES")] if "DEVICES" in env else []
         r = _gram("genotype", "--gram_dir", str(tmp_path), "--reads", *[str(tmp_path / f) for f in files], "--sample_id", "s", "--ploidy", "diploid",
@@ -310,7 +312,7 @@ def test_gram_genotype_bgzf_on_the_device_equals_plain(tmp_path):
         counters = [l for l in r.stdout.splitlines() if l.startswith("Count ")]
         outs[name] = ([(out / "coverage" / f).read_bytes() for f in ("allele_sum_coverage", "allele_base_coverage.json", "grouped_allele_counts_coverage.json")],
                       counters, json.loads((out / "read_stats.json").read_text())["Read_depth"])
-    for name in ("device", "host", "mixed", "two-engines"):
+    for name in ("device", "host", "mixed", "two-engines", "three-engines", "first-engine-only"):
         assert outs[name] == outs["plain"], name
 
 
@@ -326,8 +328,8 @@ def test_gram_damaged_bgzf_is_fatal_on_the_device_path_too(tmp_path):
     assert out.returncode != 0, out.stdout
 
 
-@pytest.mark.parametrize("fail_chunk", ["0", "2"])
-def test_gram_host_reader_takes_over_where_the_device_decoder_gives_up(tmp_path, fail_chunk):
+@pytest.mark.parametrize("fail_chunk,devices", [("0", None), ("2", None), ("3", "0,0")])
+def test_gram_host_reader_takes_over_where_the_device_decoder_gives_up(tmp_path, fail_chunk, devices):
     """GMX_INGEST_TEST_FAIL_CHUNK: `gram genotype` treats that chunk as one the device decoder would not take. The host reader then
     reads the file from its start and drops the reads already mapped from the device feed — coverage files, counters and the
     seeds' assignment (a second file follows) must come out as for the plain text."""
@@ -348,7 +350,7 @@ def test_gram_host_reader_takes_over_where_the_device_decoder_gives_up(tmp_path,
                                                                                                 "GMX_FASTQ_BLOCK": "200000"})):
         out = tmp_path / name
         r = _gram("genotype", "--gram_dir", str(tmp_path), "--reads", *[str(tmp_path / f) for f in files], "--sample_id", "s", "--ploidy", "diploid",
-                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", env=env)
+                  "--kmer_size", "6", "--genotype_dir", str(out), "--seed", "1234", *(["--devices", devices] if devices and name == "takeover" else []), env=env)
         assert r.returncode == 0, r.stdout
         if name == "takeover":
             assert "the host reader takes over" in r.stdout

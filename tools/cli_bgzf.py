@@ -53,10 +53,13 @@ if __name__ == "__main__":
     print(f"{N} reads: {sum(t for _, t in parts) / 1e6:.0f} MB of text, {os.path.getsize(fq) / 1e6:.0f} MB of BGZF, written in {time.time() - t0:.0f} s", flush=True)
     subprocess.run([gram, "build", "--gram_dir", gram_dir, "--kmer_size", "10"], stdout=subprocess.DEVNULL)
     outs = {}
-    for name, env in (("device", {}), ("host", {"GMX_HOST_GZ": "1"}), ("device", {}), ("host", {"GMX_HOST_GZ": "1"})):
+    legs = [("device", {}), ("host", {"GMX_HOST_GZ": "1"}), ("device", {}), ("host", {"GMX_HOST_GZ": "1"})]
+    if os.environ.get("CLI_BGZF_DEVICES"):  # e.g. 0,0: two engines on one GPU, the file's chunks dealt over their ingests
+        legs += [("dealt", {}), ("dealt", {})]
+    for name, env in legs:
         out = os.path.join(tmp, "geno_" + name)
         cmd = [gram, "genotype", "--gram_dir", gram_dir, "--reads", fq, "--sample_id", "s", "--ploidy", "haploid", "--kmer_size", "10", "--genotype_dir", out,
-               "--max_threads", "16", "--seed", "42"]
+               "--max_threads", "16", "--seed", "42"] + (["--devices", os.environ["CLI_BGZF_DEVICES"]] if name == "dealt" else [])
         t0 = time.time()
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, GMX_PHASE_TRACE="1", **env))
         dt = time.time() - t0
@@ -66,10 +69,10 @@ if __name__ == "__main__":
         outs[name] = [open(os.path.join(out, "coverage", f), "rb").read() for f in ("allele_sum_coverage", "allele_base_coverage.json", "grouped_allele_counts_coverage.json")] + counts
         q = (t_map[1] - t_map[0]) / 1e3 if len(t_map) == 2 else float("nan")
         print(f"{name:7s} rc={p.returncode}  whole call {dt:.2f} s; reads decoded + mapped in {q:.3f} s = {N / q / 1e6:.1f} M reads/s  ({counts[-1] if counts else p.stdout[-300:]})", flush=True)
-    print("coverage files and counters identical:", outs["device"] == outs["host"])
+    print("coverage files and counters identical:", outs["device"] == outs["host"] and outs.get("dealt", outs["host"]) == outs["host"])
     if os.environ.get("CLI_BGZF_TRACE"):
         out = os.path.join(tmp, "geno_trace")
         cmd = [gram, "genotype", "--gram_dir", gram_dir, "--reads", fq, "--sample_id", "s", "--ploidy", "haploid", "--kmer_size", "10", "--genotype_dir", out,
-               "--max_threads", "16", "--seed", "42"]
+               "--max_threads", "16", "--seed", "42"] + (["--devices", os.environ["CLI_BGZF_DEVICES"]] if os.environ.get("CLI_BGZF_DEVICES") else [])
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, GMX_PHASE_TRACE="1", GMX_FEED_TRACE="1"))
         print("\n".join(l for l in p.stdout.splitlines() if l.startswith("[phase") or l.startswith("[feed")))
