@@ -89,31 +89,47 @@ struct IngestMember {
 #define ING_RING_MASK (ING_RING - 1u)
 #define ING_NEAR_MAX (ING_RING - 320u)  // distances up to this are served from the LDS window
 
-// table entry: bits 0-3 the bits it takes (0: no code here), bits 4-5 its type, and
-//   literals     bits 6-7 how many more than one (gmx ing_fuse: up to three literals whose codes fit the root bits together
-//                take ONE look-up), bits 8-31 the bytes, first one lowest
-//   length/dist  bits 8-11 extra bits, bits 12-27 base value
+// table entry (32 bits): bits 0-3 the bits its code takes (0: no code here), bit 31 ING_RARE, and
+//   literals     (literal/length table) bits 6-7 how many (ing_fuse: up to three literals whose codes fit the root bits together
+//                take ONE look-up; 0: the entry that does nothing), bits 8-31 the bytes, first one lowest; bits 4-5 clear
+//   length       (literal/length table) bit 5 (ING_LENGTH), bits 6-14 base value, bits 16-18 extra bits, bits 23-27 code + extra
+//                bits: the entry itself is the operand of s_bfe_u32 that takes the extra bits out of the stream (offset = bits
+//                0-4, width = bits 16-22), and one shift drops code and extra bits together
+//   distance     (distance table) bit 4, bits 8-11 extra bits, bits 12-27 base value
 //   code length  bits 8-12 the symbol
+//   ING_RARE     bits 4-5 say which: ING_T_EOB, ING_T_LONG (a code longer than the table's bits), else no code
 #define ING_T_LIT 0u
 #define ING_T_BASE 1u
 #define ING_T_EOB 2u
 #define ING_T_LONG 3u
-#define ING_TYPE(e) (((e) >> 4) & 3u)
+#define ING_TYPE(e) (((e) >> 4) & 3u)  // of an ING_RARE entry
+#define ING_LENGTH 32u
+#define ING_IS_LIT(e) (((e) & (ING_RARE | 48u)) == 0)
 #define ING_RARE 0x80000000u  // set in every entry that is not a literal or a length / distance base: no code, end of block, longer code
                                // (a third fused literal is below 0x80, so that its byte does not reach the bit)
 
-struct WaveLds {
+struct WaveLds {  // 8 KB: twenty wavefronts per CU
   uint32_t lit[1u << ING_LIT_ROOT];    // literal/length codes of up to ING_LIT_ROOT bits, by the next bits of the stream (4 KB); the CRC table afterwards
-  uint32_t dist[1u << ING_DIST_ROOT];  // distance codes (1 KB); the code-length code while a dynamic block's lengths are read
-  alignas(16) uint8_t ring[ING_RING];  // the last 4 KB of the member's text
+  uint64_t dist[1u << ING_DIST_ROOT];  // distance codes (1 KB, entries of two words); as 32-bit entries the code-length code while a dynamic block's lengths are read
+  alignas(16) uint8_t ring[ING_RING];  // the last 2 KB of the member's text
   uint16_t lit_sorted[288];            // symbols by (code length, symbol): codes longer than the root are decoded bit by bit
   uint16_t dist_sorted[32];
-  uint32_t lit_count[16], dist_count[16];
-  uint8_t lens[320];
-  uint8_t dummy[64];                   // where a lane with nothing to write writes: the symbol loop has no lane-divergent branch
+  uint16_t lit_count[16], dist_count[16];
+  union {
+    uint8_t lens[320];                 // code lengths of the block being set up
+    uint8_t dummy[64];                 // in the symbol loop (lens[] is dead then): where a lane with nothing to write writes, no lane-divergent branch
+  };
 };
+static_assert(sizeof(WaveLds) <= 8192, "twenty wavefronts per CU");
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// bits [offset, offset + width) of v, offset = op bits 0-4, width = op bits 16-22 (the other bits of op are ignored): one scalar
+// instruction where shift-and-mask by run-time amounts takes three
+__device__ __forceinline__ uint32_t ing_sbfe(uint32_t v, uint32_t op) {
+  uint32_t r;
+  asm("s_bfe_u32 %0, %1, %2" : "=s"(r) : "s"(v), "s"(op) : "scc");
+  return r;
+}
 
 
 // The bit reader. Everything but `cur` is wave-uniform. The compressed words are fetched 64 at a time, one per lane (a
@@ -168,7 +184,7 @@ struct Bits {
 // what a symbol of one of the three codes stands for, as a table entry of `len` bits
 __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len) {
   if (kind == 0) {  // literal / length (RFC 1951 §3.2.5)
-    if (s < 256u) return len | (ING_T_LIT << 4) | (s << 8);
+    if (s < 256u) return len | (1u << 6) | (s << 8);
     if (s == 256u) return len | (ING_T_EOB << 4) | ING_RARE;
     if (s > 285u) return ING_RARE;
     const uint32_t t = s - 257u;
@@ -183,30 +199,36 @@ __device__ __forceinline__ uint32_t ing_entry(int kind, uint32_t s, uint32_t len
       extra = (t - 4u) >> 2;
       base = 3u + ((4u + (t & 3u)) << extra);
     }
-    return len | (ING_T_BASE << 4) | (extra << 8) | (base << 12);
-  }
-  if (kind == 1) {  // distance
-    if (s > 29u) return ING_RARE;
-    uint32_t base, extra;
-    if (s < 4u) {
-      base = 1u + s;
-      extra = 0;
-    } else {
-      extra = (s - 2u) >> 1;
-      base = 1u + ((2u + (s & 1u)) << extra);
-    }
-    return len | (ING_T_BASE << 4) | (extra << 8) | (base << 12);
+    return len | ING_LENGTH | (base << 6) | (extra << 16) | ((len + extra) << 23);
   }
   return len | (ING_T_LIT << 4) | (s << 8);  // code-length code: the symbol itself
+}
+
+// distance symbol s as a table entry of `len` bits: low word = bits 0-3 len, bits 16-19 extra bits, bits 23-27 len + extra bits
+// (the word is the s_bfe_u32 operand that takes the extra bits out of the stream); high word = base value. s > 29: ING_RARE
+__device__ __forceinline__ uint64_t ing_dist_entry(uint32_t s, uint32_t len) {
+  if (s > 29u) return ING_RARE;
+  uint32_t base, extra;
+  if (s < 4u) {
+    base = 1u + s;
+    extra = 0;
+  } else {
+    extra = (s - 2u) >> 1;
+    base = 1u + ((2u + (s & 1u)) << extra);
+  }
+  return ((uint64_t)base << 32) | len | (extra << 16) | ((len + extra) << 23);
 }
 
 // Canonical Huffman code of lens[0, n) (RFC 1951 §3.2.2) -> look-up table of `root` bits + the sorted symbols and the
 // counts per length for the bit-by-bit path. The wave works on 64 symbols at a time; a symbol's rank among those of its
 // length comes from ballots. Returns false on an over-subscribed set of lengths.
-__device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint32_t *count, int kind) {
+__device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_t n, uint32_t *tab, uint32_t root, uint16_t *sorted, uint16_t *count, int kind) {
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long lt = (1ull << lane) - 1ull;
-  for (uint32_t i = lane; i < (1u << root); i += 64u) tab[i] = ING_RARE;
+  uint64_t *const tab2 = reinterpret_cast<uint64_t *>(tab);  // kind 1: the distance table's entries have two words
+  for (uint32_t i = lane; i < (1u << root); i += 64u) {
+    if (kind == 1) tab2[i] = ING_RARE; else tab[i] = ING_RARE;
+  }
   uint32_t cnt[16];
 #pragma unroll
   for (int L = 0; L < 16; ++L) cnt[L] = 0;
@@ -236,7 +258,7 @@ __device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_
   }
   if (lane == 0) {
 #pragma unroll
-    for (int L = 0; L < 16; ++L) count[L] = cnt[L];
+    for (int L = 0; L < 16; ++L) count[L] = (uint16_t)cnt[L];
     count[0] = 0;
   }
   __syncthreads();  // (the zeroed table before the entries)
@@ -258,8 +280,15 @@ __device__ __attribute__((noinline)) bool ing_build(const uint8_t *lens, uint32_
       const uint32_t code = my_first + (my_at - my_offs);
       const uint32_t rev = __builtin_bitreverse32(code) >> (32u - l);
       if (l <= root) {
-        const uint32_t e = ing_entry(kind, s, l);
-        for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab[j] = e;
+        if (kind == 1) {
+          const uint64_t e = ing_dist_entry(s, l);
+          for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab2[j] = e;
+        } else {
+          const uint32_t e = ing_entry(kind, s, l);
+          for (uint32_t j = rev; j < (1u << root); j += 1u << l) tab[j] = e;
+        }
+      } else if (kind == 1) {
+        tab2[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 4) | ING_RARE;
       } else {
         tab[rev & ((1u << root) - 1u)] = 15u | (ING_T_LONG << 4) | ING_RARE;
       }
@@ -279,14 +308,14 @@ __device__ __attribute__((noinline)) void ing_fuse(uint32_t *tab, uint32_t root)
     const uint32_t i = (uint32_t)c * 64u + lane;
     uint32_t e = tab[i];
     uint32_t l = e & 15u;
-    if (l != 0 && ING_TYPE(e) == ING_T_LIT && l < root) {
+    if (l != 0 && ING_IS_LIT(e) && l < root) {
       const uint32_t e2 = tab[i >> l], l2 = e2 & 15u;
-      if (l2 != 0 && ING_TYPE(e2) == ING_T_LIT && l + l2 <= root) {
-        e = (l + l2) | (1u << 6) | (e & 0xFF00u) | ((e2 & 0xFF00u) << 8);
+      if (l2 != 0 && ING_IS_LIT(e2) && l + l2 <= root) {
+        e = (l + l2) | (2u << 6) | (e & 0xFF00u) | ((e2 & 0xFF00u) << 8);
         l += l2;
         if (l < root) {
           const uint32_t e3 = tab[i >> l], l3 = e3 & 15u;
-          if (l3 != 0 && ING_TYPE(e3) == ING_T_LIT && l + l3 <= root && (e3 & 0x8000u) == 0) e = (l + l3) | (2u << 6) | (e & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
+          if (l3 != 0 && ING_IS_LIT(e3) && l + l3 <= root && (e3 & 0x8000u) == 0) e = (l + l3) | (3u << 6) | (e & 0xFFFF00u) | ((e3 & 0xFF00u) << 16);
         }
       }
     }
@@ -297,7 +326,7 @@ __device__ __attribute__((noinline)) void ing_fuse(uint32_t *tab, uint32_t root)
 
 // a code longer than the table's root: bit by bit against the canonical code's first code of every length. Out of line and
 // by value (the symbol loop stays small): returns symbol | bits taken << 16, or ~0 when no code matches.
-__device__ __attribute__((noinline)) uint32_t ing_decode_slow(uint64_t buf, const uint32_t *count, const uint16_t *sorted) {
+__device__ __attribute__((noinline)) uint32_t ing_decode_slow(uint64_t buf, const uint16_t *count, const uint16_t *sorted) {
   uint32_t code = 0, first = 0, index = 0;
   for (uint32_t len = 1; len <= 15u; ++len) {
     code |= (uint32_t)(buf >> (len - 1u)) & 1u;
@@ -309,6 +338,31 @@ __device__ __attribute__((noinline)) uint32_t ing_decode_slow(uint64_t buf, cons
     code <<= 1;
   }
   return 0xFFFFFFFFu;
+}
+
+// What the symbol loop does with a table entry that has ING_RARE set (e: its low word), out of line and with ONE result.
+// Low word: bits 0-7 bits to drop now, bits 8-9 the loop's `stop` (1 damaged, 2 the block's end). High word, literal/length
+// table (kind 0): the entry the loop goes on with — the symbol's, as an entry of ONE bit (the code's other bits are the ones
+// to drop now), or when stopping the entry that does nothing; distance table (kind 1): the distance itself, extra bits
+// included (all of its bits are dropped now), 1 when stopping.
+__device__ __attribute__((noinline)) uint64_t ing_rare(int kind, uint32_t e, uint64_t buf, const uint16_t *count, const uint16_t *sorted) {
+  const uint64_t nop = (uint64_t)(kind == 0 ? 0u : 1u) << 32;
+  const uint64_t bad = nop | (1u << 8);
+  if ((e & 15u) == 0) return bad;                                             // no code here
+  if (ING_TYPE(e) == ING_T_EOB) return nop | (2u << 8) | (e & 15u);             // the end of the block, from the table
+  const uint32_t r = ing_decode_slow(buf, count, sorted);                     // a code longer than the table's bits
+  if (r == 0xFFFFFFFFu) return bad;
+  const uint32_t sym = r & 0xFFFFu, bits = r >> 16;
+  if (kind == 1) {
+    const uint64_t de = ing_dist_entry(sym, bits);
+    if ((uint32_t)de & ING_RARE) return bad;
+    const uint32_t extra = ((uint32_t)de >> 16) & 15u;
+    const uint32_t dist = (uint32_t)(de >> 32) + ((uint32_t)(buf >> bits) & ((1u << extra) - 1u));
+    return ((uint64_t)dist << 32) | (bits + extra);
+  }
+  const uint32_t e1 = ing_entry(0, sym, 1);
+  if (e1 & ING_RARE) return (e1 & 15u) != 0 && ING_TYPE(e1) == ING_T_EOB ? nop | (2u << 8) | bits : bad;
+  return ((uint64_t)e1 << 32) | (bits - 1u);
 }
 
 // CRC-32 (IEEE, reflected) as polynomial arithmetic: a * b mod P, and x^n mod P (zlib's crc32_combine does the same)
@@ -346,6 +400,17 @@ __device__ __forceinline__ uint8_t ing_load_coherent(const ing_g8 *p) {  // text
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// [lo, hi) within one KB of the window -> memory; the member's first and last pieces: a neighbour owns the rest of a 16-byte piece
+__device__ __attribute__((noinline)) void ing_flush_partial(const uint8_t *ring, ing_g8 *al, uint32_t lo, uint32_t hi) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t cs = (lo & ~1023u) + 16u * lane, ce = cs + 16u;
+  if (cs >= lo && ce <= hi) {
+    *(ing_g128 *)(al + cs) = *reinterpret_cast<const ing_v4 *>(&ring[cs & ING_RING_MASK]);
+  } else if (ce > lo && cs < hi) {
+    for (uint32_t i = max(cs, lo); i < min(ce, hi); ++i) al[i] = ring[i & ING_RING_MASK];
+  }
+}
+
 // One wavefront per member: its text goes to text[out_off, out_off + isize).
 template <bool STATS>
 __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *__restrict__ comp, const IngestMember *__restrict__ members, uint32_t n_members,
@@ -374,14 +439,9 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
   // The symbol loop below has only wave-uniform branches: a lane with nothing to do writes its byte to L.dummy instead of
   // sitting out a branch. (With lane-divergent branches and loops inside it the compiler restructured the whole loop around
   // flag registers: some 170 instruction slots per table look-up — and one wave issues an instruction every four clocks.)
-  auto flush_partial = [&](uint32_t lo, uint32_t hi) {  // within one KB; the member's first and last pieces: a neighbour owns the rest of a 16-byte piece
-    const uint32_t cs = (lo & ~1023u) + 16u * lane, ce = cs + 16u;
-    if (cs >= lo && ce <= hi) {
-      *(ing_g128 *)(al + cs) = *reinterpret_cast<const ing_v4 *>(&L.ring[cs & ING_RING_MASK]);
-    } else if (ce > lo && cs < hi) {
-      for (uint32_t i = max(cs, lo); i < min(ce, hi); ++i) al[i] = L.ring[i & ING_RING_MASK];
-    }
-  };
+  // (out of line: its branches are lane-divergent, and one divergent branch inside the symbol loop makes the compiler restructure
+  // the whole loop around flag registers; with none the loop's wave-uniform branches stay plain scalar branches)
+  auto flush_partial = [&](uint32_t lo, uint32_t hi) { ing_flush_partial(L.ring, al, lo, hi); };
   auto flush_to = [&](uint32_t upto) {  // [flushed, upto), upto a multiple of 1024
     if (xm & 4u) {
       flushed = upto;
@@ -395,39 +455,42 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
     for (; blk < upto; blk += 1024u) *(ing_g128 *)(al + blk + 16u * lane) = *reinterpret_cast<const ing_v4 *>(&L.ring[(blk + 16u * lane) & ING_RING_MASK]);
     flushed = upto;
   };
-  // bytes [out_pos, out_pos + len) = the len bytes starting dist back (RFC 1951 §3.2.3: may overlap what it writes)
+  // bytes [out_pos, out_pos + len) = the len bytes starting dist back (RFC 1951 §3.2.3: may overlap what it writes); len >= 3.
+  // Three loops that run at least once, so that the choice between them is two plain branches.
   auto copy_match = [&](uint32_t len, uint32_t dist) {
     if (xm & 1u) {
       out_pos += len;
       if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
       return;
     }
-    if (dist <= ING_NEAR_MAX || (xm & 2u)) {  // from the window
-      if (dist >= len) {
-        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
-          const uint32_t i = i0 + lane;
-          const uint8_t v = L.ring[(out_pos - dist + i) & ING_RING_MASK];
-          uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
-          *dst = v;
-        }
-      } else {  // the copy overlaps what it writes: byte i repeats byte i mod dist
-        for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
-          const uint32_t i = i0 + lane;
-          const uint8_t v = L.ring[(out_pos - dist + i % dist) & ING_RING_MASK];
-          uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
-          *dst = v;
-        }
-      }
-    } else {  // beyond the window: from the KBs already flushed (dist > 3776: every byte read lies below `flushed`, for the idle lanes too)
-      for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
+    uint32_t i0 = 0;
+    if (dist > ING_NEAR_MAX && !(xm & 2u)) {  // beyond the window: from the KBs already flushed (dist > 1 728: every byte read lies below `flushed`, for the idle lanes too)
+      do {
         const uint32_t i = i0 + lane;
         const uint8_t v = ing_load_coherent(al + (out_pos - dist + i));
         uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
         *dst = v;
-      }
+        i0 += 64u;
+      } while (i0 < len);
+    } else if (dist >= len) {  // from the window
+      do {
+        const uint32_t i = i0 + lane;
+        const uint8_t v = L.ring[(out_pos - dist + i) & ING_RING_MASK];
+        uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
+        *dst = v;
+        i0 += 64u;
+      } while (i0 < len);
+    } else {  // the copy overlaps what it writes: byte i repeats byte i mod dist
+      do {
+        const uint32_t i = i0 + lane;
+        const uint8_t v = L.ring[(out_pos - dist + i % dist) & ING_RING_MASK];
+        uint8_t *dst = i < len ? &L.ring[(out_pos + i) & ING_RING_MASK] : &L.dummy[lane];
+        *dst = v;
+        i0 += 64u;
+      } while (i0 < len);
     }
     out_pos += len;
-    if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
+    if (__builtin_expect((out_pos & ~1023u) > flushed, 0)) flush_to(out_pos & ~1023u);
   };
   for (bool last = false; !last && !err;) {
     bs.refill();
@@ -451,7 +514,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
       const uint8_t *src = reinterpret_cast<const uint8_t *>(comp) + from;
       for (uint32_t i0 = 0; i0 < len; i0 += 64u) {
         const uint32_t n = min(64u, len - i0);
-        if (lane < n) L.ring[(out_pos + lane) & ING_RING_MASK] = src[i0 + lane];
+        *(lane < n ? &L.ring[(out_pos + lane) & ING_RING_MASK] : &L.dummy[lane]) = src[i0 + min(lane, n - 1u)];
         out_pos += n;
         if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
       }
@@ -463,34 +526,41 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
       break;
     }
     if (btype == 1) {  // fixed codes (§3.2.6)
-      for (uint32_t s = lane; s < 288u; s += 64u) L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+      for (uint32_t s0 = 0; s0 < 320u; s0 += 64u) {  // (lens[] has 320 entries; no lane-divergent branch inside the block loop, see the symbol loop)
+        const uint32_t s = s0 + lane;
+        L.lens[s] = s < 144u ? 8 : s < 256u ? 9 : s < 280u ? 7 : 8;
+      }
       __syncthreads();
       bool ok = uni(ing_build(L.lens, 288, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0)) != 0;
-      if (lane < 32) L.lens[lane] = 5;
+      L.lens[lane] = 5;  // (32 distance codes; the lanes above write lengths nobody reads)
       __syncthreads();
-      ok = uni(ing_build(L.lens, 32, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
+      ok = uni(ing_build(L.lens, 32, reinterpret_cast<uint32_t *>(L.dist), ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
       if (!ok) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
     } else {  // dynamic codes (§3.2.7)
+      // (while the lengths are read a lane with nothing to write writes into lit_sorted[]: the block before is done with it, this one
+      // fills it when its lengths are complete; dummy[] shares its bytes with lens[])
+      uint8_t *const hdr_dummy = reinterpret_cast<uint8_t *>(L.lit_sorted) + lane;
       const uint32_t hlit = bs.take(5) + 257u, hdist = bs.take(5) + 1u, hclen = bs.take(4) + 4u;
       if (hlit > 286u || hdist > 30u) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
-      if (lane < 19) L.lens[lane] = 0;
+      *(lane < 19u ? &L.lens[lane] : hdr_dummy) = 0;
       __syncthreads();
       for (uint32_t i = 0; i < hclen; ++i) {
         bs.refill();
         const uint32_t v = bs.take(3);
         // order of the code-length code's lengths: 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
         const uint32_t sym = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1) + 0u;
-        if (lane == 0) L.lens[sym] = (uint8_t)v;
+        *(lane == 0 ? &L.lens[sym] : hdr_dummy) = (uint8_t)v;
       }
       __syncthreads();
       // (the code-length code's table borrows the distance table: root 7, every code at most 7 bits)
-      if (!uni(ing_build(L.lens, 19, L.dist, 7, L.dist_sorted, L.dist_count, 2))) {
+      uint32_t *const cl_tab = reinterpret_cast<uint32_t *>(L.dist);
+      if (!uni(ing_build(L.lens, 19, cl_tab, 7, L.dist_sorted, L.dist_count, 2))) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
@@ -498,7 +568,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
       uint32_t at = 0, prev = 0;
       while (at < total && !err) {
         bs.refill();
-        const uint32_t e = uni(L.dist[bs.peek(7)]);
+        const uint32_t e = uni(cl_tab[bs.peek(7)]);
         if ((e & 15u) == 0) {
           err = GMX_INGEST_BAD_MEMBER;
           break;
@@ -524,19 +594,19 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
           err = GMX_INGEST_BAD_MEMBER;
           break;
         }
-        for (uint32_t i = lane; i < rep; i += 64u) L.lens[at + i] = (uint8_t)val;  // (lens[0, 19) held the code-length code's lengths: its table is built)
+        for (uint32_t i0 = 0; i0 < rep; i0 += 64u) *(i0 + lane < rep ? &L.lens[at + i0 + lane] : hdr_dummy) = (uint8_t)val;  // (lens[0, 19) held the code-length code's lengths: its table is built)
         at += rep;
         prev = val;
       }
       if (err) break;
-      for (uint32_t i = total + lane; i < 320u; i += 64u) L.lens[i] = 0;
+      for (uint32_t i0 = total; i0 < 320u; i0 += 64u) *(i0 + lane < 320u ? &L.lens[i0 + lane] : hdr_dummy) = 0;
       __syncthreads();
       if (uni(L.lens[256]) == 0) {  // no end-of-block code
         err = GMX_INGEST_BAD_MEMBER;
         break;
       }
       bool ok = uni(ing_build(L.lens, hlit, L.lit, ING_LIT_ROOT, L.lit_sorted, L.lit_count, 0)) != 0;
-      ok = uni(ing_build(L.lens + hlit, hdist, L.dist, ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
+      ok = uni(ing_build(L.lens + hlit, hdist, reinterpret_cast<uint32_t *>(L.dist), ING_DIST_ROOT, L.dist_sorted, L.dist_count, 1)) != 0 && ok;
       if (!ok) {
         err = GMX_INGEST_BAD_MEMBER;
         break;
@@ -545,77 +615,71 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
     ing_fuse(L.lit, ING_LIT_ROOT);
     if (STATS) t_build += clock64() - t_b0;
     // ---- the block's symbols ----
-    // what an entry that is a literal run or a length stands for (its bits already dropped); false: the member is damaged.
-    // (Inlined at both of its call sites: merged behind the rare path the common path carried that path's flag registers.)
-    auto process = [&](uint32_t e) __attribute__((always_inline)) -> bool {
-      if ((e & 16u) == 0) {  // a literal entry (type bit 0 clear): one to three literals
-        const uint32_t n_lit = ((e >> 6) & 3u) + 1u;
-        if (out_pos + n_lit > end_v) return false;
-        uint8_t *dst = lane < n_lit ? &L.ring[(out_pos + lane) & ING_RING_MASK] : &L.dummy[lane];
-        *dst = (uint8_t)(e >> (8u + 8u * (lane & 3u)));
-        out_pos += n_lit;
-        if (STATS) n_lit_total += n_lit;
-        if ((out_pos & ~1023u) > flushed) flush_to(out_pos & ~1023u);
-        return true;
-      }
-      const uint32_t len = ((e >> 12) & 0xFFFFu) + bs.take((e >> 8) & 15u);
-      bs.refill();
-      uint32_t d = uni(L.dist[bs.peek(ING_DIST_ROOT)]);
-      if ((int32_t)d < 0) {  // rare (ING_RARE)
-        const uint32_t r = (d & 15u) == 0 ? 0xFFFFFFFFu : uni(ing_decode_slow(bs.buf, L.dist_count, L.dist_sorted));
-        d = r == 0xFFFFFFFFu ? ING_RARE : ing_entry(1, r & 0xFFFFu, 1);
-        if ((d & 15u) == 0) return false;
-        bs.drop(r >> 16);
+    // The decoder is bound by the scalar instructions it issues (see below the function), so the loop is written the way the
+    // compiler's control-flow passes leave alone: properly nested if / else, ONE way out at the bottom (`stop`, kept from the
+    // optimizer so that it does not thread the rare cases to the code behind the loop), the rare cases out of line with one
+    // result, nothing lane-divergent. As lambdas with early returns it carried its exits as a guard value and flag registers set
+    // and tested on every path: 87 scalar instructions per match; this form takes 60-odd.
+    {
+      uint32_t stop = 0;  // 1: the member is damaged, 2: the block's end
+      do {
         bs.refill();
-      } else {
-        bs.drop(d & 15u);
-      }
-      const uint32_t dist = ((d >> 12) & 0xFFFFu) + bs.take((d >> 8) & 15u);
-      if (dist > out_pos - mis || out_pos + len > end_v) return false;
-      if (STATS) {
-        ++n_match;
-        n_mbytes += len;
-        if (dist > ING_NEAR_MAX) ++n_far;
-      }
-      const long long t_c0 = STATS ? clock64() : 0;
-      copy_match(len, dist);
-      if (STATS) t_copy += clock64() - t_c0;
-      return true;
-    };
-    for (;;) {
-      bs.refill();
-      const uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
-      if (STATS) ++n_look;
-      if ((int32_t)e >= 0) {  // a literal run or a length
-        bs.drop(e & 15u);
-        if (!process(e)) {
-          err = GMX_INGEST_BAD_MEMBER;
-          break;
+        uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
+        if (STATS) ++n_look;
+        if (__builtin_expect((int32_t)e < 0, 0)) {  // ING_RARE: no code here, the end of the block, or a code longer than the table's bits
+          if (STATS) ++n_slow;
+          const uint64_t rr = ing_rare(0, e, bs.buf, L.lit_count, L.lit_sorted);
+          const uint32_t r_lo = uni((uint32_t)rr);
+          bs.drop(r_lo & 0xFFu);
+          stop = r_lo >> 8;
+          e = uni((uint32_t)(rr >> 32));  // (when stopping: the entry that does nothing)
         }
-        continue;
-      }
-      // rare (ING_RARE): no code here, the end of the block, or a code longer than the table's bits
-      if ((e & 15u) == 0) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
-      if (ING_TYPE(e) == ING_T_EOB) {
-        bs.drop(e & 15u);
-        break;
-      }
-      if (STATS) ++n_slow;
-      const uint32_t r = uni(ing_decode_slow(bs.buf, L.lit_count, L.lit_sorted));
-      const uint32_t e2 = r == 0xFFFFFFFFu ? ING_RARE : ing_entry(0, r & 0xFFFFu, 1);
-      if ((e2 & 15u) == 0) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
-      bs.drop(r >> 16);
-      if (ING_TYPE(e2) == ING_T_EOB) break;
-      if (!process(e2)) {
-        err = GMX_INGEST_BAD_MEMBER;
-        break;
-      }
+        if ((e & ING_LENGTH) == 0) {  // one to three literals (or none)
+          const uint32_t n_lit = (e >> 6) & 3u;
+          bs.drop(e & 15u);
+          if (__builtin_expect(out_pos + n_lit > end_v, 0)) {
+            stop = 1u;
+          } else {
+            uint8_t *dst = lane < n_lit ? &L.ring[(out_pos + lane) & ING_RING_MASK] : &L.dummy[lane];
+            *dst = (uint8_t)(e >> (8u + 8u * (lane & 3u)));
+            out_pos += n_lit;
+            if (STATS) n_lit_total += n_lit;
+            if (__builtin_expect((out_pos & ~1023u) > flushed, 0)) flush_to(out_pos & ~1023u);
+          }
+        } else {  // a length: its extra bits, then the distance code and its extra bits (RFC 1951 §3.2.5)
+          const uint32_t len = ((e >> 6) & 0x1FFu) + ing_sbfe((uint32_t)bs.buf, e);
+          bs.drop(e >> 23);
+          bs.refill();
+          const uint64_t de = L.dist[bs.peek(ING_DIST_ROOT)];
+          const uint32_t d = uni((uint32_t)de);
+          uint32_t dist;
+          if (__builtin_expect((int32_t)d < 0, 0)) {  // ING_RARE
+            const uint64_t rr = ing_rare(1, d, bs.buf, L.dist_count, L.dist_sorted);
+            const uint32_t r_lo = uni((uint32_t)rr);
+            bs.drop(r_lo & 0xFFu);
+            stop = r_lo >> 8;
+            dist = uni((uint32_t)(rr >> 32));  // (when stopping: 1)
+          } else {
+            dist = uni((uint32_t)(de >> 32)) + ing_sbfe((uint32_t)bs.buf, d);
+            bs.drop(d >> 23);
+          }
+          // (both in one test: every value is far below 2^31)
+          if (__builtin_expect((int32_t)((out_pos - mis - dist) | (end_v - out_pos - len)) < 0, 0)) {
+            stop = 1u;
+          } else {
+            if (STATS) {
+              ++n_match;
+              n_mbytes += len;
+              if (dist > ING_NEAR_MAX) ++n_far;
+            }
+            const long long t_c0 = STATS ? clock64() : 0;
+            copy_match(len, dist);
+            if (STATS) t_copy += clock64() - t_c0;
+          }
+        }
+        asm volatile("" : "+s"(stop));
+      } while (stop == 0);
+      if (stop == 1u) err = GMX_INGEST_BAD_MEMBER;
     }
   }
   if (!err) {
