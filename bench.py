@@ -496,7 +496,7 @@ def main():
         batches.append((pk, sd))
     t_reads = time.time() - t0
     reads = raw[0]
-    seeds = batches[0][1].array
+    seeds = np.array(batches[0][1].array, copy=True)  # (a copy: the page-locked arrays are freed before the config legs, cpu_baseline runs after them)
     qm = Quasimapper(ix, device=local_rank)
     if not args.upload_seeds:
         # the per-read seeds stay in page-locked host memory: only a read with several equally good mapping classes draws, and
