@@ -129,6 +129,8 @@ struct gmx_engine {
     bool busy = false;
   } stage[2];
   hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream2 = nullptr;  // the packed feeds' uploads alternate between the two (gmx_map_reads_packed_host / _2bit_host)
+  uint32_t copy_toggle = 0;
   hipStream_t last_stream = nullptr;
   // gmx_map_reads_packed_host: three slots of device buffers for bit planes, offsets, seeds and skip flags; the upload of
   // a chunk (copy stream, straight from the caller's page-locked buffers) runs beside the kernels of the chunks before
@@ -226,8 +228,8 @@ static hipError_t gmx_event_wait(hipEvent_t ev) {
 // 8 x 1.34 G reads/s). The callers still issue their hipDeviceSynchronize afterwards: it then returns at once.
 static int gmx_quiesce(gmx_engine *e) {
   if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming | hipEventBlockingSync));
-  hipStream_t streams[4] = {e->last_stream, e->copy_stream, e->side_stream, e->side2_stream};
-  for (int i = 0; i < 4; ++i) {
+  hipStream_t streams[5] = {e->last_stream, e->copy_stream, e->side_stream, e->side2_stream, e->copy_stream2};
+  for (int i = 0; i < 5; ++i) {
     if (i > 0 && !streams[i]) continue;  // ([0]: the null stream counts)
     bool seen = false;
     for (int j = 0; j < i; ++j) seen = seen || streams[j] == streams[i];
@@ -648,6 +650,7 @@ void gmx_engine_destroy(gmx_engine *e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->ev_wait) (void)hipEventDestroy(e->ev_wait);
   if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+  if (e->copy_stream2) (void)hipStreamDestroy(e->copy_stream2);
   if (e->h_log_state) (void)hipHostFree(e->h_log_state);
   if (e->ev_log_state) (void)hipEventDestroy(e->ev_log_state);
   for (auto &sl : e->pslot) {
@@ -1285,6 +1288,8 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
   if (n_reads == 0) return GMX_OK;
   HIP_TRY(hipSetDevice(e->opts.device));
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+  static const bool two_copy_streams = !getenv("GMX_ONE_COPY_STREAM");
+  if (two_copy_streams && !e->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
   const uint32_t ppr = (uniform_len + 31u) / 32u;
   auto base_at = [&](uint64_t r) -> uint64_t { return uniform_len ? r * uniform_len : offsets[r] - offsets[0]; };
   auto pair_at = [&](uint64_t r) -> uint64_t {  // 8-byte units from the call's first read to read r (gmx.h: layout of `planes`;
@@ -1359,17 +1364,21 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
       if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false)) || (rc = e->alloc(&sl.d_skip, cr, false))) break;
       sl.cap_reads = cr;
     }
-    // (one copy stream: the planes split over two streams reach 31-37 GB/s instead of 51, and a kernel pulling the stream
-    //  out of the caller's page-locked memory itself 34 GB/s — both measured in round 3 and removed)
-    if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, pairs * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(planes)")) break;
+    // Consecutive batches' uploads alternate between two copy streams (round 5): copies that follow one another on ONE stream
+    // leave the link idle between them — the box's link carries 57 GB/s (tools/exp/h2d_rate.py: large copies, or two streams),
+    // a batch's 37.5 MB one after the other 51 —, two streams keep a copy queued behind the one in flight. (ONE batch's planes
+    // split over two streams reached 31-37 GB/s, and a kernel pulling the stream out of the caller's page-locked memory itself
+    // 34 GB/s — both measured in round 3 and removed.) GMX_ONE_COPY_STREAM=1: as before.
+    const hipStream_t cs = two_copy_streams && ((e->copy_toggle++) & 1u) ? e->copy_stream2 : e->copy_stream;
+    if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, pairs * 8, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(planes)")) break;
     if (!uniform_len &&
-        !hip_ok(hipMemcpyAsync(sl.d_offsets, offsets + done, (n + 1) * 8, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(offsets)"))
+        !hip_ok(hipMemcpyAsync(sl.d_offsets, offsets + done, (n + 1) * 8, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(offsets)"))
       break;
     if (!d_seeds_host &&
-        !hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(seeds)"))
+        !hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(seeds)"))
       break;
-    if (skip && !hip_ok(hipMemcpyAsync(sl.d_skip, skip + done, n, hipMemcpyHostToDevice, e->copy_stream), "hipMemcpyAsync(skip)")) break;
-    if (!hip_ok(hipEventRecord(sl.copied, e->copy_stream), "hipEventRecord") ||
+    if (skip && !hip_ok(hipMemcpyAsync(sl.d_skip, skip + done, n, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(skip)")) break;
+    if (!hip_ok(hipEventRecord(sl.copied, cs), "hipEventRecord") ||
         !hip_ok(hipStreamWaitEvent(nullptr, sl.copied, 0), "hipStreamWaitEvent"))
       break;
     BatchInput in;
@@ -1390,6 +1399,7 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
   // common epilogue: a failed call, or one that registered memory, leaves nothing in flight that reads the caller's buffers
   if (rc != GMX_OK || !all_pinned) {
     (void)hipStreamSynchronize(e->copy_stream);
+    if (e->copy_stream2) (void)hipStreamSynchronize(e->copy_stream2);
     if (rc != GMX_OK) {
       (void)hipDeviceSynchronize();
       for (auto &sl : e->pslot) sl.busy = false;
@@ -1483,6 +1493,11 @@ int gmx_engine_sync_uploads(gmx_engine *e) {
   if (e->copy_stream) {  // (sleeping, not polling: gmx_quiesce)
     if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming | hipEventBlockingSync));
     HIP_TRY(hipEventRecord(e->ev_wait, e->copy_stream));
+    HIP_TRY(gmx_event_wait(e->ev_wait));
+  }
+  if (e->copy_stream2) {
+    if (!e->ev_wait) HIP_TRY(hipEventCreateWithFlags(&e->ev_wait, hipEventDisableTiming | hipEventBlockingSync));
+    HIP_TRY(hipEventRecord(e->ev_wait, e->copy_stream2));
     HIP_TRY(gmx_event_wait(e->ev_wait));
   }
   return GMX_OK;
