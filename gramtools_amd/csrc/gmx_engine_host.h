@@ -318,7 +318,9 @@ void gmx_engine_default_opts(gmx_engine_opts *o) {
 static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if (n_reads <= e->cap_reads) return GMX_OK;
   // (re)allocate: old buffers stay in `allocs` until destroy; growth is rare (first call sizes it)
-  uint64_t cap = std::max<uint64_t>(n_reads, 1024);
+  // (an eighth of headroom when the workspace GROWS: chunks of a decoded reads file differ by a few reads — the record a chunk's end
+  // cuts — and every growth is two dozen allocations that wait for the device: 11 ms in the middle of `gram`'s second chunk)
+  uint64_t cap = std::max<uint64_t>(e->cap_reads ? n_reads + n_reads / 8 : n_reads, 1024);
   uint64_t n_tasks = cap * 2;
   int rc;
   if ((rc = e->alloc(&e->d_skip, cap, true))) return rc;

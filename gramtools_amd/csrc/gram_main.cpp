@@ -916,7 +916,7 @@ struct DeviceFeed {  // one per process: the ingest object and its page-locked s
   gmx_ingest *ing = nullptr;
   uint64_t max_text = 0;
   int device = 0;
-  HostBuf<uint8_t> stage[2];
+  HostBuf<uint8_t> stage[3];  // (three: chunk i + 2's bytes are staged while chunks i and i + 1 are on the device)
   ~DeviceFeed() {
     if (ing) gmx_ingest_destroy(ing);
   }
@@ -969,74 +969,104 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     size_t n;
     ~Unmap() { munmap(p, n); }
   } unmap{mp, size};
-  // the member table: every byte of the file must belong to a BGZF member
-  std::vector<gmx_bgzf_member> members;
-  members.reserve(size / 16000 + 16);
-  for (size_t at = 0; at < size;) {
-    gmx_bgzf_member m;
-    size_t next;
-    if (!bgzf_member_at(in, size, at, &m, &next)) return 1;
-    if (m.isize) members.push_back(m);  // (empty members — the EOF marker — hold nothing)
-    at = next;
-  }
-  feed_trace("BGZF member table walked");
-  // chunks of members: at most kMembers, and what the ingest has room for
-  const uint64_t kMembers = device_feed_members();
-  uint64_t file_text = 0;
-  for (const auto &m : members) file_text += m.isize;
+  // The member table is walked a chunk at a time, beside the device (round 5: the whole table first cost 7 ms of a 22 000-member file
+  // before the first byte went up). Every byte of the file must belong to a BGZF member: a file that stops being BGZF behind chunks
+  // already delivered is handed to the host reader, which drops what was mapped (return value 2).
   DeviceFeed &df = g_device_feed;
-  device_feed_prepare(device, device_feed_text_for(file_text), 0);
+  device_feed_prepare(device, device_feed_text_for((uint64_t)size * 6), 0);  // (as the call beside the index load sized it)
   if (!df.ing) return 1;
   gmx_ingest *ing = df.ing;
   GMX_CHECK(gmx_ingest_reset(ing));
+  const uint64_t kMembers = device_feed_members();
   const uint64_t max_text = gmx_ingest_max_text(ing), max_comp = gmx_ingest_max_compressed(ing);
   struct Chunk {
-    size_t first, count;  // members
-    size_t lo, hi;        // file bytes their deflate data spans
+    std::vector<gmx_bgzf_member> rel;  // its members, offsets from lo
+    size_t lo = 0, hi = 0;             // file bytes their deflate data spans
   };
-  std::vector<Chunk> chunks;
-  for (size_t i = 0; i < members.size();) {
-    Chunk c{i, 0, (size_t)members[i].offset, 0};
-    uint64_t text = 0;
-    while (i < members.size() && c.count < kMembers && text + members[i].isize <= max_text &&
-           members[i].offset + members[i].size - c.lo <= max_comp) {
-      text += members[i].isize;
-      c.hi = (size_t)(members[i].offset + members[i].size);
-      ++c.count;
-      ++i;
+  size_t walk_at = 0;
+  auto skip_empty = [&]() -> bool {  // to the next member that holds text; false: the bytes there are no BGZF member
+    while (walk_at < size) {
+      gmx_bgzf_member m;
+      size_t next;
+      if (!bgzf_member_at(in, size, walk_at, &m, &next)) return false;
+      if (m.isize) break;
+      walk_at = next;  // (empty members — the EOF marker — hold nothing)
     }
-    if (c.count == 0) return 1;  // (a member the ingest has no room for: cannot happen with <= 64 KB members)
-    chunks.push_back(c);
-  }
-  if (chunks.empty()) {  // no reads at all
-    return 0;
-  }
+    return true;
+  };
+  // the next chunk of members: at most kMembers, and what the ingest has room for. 1: a chunk, 0: the file's end, -1: not BGZF
+  auto next_chunk = [&](Chunk &c) -> int {
+    c.rel.clear();
+    c.lo = c.hi = 0;
+    uint64_t text = 0;
+    while (walk_at < size) {
+      gmx_bgzf_member m;
+      size_t next;
+      if (!bgzf_member_at(in, size, walk_at, &m, &next)) return -1;
+      if (m.isize) {
+        if (c.rel.empty()) c.lo = (size_t)m.offset;
+        if (c.rel.size() >= kMembers || text + m.isize > max_text || m.offset + m.size - c.lo > max_comp) break;
+        text += m.isize;
+        c.hi = (size_t)(m.offset + m.size);
+        m.offset -= c.lo;
+        c.rel.push_back(m);
+      }
+      walk_at = next;
+    }
+    if (c.rel.empty()) return walk_at < size ? -1 : 0;  // (a member the ingest has no room for: cannot happen with <= 64 KB members)
+    return skip_empty() ? 1 : -1;                        // (so that walk_at == size tells a chunk it is the file's last)
+  };
   const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
-  std::vector<gmx_bgzf_member> rel;
-  auto submit = [&](size_t ci) {
-    const Chunk &c = chunks[ci];
-    HostBuf<uint8_t> &st = df.stage[ci & 1];
+  // Chunk i + 2's bytes are staged (page cache -> page-locked memory, 5 ms a chunk) while chunks i and i + 1 are on the device, and
+  // it is submitted the moment chunk i's reads have been handed to the engine: the device then never waits for the host's memcpy
+  // (round 5: staged inside the submit, the copy sat between a chunk's result and the next chunk's upload — a GPU idle for 6 ms of
+  // every 13). Three staging buffers: the one chunk i + 2 takes was chunk i - 1's, whose upload is long done (it has been waited for).
+  Chunk ring[3];
+  bool last_of_file[3] = {false, false, false};
+  size_t n_staged = 0;  // chunks walked and staged so far
+  bool at_end = false, bad_walk = false;
+  auto stage = [&]() -> bool {  // the next chunk, into slot n_staged % 3; false: there is none
+    if (at_end || bad_walk) return false;
+    Chunk &c = ring[n_staged % 3];
+    const int rc = next_chunk(c);
+    if (rc <= 0) {
+      at_end = rc == 0;
+      bad_walk = rc < 0;
+      return false;
+    }
+    last_of_file[n_staged % 3] = walk_at >= size;
+    HostBuf<uint8_t> &st = df.stage[n_staged % 3];
     const size_t n = c.hi - c.lo;
     st.resize(n + 64);
     parallel_for(T, [&](unsigned t) {  // the compressed bytes, from the page cache into page-locked memory
       const size_t a = n * t / T, b = n * (t + 1) / T;
       if (b > a) memcpy(st.data() + a, in + c.lo + a, b - a);
     });
-    rel.assign(members.begin() + (long)c.first, members.begin() + (long)(c.first + c.count));
-    for (auto &m : rel) m.offset -= c.lo;
-    GMX_CHECK(gmx_ingest_submit_bgzf(ing, (int)(ci & 1), st.data(), n, rel.data(), rel.size(), ci + 1 == chunks.size() ? 1 : 0));
+    ++n_staged;
+    return true;
+  };
+  size_t n_submitted = 0;
+  auto submit = [&]() {  // chunk n_submitted (staged)
+    const size_t ci = n_submitted;
+    const Chunk &c = ring[ci % 3];
+    GMX_CHECK(gmx_ingest_submit_bgzf(ing, (int)(ci & 1), df.stage[ci % 3].data(), c.hi - c.lo, c.rel.data(), c.rel.size(), last_of_file[ci % 3] ? 1 : 0));
+    ++n_submitted;
     feed_trace("chunk submitted to the device");
   };
-  submit(0);
-  for (size_t ci = 0; ci < chunks.size(); ++ci) {
-    if (ci + 1 < chunks.size()) submit(ci + 1);
+  if (!skip_empty()) return 1;
+  if (!stage()) return bad_walk ? 1 : 0;  // (0: no reads at all)
+  submit();
+  feed_trace("first chunk on its way; the member table is walked beside the device");
+  if (stage()) submit();
+  for (size_t ci = 0; ci < n_submitted; ++ci) {
+    if (n_staged == n_submitted) stage();  // chunk ci + 2, while ci and ci + 1 are on the device
     gmx_ingest_result res;
     GMX_CHECK(gmx_ingest_wait(ing, (int)(ci & 1), &res));
     feed_trace("chunk decoded");
     if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))  // test hook: the device decoder "gives up" on this chunk (tests/test_ingest.py)
       if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_BAD_MEMBER;
     if (res.status) {
-      if (ci + 1 < chunks.size()) {  // (the chunk behind is in flight: let it finish before the slots are reused)
+      if (ci + 1 < n_submitted) {  // (the chunk behind is in flight: let it finish before the slots are reused)
         gmx_ingest_result drop;
         GMX_CHECK(gmx_ingest_wait(ing, (int)((ci + 1) & 1), &drop));
       }
@@ -1051,7 +1081,9 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     }
     on_chunk(res, (int)(ci & 1));
     *delivered += res.n_reads;
+    if (n_staged > n_submitted) submit();  // (its slot is chunk ci's: free once the engine has been handed those reads, gmx_ingest_release_after)
   }
+  if (bad_walk) return *delivered == 0 ? 1 : 2;  // bytes that are no BGZF member behind the chunks delivered: the host reader's
   return 0;
 }
 
@@ -1618,7 +1650,7 @@ int run_genotype(const Args &a) {
   phase("engines created (HIP start-up, index upload)");
   gmx_engine *eng = gmx_group_engine(grp, 0);  // after the exchange every engine holds the totals: engine 0 is read back
   // workspace for the calls the feed will make (a block of a reads file per call, at most 1 M reads per engine)
-  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), info.is_nested ? 4u << 20 : 1u << 20, ((info.is_nested ? 24ull : 6ull) << 20) + 64));
+  for (int d = 0; d < gmx_group_size(grp); ++d) GMX_CHECK(gmx_engine_reserve_packed(gmx_group_engine(grp, d), info.is_nested ? 4u << 20 : 3u << 19 /* (a decoded BGZF chunk of 150 bp reads: 1.46 M) */, ((info.is_nested ? 24ull : 6ull) << 20) + 64));
   if (prewarm.joinable()) prewarm.join();
   phase("workspace reserved, page-locked buffers warmed");
   double t_load = std::chrono::duration<double>(clk::now() - t0).count();
@@ -1670,15 +1702,24 @@ int run_genotype(const Args &a) {
       static std::vector<std::unique_ptr<HostBuf<uint32_t>>> dev_seeds;  // per engine and slot
       while (dev_seeds.size() < 2 * devices.size()) dev_seeds.emplace_back(new HostBuf<uint32_t>());
       uint64_t delivered = 0;
+      // several engines: every one decodes and maps its share of the file's chunks (GMX_INGEST_ONE_DEVICE=1: the first one all of them)
+      const bool dealt = devices.size() > 1 && !getenv("GMX_INGEST_ONE_DEVICE");
       auto map_chunk = [&](const gmx_ingest_result &res, size_t k, int slot) {  // engine k's ingest holds the chunk's reads in its HBM
         const uint64_t n = res.n_reads;
         if (n == 0) return;
         gmx_engine *ek = gmx_group_engine(grp, (int)k);
         HostBuf<uint32_t> &sd = *dev_seeds[2 * k + (size_t)slot];
-        // (the kernels read the few seeds they need in place: the buffer a slot used two chunks ago must be done with)
-        GMX_CHECK(gmx_engine_sync(ek));
+        // The kernels read the few seeds they need in place: the buffer a slot used two chunks ago must be done with. One ingest,
+        // chunks alternating between its slots: it is — this chunk's result was waited for, its scan waited (on the device) for the
+        // slot's release, and the slot was released behind the mapping kernels of the chunk two before (gmx_ingest_release_after
+        // below; ing_begin). Until round 5 the engine was synchronised here: the host sat out the mapping of the chunk before,
+        // queued behind the inflate kernels, 6-13 ms of every chunk in which nothing new went to the device. Chunks dealt over
+        // several ingests are submitted in another order: there the engine is synchronised as before.
+        if (dealt) GMX_CHECK(gmx_engine_sync(ek));
         sd.resize(n);
+        feed_trace("  chunk's seed buffer ready");
         seed_stream.copy(file_base + in_file, n, sd.data());
+        feed_trace("  chunk's seeds copied");
         if (res.uniform_len) {
           GMX_CHECK(gmx_map_reads_packed_device(ek, res.d_planes, nullptr, res.uniform_len, sd.data(), res.any_skip ? res.d_skip : nullptr, n));
         } else {
@@ -1688,12 +1729,11 @@ int run_genotype(const Args &a) {
                                                   res.any_skip ? res.d_skip + r0 : nullptr, m));
           }
         }
+        feed_trace("  chunk handed to the engine");
         GMX_CHECK(gmx_ingest_release_after(k == 0 ? g_device_feed.ing : g_more_feeds[k - 1]->ing, slot, nullptr));
         in_file += n;
         total_reads += n;
       };
-      // several engines: every one decodes and maps its share of the file's chunks (GMX_INGEST_ONE_DEVICE=1: the first one all of them)
-      const bool dealt = devices.size() > 1 && !getenv("GMX_INGEST_ONE_DEVICE");
       const int rc = dealt ? ingest_bgzf_file_dealt(path, max_threads, devices, map_chunk, &delivered)
                            : ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) { map_chunk(res, 0, slot); }, &delivered);
       auto sync_all = [&]() {
