@@ -1290,7 +1290,7 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
   if (n_reads == 0) return GMX_OK;
   HIP_TRY(hipSetDevice(e->opts.device));
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-  static const bool two_copy_streams = !getenv("GMX_ONE_COPY_STREAM");
+  static const bool two_copy_streams = getenv("GMX_TWO_COPY_STREAMS") != nullptr;
   if (two_copy_streams && !e->copy_stream2) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream2, hipStreamNonBlocking));
   const uint32_t ppr = (uniform_len + 31u) / 32u;
   auto base_at = [&](uint64_t r) -> uint64_t { return uniform_len ? r * uniform_len : offsets[r] - offsets[0]; };
@@ -1366,11 +1366,12 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
       if ((rc = e->alloc(&sl.d_offsets, cr + 1, false)) || (rc = e->alloc(&sl.d_seeds, cr, false)) || (rc = e->alloc(&sl.d_skip, cr, false))) break;
       sl.cap_reads = cr;
     }
-    // Consecutive batches' uploads alternate between two copy streams (round 5): copies that follow one another on ONE stream
-    // leave the link idle between them — the box's link carries 57 GB/s (tools/exp/h2d_rate.py: large copies, or two streams),
-    // a batch's 37.5 MB one after the other 51 —, two streams keep a copy queued behind the one in flight. (ONE batch's planes
-    // split over two streams reached 31-37 GB/s, and a kernel pulling the stream out of the caller's page-locked memory itself
-    // 34 GB/s — both measured in round 3 and removed.) GMX_ONE_COPY_STREAM=1: as before.
+    // One copy stream. (Round 5: the box's link carries 56-57 GB/s with nothing beside it, tools/exp/h2d_rate.py, this loop 51; with
+    // consecutive batches' uploads alternating between TWO streams — a copy queued behind the one in flight — the median job is 2.5 %
+    // faster, 1.395 against 1.365 G reads/s, but one job in five is 20-40 % slower — two copies share the link and both batches' kernels
+    // start late — where one stream's jobs lie within 0.5 % of each other. GMX_TWO_COPY_STREAMS=1 selects it. Three and four streams:
+    // worse. ONE batch's planes split over two streams reached 31-37 GB/s, and a kernel pulling the stream out of the caller's
+    // page-locked memory itself 34 GB/s — both measured in round 3 and removed.)
     const hipStream_t cs = two_copy_streams && ((e->copy_toggle++) & 1u) ? e->copy_stream2 : e->copy_stream;
     if (!hip_ok(hipMemcpyAsync(sl.d_planes, planes + p0, pairs * 8, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(planes)")) break;
     if (!uniform_len &&
