@@ -238,7 +238,7 @@ def bgzf_device_feed(ix, reads, seeds_np):
     out = {"reads": n, "bgzf_bytes_per_read": len(data) / n, "text_bytes_per_read": text_bytes / n, "members": len(mem),
            "decode_only": {"value": n / dec, "unit": "reads/s", "text_GBps": text_bytes / dec / 1e9},
            "decode_and_quasimap": {"value": n / both, "unit": "reads/s"}, "exact_mapped": st["exact_mapped"],
-           "bound": "gmx_inflate_kernel: the CU's scalar unit (one thread of control per wavefront, ~330 k scalar instructions per 64 KB member; profiles/round5/ingest_inflate_sq_counters.txt), chunks overlapped on 8 hardware queues (ingest_timeline_8_queues.txt)",
+           "bound": "gmx_inflate_kernel: the CU's scalar unit (one thread of control per wavefront, 339 k scalar instructions per 64 KB member; profiles/round5/ingest_inflate_sq_counters.txt), chunks overlapped on 8 hardware queues (ingest_timeline_8_queues.txt)",
            "host_feed_for_comparison": "BGZF inflated by 16 host cores: 32-48 M reads/s (profiles/round4/gz_feed.txt)"}
     pin.close()
     seeds.close()
