@@ -842,43 +842,68 @@ __global__ void __launch_bounds__(256) gmx_nl_count_kernel(const uint8_t *text, 
   __syncthreads();
   if (threadIdx.x == 0) tile_count[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
-// exclusive scan of in[0, n) by ONE block of 1024 threads (n up to a few hundred thousand tiles / a few million reads);
-// out may alias in. total -> *total_out (64-bit)
-template <class TIn, class TOut>
-__device__ void ing_block_scan(const TIn *in, TOut *out, uint32_t n, unsigned long long *total_out) {
-  __shared__ unsigned long long part[1024];
-  const uint32_t t = threadIdx.x, per = (n + 1023u) / 1024u;
-  const uint32_t lo = min(n, t * per), hi = min(n, lo + per);
-  unsigned long long s = 0;
-  for (uint32_t i = lo; i < hi; ++i) s += in[i];
-  part[t] = s;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024u; d <<= 1) {
-    const unsigned long long v = t >= d ? part[t - d] : 0ull;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+// Exclusive scans in two levels, ONE WAVEFRONT per block and no LDS (round 5, second half). The chunk's result waits for these
+// scans, and they run beside the inflate kernel of the next chunk, whose twenty wavefronts per CU hold all of the CU's LDS and five
+// of a SIMD's eight wave slots: the single block of 1024 threads with 8 KB of LDS that did this until then found no CU to start on
+// before that kernel's queue of workgroups ran dry (1.7-3.4 ms instead of 0.25). A wavefront without LDS fits beside them.
+//   level 1 (a block per 1024 elements, 16 per lane): offsets within the block (out may alias in), the block's sum -> blk_tot
+//   level 2 (one wavefront): blk_tot -> the blocks' offsets, in place; returns the total
+// and whoever reads element i adds blk_tot[i >> 10].
+#define ING_SCAN_BLOCK 1024u
+template <class TIn, class TOut, class TTot>
+__device__ __forceinline__ void ing_scan_level1(const TIn *in, TOut *out, uint32_t n, uint32_t blk, TTot *blk_tot) {
+  const uint32_t lane = threadIdx.x & 63u, base = blk * ING_SCAN_BLOCK + lane * 16u;
+  TTot v[16], sum = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 16u; ++j) {
+    v[j] = base + j < n ? (TTot)in[base + j] : (TTot)0;
+    sum += v[j];
   }
-  unsigned long long run = part[t] - s;
+  TTot incl = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const TTot up = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += up;
+  }
+  TTot run = incl - sum;
+#pragma unroll
+  for (uint32_t j = 0; j < 16u; ++j) {
+    if (base + j < n) out[base + j] = (TOut)run;
+    run += v[j];
+  }
+  if (lane == 63u) blk_tot[blk] = incl;
+}
+template <class TTot>
+__device__ __forceinline__ TTot ing_scan_level2(TTot *blk_tot, uint32_t n_blk) {
+  const uint32_t lane = threadIdx.x & 63u, per = (n_blk + 63u) / 64u;
+  const uint32_t lo = min(n_blk, lane * per), hi = min(n_blk, lo + per);
+  TTot sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += blk_tot[i];
+  TTot incl = sum;
+  for (int d = 1; d < 64; d <<= 1) {
+    const TTot up = __shfl_up(incl, d);
+    if ((int)lane >= d) incl += up;
+  }
+  TTot run = incl - sum;
   for (uint32_t i = lo; i < hi; ++i) {
-    const unsigned long long v = in[i];
-    out[i] = (TOut)run;
+    const TTot v = blk_tot[i];
+    blk_tot[i] = run;
     run += v;
   }
-  if (t == 1023u && total_out) *total_out = part[1023];
+  return __shfl(incl, 63);
 }
-__global__ void __launch_bounds__(1024) gmx_tile_scan_kernel(uint32_t *tile_count, uint32_t n_tiles, IngestState *st, uint32_t cap_lines) {
-  __builtin_amdgcn_s_setprio(3);  // one workgroup on a CU it shares with twenty inflate wavefronts, and the chunk's result waits for it
-  __shared__ unsigned long long total;
-  ing_block_scan<uint32_t, uint32_t>(tile_count, tile_count, n_tiles, &total);
-  __syncthreads();
+__global__ void __launch_bounds__(64) gmx_tile_scan1_kernel(uint32_t *tile_count, uint32_t n_tiles, uint32_t *tile_blk) {
+  ing_scan_level1<uint32_t, uint32_t, uint32_t>(tile_count, tile_count, n_tiles, blockIdx.x, tile_blk);
+}
+__global__ void __launch_bounds__(64) gmx_tile_scan2_kernel(uint32_t *tile_blk, uint32_t n_blk, IngestState *st, uint32_t cap_lines) {
+  // (a tile holds at most 4096 newlines and a chunk's text at most 3 GB: the total fits 32 bits)
+  const uint32_t total = ing_scan_level2<uint32_t>(tile_blk, n_blk);
   if (threadIdx.x == 0) {
-    st->n_lines = total > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)total;
+    st->n_lines = total;
     if (total > cap_lines) atomicOr(&st->flags, GMX_INGEST_TOO_MANY_LINES);
   }
 }
-__global__ void __launch_bounds__(256) gmx_nl_mark_kernel(const uint8_t *text, const IngestState *st, const uint32_t *tile_base, uint32_t *line_end,
-                                                          uint32_t cap_lines) {
+__global__ void __launch_bounds__(256) gmx_nl_mark_kernel(const uint8_t *text, const IngestState *st, const uint32_t *tile_base, const uint32_t *tile_blk,
+                                                          uint32_t *line_end, uint32_t cap_lines) {
   if (st->flags & GMX_INGEST_TOO_MANY_LINES) return;
   const uint32_t lo = st->text_start, hi = lo + st->text_len;
   const uint32_t at = blockIdx.x * ING_TILE + threadIdx.x * 16u;
@@ -892,7 +917,7 @@ __global__ void __launch_bounds__(256) gmx_nl_mark_kernel(const uint8_t *text, c
   __shared__ uint32_t wsum[4];
   if ((threadIdx.x & 63u) == 63u) wsum[threadIdx.x >> 6] = incl;
   __syncthreads();
-  uint32_t before = tile_base[blockIdx.x] + incl - c;
+  uint32_t before = tile_blk[blockIdx.x / ING_SCAN_BLOCK] + tile_base[blockIdx.x] + incl - c;
   for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) before += wsum[w];
   while (m) {
     const uint32_t j = (uint32_t)__builtin_ctz(m);
@@ -965,34 +990,46 @@ __global__ void __launch_bounds__(256) gmx_records_kernel(const uint8_t *text, I
   }
 }
 // one length for all reads? -> layout of the planes; reads of different lengths: their base offsets (one block)
-__global__ void __launch_bounds__(1024) gmx_layout_kernel(IngestState *st, const uint32_t *rec_len, unsigned long long *offsets, const IngestInflateStatus *inf) {
-  __builtin_amdgcn_s_setprio(3);  // one workgroup on a CU it shares with twenty inflate wavefronts, and the chunk's result waits for it
+__global__ void __launch_bounds__(64) gmx_layout_kernel(IngestState *st, const IngestInflateStatus *inf) {
   if (threadIdx.x == 0 && inf && inf->flags) {  // what the inflate kernel reported
     st->flags |= inf->flags;
     st->bad_member = inf->bad_member;
   }
   const uint32_t n = st->n_reads;
   const bool uniform = n != 0 && st->min_len == st->max_len;
-  if (uniform || n == 0) {
-    if (threadIdx.x == 0) {
-      st->uniform_len = uniform ? st->max_len : 0u;
-      const unsigned long long ppr = (st->max_len + 31u) / 32u;
-      st->n_pairs = (unsigned long long)n * ppr;
-      for (uint32_t i = 0; i < 16u; ++i) st->sub_pairs[i] = ((unsigned long long)i << 20) * ppr;
-    }
-    return;
+  if (threadIdx.x == 0) {
+    st->uniform_len = uniform ? st->max_len : 0u;
+    const unsigned long long ppr = (st->max_len + 31u) / 32u;
+    if (uniform || n == 0) st->n_pairs = (unsigned long long)n * ppr;
+    for (uint32_t i = 0; i < 16u; ++i) st->sub_pairs[i] = uniform || n == 0 ? ((unsigned long long)i << 20) * ppr : 0ull;
   }
-  __shared__ unsigned long long total;
-  ing_block_scan<uint32_t, unsigned long long>(rec_len, offsets, n, &total);
-  __syncthreads();
+}
+// reads of different lengths: their base offsets, offsets[0, n] (two-level scan as above; nothing to do for one length)
+__global__ void __launch_bounds__(64) gmx_offsets1_kernel(const IngestState *st, const uint32_t *rec_len, unsigned long long *offsets, unsigned long long *off_blk) {
+  const uint32_t n = st->n_reads;
+  if (st->uniform_len || blockIdx.x * ING_SCAN_BLOCK >= n) return;
+  ing_scan_level1<uint32_t, unsigned long long, unsigned long long>(rec_len, offsets, n, blockIdx.x, off_blk);
+}
+__global__ void __launch_bounds__(64) gmx_offsets2_kernel(IngestState *st, unsigned long long *offsets, unsigned long long *off_blk) {
+  const uint32_t n = st->n_reads;
+  if (st->uniform_len || n == 0) return;
+  const unsigned long long total = ing_scan_level2<unsigned long long>(off_blk, (n + ING_SCAN_BLOCK - 1u) / ING_SCAN_BLOCK);
   if (threadIdx.x == 0) {
     offsets[n] = total;
-    st->uniform_len = 0;
     st->n_pairs = (total >> 5) + n;
   }
-  if (threadIdx.x < 16u) {
-    const unsigned long long r = (unsigned long long)threadIdx.x << 20;
-    st->sub_pairs[threadIdx.x] = r < n ? (offsets[r] >> 5) + r : 0ull;
+}
+__global__ void __launch_bounds__(64) gmx_offsets3_kernel(IngestState *st, unsigned long long *offsets, const unsigned long long *off_blk) {
+  const uint32_t n = st->n_reads;
+  if (st->uniform_len || blockIdx.x * ING_SCAN_BLOCK >= n) return;
+  const unsigned long long base = off_blk[blockIdx.x];
+  const uint32_t at = blockIdx.x * ING_SCAN_BLOCK + (threadIdx.x & 63u) * 16u;
+  for (uint32_t j = 0; j < 16u; ++j) {
+    const uint32_t r = at + j;
+    if (r >= n) break;
+    const unsigned long long off = offsets[r] + base;
+    offsets[r] = off;
+    if ((r & 0xFFFFFu) == 0 && (r >> 20) < 16u) st->sub_pairs[r >> 20] = (off >> 5) + r;  // where a launch of <= 2^20 reads starts
   }
 }
 // One thread per pair of planes: 32 letters -> (low bits, high bits) of the codes A,C,G,T = 0..3; from the letters' own bits
@@ -1051,7 +1088,8 @@ struct gmx_ingest {
     uint32_t *d_comp = nullptr;
     IngestMember *d_members = nullptr;
     uint8_t *d_text = nullptr;
-    uint32_t *d_line_end = nullptr, *d_rec_start = nullptr, *d_rec_len = nullptr, *d_tiles = nullptr;
+    uint32_t *d_line_end = nullptr, *d_rec_start = nullptr, *d_rec_len = nullptr, *d_tiles = nullptr, *d_tile_blk = nullptr;
+    unsigned long long *d_off_blk = nullptr;  // (the scans' block sums: gmx_tile_scan1/2_kernel, gmx_offsets1/2/3_kernel)
     unsigned long long *d_planes = nullptr, *d_offsets = nullptr;
     uint8_t *d_skip = nullptr;
     IngestState *d_state = nullptr, *h_state = nullptr;
@@ -1121,7 +1159,8 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
     if ((rc = ing_alloc(g, &s.d_comp, g->max_comp / 4 + 256, false)) || (rc = ing_alloc(g, &s.d_members, g->cap_members, false)) ||
         (rc = ing_alloc(g, &s.d_text, ING_CARRY_MAX + max_text_bytes + 64, false)) || (rc = ing_alloc(g, &s.d_line_end, g->cap_lines, false)) ||
         (rc = ing_alloc(g, &s.d_rec_start, g->cap_reads, false)) || (rc = ing_alloc(g, &s.d_rec_len, g->cap_reads, false)) ||
-        (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, false)) ||
+        (rc = ing_alloc(g, &s.d_tiles, g->n_tiles_max + 1, false)) || (rc = ing_alloc(g, &s.d_tile_blk, g->n_tiles_max / ING_SCAN_BLOCK + 2, false)) ||
+        (rc = ing_alloc(g, &s.d_off_blk, (size_t)g->cap_reads / ING_SCAN_BLOCK + 2, false)) || (rc = ing_alloc(g, &s.d_planes, max_text_bytes / 16 + 2ull * g->cap_reads + 64, false)) ||
         (rc = ing_alloc(g, &s.d_offsets, (size_t)g->cap_reads + 1, false)) || (rc = ing_alloc(g, &s.d_skip, g->cap_reads, false)) ||
         (rc = ing_alloc(g, &s.d_state, 1, true)) || (rc = ing_alloc(g, &s.d_inflate_status, 1, true)))
       return fail(rc);
@@ -1221,10 +1260,16 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
   ING_TRY(hipStreamWaitEvent(g->stream, inflate ? s.inflated : s.copied, 0));
   const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
   hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);
-  hipLaunchKernelGGL(gmx_tile_scan_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_tiles, n_tiles, s.d_state, g->cap_lines);
-  hipLaunchKernelGGL(gmx_nl_mark_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles, s.d_line_end, g->cap_lines);
+  const uint32_t n_tile_blk = (n_tiles + ING_SCAN_BLOCK - 1) / ING_SCAN_BLOCK;
+  hipLaunchKernelGGL(gmx_tile_scan1_kernel, dim3(n_tile_blk), dim3(64), 0, g->stream, s.d_tiles, n_tiles, s.d_tile_blk);
+  hipLaunchKernelGGL(gmx_tile_scan2_kernel, dim3(1), dim3(64), 0, g->stream, s.d_tile_blk, n_tile_blk, s.d_state, g->cap_lines);
+  hipLaunchKernelGGL(gmx_nl_mark_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles, s.d_tile_blk, s.d_line_end, g->cap_lines);
   hipLaunchKernelGGL(gmx_records_kernel, dim3(2048), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_line_end, s.d_rec_start, s.d_rec_len, s.d_skip, g->cap_reads);
-  hipLaunchKernelGGL(gmx_layout_kernel, dim3(1), dim3(1024), 0, g->stream, s.d_state, s.d_rec_len, s.d_offsets, inflate ? s.d_inflate_status : nullptr);
+  const uint32_t n_off_blk = (uint32_t)((g->cap_reads + ING_SCAN_BLOCK - 1) / ING_SCAN_BLOCK);  // (the chunk's read count is on the device: blocks beyond it leave at once)
+  hipLaunchKernelGGL(gmx_layout_kernel, dim3(1), dim3(64), 0, g->stream, s.d_state, inflate ? s.d_inflate_status : nullptr);
+  hipLaunchKernelGGL(gmx_offsets1_kernel, dim3(n_off_blk), dim3(64), 0, g->stream, s.d_state, s.d_rec_len, s.d_offsets, s.d_off_blk);
+  hipLaunchKernelGGL(gmx_offsets2_kernel, dim3(1), dim3(64), 0, g->stream, s.d_state, s.d_offsets, s.d_off_blk);
+  hipLaunchKernelGGL(gmx_offsets3_kernel, dim3(n_off_blk), dim3(64), 0, g->stream, s.d_state, s.d_offsets, s.d_off_blk);
   hipLaunchKernelGGL(gmx_fq_pack_kernel, dim3(4096), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_rec_start, s.d_rec_len, s.d_offsets, s.d_planes, s.d_skip);
   ING_TRY(hipGetLastError());
   ING_TRY(hipMemcpyAsync(s.h_state, s.d_state, sizeof(IngestState), hipMemcpyDeviceToHost, g->stream));
