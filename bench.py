@@ -213,18 +213,20 @@ def bgzf_device_feed(ix, reads, seeds_np):
         def submit(ci):
             ch = chunks[ci]
             lo, hi = ch[0][0], ch[-1][0] + ch[-1][1]
-            ing.submit_bgzf(ci & 1, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
+            ing.submit_bgzf(ci % 3, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
         t0 = time.perf_counter()
         submit(0)
+        if len(chunks) > 1:
+            submit(1)
         for ci in range(len(chunks)):
-            if ci + 1 < len(chunks):
-                submit(ci + 1)
-            res = ing.wait(ci & 1)
+            if ci + 2 < len(chunks):  # (three slots: chunk ci + 2 takes chunk ci - 1's, waited for and released)
+                submit(ci + 2)
+            res = ing.wait(ci % 3)
             if res.status:
                 raise RuntimeError(f"gmx_ingest status {res.status} at member {res.bad_member}")
             if mapped:
                 qm.map_ingested(res, seeds, first=at)
-                ing.release_after(ci & 1)
+                ing.release_after(ci % 3)
             at += int(res.n_reads)
             total += int(res.n_reads)
         if mapped:

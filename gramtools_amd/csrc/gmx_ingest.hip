@@ -1079,6 +1079,7 @@ __global__ void __launch_bounds__(256) gmx_fq_pack_kernel(const uint8_t *text, I
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
+#define GMX_INGEST_SLOTS 3  // chunks in flight per ingest (include/gmx.h: slots 0, 1, 2; a caller may alternate between two of them)
 struct gmx_ingest {
   int device = 0;
   uint64_t max_text = 0, max_comp = 0;
@@ -1098,9 +1099,11 @@ struct gmx_ingest {
     hipStream_t inflate_stream = nullptr;  // the slot's inflate kernel: beside the scan of the chunk before and the tail of its inflate kernel
     hipEvent_t copied = nullptr, done = nullptr, released = nullptr, inflated = nullptr, carried = nullptr;
     bool in_flight = false, has_release = false, has_carried = false;
+    hipEvent_t follower_carried = nullptr;  // `carried` of the chunk that continued this slot's: its carry kernel read the end of this slot's text
+    bool has_follower = false;
     bool deferred = false;       // gmx_ingest_submit_bgzf_deferred: inflate kernel enqueued, scan still to come (gmx_ingest_scan)
     uint32_t deferred_text = 0;  // ... bytes of text of its members
-  } slot[2];
+  } slot[GMX_INGEST_SLOTS];
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
   std::vector<void *> allocs;
   int check_crc = 1;
@@ -1248,7 +1251,7 @@ static int ing_enqueue_inflate(gmx_ingest *g, int si, uint32_t n_members) {
 static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int final_chunk, bool inflate, uint32_t n_members, uint32_t host_tail = 0xFFFFFFFFu) {
   gmx_ingest::Slot &s = g->slot[si];
   const bool from_device = host_tail == 0xFFFFFFFFu;
-  const gmx_ingest::Slot *prev = from_device && g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
+  gmx_ingest::Slot *prev = from_device && g->last_slot >= 0 ? &g->slot[g->last_slot] : nullptr;
   if (inflate && from_device) {
     int rc = ing_enqueue_inflate(g, si, n_members);
     if (rc) return rc;
@@ -1257,6 +1260,10 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
                      members_text, (uint32_t)(final_chunk ? 1 : 0), from_device ? 0u : host_tail);
   ING_TRY(hipEventRecord(s.carried, g->stream));
   s.has_carried = true;
+  if (prev) {  // (the slot of the chunk before may be overwritten once this kernel has read its end: ing_begin)
+    prev->follower_carried = s.carried;
+    prev->has_follower = true;
+  }
   ING_TRY(hipStreamWaitEvent(g->stream, inflate ? s.inflated : s.copied, 0));
   const uint32_t n_tiles = (uint32_t)((ING_CARRY_MAX + (uint64_t)members_text + ING_TILE - 1) / ING_TILE);
   hipLaunchKernelGGL(gmx_nl_count_kernel, dim3(n_tiles), dim3(256), 0, g->stream, s.d_text, s.d_state, s.d_tiles);
@@ -1281,8 +1288,8 @@ static int ing_enqueue_scan(gmx_ingest *g, int si, uint32_t members_text, int fi
 }
 
 static int ing_begin(gmx_ingest *g, int si, const char *who) {
-  if (!g || si < 0 || si > 1) {
-    gmx_set_error(std::string(who) + ": null ingest or slot not 0 / 1");
+  if (!g || si < 0 || si >= GMX_INGEST_SLOTS) {
+    gmx_set_error(std::string(who) + ": null ingest or slot not 0 / 1 / 2");
     return GMX_EINVAL;
   }
   if (g->slot[si].in_flight || g->slot[si].deferred) {
@@ -1301,12 +1308,13 @@ static int ing_begin(gmx_ingest *g, int si, const char *who) {
     ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.released, 0));
     s.has_release = false;
   }
-  // this slot's text is about to be overwritten (inflate kernel, or the upload of a text chunk): the carry of the chunk before —
-  // in the other slot — reads the end of this slot's old text
-  gmx_ingest::Slot &other = g->slot[si ^ 1];
-  if (g->last_slot == (si ^ 1) && other.has_carried) {
-    ING_TRY(hipStreamWaitEvent(s.inflate_stream, other.carried, 0));
-    ING_TRY(hipStreamWaitEvent(g->copy_stream, other.carried, 0));
+  // this slot's text is about to be overwritten (inflate kernel, or the upload of a text chunk): the carry kernel of the chunk that
+  // continued this slot's old chunk reads the end of that text. (With two slots that is the chunk before the one being submitted;
+  // with three it ran long ago — the new chunk's inflate kernel does not wait for the scan of the chunk two before it.)
+  if (s.has_follower) {
+    ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.follower_carried, 0));
+    ING_TRY(hipStreamWaitEvent(g->copy_stream, s.follower_carried, 0));
+    s.has_follower = false;
   }
   return GMX_OK;
 }
@@ -1393,7 +1401,7 @@ int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *comp
 }
 
 int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk) {
-  if (!g || slot < 0 || slot > 1 || !g->slot[slot].deferred || (!carry && n_carry) || n_carry > ING_CARRY_MAX) {
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || !g->slot[slot].deferred || (!carry && n_carry) || n_carry > ING_CARRY_MAX) {
     gmx_set_error("gmx_ingest_scan: null ingest, slot without a gmx_ingest_submit_bgzf_deferred chunk, or more than 1 MB of carried text (a record that long is not FASTQ)");
     return GMX_EINVAL;
   }
@@ -1405,7 +1413,7 @@ int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_ca
 }
 
 int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
-  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_tail: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
   }
@@ -1424,8 +1432,8 @@ int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t ca
 }
 
 int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {
-  if (!g || slot < 0 || slot > 1 || !out) {
-    gmx_set_error("gmx_ingest_wait: null argument or slot not 0 / 1");
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || !out) {
+    gmx_set_error("gmx_ingest_wait: null argument or slot not 0 / 1 / 2");
     return GMX_EINVAL;
   }
   gmx_ingest::Slot &s = g->slot[slot];
@@ -1456,8 +1464,8 @@ int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {
 }
 
 int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) {
-  if (!g || slot < 0 || slot > 1) {
-    gmx_set_error("gmx_ingest_release_after: null ingest or slot not 0 / 1");
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS) {
+    gmx_set_error("gmx_ingest_release_after: null ingest or slot not 0 / 1 / 2");
     return GMX_EINVAL;
   }
   ING_TRY(hipSetDevice(g->device));
@@ -1467,7 +1475,7 @@ int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) {
 }
 
 int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
-  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_text: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
   }
@@ -1485,7 +1493,7 @@ int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t ca
 }
 
 int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *offsets, uint8_t *skip) {
-  if (!g || slot < 0 || slot > 1 || g->slot[slot].in_flight) {
+  if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_reads: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
   }

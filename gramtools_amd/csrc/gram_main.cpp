@@ -1017,8 +1017,8 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
     return skip_empty() ? 1 : -1;                        // (so that walk_at == size tells a chunk it is the file's last)
   };
   const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
-  // Chunk i + 2's bytes are staged (page cache -> page-locked memory, 5 ms a chunk) while chunks i and i + 1 are on the device, and
-  // it is submitted the moment chunk i's reads have been handed to the engine: the device then never waits for the host's memcpy
+  // Chunk i + 2's bytes are staged (page cache -> page-locked memory, 5 ms a chunk) and submitted while chunks i and i + 1 are on the
+  // device (the ingest's three slots): the device never waits for the host's memcpy
   // (round 5: staged inside the submit, the copy sat between a chunk's result and the next chunk's upload — a GPU idle for 6 ms of
   // every 13). Three staging buffers: the one chunk i + 2 takes was chunk i - 1's, whose upload is long done (it has been waited for).
   Chunk ring[3];
@@ -1049,7 +1049,7 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
   auto submit = [&]() {  // chunk n_submitted (staged)
     const size_t ci = n_submitted;
     const Chunk &c = ring[ci % 3];
-    GMX_CHECK(gmx_ingest_submit_bgzf(ing, (int)(ci & 1), df.stage[ci % 3].data(), c.hi - c.lo, c.rel.data(), c.rel.size(), last_of_file[ci % 3] ? 1 : 0));
+    GMX_CHECK(gmx_ingest_submit_bgzf(ing, (int)(ci % 3), df.stage[ci % 3].data(), c.hi - c.lo, c.rel.data(), c.rel.size(), last_of_file[ci % 3] ? 1 : 0));
     ++n_submitted;
     feed_trace("chunk submitted to the device");
   };
@@ -1059,16 +1059,19 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
   feed_trace("first chunk on its way; the member table is walked beside the device");
   if (stage()) submit();
   for (size_t ci = 0; ci < n_submitted; ++ci) {
-    if (n_staged == n_submitted) stage();  // chunk ci + 2, while ci and ci + 1 are on the device
+    // chunk ci + 2 goes to the device BEFORE chunk ci is waited for (three slots: its slot is chunk ci - 1's, waited for and handed to
+    // the engine): two inflate kernels are queued behind the one in flight, and a kernel's last wavefronts never have the GPU alone
+    if (n_staged == n_submitted) stage();
+    if (n_staged > n_submitted) submit();
     gmx_ingest_result res;
-    GMX_CHECK(gmx_ingest_wait(ing, (int)(ci & 1), &res));
+    GMX_CHECK(gmx_ingest_wait(ing, (int)(ci % 3), &res));
     feed_trace("chunk decoded");
     if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))  // test hook: the device decoder "gives up" on this chunk (tests/test_ingest.py)
       if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_BAD_MEMBER;
     if (res.status) {
-      if (ci + 1 < n_submitted) {  // (the chunk behind is in flight: let it finish before the slots are reused)
+      for (size_t cj = ci + 1; cj < n_submitted; ++cj) {  // (the chunks behind are in flight: let them finish before the slots are reused)
         gmx_ingest_result drop;
-        GMX_CHECK(gmx_ingest_wait(ing, (int)((ci + 1) & 1), &drop));
+        GMX_CHECK(gmx_ingest_wait(ing, (int)(cj % 3), &drop));
       }
       const bool decoder = (res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC | GMX_INGEST_TOO_MANY_LINES)) != 0;
       if (!decoder) {  // the text itself is not four-line FASTQ: the host's fast path would say the same
@@ -1079,9 +1082,8 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
       // a member the kernels would not decode, or lines of a few bytes (more records than the ingest has room for): the host reader's
       return *delivered == 0 && !(res.status & (GMX_INGEST_BAD_MEMBER | GMX_INGEST_BAD_CRC)) ? 1 : 2;
     }
-    on_chunk(res, (int)(ci & 1));
+    on_chunk(res, (int)(ci % 3));
     *delivered += res.n_reads;
-    if (n_staged > n_submitted) submit();  // (its slot is chunk ci's: free once the engine has been handed those reads, gmx_ingest_release_after)
   }
   if (bad_walk) return *delivered == 0 ? 1 : 2;  // bytes that are no BGZF member behind the chunks delivered: the host reader's
   return 0;
@@ -1700,7 +1702,7 @@ int run_genotype(const Args &a) {
     uint64_t skip_reads = 0;
     if (!getenv("GMX_HOST_GZ")) {
       static std::vector<std::unique_ptr<HostBuf<uint32_t>>> dev_seeds;  // per engine and slot
-      while (dev_seeds.size() < 2 * devices.size()) dev_seeds.emplace_back(new HostBuf<uint32_t>());
+      while (dev_seeds.size() < 3 * devices.size()) dev_seeds.emplace_back(new HostBuf<uint32_t>());
       uint64_t delivered = 0;
       // several engines: every one decodes and maps its share of the file's chunks (GMX_INGEST_ONE_DEVICE=1: the first one all of them)
       const bool dealt = devices.size() > 1 && !getenv("GMX_INGEST_ONE_DEVICE");
@@ -1708,10 +1710,10 @@ int run_genotype(const Args &a) {
         const uint64_t n = res.n_reads;
         if (n == 0) return;
         gmx_engine *ek = gmx_group_engine(grp, (int)k);
-        HostBuf<uint32_t> &sd = *dev_seeds[2 * k + (size_t)slot];
-        // The kernels read the few seeds they need in place: the buffer a slot used two chunks ago must be done with. One ingest,
-        // chunks alternating between its slots: it is — this chunk's result was waited for, its scan waited (on the device) for the
-        // slot's release, and the slot was released behind the mapping kernels of the chunk two before (gmx_ingest_release_after
+        HostBuf<uint32_t> &sd = *dev_seeds[3 * k + (size_t)slot];
+        // The kernels read the few seeds they need in place: the buffer a slot used three chunks ago must be done with. One ingest,
+        // chunks taking its slots in turn: it is — this chunk's result was waited for, its scan waited (on the device) for the
+        // slot's release, and the slot was released behind the mapping kernels of the chunk three before (gmx_ingest_release_after
         // below; ing_begin). Until round 5 the engine was synchronised here: the host sat out the mapping of the chunk before,
         // queued behind the inflate kernels, 6-13 ms of every chunk in which nothing new went to the device. Chunks dealt over
         // several ingests are submitted in another order: there the engine is synchronised as before.

@@ -695,14 +695,14 @@ def bgzf_members(data) -> list:
 
 class Ingest:
     """Reads files decoded on the device (include/gmx.h, gmx_ingest_*): BGZF members inflated, four-line records found and
-    packed into bit planes by HIP kernels; two slots. ``submit_bgzf`` / ``submit_text`` enqueue a chunk, ``wait`` returns
+    packed into bit planes by HIP kernels; three slots (0, 1, 2) taken in turn. ``submit_bgzf`` / ``submit_text`` enqueue a chunk, ``wait`` returns
     its gmx_ingest_result; Quasimapper.map_ingested maps what a slot holds."""
 
     def __init__(self, device: int = 0, max_text_bytes: int = 64 << 20):
         self.lib = _lib.load()
         self.h = C.c_void_p()
         check(self.lib.gmx_ingest_create(device, max_text_bytes, C.byref(self.h)))
-        self._keep = [None, None]
+        self._keep = [None, None, None]
 
     def close(self):
         if getattr(self, "h", None):

@@ -211,9 +211,11 @@ int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const u
  * of <= 64 KB that carry their size in a `BC` extra field, SAM spec §4.1): the compressed members are uploaded as they lie in
  * the file and HIP kernels inflate them (one wavefront per member, CRC-32 checked), find the four-line records and pack
  * their bases into the bit planes of gmx_map_reads_packed_host, all in HBM. A file is handed over in CHUNKS of whole
- * members, in order; a record cut by a chunk's end is carried into the next chunk on the device. Two slots alternate, so
- * that a chunk uploads and inflates while the one before is mapped:
- *     submit(slot 0, chunk 0); submit(slot 1, chunk 1); wait(slot 0) -> map -> release_after(slot 0); submit(slot 0, chunk 2); ...
+ * members, in order; a record cut by a chunk's end is carried into the next chunk on the device. THREE slots (0, 1, 2) take
+ * the chunks in turn, so that two chunks upload and inflate — their inflate kernels side by side: a kernel's last wavefronts
+ * leave most of the GPU idle — while the one before them is mapped:
+ *     submit(0, chunk 0); submit(1, chunk 1); submit(2, chunk 2); wait(0) -> map -> release_after(0); submit(0, chunk 3); wait(1) ...
+ * (a caller may also alternate between two of the slots, as until round 5: consecutive chunks must go to different slots).
  * There is no CPU fallback inside: a chunk the kernels cannot take (status != 0) is the caller's to handle — `gram` inflates
  * it with zlib and passes the text through gmx_ingest_submit_text (same kernels behind the inflate step), or reports the
  * file as damaged when zlib agrees. */

@@ -79,17 +79,19 @@ if __name__ == "__main__":
         def submit(ci):
             ch = chunks[ci]
             lo, hi = ch[0][0], ch[-1][0] + ch[-1][1]
-            ing.submit_bgzf(ci & 1, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
+            ing.submit_bgzf(ci % 3, pin.array[lo:hi], arrays[ci], ci == len(chunks) - 1)
         t = time.perf_counter()
         submit(0)
+        if len(chunks) > 1:
+            submit(1)
         for ci in range(len(chunks)):
-            if ci + 1 < len(chunks):
-                submit(ci + 1)
-            res = ing.wait(ci & 1)
+            if ci + 2 < len(chunks):  # (three slots: chunk ci + 2 takes chunk ci - 1's, waited for and released)
+                submit(ci + 2)
+            res = ing.wait(ci % 3)
             assert res.status == 0, (res.status, res.bad_member)
             if mapper is not None:
                 mapper.map_ingested(res, seeds)
-                ing.release_after(ci & 1)
+                ing.release_after(ci % 3)
             total += int(res.n_reads)
         if mapper is not None:
             mapper.sync()
