@@ -39,6 +39,10 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
 import argparse
 import json
 import os
+
+# The HIP runtime reads this at its first call — here torch's, before libgmx.so is loaded and can ask for it itself (gmx_capi.cpp;
+# INTEGRATION.md): an ingest's five streams and an engine's four need more than the runtime's 4 hardware queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import subprocess
 import sys
 import tempfile
