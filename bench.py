@@ -39,10 +39,6 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
 import argparse
 import json
 import os
-
-# The HIP runtime reads this at its first call — here torch's, before libgmx.so is loaded and can ask for it itself (gmx_capi.cpp;
-# INTEGRATION.md): an ingest's five streams and an engine's four need more than the runtime's 4 hardware queues.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import subprocess
 import sys
 import tempfile
@@ -244,7 +240,7 @@ def bgzf_device_feed(ix, reads, seeds_np):
     out = {"reads": n, "bgzf_bytes_per_read": len(data) / n, "text_bytes_per_read": text_bytes / n, "members": len(mem),
            "decode_only": {"value": n / dec, "unit": "reads/s", "text_GBps": text_bytes / dec / 1e9},
            "decode_and_quasimap": {"value": n / both, "unit": "reads/s"}, "exact_mapped": st["exact_mapped"],
-           "bound": "gmx_inflate_kernel: the CU's scalar unit (one thread of control per wavefront, 339 k scalar instructions per 64 KB member; profiles/round5/ingest_inflate_sq_counters.txt), chunks overlapped on 8 hardware queues (ingest_timeline_8_queues.txt)",
+           "bound": "gmx_inflate_kernel: the CU's scalar unit (one thread of control per wavefront, 339 k scalar instructions per 64 KB member; profiles/round5/ingest_inflate_sq_counters.txt), the chunks' inflate kernels side by side (three slots, streams of their own hardware queues)",
            "host_feed_for_comparison": "BGZF inflated by 16 host cores: 32-48 M reads/s (profiles/round4/gz_feed.txt)"}
     pin.close()
     seeds.close()

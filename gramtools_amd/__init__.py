@@ -4,12 +4,6 @@ The package holds the HIP kernels + C-ABI (``csrc/``, built in-tree into ``lib/l
 ``gram`` drop-in executable (``bin/gram``) and this thin Python mirror of the reference's quasimap
 interface. See DESIGN.md for the path, the boundary and the data layout.
 """
-import os as _os
-
-# (as libgmx.so does when it is loaded — here earlier, for a process that brings the HIP runtime up through torch before the
-# library is loaded; a value the user set stays: INTEGRATION.md)
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 from .quasimap import (  # noqa: F401
     Index,
     Quasimapper,

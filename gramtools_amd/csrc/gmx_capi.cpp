@@ -21,14 +21,6 @@ struct gmx_index {
 
 static thread_local std::string g_error;
 void gmx_set_error(const std::string &msg) { g_error = msg; }
-
-// The HIP runtime spreads a process's streams over 4 hardware queues unless told otherwise, and kernels of two streams that share a
-// queue run one after the other. An ingest has five streams and an engine four: with 4 queues the inflate kernel of chunk i + 1
-// waited for that of chunk i instead of filling the CUs its tail leaves idle (profiles/round5/ingest_timeline_4_queues.txt /
-// _8_queues.txt). The runtime reads the variable at its first call, the library sets it when it is loaded; a value the user set stays.
-// (16: an ingest with three slots has five streams, an engine four; with 8 queues two inflate streams shared one again: the bench's
-// bgzf leg 146 instead of 159 M reads/s.)
-__attribute__((constructor)) static void gmx_hw_queues_default() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 const gmx::HostIndex &gmx_index_host(const gmx_index *ix) { return ix->h; }
 uint64_t gmx_index_serial(const gmx_index *ix) { return ix->serial; }
 

@@ -1126,6 +1126,21 @@ int ing_alloc(gmx_ingest *g, T **p, size_t count, bool zero) {
 
 extern "C" {
 
+// The slots' inflate streams are created at the LOWEST stream priority: the runtime keeps a pool of hardware queues per priority
+// (4 each by default), so the three of them get queues of their own — two streams on one hardware queue run their kernels one after the
+// other, and chunk i + 1's inflate kernel then waits for chunk i's instead of filling the CUs its tail leaves idle — without the
+// process asking for more queues (GPU_MAX_HW_QUEUES), which changes how an engine's own streams are spread (configs[3]'s host feed
+// -12 % at 16). And it is the right order of precedence: scans and mapping kernels go first. GMX_INGEST_STREAM_PRIORITY=0: as the others.
+static hipError_t ing_inflate_stream_create(hipStream_t *st) {
+  int least = 0, greatest = 0;
+  if (getenv("GMX_INGEST_STREAM_PRIORITY") && atoi(getenv("GMX_INGEST_STREAM_PRIORITY")) == 0) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  }
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
+}
+
 int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
   if (!out || max_text_bytes < (1u << 16) || max_text_bytes > (3ull << 30)) {
     gmx_set_error("gmx_ingest_create: max_text_bytes must lie between 64 KB and 3 GB");
@@ -1172,7 +1187,7 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
         hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
         hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.inflated, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s.carried, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&s.inflate_stream, hipStreamNonBlocking) != hipSuccess) {
+        hipEventCreateWithFlags(&s.carried, hipEventDisableTiming) != hipSuccess || ing_inflate_stream_create(&s.inflate_stream) != hipSuccess) {
       gmx_set_error("gmx_ingest_create: page-locked memory / events");
       return fail(GMX_EHIP);
     }
