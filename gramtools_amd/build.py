@@ -15,7 +15,7 @@ LIB = os.path.join(LIB_DIR, "libgmx.so")
 GRAM = os.path.join(BIN_DIR, "gram")
 
 LIB_SOURCES = ["gmx_engine.hip", "gmx_ingest.hip", "gmx_multi.hip", "gmx_seedwalk.hip", "gmx_suffixsort.hip", "gmx_capi.cpp", "gmx_index.cpp", "gmx_infer.cpp", "gmx_stock.cpp"]
-HEADERS = ["gmx_engine_search.h", "gmx_engine_cover_kernels.h", "gmx_engine_host.h", "gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_index.h", "gmx_internal.h", "gmx_engine_debug.h", "gmx_gzsource.h", "gmx_pargz.h", "gmx_crc32.h", "../../include/gmx.h"]
+HEADERS = ["gmx_engine_search.h", "gmx_engine_cover_kernels.h", "gmx_engine_host.h", "gmx_types.h", "gmx_core.h", "gmx_cover.h", "gmx_dfs.h", "gmx_index.h", "gmx_internal.h", "gmx_engine_debug.h", "gmx_gzsource.h", "gmx_pargz.h", "gmx_crc32.h", "libgmx.map", "../../include/gmx.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
@@ -48,7 +48,8 @@ def _link(target, extra_flags, tag, force, verbose):
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
     if jobs or force or _stale(target, objs):
-        cmd = [HIPCC] + FLAGS + ["-shared", "-o", target] + objs + ["-lpthread", "-ldl", "-lz"]
+        # (libgmx.map: the library's replacement operator new / delete — gmx_capi.cpp, the allocation-failure test hook — stay local)
+        cmd = [HIPCC] + FLAGS + ["-shared", "-o", target] + objs + ["-Wl,--version-script=" + os.path.join(CSRC, "libgmx.map"), "-lpthread", "-ldl", "-lz"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

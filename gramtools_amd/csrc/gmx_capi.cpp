@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <stdexcept>
+#include <system_error>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,7 +22,75 @@ struct gmx_index {
 };
 
 static thread_local std::string g_error;
-void gmx_set_error(const std::string &msg) { g_error = msg; }
+void gmx_set_error(const std::string &msg) noexcept {
+  try {
+    g_error = msg;
+  } catch (...) {
+    g_error.clear();  // (clear() keeps the capacity and cannot throw)
+  }
+}
+
+int gmx_guard_catch(const char *fn) noexcept {
+  auto set = [&](const char *what) noexcept {  // "<function>: <what>" without a temporary that could throw again
+    try {
+      g_error.assign(fn);
+      g_error.append(": ");
+      g_error.append(what);
+    } catch (...) {
+      g_error.clear();
+    }
+  };
+  try {
+    throw;
+  } catch (std::bad_alloc const &) {
+    set("out of host memory");
+    return GMX_ENOMEM;
+  } catch (std::system_error const &e) {  // std::thread could not start a thread (EAGAIN)
+    set(e.what());
+    return GMX_ENOMEM;
+  } catch (std::exception const &e) {
+    set(e.what());
+    return GMX_EINVAL;
+  } catch (...) {
+    set("unknown C++ exception");
+    return GMX_EINVAL;
+  }
+}
+
+// ---- test hook: make the library's n-th host allocation fail -------------------------------------------------------------
+// GMX_TEST_FAIL_ALLOC=n in the environment, or gmx_debug_fail_alloc(n) (tests/test_alloc_failure.py): the n-th call of
+// operator new made BY THIS LIBRARY from now on throws std::bad_alloc (n = 0: off; every later one succeeds again). The
+// replacement functions are LOCAL symbols of libgmx.so (version script libgmx.map): they serve the library's own translation units only — the HIP runtime, RCCL,
+// libstdc++'s own code and the host program keep theirs (an exception thrown into the runtime's frames would prove nothing) —
+// and both sides end in malloc / free, so memory may cross. Cost when off: one relaxed load per allocation.
+static std::atomic<int64_t> g_fail_alloc{[] {
+  const char *e = getenv("GMX_TEST_FAIL_ALLOC");
+  return e ? (int64_t)atoll(e) : (int64_t)0;
+}()};
+static std::atomic<uint64_t> g_alloc_calls{0};
+static inline void *gmx_new_impl(size_t n, size_t align) {
+  g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+  if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1, std::memory_order_relaxed) == 1) throw std::bad_alloc();
+  void *p = align > alignof(max_align_t) ? aligned_alloc(align, (n + align - 1) / align * align) : malloc(n ? n : 1);
+  if (!p) throw std::bad_alloc();
+  return p;
+}
+void *operator new(size_t n) { return gmx_new_impl(n, 0); }
+void *operator new[](size_t n) { return gmx_new_impl(n, 0); }
+void *operator new(size_t n, std::align_val_t a) { return gmx_new_impl(n, (size_t)a); }
+void *operator new[](size_t n, std::align_val_t a) { return gmx_new_impl(n, (size_t)a); }
+void operator delete(void *p) noexcept { free(p); }
+void operator delete[](void *p) noexcept { free(p); }
+void operator delete(void *p, size_t) noexcept { free(p); }
+void operator delete[](void *p, size_t) noexcept { free(p); }
+void operator delete(void *p, std::align_val_t) noexcept { free(p); }
+void operator delete[](void *p, std::align_val_t) noexcept { free(p); }
+void operator delete(void *p, size_t, std::align_val_t) noexcept { free(p); }
+void operator delete[](void *p, size_t, std::align_val_t) noexcept { free(p); }
+extern "C" uint64_t gmx_debug_fail_alloc(int64_t nth) {  // returns the library's allocation count so far
+  g_fail_alloc.store(nth, std::memory_order_relaxed);
+  return g_alloc_calls.load(std::memory_order_relaxed);
+}
 const gmx::HostIndex &gmx_index_host(const gmx_index *ix) { return ix->h; }
 uint64_t gmx_index_serial(const gmx_index *ix) { return ix->serial; }
 
@@ -82,7 +152,7 @@ static int index_build_owned(std::vector<uint32_t> &&v, uint32_t kmer_size, int 
   }
 }
 
-int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int threads, gmx_index **out) {
+int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int threads, gmx_index **out) try {
   if (!prg || !out) {
     gmx_set_error("gmx_index_build: null argument");
     return GMX_EINVAL;
@@ -93,9 +163,9 @@ int gmx_index_build(const uint32_t *prg, uint64_t n, uint32_t kmer_size, int thr
     gmx_set_error("out of memory while building the index");
     return GMX_ENOMEM;
   }
-}
+} GMX_GUARD_INT("gmx_index_build")
 
-int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads, gmx_index **out) {
+int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads, gmx_index **out) try {
   if (!path || !out) {
     gmx_set_error("gmx_index_build_from_file: null argument");
     return GMX_EINVAL;
@@ -109,9 +179,9 @@ int gmx_index_build_from_file(const char *path, uint32_t kmer_size, int threads,
     gmx_set_error(e.what());
     return GMX_EINVAL;
   }
-}
+} GMX_GUARD_INT("gmx_index_build_from_file")
 
-int gmx_index_save(const gmx_index *ix, const char *path) {
+int gmx_index_save(const gmx_index *ix, const char *path) try {
   if (!ix || !path) {
     gmx_set_error("gmx_index_save: null argument");
     return GMX_EINVAL;
@@ -123,9 +193,9 @@ int gmx_index_save(const gmx_index *ix, const char *path) {
     gmx_set_error(e.what());
     return GMX_EINVAL;
   }
-}
+} GMX_GUARD_INT("gmx_index_save")
 
-int gmx_index_load(const char *cache_path, const char *prg_path, uint32_t kmer_size, gmx_index **out) {
+int gmx_index_load(const char *cache_path, const char *prg_path, uint32_t kmer_size, gmx_index **out) try {
   if (!cache_path || !prg_path || !out) {
     gmx_set_error("gmx_index_load: null argument");
     return GMX_EINVAL;
@@ -148,11 +218,11 @@ int gmx_index_load(const char *cache_path, const char *prg_path, uint32_t kmer_s
     gmx_set_error(e.what());
     return GMX_EINVAL;
   }
-}
+} GMX_GUARD_INT("gmx_index_load")
 
 void gmx_index_destroy(gmx_index *ix) { delete ix; }
 
-int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
+int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) try {
   const gmx::HostIndex &h = ix->h;
   memset(o, 0, sizeof(*o));
   o->n_text = h.prg.size() + 1;
@@ -178,10 +248,10 @@ int gmx_index_get_info(const gmx_index *ix, gmx_index_info *o) {
                    h.edges.size() + h.seed_words.size() + h.kmer_bitmap.size()) * 4 + h.seeds2.size() * sizeof(GmxSeed) + h.nodes.size() * sizeof(GmxNode) +
                    h.sites.size() * (sizeof(GmxSite) + sizeof(GmxSiteGeo)) + h.seeds.size() * sizeof(GmxSeed);
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_index_get_info")
 
 int gmx_index_site_layout(const gmx_index *ix, uint32_t *n_alleles, uint32_t *allele_sum_off, uint32_t *grouped_off,
-                          uint32_t *parent_site, int32_t *parent_allele) {
+                          uint32_t *parent_site, int32_t *parent_allele) try {
   const auto &s = ix->h.sites;
   for (size_t i = 0; i < s.size(); ++i) {
     if (n_alleles) n_alleles[i] = s[i].n_alleles;
@@ -191,9 +261,9 @@ int gmx_index_site_layout(const gmx_index *ix, uint32_t *n_alleles, uint32_t *al
     if (parent_allele) parent_allele[i] = s[i].parent_allele;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_index_site_layout")
 
-int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t cap) {
+int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t cap) try {
   const auto &h = ix->h;
   uint64_t n = 0;
   for (size_t i = 0; i + 1 < h.nodes.size(); ++i) {
@@ -210,10 +280,10 @@ int64_t gmx_index_per_base_layout(const gmx_index *ix, uint32_t *out, uint64_t c
     ++n;
   }
   return (int64_t)n;
-}
+} GMX_GUARD_INT("gmx_index_per_base_layout")
 
 // allele_base_non_nested (allele_base.cpp:10-38): one slice per (site, allele); direct deletions have length 0.
-int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t *len) {
+int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t *len) try {
   const auto &h = ix->h;
   if (h.is_nested) {
     gmx_set_error("allele_base_non_nested is empty by convention for nested PRGs");
@@ -235,7 +305,7 @@ int gmx_index_allele_base_layout(const gmx_index *ix, uint32_t *pb_off, uint32_t
     }
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_index_allele_base_layout")
 
 static std::vector<uint32_t> bubble_order(const gmx::HostIndex &h) {
   std::vector<uint32_t> order(h.sites.size());
@@ -247,14 +317,14 @@ static std::vector<uint32_t> bubble_order(const gmx::HostIndex &h) {
   return order;
 }
 
-int gmx_index_bubble_order(const gmx_index *ix, uint32_t *out) {
+int gmx_index_bubble_order(const gmx_index *ix, uint32_t *out) try {
   auto o = bubble_order(ix->h);
   for (size_t i = 0; i < o.size(); ++i) out[i] = 5 + 2 * o[i];
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_index_bubble_order")
 
 int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw, const uint32_t *grouped_raw,
-                               const uint32_t *glog, uint64_t n_log, gmx_depth_stats *out) {
+                               const uint32_t *glog, uint64_t n_log, gmx_depth_stats *out) try {
   const gmx::HostIndex &h = ix->h;
   // per-site haplogroup totals in uint16 arithmetic (get_max_cov_haplogroup, read_stats.cpp:72-92)
   std::vector<std::map<int32_t, uint16_t>> hap(h.sites.size());
@@ -350,9 +420,9 @@ int gmx_compute_coverage_depth(const gmx_index *ix, const uint32_t *per_base_raw
   out->num_sites_noCov = no_cov;
   out->num_sites_total = coverages.size();
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_compute_coverage_depth")
 
-int gmx_debug_suffix_array_u16(const uint16_t *text, uint64_t n, uint16_t *out) {
+int gmx_debug_suffix_array_u16(const uint16_t *text, uint64_t n, uint16_t *out) try {
   try {
     gmx::debug_suffix_array_u16(text, (size_t)n, out);
     return GMX_OK;
@@ -360,26 +430,26 @@ int gmx_debug_suffix_array_u16(const uint16_t *text, uint64_t n, uint16_t *out) 
     gmx_set_error(ex.what());
     return GMX_EINVAL;
   }
-}
+} GMX_GUARD_INT("gmx_debug_suffix_array_u16")
 
-int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out) {
+int gmx_index_copy_sa(const gmx_index *ix, uint32_t *out) try {
   memcpy(out, ix->h.sa.data(), ix->h.sa.size() * 4);
   return GMX_OK;
-}
-int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out) {
+} GMX_GUARD_INT("gmx_index_copy_sa")
+int gmx_index_copy_bwt(const gmx_index *ix, uint32_t *out) try {
   if (ix->h.bwt.empty()) {  // (dropped by the builder on PRGs of 2^28 symbols and more: GMX_INDEX_INTROSPECTION=1 keeps it)
     gmx_set_error("this index was built without its introspection tables (GMX_INDEX_INTROSPECTION=1 keeps them)");
     return GMX_EINVAL;
   }
   memcpy(out, ix->h.bwt.data(), ix->h.bwt.size() * 4);
   return GMX_OK;
-}
-uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base) {
+} GMX_GUARD_INT("gmx_index_copy_bwt")
+uint32_t gmx_index_rank(const gmx_index *ix, uint32_t upper, uint32_t base) try {
   if (base < 1 || base > 4) return 0;
   GmxIndexView v = ix->h.view();
   return gmx_rank(v, upper, base);
-}
-int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out) {
+} GMX_GUARD_ZERO("gmx_index_rank")
+int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out) try {
   const auto &h = ix->h;
   if (h.pos_target.size() != h.prg.size()) {
     gmx_set_error("this index was built without its introspection tables (GMX_INDEX_INTROSPECTION=1 keeps them)");
@@ -394,8 +464,8 @@ int gmx_index_copy_pos_info(const gmx_index *ix, int64_t *out) {
     out[5 * p + 4] = h.pos_target[p].second;
   }
   return GMX_OK;
-}
-int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t cap) {
+} GMX_GUARD_INT("gmx_index_copy_pos_info")
+int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t cap) try {
   std::vector<int64_t> v{(int64_t)ix->h.target_map.size()};
   for (auto &e : ix->h.target_map) {
     v.push_back(e.first);
@@ -408,11 +478,11 @@ int64_t gmx_index_copy_target_map(const gmx_index *ix, int64_t *out, uint64_t ca
   if (v.size() > cap) return -(int64_t)v.size();
   std::copy(v.begin(), v.end(), out);
   return (int64_t)v.size();
-}
-int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap) {
+} GMX_GUARD_INT("gmx_index_copy_target_map")
+int64_t gmx_index_seed_states(const gmx_index *ix, const uint8_t *kmer, int64_t *out, uint64_t cap) try {
   return gmx_index_seed_states_k(ix, kmer, ix->h.kmer_size, out, cap);
-}
-int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32_t len, int64_t *out, uint64_t cap) {
+} GMX_GUARD_INT("gmx_index_seed_states")
+int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32_t len, int64_t *out, uint64_t cap) try {
   const auto &h = ix->h;
   if (len == 0 || (len != h.kmer_size && len != h.kmer_size2)) return GMX_EINVAL;
   uint32_t code = 0;
@@ -424,8 +494,8 @@ int64_t gmx_index_seed_states_k(const gmx_index *ix, const uint8_t *kmer, uint32
   if (v.size() > cap) return -(int64_t)v.size();
   std::copy(v.begin(), v.end(), out);
   return (int64_t)v.size();
-}
-int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int64_t *out, uint64_t cap) {
+} GMX_GUARD_INT("gmx_index_seed_states_k")
+int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int64_t *out, uint64_t cap) try {
   const auto &h = ix->h;
   GmxIndexView v = h.view();
   ProbeCtx ctx;
@@ -453,10 +523,10 @@ int64_t gmx_index_jump_states(const gmx_index *ix, uint32_t lo, uint32_t hi, int
   if (r.size() > cap) return -(int64_t)r.size();
   std::copy(r.begin(), r.end(), out);
   return (int64_t)r.size();
-}
+} GMX_GUARD_INT("gmx_index_jump_states")
 
 // quasimap.cpp:120-141 + random.hpp:20: raw mt19937 outputs, 5000 per batch of <= 5000 reads
-int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out) {
+int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint64_t n_files, uint32_t *out) try {
   uint32_t mt[624];
   mt[0] = master_seed;
   for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
@@ -484,14 +554,14 @@ int gmx_master_seeds(uint32_t master_seed, const uint64_t *reads_per_file, uint6
         if (start + i < reads_per_file[f]) out[o++] = s;
       }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_master_seeds")
 
 // ---- bit planes of encoded reads on the host (the form gmx_map_reads_packed_host uploads as it is) -------------------
-uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) {
+uint64_t gmx_packed_pairs(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) try {
   if (uniform_len) return n_reads * (uint64_t)((uniform_len + 31u) / 32u);
   if (!offsets) return 0;
   return ((offsets[n_reads] >> 5) - (offsets[0] >> 5)) + n_reads;
-}
+} GMX_GUARD_ZERO("gmx_packed_pairs")
 
 namespace {
 // 8 encoded bases (bytes 1..4, base j in byte j) -> 8 bits of each plane; flags bytes outside 1..4 (gmx_pack_kernel's pack4)
@@ -532,7 +602,7 @@ inline bool pack_read(const uint8_t *p, uint32_t len, uint64_t *out) {
 }  // namespace
 
 int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *planes,
-                   uint8_t *skip, int threads) {
+                   uint8_t *skip, int threads) try {
   if ((!reads && n_reads) || !offsets || !planes) {
     gmx_set_error("gmx_pack_reads: null argument");
     return GMX_EINVAL;
@@ -562,23 +632,23 @@ int gmx_pack_reads(const uint8_t *reads, const uint64_t *offsets, uint32_t unifo
     (void)keep;
     for (unsigned t = 0; t < T; ++t) work(t);
   } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    GmxThreads th;  // (the workers only move bits between the caller's buffers: nothing in them throws)
+    for (unsigned t = 1; t < T; ++t) th.run([&work, t] { work(t); });
     work(0);
-    for (auto &x : th) x.join();
+    th.join();
   }
   (void)n_pairs;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_pack_reads")
 
 // ---- reads as a 2-bit stream (gmx_map_reads_2bit_host): base j of the batch in bits 2j, 2j + 1 of the stream -------------
-uint64_t gmx_twobit_units(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) {
+uint64_t gmx_twobit_units(const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads) try {
   const uint64_t bases = uniform_len ? n_reads * (uint64_t)uniform_len : (offsets ? offsets[n_reads] - offsets[0] : 0);
   return (bases + 31) / 32 + 1;  // (+ 1: the unit the device reads ahead of a chunk's last base)
-}
+} GMX_GUARD_ZERO("gmx_twobit_units")
 
 int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t uniform_len, uint64_t n_reads, uint64_t *stream,
-                        uint8_t *skip, int threads) {
+                        uint8_t *skip, int threads) try {
   if ((!reads && n_reads) || !offsets || !stream) {
     gmx_set_error("gmx_pack_reads_2bit: null argument");
     return GMX_EINVAL;
@@ -609,19 +679,19 @@ int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t 
   if (T == 1 || n_reads < 4096) {
     for (unsigned t = 0; t < T; ++t) work(t);
   } else {
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    GmxThreads th;  // (the workers only move bits between the caller's buffers: nothing in them throws)
+    for (unsigned t = 1; t < T; ++t) th.run([&work, t] { work(t); });
     work(0);
-    for (auto &x : th) x.join();
+    th.join();
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_pack_reads_2bit")
 
 // ---- grouped logs as values: what every rank does with the all-gathered logs of an exchange (gmx_multi.hip) -----------
 // `gathered` holds `world` slices of `pad` words, slice r carrying sizes[r] words of rank r's log (either record form,
 // GMX_LOG_PAD words skipped); the result is one counted record per distinct (site, ids), in key order.
 int64_t gmx_grouped_log_merge_gathered(const uint32_t *gathered, const uint64_t *sizes, int world, uint64_t pad, uint32_t *out,
-                                       uint64_t cap_words) {
+                                       uint64_t cap_words) try {
   if ((!gathered && pad) || !sizes || world < 0) {
     gmx_set_error("gmx_grouped_log_merge_gathered: null argument");
     return GMX_EINVAL;
@@ -670,10 +740,10 @@ int64_t gmx_grouped_log_merge_gathered(const uint32_t *gathered, const uint64_t 
     at += words;
   }
   return (int64_t)at;
-}
+} GMX_GUARD_INT("gmx_grouped_log_merge_gathered")
 
-void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate) {
+void gmx_finalize_u16(uint32_t *values, uint64_t n, int saturate) try {
   for (uint64_t i = 0; i < n; ++i) values[i] = saturate ? (values[i] > 65535u ? 65535u : values[i]) : (values[i] & 0xFFFFu);
-}
+} GMX_GUARD_VOID("gmx_finalize_u16")
 
 }  // extern "C"

@@ -197,16 +197,16 @@ void debug_pools_free(gmx_engine *e, GmxDebugPools &p) {
 
 extern "C" {
 
-int gmx_engine_debug_keep_states(gmx_engine *e, int on) {
+int gmx_engine_debug_keep_states(gmx_engine *e, int on) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
   }
   e->keep_states = on != 0;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_debug_keep_states")
 
-int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t cap_words, uint64_t *n_words, int *tier) {
+int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t cap_words, uint64_t *n_words, int *tier) try {
   if (!e || !n_words) {
     gmx_set_error("gmx_debug_final_states: null argument");
     return GMX_EINVAL;
@@ -313,10 +313,10 @@ int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t
   if (tier) *tier = 0;
   *n_words = w.n;
   return w.n > cap_words && out ? GMX_ECAP : GMX_OK;
-}
+} GMX_GUARD_INT("gmx_debug_final_states")
 
 int gmx_debug_search(gmx_engine *e, const uint8_t *read, uint32_t read_len, int from_seed_table, const uint32_t *states, uint64_t n_state_words,
-                     uint32_t from, uint32_t stop, int lf_only, uint32_t *out, uint64_t cap_words, uint64_t *n_words) {
+                     uint32_t from, uint32_t stop, int lf_only, uint32_t *out, uint64_t cap_words, uint64_t *n_words) try {
   if (!e || !read || !n_words || read_len == 0 || (!from_seed_table && (!states || n_state_words == 0 || from > read_len || stop > from))) {
     gmx_set_error("gmx_debug_search: bad argument");
     return GMX_EINVAL;
@@ -392,10 +392,10 @@ int gmx_debug_search(gmx_engine *e, const uint8_t *read, uint32_t read_len, int 
   }
   *n_words = w.n;
   return w.n > cap_words && out ? GMX_ECAP : GMX_OK;
-}
+} GMX_GUARD_INT("gmx_debug_search")
 
 int gmx_debug_encapsulate(gmx_engine *e, const uint32_t *states, uint64_t n_state_words, uint32_t *out, uint64_t cap_words, uint64_t *n_words,
-                          uint32_t *nonvariant_sa, uint64_t cap_nonvariant, uint64_t *n_nonvariant) {
+                          uint32_t *nonvariant_sa, uint64_t cap_nonvariant, uint64_t *n_nonvariant) try {
   if (!e || !states || n_state_words == 0 || !n_words || !n_nonvariant) {
     gmx_set_error("gmx_debug_encapsulate: bad argument");
     return GMX_EINVAL;
@@ -482,6 +482,6 @@ int gmx_debug_encapsulate(gmx_engine *e, const uint32_t *states, uint64_t n_stat
   *n_nonvariant = res[1];
   for (uint32_t i = 0; i < res[1] && nonvariant_sa && i < cap_nonvariant; ++i) nonvariant_sa[i] = res[2 + 6 * (size_t)cap_items + i];
   return (w.n > cap_words && out) || (nonvariant_sa && res[1] > cap_nonvariant) ? GMX_ECAP : GMX_OK;
-}
+} GMX_GUARD_INT("gmx_debug_encapsulate")
 
 }  // extern "C"

@@ -168,6 +168,7 @@ struct gmx_engine {
   int alloc(T **p, size_t count, bool zero) {
     void *q = nullptr;
     size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    allocs.reserve(allocs.size() + 1);  // (may throw BEFORE there is device memory to lose)
     HIP_TRY(hipMalloc(&q, bytes));
     if (zero) HIP_TRY(hipMemset(q, 0, bytes));
     allocs.push_back(q);
@@ -304,7 +305,7 @@ static void launch_cover_coop(gmx_engine *e, hipStream_t stream, const BatchView
 
 extern "C" {
 
-void gmx_engine_default_opts(gmx_engine_opts *o) {
+void gmx_engine_default_opts(gmx_engine_opts *o) try {
   o->device = 0;
   o->rng_mode = GMX_RNG_LEMIRE;
   o->max_states = 1024;
@@ -313,7 +314,7 @@ void gmx_engine_default_opts(gmx_engine_opts *o) {
   o->forward_only = 0;
   o->huge_heap_bytes = 512ull << 20;
   o->log_cap_words = 0;
-}
+} GMX_GUARD_VOID("gmx_engine_default_opts")
 
 static int ensure_batch_capacity(gmx_engine *e, uint64_t n_reads) {
   if (n_reads <= e->cap_reads) return GMX_OK;
@@ -402,7 +403,7 @@ static void gmx_dev_index_release(GmxDeviceIndex *d) {
   delete d;
 }
 
-int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine **out) {
+int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine **out) try {
   if (!ixh || !out) {
     gmx_set_error("gmx_engine_create: null argument");
     return GMX_EINVAL;
@@ -637,9 +638,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   }
   *out = e;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_create")
 
-void gmx_engine_destroy(gmx_engine *e) {
+void gmx_engine_destroy(gmx_engine *e) try {
   if (!e) return;
   (void)hipSetDevice(e->opts.device);
   (void)hipDeviceSynchronize();
@@ -668,9 +669,9 @@ void gmx_engine_destroy(gmx_engine *e) {
   for (void *p : e->allocs) (void)hipFree(p);
   gmx_dev_index_release(e->shared_index);
   delete e;
-}
+} GMX_GUARD_VOID("gmx_engine_destroy")
 
-int gmx_engine_reset(gmx_engine *e) {
+int gmx_engine_reset(gmx_engine *e) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   e->reset_pending = false;
   HIP_TRY(hipDeviceSynchronize());
@@ -681,9 +682,9 @@ int gmx_engine_reset(gmx_engine *e) {
   e->log_known = e->log_reads_since = 0;
   e->log_state_pending = false;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_reset")
 
-int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
+int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   hipStream_t st = (hipStream_t)hip_stream;
   int frc = flush_reset(e);  // (an earlier one still pending, on whatever stream it named)
@@ -694,7 +695,7 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) {
   e->log_known = e->log_reads_since = 0;
   e->log_state_pending = false;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_reset_async")
 
 static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass,
                           hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
@@ -1105,7 +1106,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
 }
 
 int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *d_offsets, const uint32_t *d_seeds,
-                         uint64_t n_reads, uint64_t total_bases, void *hip_stream) {
+                         uint64_t n_reads, uint64_t total_bases, void *hip_stream) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1130,7 +1131,7 @@ int gmx_map_reads_device(gmx_engine *e, const uint8_t *d_reads, const uint64_t *
   // without log sites — every dense-count index — stay asynchronous).
   if (e->log_sites) return log_settle(e);
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_map_reads_device")
 
 // Is [p, p + bytes) page-locked memory the runtime can DMA from asynchronously (gmx_host_alloc, hipHostMalloc, registered)?
 static bool gmx_is_pinned(const void *p) {
@@ -1159,6 +1160,7 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
     return false;
   };
   uint64_t done = 0;
+  try {  // (an exception — host memory — must not skip the epilogue: the caller's buffer is registered, copies are in flight)
   for (uint32_t i = 0; done < n_reads && rc == GMX_OK; ++i) {
     gmx_engine::StageSlot &sl = e->stage[i & 1];
     const uint64_t n = std::min<uint64_t>(chunk, n_reads - done);
@@ -1219,6 +1221,9 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
     sl.busy = true;
     done += n;
   }
+  } catch (...) {
+    rc = gmx_guard_catch("gmx_map_reads_host");
+  }
   // common epilogue, error or not: nothing in flight reads the caller's buffer, the slots are idle, the buffer is unregistered
   (void)hipStreamSynchronize(e->copy_stream);
   (void)hipDeviceSynchronize();
@@ -1230,7 +1235,7 @@ static int map_reads_host_pipelined(gmx_engine *e, const uint8_t *reads, const u
 
 static uint64_t gmx_feed_chunk(const gmx_engine *e);  // reads per launch of the host feeds (below)
 int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds,
-                       uint64_t n_reads) {
+                       uint64_t n_reads) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1278,7 +1283,7 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
     done += n;
   }
   return gmx_engine_sync(e);
-}
+} GMX_GUARD_INT("gmx_map_reads_host")
 
 // planes: the bit planes (twobit = false) or the 2-bit stream as 32-bit words (twobit = true; gmx_map_reads_2bit_host)
 static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool twobit, const uint64_t *offsets, uint32_t uniform_len,
@@ -1325,6 +1330,7 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
     rc = GMX_EHIP;
     return false;
   };
+  try {  // (as above: the epilogue unregisters the caller's buffers and waits for the copies that read them)
   for (uint64_t done = 0; done < n_reads && rc == GMX_OK;) {
     gmx_engine::PackSlot &sl = e->pslot[e->pslot_next];
     e->pslot_next = (e->pslot_next + 1) % 3;
@@ -1399,6 +1405,9 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
     sl.busy = true;
     done += n;
   }
+  } catch (...) {
+    rc = gmx_guard_catch(twobit ? "gmx_map_reads_2bit_host" : "gmx_map_reads_packed_host");
+  }
   // common epilogue: a failed call, or one that registered memory, leaves nothing in flight that reads the caller's buffers
   if (rc != GMX_OK || !all_pinned) {
     (void)hipStreamSynchronize(e->copy_stream);
@@ -1415,9 +1424,9 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
 }
 
 int gmx_map_reads_packed_host(gmx_engine *e, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
-                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+                              const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) try {
   return map_reads_packed_impl(e, planes, false, offsets, uniform_len, seeds, skip, n_reads);
-}
+} GMX_GUARD_INT("gmx_map_reads_packed_host")
 
 // Reads per launch of the host / device-plane feeds: the whole call, up to max_batch_reads (4 M). Every batch ends with a tail
 // of few-lane kernels — on a NESTED PRG with ~2 ms of a few straggler tasks (reads inside MSA regions: hundreds of dependent
@@ -1433,7 +1442,7 @@ static uint64_t gmx_feed_chunk(const gmx_engine *e) {
 
 // bit planes already in HBM (gmx_ingest_*): nothing to upload; seeds in device memory, or page-locked and read in place
 int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const uint64_t *d_offsets, uint32_t uniform_len,
-                                const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads) {
+                                const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads) try {
   if (!e || !d_planes || !seeds || (!d_offsets && !uniform_len)) {
     gmx_set_error("gmx_map_reads_packed_device: null argument (d_offsets may be null only with uniform_len)");
     return GMX_EINVAL;
@@ -1471,23 +1480,23 @@ int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const u
     done += n;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_map_reads_packed_device")
 
 int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_t *offsets, uint32_t uniform_len, const uint32_t *seeds,
-                            const uint8_t *skip, uint64_t n_reads) {
+                            const uint8_t *skip, uint64_t n_reads) try {
   return map_reads_packed_impl(e, stream, true, offsets, uniform_len, seeds, skip, n_reads);
-}
+} GMX_GUARD_INT("gmx_map_reads_2bit_host")
 
-int gmx_engine_seeds_in_place(gmx_engine *e, int on) {
+int gmx_engine_seeds_in_place(gmx_engine *e, int on) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
   }
   e->seeds_in_place = on != 0;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_seeds_in_place")
 
-int gmx_engine_sync_uploads(gmx_engine *e) {
+int gmx_engine_sync_uploads(gmx_engine *e) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1504,7 +1513,7 @@ int gmx_engine_sync_uploads(gmx_engine *e) {
     HIP_TRY(gmx_event_wait(e->ev_wait));
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_sync_uploads")
 
 // page-locked allocations are remembered so that gmx_host_free knows which call returns them. Freed page-locked blocks
 // of 1 MB or more are kept (up to 16 of them) and handed out again: pinning and unpinning 100 MB costs 10-20 ms each
@@ -1516,7 +1525,7 @@ struct HostBlock {
 };
 static std::map<void *, HostBlock> g_host_live;
 static std::vector<std::pair<void *, uint64_t>> g_host_spare;  // pinned blocks waiting for reuse
-void *gmx_host_alloc(uint64_t bytes) {
+void *gmx_host_alloc(uint64_t bytes) try {
   bytes = std::max<uint64_t>(bytes, 1);
   {
     std::lock_guard<std::mutex> lk(g_host_mu);
@@ -1544,8 +1553,8 @@ void *gmx_host_alloc(uint64_t bytes) {
     g_host_live[p] = HostBlock{bytes, pinned};
   }
   return p;
-}
-void gmx_host_free(void *p) {
+} GMX_GUARD_PTR("gmx_host_alloc")
+void gmx_host_free(void *p) try {
   if (!p) return;
   HostBlock blk{0, false};
   {
@@ -1563,11 +1572,11 @@ void gmx_host_free(void *p) {
     (void)hipHostFree(p);
   else
     free(p);
-}
+} GMX_GUARD_VOID("gmx_host_free")
 
 // Sizes the batch workspace and the staging buffers of the _host entry point ahead of the first call (otherwise the first
 // call allocates them, and a later, larger call allocates them again).
-int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) {
+int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1590,11 +1599,11 @@ int gmx_engine_reserve(gmx_engine *e, uint64_t n_reads, uint64_t n_bases) {
     e->cap_stage_reads = n_reads;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_reserve")
 
 // The same for gmx_map_reads_packed_host: the batch workspace, the copy stream and the three upload slots (bit planes,
 // offsets, seeds, skip flags) for chunks of up to n_reads reads / n_pairs plane pairs.
-int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs) {
+int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1632,9 +1641,9 @@ int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs)
     }
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_reserve_packed")
 
-int gmx_engine_sync(gmx_engine *e) {
+int gmx_engine_sync(gmx_engine *e) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   {
     int frc = flush_reset(e);
@@ -1677,14 +1686,14 @@ int gmx_engine_sync(gmx_engine *e) {
     return GMX_EREF;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_sync")
 
-int gmx_engine_enable_timing(gmx_engine *e, int on) {
+int gmx_engine_enable_timing(gmx_engine *e, int on) try {
   e->timing = on != 0;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_enable_timing")
 
-int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
+int gmx_engine_timing(gmx_engine *e, gmx_timing *out) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   for (auto &ev : e->pending) {
     HIP_TRY(hipEventSynchronize(ev.c));
@@ -1728,9 +1737,9 @@ int gmx_engine_timing(gmx_engine *e, gmx_timing *out) {
   e->search_ms = e->cover_ms = 0;
   e->search_launches = e->cover_launches = e->timed_reads = 0;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_timing")
 
-int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
+int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
   uint32_t raw[GMX_N_COUNTERS * GMX_CNT_STRIDE];
@@ -1754,9 +1763,9 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) {
   out->log_replays = e->log_replays;
   out->log_replayed_entries = e->log_replayed_entries;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_engine_queue_counts")
 
-int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
+int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) try {
   {
     int frc = flush_reset(e);
     if (frc) return frc;
@@ -1770,9 +1779,9 @@ int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) {
   out->fused = e->d_fused;
   out->n_fused = e->n_fused;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_coverage_device")
 
-int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
+int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1786,9 +1795,9 @@ int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) {
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 0);
   HIP_TRY(hipGetLastError());
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_coverage_reduce_begin")
 
-int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
+int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1801,9 +1810,9 @@ int gmx_coverage_reduce_end(gmx_engine *e, void *hip_stream) {
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 1);
   HIP_TRY(hipGetLastError());
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_coverage_reduce_end")
 
-int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) {
+int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, uint32_t *grouped, gmx_stats *stats) try {
   if (!e) {
     gmx_set_error("null engine");
     return GMX_EINVAL;
@@ -1836,9 +1845,9 @@ int gmx_coverage_fetch(gmx_engine *e, uint32_t *allele_sum, uint32_t *per_base, 
     stats->exact_mapped_reads_count = s[4];
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_coverage_fetch")
 
-int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words) {
+int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t cap_words) try {
   if (!e) return GMX_EINVAL;
   if (hipSetDevice(e->opts.device) != hipSuccess) return GMX_EHIP;
   if (log_settle(e)) return GMX_EHIP;
@@ -1856,9 +1865,9 @@ int64_t gmx_coverage_fetch_grouped_log(gmx_engine *e, uint32_t *out, uint64_t ca
     n += words;
   }
   return (int64_t)n;
-}
+} GMX_GUARD_INT("gmx_coverage_fetch_grouped_log")
 
-int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace) {
+int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint64_t n_words, int replace) try {
   if (!e || (!records && n_words)) {
     gmx_set_error("gmx_coverage_import_grouped_log: null argument");
     return GMX_EINVAL;
@@ -1869,7 +1878,7 @@ int gmx_coverage_import_grouped_log(gmx_engine *e, const uint32_t *records, uint
   }
   HIP_TRY(hipSetDevice(e->opts.device));
   return gmx_engine_log_import(e, records, (size_t)n_words, replace != 0);
-}
+} GMX_GUARD_INT("gmx_coverage_import_grouped_log")
 
 }  // extern "C"
 

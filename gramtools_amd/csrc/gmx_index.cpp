@@ -19,6 +19,7 @@
 #include <unordered_map>
 
 #include "gmx_core.h"
+#include "gmx_internal.h"
 
 namespace gmx {
 
@@ -167,16 +168,28 @@ static void par_for(size_t n_items, unsigned threads, F fn) {
     return;
   }
   std::atomic<size_t> next{0};
-  std::vector<std::thread> pool;
-  for (unsigned w = 0; w < threads; ++w)
-    pool.emplace_back([&]() {
-      for (;;) {
-        const size_t i = next.fetch_add(1);
-        if (i >= n_items) break;
-        fn(i);
-      }
-    });
-  for (auto &t : pool) t.join();
+  // an exception in a worker (std::bad_alloc at whole-genome scale) ends the loop and is thrown again on the caller's thread:
+  // out of a thread's function it would end the process, and so would the destructor of a thread not yet joined
+  std::exception_ptr first;
+  std::mutex first_mu;
+  {
+    GmxThreads pool;
+    for (unsigned w = 0; w < threads; ++w)
+      pool.run([&]() {
+        try {
+          for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_items) break;
+            fn(i);
+          }
+        } catch (...) {
+          next.store(n_items);
+          std::lock_guard<std::mutex> lk(first_mu);
+          if (!first) first = std::current_exception();
+        }
+      });
+  }
+  if (first) std::rethrow_exception(first);
 }
 
 // Parallel suffix sort for the PRG texts of this engine (round 3): suffixes are bucketed by the class of their first eight
@@ -1367,6 +1380,8 @@ static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, in
           progs_bwt[mi] = prog_off;
           out.hits[mi] = hit;
         }
+      } catch (std::bad_alloc const &) {
+        throw;  // (par_for hands it to the caller's thread: GMX_ENOMEM, not a message in a runtime_error)
       } catch (std::exception const &e) {
         ck.error = e.what();
       }
@@ -1583,6 +1598,8 @@ static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, in
           if (level[i].list.empty()) return;
           try {
             seed_step_parallel(ix, level[i], d > 0, &next[4 * i], 1);
+          } catch (std::bad_alloc const &) {
+            throw;  // (par_for hands it to the caller's thread: GMX_ENOMEM, not a message in a runtime_error)
           } catch (std::exception const &e) {
             std::lock_guard<std::mutex> lock(mu);
             if (first_error.empty()) first_error = e.what();
@@ -1632,6 +1649,8 @@ static void build_index_impl(HostIndex &out, uint32_t kmer_size, int threads, in
         node.arena.swap(level[task].arena);
         seed_walk(ix, tb, split, split ? task << (2 * (16 - split)) : 0u, node.list, node.arena, tk);
         t_dfs[task] = now() - tc;
+      } catch (std::bad_alloc const &) {
+        throw;  // (par_for hands it to the caller's thread: GMX_ENOMEM, not a message in a runtime_error)
       } catch (std::exception const &e) {
         errors[task] = e.what();
       }

@@ -50,17 +50,18 @@ void par_ranges(size_t n, size_t min_per_part, F fn) {
     fn((size_t)0, n, (size_t)0);
     return;
   }
-  std::vector<std::thread> th;
   std::vector<std::exception_ptr> err(parts);
-  for (size_t p = 0; p < parts; ++p)
-    th.emplace_back([&, p]() {
-      try {
-        fn(n * p / parts, n * (p + 1) / parts, p);
-      } catch (...) {
-        err[p] = std::current_exception();
-      }
-    });
-  for (auto &t : th) t.join();
+  {
+    GmxThreads th;  // (joined also when a thread cannot be started)
+    for (size_t p = 0; p < parts; ++p)
+      th.run([&, p]() {
+        try {
+          fn(n * p / parts, n * (p + 1) / parts, p);
+        } catch (...) {
+          err[p] = std::current_exception();
+        }
+      });
+  }
   for (auto &e : err)
     if (e) std::rethrow_exception(e);
 }
@@ -941,7 +942,7 @@ extern "C" {
 
 int gmx_infer_run(const gmx_index *ix, const uint32_t *per_base_raw, const uint32_t *grouped_dense_raw, const uint32_t *grouped_log,
                   uint64_t n_log_words, double mean_cov_depth, double variance_cov_depth, double mean_pb_error, int ploidy,
-                  gmx_infer **out) {
+                  gmx_infer **out) try {
   if (!ix || !out || (ploidy != 1 && ploidy != 2)) return fail("gmx_infer_run: bad argument (ploidy is 1 or 2)");
   const gmx::HostIndex &h = gmx_index_host(ix);
   try {
@@ -963,26 +964,26 @@ int gmx_infer_run(const gmx_index *ix, const uint32_t *per_base_raw, const uint3
   } catch (std::exception const &ex) {
     return fail(std::string("genotyping: ") + ex.what(), GMX_EREF);
   }
-}
+} GMX_GUARD_INT("gmx_infer_run")
 
 void gmx_infer_destroy(gmx_infer *inf) { delete inf; }
 
 // One site as the jVCF site object (tests, and the unit the JSON writer is made of). Returns the length needed.
 // site_gtyping_debug_info.txt (`--debug`; genotype/parameters.cpp:98, runner.cpp:66-75): returns the length, copies when it fits.
-int64_t gmx_infer_debug_text(const gmx_infer *inf, char *out, uint64_t cap) {
+int64_t gmx_infer_debug_text(const gmx_infer *inf, char *out, uint64_t cap) try {
   if (!inf || !inf->g) return fail("null genotyper");
   const std::string &t = inf->g->debug_text;
   if (out && cap > t.size()) memcpy(out, t.c_str(), t.size() + 1);
   return (int64_t)t.size();
-}
+} GMX_GUARD_INT("gmx_infer_debug_text")
 
-int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out, uint64_t cap) {
+int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out, uint64_t cap) try {
   if (!inf || site_index >= inf->g->recs.size()) return fail("gmx_infer_site_json: bad argument");
   const Site &s = *inf->g->recs[site_index];
   const std::string js = site_json(s, nullptr, s.pos + 1);
   if (out && cap > js.size()) memcpy(out, js.c_str(), js.size() + 1);
   return (int64_t)js.size();
-}
+} GMX_GUARD_INT("gmx_infer_site_json")
 
 // The likelihood model on explicit data (known-answer tests of level_genotyping/test_model.cpp): alleles as
 // (sequence, per-base coverage, haplogroup, callable), grouped counts as (ids, count). Writes the site as JSON plus
@@ -990,7 +991,7 @@ int64_t gmx_infer_site_json(const gmx_infer *inf, uint32_t site_index, char *out
 int64_t gmx_infer_model(uint32_t n_alleles, const char *const *seqs, const uint32_t *pb_off, const uint32_t *pb_cov,
                         const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
                         const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
-                        double mean_pb_error, char *out, uint64_t cap) {
+                        double mean_pb_error, char *out, uint64_t cap) try {
   try {
     Alleles als(n_alleles);
     for (uint32_t i = 0; i < n_alleles; ++i) {
@@ -1018,7 +1019,7 @@ int64_t gmx_infer_model(uint32_t n_alleles, const char *const *seqs, const uint3
   } catch (std::exception const &ex) {
     return fail(std::string("genotyping model: ") + ex.what(), GMX_EREF);
   }
-}
+} GMX_GUARD_INT("gmx_infer_model")
 
 // Test hook: the model's pieces one by one, as the reference's unit tests call them (tests/genotype/infer/level_genotyping/
 // test_model.cpp). Inputs as gmx_infer_model, plus `ids` (meaning per op) and, for GMX_DBG_CALL, a likelihood map.
@@ -1034,7 +1035,7 @@ int64_t gmx_infer_debug(int op, uint32_t n_alleles, const char *const *seqs, con
                         const int32_t *haplogroups, const uint8_t *callable, uint32_t n_groups, const uint32_t *group_off,
                         const int32_t *group_ids, const uint32_t *group_counts, int ploidy, double mean_cov, double var_cov,
                         double mean_pb_error, const int32_t *ids, uint32_t n_ids, const double *lik, const uint32_t *lik_off,
-                        const int32_t *lik_gt, uint32_t n_lik, char *out, uint64_t cap) {
+                        const int32_t *lik_gt, uint32_t n_lik, char *out, uint64_t cap) try {
   try {
     Alleles als(n_alleles);
     for (uint32_t i = 0; i < n_alleles; ++i) {
@@ -1139,12 +1140,12 @@ int64_t gmx_infer_debug(int op, uint32_t n_alleles, const char *const *seqs, con
   } catch (std::exception const &ex) {
     return fail(std::string("genotyping model: ") + ex.what(), GMX_EREF);
   }
-}
+} GMX_GUARD_INT("gmx_infer_debug")
 
 // Test hook for the segment tracker (output_specs/segment_tracker.hpp; tests/genotype/infer/test_segment_tracker.cpp): `coords` =
 // the text of prg_coords.tsv, `script` = commands separated by ';': "id N", "rel N", "edge", "global_edge", "reset". JSON list
 // of the answers; a command on which the reference asserts ends the script with GMX_EREF.
-int64_t gmx_infer_segments_debug(const char *coords, const char *script, char *out, uint64_t cap) {
+int64_t gmx_infer_segments_debug(const char *coords, const char *script, char *out, uint64_t cap) try {
   try {
     std::istringstream in(coords ? coords : "");
     Tracker tr(&in);
@@ -1179,14 +1180,14 @@ int64_t gmx_infer_segments_debug(const char *coords, const char *script, char *o
   } catch (std::exception const &ex) {
     return fail(std::string("segment tracker: ") + ex.what(), GMX_EREF);
   }
-}
+} GMX_GUARD_INT("gmx_infer_segments_debug")
 
 // Test hook for the allele extracter (infer/allele_extracter.cpp; known answers of tests/genotype/infer/test_allele_extracter.cpp).
 // Alleles travel as text "SEQ/c,c,c/haplogroup/callable;...": `existing` for op 2; `mocks` = one line per already-genotyped
 // child site: "site_index|g,g (-1 = null)|alleles|extra alleles ('-' = none)". per_base NULL = zero coverage everywhere.
 //   0  AlleleExtracter(site).get_alleles()        1  extract_ref_allele(site)        2  allele_combine(existing, site)
 int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index, const uint32_t *per_base_raw, const char *existing,
-                                const char *mocks, char *out, uint64_t cap) {
+                                const char *mocks, char *out, uint64_t cap) try {
   try {
     const gmx::HostIndex &h = gmx_index_host(ix);
     if (site_index >= h.sites.size()) return fail("gmx_infer_extract_debug: no such site");
@@ -1282,10 +1283,10 @@ int64_t gmx_infer_extract_debug(const gmx_index *ix, int op, uint32_t site_index
   } catch (std::exception const &ex) {
     return fail(std::string("allele extraction: ") + ex.what(), GMX_EREF);
   }
-}
+} GMX_GUARD_INT("gmx_infer_extract_debug")
 
 // genotype/genotyped.json (genotype.cpp:97-105; make_json.cpp, json_prg_spec.cpp). coords_path: gram_dir/prg_coords.tsv or NULL.
-int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path) {
+int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path) try {
   if (!inf || !out_path) return fail("gmx_infer_write_json: bad argument");
   const Genotyper &g = *inf->g;
   std::ifstream coords;
@@ -1352,10 +1353,10 @@ int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const ch
   o << "]}" << std::endl;
   o.close();
   return o.good() || !o.fail() ? GMX_OK : fail(std::string("error writing ") + out_path);
-}
+} GMX_GUARD_INT("gmx_infer_write_json")
 
 // genotype/genotyped.vcf.gz (make_vcf.cpp:8-149): level-1 sites only, one sample
-int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path) {
+int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const char *sample_id, const char *out_path) try {
   if (!inf || !out_path) return fail("gmx_infer_write_vcf: bad argument");
   const Genotyper &g = *inf->g;
   std::ifstream coords;
@@ -1416,10 +1417,10 @@ int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const cha
   for (auto const &ps : part) z.write(ps);
   z.close();
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_infer_write_vcf")
 
 // genotype/personalised_reference.fasta (personalised_reference.cpp:8-151; genotype.cpp:16-21 dedups by sequence)
-int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const char *description, const char *out_path) {
+int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const char *description, const char *out_path) try {
   if (!inf || !out_path) return fail("gmx_infer_write_fasta: bad argument");
   const Genotyper &g = *inf->g;
   const gmx::HostIndex &h = g.h;
@@ -1519,6 +1520,6 @@ int gmx_infer_write_fasta(const gmx_infer *inf, const char *coords_path, const c
     o << std::endl;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_infer_write_fasta")
 
 }  // extern "C"

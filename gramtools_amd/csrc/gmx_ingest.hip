@@ -1141,7 +1141,7 @@ static hipError_t ing_inflate_stream_create(hipStream_t *st) {
   return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least);
 }
 
-int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
+int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) try {
   if (!out || max_text_bytes < (1u << 16) || max_text_bytes > (3ull << 30)) {
     gmx_set_error("gmx_ingest_create: max_text_bytes must lie between 64 KB and 3 GB");
     return GMX_EINVAL;
@@ -1194,9 +1194,9 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) {
   }
   *out = g;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_create")
 
-void gmx_ingest_destroy(gmx_ingest *g) {
+void gmx_ingest_destroy(gmx_ingest *g) try {
   if (!g) return;
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
@@ -1226,19 +1226,19 @@ void gmx_ingest_destroy(gmx_ingest *g) {
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
   (void)hipGetLastError();
   delete g;
-}
+} GMX_GUARD_VOID("gmx_ingest_destroy")
 
 uint64_t gmx_ingest_max_text(const gmx_ingest *g) { return g ? g->max_text : 0; }
 uint64_t gmx_ingest_max_compressed(const gmx_ingest *g) { return g ? g->max_comp : 0; }
 
-int gmx_ingest_reset(gmx_ingest *g) {  // the next chunk starts a file: nothing is carried into it
+int gmx_ingest_reset(gmx_ingest *g) try {  // the next chunk starts a file: nothing is carried into it
   if (!g) {
     gmx_set_error("null ingest");
     return GMX_EINVAL;
   }
   g->last_slot = -1;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_reset")
 
 // The kernels behind a chunk's bytes. Three streams: the slot's own for its inflate kernel — so that it runs beside the scan of
 // the chunk before and fills the CUs the tail of that chunk's inflate kernel leaves idle —, one for the scans (in chunk order:
@@ -1335,7 +1335,7 @@ static int ing_begin(gmx_ingest *g, int si, const char *who) {
 }
 
 int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members, uint64_t n_members,
-                           int final_chunk) {
+                           int final_chunk) try {
   int rc = ing_begin(g, slot, "gmx_ingest_submit_bgzf");
   if (rc) return rc;
   if ((!compressed && n_bytes) || (!members && n_members) || n_bytes > g->max_comp || n_members > g->cap_members) {
@@ -1363,9 +1363,9 @@ int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, u
   if (n_members) ING_TRY(hipMemcpyAsync(s.d_members, s.h_members, n_members * sizeof(IngestMember), hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipEventRecord(s.copied, g->copy_stream));
   return ing_enqueue_scan(g, slot, (uint32_t)text, final_chunk, true, (uint32_t)n_members);
-}
+} GMX_GUARD_INT("gmx_ingest_submit_bgzf")
 
-int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes, int final_chunk) {
+int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes, int final_chunk) try {
   int rc = ing_begin(g, slot, "gmx_ingest_submit_text");
   if (rc) return rc;
   if ((!text && n_bytes) || n_bytes > g->max_text) {
@@ -1376,12 +1376,12 @@ int gmx_ingest_submit_text(gmx_ingest *g, int slot, const uint8_t *text, uint64_
   if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX, text, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
   ING_TRY(hipEventRecord(s.copied, g->copy_stream));
   return ing_enqueue_scan(g, slot, (uint32_t)n_bytes, final_chunk, false, 0);
-}
+} GMX_GUARD_INT("gmx_ingest_submit_text")
 
 // Chunks dealt over several devices (one ingest per device): the cut record at a chunk's start lies on ANOTHER device, so a chunk
 // is uploaded and inflated at once (_deferred) and scanned (gmx_ingest_scan) when the caller has the end of the chunk before —
 // gmx_ingest_fetch_tail of that chunk's slot, on its device — which it hands over as host bytes.
-int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members, uint64_t n_members) {
+int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members, uint64_t n_members) try {
   if (g) g->last_slot = -1;  // (nothing is carried on the device in this mode: the slots need not alternate)
   int rc = ing_begin(g, slot, "gmx_ingest_submit_bgzf_deferred");
   if (rc) return rc;
@@ -1413,9 +1413,9 @@ int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *comp
   s.deferred = true;
   s.deferred_text = (uint32_t)text;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_submit_bgzf_deferred")
 
-int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk) {
+int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || !g->slot[slot].deferred || (!carry && n_carry) || n_carry > ING_CARRY_MAX) {
     gmx_set_error("gmx_ingest_scan: null ingest, slot without a gmx_ingest_submit_bgzf_deferred chunk, or more than 1 MB of carried text (a record that long is not FASTQ)");
     return GMX_EINVAL;
@@ -1425,9 +1425,9 @@ int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_ca
   // the carried bytes right in front of the members' text (pageable memory: the copy is over when the call returns)
   if (n_carry) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX - n_carry, carry, n_carry, hipMemcpyHostToDevice, g->stream));
   return ing_enqueue_scan(g, slot, s.deferred_text, final_chunk, true, 0, (uint32_t)n_carry);
-}
+} GMX_GUARD_INT("gmx_ingest_scan")
 
-int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
+int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_tail: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
@@ -1444,9 +1444,9 @@ int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t ca
     return GMX_EHIP;
   }
   return (int64_t)st.tail_len;
-}
+} GMX_GUARD_INT("gmx_ingest_fetch_tail")
 
-int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {
+int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || !out) {
     gmx_set_error("gmx_ingest_wait: null argument or slot not 0 / 1 / 2");
     return GMX_EINVAL;
@@ -1476,9 +1476,9 @@ int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out) {
   out->d_offsets = st.uniform_len ? nullptr : reinterpret_cast<const uint64_t *>(s.d_offsets);
   out->d_skip = s.d_skip;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_wait")
 
-int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) {
+int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS) {
     gmx_set_error("gmx_ingest_release_after: null ingest or slot not 0 / 1 / 2");
     return GMX_EINVAL;
@@ -1487,9 +1487,9 @@ int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) {
   ING_TRY(hipEventRecord(g->slot[slot].released, (hipStream_t)hip_stream));
   g->slot[slot].has_release = true;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_release_after")
 
-int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) {
+int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_text: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
@@ -1505,9 +1505,9 @@ int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t ca
     return GMX_EHIP;
   }
   return (int64_t)st.text_len;
-}
+} GMX_GUARD_INT("gmx_ingest_fetch_text")
 
-int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *offsets, uint8_t *skip) {
+int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *offsets, uint8_t *skip) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || g->slot[slot].in_flight) {
     gmx_set_error("gmx_ingest_fetch_reads: null ingest, bad slot, or the slot's chunk is still in flight");
     return GMX_EINVAL;
@@ -1519,6 +1519,6 @@ int gmx_ingest_fetch_reads(gmx_ingest *g, int slot, uint64_t *planes, uint64_t *
   if (offsets && !st.uniform_len && st.n_reads) ING_TRY(hipMemcpy(offsets, s.d_offsets, ((size_t)st.n_reads + 1) * 8, hipMemcpyDeviceToHost));
   if (skip && st.n_reads) ING_TRY(hipMemcpy(skip, s.d_skip, st.n_reads, hipMemcpyDeviceToHost));
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_ingest_fetch_reads")
 
 }  // extern "C"

@@ -269,21 +269,21 @@ struct gmx_comm {
 
 extern "C" {
 
-int gmx_device_count(void) {
+int gmx_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return n;
-}
+} GMX_GUARD_INT("gmx_device_count")
 
 // (gmx.h) Brings the HIP runtime, the device's context and this library's code objects up — 150-250 ms that a caller can
 // spend on another thread while it loads its index from disk.
 __global__ void gmx_warmup_kernel(uint32_t *p) {
   if (p) *p = 1u;
 }
-int gmx_device_warmup(int device) {
+int gmx_device_warmup(int device) try {
   if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) {
     gmx_set_error(std::string("gmx_device_warmup: device ") + std::to_string(device) + ": " + hipGetErrorString(hipGetLastError()));
     return GMX_ENODEV;
@@ -294,9 +294,9 @@ int gmx_device_warmup(int device) {
     return GMX_EHIP;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_device_warmup")
 
-int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const int *devices, int n_devices, gmx_group **out) {
+int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const int *devices, int n_devices, gmx_group **out) try {
   if (!ix || !devices || n_devices <= 0 || !out) {
     gmx_set_error("gmx_group_create: bad argument");
     return GMX_EINVAL;
@@ -319,13 +319,16 @@ int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const 
     gmx_engine_opts o = opts;
     o.device = devices[i];
     rcs[i] = gmx_engine_create(ix, &o, &g->ms[i].e);
-    if (rcs[i]) errs[i] = gmx_last_error();
-    else gmx_engine_raw(g->ms[i].e, &g->ms[i].raw);
+    try {
+      if (rcs[i]) errs[i] = gmx_last_error();
+      else gmx_engine_raw(g->ms[i].e, &g->ms[i].raw);
+    } catch (...) {  // (the message could not be copied: the code stands)
+    }
   };
   if (distinct && n_devices > 1) {
-    std::vector<std::thread> th;
-    for (int i = 0; i < n_devices; ++i) th.emplace_back(create, i);
-    for (auto &t : th) t.join();
+    GmxThreads th;
+    for (int i = 0; i < n_devices; ++i) th.run([&create, i] { create(i); });
+    th.join();
   } else {
     for (int i = 0; i < n_devices; ++i) create(i);
   }
@@ -345,22 +348,22 @@ int gmx_group_create(const gmx_index *ix, const gmx_engine_opts *opts_in, const 
   }
   *out = g;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_group_create")
 
-void gmx_group_destroy(gmx_group *g) {
+void gmx_group_destroy(gmx_group *g) try {
   if (!g) return;
   for (auto &m : g->ms) {
     if (m.comm) (void)rccl().CommDestroy(m.comm);
     if (m.e) gmx_engine_destroy(m.e);
   }
   delete g;
-}
+} GMX_GUARD_VOID("gmx_group_destroy")
 
 int gmx_group_size(const gmx_group *g) { return g ? (int)g->ms.size() : 0; }
 gmx_engine *gmx_group_engine(gmx_group *g, int i) { return g && i >= 0 && i < (int)g->ms.size() ? g->ms[i].e : nullptr; }
 int gmx_group_uses_rccl(const gmx_group *g) { return g && g->use_rccl ? 1 : 0; }
 
-int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads) {
+int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t *offsets, const uint32_t *seeds, uint64_t n_reads) try {
   if (!g || g->ms.empty()) {
     gmx_set_error("null group");
     return GMX_EINVAL;
@@ -369,30 +372,33 @@ int gmx_group_map_reads_host(gmx_group *g, const uint8_t *reads, const uint64_t 
   if (n == 1) return gmx_map_reads_host(g->ms[0].e, reads, offsets, seeds, n_reads);
   std::vector<int> rcs(n, GMX_OK);
   std::vector<std::string> errs(n);
-  std::vector<std::thread> th;
+  GmxThreads th;
   for (size_t i = 0; i < n; ++i) {  // contiguous ranges of the global read index; the seeds are the global stream's
     const uint64_t base = n_reads / n, rem = n_reads % n;
     const uint64_t lo = i * base + std::min<uint64_t>(i, rem), cnt = base + (i < rem ? 1 : 0);
-    th.emplace_back([=, &rcs, &errs]() {
+    th.run([=, &rcs, &errs]() {
       if (cnt == 0) return;
       rcs[i] = gmx_map_reads_host(g->ms[i].e, reads, offsets + lo, seeds + lo, cnt);
-      if (rcs[i]) errs[i] = gmx_last_error();
+      try {
+        if (rcs[i]) errs[i] = gmx_last_error();
+      } catch (...) {
+      }
     });
   }
-  for (auto &t : th) t.join();
+  th.join();
   for (size_t i = 0; i < n; ++i)
     if (rcs[i]) {
       gmx_set_error("device " + std::to_string(g->ms[i].raw.device) + ": " + errs[i]);
       return rcs[i];
     }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_group_map_reads_host")
 
 // The packed form, dealt the same way: engine i takes a contiguous range of the read index, its planes start at that
 // range's first pair (gmx.h: a sub-range of a packed batch is a packed batch). Every engine's call returns once its
 // chunks are enqueued (page-locked buffers), so the host threads are short-lived; gmx_group_sync_uploads waits for all.
 int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const uint64_t *offsets, uint32_t uniform_len,
-                                    const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
+                                    const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) try {
   if (!g || g->ms.empty()) {
     gmx_set_error("null group");
     return GMX_EINVAL;
@@ -405,7 +411,7 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
   }
   std::vector<int> rcs(n, GMX_OK);
   std::vector<std::string> errs(n);
-  std::vector<std::thread> th;
+  GmxThreads th;
   const uint64_t ppr = (uniform_len + 31u) / 32u;
   auto pair_at = [&](uint64_t r) { return uniform_len ? r * ppr : ((offsets[r] >> 5) - (offsets[0] >> 5)) + r; };
   // Pageable buffers are registered with the runtime HERE, once and whole: the members' sub-ranges share pages, so a
@@ -428,15 +434,18 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
     const uint64_t base = n_reads / n, rem = n_reads % n;
     const uint64_t lo = i * base + std::min<uint64_t>(i, rem), cnt = base + (i < rem ? 1 : 0);
     const uint64_t p0 = pair_at(lo);
-    th.emplace_back([=, &rcs, &errs]() {
+    th.run([=, &rcs, &errs]() {
       if (cnt == 0) return;
       gmx_pin_feeder(i);
       rcs[i] = gmx_map_reads_packed_host(g->ms[i].e, planes + p0, offsets ? offsets + lo : nullptr, uniform_len, seeds + lo,
                                          skip ? skip + lo : nullptr, cnt);
-      if (rcs[i]) errs[i] = gmx_last_error();
+      try {
+        if (rcs[i]) errs[i] = gmx_last_error();
+      } catch (...) {
+      }
     });
   }
-  for (auto &t : th) t.join();
+  th.join();
   if (registered) {
     for (auto &m : g->ms) (void)gmx_engine_sync_uploads(m.e);
     for (auto &r : regs)
@@ -449,9 +458,9 @@ int gmx_group_map_reads_packed_host(gmx_group *g, const uint64_t *planes, const 
       return rcs[i];
     }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_group_map_reads_packed_host")
 
-int gmx_group_sync_uploads(gmx_group *g) {
+int gmx_group_sync_uploads(gmx_group *g) try {
   if (!g) {
     gmx_set_error("null group");
     return GMX_EINVAL;
@@ -461,9 +470,9 @@ int gmx_group_sync_uploads(gmx_group *g) {
     if (rc) return rc;
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_group_sync_uploads")
 
-int gmx_group_allreduce(gmx_group *g) {
+int gmx_group_allreduce(gmx_group *g) try {
   if (!g || g->ms.empty()) {
     gmx_set_error("null group");
     return GMX_EINVAL;
@@ -480,9 +489,9 @@ int gmx_group_allreduce(gmx_group *g) {
     HIP_TRY(hipStreamSynchronize(m.stream));
   }
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_group_allreduce")
 
-int gmx_comm_unique_id(uint8_t *out128) {
+int gmx_comm_unique_id(uint8_t *out128) try {
   if (!rccl().ok) {
     gmx_set_error("RCCL (librccl.so) could not be loaded");
     return GMX_ENODEV;
@@ -492,9 +501,9 @@ int gmx_comm_unique_id(uint8_t *out128) {
   NCCL_TRY(rccl().GetUniqueId(&id));
   memcpy(out128, &id, 128);
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_comm_unique_id")
 
-int gmx_comm_create(const uint8_t *id128, int world, int rank, gmx_engine *e, gmx_comm **out) {
+int gmx_comm_create(const uint8_t *id128, int world, int rank, gmx_engine *e, gmx_comm **out) try {
   if (!id128 || !e || !out || world <= 0 || rank < 0 || rank >= world) {
     gmx_set_error("gmx_comm_create: bad argument");
     return GMX_EINVAL;
@@ -523,15 +532,15 @@ int gmx_comm_create(const uint8_t *id128, int world, int rank, gmx_engine *e, gm
   }
   *out = c;
   return GMX_OK;
-}
+} GMX_GUARD_INT("gmx_comm_create")
 
-void gmx_comm_destroy(gmx_comm *c) {
+void gmx_comm_destroy(gmx_comm *c) try {
   if (!c) return;
   if (c->m.comm) (void)rccl().CommDestroy(c->m.comm);
   delete c;
-}
+} GMX_GUARD_VOID("gmx_comm_destroy")
 
-int gmx_comm_allreduce_coverage(gmx_comm *c, void *hip_stream) {
+int gmx_comm_allreduce_coverage(gmx_comm *c, void *hip_stream) try {
   if (!c) {
     gmx_set_error("null communicator");
     return GMX_EINVAL;
@@ -540,6 +549,6 @@ int gmx_comm_allreduce_coverage(gmx_comm *c, void *hip_stream) {
   c->m.stream = (hipStream_t)hip_stream;
   std::vector<Member> ms(1, c->m);
   return gmx_exchange(ms, c->world);
-}
+} GMX_GUARD_INT("gmx_comm_allreduce_coverage")
 
 }  // extern "C"

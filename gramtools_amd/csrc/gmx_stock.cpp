@@ -125,7 +125,7 @@ int fail(const std::string &m, int code = GMX_EINVAL) {
 
 extern "C" {
 
-int64_t gmx_stock_read_int_vector(const char *path, uint32_t fixed_width, uint64_t *out, uint64_t cap, uint32_t *width_out) {
+int64_t gmx_stock_read_int_vector(const char *path, uint32_t fixed_width, uint64_t *out, uint64_t cap, uint32_t *width_out) try {
   if (!path) return fail("gmx_stock_read_int_vector: null path");
   try {
     IntVector v = read_int_vector(path, fixed_width);
@@ -138,9 +138,9 @@ int64_t gmx_stock_read_int_vector(const char *path, uint32_t fixed_width, uint64
   } catch (std::exception const &e) {
     return fail(e.what());
   }
-}
+} GMX_GUARD_INT("gmx_stock_read_int_vector")
 
-int gmx_stock_write_int_vector(const char *path, const uint64_t *values, uint64_t n, uint32_t width, int fixed) {
+int gmx_stock_write_int_vector(const char *path, const uint64_t *values, uint64_t n, uint32_t width, int fixed) try {
   if (!path || (!values && n)) return fail("gmx_stock_write_int_vector: null argument");
   try {
     write_int_vector(path, values, n, width, fixed != 0);
@@ -148,11 +148,11 @@ int gmx_stock_write_int_vector(const char *path, const uint64_t *values, uint64_
   } catch (std::exception const &e) {
     return fail(e.what());
   }
-}
+} GMX_GUARD_INT("gmx_stock_write_int_vector")
 
 // The k-mer index and the four base masks of `ix` in the stock files' formats (k-mers in ascending table order; the
 // reference writes them in its hash map's order, and reads any order).
-int gmx_index_write_stock_files(const gmx_index *ix, const char *gram_dir) {
+int gmx_index_write_stock_files(const gmx_index *ix, const char *gram_dir) try {
   if (!ix || !gram_dir) return fail("gmx_index_write_stock_files: null argument");
   const gmx::HostIndex &h = gmx_index_host(ix);
   const uint32_t k = h.kmer_size;
@@ -198,11 +198,11 @@ int gmx_index_write_stock_files(const gmx_index *ix, const char *gram_dir) {
   } catch (std::exception const &e) {
     return fail(e.what());
   }
-}
+} GMX_GUARD_INT("gmx_index_write_stock_files")
 
 // Reads gram_dir's kmers / kmers_stats / sa_intervals / paths as kmer_index::load does (load.cpp:161-173) and the four
 // masks (make_data_structures.cpp:140-156), and compares them with the native index of the same PRG and k.
-int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_stock_report *out) {
+int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_stock_report *out) try {
   if (!ix || !gram_dir || !out) return fail("gmx_index_check_stock_files: null argument");
   memset(out, 0, sizeof(*out));
   const gmx::HostIndex &h = gmx_index_host(ix);
@@ -294,6 +294,6 @@ int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_s
   } catch (std::exception const &e) {
     return fail(e.what());
   }
-}
+} GMX_GUARD_INT("gmx_index_check_stock_files")
 
 }  // extern "C"

@@ -29,7 +29,9 @@
 #include <fstream>
 #include <iostream>
 #include <condition_variable>
+#include <exception>
 #include <functional>
+#include <new>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -2018,7 +2020,46 @@ int run_genotype(const Args &a) {
 
 }  // namespace
 
+// A C++ exception nobody caught — std::bad_alloc in a parser or writer thread, in a destructor's path — ends the run the way the
+// reference's front-end expects a failed `gram` to end (genotype.py:106-107: non-zero exit code, message on the output), not
+// with SIGABRT and a core file. Called by the runtime on whatever thread the exception died on; does not return.
+static void gram_terminate() {
+  const char *what = "unknown error";
+  char buf[512];
+  if (std::exception_ptr ep = std::current_exception()) {
+    try {
+      std::rethrow_exception(ep);
+    } catch (std::bad_alloc const &) {
+      what = "out of host memory";
+    } catch (std::exception const &e) {
+      snprintf(buf, sizeof(buf), "%s", e.what());
+      what = buf;
+    } catch (...) {
+    }
+  }
+  char line[640];
+  const int n = snprintf(line, sizeof(line), "gram: fatal: %s\n", what);
+  if (n > 0) {
+    (void)!write(1, line, (size_t)std::min<int>(n, (int)sizeof(line) - 1));
+    (void)!write(2, line, (size_t)std::min<int>(n, (int)sizeof(line) - 1));
+  }
+  _exit(1);
+}
+
+static int gram_run(int argc, const char *const *argv);
 int main(int argc, const char *const *argv) {
+  std::set_terminate(gram_terminate);
+  try {
+    return gram_run(argc, argv);
+  } catch (std::bad_alloc const &) {
+    std::cout << "gram: out of host memory" << std::endl;
+  } catch (std::exception const &e) {
+    std::cout << "gram: " << e.what() << std::endl;
+  }
+  return 1;
+}
+
+static int gram_run(int argc, const char *const *argv) {
   // main.cpp:51-100: first positional token is the command; --help or no command prints help and exits 0
   std::string command;
   int cmd_at = -1;

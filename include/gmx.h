@@ -8,7 +8,10 @@
  * Conventions: plain pointers and sizes; the caller owns every host buffer; the
  * library owns device memory. Every function returns 0 on success or a negative
  * GMX_E* code; gmx_last_error() returns the message of the calling thread's last
- * failure. One engine = one GPU = one host thread at a time.
+ * failure. No C++ exception leaves the library: every entry point is a function-try-block
+ * (gmx_internal.h: GMX_GUARD_*), host memory exhaustion is GMX_ENOMEM (the reference's
+ * process ends such a run with a message and a non-zero exit code,
+ * gramtools/commands/genotype/genotype.py:106-107 — not with SIGABRT). One engine = one GPU = one host thread at a time.
  * Mapping entry points ALWAYS run on the GPU; there is no CPU fallback.
  */
 #ifndef GMX_H
@@ -350,6 +353,11 @@ int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_s
  *   given states: position by position; out = the states that stay mapping instances of a site, nonvariant_sa =
  *   the SA indices of the path-less positions outside every site (the reference keeps them as path-less states). */
 int gmx_engine_debug_keep_states(gmx_engine *e, int on);
+/* Allocation-failure injection (tests/test_alloc_failure.py): the nth call of operator new made by libgmx.so's own code
+ * from now on throws std::bad_alloc, once (0: off); also GMX_TEST_FAIL_ALLOC=n in the environment at load time. Returns the
+ * number of allocations the library has made so far (so a test can count the allocations of a call and walk n over them).
+ * The HIP runtime's, RCCL's and the host program's allocations are not touched. */
+uint64_t gmx_debug_fail_alloc(int64_t nth);
 int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t cap_words, uint64_t *n_words, int *tier);
 int gmx_debug_search(gmx_engine *e, const uint8_t *read, uint32_t read_len, int from_seed_table, const uint32_t *states,
                      uint64_t n_state_words, uint32_t from, uint32_t stop, int lf_only, uint32_t *out, uint64_t cap_words,
