@@ -118,6 +118,8 @@ SYMBOLS = {
     "gmx_ingest_reset": (C.c_int, [_vp]),
     "gmx_ingest_submit_bgzf": (C.c_int, [_vp, C.c_int, _vp, _u64, C.POINTER(BgzfMember), _u64, C.c_int]),
     "gmx_ingest_submit_text": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int]),
+    "gmx_ingest_submit_text_deferred": (C.c_int, [_vp, C.c_int, _vp, _u64]),
+    "gmx_ingest_max_members": (_u64, [_vp]),
     "gmx_ingest_wait": (C.c_int, [_vp, C.c_int, C.POINTER(IngestResult)]),
     "gmx_ingest_submit_bgzf_deferred": (C.c_int, [_vp, C.c_int, _vp, _u64, C.POINTER(BgzfMember), _u64]),
     "gmx_ingest_scan": (C.c_int, [_vp, C.c_int, _vp, _u64, C.c_int]),

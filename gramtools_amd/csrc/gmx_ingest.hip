@@ -151,11 +151,13 @@ struct Bits {
   uint32_t cur;
   uint64_t buf;
   uint32_t cnt;
+  uint32_t limit;  // words at and beyond this index are not the member's: never loaded, read as zero (set before start())
+  __device__ __forceinline__ uint32_t fetch(uint32_t idx) const { return idx < limit ? w[idx] : 0u; }
   __device__ __forceinline__ void start(const uint32_t *words, uint32_t byte_off) {
     w = words;
     const uint32_t idx = byte_off >> 2, skip = (byte_off & 3u) * 8u;
     base = idx;
-    cur = words[idx + threadIdx.x];
+    cur = fetch(idx + threadIdx.x);
     buf = (uint64_t)(word_of(0) >> skip);
     cnt = 32u - skip;
     rel = 1u;
@@ -167,7 +169,7 @@ struct Bits {
     if (cnt <= 32u) {
       if (rel == 64u) {
         base += 64u;
-        cur = w[base + threadIdx.x];
+        cur = fetch(base + threadIdx.x);  // (a truncated or damaged member decodes zeros from its end on: BAD_MEMBER below, nothing read beyond it)
         rel = 0;
       }
       buf |= (uint64_t)word_of(rel) << cnt;
@@ -441,6 +443,7 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
   ing_g8 *const al = out0 - mis;
   const uint32_t end_v = isize + mis;
   Bits bs;
+  bs.limit = (in_off + in_len + 3u) / 4u + 2u;  // (the member's words and the zeroed ones right behind them: ADVICE round 5 — the reader used to run on into the next member, or past the chunk's bytes)
   bs.start(comp, in_off);
   uint32_t out_pos = mis, flushed = mis;  // bytes decoded so far end here; bytes already stored from the window end here
   uint32_t err = 0;
@@ -725,8 +728,11 @@ __device__ __forceinline__ void ing_inflate_member(WaveLds &L, const uint32_t *_
     // slices of whole words, counted like everything else from the 16-byte boundary below the member's first byte
     const uint32_t total = end_v;
     const uint32_t per = (((total + 63u) / 64u) + 3u) & ~3u;
-    uint32_t lo = min(total, lane * per), hi = min(total, lo + per);
-    if (lane == 0) lo = mis;
+    // (EVERY lane's slice starts at the member's first byte at the earliest — `mis` bytes above the boundary: with only lane 0
+    //  clamped, a member of a few hundred bytes that does not start on a 16-byte boundary had the bytes in front of it hashed
+    //  by lanes 1.. and was reported as GMX_INGEST_BAD_CRC)
+    uint32_t lo = min(total, max(mis, lane * per));
+    const uint32_t hi = max(lo, min(total, (lane + 1u) * per));
     uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
     const uint32_t n = hi > lo ? hi - lo : 0u;
     auto byte_step = [&](uint32_t at) { c = crc_tab[(c ^ ing_load_coherent(al + at)) & 0xFFu] ^ (c >> 8); };
@@ -1101,7 +1107,8 @@ struct gmx_ingest {
     bool in_flight = false, has_release = false, has_carried = false;
     hipEvent_t follower_carried = nullptr;  // `carried` of the chunk that continued this slot's: its carry kernel read the end of this slot's text
     bool has_follower = false;
-    bool deferred = false;       // gmx_ingest_submit_bgzf_deferred: inflate kernel enqueued, scan still to come (gmx_ingest_scan)
+    bool deferred = false;       // gmx_ingest_submit_bgzf_deferred / _text_deferred: uploaded (and inflating), scan still to come (gmx_ingest_scan)
+    bool deferred_inflate = true;  // ... with an inflate kernel (false: the chunk arrived as text)
     uint32_t deferred_text = 0;  // ... bytes of text of its members
   } slot[GMX_INGEST_SLOTS];
   int last_slot = -1;  // the slot whose chunk the next one continues (-1: a file's first chunk)
@@ -1230,6 +1237,7 @@ void gmx_ingest_destroy(gmx_ingest *g) try {
 
 uint64_t gmx_ingest_max_text(const gmx_ingest *g) { return g ? g->max_text : 0; }
 uint64_t gmx_ingest_max_compressed(const gmx_ingest *g) { return g ? g->max_comp : 0; }
+uint64_t gmx_ingest_max_members(const gmx_ingest *g) { return g ? g->cap_members : 0; }
 
 int gmx_ingest_reset(gmx_ingest *g) try {  // the next chunk starts a file: nothing is carried into it
   if (!g) {
@@ -1411,9 +1419,28 @@ int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *comp
   rc = ing_enqueue_inflate(g, slot, (uint32_t)n_members);
   if (rc) return rc;
   s.deferred = true;
+  s.deferred_inflate = true;
   s.deferred_text = (uint32_t)text;
   return GMX_OK;
 } GMX_GUARD_INT("gmx_ingest_submit_bgzf_deferred")
+
+// The same for a chunk of plain text (an uncompressed FASTQ dealt over several devices): uploaded at once, scanned by gmx_ingest_scan.
+int gmx_ingest_submit_text_deferred(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes) try {
+  if (g) g->last_slot = -1;
+  int rc = ing_begin(g, slot, "gmx_ingest_submit_text_deferred");
+  if (rc) return rc;
+  if ((!text && n_bytes) || n_bytes > g->max_text) {
+    gmx_set_error("gmx_ingest_submit_text_deferred: null text, or more text than the ingest was created for");
+    return GMX_EINVAL;
+  }
+  gmx_ingest::Slot &s = g->slot[slot];
+  if (n_bytes) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX, text, n_bytes, hipMemcpyHostToDevice, g->copy_stream));
+  ING_TRY(hipEventRecord(s.copied, g->copy_stream));
+  s.deferred = true;
+  s.deferred_inflate = false;
+  s.deferred_text = (uint32_t)n_bytes;
+  return GMX_OK;
+} GMX_GUARD_INT("gmx_ingest_submit_text_deferred")
 
 int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk) try {
   if (!g || slot < 0 || slot >= GMX_INGEST_SLOTS || !g->slot[slot].deferred || (!carry && n_carry) || n_carry > ING_CARRY_MAX) {
@@ -1424,7 +1451,7 @@ int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_ca
   gmx_ingest::Slot &s = g->slot[slot];
   // the carried bytes right in front of the members' text (pageable memory: the copy is over when the call returns)
   if (n_carry) ING_TRY(hipMemcpyAsync(s.d_text + ING_CARRY_MAX - n_carry, carry, n_carry, hipMemcpyHostToDevice, g->stream));
-  return ing_enqueue_scan(g, slot, s.deferred_text, final_chunk, true, 0, (uint32_t)n_carry);
+  return ing_enqueue_scan(g, slot, s.deferred_text, final_chunk, s.deferred_inflate, 0, (uint32_t)n_carry);
 } GMX_GUARD_INT("gmx_ingest_scan")
 
 int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap) try {

@@ -918,7 +918,7 @@ struct DeviceFeed {  // one per process: the ingest object and its page-locked s
   gmx_ingest *ing = nullptr;
   uint64_t max_text = 0;
   int device = 0;
-  HostBuf<uint8_t> stage[3];  // (three: chunk i + 2's bytes are staged while chunks i and i + 1 are on the device)
+  HostBuf<uint8_t> stage[4];  // (BGZF uses three: chunk i + 2's bytes are staged while chunks i and i + 1 are on the device; plain text four: ingest_text_file)
   ~DeviceFeed() {
     if (ing) gmx_ingest_destroy(ing);
   }
@@ -974,12 +974,19 @@ int ingest_bgzf_file(const std::string &path, int threads, int device, OnChunk o
   // The member table is walked a chunk at a time, beside the device (round 5: the whole table first cost 7 ms of a 22 000-member file
   // before the first byte went up). Every byte of the file must belong to a BGZF member: a file that stops being BGZF behind chunks
   // already delivered is handed to the host reader, which drops what was mapped (return value 2).
+  {  // not BGZF at its first byte: declined BEFORE the ingest is sized for it (round 6: a plain FASTQ of 1.26 GB had the ingest the
+     // prewarm thread made for its text chunks thrown away and one for 470 MB chunks made here — 40 ms — just to be declined)
+    gmx_bgzf_member m0;
+    size_t next0;
+    if (!bgzf_member_at(in, size, 0, &m0, &next0)) return 1;
+  }
   DeviceFeed &df = g_device_feed;
   device_feed_prepare(device, device_feed_text_for((uint64_t)size * 6), 0);  // (as the call beside the index load sized it)
   if (!df.ing) return 1;
   gmx_ingest *ing = df.ing;
   GMX_CHECK(gmx_ingest_reset(ing));
-  const uint64_t kMembers = device_feed_members();
+  // (a chunk holds at most what the ingest's member table holds: a file of many tiny members must not be refused by the submit)
+  const uint64_t kMembers = std::min<uint64_t>(device_feed_members(), gmx_ingest_max_members(ing));
   const uint64_t max_text = gmx_ingest_max_text(ing), max_comp = gmx_ingest_max_compressed(ing);
   struct Chunk {
     std::vector<gmx_bgzf_member> rel;  // its members, offsets from lo
@@ -1125,7 +1132,7 @@ int ingest_bgzf_file_dealt(const std::string &path, int threads, const std::vect
     if (m.isize) members.push_back(m);
     at = next;
   }
-  const uint64_t kMembers = device_feed_members();
+  uint64_t kMembers = device_feed_members();
   uint64_t file_text = 0;
   for (const auto &m : members) file_text += m.isize;
   while (g_more_feeds.size() + 1 < N) g_more_feeds.emplace_back(new DeviceFeed());
@@ -1137,6 +1144,7 @@ int ingest_bgzf_file_dealt(const std::string &path, int threads, const std::vect
   }
   feed_trace("ingests of all engines ready");
   const uint64_t max_text = gmx_ingest_max_text(feed(0).ing), max_comp = gmx_ingest_max_compressed(feed(0).ing);
+  kMembers = std::min<uint64_t>(kMembers, gmx_ingest_max_members(feed(0).ing));
   struct Chunk {
     size_t first, count, lo, hi;
   };
@@ -1202,6 +1210,251 @@ int ingest_bgzf_file_dealt(const std::string &path, int threads, const std::vect
     on_chunk(res, dev_of(ci), slot_of(ci));
     *delivered += res.n_reads;
     if (submitted < chunks.size()) submit(submitted++);  // (its slot: chunk submitted - 2 N, waited for and handed on two rounds ago)
+  }
+  return 0;
+}
+
+// ---- plain (uncompressed) four-line FASTQ through the same device chain (round 6) -----------------------------------------
+// The reference reads every text format through one host reader (include/sequence_read/seqread.hpp:94-180, seq_file.h:626-633,
+// quasimap.cpp:65-76). Until round 6 `gram` took the device route for BGZF only and parsed a plain FASTQ on the host: 42 M
+// reads/s parse + map at configs[1], 3.5 x slower than the same reads bgzipped. Now the file's bytes go up as they are: all
+// threads pread their slices of a chunk from the page cache into page-locked memory (ONE pass over the text on the host, no
+// parsing), the chunk is uploaded (gmx_ingest_submit_text) and gmx_nl_* / gmx_records / gmx_fq_pack find the records and pack the
+// bases in HBM; a record cut by a chunk's end is carried into the next chunk on the device. Bound: the host link at ~316 B per
+// 150-base read (measured 120-140 M reads/s; the link's 55 GB/s would be 175 M). Whether a file takes this route or the host parser:
+// plain_fastq_on_device() below. Return values as ingest_bgzf_file.
+// Which reader takes a plain FASTQ (measured on the GPU boxes, configs[1], 4 M x 150 bp = 1.26 GB in the page cache, parse + map;
+// profiles/round6/cli_text_feed_by_threads.txt): the device route moves 316 B per read over the host link and is bound by it —
+// 28-33 ms = 120-140 M reads/s from 2 host threads on, 67 M with ONE (one core copies 21 GB/s out of the page cache) — while the
+// host parser sends 40 B per read and scales with the cores: 24 M reads/s on 1 thread, 35-45 M on 2-4, 52-82 M on 8, 75-102 M on 16,
+// 140-165 M on 32, 140-215 M on 64. So: the device route below 32 host threads (`--max_threads` defaults to 1 in the reference's
+// front-end: 2.8 x) and with several engines (their links add up; one host's parser does not), the host parser from 32 threads
+// on. GMX_DEVICE_FASTQ=1 / GMX_HOST_FASTQ=1 force either.
+static bool plain_fastq_on_device(int max_threads, size_t n_engines) {
+  if (getenv("GMX_HOST_FASTQ")) return false;
+  if (const char *e = getenv("GMX_DEVICE_FASTQ")) return atoi(e) != 0;
+  return max_threads < 32 || n_engines > 1;
+}
+static uint64_t device_feed_text_chunk(size_t scale = 0) {
+  uint64_t c = (128ull << 20) * (scale ? scale : std::min<size_t>(g_block_scale, 4));  // (nested PRGs: larger launches, see g_block_scale; 128 MB: 29-33 ms per 1.26 GB where 64 MB chunks take 34-40)
+  if (const char *e = getenv("GMX_TEXT_CHUNK")) c = std::max<uint64_t>(64, (uint64_t)atoll(e));
+  return std::min<uint64_t>(c, (3ull << 30) - (1u << 20));
+}
+static uint64_t fstat_ok_size(const std::string &path) {
+  struct stat sb;
+  return stat(path.c_str(), &sb) == 0 && S_ISREG(sb.st_mode) ? (uint64_t)sb.st_size : 0;
+}
+static bool looks_like_plain_fastq(const std::string &path, uint64_t *size_out) {
+  const int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return false;
+  struct stat sb;
+  unsigned char h[2] = {0, 0};
+  const bool ok = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size >= 4 && pread(fd, h, 2, 0) == 2 && h[0] == '@';
+  close(fd);
+  if (ok && size_out) *size_out = (uint64_t)sb.st_size;
+  return ok;
+}
+// bytes [at, at + n) of the file into dst, every thread its slice (page cache -> page-locked memory); false: a read failed
+static bool pread_parallel(int fd, uint64_t at, uint8_t *dst, size_t n, unsigned T) {
+  std::atomic<bool> bad{false};
+  parallel_for(T, [&](unsigned t) {
+    size_t lo = n * t / T;
+    const size_t hi = n * (t + 1) / T;
+    while (lo < hi) {
+      const ssize_t got = pread(fd, dst + lo, hi - lo, (off_t)(at + lo));
+      if (got <= 0) {
+        bad.store(true);
+        return;
+      }
+      lo += (size_t)got;
+    }
+  });
+  return !bad.load();
+}
+struct FdCloser {
+  int fd;
+  ~FdCloser() {
+    if (fd >= 0) close(fd);
+  }
+};
+// what a chunk's status means for the caller (both text feeds): 0 go on, else the function's return value
+static int text_chunk_verdict(const gmx_ingest_result &res, const std::string &path, uint64_t delivered) {
+  if (!res.status) return 0;
+  if (res.status & GMX_INGEST_BAD_RECORD) {  // not four-line FASTQ: the host's fast path would say the same
+    if (delivered == 0) return 1;
+    die("gram: " + path + ": irregular FASTQ record after the first " + std::to_string(delivered) +
+        " reads (multi-line or blank lines); reformat, or use a four-line FASTQ");
+  }
+  return delivered == 0 ? 1 : 2;  // lines of a few bytes (more records than the ingest has room for): the host reader's
+}
+
+template <class OnChunk>
+int ingest_text_file(const std::string &path, int threads, int device, OnChunk on_chunk, uint64_t *delivered) {
+  *delivered = 0;
+  uint64_t size = 0;
+  if (!looks_like_plain_fastq(path, &size)) return 1;
+  FdCloser f{open(path.c_str(), O_RDONLY)};
+  if (f.fd < 0) return 1;
+  const uint64_t chunk = std::min<uint64_t>(device_feed_text_chunk(), size);
+  DeviceFeed &df = g_device_feed;
+  device_feed_prepare(device, std::max<uint64_t>(chunk, 1u << 16) + (1u << 16), 0);
+  if (!df.ing) return 1;
+  gmx_ingest *ing = df.ing;
+  GMX_CHECK(gmx_ingest_reset(ing));
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  const size_t n_chunks = (size_t)((size + chunk - 1) / chunk);
+  auto bytes_of = [&](size_t ci) { return (size_t)std::min<uint64_t>(chunk, size - (uint64_t)ci * chunk); };
+  // A thread of its own reads the chunks ahead into four page-locked buffers (round 6: read, submit, wait and map in turn on one
+  // thread cost 1.55 ms per 64 MB chunk of which 1.25 were the read — the reads now run back to back). Buffer k % 4 is free for
+  // chunk k once chunk k - 4 has been waited for (its upload is over).
+  constexpr size_t NB = 4;
+  HostBuf<uint8_t> *const ring = df.stage;  // (sized beside the index load: device_feed_prepare; page-locking 4 x 64 MB takes 30 ms)
+  struct Reader {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t staged = 0, waited = 0;  // chunks read so far / chunks the consumer is done with
+    bool failed = false, stop = false;
+    std::thread th;
+    ~Reader() {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+      }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+  } rd;
+  for (size_t b = 0; b < std::min(NB, n_chunks); ++b) ring[b].resize(bytes_of(0) + 64);
+  rd.th = std::thread([&]() {
+    for (size_t k = 0; k < n_chunks; ++k) {
+      {
+        std::unique_lock<std::mutex> lk(rd.m);
+        rd.cv.wait(lk, [&] { return rd.stop || k < rd.waited + NB; });
+        if (rd.stop) return;
+      }
+      const double t_read = now_s();
+      const bool ok = pread_parallel(f.fd, (uint64_t)k * chunk, ring[k % NB].data(), bytes_of(k), T);
+      g_feed.read_s += now_s() - t_read;
+      feed_trace("  text chunk read into page-locked memory");
+      {
+        std::lock_guard<std::mutex> lk(rd.m);
+        if (!ok) rd.failed = true;
+        rd.staged = k + 1;
+      }
+      rd.cv.notify_all();
+      if (!ok) return;
+    }
+  });
+  auto staged = [&](size_t k, bool block) -> int {  // 1: chunk k is read, 0: not yet (block = false), -1: its read failed
+    std::unique_lock<std::mutex> lk(rd.m);
+    if (block) rd.cv.wait(lk, [&] { return rd.staged > k || rd.failed; });
+    if (rd.staged > k) return 1;
+    return rd.failed ? -1 : 0;
+  };
+  size_t n_submitted = 0;
+  auto submit = [&]() {
+    const size_t ci = n_submitted;
+    GMX_CHECK(gmx_ingest_submit_text(ing, (int)(ci % 3), ring[ci % NB].data(), bytes_of(ci), ci + 1 == n_chunks ? 1 : 0));
+    ++n_submitted;
+    feed_trace("text chunk submitted to the device");
+  };
+  bool io_error = false;
+  for (size_t ci = 0; ci < n_chunks && !io_error; ++ci) {
+    if (n_submitted <= ci) {  // this chunk itself: wait for its bytes
+      if (staged(ci, true) < 0) {
+        io_error = true;
+        break;
+      }
+      submit();
+    }
+    while (n_submitted < std::min(n_chunks, ci + 3) && staged(n_submitted, false) == 1) submit();  // the two behind it, when they are there
+    gmx_ingest_result res;
+    GMX_CHECK(gmx_ingest_wait(ing, (int)(ci % 3), &res));
+    feed_trace("text chunk scanned and packed");
+    if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))  // test hook: "more records than the ingest has room for" in this chunk
+      if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_TOO_MANY_LINES;
+    if (res.status) {
+      for (size_t cj = ci + 1; cj < n_submitted; ++cj) {  // (the chunks behind are in flight: let them finish before the slots are reused)
+        gmx_ingest_result drop;
+        GMX_CHECK(gmx_ingest_wait(ing, (int)(cj % 3), &drop));
+      }
+      return text_chunk_verdict(res, path, *delivered);
+    }
+    on_chunk(res, (int)(ci % 3));
+    *delivered += res.n_reads;
+    {
+      std::lock_guard<std::mutex> lk(rd.m);
+      rd.waited = ci + 1;
+    }
+    rd.cv.notify_all();
+  }
+  if (io_error) {  // (chunks in flight first; then the host reader reports the file)
+    for (size_t cj = 0; cj < n_submitted; ++cj) {
+      gmx_ingest_result drop;
+      (void)gmx_ingest_wait(ing, (int)(cj % 3), &drop);
+    }
+    return *delivered == 0 ? 1 : 2;
+  }
+  return 0;
+}
+
+// Several engines: the chunks dealt round, each uploaded to its device at once (gmx_ingest_submit_text_deferred, two per device
+// ahead), scanned in file order with the cut record of the chunk before handed over through the host — as ingest_bgzf_file_dealt.
+template <class OnChunk>
+int ingest_text_file_dealt(const std::string &path, int threads, const std::vector<int> &devs, OnChunk on_chunk, uint64_t *delivered) {
+  *delivered = 0;
+  const size_t N = devs.size();
+  uint64_t size = 0;
+  if (!looks_like_plain_fastq(path, &size)) return 1;
+  FdCloser f{open(path.c_str(), O_RDONLY)};
+  if (f.fd < 0) return 1;
+  const uint64_t chunk = std::min<uint64_t>(device_feed_text_chunk(), size);
+  while (g_more_feeds.size() + 1 < N) g_more_feeds.emplace_back(new DeviceFeed());
+  auto feed = [&](size_t k) -> DeviceFeed & { return k == 0 ? g_device_feed : *g_more_feeds[k - 1]; };
+  for (size_t k = 0; k < N; ++k) {
+    device_feed_prepare(devs[k], std::max<uint64_t>(chunk, 1u << 16) + (1u << 16), 0, &feed(k));
+    if (!feed(k).ing) return 1;
+    GMX_CHECK(gmx_ingest_reset(feed(k).ing));
+  }
+  const size_t n_chunks = (size_t)((size + chunk - 1) / chunk);
+  const unsigned T = (unsigned)std::max(1, std::min(threads, 64));
+  auto dev_of = [&](size_t ci) { return ci % N; };
+  auto slot_of = [&](size_t ci) { return (int)((ci / N) & 1); };
+  bool io_error = false;
+  auto submit = [&](size_t ci) {
+    const uint64_t lo = (uint64_t)ci * chunk;
+    const size_t n = (size_t)std::min<uint64_t>(chunk, size - lo);
+    HostBuf<uint8_t> &st = feed(dev_of(ci)).stage[slot_of(ci)];
+    st.resize(n + 64);
+    if (!pread_parallel(f.fd, lo, st.data(), n, T)) io_error = true;
+    GMX_CHECK(gmx_ingest_submit_text_deferred(feed(dev_of(ci)).ing, slot_of(ci), st.data(), n));
+    feed_trace("text chunk submitted to its device");
+  };
+  size_t submitted = 0;
+  for (; submitted < std::min(n_chunks, 2 * N); ++submitted) submit(submitted);
+  std::vector<uint8_t> tail;
+  for (size_t ci = 0; ci < n_chunks; ++ci) {
+    gmx_ingest *ing = feed(dev_of(ci)).ing;
+    GMX_CHECK(gmx_ingest_scan(ing, slot_of(ci), tail.data(), tail.size(), ci + 1 == n_chunks ? 1 : 0));
+    gmx_ingest_result res;
+    GMX_CHECK(gmx_ingest_wait(ing, slot_of(ci), &res));
+    feed_trace("text chunk scanned");
+    if (const char *tf = getenv("GMX_INGEST_TEST_FAIL_CHUNK"))
+      if ((size_t)atoll(tf) == ci) res.status |= GMX_INGEST_TOO_MANY_LINES;
+    if (io_error) res.status |= GMX_INGEST_TOO_MANY_LINES;  // (a failed read: the host reader takes the file and reports it)
+    if (res.status) {
+      for (size_t cj = ci + 1; cj < submitted; ++cj) {  // (chunks uploaded ahead: scanned with nothing and dropped, so that their slots are free again)
+        gmx_ingest_result drop;
+        GMX_CHECK(gmx_ingest_scan(feed(dev_of(cj)).ing, slot_of(cj), nullptr, 0, 0));
+        GMX_CHECK(gmx_ingest_wait(feed(dev_of(cj)).ing, slot_of(cj), &drop));
+      }
+      return text_chunk_verdict(res, path, *delivered);
+    }
+    tail.resize(res.tail_bytes);
+    if (res.tail_bytes && gmx_ingest_fetch_tail(ing, slot_of(ci), tail.data(), tail.size()) < 0) die(std::string("gram: ") + gmx_last_error());
+    on_chunk(res, dev_of(ci), slot_of(ci));
+    *delivered += res.n_reads;
+    if (submitted < n_chunks) submit(submitted++);
   }
   return 0;
 }
@@ -1339,7 +1592,7 @@ int run_parse_check(const std::string &path, int threads) {
     fast = Flat{};
     ParsedReads blk;
     uint64_t delivered = 0;
-    const int rc = ingest_bgzf_file(path, threads, 0, [&](const gmx_ingest_result &res, int slot) {
+    auto take = [&](const gmx_ingest_result &res, int slot) {
       blk.reset();
       blk.n_reads = res.n_reads;
       blk.n_bases = res.n_bases;
@@ -1349,7 +1602,9 @@ int run_parse_check(const std::string &path, int threads) {
       blk.skip.resize(std::max<uint64_t>(res.n_reads, 1));
       GMX_CHECK(gmx_ingest_fetch_reads(g_device_feed.ing, slot, blk.planes.data(), blk.offsets.data(), blk.skip.data()));
       collect(blk);
-    }, &delivered);
+    };
+    int rc = ingest_bgzf_file(path, threads, 0, take, &delivered);
+    if (rc == 1 && delivered == 0) rc = ingest_text_file(path, threads, 0, take, &delivered);  // (not BGZF: plain text through the same kernels)
     if (rc == 0)
       std::cout << "device " << fast.offsets.size() - 1 << " " << fast.bases.size() << " " << fnv(fast) << std::endl;
     else
@@ -1588,6 +1843,9 @@ int run_genotype(const Args &a) {
         if (bg && hipSetDeviceForPrewarm(devices[0])) {
           const uint64_t text = device_feed_text_for((uint64_t)sb.st_size * 6);
           device_feed_prepare(devices[0], text, std::min<uint64_t>((uint64_t)sb.st_size, text / 2) + 64);
+        } else if (h[0] == '@' && plain_fastq_on_device(max_threads, devices.size()) && fstat_ok_size(smp.reads[0]) >= 4) {  // plain FASTQ: text chunks (ingest_text_file)
+          const uint64_t chunk = std::min<uint64_t>(device_feed_text_chunk(1), fstat_ok_size(smp.reads[0]));  // (a nested PRG's larger chunks: sized when the file is opened)
+          device_feed_prepare(devices[0], std::max<uint64_t>(chunk, 1u << 16) + (1u << 16), chunk + 64);
         }
         break;
       }
@@ -1738,8 +1996,13 @@ int run_genotype(const Args &a) {
         in_file += n;
         total_reads += n;
       };
-      const int rc = dealt ? ingest_bgzf_file_dealt(path, max_threads, devices, map_chunk, &delivered)
-                           : ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) { map_chunk(res, 0, slot); }, &delivered);
+      int rc = dealt ? ingest_bgzf_file_dealt(path, max_threads, devices, map_chunk, &delivered)
+                     : ingest_bgzf_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) { map_chunk(res, 0, slot); }, &delivered);
+      // not BGZF: plain four-line FASTQ takes the same route minus the inflate kernel (round 6; GMX_HOST_FASTQ=1: the host parser)
+      const bool text_route = rc == 1 && delivered == 0 && plain_fastq_on_device(max_threads, devices.size());
+      if (text_route)
+        rc = dealt ? ingest_text_file_dealt(path, max_threads, devices, map_chunk, &delivered)
+                   : ingest_text_file(path, max_threads, devices[0], [&](const gmx_ingest_result &res, int slot) { map_chunk(res, 0, slot); }, &delivered);
       auto sync_all = [&]() {
         for (int d = 0; d < (dealt ? gmx_group_size(grp) : 1); ++d) GMX_CHECK(gmx_engine_sync(gmx_group_engine(grp, d)));
       };
@@ -1750,7 +2013,7 @@ int run_genotype(const Args &a) {
       }
       if (rc == 2) {
         sync_all();
-        std::cerr << "warning: " << path << ": the device-side BGZF decoder gave up after " << delivered << " reads; the host reader takes over" << std::endl;
+        std::cerr << "warning: " << path << ": the device-side " << (text_route ? "FASTQ scanner" : "BGZF decoder") << " gave up after " << delivered << " reads; the host reader takes over" << std::endl;
         skip_reads = delivered;
         in_file = 0;               // (the host reader counts the file's reads from its start again)
         total_reads -= delivered;

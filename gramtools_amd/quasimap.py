@@ -739,6 +739,12 @@ class Ingest:
         self._keep[slot] = (buf, arr)
         check(self.lib.gmx_ingest_submit_bgzf_deferred(self.h, slot, buf.ctypes.data if buf.size else None, buf.size, arr, len(members)))
 
+    def submit_text_deferred(self, slot: int, text):
+        """Upload only (plain text dealt over several devices): gmx_ingest_scan follows when the end of the chunk before is known."""
+        buf = np.frombuffer(text, dtype=np.uint8) if not isinstance(text, np.ndarray) else text
+        self._keep[slot] = (buf,)
+        check(self.lib.gmx_ingest_submit_text_deferred(self.h, slot, buf.ctypes.data if buf.size else None, buf.size))
+
     def scan(self, slot: int, carry: bytes, final: bool):
         c = np.frombuffer(carry, dtype=np.uint8) if carry else np.zeros(0, dtype=np.uint8)
         check(self.lib.gmx_ingest_scan(self.h, slot, c.ctypes.data if c.size else None, c.size, 1 if final else 0))

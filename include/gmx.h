@@ -251,6 +251,7 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out);
 void gmx_ingest_destroy(gmx_ingest *g);
 uint64_t gmx_ingest_max_text(const gmx_ingest *g);
 uint64_t gmx_ingest_max_compressed(const gmx_ingest *g);
+uint64_t gmx_ingest_max_members(const gmx_ingest *g); /* most members a chunk may hold (files of many tiny members) */
 int gmx_ingest_reset(gmx_ingest *g); /* the next chunk is a file's first: nothing is carried into it */
 /* `compressed` (host memory; page-locked = asynchronous upload) must stay untouched until the slot's gmx_ingest_wait. */
 int gmx_ingest_submit_bgzf(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members,
@@ -264,6 +265,7 @@ int gmx_ingest_wait(gmx_ingest *g, int slot, gmx_ingest_result *out);
  * usual. Chunks are scanned in file order; their inflate kernels run ahead on all devices. */
 int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *compressed, uint64_t n_bytes, const gmx_bgzf_member *members,
                                     uint64_t n_members);
+int gmx_ingest_submit_text_deferred(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes); /* plain text dealt the same way */
 int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk);
 int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap); /* NULL out: its length */
 /* The slot's planes are read by work enqueued on hip_stream (the mapping call): its next submit waits for that work. */

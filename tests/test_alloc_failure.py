@@ -159,3 +159,76 @@ def test_engine_calls_survive_every_failed_allocation():
         feed()
         check_same(name)
     pk2.close()
+
+
+@pytest.mark.gpu
+def test_repeats_workload_survives_every_failed_allocation():
+    """The call that aborted a round-5 GPU suite (tests/test_repeats.py::test_gpu_matches_oracle: reads in 10-copy repeats —
+    instance lanes, large-capacity slots, their coverage chain): every host allocation of the call failing in turn."""
+    from test_repeats import _repeat_workload
+    lib = _lib.load()
+    prg, reads = _repeat_workload(60000, 800, 4000, 3, copies=10, seg=1500)
+    seeds = master_seeds(3, [4000])
+    offs = flat_offsets(4000, 150)
+    flat = np.ascontiguousarray(reads.reshape(-1))
+    ix = Index(prg, 10)
+    clean = Quasimapper(ix)
+    clean.map_reads(flat, offs, seeds)
+    want = clean.coverage()
+    qm = Quasimapper(ix)
+
+    def call():
+        try:
+            qm.reset()
+            qm.map_reads(flat, offs, seeds)
+            qm.coverage()
+            return 0
+        except GmxError as e:
+            return e.code
+    n = _count_allocs(lib, call)
+    codes = _walk(lib, call, max(n, 8))
+    assert all(c <= 0 for c in codes)
+    qm.reset()
+    qm.map_reads(flat, offs, seeds)
+    got = qm.coverage()
+    assert got.allele_sum_coverage == want.allele_sum_coverage and got.grouped_allele_counts == want.grouped_allele_counts
+    assert got.allele_base_coverage == want.allele_base_coverage and got.stats.as_dict() == want.stats.as_dict()
+
+
+@pytest.mark.gpu
+def test_grouped_log_paths_survive_every_failed_allocation(monkeypatch):
+    """Sites that use the grouped log with a log of 300 words: the host code between batches (log_settle: drain into a
+    std::map, replay) allocates per record; each of those allocations failing in turn is an error code, and a fresh engine
+    of the same index agrees with the oracle-checked clean run afterwards."""
+    from common import flatten_reads
+    from gramtools_amd.synth import mixed_variant_prg, simulate_haplotype_reads
+    monkeypatch.setenv("GMX_DENSE_MAX_ALLELES", "2")
+    lib = _lib.load()
+    ref = random_ref(6000, 3)
+    prg, sites = mixed_variant_prg(ref, 150, 4, max_alleles=7)
+    reads = simulate_haplotype_reads(ref, sites, 1500, 60, 150, 5)
+    seeds = master_seeds(42, [len(reads)])
+    flat, offs = flatten_reads(reads)
+    ix = Index(prg, 7)
+    assert ix.uses_grouped_log
+    clean = Quasimapper(ix, log_cap_words=300, max_batch_reads=500)
+    clean.map_reads(flat, offs, seeds)
+    want = clean.coverage()
+    qm = Quasimapper(ix, log_cap_words=300, max_batch_reads=500)
+
+    def call():
+        try:
+            qm.reset()
+            qm.map_reads(flat, offs, seeds)
+            qm.coverage()
+            return 0
+        except GmxError as e:
+            return e.code
+    n = _count_allocs(lib, call)
+    assert n > 50  # (the drained records)
+    codes = _walk(lib, call, n, max_points=250)
+    assert any(c != 0 for c in codes)
+    qm.reset()
+    qm.map_reads(flat, offs, seeds)
+    got = qm.coverage()
+    assert got.grouped_allele_counts == want.grouped_allele_counts and got.allele_sum_coverage == want.allele_sum_coverage
