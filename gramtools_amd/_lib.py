@@ -39,7 +39,8 @@ class QueueCounts(C.Structure):
 
 class StockReport(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("kmers", "states", "kmer_mismatches", "kmers_missing_in_files", "duplicate_kmers",
-                                          "mask_bits", "mask_mismatches")]
+                                          "mask_bits", "mask_mismatches", "cov_graph_state", "cov_graph_library_version",
+                                          "cov_graph_sites", "fm_index_bytes")]
 
 
 class Timing(C.Structure):

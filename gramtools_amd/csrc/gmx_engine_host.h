@@ -697,8 +697,13 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) try {
   return GMX_OK;
 } GMX_GUARD_INT("gmx_engine_reset_async")
 
+static bool gmx_ab_no_filter() {  // A/B runs ONLY (tools/kab.py): no k-mer filter, the two counters it decides stay zero
+  static const bool off = getenv("GMX_AB_NO_FILTER") != nullptr;
+  return off;
+}
 static void launch_filter(gmx_engine *e, hipStream_t st, dim3 task_grid, const BatchView &b, const SearchOut &o, int pass,
                           hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+  if (gmx_ab_no_filter()) return;
   if (e->filter_lds_words)
     hipExtLaunchKernelGGL(gmx_filter_lds_kernel, dim3(e->n_cus), dim3(GMX_FILTER_LDS_THREADS), e->filter_lds_words * 4,
                           st, t0, t1, 0u, e->dview, b, o, e->d_kmer_planar, e->filter_lds_words, pass);
@@ -994,7 +999,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
     hipLaunchKernelGGL(gmx_search_big_kernel, dim3(1024), dim3(64), big_lds, e->side_stream, e->dview, b, o, e->big, 0);
   }
   HIP_TRY(hipEventRecord(e->ev_side1, e->side_stream));
-  launch_filter(e, e->side_stream, task_grid, b, o, 0, t_ev(GMX_TK_FILTER0, 0), t_ev(GMX_TK_FILTER0, 1));
+  if (!gmx_ab_no_filter()) launch_filter(e, e->side_stream, task_grid, b, o, 0, t_ev(GMX_TK_FILTER0, 0), t_ev(GMX_TK_FILTER0, 1));
   // (timing leg: the events are attached to this very dispatch — its own start and end, as a kernel trace sees them —
   // instead of being recorded around it, where they add the gap to the kernel before and two barrier packets)
   hipEvent_t k0 = e->timing ? ev.a : nullptr, k1 = e->timing ? ev.b : nullptr;
@@ -1027,7 +1032,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   HIP_TRY(hipStreamWaitEvent(e->side2_stream, e->ev_side1, 0));
   // the second filter pass (the tasks the extend kernel found dead) comes first here: side 1 is busy with the first pass
   // for most of the batch, and behind the few-lane kernels below it would end after the main stream's last kernel
-  launch_filter(e, e->side2_stream, task_grid, b, o, 1, t_ev(GMX_TK_FILTER1, 0), t_ev(GMX_TK_FILTER1, 1));
+  if (!gmx_ab_no_filter()) launch_filter(e, e->side2_stream, task_grid, b, o, 1, t_ev(GMX_TK_FILTER1, 0), t_ev(GMX_TK_FILTER1, 1));
   // the extend kernel's overflow queue (and the tasks whose instances ran out of their pools): the 16-lane split search
   // first, one lane with a whole slot for what that leaves
   static const bool split2 = getenv("GMX_NO_SPLIT2") == nullptr;

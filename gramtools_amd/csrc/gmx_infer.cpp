@@ -141,8 +141,11 @@ struct Pmf {
   bool negbinom = false;
   double lambda = 0, k = 0, p = 0;
   double operator()(double cov) const {
-    if (!negbinom) return (-1 * lambda + cov * log(lambda) - lgamma(cov + 1));
-    return (lgamma(k + cov) - lgamma(cov + 1) - lgamma(k) + k * log(p) + cov * log(1 - p));
+    // (lgamma_r: the same values as lgamma — glibc's lgamma is lgamma_r plus a store to the global `signgam`, a formal data race
+    //  when the sites of a non-nested PRG are genotyped side by side)
+    int sg = 0;
+    if (!negbinom) return (-1 * lambda + cov * log(lambda) - lgamma_r(cov + 1, &sg));
+    return (lgamma_r(k + cov, &sg) - lgamma_r(cov + 1, &sg) - lgamma_r(k, &sg) + k * log(p) + cov * log(1 - p));
   }
 };
 struct LStats {  // likelihood_related_stats

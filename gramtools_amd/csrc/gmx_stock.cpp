@@ -8,8 +8,10 @@
 // read the way load.cpp:71-173 / make_data_structures.cpp:140-156 read them. On-disk form (sdsl/int_vector.hpp of v2.1.1,
 // int_vector_trait::write_header + int_vector::serialize): a 64-bit little-endian length IN BITS, then — variable-width
 // vectors only — one byte holding the width, then the values packed least-significant-bit first into 64-bit little-endian
-// words, (bits + 63) / 64 of them. `fm_index` (a serialised csa_wt) and `cov_graph` (a Boost binary archive) are not read:
-// both are pure functions of gram_dir/prg, which the native index is built from.
+// words, (bits + 63) / 64 of them. `fm_index` (a serialised csa_wt) is not decoded and of `cov_graph` (a Boost binary archive)
+// only the head is looked at (signature, library version, bubble_map's element count = the number of sites): both are pure
+// functions of gram_dir/prg, which the native index is built from. `gram build --check_stock` runs the comparison
+// (gmx_index_check_stock_files) on a gram_dir a stock build filled; `gram build --write_stock` writes the vectors and masks.
 //
 // PARITY UNPINNED: no file written by the reference exists in this repository (its tests hold none, and it cannot be built
 // here: SDSL, Boost and htslib are absent), so these readers are checked against the format as specified above, against
@@ -289,6 +291,48 @@ int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_s
       }
       for (uint64_t i = 0; i < m.v.size(); ++i)
         if ((m.v[i] != 0) != bwt_is(h, i, base)) out->mask_mismatches += 1;
+    }
+    // cov_graph: the head of the Boost binary archive (basic_binary_oarchive: the signature as a length-prefixed string, the
+    // library version, then the object — whose first member, bubble_map, starts with its element count). Where exactly the
+    // count lies depends on the Boost version's widths for class information (tracking flag, class version) and collection
+    // sizes: the first 8-byte value in the 64 bytes behind the version that equals the native site count is taken as found,
+    // else the first plausible one (non-zero, below 2^32) is reported. PARITY UNPINNED like the rest of this file.
+    {
+      FILE *f = fopen(join_path(d, "cov_graph").c_str(), "rb");
+      if (f) {
+        unsigned char head[160];
+        const size_t got = fread(head, 1, sizeof(head), f);
+        fclose(f);
+        static const char sig[] = "serialization::archive";
+        const size_t sl = sizeof(sig) - 1;
+        uint64_t len = 0;
+        if (got >= 8 + sl + 2) memcpy(&len, head, 8);
+        if (len == sl && memcmp(head + 8, sig, sl) == 0) {
+          out->cov_graph_state = 1;
+          out->cov_graph_library_version = (uint64_t)head[8 + sl] | ((uint64_t)head[8 + sl + 1] << 8);
+          const uint64_t want = h.sites.size();
+          uint64_t first_plausible = 0;
+          for (size_t at = 8 + sl + 2; at + 8 <= got && at < 8 + sl + 2 + 64; ++at) {
+            uint64_t v = 0;
+            memcpy(&v, head + at, 8);
+            if (v == want && want) {
+              out->cov_graph_state = 2;
+              out->cov_graph_sites = v;
+              break;
+            }
+            if (!first_plausible && v && v < (1ull << 32) && at >= 8 + sl + 2 + 2) first_plausible = v;
+          }
+          if (out->cov_graph_state == 1 && want) {
+            out->cov_graph_state = 3;
+            out->cov_graph_sites = first_plausible;
+          }
+        }
+      }
+      FILE *g = fopen(join_path(d, "fm_index").c_str(), "rb");
+      if (g) {
+        if (fseek(g, 0, SEEK_END) == 0) out->fm_index_bytes = (uint64_t)std::max<long>(ftell(g), 0);
+        fclose(g);
+      }
     }
     return GMX_OK;
   } catch (std::exception const &e) {

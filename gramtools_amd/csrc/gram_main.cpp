@@ -1649,8 +1649,29 @@ int run_build(const Args &a) {
     GMX_CHECK(gmx_index_save(ix, cache.c_str()));
     std::cout << "Wrote index cache " << cache << std::endl;
   }
+  int rc = 0;
+  // a gram_dir that a STOCK `gramtools build` filled (kmers, kmers_stats, sa_intervals, paths, the four base
+  // masks: build/kmer_index/dump.cpp:27-137, load.cpp:71-173; cov_graph: prg_info.cpp:13-15) checked against the index built
+  // here from the same prg; --write_stock writes the SDSL vectors and masks of this index in those formats.
+  if (a.has("write_stock") && k > 0) {
+    GMX_CHECK(gmx_index_write_stock_files(ix, gram_dir.c_str()));
+    std::cout << "Wrote kmers, kmers_stats, sa_intervals, paths and the four base masks in the stock (SDSL) formats" << std::endl;
+  }
+  if (a.has("check_stock") && k > 0) {
+    gmx_stock_report rep;
+    GMX_CHECK(gmx_index_check_stock_files(ix, gram_dir.c_str(), &rep));
+    const bool ok = rep.kmer_mismatches == 0 && rep.duplicate_kmers == 0 && rep.mask_mismatches == 0 && rep.cov_graph_state != 3;
+    std::cout << "Stock files: " << rep.kmers << " kmers, " << rep.states << " states, " << rep.kmer_mismatches << " kmers with other states, "
+              << rep.kmers_missing_in_files << " indexed here and not in the files, " << rep.duplicate_kmers << " duplicates; masks: " << rep.mask_bits
+              << " bits, " << rep.mask_mismatches << " differ; cov_graph: "
+              << (rep.cov_graph_state == 0 ? "absent" : rep.cov_graph_state == 1 ? "archive signature found" : rep.cov_graph_state == 2 ? "archive signature and site count agree" : "site count differs")
+              << (rep.cov_graph_state ? " (Boost archive version " + std::to_string(rep.cov_graph_library_version) + ")" : std::string())
+              << "; fm_index: " << (rep.fm_index_bytes ? std::to_string(rep.fm_index_bytes) + " bytes (not decoded)" : std::string("absent")) << std::endl;
+    std::cout << (ok ? "Stock files agree with the native index" : "Stock files DIFFER from the native index") << std::endl;
+    if (!ok) rc = 1;
+  }
   gmx_index_destroy(ix);
-  return 0;
+  return rc;
 }
 
 // The master generator's raw draws (RandomInclusiveInt's mt19937, random.cpp:4-19: operator() = the raw 32-bit output),

@@ -327,6 +327,13 @@ typedef struct gmx_stock_report {
   uint64_t kmers_missing_in_files;      /* indexed natively, absent from the files (a stock build may index fewer k-mers) */
   uint64_t duplicate_kmers;
   uint64_t mask_bits, mask_mismatches;  /* over the four masks */
+  /* cov_graph (a Boost binary archive of coverage_Graph, prg_info.cpp:13-15; only its head is looked at — the archive signature,
+   * the library version, and the first collection count behind them, which is bubble_map's = the number of variant sites,
+   * coverage_graph.hpp:220-233). 0 = no such file; 1 = signature found; 2 = ... and the site count equals the native index's;
+   * 3 = signature found, a different count where the site count was expected */
+  uint64_t cov_graph_state, cov_graph_library_version, cov_graph_sites;
+  /* fm_index (sdsl::csa_wt over int_vector<>): bytes of the file, 0 = absent; not decoded (SA and BWT are re-derived from prg) */
+  uint64_t fm_index_bytes;
 } gmx_stock_report;
 /* reads the files of gram_dir and compares them with the native index of the same PRG and k */
 int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_stock_report *out);

@@ -136,3 +136,43 @@ def test_round_trip_of_the_native_index(tmp_path, seed):
     assert lib.gmx_stock_write_int_vector(str(tmp_path / "sa_intervals").encode(), v.ctypes.data_as(C.POINTER(C.c_uint64)), v.size, w, 0) == 0
     assert lib.gmx_index_check_stock_files(ix.h, str(tmp_path).encode(), C.byref(rep)) == 0
     assert rep.kmer_mismatches == 1
+
+
+def test_gram_build_write_and_check_stock(tmp_path):
+    """`gram build --write_stock` then `gram build --check_stock` (round 6: the readers are wired into the executable): the
+    round trip agrees; a cov_graph whose Boost archive head carries the right / a wrong site count is told apart (hand-assembled
+    head: signature string, library version 17, class information, bubble_map's element count — unpinned like the rest); a
+    damaged mask makes the command fail with exit code 1."""
+    import subprocess
+    from gramtools_amd.build import build_gram
+    gram = build_gram()
+    ref = random_ref(3000, 9)
+    prg, *_ = snp_prg(ref, 80, 10, multi_allelic_frac=0.3)
+    n_sites = len({x for x in prg if x > 4 and x % 2 == 1})
+    np.asarray(prg, dtype="<u4").tofile(tmp_path / "prg")
+
+    def run(*flags):
+        return subprocess.run([gram, "build", "--gram_dir", str(tmp_path), "--kmer_size", "5", "--max_threads", "2", *flags],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    r = run("--write_stock")
+    assert r.returncode == 0 and "Wrote kmers" in r.stdout, r.stdout
+    r = run("--check_stock")
+    assert r.returncode == 0 and "Stock files agree" in r.stdout and "cov_graph: absent" in r.stdout, r.stdout
+
+    def archive_head(count):
+        sig = b"serialization::archive"
+        return struct.pack("<Q", len(sig)) + sig + struct.pack("<H", 17) + b"\x00\x00\x00\x00\x00" + struct.pack("<Q", count) + b"\x00" * 40
+    (tmp_path / "cov_graph").write_bytes(archive_head(n_sites))
+    (tmp_path / "fm_index").write_bytes(b"\x00" * 100)
+    r = run("--check_stock")
+    assert r.returncode == 0 and "archive signature and site count agree (Boost archive version 17)" in r.stdout and "fm_index: 100 bytes" in r.stdout, r.stdout
+    (tmp_path / "cov_graph").write_bytes(archive_head(n_sites + 3))
+    r = run("--check_stock")
+    assert r.returncode == 1 and "site count differs" in r.stdout and "DIFFER" in r.stdout, r.stdout
+    (tmp_path / "cov_graph").unlink()
+    bits, w = _read(tmp_path / "g_base_bwt_mask", 1)
+    bits[7] ^= 1
+    v = np.asarray(bits, dtype=np.uint64)
+    assert _lib.load().gmx_stock_write_int_vector(str(tmp_path / "g_base_bwt_mask").encode(), v.ctypes.data_as(C.POINTER(C.c_uint64)), v.size, 1, 1) == 0
+    r = run("--check_stock")
+    assert r.returncode == 1 and "1 differ" in r.stdout, r.stdout
