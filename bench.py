@@ -32,9 +32,9 @@ Extra keys (rank 0; the side legs run at N = 1 only unless noted):
                    dominant one: HBM fraction by the byte model of DESIGN.md §8, by counter traffic, and its issue fraction),
                    then the single-instance coverage kernel, the k-mer filter and the seed look-up — each with the duration
                    of its own dispatch measured live (HIP events attached to the dispatch inside the library)
-  configs          (N = 1) BASELINE.json configs[2] and configs[3] built at full size: kernel-pipeline and packed-feed
-                   reads/s and their leading kernels' durations (--configs 2,3,4 adds configs[4] on a box with >= 280 GiB)
-  jobs             the timed job is run --jobs times (default 5), exactly --steps steps each; `value` is the MEDIAN job
+  configs          (N = 1) BASELINE.json configs[2], configs[3] and (on a box with >= 280 GiB of host memory) configs[4] built at
+                   full size: kernel-pipeline and packed-feed reads/s, their leading kernels' durations and roofline objects
+  jobs             the timed job (exactly --steps steps) is run as often as it takes to add up to 1 s; `value` is the MEDIAN job
 """
 import argparse
 import json
@@ -66,7 +66,7 @@ PCIE_PEAK_GBS = 63.0                                       # MI355X_MICROARCH.md
 # planes 48 + PRG text records 3.4 x 32 (64 symbols each; loop_stats.txt: 3.3 heavy steps per lane) + marker sub-records of the
 # sites that are not inline 0.15 x 16 + path nodes 2 x 12 + coverage record 32 + task id 4   (264 B with round 2's 16 B records)
 B_DESIGN_PER_READ = 4 + 8 + 48 + 109 + 2 + 2 * 12 + 32 + 4
-PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round5"), os.path.join(ROOT, "profiles", "round4"), os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", "round6"), os.path.join(ROOT, "profiles", "round5"), os.path.join(ROOT, "profiles", "round4"), os.path.join(ROOT, "profiles", "round3"), os.path.join(ROOT, "profiles", "round2")]
 
 
 def profile_json(name):
@@ -261,12 +261,13 @@ def cli_end_to_end(prg, batches, threads):
         t_build = time.time() - t0
         if b.returncode:
             return {"error": b.stdout[-400:]}
-        runs = []
-        for rep in range(2):  # the same call twice (the FASTQ is in the page cache both times); both are reported
+        def one_call(n_threads, tag, extra_env=None):
+            env = dict(os.environ)
+            env.update(extra_env or {})
             t0 = time.time()
             g = subprocess.run([gram, "genotype", "--gram_dir", d, "--reads", fq, "--sample_id", "bench", "--ploidy", "haploid",
-                                "--kmer_size", str(KMER), "--genotype_dir", os.path.join(d, f"run{rep}"), "--max_threads",
-                                str(threads), "--seed", "42"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                                "--kmer_size", str(KMER), "--genotype_dir", os.path.join(d, tag), "--max_threads",
+                                str(n_threads), "--seed", "42"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
             t_all = time.time() - t0
             if g.returncode:
                 return {"error": g.stdout[-400:]}
@@ -279,7 +280,30 @@ def cli_end_to_end(prg, batches, threads):
                     t_load = float(line.rsplit(":", 1)[1])
                 if line.strip().startswith("feed:"):
                     feed = line.strip()
-            runs.append(dict(parse_and_map_s=t_map, whole_call_s=t_all, index_load_s=t_load, feed=feed))
+            return dict(parse_and_map_s=t_map, whole_call_s=t_all, index_load_s=t_load, feed=feed)
+        runs = []
+        for rep in range(2):  # the same call twice (the FASTQ is in the page cache both times); both are reported
+            r_ = one_call(threads, f"run{rep}")
+            if "error" in r_:
+                return r_
+            runs.append(r_)
+        # Which reader takes a plain FASTQ depends on the host threads the caller grants (gram_main.cpp: plain_fastq_on_device): below
+        # 32 the file's bytes go up as they are and the GPU scans and packs them (round 6), from 32 on the host's parallel parser packs
+        # them to 2 bits first. Both routes at the thread counts a user is likely to pass (the reference's default is 1):
+        n_reads_cli = sum(r.shape[0] for r in batches)
+        by_threads = {}
+        for nt, env_, label in ((1, {}, "device text feed"), (16, {}, "device text feed"), (1, {"GMX_HOST_FASTQ": "1"}, "host parser"),
+                                (16, {"GMX_HOST_FASTQ": "1"}, "host parser"), (threads, {"GMX_DEVICE_FASTQ": "1"}, "device text feed")):
+            best_ = None
+            for rep in range(2):
+                r_ = one_call(nt, f"t{nt}_{label.split()[0]}", env_)
+                if "error" in r_:
+                    best_ = r_
+                    break
+                if best_ is None or (r_["parse_and_map_s"] or 1e30) < (best_["parse_and_map_s"] or 1e30):
+                    best_ = r_
+            key = f"{label}, --max_threads {nt}"
+            by_threads[key] = best_ if "error" in best_ else {"parse_and_map_s": best_["parse_and_map_s"], "value": n_reads_cli / best_["parse_and_map_s"], "unit": "reads/s", "whole_call_s": best_["whole_call_s"]}
         # many samples on one index upload (`--samples_list`, round 5): the same FASTQ as 8 samples of one call
         n_smp = 8
         with open(os.path.join(d, "samples.tsv"), "w") as fh:
@@ -308,6 +332,8 @@ def cli_end_to_end(prg, batches, threads):
                 "whole_call_s": t_all, "whole_call_reads_per_s": n / t_all, "index_load_s": t_load, "gram_build_s": t_build,
                 "feed": feed, "parse_and_map_s_of_both_calls": [r["parse_and_map_s"] for r in runs],
                 "whole_call_s_of_both_calls": [r["whole_call_s"] for r in runs], "samples_in_one_call": multi,
+                "reader": "host parser (2-bit planes, 40 B per read over the link): --max_threads >= 32; by_threads holds both readers at 1, 16 and this many threads",
+                "by_threads": by_threads,
                 "note": "plain four-line FASTQ -> coverage files, the call made twice and the faster one quoted; parse_and_map = parser threads (2-bit planes) + H2D + kernels"}
 
 
@@ -341,6 +367,8 @@ def config_leg(which, n_reads, steps, device, stream):
         ix = Index(prg, k)
     else:
         k, what = 14, "configs[4]: 3.1 G bases + 85 M sites (the configs[3] mix), k = 14; index replicated per GPU"
+        if os.environ.get("GMX_BENCH_SKIP_C4"):
+            return {"skipped": "GMX_BENCH_SKIP_C4 is set"}
         if _container_memory_gib() < 280:
             return {"skipped": f"needs >= 280 GiB of host memory for the index build; this box has {_container_memory_gib():.0f} GiB"}
         path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gmx_bench_{os.getpid()}.prg")
@@ -423,7 +451,30 @@ def config_leg(which, n_reads, steps, device, stream):
         if kk["launches"]:
             kernels[label] = kk["ms"] / kk["launches"]
     dominant = max(kernels, key=kernels.get)
-    out = {"workload": what, "reads_per_step": n, "steps": steps, "symbols": int(info.n_text - 1), "sites": int(info.n_sites),
+    # roofline objects (round 6): algorithmic bytes and counter traffic from the configuration's own profile
+    # (profiles/round*/config<N>_roofline.json: rocprofv3 kernel stats, FETCH_SIZE / WRITE_SIZE passes and the stats build's step
+    # counts of the same workload; tools/config_roofline.py), the kernels' durations LIVE from this run's dispatch events
+    rj, rj_src = profile_json(f"config{which}_roofline.json")
+    roof = []
+    for obj in (rj or {}).get("roofline", []):
+        kn = obj.get("kernel", "")
+        if kn.startswith("gmx_extend_kernel"):
+            ms = tm["search_ms"] / L
+        elif kn.startswith("gmx_probe_kernel") or kn.startswith("gmx_seed_kernel"):
+            ms = tm["kernels"]["seed"]["ms"] / max(tm["kernels"]["seed"]["launches"], 1)
+        elif kn.startswith("gmx_cover"):
+            ms = tm["kernels"]["single"]["ms"] / max(tm["kernels"]["single"]["launches"], 1)
+        else:
+            continue
+        if not ms:
+            continue
+        per_launch = obj["alg_bytes_per_read"] * n if "alg_bytes_per_read" in obj else obj.get("alg_bytes_per_task", 0) * 2 * n
+        a = per_launch / (ms / 1e3) / 1e9
+        roof.append({"kernel": kn, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                     "traffic": obj.get("traffic"), "traffic_over_algorithmic": (obj["traffic"] / per_launch) if obj.get("traffic") and per_launch else None,
+                     "avg_launch_ms": ms, "alg_bytes_per_launch": int(per_launch), "alg_bytes_model": obj.get("alg_bytes_model"),
+                     "measured": "duration: HIP events attached to this run's dispatches; bytes model and counter traffic: " + str(rj_src)})
+    out = {"workload": what, "roofline": roof, "reads_per_step": n, "steps": steps, "symbols": int(info.n_text - 1), "sites": int(info.n_sites),
            "index_bytes": int(info.index_bytes), "is_nested": bool(info.is_nested), "build_and_generate_s": round(t_build, 1),
            "kernel_pipeline": {"value": float(np.median(rates)), "unit": "reads/s", "runs": [float(r) for r in rates]},
            "packed_host_feed": {"value": float(np.median(feed[1:])), "unit": "reads/s", "runs": [float(r) for r in feed[1:]]},
@@ -445,8 +496,10 @@ def main():
     ap.add_argument("--total-reads", type=int, default=0,
                     help="strong scaling: this many reads per step for the WHOLE job, split over the GPUs")
     ap.add_argument("--batches", type=int, default=N_BATCHES, help="distinct batches of reads cycled by the timed loop")
-    ap.add_argument("--jobs", type=int, default=5, help="the timed job (exactly --steps steps) is run this many times; value = the median job")
-    ap.add_argument("--configs", default="2,3", help="N = 1 side legs: BASELINE configs built at full size (2,3; 4 needs >= 280 GiB of host memory and ~6 minutes)")
+    ap.add_argument("--jobs", type=int, default=0, help="the timed job (exactly --steps steps) is run this many times; value = the median job. "
+                                                        "0 (default): as many as it takes for the jobs to add up to 1 s of timed work (5 <= jobs <= 150)")
+    ap.add_argument("--configs", default="2,3,4", help="N = 1 side legs: BASELINE configs built at full size (configs[4] runs when the box has >= 280 GiB of host memory: ~6 minutes; "
+                                                       "GMX_BENCH_SKIP_C4=1 leaves it out)")
     ap.add_argument("--config-reads", type=int, default=1_000_000, help="reads per step of the --configs legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel_pipeline / sustained / cli_end_to_end / roofline leg")
@@ -611,8 +664,15 @@ def main():
         job(args.warmup)
     # `--jobs` jobs of EXACTLY `steps` steps each, every one between fences (barrier + device synchronisation on both
     # sides, max over ranks); the MEDIAN job is the one quoted (a 15 ms job moves by several per cent on one hiccup)
-    runs = []
-    for j in range(max(1, args.jobs)):
+    # (round 6: `value` rests on >= 1 s of timed jobs — a K = 20 job takes 15 ms and five of them were all the headline stood on;
+    #  every job is still EXACTLY K steps between its own fences, the count of jobs is what grows)
+    runs = [timed(job, args.steps, args.warmup)]
+    n_jobs = args.jobs if args.jobs > 0 else int(min(150, max(5, -(-1.0 // max(runs[0][0], 1e-4)))))
+    if world > 1:  # (every rank must run the same number of jobs: rank 0's count)
+        nj = torch.tensor([n_jobs], device="cuda")
+        dist.broadcast(nj, 0)
+        n_jobs = int(nj.item())
+    for j in range(1, n_jobs):
         runs.append(timed(job, args.steps, args.warmup + j * args.steps))
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     dt, own, cov = runs[order[len(order) // 2]]
@@ -691,6 +751,20 @@ def main():
         add_kernel("gmx_seed_kernel", k_ms("seed"), n_tasks_l * (16 + 8) + reads_per_launch * 12 + (n_dead0 or 0) * 4,
                    "per task: the read's last plane pair 16 + seed directory entry 8; per alive task 12 (queue entry + entry copy), per dead task 4",
                    "2 M scattered 8-byte entries of a 537 MB table per launch", "gmx_seed_kernel")
+        # which kernel leads: the arg-max of the LIVE timers of this run (round 5's line named gmx_extend_kernel by a literal while its own
+        # timers showed the filter's first pass longer). Two answers, both stated: the longest kernel on the batch's main chain
+        # (unpack -> seed -> extend -> extend<2> -> single-instance coverage: what a batch cannot be shorter than) and the longest
+        # dispatch on any stream (the k-mer filter's passes run on side streams beside that chain: tools/kab.py, round 6 — without
+        # the filter a step of the kernel pipeline is 4-6 % shorter, so its duration is mostly waiting for a CU's LDS, not work).
+        live = {"gmx_extend_kernel<false,1>": (search_s * 1e3, "main"), "gmx_seed_kernel": (k_ms("seed"), "main"),
+                "gmx_cover_jump_kernel": (k_ms("single"), "main"), "gmx_extend_kernel<false,2> (stragglers)": (k_ms("extend2"), "main"),
+                "gmx_unpack2_kernel": (k_ms("unpack"), "main"), "gmx_filter_lds_kernel pass 0": (k_ms("filter0"), "side stream 1"),
+                "gmx_filter_lds_kernel pass 1": (k_ms("filter1"), "side stream 2")}
+        live = {k_: v_ for k_, v_ in live.items() if v_[0]}
+        dominant = {"longest_on_the_main_chain": max((k_ for k_ in live if live[k_][1] == "main"), key=lambda k_: live[k_][0]),
+                    "longest_dispatch_on_any_stream": max(live, key=lambda k_: live[k_][0]),
+                    "live_ms": {k_: {"ms": round(v_[0], 4), "stream": v_[1]} for k_, v_ in live.items()},
+                    "measured": "HIP events attached to each dispatch in this run (reads-resident leg, 5 timed batches)"}
         out = {
             "metric": "150bp reads quasimapped/sec (whole node); bit-exact coverage",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -713,8 +787,10 @@ def main():
                        "exchange": exchange, "index_build_s": round(t_index, 2), "reads_generation_s": round(t_reads, 2),
                        "index_bytes": int(ix.info.index_bytes)},
             "h2d_rate_GBps": h2d_gbs,
-            "jobs": {"n": len(job_seconds), "seconds": job_seconds, "value_is": "the median job",
-                     "values": [total_reads / x for x in job_seconds]},
+            "jobs": {"n": len(job_seconds), "total_seconds": float(sum(job_seconds)), "value_is": "the median job (each job: exactly `steps` steps between fences; enough jobs for >= 1 s of timed work)",
+                     "min_value": total_reads / max(job_seconds), "max_value": total_reads / min(job_seconds),
+                     "p10_p90_values": [total_reads / float(np.percentile(job_seconds, 90)), total_reads / float(np.percentile(job_seconds, 10))],
+                     "first_values": [total_reads / x for x in job_seconds[:8]]},
             "roofline": {
                 # what bounds the STEP: the host link. 37.5 B per read cross PCIe once; the kernels of a batch take less than
                 # half of the step (kernel_pipeline), the rest of the time the GPU waits for the next batch's bytes.
@@ -724,7 +800,8 @@ def main():
                 "peak_source": "MI355X_MICROARCH.md: host link PCIe Gen5 x16, 63 GB/s (spec), per direction",
                 "step_ms": dt / args.steps * 1e3,
                 "kernels_ms_per_step": side.get("kernel_pipeline", {}).get("ms_per_step"),
-                "dominant_kernel": "gmx_extend_kernel",
+                "dominant_kernel": dominant["longest_on_the_main_chain"],
+                "dominant_kernel_is": dominant,
                 "kernels": kernel_rooflines,
             },
             "stats_job": st,

@@ -1,6 +1,7 @@
 """One configuration's index built and its reads mapped through the kernel-pipeline loop (bytes resident in HBM) and the
 packed host feed (2-bit stream from page-locked memory), for use under rocprofv3 (tools/profile_round4.sh):
-  python tools/profile_config.py 3|4|4s [N_READS=1000000] [STEPS=6]
+  python tools/profile_config.py 2|3|4|4s [N_READS=1000000] [STEPS=6]
+    2   BASELINE configs[2]: 23.3 Mb + 2000 nested MSA regions + 100 k SNPs, k = 10
     3   BASELINE configs[3]: 64.4 Mb + 1.8 M sites, k = 14 (index 15.5 GB)
     4   BASELINE configs[4]: 3.1 Gb + 85 M sites, k = 14 (index 160 GB; 4-5 minutes of build)
     4s  configs[4] at an eighth of its length (400 Mb + 11 M sites)
@@ -21,7 +22,11 @@ which = sys.argv[1]
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 t0 = time.time()
-if which == "3":
+if which == "2":
+    from gramtools_amd.synth import pf3d7_recipe
+    prg, reads = pf3d7_recipe(23_300_000, 2000, 100_000, n, 22)
+    ix = Index(prg, 10)
+elif which == "3":
     prg, reads = chr20_recipe(64_444_167, 1_800_000, n, 32)
     ix = Index(prg, 14)
 else:
