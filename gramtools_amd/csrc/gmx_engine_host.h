@@ -621,6 +621,25 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
       (void)hipGetLastError();  // (no room: the occurrences are screened through the suffix array and the text, as before)
     }
   }
+  // ... and the screening side table of the multi-state entries (GmxIndexView::seed_side; gmx_seed_side_kernel): + a word per
+  // four seed words (20 GB at configs[4]). GMX_NO_SEED_SIDE=1: entries are walked header by header as until round 5 (A/B runs).
+  if (e->seed_cursor && !rc && !getenv("GMX_NO_SEED_SIDE") && h.seed_words.size() > 1) {
+    uint32_t *side = nullptr;
+    const size_t n_side = h.seed_words.size() / 4 + 2;
+    if (e->alloc(&side, n_side, false) == GMX_OK) {
+      hipLaunchKernelGGL(gmx_seed_side_kernel, dim3(8192), dim3(256), 0, nullptr, e->dview.seeds, (uint64_t)h.seeds.size(), e->dview.seed_words,
+                         e->dview.seed_shift, side);
+      if (h.kmer_size2)
+        hipLaunchKernelGGL(gmx_seed_side_kernel, dim3(8192), dim3(256), 0, nullptr, e->dview.seeds2, (uint64_t)h.seeds2.size(), e->dview.seed_words,
+                           e->dview.seed_shift, side);
+      if (hipDeviceSynchronize() == hipSuccess) {
+        e->dview.seed_side = side;
+        e->index_bytes += n_side * sizeof(uint32_t);
+      }
+    } else {
+      (void)hipGetLastError();  // (no room: the screen walks the entries themselves)
+    }
+  }
   // (stream priorities for the side streams — the few-task kernels first — were measured in round 4: no difference, the
   //  chains there wait for memory, not for wave slots)
   rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;

@@ -134,6 +134,8 @@ static_assert(GMX_STACK_DEPTH * sizeof(GmxParked) <= GMX_FAST_STATES * sizeof(Gm
 // how many there are: a seed state is rejected on it without any fetch (FastCtx::next_seed_screened).
 #define GMX_SEEDST_TEXT 0x80000000u
 #define GMX_SEEDST_CTX 14u
+#define GMX_SIDE_NONE 0xFFFFFFFFu  // screening side table (gmx_seed_side_kernel below): "this entry has no side words"
+#define GMX_SIDE_CTX 6u            // ... bases of left context in a side word
 struct GmxSeedState {
   uint32_t lo, hi, nt, ng, ctx;
   __device__ __forceinline__ bool text() const { return hi == GMX_TEXT_MARK; }
@@ -184,6 +186,8 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
   uint32_t seed_pos;                // read position of the seed states
   uint32_t mark_arena, mark_out;    // arena / emitted-state counts when the current seed state started
   uint32_t seed_rctx, seed_rn = 0xFFFFFFFFu;  // the read's bases left of seed_pos as a left-context word, and how many (lazily)
+  uint64_t seed_base = 0;           // word offset of the entry's FIRST state (0: not known — a cursor continued by a later kernel: no side words)
+  uint32_t seed_ns = 0;             // ... and its number of states
   __device__ __forceinline__ bool more_seeds() const { return seed_left != 0 && status == GMX_TASK_MAPPED; }
   __device__ __forceinline__ bool next_seed(const GmxIndexView &ix, bool release, uint32_t &a, uint32_t &b, uint32_t &tvd,
                                             uint32_t &tvg, uint32_t &pos, uint32_t &mode) {
@@ -275,7 +279,33 @@ struct FastCtx {  // pending-entry stack in LDS (lane-strided), traversed-path a
       // iteration found some lane with a candidate and the wave paid the heavy path ~30 times per entry.
       GmxSeedState ss;
       bool have = false;
+      const uint32_t *side = ix.seed_side && seed_base ? ix.seed_side + ((seed_base - 1u) >> 2) : nullptr;
+      if (side && side[0] == GMX_SIDE_NONE) side = nullptr;
       while (seed_left != 0) {
+        if (side) {  // skip what the side words reject (consecutive words: a line or two per entry), land on the next candidate's header
+          // (four side words per load, from the aligned 16 bytes that hold word j: a word per load was a chain of ~ns dependent
+          //  L1 round trips per lane; what the block holds beyond the entry's words is never looked at)
+          uint32_t j = seed_ns - seed_left, sw = 0;
+          bool cand = false;
+          while (j < seed_ns && !cand) {
+            const uintptr_t at = reinterpret_cast<uintptr_t>(side + j);
+            const uint4 q = *reinterpret_cast<const uint4 *>(at & ~(uintptr_t)15);
+            const uint32_t qs[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+              if (cand || t < (uint32_t)((at & 15u) >> 2) || j >= seed_ns) continue;
+              sw = qs[t];
+              const uint32_t n6 = min((sw >> 12) & 7u, seed_rn);
+              if (n6 == 0 || ((sw ^ seed_rctx) & ((1u << (2u * n6)) - 1u)) == 0u)
+                cand = true;
+              else
+                ++j;
+            }
+          }
+          seed_left = seed_ns - j;
+          if (seed_left == 0) break;
+          seed_off = seed_base + (sw >> 16);
+        }
         ss = gmx_seed_state(ix.seed_words + seed_off);
         if (!(ss.text() && ctx_dead(ss.ctx))) {
           have = true;
@@ -612,6 +642,44 @@ __global__ void gmx_sa_ctx_kernel(const uint32_t *sa, const GmxTextRec *text, ui
     out[i] = gmx_left_context(text, sa[i]);
 }
 
+// The screening side table (round 6; GmxIndexView::seed_side). A whole-genome index has ~16 states per 14-mer and a task's screen
+// (FastCtx::next_seed_screened, phase A) walked its entry header by header — 16 bytes of every state, 24 with paths: ~7 scattered
+// 64-byte lines among 82 GB per task, and scattered lines are what the probe kernel is bound by (profiles/round4/
+// config4_roofline.json: 19 G lines/s). All the screen needs of a state is its left context; here it is, ONE word per state, the
+// entry's words side by side: bits 0-11 the six bases left of the position (nearest first), bits 12-14 how many there are (0: the
+// state is never rejected here — an interval state, or a position right of a marker), bits 16-31 the state's word offset from the
+// entry's first state. The states the six bases do not reject (one in 4 096 of the dead ones) are then judged as before, on
+// their own header and text record. An entry at word offset W (its count word) of n states owns seed_side[W >> 2 .. (W >> 2) + n):
+// it is at least 1 + 4 n words long, so the next entry's words start behind. GMX_SIDE_NONE in an entry's first word: no side
+// words (a state lies more than 65 535 words into the entry): the entry is walked as before.
+__global__ void gmx_seed_side_kernel(const GmxSeed *seeds, uint64_t n, const uint32_t *seed_words, uint32_t seed_shift, uint32_t *side) {
+  for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const GmxSeed s = seeds[i];
+    if (s.a != GMX_SEED_COMPLEX || (s.b & GMX_SEEDF_EMPTY)) continue;
+    const uint64_t W = (uint64_t)GMX_SEED_OFF(s.b) << seed_shift;
+    const uint32_t *w = seed_words + W;
+    const uint32_t ns = *w++;
+    uint32_t *out = side + (W >> 2);
+    uint64_t rel = 0;
+    bool ok = ns <= 0xFFFFu;
+    for (uint32_t j = 0; ok && j < ns; ++j) {
+      if (rel > 0xFFFFu) {
+        ok = false;
+        break;
+      }
+      const GmxSeedState ss = gmx_seed_state(w + rel);
+      uint32_t word = (uint32_t)rel << 16;
+      if (ss.text()) {
+        const uint32_t cnt = min(ss.ctx >> 28, GMX_SIDE_CTX);
+        word |= (ss.ctx & ((1u << (2u * cnt)) - 1u)) | (cnt << 12);
+      }
+      out[j] = word;
+      rel += ss.words();
+    }
+    if (!ok && ns) out[0] = GMX_SIDE_NONE;
+  }
+}
+
 // push(lo, hi, tvd, tvg) receives every seed state
 template <class Ctx, class Push>
 __device__ void load_seed(const GmxIndexView &ix, const GmxSeed *table, uint32_t code, Ctx &ctx, Push push) {
@@ -667,6 +735,8 @@ __device__ __forceinline__ void load_seed_cursor(const GmxIndexView &ix, const G
     return;
   }
   ctx.seed_off = (uint64_t)(gmx_seed_entry(ix, s.b) - ix.seed_words) + 1;
+  ctx.seed_base = ctx.seed_off;
+  ctx.seed_ns = ns;
   ctx.seed_pos = from;
   ctx.seed_left = ns;
   ctx.mark_arena = ctx.arena_n;

@@ -244,6 +244,9 @@ struct GmxIndexView {
   const uint32_t *kmer_bitmap;  // [4^k / 32] presence bits (all_read_kmers_occur_in_index, quasimap.cpp:212-225)
   const uint32_t *sa_ctx;       // [n] or null: left-context word of text position sa[i] (device only, engines with a seed cursor:
                                 //   the occurrences of a path-less seed interval are screened from consecutive words; gmx_engine.hip)
+  const uint32_t *seed_side;    // [n_seed_words / 4 + 1] or null: one word per state of every multi-state k-mer index entry, the states
+                                //   of the entry at word offset W (its count word) at seed_side[W >> 2 ...] (device only, engines with a
+                                //   seed cursor; gmx_seed_side_kernel, FastCtx::next_seed_screened)
 };
 
 // Status of one (read, orientation) task after the search kernel.

@@ -102,3 +102,37 @@ def test_engine_flat_prg_with_units_and_a_cached_index(monkeypatch, tmp_path):
         qm = Quasimapper(ix)
         qm.map_reads(flat, offs, seeds)
         assert canonical_cov(qm.coverage()) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,shift", [(5, "0"), (6, "3"), (4, "2")])
+def test_screening_side_table_matches_oracle_and_the_header_walk(monkeypatch, k, shift):
+    """Round 6: the seed cursor's screen reads one side word per state (six bases of left context + the state's offset;
+    gmx_seed_side_kernel) instead of every state's header. A small k on a dense PRG (configs[4]'s variant mix: SNPs, anchored
+    indels, pure deletions, 3-4 alleles, a site every 36 bases) gives every k-mer hundreds of states — text-form ones, interval
+    states, states with paths (whose headers have other lengths: the offsets) —, reads error-free and as a sequencer delivers
+    them (mismatches: the six bases pass, the fourteen reject; Ns; ragged). Against the oracle, and identical raw accumulators
+    with GMX_NO_SEED_SIDE=1 (the header walk of rounds 4-5)."""
+    from gramtools_amd.synth import chr20_recipe, realistic_reads, flat_offsets
+    prg, reads2d = chr20_recipe(150_000, 4_100, 2_500, 70 + k)
+    clean = (np.ascontiguousarray(reads2d).reshape(-1), flat_offsets(*reads2d.shape))
+    cases = [clean, realistic_reads(reads2d, 9, sub_rate=0.01, n_read_frac=0.02, len_lo=60)]
+    monkeypatch.setenv("GMX_SEED_SHIFT", shift)
+    monkeypatch.setenv("GMX_SEED_CURSOR", "1")
+    ix = Index(prg, k)
+    for flat, offs in cases:
+        seeds = master_seeds(42, [len(offs) - 1])
+        want = oracle_map(prg, k, (flat, offs), seeds, threads=8)
+        raws = []
+        for no_side in (False, True):
+            if no_side:
+                monkeypatch.setenv("GMX_NO_SEED_SIDE", "1")
+            else:
+                monkeypatch.delenv("GMX_NO_SEED_SIDE", raising=False)
+            qm = Quasimapper(ix)
+            qm.map_reads(flat, offs, seeds)
+            cov = qm.coverage()
+            assert qm.queue_counts()["seed_cursor"] == 1
+            assert canonical_cov(cov) == want, "header walk" if no_side else "side table"
+            raws.append((cov.raw_allele_sum.copy(), cov.raw_per_base.copy(), cov.raw_grouped.copy(), cov.stats.as_dict()))
+        assert all((a == b).all() for a, b in zip(raws[0][:3], raws[1][:3])) and raws[0][3] == raws[1][3]
