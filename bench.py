@@ -226,7 +226,7 @@ def bgzf_device_feed(ix, reads, seeds_np):
                 raise RuntimeError(f"gmx_ingest status {res.status} at member {res.bad_member}")
             if mapped:
                 qm.map_ingested(res, seeds, first=at)
-                ing.release_after(ci % 3)
+                ing.release_after(ci % 3, engine=qm)
             at += int(res.n_reads)
             total += int(res.n_reads)
         if mapped:

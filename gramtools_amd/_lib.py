@@ -141,6 +141,7 @@ SYMBOLS = {
     "gmx_stock_write_int_vector": (C.c_int, [C.c_char_p, _u64p, _u64, _u32, C.c_int]),
     "gmx_index_write_stock_files": (C.c_int, [_vp, C.c_char_p]),
     "gmx_index_check_stock_files": (C.c_int, [_vp, C.c_char_p, C.POINTER(StockReport)]),
+    "gmx_engine_second_stream": (_vp, [_vp]),
     "gmx_engine_debug_keep_states": (C.c_int, [_vp, C.c_int]),
     "gmx_debug_fail_alloc": (C.c_uint64, [C.c_int64]),
     "gmx_debug_final_states": (C.c_int, [_vp, _u64, _u32p, _u64, _u64p, C.POINTER(C.c_int)]),

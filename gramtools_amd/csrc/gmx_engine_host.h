@@ -104,6 +104,21 @@ struct gmx_engine {
   uint32_t extend_cap = 0;      // iterations of the LAST pass after which a task goes to the large-capacity route (0: runs to the end)
   uint32_t extend_budget = 8;   // wave-loop iterations of the extend kernel before a lane with work left is parked for the second pass
   bool seeds_in_place = false;  // gmx_engine_seeds_in_place
+  // A second batch in flight (round 6). Every batch ends with a tail of few-lane kernels — on a nested PRG ~2 ms of a few straggler
+  // tasks on a handful of CUs — during which the GPU is all but idle. The TWIN is a second workspace with streams of its own that
+  // shares this engine's index and ACCUMULATORS (coverage is atomic adds: two batches may record side by side): the host feeds hand
+  // consecutive launches to engine and twin in turn, so launch i + 1's full-GPU kernels run beside launch i's tail. Measured with
+  // two engines per device in round 5 (tools/exp/engines_in_flight.py): configs[2] 388 -> 499 M reads/s at 1 M reads per launch,
+  // configs[3] + 11 %, configs[1] +- 0 — so the twin exists for nested PRGs and indexes of 2 GB and more (GMX_TWIN=0 / 1 forces),
+  // never for an index whose sites use the grouped log (its replay is per batch).
+  gmx_engine *twin = nullptr;
+  bool is_twin = false, twin_off = false;
+  hipStream_t main_stream = nullptr;  // the twin's main chain (the engine's own: the NULL stream, or the caller's)
+  uint32_t twin_toggle = 0;
+  hipEvent_t ev_zeroed = nullptr, ev_twin_done = nullptr;  // a queued reset has executed | the twin's last batch has ended
+  uint64_t zero_epoch = 0, seen_zero_epoch = 0;
+  bool twin_in_flight = false;   // the twin has launched since the last join
+  bool last_on_twin = false;     // the last launch went to the twin (gmx_engine_queue_counts reads that workspace's counters)
   uint32_t extend_passes = 1;   // launches over the stragglers (<= GMX_EXTRA_PASSES); all but the last with a budget of their own
   uint32_t extend_budget2[GMX_EXTRA_PASSES] = {24, 96, 0};
                                 // (GMX_EXTEND_BUDGET in the environment; 0 = one pass)
@@ -241,11 +256,28 @@ static int gmx_quiesce(gmx_engine *e) {
   return GMX_OK;
 }
 
+// the accumulators have been zeroed by work on `stream` (a queued reset): the twin's next batch must come behind it
+static int note_zeroed(gmx_engine *e, hipStream_t stream) {
+  if (!e->twin) return GMX_OK;
+  if (!e->ev_zeroed) HIP_TRY(hipEventCreateWithFlags(&e->ev_zeroed, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->ev_zeroed, stream));
+  ++e->zero_epoch;
+  return GMX_OK;
+}
+// `stream` waits for the twin's last batch (its main stream joins its side streams at the end of every batch)
+static int twin_join(gmx_engine *e, hipStream_t stream) {
+  gmx_engine *tw = e->twin;
+  if (!tw || !e->twin_in_flight) return GMX_OK;
+  if (!e->ev_twin_done) HIP_TRY(hipEventCreateWithFlags(&e->ev_twin_done, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->ev_twin_done, tw->main_stream));
+  HIP_TRY(hipStreamWaitEvent(stream, e->ev_twin_done, 0));
+  return GMX_OK;
+}
 static int flush_reset(gmx_engine *e) {
   if (!e->reset_pending) return GMX_OK;
   e->reset_pending = false;
   HIP_TRY(hipMemsetAsync(e->d_fused, 0, (e->n_fused + 32) * 4, e->reset_stream));
-  return GMX_OK;
+  return note_zeroed(e, e->reset_stream);
 }
 
 // Grouped log -> host. Waits for the device, adds the log's records to e->log_counts when more than `keep_below` words are in
@@ -403,7 +435,27 @@ static void gmx_dev_index_release(GmxDeviceIndex *d) {
   delete d;
 }
 
+static int engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine *primary, gmx_engine **out);
 int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine **out) try {
+  int rc = engine_create(ixh, opts_in, nullptr, out);
+  if (rc) return rc;
+  gmx_engine *e = *out;
+  // the twin (a second batch in flight; gmx_engine::twin): nested PRGs and indexes of 2 GB and more
+  const gmx::HostIndex &h = gmx_index_host(ixh);
+  bool want = !e->log_sites && e->shared_index && (h.is_nested || e->index_bytes >= (2ull << 30));
+  if (const char *tw = getenv("GMX_TWIN")) want = atoi(tw) != 0 && !e->log_sites && e->shared_index;
+  if (want) {
+    gmx_engine *t = nullptr;
+    if (engine_create(ixh, &e->opts, e, &t) == GMX_OK) {
+      e->twin = t;
+    } else {
+      (void)hipGetLastError();  // (no room for a second workspace: one batch at a time, as before)
+    }
+  }
+  return GMX_OK;
+} GMX_GUARD_INT("gmx_engine_create")
+
+static int engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_engine *primary, gmx_engine **out) {
   if (!ixh || !out) {
     gmx_set_error("gmx_engine_create: null argument");
     return GMX_EINVAL;
@@ -500,7 +552,10 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   {  // one contiguous block: a single all-reduce covers the whole coverage (gmx_coverage_device)
     e->n_acc = ((size_t)h.n_acc_slots + 63) / 64 * 64;
     e->n_fused = e->n_acc + 32;
-    rc |= e->alloc(&e->d_fused, e->n_fused + 32, true);  // + 16 words of read counters + log cursor
+    if (primary)
+      e->d_fused = primary->d_fused;  // (the twin records into the engine's accumulators)
+    else
+      rc |= e->alloc(&e->d_fused, e->n_fused + 32, true);  // + 16 words of read counters + log cursor
     e->d_limbs = e->d_fused ? e->d_fused + e->n_acc : nullptr;
     e->d_stats = e->d_fused ? reinterpret_cast<unsigned long long *>(e->d_fused + e->n_fused) : nullptr;
     e->d_log_cursor = e->d_fused ? e->d_fused + e->n_fused + 16 : nullptr;
@@ -527,7 +582,10 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
                                       : 64;
     e->log_cap = (uint32_t)std::min<uint64_t>(cap, 0xFFFFFF00ull);
   }
-  rc |= e->alloc(&e->d_log, e->log_cap, false);
+  if (primary)
+    e->d_log = primary->d_log;  // (never written: an index with log sites has no twin)
+  else
+    rc |= e->alloc(&e->d_log, e->log_cap, false);
   e->heap_words = opts.huge_heap_bytes / 4 / 64 * 64;
   rc |= e->alloc(&e->d_heap, e->heap_words, false);
   rc |= e->alloc(&e->d_counters, GMX_N_COUNTERS * GMX_CNT_STRIDE, true);
@@ -545,7 +603,13 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
                             (int)(words * 4)) == hipSuccess)
       e->filter_lds_words = (uint32_t)words;
     (void)hipGetLastError();
-    if (e->filter_lds_words) {  // re-index the presence bitmap: table index (base j from the left in bit pair j) -> planar
+    if (primary) {  // (the k-mer filter's tables: the engine's)
+      e->filter_lds_words = primary->filter_lds_words;
+      e->d_kmer_planar = primary->d_kmer_planar;
+      e->d_absent = primary->d_absent;
+      e->n_absent = primary->n_absent;
+      e->use_absent = primary->use_absent;
+    } else if (e->filter_lds_words) {  // re-index the presence bitmap: table index (base j from the left in bit pair j) -> planar
       const uint32_t k = h.kmer_size;
       std::vector<uint32_t> planar(words, 0);
       for (uint64_t code = 0; code < (1ull << (2 * k)); ++code) {
@@ -609,7 +673,12 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   // the rare large entry goes to the large-capacity pass
   e->seed_cursor = h.n_seed_states_large * 10 > h.n_seed_states;
   if (const char *sc = getenv("GMX_SEED_CURSOR")) e->seed_cursor = atoi(sc) != 0;
-  if (e->seed_cursor && !rc && !getenv("GMX_NO_SA_CTX")) {  // left-context word per suffix-array position (GmxIndexView::sa_ctx): + 4 B per symbol
+  if (primary) {  // (the twin reads the engine's own copies)
+    e->seed_cursor = primary->seed_cursor;
+    e->dview.sa_ctx = primary->dview.sa_ctx;
+    e->dview.seed_side = primary->dview.seed_side;
+  }
+  if (!primary && e->seed_cursor && !rc && !getenv("GMX_NO_SA_CTX")) {  // left-context word per suffix-array position (GmxIndexView::sa_ctx): + 4 B per symbol
     uint32_t *sc = nullptr;
     if (e->alloc(&sc, h.sa.size(), false) == GMX_OK) {
       hipLaunchKernelGGL(gmx_sa_ctx_kernel, dim3(8192), dim3(256), 0, nullptr, e->dview.sa, e->dview.text, (uint64_t)h.sa.size(), sc);
@@ -623,7 +692,7 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   }
   // ... and the screening side table of the multi-state entries (GmxIndexView::seed_side; gmx_seed_side_kernel): + a word per
   // four seed words (20 GB at configs[4]). GMX_NO_SEED_SIDE=1: entries are walked header by header as until round 5 (A/B runs).
-  if (e->seed_cursor && !rc && !getenv("GMX_NO_SEED_SIDE") && h.seed_words.size() > 1) {
+  if (!primary && e->seed_cursor && !rc && !getenv("GMX_NO_SEED_SIDE") && h.seed_words.size() > 1) {
     uint32_t *side = nullptr;
     const size_t n_side = h.seed_words.size() / 4 + 2;
     if (e->alloc(&side, n_side, false) == GMX_OK) {
@@ -642,8 +711,19 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   }
   // (stream priorities for the side streams — the few-task kernels first — were measured in round 4: no difference, the
   //  chains there wait for memory, not for wave slots)
-  rc |= hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking) != hipSuccess;
-  rc |= hipStreamCreateWithFlags(&e->side2_stream, hipStreamNonBlocking) != hipSuccess;
+  // The twin's streams are created at the HIGHEST stream priority: the runtime keeps a pool of hardware queues per priority (4 each
+  // by default), so they get queues of their own. At one priority the engine's and the twin's seven streams shared four queues, a
+  // twin's main chain sat in a queue behind the engine's straggler kernels, and two launches in flight gained 17 % at configs[2]
+  // where two engines of round 5 had gained 29 % (profiles/round6/twin_ab.txt). GMX_TWIN_PRIORITY=0: one priority.
+  auto make_stream = [&](hipStream_t *st) -> bool {
+    int least = 0, greatest = 0;
+    const bool prio = primary && !(getenv("GMX_TWIN_PRIORITY") && atoi(getenv("GMX_TWIN_PRIORITY")) == 0) &&
+                      hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    (void)hipGetLastError();
+    return (prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+  };
+  rc |= !make_stream(&e->side_stream);
+  rc |= !make_stream(&e->side2_stream);
   rc |= hipEventCreateWithFlags(&e->ev_fork2, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_side1, hipEventDisableTiming) != hipSuccess;
   rc |= hipEventCreateWithFlags(&e->ev_filter, hipEventDisableTiming) != hipSuccess;
@@ -651,18 +731,28 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   rc |= hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess;
   e->cover_big_lanes = 64 * 32;
   rc |= e->alloc(&e->d_scratch_big, (size_t)GmxScratchFixed<CoverEnvBig>::total * e->cover_big_lanes, false);
+  if (primary) {
+    e->is_twin = true;
+    rc |= !make_stream(&e->main_stream);
+    e->last_stream = e->main_stream;
+  }
   if (rc) {
     gmx_engine_destroy(e);
     return GMX_EHIP;
   }
   *out = e;
   return GMX_OK;
-} GMX_GUARD_INT("gmx_engine_create")
+}
 
 void gmx_engine_destroy(gmx_engine *e) try {
   if (!e) return;
   (void)hipSetDevice(e->opts.device);
   (void)hipDeviceSynchronize();
+  if (e->twin) gmx_engine_destroy(e->twin);
+  e->twin = nullptr;
+  if (e->main_stream) (void)hipStreamDestroy(e->main_stream);
+  if (e->ev_zeroed) (void)hipEventDestroy(e->ev_zeroed);
+  if (e->ev_twin_done) (void)hipEventDestroy(e->ev_twin_done);
   if (e->side_stream) (void)hipStreamDestroy(e->side_stream);
   if (e->side2_stream) (void)hipStreamDestroy(e->side2_stream);
   if (e->ev_fork2) (void)hipEventDestroy(e->ev_fork2);
@@ -697,6 +787,11 @@ int gmx_engine_reset(gmx_engine *e) try {
   HIP_TRY(hipMemset(e->d_fused, 0, (e->n_fused + 32) * 4));
   HIP_TRY(hipMemset(e->d_error, 0, 8));
   HIP_TRY(hipMemset(e->d_counters, 0, GMX_N_COUNTERS * GMX_CNT_STRIDE * 4));
+  if (e->twin) {
+    HIP_TRY(hipMemset(e->twin->d_error, 0, 8));
+    HIP_TRY(hipMemset(e->twin->d_counters, 0, GMX_N_COUNTERS * GMX_CNT_STRIDE * 4));
+    e->twin_in_flight = false;
+  }
   e->log_counts.clear();
   e->log_known = e->log_reads_since = 0;
   e->log_state_pending = false;
@@ -708,6 +803,8 @@ int gmx_engine_reset_async(gmx_engine *e, void *hip_stream) try {
   hipStream_t st = (hipStream_t)hip_stream;
   int frc = flush_reset(e);  // (an earlier one still pending, on whatever stream it named)
   if (frc) return frc;
+  if ((frc = twin_join(e, st))) return frc;  // (the zeroing comes behind whatever the twin still records)
+  e->twin_in_flight = false;
   e->reset_pending = true;
   e->reset_stream = st;
   e->log_counts.clear();  // what earlier batches left in the device log goes with the cursor
@@ -983,6 +1080,7 @@ static int launch_batch(gmx_engine *e, const BatchInput &in, hipStream_t stream)
   } else
     hipLaunchKernelGGL(gmx_pack_kernel, dim3((unsigned)((n_reads + GMX_PACK_READS - 1) / GMX_PACK_READS)), dim3(GMX_PACK_THREADS), 0, stream, b,
                        e->d_skip, e->d_packed, e->d_counters, fold_reset ? e->d_fused : nullptr, fold_reset ? (uint32_t)(e->n_fused + 32) : 0u);
+  if (fold_reset && (rc = note_zeroed(e, stream))) return rc;  // (the batch's first kernel zeroed the accumulators: the twin's next batch waits for it)
   size_t lds = (size_t)GMX_STACK_DEPTH * GMX_STACK_WORDS * GMX_BLOCK * sizeof(uint32_t);
   const size_t big_lds = (size_t)GMX_BIG_LDS_DEPTH * GMX_STACK_WORDS * 64 * sizeof(uint32_t);
   dim3 task_grid((n_tasks + GMX_BLOCK - 1) / GMX_BLOCK);
@@ -1309,6 +1407,36 @@ int gmx_map_reads_host(gmx_engine *e, const uint8_t *reads, const uint64_t *offs
   return gmx_engine_sync(e);
 } GMX_GUARD_INT("gmx_map_reads_host")
 
+// Which workspace and main stream the next launch of a host feed takes: the engine's own (NULL stream) and its twin's in turn
+// (gmx_engine::twin). The launch that carries a queued reset goes to the engine itself (its first kernel zeroes the accumulators);
+// the twin's next launch waits for that kernel.
+struct BatchTarget {
+  gmx_engine *eng;
+  hipStream_t stream;
+};
+static int pick_target(gmx_engine *e, BatchTarget *out) {
+  out->eng = e;
+  out->stream = nullptr;
+  e->last_on_twin = false;
+  gmx_engine *tw = e->twin;
+  if (!tw || e->twin_off || e->keep_states) return GMX_OK;
+  if (e->reset_pending) {
+    e->twin_toggle = 1;
+    return GMX_OK;
+  }
+  if ((e->twin_toggle++ & 1u) == 0) return GMX_OK;
+  if (tw->seen_zero_epoch != e->zero_epoch) {
+    HIP_TRY(hipStreamWaitEvent(tw->main_stream, e->ev_zeroed, 0));
+    tw->seen_zero_epoch = e->zero_epoch;
+  }
+  tw->timing = e->timing;
+  out->eng = tw;
+  out->stream = tw->main_stream;
+  e->twin_in_flight = true;
+  e->last_on_twin = true;
+  return GMX_OK;
+}
+
 // planes: the bit planes (twobit = false) or the 2-bit stream as 32-bit words (twobit = true; gmx_map_reads_2bit_host)
 static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool twobit, const uint64_t *offsets, uint32_t uniform_len,
                                  const uint32_t *seeds, const uint8_t *skip, uint64_t n_reads) {
@@ -1411,8 +1539,10 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
         !hip_ok(hipMemcpyAsync(sl.d_seeds, seeds + done, n * 4, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(seeds)"))
       break;
     if (skip && !hip_ok(hipMemcpyAsync(sl.d_skip, skip + done, n, hipMemcpyHostToDevice, cs), "hipMemcpyAsync(skip)")) break;
+    BatchTarget tg;
+    if ((rc = pick_target(e, &tg))) break;
     if (!hip_ok(hipEventRecord(sl.copied, cs), "hipEventRecord") ||
-        !hip_ok(hipStreamWaitEvent(nullptr, sl.copied, 0), "hipStreamWaitEvent"))
+        !hip_ok(hipStreamWaitEvent(tg.stream, sl.copied, 0), "hipStreamWaitEvent"))
       break;
     BatchInput in;
     in.d_offsets = uniform_len ? nullptr : sl.d_offsets;
@@ -1424,8 +1554,8 @@ static int map_reads_packed_impl(gmx_engine *e, const uint64_t *planes, bool two
     in.uniform_len = uniform_len;
     in.n_reads = n;
     in.total_bases = uniform_len ? n * (uint64_t)uniform_len : offsets[done + n] - offsets[done];
-    if ((rc = launch_batch(e, in, nullptr))) break;
-    if (!hip_ok(hipEventRecord(sl.done, nullptr), "hipEventRecord")) break;
+    if ((rc = launch_batch(tg.eng, in, tg.stream))) break;
+    if (!hip_ok(hipEventRecord(sl.done, tg.stream), "hipEventRecord")) break;
     sl.busy = true;
     done += n;
   }
@@ -1499,8 +1629,12 @@ int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const u
     in.uniform_len = uniform_len;
     in.n_reads = n;
     in.total_bases = uniform_len ? n * (uint64_t)uniform_len : 0;  // (sizes the pack buffer of byte input only)
-    int rc = launch_batch(e, in, nullptr);
+    BatchTarget tg;
+    int rc = pick_target(e, &tg);
     if (rc) return rc;
+    // (the planes were written by work on the NULL stream or on streams the caller has ordered before it — gmx_ingest_wait has
+    //  returned —: the twin's stream needs no extra wait for them)
+    if ((rc = launch_batch(tg.eng, in, tg.stream))) return rc;
     done += n;
   }
   return GMX_OK;
@@ -1510,6 +1644,8 @@ int gmx_map_reads_2bit_host(gmx_engine *e, const uint64_t *stream, const uint64_
                             const uint8_t *skip, uint64_t n_reads) try {
   return map_reads_packed_impl(e, stream, true, offsets, uniform_len, seeds, skip, n_reads);
 } GMX_GUARD_INT("gmx_map_reads_2bit_host")
+
+void *gmx_engine_second_stream(gmx_engine *e) { return e && e->twin ? (void *)e->twin->main_stream : nullptr; }
 
 int gmx_engine_seeds_in_place(gmx_engine *e, int on) try {
   if (!e) {
@@ -1636,6 +1772,7 @@ int gmx_engine_reserve_packed(gmx_engine *e, uint64_t n_reads, uint64_t n_pairs)
   n_reads = std::min<uint64_t>(n_reads, gmx_feed_chunk(e));
   int rc = ensure_batch_capacity(e, n_reads);
   if (rc) return rc;
+  if (e->twin && (rc = ensure_batch_capacity(e->twin, n_reads))) return rc;
   if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
   for (auto &sl : e->pslot) {
     if (sl.busy) continue;
@@ -1677,11 +1814,17 @@ int gmx_engine_sync(gmx_engine *e) try {
   {
     int qrc = gmx_quiesce(e);
     if (qrc) return qrc;
+    if (e->twin && (qrc = gmx_quiesce(e->twin))) return qrc;
+    e->twin_in_flight = false;
   }
   HIP_TRY(hipStreamSynchronize(e->last_stream));
   HIP_TRY(hipDeviceSynchronize());
   uint32_t c[4] = {0, 0, 0, 0};
   HIP_TRY(hipMemcpy(c + 2, e->d_error, 8, hipMemcpyDeviceToHost));
+  if (c[2] == 0 && e->twin) {  // (the twin's batches report in its own words)
+    HIP_TRY(hipMemcpy(c + 2, e->twin->d_error, 8, hipMemcpyDeviceToHost));
+    if (c[2] != 0) HIP_TRY(hipMemset(e->twin->d_error, 0, 8));
+  }
   if (c[2] != 0) {
     HIP_TRY(hipMemset(e->d_error, 0, 8));
     char msg[256];
@@ -1714,11 +1857,16 @@ int gmx_engine_sync(gmx_engine *e) try {
 
 int gmx_engine_enable_timing(gmx_engine *e, int on) try {
   e->timing = on != 0;
+  if (e->twin) e->twin->timing = e->timing;
   return GMX_OK;
 } GMX_GUARD_INT("gmx_engine_enable_timing")
 
 int gmx_engine_timing(gmx_engine *e, gmx_timing *out) try {
   HIP_TRY(hipSetDevice(e->opts.device));
+  if (e->twin) {  // (the twin's batches: its events, added to this engine's sums)
+    e->pending.insert(e->pending.end(), e->twin->pending.begin(), e->twin->pending.end());
+    e->twin->pending.clear();
+  }
   for (auto &ev : e->pending) {
     HIP_TRY(hipEventSynchronize(ev.c));
     float ms0 = 0, ms1 = 0, ms2 = 0;
@@ -1767,7 +1915,7 @@ int gmx_engine_queue_counts(gmx_engine *e, gmx_queue_counts *out) try {
   HIP_TRY(hipSetDevice(e->opts.device));
   HIP_TRY(hipDeviceSynchronize());
   uint32_t raw[GMX_N_COUNTERS * GMX_CNT_STRIDE];
-  HIP_TRY(hipMemcpy(raw, e->d_counters, sizeof(raw), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(raw, (e->twin && e->last_on_twin ? e->twin : e)->d_counters, sizeof(raw), hipMemcpyDeviceToHost));  // (the workspace of the LAST launch)
   auto c = [&](int i) { return (uint64_t)raw[i * GMX_CNT_STRIDE]; };
   out->mapped = 0;
   for (int r = 0; r < GMX_REGIONS; ++r) out->mapped += c(16 + r);
@@ -1794,6 +1942,11 @@ int gmx_coverage_device(gmx_engine *e, gmx_device_coverage *out) try {
     int frc = flush_reset(e);
     if (frc) return frc;
   }
+  if (e->twin && e->twin_in_flight) {  // (the caller is about to read the block: the twin's batches first)
+    int qrc = gmx_quiesce(e->twin);
+    if (qrc) return qrc;
+    e->twin_in_flight = false;
+  }
   out->allele_sum = out->per_base = out->grouped = nullptr;  // interleaved in the block: use `fused`, or gmx_coverage_fetch
   out->n_allele_sum = e->n_allele;
   out->n_per_base = e->n_pb;
@@ -1816,6 +1969,10 @@ int gmx_coverage_reduce_begin(gmx_engine *e, void *hip_stream) try {
     if ((frc = log_settle(e))) return frc;
   }
   HIP_TRY(hipSetDevice(e->opts.device));
+  {
+    int trc = twin_join(e, (hipStream_t)hip_stream);  // (the exchange reads what the twin's batches record)
+    if (trc) return trc;
+  }
   hipLaunchKernelGGL(gmx_stats_limbs_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, e->d_stats, e->d_limbs, 0);
   HIP_TRY(hipGetLastError());
   return GMX_OK;

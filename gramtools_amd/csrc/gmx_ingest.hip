@@ -1103,8 +1103,8 @@ struct gmx_ingest {
     IngestMember *h_members = nullptr;  // page-locked staging of the member table
     IngestInflateStatus *d_inflate_status = nullptr;
     hipStream_t inflate_stream = nullptr;  // the slot's inflate kernel: beside the scan of the chunk before and the tail of its inflate kernel
-    hipEvent_t copied = nullptr, done = nullptr, released = nullptr, inflated = nullptr, carried = nullptr;
-    bool in_flight = false, has_release = false, has_carried = false;
+    hipEvent_t copied = nullptr, done = nullptr, released = nullptr, released2 = nullptr, inflated = nullptr, carried = nullptr;
+    bool in_flight = false, has_release = false, has_release2 = false, has_carried = false;
     hipEvent_t follower_carried = nullptr;  // `carried` of the chunk that continued this slot's: its carry kernel read the end of this slot's text
     bool has_follower = false;
     bool deferred = false;       // gmx_ingest_submit_bgzf_deferred / _text_deferred: uploaded (and inflating), scan still to come (gmx_ingest_scan)
@@ -1193,7 +1193,8 @@ int gmx_ingest_create(int device, uint64_t max_text_bytes, gmx_ingest **out) try
         hipHostMalloc(reinterpret_cast<void **>(&s.h_members), (size_t)g->cap_members * sizeof(IngestMember), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&s.copied, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
-        hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.inflated, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.released, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.released2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.inflated, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.carried, hipEventDisableTiming) != hipSuccess || ing_inflate_stream_create(&s.inflate_stream) != hipSuccess) {
       gmx_set_error("gmx_ingest_create: page-locked memory / events");
       return fail(GMX_EHIP);
@@ -1221,6 +1222,7 @@ void gmx_ingest_destroy(gmx_ingest *g) try {
     if (s.copied) (void)hipEventDestroy(s.copied);
     if (s.done) (void)hipEventDestroy(s.done);
     if (s.released) (void)hipEventDestroy(s.released);
+    if (s.released2) (void)hipEventDestroy(s.released2);
     if (s.inflated) (void)hipEventDestroy(s.inflated);
     if (s.carried) (void)hipEventDestroy(s.carried);
     if (s.inflate_stream) {
@@ -1330,6 +1332,12 @@ static int ing_begin(gmx_ingest *g, int si, const char *who) {
     ING_TRY(hipStreamWaitEvent(g->stream, s.released, 0));
     ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.released, 0));
     s.has_release = false;
+  }
+  if (s.has_release2) {  // (an engine with two workspaces: the launches on its second stream)
+    ING_TRY(hipStreamWaitEvent(g->copy_stream, s.released2, 0));
+    ING_TRY(hipStreamWaitEvent(g->stream, s.released2, 0));
+    ING_TRY(hipStreamWaitEvent(s.inflate_stream, s.released2, 0));
+    s.has_release2 = false;
   }
   // this slot's text is about to be overwritten (inflate kernel, or the upload of a text chunk): the carry kernel of the chunk that
   // continued this slot's old chunk reads the end of that text. (With two slots that is the chunk before the one being submitted;
@@ -1511,8 +1519,14 @@ int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream) try {
     return GMX_EINVAL;
   }
   ING_TRY(hipSetDevice(g->device));
-  ING_TRY(hipEventRecord(g->slot[slot].released, (hipStream_t)hip_stream));
-  g->slot[slot].has_release = true;
+  gmx_ingest::Slot &s = g->slot[slot];
+  if (s.has_release) {  // a second stream behind the same chunk
+    ING_TRY(hipEventRecord(s.released2, (hipStream_t)hip_stream));
+    s.has_release2 = true;
+  } else {
+    ING_TRY(hipEventRecord(s.released, (hipStream_t)hip_stream));
+    s.has_release = true;
+  }
   return GMX_OK;
 } GMX_GUARD_INT("gmx_ingest_release_after")
 

@@ -2013,7 +2013,9 @@ int run_genotype(const Args &a) {
           }
         }
         feed_trace("  chunk handed to the engine");
+        // (the slot's planes are read by the launch just enqueued: on the engine's NULL stream or on its second workspace's stream)
         GMX_CHECK(gmx_ingest_release_after(k == 0 ? g_device_feed.ing : g_more_feeds[k - 1]->ing, slot, nullptr));
+        if (void *second = gmx_engine_second_stream(ek)) GMX_CHECK(gmx_ingest_release_after(k == 0 ? g_device_feed.ing : g_more_feeds[k - 1]->ing, slot, second));
         in_file += n;
         total_reads += n;
       };

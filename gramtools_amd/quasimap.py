@@ -770,8 +770,14 @@ class Ingest:
         self._keep[slot] = None
         return res
 
-    def release_after(self, slot: int, stream=None):
+    def release_after(self, slot: int, stream=None, engine=None):
+        """The slot's next submit waits for the work enqueued on `stream` (default: the NULL stream); with `engine` (the Quasimapper
+        that just mapped the slot's reads) also for the launches on its second workspace's stream (gmx_engine_second_stream)."""
         check(self.lib.gmx_ingest_release_after(self.h, slot, C.c_void_p(stream) if stream else None))
+        if engine is not None:
+            second = self.lib.gmx_engine_second_stream(engine.h)
+            if second:
+                check(self.lib.gmx_ingest_release_after(self.h, slot, C.c_void_p(second)))
 
     def fetch_text(self, slot: int) -> bytes:
         n = self.lib.gmx_ingest_fetch_text(self.h, slot, None, 0)

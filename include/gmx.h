@@ -207,6 +207,12 @@ int gmx_pack_reads_2bit(const uint8_t *reads, const uint64_t *offsets, uint32_t 
  * until gmx_engine_sync (or an event recorded behind the call on the NULL stream). */
 int gmx_map_reads_packed_device(gmx_engine *e, const uint64_t *d_planes, const uint64_t *d_offsets, uint32_t uniform_len,
                                 const uint32_t *seeds, const uint8_t *d_skip, uint64_t n_reads);
+/* An engine of a nested PRG or of an index of 2 GB and more keeps TWO launches in flight: it hands consecutive launches of the
+ * host feeds and of gmx_map_reads_packed_device to its two workspaces in turn, the first on the NULL stream, the second on a
+ * stream of its own (a launch's tail of few-lane kernels beside the next launch's full-GPU kernels). This returns
+ * that second stream (NULL: the engine has one workspace). A caller that orders its own work behind launches it has enqueued —
+ * gmx_ingest_release_after — does so on both streams. gmx_engine_sync, gmx_coverage_fetch and the exchange wait for both. */
+void *gmx_engine_second_stream(gmx_engine *e);
 
 /* ---- reads files decoded on the device -----------------------------------------------------------
  * Replaces the reference's reads reader for gzipped FASTQ — SeqRead over zlib / htslib on one host thread
@@ -268,7 +274,8 @@ int gmx_ingest_submit_bgzf_deferred(gmx_ingest *g, int slot, const uint8_t *comp
 int gmx_ingest_submit_text_deferred(gmx_ingest *g, int slot, const uint8_t *text, uint64_t n_bytes); /* plain text dealt the same way */
 int gmx_ingest_scan(gmx_ingest *g, int slot, const uint8_t *carry, uint64_t n_carry, int final_chunk);
 int64_t gmx_ingest_fetch_tail(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap); /* NULL out: its length */
-/* The slot's planes are read by work enqueued on hip_stream (the mapping call): its next submit waits for that work. */
+/* The slot's planes are read by work enqueued on hip_stream (the mapping call): its next submit waits for that work. May be
+ * called twice per chunk, for two streams (gmx_engine_second_stream): the next submit waits for both. */
 int gmx_ingest_release_after(gmx_ingest *g, int slot, void *hip_stream);
 /* test hooks: the chunk's text (NULL out: its length), its reads in the host layout of gmx_map_reads_packed_host */
 int64_t gmx_ingest_fetch_text(gmx_ingest *g, int slot, uint8_t *out, uint64_t cap);

@@ -91,7 +91,7 @@ if __name__ == "__main__":
             assert res.status == 0, (res.status, res.bad_member)
             if mapper is not None:
                 mapper.map_ingested(res, seeds)
-                ing.release_after(ci % 3)
+                ing.release_after(ci % 3, engine=qm)
             total += int(res.n_reads)
         if mapper is not None:
             mapper.sync()
