@@ -711,14 +711,17 @@ static int engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, g
   }
   // (stream priorities for the side streams — the few-task kernels first — were measured in round 4: no difference, the
   //  chains there wait for memory, not for wave slots)
-  // The twin's streams are created at the HIGHEST stream priority: the runtime keeps a pool of hardware queues per priority (4 each
-  // by default), so they get queues of their own. At one priority the engine's and the twin's seven streams shared four queues, a
-  // twin's main chain sat in a queue behind the engine's straggler kernels, and two launches in flight gained 17 % at configs[2]
-  // where two engines of round 5 had gained 29 % (profiles/round6/twin_ab.txt). GMX_TWIN_PRIORITY=0: one priority.
+  // On a NESTED PRG the twin's streams are created at the HIGHEST stream priority: the runtime keeps a pool of hardware queues per
+  // priority (4 each by default), so they get queues of their own. At one priority the engine's and the twin's seven streams share
+  // four queues and a twin's main chain sits in a queue behind the engine's straggler kernels: configs[2]'s packed feed 372 M
+  // reads/s with one workspace, 436 M with two at one priority, 472 M with the twin's streams on queues of their own
+  // (profiles/round6/twin_ab.txt). On a flat PRG every kernel of a batch fills the GPU and precedence for one workspace only
+  // delays the other: configs[3] 856 M -> 892 M at one priority, 833 M with the pool. GMX_TWIN_PRIORITY=0 / 1 forces.
   auto make_stream = [&](hipStream_t *st) -> bool {
     int least = 0, greatest = 0;
-    const bool prio = primary && !(getenv("GMX_TWIN_PRIORITY") && atoi(getenv("GMX_TWIN_PRIORITY")) == 0) &&
-                      hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
+    bool want_prio = h.is_nested;
+    if (const char *tp = getenv("GMX_TWIN_PRIORITY")) want_prio = atoi(tp) != 0;
+    const bool prio = primary && want_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest;
     (void)hipGetLastError();
     return (prio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest) : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
   };
