@@ -1228,12 +1228,13 @@ int ingest_bgzf_file_dealt(const std::string &path, int threads, const std::vect
 // 28-33 ms = 120-140 M reads/s from 2 host threads on, 67 M with ONE (one core copies 21 GB/s out of the page cache) — while the
 // host parser sends 40 B per read and scales with the cores: 24 M reads/s on 1 thread, 35-45 M on 2-4, 52-82 M on 8, 75-102 M on 16,
 // 140-165 M on 32, 140-215 M on 64. So: the device route below 32 host threads (`--max_threads` defaults to 1 in the reference's
-// front-end: 2.8 x) and with several engines (their links add up; one host's parser does not), the host parser from 32 threads
-// on. GMX_DEVICE_FASTQ=1 / GMX_HOST_FASTQ=1 force either.
+// front-end: 2.8 x), the host parser from 32 threads on. GMX_DEVICE_FASTQ=1 / GMX_HOST_FASTQ=1 force either.
 static bool plain_fastq_on_device(int max_threads, size_t n_engines) {
   if (getenv("GMX_HOST_FASTQ")) return false;
   if (const char *e = getenv("GMX_DEVICE_FASTQ")) return atoi(e) != 0;
-  return max_threads < 32 || n_engines > 1;
+  (void)n_engines;  // (several engines: the same rule — the chunks are then dealt over the engines' ingests, ingest_text_file_dealt; measured
+                    //  only with several engines on ONE GPU, tools/feed_x8.py, where it has nothing to gain)
+  return max_threads < 32;
 }
 static uint64_t device_feed_text_chunk(size_t scale = 0) {
   uint64_t c = (128ull << 20) * (scale ? scale : std::min<size_t>(g_block_scale, 4));  // (nested PRGs: larger launches, see g_block_scale; 128 MB: 29-33 ms per 1.26 GB where 64 MB chunks take 34-40)
@@ -1408,7 +1409,10 @@ int ingest_text_file_dealt(const std::string &path, int threads, const std::vect
   if (!looks_like_plain_fastq(path, &size)) return 1;
   FdCloser f{open(path.c_str(), O_RDONLY)};
   if (f.fd < 0) return 1;
-  const uint64_t chunk = std::min<uint64_t>(device_feed_text_chunk(), size);
+  // (chunks of 32 MB here — scaled for nested PRGs —: every engine's ingest and its two page-locked buffers are made for the chunk size
+  //  the moment the first plain file arrives — N x (1.1 GB of device memory + 256 MB page-locked) at the single-engine size of 128 MB
+  //  cost a four-engine run 0.25 s before its first read was mapped, tools/cli_dealt_text.sh)
+  const uint64_t chunk = std::min<uint64_t>(getenv("GMX_TEXT_CHUNK") ? device_feed_text_chunk() : device_feed_text_chunk() / 4, size);
   while (g_more_feeds.size() + 1 < N) g_more_feeds.emplace_back(new DeviceFeed());
   auto feed = [&](size_t k) -> DeviceFeed & { return k == 0 ? g_device_feed : *g_more_feeds[k - 1]; };
   for (size_t k = 0; k < N; ++k) {
