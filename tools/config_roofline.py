@@ -71,7 +71,7 @@ if ext:
         "achieved": alg * n_reads / ns, "peak": 8000.0, "unit": "GB/s", "frac": alg * n_reads / ns / 8000.0, "traffic": tr(ext),
         "text_steps_per_read": round(text_steps, 2), "hit_steps_per_read": round(hit_steps, 2), "general_steps_per_read": round(slow_steps, 3),
         "alg_bytes_model": "queue entry 4 + seed entry 8 + read planes 48 + TEXT steps x 32 + HIT steps x (16 + 12) + general iterations x 64 + coverage record 32 + task id 4; steps from the stats build (loop_stats.txt)"})
-for prefix, per_task, model in (("gmx_probe_kernel", 460, "per (read, orientation): k-mer table entry 8 + read planes 48 + the entry's words, 16 states x ~24 B + queue / parked entries ~20"),
+for prefix, per_task, model in (("gmx_probe_kernel", 217, "per (read, orientation), with the screening side table (round 6): k-mer table entry 8 + read planes 48 + the entry's count word 4 + 16 side words 64 + 1.3 candidates x (header 24 + text record 32) + queue / parked entries ~20 (460 with the header walk of rounds 4-5: 16 states x ~24 B)"),
                                 ("gmx_seed_kernel", 24 + 6, "per task: the read's last plane pair 16 + seed directory entry 8; + 12 per alive task")):
     k = find(prefix)
     if k:
