@@ -40,21 +40,32 @@ except OSError:
     pass
 
 
+def short(name):  # "void gmx_extend_kernel<false, 1>(GmxIndexView, ...)" -> "gmx_extend_kernel<false, 1>" (the key tools/hbm_traffic.py uses)
+    n = name[5:] if name.startswith("void ") else name
+    depth = 0
+    for i, ch in enumerate(n):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return n[:i]
+    return n
+
+
 def find(prefix, exclude=None):
     for name in stats:
-        if name.startswith(prefix) and not (exclude and exclude in name):
+        if short(name).startswith(prefix) and not (exclude and exclude in name):
             return name
     return None
 
 
 def tr(name):
-    t = traffic.get(name) if name else None
+    t = traffic.get(short(name)) if name else None
     return int(t["fetch_bytes"] + t["write_bytes"]) if t else None
 
 
 out = {"config": WORKLOAD.get(which, which), "reads_per_launch": n_reads, "source": f"{d} (tools/profile_round6.sh)", "roofline": []}
 ext = find("gmx_extend_kernel", ", 2>")
-if ext:
+if ext and loop.get("extend"):  # (without the stats build's step counts there is no byte model for this configuration)
     both = {k: loop.get("extend", {}).get(k, 0) + loop.get("probe", {}).get(k, 0) for k in ("heavy TEXT", "heavy HIT", "lanes in heavy kinds", "lanes in slow iterations")}
     # lanes in heavy kinds = TEXT + HIT + WIDE lanes summed over iterations; split by the iterations' kinds
     e = loop.get("extend", {})
@@ -67,17 +78,17 @@ if ext:
     alg = 4 + 8 + 48 + 32 * text_steps + (16 + 12) * hit_steps + 32 + 4 + 64 * slow_steps
     ns = stats[ext][0]
     out["roofline"].append({
-        "bound": "hbm", "kernel": ext, "alg_bytes_per_read": round(alg, 1), "avg_launch_ms": ns / 1e6,
+        "bound": "hbm", "kernel": short(ext), "alg_bytes_per_read": round(alg, 1), "avg_launch_ms": ns / 1e6,
         "achieved": alg * n_reads / ns, "peak": 8000.0, "unit": "GB/s", "frac": alg * n_reads / ns / 8000.0, "traffic": tr(ext),
         "text_steps_per_read": round(text_steps, 2), "hit_steps_per_read": round(hit_steps, 2), "general_steps_per_read": round(slow_steps, 3),
-        "alg_bytes_model": "queue entry 4 + seed entry 8 + read planes 48 + TEXT steps x 32 + HIT steps x (16 + 12) + general iterations x 64 + coverage record 32 + task id 4; steps from the stats build (loop_stats.txt)"})
+        "alg_bytes_model": "queue entry 4 + seed entry 8 + read planes 48 + TEXT steps x 32 + HIT steps x (16 + 12) + general iterations x 64 + coverage record 32 + task id 4; steps from the stats build (loop_stats.txt: lanes served by heavy iterations, split over TEXT and HIT in proportion to the iterations that ran each kind — the build counts lanes per iteration, not per kind)"})
 for prefix, per_task, model in (("gmx_probe_kernel", 217, "per (read, orientation), with the screening side table (round 6): k-mer table entry 8 + read planes 48 + the entry's count word 4 + 16 side words 64 + 1.3 candidates x (header 24 + text record 32) + queue / parked entries ~20 (460 with the header walk of rounds 4-5: 16 states x ~24 B)"),
                                 ("gmx_seed_kernel", 24 + 6, "per task: the read's last plane pair 16 + seed directory entry 8; + 12 per alive task")):
     k = find(prefix)
     if k:
         ns = stats[k][0]
         b = per_task * 2 * n_reads
-        out["roofline"].append({"bound": "hbm", "kernel": k, "alg_bytes_per_task": per_task, "tasks_per_launch": 2 * n_reads, "avg_launch_ms": ns / 1e6,
+        out["roofline"].append({"bound": "hbm", "kernel": short(k), "alg_bytes_per_task": per_task, "tasks_per_launch": 2 * n_reads, "avg_launch_ms": ns / 1e6,
                                 "achieved": b / ns, "peak": 8000.0, "unit": "GB/s", "frac": b / ns / 8000.0, "traffic": tr(k), "alg_bytes_model": model})
 for prefix in ("gmx_cover_jump_kernel", "gmx_cover_single_kernel"):
     k = find(prefix)
@@ -85,8 +96,8 @@ for prefix in ("gmx_cover_jump_kernel", "gmx_cover_single_kernel"):
         ns = stats[k][0]
         sites = {"2": 1.0, "3": 4.0, "4": 4.0}.get(which, 2.0)
         alg = 32 + 4 + sites * (32 + 8)
-        out["roofline"].append({"bound": "hbm", "kernel": k, "alg_bytes_per_read": alg, "avg_launch_ms": ns / 1e6, "achieved": alg * n_reads / ns, "peak": 8000.0,
+        out["roofline"].append({"bound": "hbm", "kernel": short(k), "alg_bytes_per_read": alg, "avg_launch_ms": ns / 1e6, "achieved": alg * n_reads / ns, "peak": 8000.0,
                                 "unit": "GB/s", "frac": alg * n_reads / ns / 8000.0, "traffic": tr(k),
                                 "alg_bytes_model": f"compact record 32 + task id 4 + {sites:g} sites crossed x (a 32 B site record + one 8 B atomic) per mapped read"})
-out["kernel_time_shares"] = {n: {"avg_ms": round(v[0] / 1e6, 4), "calls": v[1], "percent": v[2]} for n, v in sorted(stats.items(), key=lambda kv: -kv[1][2])[:8]}
+out["kernel_time_shares"] = {short(n): {"avg_ms": round(v[0] / 1e6, 4), "calls": v[1], "percent": v[2]} for n, v in sorted(stats.items(), key=lambda kv: -kv[1][2])[:8]}
 print(json.dumps(out, indent=1))
