@@ -1341,6 +1341,11 @@ int gmx_infer_write_json(const gmx_infer *inf, const char *coords_path, const ch
   {  // the records formatted side by side (each range with a tracker of its own: positions ascend within a range), written in order
     const size_t n = g.recs.size();
     std::vector<std::string> part(par_parts(n, 2048));
+    {  // ONE tracker over all sites first, as the reference's single tracker sees them: a position queried backwards is an error
+       // wherever it stands — a range's own tracker below would not notice it at the range's first site
+      Tracker serial = tr;
+      for (size_t i = 0; i < n; ++i) (void)serial.id_of(g.recs[i]->pos);
+    }
     par_ranges(n, 2048, [&](size_t b, size_t e, size_t p) {
       Tracker t2 = tr;
       std::string &out = part[p];
@@ -1382,6 +1387,11 @@ int gmx_infer_write_vcf(const gmx_infer *inf, const char *coords_path, const cha
   z.write(hd.str());
   const size_t n_recs = g.recs.size();
   std::vector<std::string> part(par_parts(n_recs, 2048));
+  {  // (the serial check of the order of positions: as in the jVCF writer above)
+    Tracker serial = tr;
+    for (size_t i = 0; i < n_recs; ++i)
+      if (g.h.sites[i].parent_site == 0) (void)serial.id_of(g.recs[i]->pos);
+  }
   par_ranges(n_recs, 2048, [&](size_t rb, size_t re, size_t pp) {
   Tracker t2 = tr;  // (a tracker per range: positions ascend within it)
   std::string &acc = part[pp];

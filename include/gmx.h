@@ -225,9 +225,10 @@ void *gmx_engine_second_stream(gmx_engine *e);
  * leave most of the GPU idle — while the one before them is mapped:
  *     submit(0, chunk 0); submit(1, chunk 1); submit(2, chunk 2); wait(0) -> map -> release_after(0); submit(0, chunk 3); wait(1) ...
  * (a caller may also alternate between two of the slots, as until round 5: consecutive chunks must go to different slots).
- * There is no CPU fallback inside: a chunk the kernels cannot take (status != 0) is the caller's to handle — `gram` inflates
- * it with zlib and passes the text through gmx_ingest_submit_text (same kernels behind the inflate step), or reports the
- * file as damaged when zlib agrees. */
+ * There is no CPU fallback inside: a chunk the kernels cannot take (status != 0) is the caller's to handle — `gram` lets its
+ * host reader take the whole file from its start (dropping the reads already mapped), which reports the damage or, if the
+ * device decoder was at fault, delivers the rest; a caller may also inflate the chunk itself and pass the text through
+ * gmx_ingest_submit_text (same kernels behind the inflate step). */
 typedef struct gmx_ingest gmx_ingest;
 typedef struct {
   uint64_t offset;   /* of the member's deflate data within the chunk's bytes (behind the gzip header and its extra field) */
