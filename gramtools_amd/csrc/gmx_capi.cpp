@@ -62,15 +62,21 @@ int gmx_guard_catch(const char *fn) noexcept {
 // operator new made BY THIS LIBRARY from now on throws std::bad_alloc (n = 0: off; every later one succeeds again). The
 // replacement functions are LOCAL symbols of libgmx.so (version script libgmx.map): they serve the library's own translation units only — the HIP runtime, RCCL,
 // libstdc++'s own code and the host program keep theirs (an exception thrown into the runtime's frames would prove nothing) —
-// and both sides end in malloc / free, so memory may cross. Cost when off: one relaxed load per allocation.
+// and both sides end in malloc / free, so memory may cross. Cost when off: one relaxed load of a read-only flag per allocation.
 static std::atomic<int64_t> g_fail_alloc{[] {
   const char *e = getenv("GMX_TEST_FAIL_ALLOC");
   return e ? (int64_t)atoll(e) : (int64_t)0;
 }()};
 static std::atomic<uint64_t> g_alloc_calls{0};
+// Counting is ON only in a process that uses the hook (the environment variable, or a first gmx_debug_fail_alloc call): a counter
+// every thread increments on every allocation is one contended cache line — the index builder's 64 threads allocate per k-mer, and
+// with the count unconditional the whole-genome build took 471 s instead of 262 (round 6, found by the configs[4] test's time).
+static std::atomic<bool> g_alloc_counting{getenv("GMX_TEST_FAIL_ALLOC") != nullptr};
 static inline void *gmx_new_impl(size_t n, size_t align) {
-  g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
-  if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1, std::memory_order_relaxed) == 1) throw std::bad_alloc();
+  if (g_alloc_counting.load(std::memory_order_relaxed)) {
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    if (g_fail_alloc.load(std::memory_order_relaxed) > 0 && g_fail_alloc.fetch_sub(1, std::memory_order_relaxed) == 1) throw std::bad_alloc();
+  }
   void *p = align > alignof(max_align_t) ? aligned_alloc(align, (n + align - 1) / align * align) : malloc(n ? n : 1);
   if (!p) throw std::bad_alloc();
   return p;
@@ -88,6 +94,7 @@ void operator delete[](void *p, std::align_val_t) noexcept { free(p); }
 void operator delete(void *p, size_t, std::align_val_t) noexcept { free(p); }
 void operator delete[](void *p, size_t, std::align_val_t) noexcept { free(p); }
 extern "C" uint64_t gmx_debug_fail_alloc(int64_t nth) {  // returns the library's allocation count so far
+  g_alloc_counting.store(true, std::memory_order_relaxed);  // (from the first call on: a test process)
   g_fail_alloc.store(nth, std::memory_order_relaxed);
   return g_alloc_calls.load(std::memory_order_relaxed);
 }

@@ -372,7 +372,7 @@ int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_s
 int gmx_engine_debug_keep_states(gmx_engine *e, int on);
 /* Allocation-failure injection (tests/test_alloc_failure.py): the nth call of operator new made by libgmx.so's own code
  * from now on throws std::bad_alloc, once (0: off); also GMX_TEST_FAIL_ALLOC=n in the environment at load time. Returns the
- * number of allocations the library has made so far (so a test can count the allocations of a call and walk n over them).
+ * number of allocations the library has made since its first call (counting starts with the first call or the variable; so a test can count the allocations of a call and walk n over them).
  * The HIP runtime's, RCCL's and the host program's allocations are not touched. */
 uint64_t gmx_debug_fail_alloc(int64_t nth);
 int gmx_debug_final_states(gmx_engine *e, uint64_t task, uint32_t *out, uint64_t cap_words, uint64_t *n_words, int *tier);
