@@ -442,8 +442,9 @@ int gmx_engine_create(const gmx_index *ixh, const gmx_engine_opts *opts_in, gmx_
   gmx_engine *e = *out;
   // the twin (a second batch in flight; gmx_engine::twin): nested PRGs and indexes of 2 GB and more
   const gmx::HostIndex &h = gmx_index_host(ixh);
-  bool want = !e->log_sites && e->shared_index && (h.is_nested || e->index_bytes >= (2ull << 30));
-  if (const char *tw = getenv("GMX_TWIN")) want = atoi(tw) != 0 && !e->log_sites && e->shared_index;
+  const bool can = !e->log_sites && e->shared_index && !getenv("GMX_NO_INDEX_SHARE");  // (the twin reads the engine's copy of the index, never one of its own)
+  bool want = can && (h.is_nested || e->index_bytes >= (2ull << 30));
+  if (const char *tw = getenv("GMX_TWIN")) want = can && atoi(tw) != 0;
   if (want) {
     gmx_engine *t = nullptr;
     if (engine_create(ixh, &e->opts, e, &t) == GMX_OK) {
