@@ -334,6 +334,8 @@ class WorkerPool {
       fn(0u);
       return;
     }
+    // one caller at a time (round 6: the plain-text feed's reader thread uses the pool beside the main thread)
+    std::lock_guard<std::mutex> one_caller(callers_);
     std::unique_lock<std::mutex> lk(m_);
     while (threads_.size() < T - 1) {
       const unsigned id = (unsigned)threads_.size() + 1;
@@ -381,7 +383,7 @@ class WorkerPool {
       done_.notify_one();
     }
   }
-  std::mutex m_;
+  std::mutex m_, callers_;
   std::condition_variable cv_, done_;
   std::vector<std::thread> threads_;
   const std::function<void(unsigned)> *fn_ = nullptr;
