@@ -1,6 +1,9 @@
 """Parity fuzz on flat PRGs: random site densities, allele lengths (0..max_len bases), allele counts (2..9: dense counters and the
 append log), adjacent sites, ragged read lengths, both strands — the HIP path against the oracle, bit-exact, case after case
-until the time is up. Usage: python tools/fuzz_parity.py [SECONDS=120] [FIRST_SEED=0]"""
+until the time is up. Usage: python tools/fuzz_parity.py [SECONDS=120] [FIRST_SEED=0] [new]
+`new` (round 6): the reads go through the packed feed in launches of 600 reads with two launches in flight (GMX_TWIN=1), every
+second case with the seed cursor and its screening side table forced on (GMX_SEED_CURSOR=1), every fourth without the side table."""
+import os
 import sys
 import time
 
@@ -14,6 +17,9 @@ from gramtools_amd.synth import mixed_variant_prg, random_ref, simulate_haplotyp
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+new_paths = len(sys.argv) > 3 and sys.argv[3] == "new"
+if new_paths:
+    from gramtools_amd import pack_reads  # noqa: E402
 t0, cases, jump_sites, sites = time.time(), 0, 0, 0
 while time.time() - t0 < secs:
     rng = np.random.default_rng(1000 + seed)
@@ -30,13 +36,27 @@ while time.time() - t0 < secs:
     rng_mode = seed % 2
     want = oracle_map(prg, k, reads, seeds, rng_mode=rng_mode, threads=8)
     ix = Index(prg, k)
-    qm = Quasimapper(ix, rng_mode=rng_mode)
     flat, offs = flatten_reads(reads)
-    qm.map_reads(flat, offs, seeds)
+    if new_paths:
+        os.environ["GMX_TWIN"] = "1"
+        os.environ.pop("GMX_SEED_CURSOR", None)
+        os.environ.pop("GMX_NO_SEED_SIDE", None)
+        if seed % 2:
+            os.environ["GMX_SEED_CURSOR"] = "1"
+        if seed % 4 == 3:
+            os.environ["GMX_NO_SEED_SIDE"] = "1"
+        qm = Quasimapper(ix, rng_mode=rng_mode, max_batch_reads=600)
+        pk = pack_reads(flat, offs, pinned=True)
+        qm.map_reads_packed(pk, seeds)
+    else:
+        qm = Quasimapper(ix, rng_mode=rng_mode)
+        qm.map_reads(flat, offs, seeds)
     got = canonical_cov(qm.coverage())
     if got != want:
         print(f"MISMATCH at seed {seed}: G {G}, a site per {density} bases, max_len {max_len}, k {k}, reads from {lo} bases, stats {got['stats']} / {want['stats']}", flush=True)
         sys.exit(1)
+    if new_paths:
+        pk.close()
     jump_sites += ix.info.n_jump_sites
     sites += ix.info.n_sites
     cases += 1
