@@ -371,7 +371,9 @@ int gmx_index_check_stock_files(const gmx_index *ix, const char *gram_dir, gmx_s
  *   the SA indices of the path-less positions outside every site (the reference keeps them as path-less states). */
 int gmx_engine_debug_keep_states(gmx_engine *e, int on);
 /* Allocation-failure injection (tests/test_alloc_failure.py): the nth call of operator new made by libgmx.so's own code
- * from now on throws std::bad_alloc, once (0: off); also GMX_TEST_FAIL_ALLOC=n in the environment at load time. Returns the
+ * from now on throws std::bad_alloc, once; nth < 0: only count allocations; nth == 0: off, counting stops (the counter is one
+ * cache line every allocating thread hits: it is on only between such calls); also GMX_TEST_FAIL_ALLOC=n in the environment
+ * at load time. Returns the
  * number of allocations the library has made since its first call (counting starts with the first call or the variable; so a test can count the allocations of a call and walk n over them).
  * The HIP runtime's, RCCL's and the host program's allocations are not touched. */
 uint64_t gmx_debug_fail_alloc(int64_t nth);

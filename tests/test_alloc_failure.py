@@ -23,9 +23,9 @@ GMX_ENOMEM = -6
 
 def _count_allocs(lib, fn):
     """Allocations libgmx.so makes inside fn() (the hook's counter before and after, the hook off)."""
-    a = lib.gmx_debug_fail_alloc(0)
+    a = lib.gmx_debug_fail_alloc(-1)  # count only
     fn()
-    return lib.gmx_debug_fail_alloc(0) - a
+    return lib.gmx_debug_fail_alloc(0) - a  # (0: counting off again — the counter is a contended cache line)
 
 
 def _walk(lib, call, n_allocs, max_points=400):
