@@ -111,3 +111,18 @@ def test_two_bit_stream_packer_argument_checks():
     assert lib.gmx_ingest_wait(None, 0, C.byref(res)) == -1 and lib.gmx_ingest_submit_text(None, 0, None, 0, 1) == -1
     h = C.c_void_p()
     assert lib.gmx_ingest_create(0, 1000, C.byref(h)) == -1 and b"64 KB" in lib.gmx_last_error()   # GMX_EINVAL before the device is looked for
+
+
+def test_every_exported_function_is_guarded_against_exceptions():
+    """include/gmx.h: "no C++ exception leaves the library". Every function the header declares is either closed by a GMX_GUARD_*
+    macro (a function-try-block, gmx_internal.h) or is one of the one-line accessors that cannot throw."""
+    csrc = os.path.join(ROOT, "gramtools_amd", "csrc")
+    text = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip", ".cpp")))
+    guarded = set(re.findall(r'GMX_GUARD_(?:INT|VOID|PTR|ZERO)\("(gmx_[a-z0-9_]+)"\)', text))
+    trivial = {"gmx_last_error", "gmx_index_destroy", "gmx_infer_destroy", "gmx_group_size", "gmx_group_engine", "gmx_group_uses_rccl",
+               "gmx_ingest_max_text", "gmx_ingest_max_compressed", "gmx_ingest_max_members", "gmx_engine_second_stream", "gmx_debug_fail_alloc"}
+    missing = [n for n in declared_symbols() if n not in guarded and n not in trivial]
+    assert not missing, missing
+    for n in trivial & set(declared_symbols()):  # the accessors really are one-liners
+        m = re.search(r"\b" + n + r"\([^)]*\)\s*(?:try\s*)?\{([^\n]*)", text)
+        assert m, n
